@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (container-only; never runs on the GPU box).
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+Imports /root/reference/azulnet (with the two removed numpy aliases restored), plays seeded games
+through the reference's own GameRunner / Azul / RandomAgent code and stores inputs + expected
+outputs as arrays.  Only DATA is written: no reference source text leaves the container.
+"""
+import copy
+import os
+import random
+import shutil
+import sys
+
+import numpy as np
+
+np.int = int      # the reference uses aliases removed in numpy >= 1.24 (azul.py:19-26)
+np.bool = bool
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+
+import torch  # noqa: E402
+import azulnet  # noqa: E402
+from azulnet import Azul, GameRunner, RandomAgent, check_all_valid, nn_serialize  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+RES = "/root/reference/tests/resources"
+
+RULESETS = {
+    # name: (rules dict handed to the reference, first_player code, tile_pool code)
+    "lid_randomfirst": ({"first_player": "Random", "tile_pool": "Lid"}, 0, 1),   # GameRunner default
+    "random_first1": ({}, -1, 0),                                               # Azul default
+    "lid_first2": ({"first_player": 2, "tile_pool": "Lid"}, 2, 1),
+}
+
+
+def words_pos():
+    return random.getstate()[1][624]
+
+
+class Recorder:
+    """Wraps Azul.step at class level and records every env move of the reference."""
+
+    FIELDS = ["mask", "action", "phi", "eog", "displays", "center", "pattern_lines", "walls", "floors",
+              "score", "cur", "nfp", "eog_flag", "turn_counter", "box", "lid", "first_player_stats",
+              "floor_penalty", "max_combo", "completed_lines", "obs", "rng_words", "player_before"]
+
+    def __init__(self):
+        self.rows = {k: [] for k in self.FIELDS}
+        self.words = 0
+        self.last_pos = None
+
+    def sync_words(self):
+        pos = words_pos()
+        if self.last_pos is not None:
+            d = pos - self.last_pos
+            if d < 0 or (d == 0 and False):
+                d += 624
+            self.words += d
+        self.last_pos = pos
+
+    def install(self, runner_ref):
+        rec = self
+        orig = Azul.step
+
+        def step(game, display, color, pattern):
+            mask = check_all_valid(game)
+            player_before = game.current_player
+            orig(game, display, color, pattern)
+            g2 = copy.deepcopy(game)
+            g2.count_score()
+            rec.sync_words()
+            r = rec.rows
+            r["mask"].append(np.packbits(mask, bitorder="little"))
+            r["action"].append(nn_serialize(display, color, pattern))
+            r["phi"].append(int(g2.score[0] - g2.score[1]))
+            r["eog"].append(bool(game.is_end_of_game()))
+            r["displays"].append(np.array(game.game_board_displays, dtype=np.uint8))
+            r["center"].append(np.array(game.game_board_center, dtype=np.uint8))
+            r["pattern_lines"].append(np.array(game.pattern_lines, dtype=np.uint8))
+            r["walls"].append(np.array(game.walls, dtype=np.uint8))
+            r["floors"].append(np.array(game.floors, dtype=np.uint8))
+            r["score"].append(np.array(game.score, dtype=np.int16))
+            r["cur"].append(game.current_player)
+            r["nfp"].append(game.next_first_player)
+            r["eog_flag"].append(bool(game.end_of_game))
+            r["turn_counter"].append(game.turn_counter)
+            if game.tile_pool == "Lid":
+                r["box"].append(np.array(game.box_tiles, dtype=np.uint8))
+                r["lid"].append(np.array(game.lid_tiles, dtype=np.uint8))
+            else:
+                r["box"].append(np.zeros(5, np.uint8))
+                r["lid"].append(np.zeros(5, np.uint8))
+            r["first_player_stats"].append(np.array(game.first_player_stats, dtype=np.uint16))
+            r["floor_penalty"].append(np.array(game.floor_penalty, dtype=np.int16))
+            r["max_combo"].append(np.array(game.max_combo, dtype=np.uint8))
+            r["completed_lines"].append(np.array(game.completed_lines, dtype=np.uint8))
+            runner = runner_ref[0]
+            r["obs"].append(np.stack([runner.get_state(0), runner.get_state(1)]).astype(np.int16))
+            r["rng_words"].append(rec.words)
+            r["player_before"].append(player_before)
+
+        Azul.step = step
+        return orig
+
+
+def play_stream(seed, rules, episodes):
+    """random.seed(seed); GameRunner(rules); `episodes` x (reset(); RandomAgent vs RandomAgent)."""
+    rec = Recorder()
+    runner_ref = [None]
+    orig = rec.install(runner_ref)
+    agent_rows = {"env_index": [], "reward": [], "done": [], "obs_before": [], "mask_before": [],
+                  "action": [], "move_counter": [], "player_score": []}
+    episode_rows = {"first_env_index": [], "stats": [], "words_at_start": []}
+    try:
+        random.seed(seed)
+        rec.last_pos = words_pos()
+        runner = GameRunner(rules=dict(rules))
+        runner_ref[0] = runner
+        agent = RandomAgent()
+        for _ in range(episodes):
+            runner.reset()
+            rec.sync_words()
+            episode_rows["first_env_index"].append(len(rec.rows["action"]) - runner.move_counter)
+            episode_rows["words_at_start"].append(rec.words)
+            done = False
+            while not done:
+                mask = runner.get_valid_moves()
+                obs = runner.get_state()
+                a = agent.get_a_output(None, torch.from_numpy(mask.reshape(1, 180)))
+                reward, done = runner.step(a)
+                agent_rows["env_index"].append(len(rec.rows["action"]))
+                agent_rows["reward"].append(int(reward))
+                agent_rows["done"].append(bool(done))
+                agent_rows["obs_before"].append(obs.astype(np.int16))
+                agent_rows["mask_before"].append(np.packbits(mask, bitorder="little"))
+                agent_rows["action"].append(int(a))
+                agent_rows["move_counter"].append(runner.move_counter)
+                agent_rows["player_score"].append(int(runner.player_score))
+            st = runner.game.get_statistics()
+            episode_rows["stats"].append(np.array([float(st[k]) for k in
+                                                   ["player_score", "opponent_score", "rounds", "percent_first_player",
+                                                    "floor_penalty", "max_combo", "completed_rows", "completed_columns",
+                                                    "completed_colors", "win_percent"]]))
+    finally:
+        Azul.step = orig
+    out = {("env_" + k): np.array(v) for k, v in rec.rows.items()}
+    out.update({("agent_" + k): np.array(v) for k, v in agent_rows.items()})
+    out.update({("episode_" + k): np.array(v) for k, v in episode_rows.items()})
+    return out
+
+
+def gen_trajectories():
+    for name, (rules, _fp, _pool) in RULESETS.items():
+        seeds = list(range(32)) if name != "lid_first2" else list(range(8))
+        seeds += [2 ** 32 + 7, 2 ** 63 + 11] if name == "lid_randomfirst" else []
+        blob = {"seeds": np.array(seeds, dtype=np.uint64)}
+        for i, s in enumerate(seeds):
+            d = play_stream(s, rules, episodes=2)
+            for k, v in d.items():
+                blob["s%d_%s" % (i, k)] = v
+        np.savez_compressed(os.path.join(OUT, "traj_%s.npz" % name), **blob)
+        print("wrote traj_%s.npz (%d seeds)" % (name, len(seeds)))
+
+
+def gen_rng():
+    blob = {}
+    seeds = [0, 1, 12345, 2 ** 32 - 1, 2 ** 32, 2 ** 32 + 7, 2 ** 63 + 11]
+    blob["seeds"] = np.array(seeds, dtype=np.uint64)
+    for i, s in enumerate(seeds):
+        random.seed(s)
+        st = random.getstate()
+        blob["state_%d" % i] = np.array(st[1], dtype=np.uint64).astype(np.uint32)
+        blob["u32_%d" % i] = np.array([random.getrandbits(32) for _ in range(1400)], dtype=np.uint32)
+        random.seed(s)
+        blob["random_%d" % i] = np.array([random.random() for _ in range(700)], dtype=np.float64)
+        random.seed(s)
+        blob["randbelow5_%d" % i] = np.array([random.randrange(0, 5, 1) for _ in range(300)], dtype=np.uint8)
+        random.seed(s)
+        blob["choice12_%d" % i] = np.array([random.choice([1, 2]) for _ in range(300)], dtype=np.uint8)
+    # random.choices on tile-pool style weights and on RandomAgent style weights
+    random.seed(99)
+    rs = np.random.RandomState(7)
+    boxes, picks = [], []
+    for _ in range(400):
+        box = rs.randint(0, 21, size=5)
+        if box.sum() == 0:
+            box[2] = 3
+        total = np.sum(box)
+        picks.append(random.choices([0, 1, 2, 3, 4], weights=[b / total for b in box])[0])
+        boxes.append(box)
+    blob["choices_box"] = np.array(boxes, dtype=np.uint8)
+    blob["choices_box_pick"] = np.array(picks, dtype=np.uint8)
+    random.seed(2024)
+    agent = RandomAgent()
+    masks, picks = [], []
+    for i in range(600):
+        dens = [0.02, 0.1, 0.3, 0.7, 1.0][i % 5]
+        m = rs.rand(180) < dens
+        if i % 7 == 0:
+            m[:30] = False
+        if i % 11 == 0:
+            m[30:] = False
+        if not m.any():
+            m[rs.randint(0, 180)] = True
+        picks.append(agent.get_a_output(None, torch.from_numpy(m.reshape(1, 180))))
+        masks.append(np.packbits(m, bitorder="little"))
+    blob["choices_mask"] = np.array(masks)
+    blob["choices_mask_pick"] = np.array(picks, dtype=np.uint8)
+    blob["choices_mask_words_end"] = np.array(random.getstate()[1][624])
+    np.savez_compressed(os.path.join(OUT, "pyrandom.npz"), **blob)
+    print("wrote pyrandom.npz")
+
+
+def gen_boards():
+    """Copy the reference's JSON board fixtures (data files) and record derived known answers."""
+    dst = os.path.join(OUT, "resources")
+    os.makedirs(dst, exist_ok=True)
+    blob = {}
+    names = sorted(f for f in os.listdir(RES) if f.endswith(".json"))
+    for f in names:
+        shutil.copyfile(os.path.join(RES, f), os.path.join(dst, f))
+        g = Azul()
+        g.import_JSON(os.path.join(RES, f))
+        key = f[:-5]
+        blob[key + "_mask"] = np.packbits(check_all_valid(g), bitorder="little")
+        runner = GameRunner(rules={})
+        runner.game = g
+        blob[key + "_obs"] = np.stack([runner.get_state(0), runner.get_state(1)]).astype(np.int16)
+        g2 = copy.deepcopy(g)
+        g2.count_score()
+        blob[key + "_scored_score"] = np.array(g2.score, dtype=np.int16)
+        blob[key + "_scored_walls"] = np.array(g2.walls, dtype=np.uint8)
+        blob[key + "_scored_pattern_lines"] = np.array(g2.pattern_lines, dtype=np.uint8)
+        blob[key + "_scored_stats"] = np.concatenate([g2.floor_penalty, g2.max_combo, g2.completed_lines.flatten()])
+        blob[key + "_eor"] = np.array(g.is_end_of_round())
+        blob[key + "_eog"] = np.array(g.is_end_of_game())
+    np.savez_compressed(os.path.join(OUT, "boards.npz"), **blob)
+    print("wrote boards.npz + %d resource json files" % len(names))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    print("reference:", os.path.dirname(azulnet.__file__))
+    gen_rng()
+    gen_boards()
+    gen_trajectories()
+
+
+if __name__ == "__main__":
+    main()

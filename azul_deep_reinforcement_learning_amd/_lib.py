@@ -1,0 +1,83 @@
+"""ctypes binding of libazulhip.so (C ABI: include/azul_hip.h).
+
+The library is the product: there is NO fallback.  If it is missing or fails to load, importing this
+module raises -- build it with ``python -c "import __graft_entry__ as g; g.build()"`` (hipcc, gfx950).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libazulhip.so")
+
+RECORD_BYTES, NUM_ACTIONS, OBS_SIZE, MT_WORDS, NUM_STATS = 128, 180, 136, 624, 10
+SUCCESS, ERR_INVALID, ERR_HIP, ERR_RANGE, ERR_RULE = 0, -1, -2, -3, -4
+OK, ILLEGAL_MOVE, GAME_ENDED, STUCK, BAD_ACTION, BOX_EMPTY = 0, 1, 2, 3, 4, 5
+POOL_RANDOM, POOL_LID = 0, 1
+FIRST_RANDOM = 0
+PERSP_PLAYER0, PERSP_PLAYER1, PERSP_CURRENT = 0, 1, 2
+FLAG_END_OF_ROUND, FLAG_END_OF_GAME, FLAG_ENDED_FLAG = 1, 2, 4
+
+_vp, _i, _u64, _u32 = C.c_void_p, C.c_int, C.c_uint64, C.c_uint32
+
+# name -> (restype, argtypes); every symbol declared in include/azul_hip.h
+SIGNATURES = {
+    "azul_last_error_string": (C.c_char_p, []),
+    "azul_version": (C.c_char_p, []),
+    "azul_batch_create": (_i, [C.POINTER(_vp), _i, _i, _i]),
+    "azul_batch_destroy": (_i, [_vp]),
+    "azul_batch_size": (_i, [_vp]),
+    "azul_batch_state_dev": (_vp, [_vp]),
+    "azul_batch_mt_dev": (_vp, [_vp]),
+    "azul_batch_mtpos_dev": (_vp, [_vp]),
+    "azul_batch_get_state": (_i, [_vp, _i, _i, _vp, _vp]),
+    "azul_batch_set_state": (_i, [_vp, _i, _i, _vp, _vp]),
+    "azul_batch_get_rng": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "azul_batch_set_rng": (_i, [_vp, _i, _vp, _u32, _vp]),
+    "azul_batch_seed": (_i, [_vp, _u64, _vp, _vp]),
+    "azul_batch_init": (_i, [_vp, _vp, _vp]),
+    "azul_batch_new_round": (_i, [_vp, _vp, _vp, _vp]),
+    "azul_batch_move": (_i, [_vp, _vp, _vp, _vp]),
+    "azul_batch_legal_mask": (_i, [_vp, _vp, _vp]),
+    "azul_batch_next_player": (_i, [_vp, _vp, _vp]),
+    "azul_batch_flags": (_i, [_vp, _vp, _vp]),
+    "azul_batch_count_score": (_i, [_vp, _vp, _vp]),
+    "azul_batch_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "azul_batch_statistics": (_i, [_vp, _vp, _vp]),
+    "azul_batch_runner_init": (_i, [_vp, _vp, _vp, _vp]),
+    "azul_batch_runner_reset": (_i, [_vp, _vp, _vp, _vp]),
+    "azul_batch_runner_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "azul_batch_observe": (_i, [_vp, _i, _vp, _vp]),
+    "azul_batch_random_action": (_i, [_vp, _vp, _vp, _vp]),
+    "azul_batch_score_preview": (_i, [_vp, _vp, _vp]),
+    "azul_batch_selfplay": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "azul_batch_counters": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "azul_batch_reset_counters": (_i, [_vp, _vp]),
+    "azul_timing_begin": (_i, [_vp, _vp]),
+    "azul_timing_end": (_i, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(_i)]),
+}
+
+
+class AzulHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libazulhip.so not found at %s: the HIP extension is the product and has no fallback. "
+            "Build it with __graft_entry__.build() (hipcc --offload-arch=gfx950)." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != SUCCESS:
+        raise AzulHipError("libazulhip error %d: %s" % (rc, lib.azul_last_error_string().decode()))
+    return rc

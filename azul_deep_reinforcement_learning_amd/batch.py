@@ -1,0 +1,221 @@
+"""BatchedAzul: N concurrent two-player Azul games resident on one MI355X.
+
+Host-side mirror of the reference's env wrapper for the batched case: the method names follow
+``azulnet.GameRunner`` (``reset`` / ``step`` / ``get_state`` / ``get_valid_moves``; reference
+azulnet/game_runner.py:43-85) and ``azulnet.Azul`` (``new_round`` / ``move`` / ``count_score`` / ...;
+azulnet/azul.py), every call is one kernel launch over all games through the C ABI of libazulhip.so.
+PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .records import RECORD_DTYPE, STAT_KEYS
+
+_RULE_POOL = {"Random": L.POOL_RANDOM, "Lid": L.POOL_LID}
+
+
+class IllegalRule(Exception):
+    pass
+
+
+def parse_rules(rules, players=2):
+    """rules dict of the reference (azul.py:35-56) -> (first_player code, tile_pool code)."""
+    first = 1
+    if "first_player" in rules:
+        fp = rules["first_player"]
+        if fp == "Random":
+            first = L.FIRST_RANDOM
+        elif type(fp) == int and 1 <= fp <= players:
+            first = fp
+        else:
+            raise IllegalRule
+    pool = L.POOL_RANDOM
+    if "tile_pool" in rules:
+        if rules["tile_pool"] not in _RULE_POOL:
+            raise IllegalRule
+        pool = _RULE_POOL[rules["tile_pool"]]
+    return first, pool
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchedAzul:
+    def __init__(self, n_games, rules={"first_player": "Random", "tile_pool": "Lid"}, device=None, seed=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedAzul needs an MI355X: there is no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.n = int(n_games)
+        self.rules = dict(rules)
+        first, pool = parse_rules(rules)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(L.lib.azul_batch_create(C.byref(self._h), self.n, first, pool))
+        if seed is not None:
+            self.seed(seed)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and L is not None and getattr(L, "lib", None) is not None:   # module globals may be gone at interpreter exit
+            L.lib.azul_batch_destroy(h)
+            self._h = None
+
+    # -- plumbing --------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _new(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _dev(self, x, dtype):
+        if x is None:
+            return None
+        t = torch.as_tensor(x)
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    # -- RNG / state I/O -------------------------------------------------------------------------
+    def seed(self, seed_base=0, seeds=None):
+        """random.seed(seeds[g]) (or seed_base + g) for every game's private CPython-exact stream."""
+        arr = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint64)
+        if arr is not None and arr.shape != (self.n,):
+            raise ValueError("seeds must have shape (n_games,)")
+        L.check(L.lib.azul_batch_seed(self._h, int(seed_base), None if arr is None else arr.ctypes.data_as(C.c_void_p), self._stream()))
+
+    def get_records(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        out = np.zeros(count, dtype=RECORD_DTYPE)
+        L.check(L.lib.azul_batch_get_state(self._h, first, count, out.ctypes.data_as(C.c_void_p), self._stream()))
+        return out
+
+    def set_records(self, records, first=0):
+        rec = np.ascontiguousarray(records, dtype=RECORD_DTYPE).reshape(-1)
+        L.check(L.lib.azul_batch_set_state(self._h, first, len(rec), rec.ctypes.data_as(C.c_void_p), self._stream()))
+
+    def get_rng(self, game):
+        mt = np.zeros(624, dtype=np.uint32)
+        pos = np.zeros(1, dtype=np.uint32)
+        L.check(L.lib.azul_batch_get_rng(self._h, game, mt.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p), self._stream()))
+        return mt, int(pos[0])
+
+    def set_rng(self, game, mt, pos):
+        mt = np.ascontiguousarray(mt, dtype=np.uint32)
+        L.check(L.lib.azul_batch_set_rng(self._h, game, mt.ctypes.data_as(C.c_void_p), int(pos), self._stream()))
+
+    # -- Azul methods, batched --------------------------------------------------------------------
+    def init(self, active=None):
+        L.check(L.lib.azul_batch_init(self._h, _ptr(self._dev(active, torch.uint8)), self._stream()))
+
+    def new_round(self, active=None):
+        st = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+        L.check(L.lib.azul_batch_new_round(self._h, _ptr(self._dev(active, torch.uint8)), _ptr(st), self._stream()))
+        return st
+
+    def move(self, actions, active=None):
+        a = self._dev(actions, torch.int32)
+        L.check(L.lib.azul_batch_move(self._h, _ptr(a), _ptr(self._dev(active, torch.uint8)), self._stream()))
+
+    def next_player(self, active=None):
+        L.check(L.lib.azul_batch_next_player(self._h, _ptr(self._dev(active, torch.uint8)), self._stream()))
+
+    def count_score(self, active=None):
+        L.check(L.lib.azul_batch_count_score(self._h, _ptr(self._dev(active, torch.uint8)), self._stream()))
+
+    def flags(self):
+        f = self._new((self.n,), torch.uint8)
+        L.check(L.lib.azul_batch_flags(self._h, _ptr(f), self._stream()))
+        return f
+
+    def is_end_of_round(self):
+        return (self.flags() & L.FLAG_END_OF_ROUND) != 0
+
+    def is_end_of_game(self):
+        return (self.flags() & L.FLAG_END_OF_GAME) != 0
+
+    def azul_step(self, actions, active=None):
+        """Azul.step for every game; returns the uint8 status vector (OK / ILLEGAL_MOVE / GAME_ENDED / ...)."""
+        a = self._dev(actions, torch.int32)
+        st = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+        L.check(L.lib.azul_batch_step(self._h, _ptr(a), _ptr(self._dev(active, torch.uint8)), _ptr(st), self._stream()))
+        return st
+
+    def statistics(self):
+        s = self._new((self.n, L.NUM_STATS), torch.float64)
+        L.check(L.lib.azul_batch_statistics(self._h, _ptr(s), self._stream()))
+        return s
+
+    # -- GameRunner methods, batched --------------------------------------------------------------
+    def runner_init(self, active=None):
+        st = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+        L.check(L.lib.azul_batch_runner_init(self._h, _ptr(self._dev(active, torch.uint8)), _ptr(st), self._stream()))
+        return st
+
+    def reset(self, active=None):
+        st = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+        L.check(L.lib.azul_batch_runner_reset(self._h, _ptr(self._dev(active, torch.uint8)), _ptr(st), self._stream()))
+        return st
+
+    def step(self, actions, active=None):
+        """GameRunner.step for every game -> (reward int32[N], done bool[N], status uint8[N])."""
+        a = self._dev(actions, torch.int32)
+        reward = torch.zeros(self.n, dtype=torch.int32, device=self.device)
+        done = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+        st = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+        L.check(L.lib.azul_batch_runner_step(self._h, _ptr(a), _ptr(self._dev(active, torch.uint8)), _ptr(reward), _ptr(done), _ptr(st), self._stream()))
+        return reward, done.bool(), st
+
+    def get_state(self, perspective=0, out=None):
+        obs = self._new((self.n, L.OBS_SIZE), torch.float32) if out is None else out
+        L.check(L.lib.azul_batch_observe(self._h, int(perspective), _ptr(obs), self._stream()))
+        return obs
+
+    def get_valid_moves(self, out=None):
+        m = self._new((self.n, L.NUM_ACTIONS), torch.uint8) if out is None else out
+        L.check(L.lib.azul_batch_legal_mask(self._h, _ptr(m), self._stream()))
+        return m if out is not None else m.bool()
+
+    def random_action(self, active=None):
+        a = torch.full((self.n,), -1, dtype=torch.int32, device=self.device)
+        L.check(L.lib.azul_batch_random_action(self._h, _ptr(self._dev(active, torch.uint8)), _ptr(a), self._stream()))
+        return a
+
+    def score_preview(self):
+        p = self._new((self.n,), torch.int32)
+        L.check(L.lib.azul_batch_score_preview(self._h, _ptr(p), self._stream()))
+        return p
+
+    # -- flat self-play rollout -------------------------------------------------------------------
+    def selfplay(self, n_steps, mask=None, action=None, reward=None, done=None, records=None):
+        """`n_steps` env moves for every game in one launch; outputs are preallocated tensors or None."""
+        L.check(L.lib.azul_batch_selfplay(self._h, int(n_steps), _ptr(mask), _ptr(action), _ptr(reward), _ptr(done), _ptr(records), self._stream()))
+
+    def alloc_trajectory(self, n_steps, with_records=False):
+        t = {"mask": self._new((n_steps, self.n, L.NUM_ACTIONS), torch.uint8),
+             "action": self._new((n_steps, self.n), torch.int32),
+             "reward": self._new((n_steps, self.n), torch.int32),
+             "done": self._new((n_steps, self.n), torch.uint8)}
+        if with_records:
+            t["records"] = self._new((n_steps, self.n, L.RECORD_BYTES), torch.uint8)
+        return t
+
+    def counters(self):
+        ep = np.zeros(self.n, dtype=np.uint64)
+        stuck = np.zeros(self.n, dtype=np.uint32)
+        ss = np.zeros((self.n, L.NUM_STATS), dtype=np.float64)
+        L.check(L.lib.azul_batch_counters(self._h, ep.ctypes.data_as(C.c_void_p), stuck.ctypes.data_as(C.c_void_p),
+                                          ss.ctypes.data_as(C.c_void_p), self._stream()))
+        return {"episodes": ep, "stuck": stuck, "stat_sums": ss, "keys": list(STAT_KEYS)}
+
+    def reset_counters(self):
+        L.check(L.lib.azul_batch_reset_counters(self._h, self._stream()))
+
+    def timing_begin(self):
+        L.check(L.lib.azul_timing_begin(self._h, self._stream()))
+
+    def timing_end(self):
+        ms, n = C.c_float(0), C.c_int(0)
+        L.check(L.lib.azul_timing_end(self._h, self._stream(), C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)

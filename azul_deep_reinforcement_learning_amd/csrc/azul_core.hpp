@@ -1,0 +1,676 @@
+// azul_core.hpp -- Azul rules, legal-move mask, scoring, RandomAgent and the CPython-exact random
+// stream, written for ONE GAME PER 64-LANE WAVEFRONT (see azul_wave.hpp for the model).
+//
+// Data layout inside a wave (P = 2 players):
+//   cs  (VGPR, "source cells")  lane 5d+c = displays[d][c] (0..24), lane 25+c = center[c], lane 30 = token
+//   cp  (VGPR, "pattern cells") lane 25p+5r+c = pattern_lines[p][r][c] (0..49)
+//   walls[p]                    uniform 25-bit bitboards, bit 5r+c  (colour-indexed like the reference)
+//   everything else             uniform scalars
+// so that  ballot(cs != 0)  IS the "which sources hold tiles" bitboard (end-of-round test and the
+// legal-move mask both fall out of it) and  ballot(cp == row+1)  IS the set of full pattern lines.
+//
+// Behaviour restated from the reference (paths relative to /root/reference):
+//   new_round        azulnet/azul.py:64-89        move            azulnet/azul.py:118-161
+//   is_legal_move    azulnet/azul.py:162-176      next_player     azulnet/azul.py:177-181
+//   is_end_of_round  azulnet/azul.py:182-183      is_end_of_game  azulnet/azul.py:184-191
+//   count_score      azulnet/azul.py:192-295      step            azulnet/azul.py:296-313
+//   GameRunner.step / reset / get_state           azulnet/game_runner.py:43-55, 76-85, 56-72
+//   RandomAgent      azulnet/game_runner.py:87-97 check_all_valid azulnet/game_runner.py:113-117
+//   random.seed / random() / getrandbits / _randbelow / choices   CPython 3.10 (_randommodule.c, random.py)
+#pragma once
+#include "azul_wave.hpp"
+
+namespace az {
+using namespace wv;
+
+enum { ST_OK = 0, ST_ILLEGAL_MOVE = 1, ST_GAME_ENDED = 2, ST_STUCK = 3, ST_BAD_ACTION = 4, ST_BOX_EMPTY = 5 };
+enum { POOL_RANDOM = 0, POOL_LID = 1 };
+enum { T_COLS = 151, T_ROWS = 31 };   // RandomAgent cumulative-weight table, see build_weight_table()
+
+struct Rules {
+    u32 first_player;   // 0 = "Random", 1..2 = fixed
+    u32 tile_pool;      // POOL_RANDOM / POOL_LID
+};
+
+// ------------------------------------------------------------------------------------------------
+// CPython MT19937 stream of one game.  The 624-word state lives in global memory (mt[624], row of
+// a [N][624] array, so a wave's accesses are contiguous); 64-word chunks are staged into a
+// per-wave LDS window on first use and the regeneration ("twist") runs in LDS across all 64 lanes.
+// ------------------------------------------------------------------------------------------------
+struct Rng {
+    u32 *gmt;       // this game's 624 words in global memory
+    u32 *lds;       // this wave's 624-word LDS window
+    u32 pos;        // CPython's `index` (0..624)
+    u32 loaded;     // bit k: chunk k (words 64k..64k+63) is staged in LDS
+    u32 dirty;      // window differs from global memory (a twist happened)
+};
+
+AZ_FN void rng_open(Rng &r, u32 *gmt, u32 *lds, u32 pos)
+{
+    r.gmt = gmt; r.lds = lds; r.pos = pos; r.loaded = 0; r.dirty = 0;
+}
+
+AZ_FN void rng_stage(Rng &r, u32 chunk)
+{
+    vu32 i = lane() + chunk * 64u;
+    vu32 w = ld_u32(r.gmt, i, i < 624u);
+    lds_st(r.lds, i, w, i < 624u);
+    lds_fence();
+    r.loaded |= 1u << chunk;
+}
+
+AZ_FN void rng_twist(Rng &r)
+{
+    // genrand_uint32's regeneration loop; ascending 64-wide chunks are legal because element i needs
+    // OLD mt[i], mt[i+1] and (i<227: OLD mt[i+397] | i>=227: NEW mt[i-227]); see DESIGN.md.
+    for (u32 k = 0; k < 10; k++)
+        if (!((r.loaded >> k) & 1u)) rng_stage(r, k);
+    for (u32 k = 0; k < 10; k++) {
+        vu32 i = lane() + k * 64u;
+        vbool act = i < 624u;
+        vu32 i1 = sel(i == 623u, splat(0u), i + 1u);
+        vu32 i2 = sel(i < 227u, i + 397u, i - 227u);
+        vu32 a = lds_ld(r.lds, i, act), b = lds_ld(r.lds, i1, act), c = lds_ld(r.lds, i2, act);
+        vu32 y = (a & 0x80000000u) | (b & 0x7fffffffu);
+        vu32 v = c ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+        lds_fence();
+        lds_st(r.lds, i, v, act);
+        lds_fence();
+    }
+    r.dirty = 1;
+    r.pos = 0;
+}
+
+AZ_FN u32 rng_u32(Rng &r)
+{
+    if (r.pos >= 624u) rng_twist(r);
+    u32 chunk = r.pos >> 6;
+    if (!((r.loaded >> chunk) & 1u)) rng_stage(r, chunk);
+    u32 y = lds_ldu(r.lds, r.pos);
+    r.pos += 1;
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+AZ_FN double rng_random(Rng &r)
+{
+    u32 a = rng_u32(r) >> 5, b = rng_u32(r) >> 6;
+    return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+}
+
+AZ_FN u32 rng_below(Rng &r, u32 n, u32 bits)
+{
+    // _randbelow_with_getrandbits: k = n.bit_length(); rejection on getrandbits(k)
+    u32 v = rng_u32(r) >> (32u - bits);
+    while (v >= n) v = rng_u32(r) >> (32u - bits);
+    return v;
+}
+
+AZ_FN void rng_close(Rng &r, u32 *pos_out)
+{
+    if (r.dirty) {
+        for (u32 k = 0; k < 10; k++) {
+            vu32 i = lane() + k * 64u;
+            vu32 w = lds_ld(r.lds, i, i < 624u);
+            st_u32(r.gmt, i, w, i < 624u);
+        }
+    }
+    AZ_LANE0(*pos_out = r.pos);
+}
+
+// ------------------------------------------------------------------------------------------------
+// game state
+// ------------------------------------------------------------------------------------------------
+struct Game {
+    vu32 cs, cp;
+    u32 wall[2];
+    i32 score[2];
+    u32 floor_[2];
+    u32 cur, nfp, eog;
+    u64 box, lid;           // byte c = tiles of colour c
+    u32 turn;
+    u32 fps[2];
+    i32 fpen[2];
+    u32 maxc[2];
+    u64 compl_;             // byte 3p+k = completed_lines[p][k]
+    i32 pscore;             // GameRunner.player_score
+    u32 moves;              // GameRunner.move_counter
+};
+
+struct LaneConst {
+    vu32 spos[3];    // action a=64w+lane: cs lane of its source cell (31 = none)
+    vu32 okpos[3];   // action a: bit of the "row accepts colour" board (31 = floor move, always ok)
+    vu32 rowp1;      // cp lane l<50: row+1, else 0xff
+};
+
+AZ_FN void lane_consts(LaneConst &k)
+{
+    for (u32 w = 0; w < 3; w++) {
+        vu32 a = lane() + w * 64u;
+        vu32 d = a % 6u, c = (a / 6u) % 5u, r = a / 30u;
+        vu32 sp = sel(d == 0u, c + 25u, (d - 1u) * 5u + c);
+        k.spos[w] = sel(a < 180u, sp, splat(31u));
+        k.okpos[w] = sel(r == 0u, splat(31u), (r - 1u) * 5u + c);
+    }
+    vu32 l = lane();
+    k.rowp1 = sel(l < 50u, ((l % 25u) / 5u) + 1u, splat(0xffu));
+}
+
+AZ_FN u32 me_index(const Game &g) { return g.cur == 0u ? 1u : g.cur - 1u; }   // numpy [-1] before the first round
+
+// ---- 128-byte record <-> registers (layout: include/azul_hip.h) ----
+AZ_FN void game_load(Game &g, const uint8_t *rec)
+{
+    vu32 l = lane();
+    vu32 a = ld_u8(rec, l, l < 32u);
+    vu32 b = ld_u8(rec + 32, l, l < 52u);
+    vu32 t = ld_u32((const u32 *)(rec + 84), l, l < 11u);
+    u32 flags = readlane(a, 31);
+    g.cur = flags & 7u; g.nfp = (flags >> 3) & 7u; g.eog = (flags >> 6) & 1u;
+    g.cs = sel(l < 31u, a, splat(0u));
+    g.cp = sel(l < 50u, b, splat(0u));
+    g.floor_[0] = readlane(b, 50); g.floor_[1] = readlane(b, 51);
+    g.wall[0] = readlane(t, 0); g.wall[1] = readlane(t, 1);
+    u32 sc = readlane(t, 2);
+    g.score[0] = (i32)(int16_t)(sc & 0xffffu); g.score[1] = (i32)(int16_t)(sc >> 16);
+    u32 w3 = readlane(t, 3), w4 = readlane(t, 4), w5 = readlane(t, 5);
+    g.box = (u64)w3 | ((u64)(w4 & 0xffu) << 32);
+    g.lid = (u64)(w4 >> 8) | ((u64)(w5 & 0xffffu) << 24);
+    g.turn = w5 >> 16;
+    u32 w6 = readlane(t, 6), w7 = readlane(t, 7), w8 = readlane(t, 8), w9 = readlane(t, 9), w10 = readlane(t, 10);
+    g.fps[0] = w6 & 0xffffu; g.fps[1] = w6 >> 16;
+    g.fpen[0] = (i32)(int16_t)(w7 & 0xffffu); g.fpen[1] = (i32)(int16_t)(w7 >> 16);
+    g.maxc[0] = w8 & 0xffu; g.maxc[1] = (w8 >> 8) & 0xffu;
+    g.compl_ = (u64)(w8 >> 16) | ((u64)w9 << 16);
+    g.pscore = (i32)(int16_t)(w10 & 0xffffu);
+    g.moves = w10 >> 16;
+}
+
+AZ_FN void game_store(const Game &g, uint8_t *rec)
+{
+    vu32 l = lane();
+    u32 flags = (g.cur & 7u) | ((g.nfp & 7u) << 3) | ((g.eog & 1u) << 6);
+    vu32 a = writelane(g.cs, flags, 31);
+    st_u8(rec, l, a, l < 32u);
+    vu32 b = writelane(writelane(g.cp, g.floor_[0], 50), g.floor_[1], 51);
+    st_u8(rec + 32, l, b, l < 52u);
+    vu32 t = splat(0u);
+    t = writelane(t, g.wall[0], 0);
+    t = writelane(t, g.wall[1], 1);
+    t = writelane(t, ((u32)g.score[0] & 0xffffu) | ((u32)g.score[1] << 16), 2);
+    t = writelane(t, (u32)g.box, 3);
+    t = writelane(t, (u32)((g.box >> 32) & 0xffu) | ((u32)g.lid << 8), 4);
+    t = writelane(t, (u32)((g.lid >> 24) & 0xffffu) | (g.turn << 16), 5);
+    t = writelane(t, (g.fps[0] & 0xffffu) | (g.fps[1] << 16), 6);
+    t = writelane(t, ((u32)g.fpen[0] & 0xffffu) | ((u32)g.fpen[1] << 16), 7);
+    t = writelane(t, (g.maxc[0] & 0xffu) | ((g.maxc[1] & 0xffu) << 8) | ((u32)(g.compl_ & 0xffffu) << 16), 8);
+    t = writelane(t, (u32)(g.compl_ >> 16), 9);
+    t = writelane(t, ((u32)g.pscore & 0xffffu) | (g.moves << 16), 10);
+    st_u32((u32 *)(rec + 84), l, t, l < 11u);
+}
+
+// ---- legal-move mask: azul.py:162-176 over all 180 actions (game_runner.py:113-117) ----
+struct Mask { u64 m[3]; };   // bit (a & 63) of m[a >> 6]
+
+AZ_FN u32 sources_board(const Game &g) { return (u32)ballot(g.cs != 0u) & 0x7fffffffu; }
+
+AZ_FN void legal_mask(const Game &g, const LaneConst &k, Mask &out)
+{
+    u32 B = sources_board(g);
+    u64 PL = ballot(g.cp != 0u);
+    u32 me = me_index(g);
+    u32 pme = (u32)(PL >> (25u * me)) & 0x1ffffffu;
+    u32 wl = g.wall[me];
+    u32 ok = 0x80000000u;                            // bit 31: "floor row" accepts everything
+    for (u32 r = 0; r < 5; r++) {
+        u32 rb = (pme >> (5u * r)) & 31u;              // colours already lying on row r
+        u32 okr = (rb == 0u) ? 31u : (((rb & (rb - 1u)) == 0u) ? rb : 0u);   // azul.py:172
+        okr &= ~(wl >> (5u * r)) & 31u;                // azul.py:174
+        ok |= okr << (5u * r);
+    }
+    for (u32 w = 0; w < 3; w++)
+        out.m[w] = ballot((((B >> (k.spos[w] & 31u)) & (ok >> (k.okpos[w] & 31u))) & 1u) != 0u);
+}
+
+AZ_FN u32 mask_test(const Mask &m, u32 a) { return (u32)(m.m[a >> 6] >> (a & 63u)) & 1u; }
+AZ_FN u32 mask_count(const Mask &m) { return popc64(m.m[0]) + popc64(m.m[1]) + popc64(m.m[2]); }
+
+AZ_FN void mask_write(const Mask &m, uint8_t *out)
+{
+    vu32 l = lane();
+    for (u32 w = 0; w < 3; w++) {
+        vu32 a = l + w * 64u;
+        u32 lo = (u32)m.m[w], hi = (u32)(m.m[w] >> 32);
+        vu32 v = sel(l < 32u, (lo >> (l & 31u)) & 1u, (hi >> (l & 31u)) & 1u);
+        st_u8(out, a, v, a < 180u);
+    }
+}
+
+// ---- RandomAgent: game_runner.py:87-97 + random.choices (random.py:506-541) ----
+// T[J][m] = the fp64 value CPython's accumulate() reaches after J weights of 0.01 followed by m weights
+// of 1.0 (zeros in between add exactly nothing).  Strictly increasing in the number of legal actions.
+AZ_FN double tseq(const double *T, u32 J, u32 k) { return (k <= J) ? T[k * T_COLS] : T[J * T_COLS + (k - J)]; }
+
+AZ_FN i32 random_agent(const Mask &m, Rng &r, const double *T)
+{
+    u32 c0 = popc64(m.m[0]), c1 = popc64(m.m[1]), c2 = popc64(m.m[2]);
+    u32 J = popc64(m.m[0] & 0x3fffffffull);           // legal floor moves (a < 30, weight 0.01)
+    u32 L = c0 + c1 + c2;
+    if (L == 0u) return -1;                            // ValueError in the reference, raised before random()
+    double total = tseq(T, J, L) + 0.0;
+    double x = rng_random(r) * total;
+    // bisect_right over the cumulative weights == smallest ordinal k with cum(k) > x
+    double sJ = T[J * T_COLS];
+    u32 kg = (x < sJ) ? ((u32)(x * 100.0) + 1u) : (J + (u32)(x - sJ) + 1u);
+    if (kg < 1u) kg = 1u;
+    if (kg > L) kg = L;
+    for (u32 it = 0; it < 400u; it++) {
+        if (x < tseq(T, J, kg - 1u) && kg > 1u) kg -= 1u;
+        else if (!(x < tseq(T, J, kg)) && kg < L) kg += 1u;
+        else break;
+    }
+    // kg-th legal action
+    u32 w, rank;
+    if (kg <= c0) { w = 0; rank = kg - 1u; }
+    else if (kg <= c0 + c1) { w = 1; rank = kg - 1u - c0; }
+    else { w = 2; rank = kg - 1u - c0 - c1; }
+    u64 mw = m.m[w];
+    vu32 l = lane();
+    u32 lo = (u32)mw, hi = (u32)(mw >> 32);
+    vu32 bit = sel(l < 32u, (lo >> (l & 31u)) & 1u, (hi >> (l & 31u)) & 1u);
+    u64 hit = ballot((bit != 0u) & (mbcnt(mw) == rank));
+    return (i32)(w * 64u + ctz64(hit));
+}
+
+// ---- move: azul.py:118-161 ----
+AZ_FN void add_to_floor(Game &g, u32 p, u32 n)
+{
+    u32 f = g.floor_[p] + n;                           // azul.py:119-123
+    g.floor_[p] = (f < 7u) ? f : 7u;
+}
+
+AZ_FN void byte_add(u64 &v, u32 idx, u32 n) { v += (u64)n << (8u * idx); }
+
+AZ_FN void do_move(Game &g, const Rules &rules, u32 d, u32 c, u32 row)
+{
+    u32 me = me_index(g);
+    vu32 l = lane();
+    u32 n;
+    if (d != 0u) {
+        u32 db = 5u * (d - 1u);
+        n = readlane(g.cs, db + c);                                    // :127
+        vu32 moved = bperm(g.cs, l - 25u + db);                         // display cell of my colour, for centre lanes
+        vbool centre = (l >= 25u) & (l < 30u) & (l != 25u + c);
+        g.cs = sel(centre, g.cs + moved, g.cs);                        // :131
+        g.cs = sel((l >= db) & (l < db + 5u), splat(0u), g.cs);        // :129,:133
+    } else {
+        n = readlane(g.cs, 25u + c);                                   // :136
+        g.cs = writelane(g.cs, 0u, 25u + c);                           // :138
+        if (readlane(g.cs, 30) == 1u) {                                // :140-143
+            g.cs = writelane(g.cs, 0u, 30);
+            g.nfp = g.cur;
+            add_to_floor(g, me, 1u);
+        }
+    }
+    if (row != 0u) {
+        u32 cell = 25u * me + 5u * (row - 1u) + c;
+        u32 old = readlane(g.cp, cell);
+        i32 overflow = (i32)row - (i32)old - (i32)n;                   // :147
+        if (overflow >= 0) {
+            g.cp = writelane(g.cp, old + n, cell);                     // :150
+        } else {
+            g.cp = writelane(g.cp, row, cell);                         // :152
+            add_to_floor(g, me, (u32)(-overflow));                     // :154
+            if (rules.tile_pool == POOL_LID) byte_add(g.lid, c, (u32)(-overflow));   // :156-157
+        }
+    } else {
+        add_to_floor(g, me, n);                                        // :159
+        if (rules.tile_pool == POOL_LID) byte_add(g.lid, c, n);        // :160-161
+    }
+}
+
+// ---- scoring: azul.py:192-295 on 25-bit wall bitboards ----
+AZ_FN u32 run_length(u32 bits, u32 pos)
+{
+    // length of the run of ones in `bits` (5 bits) that contains bit `pos`
+    u32 up = ctz32(~(bits >> pos));                       // counts `pos` itself
+    u32 below = ~bits & ((1u << pos) - 1u);
+    u32 down = below ? (pos - (32u - clz32(below))) : pos;
+    return up + down;
+}
+
+constexpr u32 column_board_c(int col)
+{
+    u32 m = 0;
+    for (int j = 0; j < 5; j++) m |= 1u << (5 * j + ((col - j + 5) % 5));
+    return m;
+}
+static_assert(column_board_c(0) == 0x222201u && column_board_c(4) == 0x111110u, "column boards");
+
+AZ_FN u32 column_board(u32 col)
+{
+    // wall cells (bit 5j + colour) that sit in board column `col`: colour = (col - j) mod 5  (azul.py:194-199)
+    return col == 0u ? column_board_c(0) : col == 1u ? column_board_c(1) : col == 2u ? column_board_c(2)
+         : col == 3u ? column_board_c(3) : column_board_c(4);
+}
+
+AZ_FN bool any_row_full(u32 w) { return ((w & (w >> 1) & (w >> 2) & (w >> 3) & (w >> 4)) & 0x108421u) != 0u; }
+
+AZ_FN bool is_end_of_game(const Game &g) { return any_row_full(g.wall[0]) || any_row_full(g.wall[1]); }   // azul.py:184-191
+
+AZ_FN u64 full_lines(const Game &g, const LaneConst &k) { return ballot(g.cp == k.rowp1); }              // azul.py:216
+
+template <bool REAL>
+AZ_FN i32 score_player(Game &g, const Rules &rules, u32 p, u64 F)
+{
+    // count_floor (azul.py:200-210): 0,-1,-2,-4,-6,-8,-11,-14
+    u32 f = g.floor_[p] > 7u ? 7u : g.floor_[p];
+    i32 pen = -(i32)((0x0e0b080604020100ull >> (8u * f)) & 0xffu);
+    u32 fp = (u32)(F >> (25u * p)) & 0x1ffffffu;
+    u32 w = g.wall[p];
+    i32 cnt = 0;
+    u32 mc = g.maxc[p];
+    u64 cl = g.compl_;
+    u64 lid = g.lid;
+    while (fp) {                                         // ascending (row, colour) == azul.py:213-214
+        u32 i = ctz32(fp);
+        fp &= fp - 1u;
+        u32 r = (i * 205u) >> 10, c = i - 5u * r;
+        w |= 1u << i;                                    // :219
+        if (rules.tile_pool == POOL_LID) byte_add(lid, c, r);     // :220-222
+        u32 col = c + r; if (col >= 5u) col -= 5u;       // to_wall_position
+        u32 rowbits = (w >> (5u * r)) & 31u;
+        u32 h = ((rowbits << r) | (rowbits >> (5u - r))) & 31u;   // row r in board-column order
+        u32 hr = run_length(h, col);                     // :230-242
+        u32 wc = w & column_board(col);
+        u32 t = wc | (wc >> 1) | (wc >> 2) | (wc >> 3) | (wc >> 4);
+        u32 v = (u32)((((u64)(t & 0x108421u)) * 0x111110ull) >> 20) & 31u;   // column `col`, bit j = row j
+        u32 vr = run_length(v, r);                       // :244-257
+        u32 pos = (hr == 1u && vr == 1u) ? 1u : ((hr > 1u && vr > 1u) ? hr + vr : hr + vr - 1u);   // :258-263
+        if (pos > mc) mc = pos;                          // :264
+        u32 bonus = 0;
+        if (rowbits == 31u) { bonus += 2u; cl += 1ull << (8u * (3u * p + 0u)); }                    // :266-272
+        if (((w >> c) & 0x108421u) == 0x108421u) { bonus += 10u; cl += 1ull << (8u * (3u * p + 1u)); }   // :274-280
+        if (v == 31u) { bonus += 7u; cl += 1ull << (8u * (3u * p + 2u)); }                          // :282-288
+        cnt += (i32)(pos + bonus);
+    }
+    i32 s = g.score[p] + pen + cnt;                      // :292
+    if (s < 0) s = 0;                                    // :294-295
+    if (REAL) {
+        g.score[p] = s;
+        g.fpen[p] += pen;                                // :208
+        g.floor_[p] = 0;                                 // :209
+        g.wall[p] = w;
+        g.maxc[p] = mc;
+        g.compl_ = cl;
+        g.lid = lid;
+    }
+    return s;
+}
+
+AZ_FN void count_score(Game &g, const Rules &rules, const LaneConst &k)
+{
+    u64 F = full_lines(g, k);
+    score_player<true>(g, rules, 0, F);
+    score_player<true>(g, rules, 1, F);
+    g.cp = sel(g.cp == k.rowp1, splat(0u), g.cp);        // :218
+}
+
+AZ_FN i32 potential(Game &g, const Rules &rules, const LaneConst &k)
+{
+    // game_runner.py:48-50: score difference "as if the round were scored now", state untouched
+    u64 F = full_lines(g, k);
+    return score_player<false>(g, rules, 0, F) - score_player<false>(g, rules, 1, F);
+}
+
+// ---- new_round: azul.py:64-89 ----
+AZ_FN u32 byte_sum5(u64 v) { return (u32)(((v & 0xffffffffffull) * 0x0101010101ull) >> 32) & 0xffu; }
+
+AZ_FN u32 new_round(Game &g, const Rules &rules, Rng &r)
+{
+    g.cur = g.nfp;
+    g.fps[g.nfp == 0u ? 1u : g.nfp - 1u] += 1u;          // :67 (numpy [-1] when nfp == 0)
+    g.turn += 1u;
+    g.nfp = 0;
+    vu32 l = lane();
+    g.cs = sel(l == 30u, splat(1u), splat(0u));          // :71,:73
+    for (u32 t = 0; t < 20u; t++) {
+        u32 disp = t >> 2;
+        u32 color;
+        if (rules.tile_pool == POOL_RANDOM) {
+            color = rng_below(r, 5u, 3u);                // :78 randrange(0,5,1)
+        } else {
+            if (byte_sum5(g.box) == 0u) { g.box = g.lid; g.lid = 0; }     // :81-83
+            u32 total = byte_sum5(g.box);                // :85
+            if (total == 0u) return ST_BOX_EMPTY;
+            // weights = box_c / total (fp64), cumulative left-to-right, x = random() * cum[-1]   (:87, choices)
+            u32 blo = (u32)g.box, bhi = (u32)(g.box >> 32);
+            vu32 mine = sel(l < 4u, (blo >> ((l & 3u) * 8u)) & 0xffu, splat(bhi & 0xffu));
+            vf64 wq = divlanes(mine, (double)total);
+            double c0 = readlane_d(wq, 0);
+            double c1 = c0 + readlane_d(wq, 1);
+            double c2 = c1 + readlane_d(wq, 2);
+            double c3 = c2 + readlane_d(wq, 3);
+            double c4 = c3 + readlane_d(wq, 4);
+            double x = rng_random(r) * (c4 + 0.0);
+            color = (x < c0) ? 0u : (x < c1) ? 1u : (x < c2) ? 2u : (x < c3) ? 3u : 4u;   // bisect_right(cum, x, 0, 4)
+            g.box -= 1ull << (8u * color);               // :89
+        }
+        g.cs = g.cs + sel(l == disp * 5u + color, splat(1u), splat(0u));   // :88
+    }
+    return ST_OK;
+}
+
+// ---- Azul.__init__ + GameRunner reset bookkeeping: azul.py:18-61, game_runner.py:76-82 ----
+AZ_FN void game_ctor(Game &g, const Rules &rules, Rng &r)
+{
+    g.cs = splat(0u); g.cp = splat(0u);
+    g.wall[0] = g.wall[1] = 0; g.score[0] = g.score[1] = 0; g.floor_[0] = g.floor_[1] = 0;
+    g.cur = 0; g.eog = 0; g.turn = 0;
+    g.fps[0] = g.fps[1] = 0; g.fpen[0] = g.fpen[1] = 0; g.maxc[0] = g.maxc[1] = 0; g.compl_ = 0;
+    if (rules.first_player == 0u) g.nfp = 1u + rng_below(r, 2u, 2u);     // random.choice([1,2]) (:37)
+    else g.nfp = rules.first_player;
+    if (rules.tile_pool == POOL_LID) { g.box = 0x1414141414ull; g.lid = 0; }   // :51-52
+    else { g.box = 0; g.lid = 0; }
+}
+
+AZ_FN u32 episode_reset(Game &g, const Rules &rules, Rng &r)
+{
+    game_ctor(g, rules, r);
+    u32 st = new_round(g, rules, r);
+    g.pscore = 0;
+    g.moves = 0;
+    return st;
+}
+
+// ---- step: azul.py:296-313 (legality is checked by the caller against the mask) ----
+AZ_FN void decode_action(u32 a, u32 &d, u32 &c, u32 &row)
+{
+    d = a % 6u; c = (a / 6u) % 5u; row = a / 30u;       // game_runner.py:107-111
+}
+
+AZ_FN u32 apply_step(Game &g, const Rules &rules, const LaneConst &k, Rng &r, u32 a)
+{
+    u32 d, c, row;
+    decode_action(a, d, c, row);
+    do_move(g, rules, d, c, row);                        // :304
+    if (sources_board(g) == 0u) {                        // :306 (the token counts)
+        count_score(g, rules, k);                        // :307
+        if (is_end_of_game(g)) g.eog = 1;                // :308-309
+        else return new_round(g, rules, r);              // :311
+    } else {
+        g.cur = (g.cur < 2u) ? g.cur + 1u : 1u;          // :313 next_player
+    }
+    return ST_OK;
+}
+
+AZ_FN u32 checked_step(Game &g, const Rules &rules, const LaneConst &k, Rng &r, i32 a)
+{
+    if (g.eog) return ST_GAME_ENDED;                     // :298-299
+    if (a < 0 || a >= 180) return ST_BAD_ACTION;
+    Mask m;
+    legal_mask(g, k, m);
+    if (!mask_test(m, (u32)a)) return ST_ILLEGAL_MOVE;   // :301-302, state untouched
+    return apply_step(g, rules, k, r, (u32)a);
+}
+
+// ---- GameRunner.step with the default RandomAgent opponent: game_runner.py:43-55 ----
+AZ_FN u32 runner_opponent_loop(Game &g, const Rules &rules, const LaneConst &k, Rng &r, const double *T, bool until_player1_only)
+{
+    for (u32 guard = 0; guard < 4096u; guard++) {
+        Mask m;
+        legal_mask(g, k, m);
+        bool keep = until_player1_only ? (g.cur != 1u)
+                                       : ((g.cur != 1u || mask_count(m) < 2u) && !is_end_of_game(g));   // :46 / :84
+        if (!keep) break;
+        i32 a = random_agent(m, r, T);                   // opponent_move, :37-42
+        if (a < 0) return ST_STUCK;
+        if (g.eog) return ST_GAME_ENDED;
+        u32 st = apply_step(g, rules, k, r, (u32)a);
+        if (st) return st;
+        g.moves += 1u;
+    }
+    return ST_OK;
+}
+
+AZ_FN u32 runner_step(Game &g, const Rules &rules, const LaneConst &k, Rng &r, const double *T, i32 a, i32 &reward, u32 &done)
+{
+    reward = 0;
+    done = is_end_of_game(g) ? 1u : 0u;
+    u32 st = checked_step(g, rules, k, r, a);            // :44
+    if (st) return st;
+    g.moves += 1u;                                       // :45
+    st = runner_opponent_loop(g, rules, k, r, T, false); // :46-47
+    if (st) return st;
+    i32 phi = potential(g, rules, k);                    // :48-50
+    reward = phi - g.pscore;                             // :51
+    g.pscore = phi;                                      // :52
+    done = is_end_of_game(g) ? 1u : 0u;                  // :55
+    return ST_OK;
+}
+
+// ---- observation: game_runner.py:56-72 (136 integers; written as f32 for the policy net) ----
+AZ_FN void observe(const Game &g, u32 persp, float *out)
+{
+    vu32 l = lane();
+    u32 o0 = persp & 1u, o1 = o0 ^ 1u;
+    u32 pnfp = g.nfp > 0u ? (((g.nfp - 1u - o0) & 1u) + 1u) : 0u;     // :58-61
+    // j = 0..63: displays+centre (cs lanes 0..30), then pattern_lines[order]
+    {
+        vu32 j = l;
+        vu32 k = j - 31u;                                              // pattern cell index 0..32
+        vu32 src = sel(k < 25u, k + 25u * o0, k - 25u + 25u * o1);
+        vu32 v = sel(j < 31u, g.cs, bperm(g.cp, src));
+        st_f32(out, j, v, j < 64u);
+    }
+    // j = 64..127: rest of pattern_lines[order[1]] (cells 8..24), then walls[order]
+    {
+        vu32 j = l + 64u;
+        vu32 pc = j - 56u;                                             // cell of order[1] for j <= 80
+        vu32 pv = bperm(g.cp, pc + 25u * o1);
+        vu32 wb = j - 81u;                                             // wall bit index 0..46 (two boards of 25)
+        vu32 wsel = sel(wb < 25u, splat(g.wall[o0]), splat(g.wall[o1]));
+        vu32 wv_ = (wsel >> (sel(wb < 25u, wb, wb - 25u) & 31u)) & 1u;
+        st_f32(out, j, sel(j <= 80u, pv, wv_), j < 128u);
+    }
+    // j = 128..135: last three wall bits of order[1], floors, scores, next first player
+    {
+        vu32 j = l + 128u;
+        vu32 v = (g.wall[o1] >> ((l + 22u) & 31u)) & 1u;
+        v = sel(l == 3u, splat(g.floor_[o0]), v);
+        v = sel(l == 4u, splat(g.floor_[o1]), v);
+        v = sel(l == 5u, splat((u32)g.score[o0]), v);
+        v = sel(l == 6u, splat((u32)g.score[o1]), v);
+        v = sel(l == 7u, splat(pnfp), v);
+        st_f32(out, j, v, l < 8u);
+    }
+}
+
+// ---- get_statistics: azul.py:314-315 (ten values per finished game, key order of game_runner.py:12) ----
+AZ_FN void game_statistics(const Game &g, double out[10])
+{
+    out[0] = (double)g.score[0];
+    out[1] = (double)g.score[1];
+    out[2] = (double)g.turn;
+    out[3] = (double)g.fps[0] / ((double)g.fps[0] + (double)g.fps[1]) * 100;
+    out[4] = -(double)g.fpen[0];
+    out[5] = (double)g.maxc[0];
+    out[6] = (double)(g.compl_ & 0xffu);
+    out[7] = (double)((g.compl_ >> 16) & 0xffu);
+    out[8] = (double)((g.compl_ >> 8) & 0xffu);
+    out[9] = g.score[0] > g.score[1] ? 1.0 : 0.0;
+}
+
+// ---- random.seed(int): CPython init_by_array over the 32-bit words of the seed (one stream per THREAD) ----
+AZ_FN void seed_stream(u32 *mt, u64 seed)
+{
+    u32 key[2] = {(u32)(seed & 0xffffffffu), (u32)(seed >> 32)};
+    u32 len = key[1] ? 2u : 1u;
+    u32 prev = 19650218u;
+    mt[0] = prev;
+    for (u32 i = 1; i < 624u; i++) { prev = 1812433253u * (prev ^ (prev >> 30)) + i; mt[i] = prev; }   // init_genrand
+    u32 i = 1, j = 0;
+    for (u32 k = 624u; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + j;
+        i++; j++;
+        if (i >= 624u) { mt[0] = mt[623]; i = 1; }
+        if (j >= len) j = 0;
+    }
+    for (u32 k = 623u; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - i;
+        i++;
+        if (i >= 624u) { mt[0] = mt[623]; i = 1; }
+    }
+    mt[0] = 0x80000000u;
+}
+
+// ---- one env move of flat random-agent self-play (the benchmarked step) ----
+struct Counters {
+    u64 *episodes;      // [1] finished games of this slot
+    u32 *stuck;         // [1] hazard-H3 resets of this slot
+    double *stat_sum;   // [10] get_statistics() summed over finished games
+};
+
+// returns 0 = move played, 1 = game ended with this move, 2 = stuck, 0x100|status on a rule error
+AZ_FN u32 selfplay_step(Game &g, const Rules &rules, const LaneConst &k, Rng &r, const double *T, const Counters &cnt,
+                        uint8_t *mask_out, i32 *action_out, i32 *reward_out, uint8_t *done_out, uint8_t *rec_out)
+{
+    Mask m;
+    legal_mask(g, k, m);
+    if (mask_out) mask_write(m, mask_out);
+    i32 a = g.eog ? -2 : random_agent(m, r, T);
+    if (a < 0) {
+        // stuck (or handed an already finished game): report, then start the next episode
+        if (action_out) AZ_LANE0(*action_out = -1);
+        if (reward_out) AZ_LANE0(*reward_out = 0);
+        if (done_out) AZ_LANE0(*done_out = 2);
+        if (rec_out) game_store(g, rec_out);
+        AZ_LANE0(*cnt.stuck += 1u);
+        u32 st = episode_reset(g, rules, r);
+        return st ? (0x100u | st) : 2u;
+    }
+    u32 st = apply_step(g, rules, k, r, (u32)a);
+    g.moves += 1u;
+    i32 phi = potential(g, rules, k);
+    i32 reward = phi - g.pscore;
+    g.pscore = phi;
+    u32 dn = is_end_of_game(g) ? 1u : 0u;
+    if (action_out) AZ_LANE0(*action_out = a);
+    if (reward_out) AZ_LANE0(*reward_out = reward);
+    if (done_out) AZ_LANE0(*done_out = (uint8_t)dn);
+    if (rec_out) game_store(g, rec_out);
+    if (st) return 0x100u | st;
+    if (dn) {
+        double s[10];
+        game_statistics(g, s);
+        AZ_LANE0(for (int q = 0; q < 10; q++) cnt.stat_sum[q] += s[q]; *cnt.episodes += 1ull);
+        st = episode_reset(g, rules, r);
+        if (st) return 0x100u | st;
+    }
+    return dn;
+}
+
+} // namespace az

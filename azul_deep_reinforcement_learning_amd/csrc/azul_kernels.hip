@@ -1,0 +1,540 @@
+// azul_kernels.hip -- gfx950 kernels and the C ABI of libazulhip.so (declared in include/azul_hip.h).
+//
+// Mapping: ONE GAME PER 64-LANE WAVEFRONT, one wavefront per workgroup (grid = N workgroups).  With the
+// benchmarked N = 4096 games that is 16 waves per CU / 4 per SIMD on all 256 CUs of an MI355X: every game
+// advances on its own scalar instruction stream (no divergence between games -- the rules are branchy),
+// while the 64 lanes hold the board cells (azul_core.hpp) and serve the ballots, the MT19937 regeneration,
+// the mask/observation write-out and the fp64 weight division.
+//
+// Kernels
+//   azul_seed_kernel      one THREAD per game: CPython init_by_array is a strictly sequential 1247-step recurrence
+//   azul_op_kernel        one wave per game: every single-call rule / runner entry point of the ABI
+//   azul_selfplay_kernel  one wave per game, state register-resident across n_steps env moves (the hot path)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/azul_hip.h"
+#include "azul_core.hpp"
+#include "azul_tables.hpp"
+
+using namespace az;
+
+// ------------------------------------------------------------------------------------------------
+// device side
+// ------------------------------------------------------------------------------------------------
+struct BatchDev {
+    uint8_t *state;      // [N][128]
+    u32 *mt;             // [N][624]
+    u32 *mtpos;          // [N]
+    const double *T;     // [31][151]
+    u64 *episodes;       // [N]
+    u32 *stuck;          // [N]
+    double *stat_sum;    // [N][10]
+    u32 n;
+    Rules rules;
+};
+
+enum {
+    OP_QUERY = 0, OP_INIT, OP_NEW_ROUND, OP_MOVE, OP_NEXT_PLAYER, OP_COUNT_SCORE, OP_STEP,
+    OP_RUNNER_INIT, OP_RUNNER_RESET, OP_RUNNER_STEP, OP_RANDOM_ACTION
+};
+
+struct OpArgs {
+    int op;
+    const i32 *actions;      // [N]   in  (MOVE / STEP / RUNNER_STEP)
+    const uint8_t *active;   // [N]   in, optional
+    i32 *actions_out;        // [N]   out (RANDOM_ACTION)
+    uint8_t *status;         // [N]   out
+    i32 *reward;             // [N]   out
+    uint8_t *done;           // [N]   out
+    uint8_t *mask;           // [N][180] out (after the op)
+    float *obs;              // [N][136] out (after the op)
+    int persp;
+    uint8_t *flags;          // [N]   out
+    i32 *potential;          // [N]   out
+    double *stats;           // [N][10] out
+};
+
+__global__ void __launch_bounds__(64) azul_seed_kernel(BatchDev b, u64 seed_base, const u64 *seeds)
+{
+    u32 g = blockIdx.x * 64u + threadIdx.x;
+    if (g >= b.n) return;
+    u64 seed = seeds ? seeds[g] : seed_base + (u64)g;
+    seed_stream(b.mt + (size_t)g * 624u, seed);
+    b.mtpos[g] = 624u;
+}
+
+__global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
+{
+    __shared__ u32 mt_lds[624];
+    const u32 gi = blockIdx.x;
+    const bool act = a.active ? (a.active[gi] != 0) : true;
+    uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
+    LaneConst k;
+    lane_consts(k);
+    Game g;
+    game_load(g, rec);
+    u32 st = ST_OK;
+    if (act && a.op != OP_QUERY) {
+        Rng r;
+        rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]);
+        bool dirty_state = true;
+        switch (a.op) {
+        case OP_INIT:
+            game_ctor(g, b.rules, r);
+            break;
+        case OP_NEW_ROUND:
+            st = new_round(g, b.rules, r);
+            break;
+        case OP_MOVE: {
+            i32 av = a.actions[gi];
+            if (av < 0 || av >= 180) { st = ST_BAD_ACTION; dirty_state = false; break; }
+            u32 d, c, row;
+            decode_action((u32)av, d, c, row);
+            do_move(g, b.rules, d, c, row);
+        } break;
+        case OP_NEXT_PLAYER:
+            g.cur = (g.cur < 2u) ? g.cur + 1u : 1u;
+            break;
+        case OP_COUNT_SCORE:
+            count_score(g, b.rules, k);
+            break;
+        case OP_STEP:
+            st = checked_step(g, b.rules, k, r, a.actions[gi]);
+            dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION);
+            break;
+        case OP_RUNNER_INIT:
+            st = episode_reset(g, b.rules, r);
+            break;
+        case OP_RUNNER_RESET:
+            st = episode_reset(g, b.rules, r);
+            if (!st) st = runner_opponent_loop(g, b.rules, k, r, b.T, true);
+            break;
+        case OP_RUNNER_STEP: {
+            i32 rew = 0;
+            u32 dn = 0;
+            st = runner_step(g, b.rules, k, r, b.T, a.actions[gi], rew, dn);
+            dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION);
+            if (a.reward) AZ_LANE0(a.reward[gi] = rew);
+            if (a.done) AZ_LANE0(a.done[gi] = (uint8_t)dn);
+            if (!st && dn) {
+                double s[10];
+                game_statistics(g, s);
+                AZ_LANE0(for (int q = 0; q < 10; q++) b.stat_sum[(size_t)gi * 10 + q] += s[q]; b.episodes[gi] += 1ull);
+            }
+            if (st == ST_STUCK) AZ_LANE0(b.stuck[gi] += 1u);
+        } break;
+        case OP_RANDOM_ACTION: {
+            Mask m;
+            legal_mask(g, k, m);
+            i32 av = random_agent(m, r, b.T);
+            AZ_LANE0(a.actions_out[gi] = av);
+            dirty_state = false;
+        } break;
+        default:
+            dirty_state = false;
+            break;
+        }
+        if (dirty_state) game_store(g, rec);
+        rng_close(r, b.mtpos + gi);
+    }
+    if (a.status && act) AZ_LANE0(a.status[gi] = (uint8_t)st);
+    // queries on the post-op state
+    if (a.mask) {
+        Mask m;
+        legal_mask(g, k, m);
+        mask_write(m, a.mask + (size_t)gi * AZUL_NUM_ACTIONS);
+    }
+    if (a.obs) {
+        u32 p = (a.persp == AZUL_PERSP_CURRENT) ? me_index(g) : (u32)a.persp;
+        observe(g, p, a.obs + (size_t)gi * AZUL_OBS_SIZE);
+    }
+    if (a.flags) {
+        u32 f = (sources_board(g) == 0u ? AZUL_FLAG_END_OF_ROUND : 0) | (is_end_of_game(g) ? AZUL_FLAG_END_OF_GAME : 0) |
+                (g.eog ? AZUL_FLAG_ENDED_FLAG : 0);
+        AZ_LANE0(a.flags[gi] = (uint8_t)f);
+    }
+    if (a.potential) {
+        i32 phi = potential(g, b.rules, k);
+        AZ_LANE0(a.potential[gi] = phi);
+    }
+    if (a.stats) {
+        double s[10];
+        game_statistics(g, s);
+        AZ_LANE0(for (int q = 0; q < 10; q++) a.stats[(size_t)gi * 10 + q] = s[q]);
+    }
+}
+
+struct TrajArgs {
+    int n_steps;
+    uint8_t *mask;     // [T][N][180]
+    i32 *action;       // [T][N]
+    i32 *reward;       // [T][N]
+    uint8_t *done;     // [T][N]
+    uint8_t *rec;      // [T][N][128]
+};
+
+__global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs t)
+{
+    __shared__ u32 mt_lds[624];
+    const u32 gi = blockIdx.x;
+    const size_t N = b.n;
+    uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
+    LaneConst k;
+    lane_consts(k);
+    Game g;
+    game_load(g, rec);
+    Rng r;
+    rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]);
+    Counters cnt = {b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10};
+    for (int s = 0; s < t.n_steps; s++) {
+        const size_t row = (size_t)s * N + gi;
+        u32 f = selfplay_step(g, b.rules, k, r, b.T, cnt,
+                              t.mask ? t.mask + row * AZUL_NUM_ACTIONS : nullptr,
+                              t.action ? t.action + row : nullptr,
+                              t.reward ? t.reward + row : nullptr,
+                              t.done ? t.done + row : nullptr,
+                              t.rec ? t.rec + row * AZUL_RECORD_BYTES : nullptr);
+        if (f & 0x100u) break;      // rule error (box empty): leave the game as it is; status is visible in the record
+    }
+    game_store(g, rec);
+    rng_close(r, b.mtpos + gi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: C ABI
+// ------------------------------------------------------------------------------------------------
+struct azul_batch {
+    BatchDev d;
+    int device;
+    hipEvent_t ev0, ev1;
+    int timed_launches;
+    bool timing;
+};
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *what, hipError_t e = hipSuccess)
+{
+    g_err = what;
+    if (e != hipSuccess) { g_err += ": "; g_err += hipGetErrorString(e); }
+    return code;
+}
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(AZUL_ERR_HIP, #expr, e_); } while (0)
+
+extern "C" {
+
+const char *azul_last_error_string(void) { return g_err.c_str(); }
+const char *azul_version(void) { return "azul-mi355x 0.1 (gfx950, wave-per-game)"; }
+
+int azul_batch_create(azul_batch_t **out, int n_games, int first_player, int tile_pool)
+{
+    if (!out || n_games <= 0) return fail(AZUL_ERR_INVALID, "azul_batch_create: bad arguments");
+    if (first_player < 0 || first_player > 2) return fail(AZUL_ERR_RULE, "first_player must be 0 (Random), 1 or 2");
+    if (tile_pool != AZUL_POOL_RANDOM && tile_pool != AZUL_POOL_LID) return fail(AZUL_ERR_RULE, "tile_pool must be AZUL_POOL_RANDOM or AZUL_POOL_LID");
+    azul_batch *b = new azul_batch();
+    memset(&b->d, 0, sizeof(b->d));
+    b->timing = false;
+    b->timed_launches = 0;
+    HIP_TRY(hipGetDevice(&b->device));
+    const size_t N = (size_t)n_games;
+    b->d.n = (u32)n_games;
+    b->d.rules.first_player = (u32)first_player;
+    b->d.rules.tile_pool = (u32)tile_pool;
+    double *T = nullptr;
+    HIP_TRY(hipMalloc((void **)&b->d.state, N * AZUL_RECORD_BYTES));
+    HIP_TRY(hipMalloc((void **)&b->d.mt, N * 624 * sizeof(u32)));
+    HIP_TRY(hipMalloc((void **)&b->d.mtpos, N * sizeof(u32)));
+    HIP_TRY(hipMalloc((void **)&T, sizeof(double) * T_ROWS * T_COLS));
+    HIP_TRY(hipMalloc((void **)&b->d.episodes, N * sizeof(u64)));
+    HIP_TRY(hipMalloc((void **)&b->d.stuck, N * sizeof(u32)));
+    HIP_TRY(hipMalloc((void **)&b->d.stat_sum, N * 10 * sizeof(double)));
+    std::vector<double> hT((size_t)T_ROWS * T_COLS);
+    build_weight_table(hT.data());
+    HIP_TRY(hipMemcpy(T, hT.data(), hT.size() * sizeof(double), hipMemcpyHostToDevice));
+    b->d.T = T;
+    HIP_TRY(hipMemset(b->d.state, 0, N * AZUL_RECORD_BYTES));
+    HIP_TRY(hipMemset(b->d.mt, 0, N * 624 * sizeof(u32)));
+    {   // a defined stream even before azul_batch_seed: index 624 over an all-zero state is never used un-seeded
+        std::vector<u32> pos(N, 624u);
+        HIP_TRY(hipMemcpy(b->d.mtpos, pos.data(), N * sizeof(u32), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemset(b->d.episodes, 0, N * sizeof(u64)));
+    HIP_TRY(hipMemset(b->d.stuck, 0, N * sizeof(u32)));
+    HIP_TRY(hipMemset(b->d.stat_sum, 0, N * 10 * sizeof(double)));
+    HIP_TRY(hipEventCreate(&b->ev0));
+    HIP_TRY(hipEventCreate(&b->ev1));
+    *out = b;
+    return AZUL_SUCCESS;
+}
+
+int azul_batch_destroy(azul_batch_t *b)
+{
+    if (!b) return AZUL_SUCCESS;
+    void *bufs[] = {b->d.state, b->d.mt, b->d.mtpos, (void *)b->d.T, b->d.episodes, b->d.stuck, b->d.stat_sum};
+    for (void *p : bufs) (void)hipFree(p);
+    (void)hipEventDestroy(b->ev0);
+    (void)hipEventDestroy(b->ev1);
+    delete b;
+    return AZUL_SUCCESS;
+}
+
+int azul_batch_size(const azul_batch_t *b) { return b ? (int)b->d.n : 0; }
+void *azul_batch_state_dev(azul_batch_t *b) { return b ? b->d.state : nullptr; }
+void *azul_batch_mt_dev(azul_batch_t *b) { return b ? b->d.mt : nullptr; }
+void *azul_batch_mtpos_dev(azul_batch_t *b) { return b ? b->d.mtpos : nullptr; }
+
+static int check_range(const azul_batch_t *b, int first, int count)
+{
+    if (!b || first < 0 || count < 0 || (u64)first + (u64)count > b->d.n) return fail(AZUL_ERR_INVALID, "game range outside the batch");
+    return AZUL_SUCCESS;
+}
+
+int azul_batch_get_state(azul_batch_t *b, int first, int count, void *records_host, void *stream)
+{
+    if (int rc = check_range(b, first, count)) return rc;
+    if (!records_host) return fail(AZUL_ERR_INVALID, "records_host is NULL");
+    HIP_TRY(hipMemcpyAsync(records_host, b->d.state + (size_t)first * AZUL_RECORD_BYTES, (size_t)count * AZUL_RECORD_BYTES,
+                           hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return AZUL_SUCCESS;
+}
+
+int azul_batch_set_state(azul_batch_t *b, int first, int count, const void *records_host, void *stream)
+{
+    if (int rc = check_range(b, first, count)) return rc;
+    if (!records_host) return fail(AZUL_ERR_INVALID, "records_host is NULL");
+    const uint8_t *p = (const uint8_t *)records_host;
+    for (int i = 0; i < count; i++, p += AZUL_RECORD_BYTES) {
+        // domain the kernels are exact on (documented in DESIGN.md)
+        u32 flags = p[31];
+        if ((flags & 7u) > 2u || ((flags >> 3) & 7u) > 2u || (flags & 0x80u)) return fail(AZUL_ERR_RANGE, "flags: players are 0..2");
+        if (p[82] > 7 || p[83] > 7) return fail(AZUL_ERR_RANGE, "floors are 0..7 (azul.py:120-123)");
+        u32 w0, w1;
+        memcpy(&w0, p + 84, 4); memcpy(&w1, p + 88, 4);
+        if ((w0 | w1) >> 25) return fail(AZUL_ERR_RANGE, "walls are 25-bit boards");
+        u32 sb = 0, sl = 0;
+        for (int c = 0; c < 5; c++) { sb += p[96 + c]; sl += p[101 + c]; }
+        if (sb > 255 || sl > 255) return fail(AZUL_ERR_RANGE, "box / lid hold at most 255 tiles in total");
+    }
+    HIP_TRY(hipMemcpyAsync(b->d.state + (size_t)first * AZUL_RECORD_BYTES, records_host, (size_t)count * AZUL_RECORD_BYTES,
+                           hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return AZUL_SUCCESS;
+}
+
+int azul_batch_get_rng(azul_batch_t *b, int game, uint32_t *mt_host, uint32_t *pos_host, void *stream)
+{
+    if (int rc = check_range(b, game, 1)) return rc;
+    if (mt_host) HIP_TRY(hipMemcpyAsync(mt_host, b->d.mt + (size_t)game * 624, 624 * sizeof(u32), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (pos_host) HIP_TRY(hipMemcpyAsync(pos_host, b->d.mtpos + game, sizeof(u32), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return AZUL_SUCCESS;
+}
+
+int azul_batch_set_rng(azul_batch_t *b, int game, const uint32_t *mt_host, uint32_t pos, void *stream)
+{
+    if (int rc = check_range(b, game, 1)) return rc;
+    if (!mt_host || pos > 624u) return fail(AZUL_ERR_INVALID, "azul_batch_set_rng: need 624 words and an index in 0..624");
+    HIP_TRY(hipMemcpyAsync(b->d.mt + (size_t)game * 624, mt_host, 624 * sizeof(u32), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(b->d.mtpos + game, &pos, sizeof(u32), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return AZUL_SUCCESS;
+}
+
+int azul_batch_seed(azul_batch_t *b, uint64_t seed_base, const uint64_t *seeds_host, void *stream)
+{
+    if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
+    u64 *dseeds = nullptr;
+    if (seeds_host) {
+        HIP_TRY(hipMalloc((void **)&dseeds, (size_t)b->d.n * sizeof(u64)));
+        HIP_TRY(hipMemcpyAsync(dseeds, seeds_host, (size_t)b->d.n * sizeof(u64), hipMemcpyHostToDevice, (hipStream_t)stream));
+    }
+    hipLaunchKernelGGL(azul_seed_kernel, dim3((b->d.n + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, b->d, (u64)seed_base, (const u64 *)dseeds);
+    HIP_TRY(hipGetLastError());
+    if (dseeds) {
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        HIP_TRY(hipFree(dseeds));
+    }
+    return AZUL_SUCCESS;
+}
+
+static int launch_op(azul_batch_t *b, const OpArgs &a, void *stream)
+{
+    if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
+    hipLaunchKernelGGL(azul_op_kernel, dim3(b->d.n), dim3(64), 0, (hipStream_t)stream, b->d, a);
+    HIP_TRY(hipGetLastError());
+    return AZUL_SUCCESS;
+}
+
+static OpArgs op_args(int op)
+{
+    OpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.op = op;
+    return a;
+}
+
+int azul_batch_init(azul_batch_t *b, const uint8_t *active_dev, void *stream)
+{
+    OpArgs a = op_args(OP_INIT); a.active = active_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_new_round(azul_batch_t *b, const uint8_t *active_dev, uint8_t *status_dev, void *stream)
+{
+    OpArgs a = op_args(OP_NEW_ROUND); a.active = active_dev; a.status = status_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_move(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *active_dev, void *stream)
+{
+    if (!actions_dev) return fail(AZUL_ERR_INVALID, "actions_dev is NULL");
+    OpArgs a = op_args(OP_MOVE); a.actions = actions_dev; a.active = active_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_legal_mask(azul_batch_t *b, uint8_t *mask_dev, void *stream)
+{
+    if (!mask_dev) return fail(AZUL_ERR_INVALID, "mask_dev is NULL");
+    OpArgs a = op_args(OP_QUERY); a.mask = mask_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_next_player(azul_batch_t *b, const uint8_t *active_dev, void *stream)
+{
+    OpArgs a = op_args(OP_NEXT_PLAYER); a.active = active_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_flags(azul_batch_t *b, uint8_t *flags_dev, void *stream)
+{
+    if (!flags_dev) return fail(AZUL_ERR_INVALID, "flags_dev is NULL");
+    OpArgs a = op_args(OP_QUERY); a.flags = flags_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_count_score(azul_batch_t *b, const uint8_t *active_dev, void *stream)
+{
+    OpArgs a = op_args(OP_COUNT_SCORE); a.active = active_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_step(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *active_dev, uint8_t *status_dev, void *stream)
+{
+    if (!actions_dev) return fail(AZUL_ERR_INVALID, "actions_dev is NULL");
+    OpArgs a = op_args(OP_STEP); a.actions = actions_dev; a.active = active_dev; a.status = status_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_statistics(azul_batch_t *b, double *stats_dev, void *stream)
+{
+    if (!stats_dev) return fail(AZUL_ERR_INVALID, "stats_dev is NULL");
+    OpArgs a = op_args(OP_QUERY); a.stats = stats_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_runner_init(azul_batch_t *b, const uint8_t *active_dev, uint8_t *status_dev, void *stream)
+{
+    OpArgs a = op_args(OP_RUNNER_INIT); a.active = active_dev; a.status = status_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_runner_reset(azul_batch_t *b, const uint8_t *active_dev, uint8_t *status_dev, void *stream)
+{
+    OpArgs a = op_args(OP_RUNNER_RESET); a.active = active_dev; a.status = status_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_runner_step(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *active_dev, int32_t *reward_dev,
+                           uint8_t *done_dev, uint8_t *status_dev, void *stream)
+{
+    if (!actions_dev) return fail(AZUL_ERR_INVALID, "actions_dev is NULL");
+    OpArgs a = op_args(OP_RUNNER_STEP);
+    a.actions = actions_dev; a.active = active_dev; a.reward = reward_dev; a.done = done_dev; a.status = status_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_observe(azul_batch_t *b, int perspective, float *obs_dev, void *stream)
+{
+    if (!obs_dev || perspective < 0 || perspective > 2) return fail(AZUL_ERR_INVALID, "azul_batch_observe: bad arguments");
+    OpArgs a = op_args(OP_QUERY); a.obs = obs_dev; a.persp = perspective;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_random_action(azul_batch_t *b, const uint8_t *active_dev, int32_t *actions_dev, void *stream)
+{
+    if (!actions_dev) return fail(AZUL_ERR_INVALID, "actions_dev is NULL");
+    OpArgs a = op_args(OP_RANDOM_ACTION); a.active = active_dev; a.actions_out = actions_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_score_preview(azul_batch_t *b, int32_t *potential_dev, void *stream)
+{
+    if (!potential_dev) return fail(AZUL_ERR_INVALID, "potential_dev is NULL");
+    OpArgs a = op_args(OP_QUERY); a.potential = potential_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, int32_t *action_dev, int32_t *reward_dev,
+                        uint8_t *done_dev, uint8_t *rec_dev, void *stream)
+{
+    if (!b || n_steps < 0) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: bad arguments");
+    if (n_steps == 0) return AZUL_SUCCESS;
+    TrajArgs t = {n_steps, mask_dev, action_dev, reward_dev, done_dev, rec_dev};
+    hipLaunchKernelGGL(azul_selfplay_kernel, dim3(b->d.n), dim3(64), 0, (hipStream_t)stream, b->d, t);
+    HIP_TRY(hipGetLastError());
+    if (b->timing) b->timed_launches++;
+    return AZUL_SUCCESS;
+}
+
+int azul_batch_counters(azul_batch_t *b, uint64_t *episodes_host, uint32_t *stuck_host, double *stat_sums_host, void *stream)
+{
+    if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
+    const size_t N = b->d.n;
+    if (episodes_host) HIP_TRY(hipMemcpyAsync(episodes_host, b->d.episodes, N * sizeof(u64), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (stuck_host) HIP_TRY(hipMemcpyAsync(stuck_host, b->d.stuck, N * sizeof(u32), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (stat_sums_host) HIP_TRY(hipMemcpyAsync(stat_sums_host, b->d.stat_sum, N * 10 * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return AZUL_SUCCESS;
+}
+
+int azul_batch_reset_counters(azul_batch_t *b, void *stream)
+{
+    if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
+    const size_t N = b->d.n;
+    HIP_TRY(hipMemsetAsync(b->d.episodes, 0, N * sizeof(u64), (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(b->d.stuck, 0, N * sizeof(u32), (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(b->d.stat_sum, 0, N * 10 * sizeof(double), (hipStream_t)stream));
+    return AZUL_SUCCESS;
+}
+
+int azul_timing_begin(azul_batch_t *b, void *stream)
+{
+    if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
+    b->timing = true;
+    b->timed_launches = 0;
+    HIP_TRY(hipEventRecord(b->ev0, (hipStream_t)stream));
+    return AZUL_SUCCESS;
+}
+
+int azul_timing_end(azul_batch_t *b, void *stream, float *total_ms, int *launches)
+{
+    if (!b || !b->timing) return fail(AZUL_ERR_INVALID, "azul_timing_end without azul_timing_begin");
+    HIP_TRY(hipEventRecord(b->ev1, (hipStream_t)stream));
+    HIP_TRY(hipEventSynchronize(b->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = b->timed_launches;
+    b->timing = false;
+    return AZUL_SUCCESS;
+}
+
+} // extern "C"

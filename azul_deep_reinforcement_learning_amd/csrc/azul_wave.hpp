@@ -1,0 +1,149 @@
+// azul_wave.hpp -- the wave64 programming model the Azul core is written against.
+//
+// The core (azul_core.hpp) maps ONE GAME TO ONE 64-LANE WAVEFRONT.  Game state lives in
+//   * "uniform" values  (plain u32/u64/i32/double: identical in every lane; hipcc keeps them in
+//     SGPRs / scalar ALU where it can), and
+//   * "lane" values     (vu32: one record byte per lane, i.e. a 64-entry cell array in ONE VGPR),
+// and the rules are expressed with wave primitives: ballot (cell-array -> bitboard), readlane /
+// writelane (uniform <-> one cell), bpermute (cell gather), mbcnt (prefix popcount).
+//
+// Under hipcc this header lowers those primitives to gfx950 builtins.  Under a plain host compiler
+// (g++, used ONLY by tests/hostcheck to cross-check the core's logic against the oracle before it
+// ever reaches a GPU) the same primitives are emulated lane by lane.  The shipped library contains
+// the gfx950 path only; there is no CPU execution path in the product.
+#pragma once
+#include <stdint.h>
+
+typedef uint32_t u32;
+typedef int32_t  i32;
+typedef uint64_t u64;
+typedef int64_t  i64;
+
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------------------------------------
+// gfx950
+// ------------------------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+#define AZ_FN __device__ __forceinline__
+#define AZ_DEVICE_BUILD 1
+
+namespace wv {
+typedef u32    vu32;
+typedef bool   vbool;
+typedef double vf64;
+
+AZ_FN vu32 lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+AZ_FN u64  ballot(vbool p) { return __builtin_amdgcn_ballot_w64(p); }
+AZ_FN u32  uni(u32 x) { return __builtin_amdgcn_readfirstlane(x); }
+AZ_FN u64  uni64(u64 x)
+{
+    u32 lo = __builtin_amdgcn_readfirstlane((u32)x), hi = __builtin_amdgcn_readfirstlane((u32)(x >> 32));
+    return ((u64)hi << 32) | lo;
+}
+AZ_FN double unid(double x) { return __longlong_as_double((long long)uni64((u64)__double_as_longlong(x))); }
+AZ_FN u32  readlane(vu32 v, u32 l) { return __builtin_amdgcn_readlane(v, l); }
+// (clang exposes no writelane builtin for this target; compare+select is one v_cmp + one v_cndmask)
+AZ_FN vu32 writelane(vu32 v, u32 val, u32 l) { return lane() == l ? val : v; }
+AZ_FN vu32 bperm(vu32 v, vu32 idx) { return __builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)v); }
+AZ_FN vu32 sel(vbool p, vu32 a, vu32 b) { return p ? a : b; }
+AZ_FN vu32 splat(u32 x) { return x; }
+// number of set bits of a uniform mask strictly below this lane
+AZ_FN vu32 mbcnt(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
+// per-lane IEEE fp64 quotient num/den (den uniform); hipcc emits the correctly rounded
+// v_div_scale/v_rcp/v_fma/v_div_fmas/v_div_fixup sequence (no fast-math in this build)
+AZ_FN vf64 divlanes(vu32 num, double den) { return (double)num / den; }
+AZ_FN double readlane_d(vf64 v, u32 l)
+{
+    u64 b = (u64)__double_as_longlong(v);
+    u32 lo = __builtin_amdgcn_readlane((u32)b, l), hi = __builtin_amdgcn_readlane((u32)(b >> 32), l);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+AZ_FN u32 popc64(u64 x) { return (u32)__builtin_popcountll(x); }
+AZ_FN u32 ctz64(u64 x) { return (u32)__builtin_ctzll(x); }
+AZ_FN u32 ctz32(u32 x) { return (u32)__builtin_ctz(x); }
+AZ_FN u32 clz32(u32 x) { return (u32)__builtin_clz(x); }
+
+// memory (addresses: uniform base + per-lane offset)
+AZ_FN vu32 ld_u8(const uint8_t *base, vu32 off, vbool act) { return act ? (u32)base[off] : 0u; }
+AZ_FN void st_u8(uint8_t *base, vu32 off, vu32 val, vbool act) { if (act) base[off] = (uint8_t)val; }
+AZ_FN vu32 ld_u32(const u32 *base, vu32 off, vbool act) { return act ? base[off] : 0u; }
+AZ_FN void st_u32(u32 *base, vu32 off, vu32 val, vbool act) { if (act) base[off] = val; }
+AZ_FN void st_f32(float *base, vu32 off, vu32 ival, vbool act) { if (act) base[off] = (float)(i32)ival; }
+// LDS (one private region per wave; a wave's DS operations execute in program order)
+AZ_FN vu32 lds_ld(const u32 *lds, vu32 idx, vbool act) { return act ? lds[idx] : 0u; }
+AZ_FN void lds_st(u32 *lds, vu32 idx, vu32 val, vbool act) { if (act) lds[idx] = val; }
+AZ_FN u32  lds_ldu(const u32 *lds, u32 idx) { return __builtin_amdgcn_readfirstlane(lds[idx]); }
+AZ_FN void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// run `stmt` on one lane only (uniform values -> memory)
+#define AZ_LANE0(stmt) do { if (wv::lane() == 0) { stmt; } } while (0)
+} // namespace wv
+
+#else
+// ------------------------------------------------------------------------------------------------
+// host emulation (tests/hostcheck only)
+// ------------------------------------------------------------------------------------------------
+#include <string.h>
+#define AZ_FN static inline
+#define AZ_DEVICE_BUILD 0
+
+namespace wv {
+struct vbool { bool v[64]; };
+struct vu32 {
+    u32 v[64];
+};
+struct vf64 { double v[64]; };
+
+AZ_FN vu32 splat(u32 x) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = x; return r; }
+AZ_FN vu32 lane() { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = (u32)i; return r; }
+
+#define AZ_VOP(op) \
+    AZ_FN vu32 operator op(const vu32 &a, const vu32 &b) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] op b.v[i]; return r; } \
+    AZ_FN vu32 operator op(const vu32 &a, u32 b) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] op b; return r; } \
+    AZ_FN vu32 operator op(u32 a, const vu32 &b) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = a op b.v[i]; return r; }
+AZ_VOP(+) AZ_VOP(-) AZ_VOP(*) AZ_VOP(&) AZ_VOP(|) AZ_VOP(^) AZ_VOP(<<) AZ_VOP(>>) AZ_VOP(/) AZ_VOP(%)
+#undef AZ_VOP
+#define AZ_VCMP(op) \
+    AZ_FN vbool operator op(const vu32 &a, const vu32 &b) { vbool r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] op b.v[i]; return r; } \
+    AZ_FN vbool operator op(const vu32 &a, u32 b) { vbool r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] op b; return r; }
+AZ_VCMP(==) AZ_VCMP(!=) AZ_VCMP(<) AZ_VCMP(<=) AZ_VCMP(>) AZ_VCMP(>=)
+#undef AZ_VCMP
+AZ_FN vbool operator&(const vbool &a, const vbool &b) { vbool r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] && b.v[i]; return r; }
+AZ_FN vbool operator|(const vbool &a, const vbool &b) { vbool r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] || b.v[i]; return r; }
+AZ_FN vbool operator!(const vbool &a) { vbool r; for (int i = 0; i < 64; i++) r.v[i] = !a.v[i]; return r; }
+AZ_FN vbool operator&(const vbool &a, bool b) { vbool r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] && b; return r; }
+
+AZ_FN u64  ballot(const vbool &p) { u64 m = 0; for (int i = 0; i < 64; i++) if (p.v[i]) m |= 1ull << i; return m; }
+AZ_FN u32  uni(u32 x) { return x; }
+AZ_FN u64  uni64(u64 x) { return x; }
+AZ_FN double unid(double x) { return x; }
+AZ_FN u32  readlane(const vu32 &v, u32 l) { return v.v[l & 63]; }
+AZ_FN vu32 writelane(vu32 v, u32 val, u32 l) { v.v[l & 63] = val; return v; }
+AZ_FN vu32 bperm(const vu32 &v, const vu32 &idx) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = v.v[idx.v[i] & 63]; return r; }
+AZ_FN vu32 sel(const vbool &p, const vu32 &a, const vu32 &b) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = p.v[i] ? a.v[i] : b.v[i]; return r; }
+AZ_FN vu32 sel(const vbool &p, u32 a, const vu32 &b) { return sel(p, splat(a), b); }
+AZ_FN vu32 sel(const vbool &p, const vu32 &a, u32 b) { return sel(p, a, splat(b)); }
+AZ_FN vu32 sel(const vbool &p, u32 a, u32 b) { return sel(p, splat(a), splat(b)); }
+AZ_FN vu32 mbcnt(u64 m) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = (u32)__builtin_popcountll(m & ((1ull << i) - 1)); return r; }
+AZ_FN vf64 divlanes(const vu32 &num, double den) { vf64 r; for (int i = 0; i < 64; i++) r.v[i] = (double)num.v[i] / den; return r; }
+AZ_FN double readlane_d(const vf64 &v, u32 l) { return v.v[l & 63]; }
+AZ_FN u32 popc64(u64 x) { return (u32)__builtin_popcountll(x); }
+AZ_FN u32 ctz64(u64 x) { return (u32)__builtin_ctzll(x); }
+AZ_FN u32 ctz32(u32 x) { return (u32)__builtin_ctz(x); }
+AZ_FN u32 clz32(u32 x) { return (u32)__builtin_clz(x); }
+
+AZ_FN vu32 ld_u8(const uint8_t *base, const vu32 &off, const vbool &act) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = act.v[i] ? base[off.v[i]] : 0u; return r; }
+AZ_FN void st_u8(uint8_t *base, const vu32 &off, const vu32 &val, const vbool &act) { for (int i = 0; i < 64; i++) if (act.v[i]) base[off.v[i]] = (uint8_t)val.v[i]; }
+AZ_FN vu32 ld_u32(const u32 *base, const vu32 &off, const vbool &act) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = act.v[i] ? base[off.v[i]] : 0u; return r; }
+AZ_FN void st_u32(u32 *base, const vu32 &off, const vu32 &val, const vbool &act) { for (int i = 0; i < 64; i++) if (act.v[i]) base[off.v[i]] = val.v[i]; }
+AZ_FN void st_f32(float *base, const vu32 &off, const vu32 &ival, const vbool &act) { for (int i = 0; i < 64; i++) if (act.v[i]) base[off.v[i]] = (float)(i32)ival.v[i]; }
+AZ_FN vu32 lds_ld(const u32 *lds, const vu32 &idx, const vbool &act) { return ld_u32(lds, idx, act); }
+AZ_FN void lds_st(u32 *lds, const vu32 &idx, const vu32 &val, const vbool &act)
+{
+    // all lanes read their operands before any lane writes (SIMD semantics)
+    for (int i = 0; i < 64; i++) if (act.v[i]) lds[idx.v[i]] = val.v[i];
+}
+AZ_FN u32  lds_ldu(const u32 *lds, u32 idx) { return lds[idx]; }
+AZ_FN void lds_fence() {}
+#define AZ_LANE0(stmt) do { stmt; } while (0)
+} // namespace wv
+#endif

@@ -1,0 +1,160 @@
+/*
+ * azul_hip.h -- C ABI of libazulhip.so: the MI355X (gfx950) batched Azul environment.
+ *
+ * The reference (patello/azul_deep_reinforcement_learning) has no FFI; its boundary for this path is
+ * the Python API of azulnet/azul.py and azulnet/game_runner.py.  Each entry point below is the batched
+ * (N games, one 64-lane wavefront per game) replacement of one reference function, cited per entry as
+ * file:line relative to the reference tree.  The Python mirror in azul_deep_reinforcement_learning_amd/
+ * binds these with ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - every launch is asynchronous on `stream`; pointers named *_dev are DEVICE pointers owned by the
+ *     caller (e.g. torch tensors via data_ptr()); pointers named *_host are host pointers;
+ *   - optional outputs may be NULL; `active_dev` (uint8[N], NULL = all games) selects games;
+ *   - return value: AZUL_SUCCESS or a negative AZUL_ERR_* (API misuse / HIP failure).  Per-game rule
+ *     outcomes are reported in `status_dev` (uint8[N]) -- the single-game Python facade maps them to
+ *     the reference's exceptions (IllegalMove / GameEnded, azul.py:8-15);
+ *   - there is no CPU implementation behind this ABI.
+ *
+ * Game record: 128 bytes per game, little endian, array-of-records [N][128] (one cache line per game;
+ * a wavefront reads its game with three coalesced loads):
+ *
+ *   off size field                         reference (azul.py / game_runner.py)
+ *     0  25  u8  displays[5][5]            game_board_displays            azul.py:19
+ *    25   6  u8  center[6]                 game_board_center ([5]=token)  azul.py:20,71
+ *    31   1  u8  flags                     bits0-2 current_player, bits3-5 next_first_player, bit6 end_of_game
+ *    32  50  u8  pattern_lines[2][5][5]                                   azul.py:21-22
+ *    82   2  u8  floors[2]                                                azul.py:25
+ *    84   8  u32 walls[2]                  bit 5*row+colour               azul.py:23-24
+ *    92   4  i16 score[2]                                                 azul.py:26
+ *    96   5  u8  box[5]                    box_tiles ("Lid" rule)         azul.py:51
+ *   101   5  u8  lid[5]                    lid_tiles                      azul.py:52
+ *   106   2  u16 turn_counter                                             azul.py:30
+ *   108   4  u16 first_player_stats[2]                                    azul.py:31
+ *   112   4  i16 floor_penalty[2]          (sum of the negative penalties) azul.py:32
+ *   116   2  u8  max_combo[2]                                             azul.py:33
+ *   118   6  u8  completed_lines[2][3]     0 row, 1 colour, 2 column      azul.py:58
+ *   124   2  i16 player_score              GameRunner.player_score        game_runner.py:35
+ *   126   2  u16 move_counter              GameRunner.move_counter        game_runner.py:36
+ *
+ * Random numbers: every game owns a CPython-exact MT19937 stream (624 words + index), i.e. what the
+ * reference consumes through the process-global `random` module (azul.py:37,78,87; game_runner.py:97).
+ */
+#ifndef AZUL_HIP_H
+#define AZUL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZUL_RECORD_BYTES 128
+#define AZUL_NUM_ACTIONS  180
+#define AZUL_OBS_SIZE     136
+#define AZUL_MT_WORDS     624
+#define AZUL_NUM_STATS    10
+
+/* return codes */
+#define AZUL_SUCCESS        0
+#define AZUL_ERR_INVALID   (-1)   /* bad argument */
+#define AZUL_ERR_HIP       (-2)   /* HIP runtime failure (azul_last_error_string) */
+#define AZUL_ERR_RANGE     (-3)   /* record field outside the representable domain */
+#define AZUL_ERR_RULE      (-4)   /* IllegalRule, azul.py:41,54 */
+
+/* per-game status (uint8) */
+#define AZUL_OK            0
+#define AZUL_ILLEGAL_MOVE  1      /* IllegalMove (azul.py:301-302); state untouched */
+#define AZUL_GAME_ENDED    2      /* GameEnded   (azul.py:298-299) */
+#define AZUL_STUCK         3      /* no legal move although the round is not over (SURVEY hazard H3) */
+#define AZUL_BAD_ACTION    4      /* action outside [0,180) */
+#define AZUL_BOX_EMPTY     5      /* "Lid" pool and lid both empty at a draw (reference raises) */
+
+/* rules (azul.py:35-56) */
+#define AZUL_POOL_RANDOM   0
+#define AZUL_POOL_LID      1
+#define AZUL_FIRST_RANDOM  0      /* "Random"; 1 or 2 = fixed first player */
+
+/* observation perspective (game_runner.py:56 `perspective`) */
+#define AZUL_PERSP_PLAYER0  0
+#define AZUL_PERSP_PLAYER1  1
+#define AZUL_PERSP_CURRENT  2     /* current_player - 1, as opponent_move uses (game_runner.py:38) */
+
+/* flags written by azul_batch_flags */
+#define AZUL_FLAG_END_OF_ROUND 1  /* azul.py:182-183 */
+#define AZUL_FLAG_END_OF_GAME  2  /* azul.py:184-191 (walls) */
+#define AZUL_FLAG_ENDED_FLAG   4  /* Azul.end_of_game attribute, azul.py:29 */
+
+typedef struct azul_batch azul_batch_t;
+
+const char *azul_last_error_string(void);
+const char *azul_version(void);
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+/* N two-player games on the current HIP device, rules as in Azul(rules=...) (azul.py:35-56). */
+int azul_batch_create(azul_batch_t **out, int n_games, int first_player, int tile_pool);
+int azul_batch_destroy(azul_batch_t *b);
+int azul_batch_size(const azul_batch_t *b);
+/* device pointers of the resident arrays (for zero-copy views): records [N][128] u8, MT words [N][624] u32, MT index [N] u32 */
+void *azul_batch_state_dev(azul_batch_t *b);
+void *azul_batch_mt_dev(azul_batch_t *b);
+void *azul_batch_mtpos_dev(azul_batch_t *b);
+
+/* ---- state / RNG I/O (superset of export_JSON / import_JSON, azul.py:90-117) ------------------ */
+int azul_batch_get_state(azul_batch_t *b, int first, int count, void *records_host, void *stream);
+int azul_batch_set_state(azul_batch_t *b, int first, int count, const void *records_host, void *stream);
+/* random.getstate() / random.setstate() of one game's stream: 624 words + index */
+int azul_batch_get_rng(azul_batch_t *b, int game, uint32_t *mt_host, uint32_t *pos_host, void *stream);
+int azul_batch_set_rng(azul_batch_t *b, int game, const uint32_t *mt_host, uint32_t pos, void *stream);
+/* random.seed(int) per game (CPython init_by_array): seed[g] = seeds_host[g], or seed_base + g when seeds_host is NULL */
+int azul_batch_seed(azul_batch_t *b, uint64_t seed_base, const uint64_t *seeds_host, void *stream);
+
+/* ---- rules: one entry per reference method ---------------------------------------------------- */
+int azul_batch_init(azul_batch_t *b, const uint8_t *active_dev, void *stream);                 /* Azul.__init__      azul.py:18-61  */
+int azul_batch_new_round(azul_batch_t *b, const uint8_t *active_dev, uint8_t *status_dev, void *stream);   /* new_round  azul.py:64-89  */
+int azul_batch_move(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *active_dev, void *stream); /* move (unchecked) azul.py:118-161 */
+int azul_batch_legal_mask(azul_batch_t *b, uint8_t *mask_dev /*[N][180]*/, void *stream);     /* check_all_valid    game_runner.py:113-117, azul.py:162-176 */
+int azul_batch_next_player(azul_batch_t *b, const uint8_t *active_dev, void *stream);          /* next_player        azul.py:177-181 */
+int azul_batch_flags(azul_batch_t *b, uint8_t *flags_dev /*[N]*/, void *stream);               /* is_end_of_round / is_end_of_game azul.py:182-191 */
+int azul_batch_count_score(azul_batch_t *b, const uint8_t *active_dev, void *stream);          /* count_score        azul.py:192-295 */
+int azul_batch_step(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *active_dev,
+                    uint8_t *status_dev, void *stream);                                         /* step               azul.py:296-313 */
+int azul_batch_statistics(azul_batch_t *b, double *stats_dev /*[N][10]*/, void *stream);       /* get_statistics     azul.py:314-315 */
+
+/* ---- env wrapper: GameRunner with the default RandomAgent opponent ----------------------------- */
+int azul_batch_runner_init(azul_batch_t *b, const uint8_t *active_dev, uint8_t *status_dev, void *stream);   /* GameRunner.__init__ game_runner.py:23-36 */
+int azul_batch_runner_reset(azul_batch_t *b, const uint8_t *active_dev, uint8_t *status_dev, void *stream);  /* reset               game_runner.py:76-85 */
+int azul_batch_runner_step(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *active_dev,
+                           int32_t *reward_dev, uint8_t *done_dev, uint8_t *status_dev, void *stream);       /* step                game_runner.py:43-55 */
+int azul_batch_observe(azul_batch_t *b, int perspective, float *obs_dev /*[N][136]*/, void *stream);         /* get_state           game_runner.py:56-72 */
+int azul_batch_random_action(azul_batch_t *b, const uint8_t *active_dev, int32_t *actions_dev,
+                             void *stream);                                                     /* RandomAgent.get_a_output game_runner.py:94-97 (-1: no legal move) */
+int azul_batch_score_preview(azul_batch_t *b, int32_t *potential_dev /*[N]*/, void *stream);   /* deepcopy+count_score, score[0]-score[1]  game_runner.py:48-50 */
+
+/* ---- flat random-agent self-play (the benchmarked hot path) ----------------------------------- */
+/*
+ * Advance every game by `n_steps` env moves in ONE launch: per move  mask -> RandomAgent -> Azul.step ->
+ * reward (delta of the what-if potential) -> done, with auto-reset (GameRunner.reset semantics, same
+ * stream) when a game ends.  Trajectory outputs are [n_steps][N]...; any may be NULL.
+ *   mask_dev   uint8 [n_steps][N][180]   legal moves before the move
+ *   action_dev int32 [n_steps][N]        chosen action (-1 when stuck)
+ *   reward_dev int32 [n_steps][N]
+ *   done_dev   uint8 [n_steps][N]        1 = game ended with this move, 2 = stuck (no move, reset)
+ *   rec_dev    uint8 [n_steps][N][128]   record after the move, before the auto-reset (tests only)
+ */
+int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, int32_t *action_dev,
+                        int32_t *reward_dev, uint8_t *done_dev, uint8_t *rec_dev, void *stream);
+/* per-game counters accumulated by selfplay / runner_step: episodes[N] u64, stuck[N] u32, stat sums [N][10] f64 (host copies; NULL to skip) */
+int azul_batch_counters(azul_batch_t *b, uint64_t *episodes_host, uint32_t *stuck_host, double *stat_sums_host, void *stream);
+int azul_batch_reset_counters(azul_batch_t *b, void *stream);
+
+/* average device time (ms) of the last azul_batch_selfplay launches, measured with hipEvents on the launch stream:
+ * call azul_timing_begin, launch any number of selfplay calls, then azul_timing_end (synchronises the stream). */
+int azul_timing_begin(azul_batch_t *b, void *stream);
+int azul_timing_end(azul_batch_t *b, void *stream, float *total_ms, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

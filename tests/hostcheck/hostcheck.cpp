@@ -1,0 +1,187 @@
+// hostcheck.cpp -- TEST-ONLY: compiles the device core (csrc/azul_core.hpp) with g++ against the
+// 64-lane host emulation of csrc/azul_wave.hpp, so the wave-level game logic can be diffed against the
+// oracle in the build container (no GPU).  Not part of the product; never shipped in libazulhip.so.
+#include <stdlib.h>
+#include <string.h>
+
+#include "azul_core.hpp"
+#include "azul_tables.hpp"
+
+using namespace az;
+
+static double g_T[T_ROWS * T_COLS];
+static bool g_T_ready = false;
+static const double *table()
+{
+    if (!g_T_ready) { build_weight_table(g_T); g_T_ready = true; }
+    return g_T;
+}
+
+struct HostStream {
+    uint8_t rec[128];
+    u32 mt[624];
+    u32 pos;
+    u32 lds[624];
+    u64 episodes;
+    u32 stuck;
+    double stat_sum[10];
+    Rules rules;
+};
+
+extern "C" {
+
+void hc_weight_table(double *out) { memcpy(out, table(), sizeof(g_T)); }
+
+HostStream *hc_stream_new(unsigned long long seed, int first_player, int tile_pool)
+{
+    HostStream *h = (HostStream *)calloc(1, sizeof(HostStream));
+    h->rules.first_player = (u32)first_player;
+    h->rules.tile_pool = (u32)tile_pool;
+    seed_stream(h->mt, seed);
+    h->pos = 624;
+    // GameRunner.__init__ then reset() (without pre-moves), like oz_stream_start
+    LaneConst k; lane_consts(k);
+    Game g; memset(&g, 0, sizeof(g));
+    Rng r; rng_open(r, h->mt, h->lds, h->pos);
+    episode_reset(g, h->rules, r);
+    episode_reset(g, h->rules, r);
+    game_store(g, h->rec);
+    rng_close(r, &h->pos);
+    return h;
+}
+
+void hc_stream_free(HostStream *h) { free(h); }
+
+int hc_stream_advance(HostStream *h, int n_steps, uint8_t *mask, int32_t *action, int32_t *reward, uint8_t *done, uint8_t *rec_after)
+{
+    LaneConst k; lane_consts(k);
+    Game g; game_load(g, h->rec);
+    Rng r; rng_open(r, h->mt, h->lds, h->pos);
+    Counters cnt = {&h->episodes, &h->stuck, h->stat_sum};
+    int rc = 0;
+    for (int t = 0; t < n_steps; t++) {
+        u32 f = selfplay_step(g, h->rules, k, r, table(), cnt,
+                              mask ? mask + (size_t)t * 180 : 0, action ? action + t : 0, reward ? reward + t : 0,
+                              done ? done + t : 0, rec_after ? rec_after + (size_t)t * 128 : 0);
+        if (f & 0x100u) { rc = (int)(f & 0xff); break; }
+    }
+    game_store(g, h->rec);
+    rng_close(r, &h->pos);
+    return rc;
+}
+
+void hc_stream_get(HostStream *h, uint8_t *rec, u32 *mt, u32 *pos, u64 *episodes, u32 *stuck, double *stat_sum)
+{
+    if (rec) memcpy(rec, h->rec, 128);
+    if (mt) memcpy(mt, h->mt, sizeof(h->mt));
+    if (pos) *pos = h->pos;
+    if (episodes) *episodes = h->episodes;
+    if (stuck) *stuck = h->stuck;
+    if (stat_sum) memcpy(stat_sum, h->stat_sum, sizeof(h->stat_sum));
+}
+
+void hc_seed(unsigned long long seed, u32 *mt) { seed_stream(mt, seed); }
+
+// single-record operations (record in/out, explicit MT state)
+void hc_mask(const uint8_t *rec, uint8_t *out180)
+{
+    LaneConst k; lane_consts(k);
+    Game g; game_load(g, rec);
+    Mask m; legal_mask(g, k, m);
+    mask_write(m, out180);
+}
+
+void hc_observe(const uint8_t *rec, int persp, float *out136)
+{
+    Game g; game_load(g, rec);
+    u32 p = persp == 2 ? me_index(g) : (u32)persp;
+    observe(g, p, out136);
+}
+
+int hc_potential(const uint8_t *rec, int tile_pool)
+{
+    LaneConst k; lane_consts(k);
+    Rules rules = {1, (u32)tile_pool};
+    Game g; game_load(g, rec);
+    return potential(g, rules, k);
+}
+
+int hc_flags(const uint8_t *rec)
+{
+    Game g; game_load(g, rec);
+    return (sources_board(g) == 0u ? 1 : 0) | (is_end_of_game(g) ? 2 : 0) | (g.eog ? 4 : 0);
+}
+
+void hc_count_score(uint8_t *rec, int tile_pool)
+{
+    LaneConst k; lane_consts(k);
+    Rules rules = {1, (u32)tile_pool};
+    Game g; game_load(g, rec);
+    count_score(g, rules, k);
+    game_store(g, rec);
+}
+
+void hc_move(uint8_t *rec, int action, int tile_pool)
+{
+    Rules rules = {1, (u32)tile_pool};
+    Game g; game_load(g, rec);
+    u32 d, c, row; decode_action((u32)action, d, c, row);
+    do_move(g, rules, d, c, row);
+    game_store(g, rec);
+}
+
+int hc_step(uint8_t *rec, int action, int first_player, int tile_pool, u32 *mt, u32 *pos)
+{
+    static u32 lds[624];
+    LaneConst k; lane_consts(k);
+    Rules rules = {(u32)first_player, (u32)tile_pool};
+    Game g; game_load(g, rec);
+    Rng r; rng_open(r, mt, lds, *pos);
+    u32 st = checked_step(g, rules, k, r, action);
+    if (st != ST_ILLEGAL_MOVE && st != ST_GAME_ENDED && st != ST_BAD_ACTION) game_store(g, rec);
+    rng_close(r, pos);
+    return (int)st;
+}
+
+int hc_runner_step(uint8_t *rec, int action, int first_player, int tile_pool, u32 *mt, u32 *pos, int *reward, int *done)
+{
+    static u32 lds[624];
+    LaneConst k; lane_consts(k);
+    Rules rules = {(u32)first_player, (u32)tile_pool};
+    Game g; game_load(g, rec);
+    Rng r; rng_open(r, mt, lds, *pos);
+    i32 rew = 0; u32 dn = 0;
+    u32 st = runner_step(g, rules, k, r, table(), action, rew, dn);
+    if (st != ST_ILLEGAL_MOVE && st != ST_GAME_ENDED && st != ST_BAD_ACTION) game_store(g, rec);
+    rng_close(r, pos);
+    *reward = rew; *done = (int)dn;
+    return (int)st;
+}
+
+int hc_runner_reset(uint8_t *rec, int first_player, int tile_pool, u32 *mt, u32 *pos, int ctor_only)
+{
+    static u32 lds[624];
+    LaneConst k; lane_consts(k);
+    Rules rules = {(u32)first_player, (u32)tile_pool};
+    Game g; memset(&g, 0, sizeof(g));
+    Rng r; rng_open(r, mt, lds, *pos);
+    u32 st = episode_reset(g, rules, r);
+    if (!st && !ctor_only) st = runner_opponent_loop(g, rules, k, r, table(), true);
+    game_store(g, rec);
+    rng_close(r, pos);
+    return (int)st;
+}
+
+int hc_random_action(const uint8_t *rec, u32 *mt, u32 *pos)
+{
+    static u32 lds[624];
+    LaneConst k; lane_consts(k);
+    Game g; game_load(g, rec);
+    Rng r; rng_open(r, mt, lds, *pos);
+    Mask m; legal_mask(g, k, m);
+    i32 a = random_agent(m, r, table());
+    rng_close(r, pos);
+    return a;
+}
+
+} // extern "C"

@@ -49,7 +49,7 @@ SIGNATURES = {
     "azul_batch_observe": (_i, [_vp, _i, _vp, _vp]),
     "azul_batch_random_action": (_i, [_vp, _vp, _vp, _vp]),
     "azul_batch_score_preview": (_i, [_vp, _vp, _vp]),
-    "azul_batch_selfplay": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "azul_batch_selfplay": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "azul_batch_counters": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "azul_batch_reset_counters": (_i, [_vp, _vp]),
     "azul_timing_begin": (_i, [_vp, _vp]),

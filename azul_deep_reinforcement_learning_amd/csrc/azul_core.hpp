@@ -39,32 +39,32 @@ struct Rules {
 // ------------------------------------------------------------------------------------------------
 struct Rng {
     u32 *gmt;       // this game's 624 words in global memory
-    u32 *lds;       // this wave's 624-word LDS window
+    u32 *lds;       // this wave's 624-word LDS window (staged whole when the stream is opened)
     u32 pos;        // CPython's `index` (0..624)
-    u32 loaded;     // bit k: chunk k (words 64k..64k+63) is staged in LDS
     u32 dirty;      // window differs from global memory (a twist happened)
 };
 
 AZ_FN void rng_open(Rng &r, u32 *gmt, u32 *lds, u32 pos)
 {
-    r.gmt = gmt; r.lds = lds; r.pos = pos; r.loaded = 0; r.dirty = 0;
-}
-
-AZ_FN void rng_stage(Rng &r, u32 chunk)
-{
-    vu32 i = lane() + chunk * 64u;
-    vu32 w = ld_u32(r.gmt, i, i < 624u);
-    lds_st(r.lds, i, w, i < 624u);
+    r.gmt = gmt; r.lds = lds; r.pos = pos; r.dirty = 0;
+#if AZ_DEVICE_BUILD
+#pragma unroll 1
+#endif
+    for (u32 k = 0; k < 10; k++) {                      // 10 coalesced 256-byte loads
+        vu32 i = lane() + k * 64u;
+        vu32 w = ld_u32(gmt, i, i < 624u);
+        lds_st(lds, i, w, i < 624u);
+    }
     lds_fence();
-    r.loaded |= 1u << chunk;
 }
 
 AZ_FN void rng_twist(Rng &r)
 {
     // genrand_uint32's regeneration loop; ascending 64-wide chunks are legal because element i needs
     // OLD mt[i], mt[i+1] and (i<227: OLD mt[i+397] | i>=227: NEW mt[i-227]); see DESIGN.md.
-    for (u32 k = 0; k < 10; k++)
-        if (!((r.loaded >> k) & 1u)) rng_stage(r, k);
+#if AZ_DEVICE_BUILD
+#pragma unroll 1
+#endif
     for (u32 k = 0; k < 10; k++) {
         vu32 i = lane() + k * 64u;
         vbool act = i < 624u;
@@ -84,8 +84,6 @@ AZ_FN void rng_twist(Rng &r)
 AZ_FN u32 rng_u32(Rng &r)
 {
     if (r.pos >= 624u) rng_twist(r);
-    u32 chunk = r.pos >> 6;
-    if (!((r.loaded >> chunk) & 1u)) rng_stage(r, chunk);
     u32 y = lds_ldu(r.lds, r.pos);
     r.pos += 1;
     y ^= (y >> 11);
@@ -112,6 +110,9 @@ AZ_FN u32 rng_below(Rng &r, u32 n, u32 bits)
 AZ_FN void rng_close(Rng &r, u32 *pos_out)
 {
     if (r.dirty) {
+#if AZ_DEVICE_BUILD
+#pragma unroll 1
+#endif
         for (u32 k = 0; k < 10; k++) {
             vu32 i = lane() + k * 64u;
             vu32 w = lds_ld(r.lds, i, i < 624u);
@@ -122,22 +123,23 @@ AZ_FN void rng_close(Rng &r, u32 *pos_out)
 }
 
 // ------------------------------------------------------------------------------------------------
-// game state
+// game state (all uniform fields are named scalars: no runtime-indexed arrays -> no scratch memory)
 // ------------------------------------------------------------------------------------------------
 struct Game {
     vu32 cs, cp;
-    u32 wall[2];
-    i32 score[2];
-    u32 floor_[2];
+    u32 wall0, wall1;
+    i32 score0, score1;
+    u32 floor0, floor1;
     u32 cur, nfp, eog;
     u64 box, lid;           // byte c = tiles of colour c
     u32 turn;
-    u32 fps[2];
-    i32 fpen[2];
-    u32 maxc[2];
+    u32 fps;                // lo16 = first_player_stats[0], hi16 = [1]
+    u32 fpen;               // two i16: floor_penalty[0], [1]
+    u32 maxc;               // byte0 = max_combo[0], byte1 = [1]
     u64 compl_;             // byte 3p+k = completed_lines[p][k]
     i32 pscore;             // GameRunner.player_score
     u32 moves;              // GameRunner.move_counter
+    i32 wi0, wi1;           // cached "what-if" scores of the two players (derived; see whatif_refresh)
 };
 
 struct LaneConst {
@@ -172,21 +174,22 @@ AZ_FN void game_load(Game &g, const uint8_t *rec)
     g.cur = flags & 7u; g.nfp = (flags >> 3) & 7u; g.eog = (flags >> 6) & 1u;
     g.cs = sel(l < 31u, a, splat(0u));
     g.cp = sel(l < 50u, b, splat(0u));
-    g.floor_[0] = readlane(b, 50); g.floor_[1] = readlane(b, 51);
-    g.wall[0] = readlane(t, 0); g.wall[1] = readlane(t, 1);
+    g.floor0 = readlane(b, 50); g.floor1 = readlane(b, 51);
+    g.wall0 = readlane(t, 0); g.wall1 = readlane(t, 1);
     u32 sc = readlane(t, 2);
-    g.score[0] = (i32)(int16_t)(sc & 0xffffu); g.score[1] = (i32)(int16_t)(sc >> 16);
+    g.score0 = (i32)(int16_t)(sc & 0xffffu); g.score1 = (i32)(int16_t)(sc >> 16);
     u32 w3 = readlane(t, 3), w4 = readlane(t, 4), w5 = readlane(t, 5);
     g.box = (u64)w3 | ((u64)(w4 & 0xffu) << 32);
     g.lid = (u64)(w4 >> 8) | ((u64)(w5 & 0xffffu) << 24);
     g.turn = w5 >> 16;
-    u32 w6 = readlane(t, 6), w7 = readlane(t, 7), w8 = readlane(t, 8), w9 = readlane(t, 9), w10 = readlane(t, 10);
-    g.fps[0] = w6 & 0xffffu; g.fps[1] = w6 >> 16;
-    g.fpen[0] = (i32)(int16_t)(w7 & 0xffffu); g.fpen[1] = (i32)(int16_t)(w7 >> 16);
-    g.maxc[0] = w8 & 0xffu; g.maxc[1] = (w8 >> 8) & 0xffu;
+    g.fps = readlane(t, 6);
+    g.fpen = readlane(t, 7);
+    u32 w8 = readlane(t, 8), w9 = readlane(t, 9), w10 = readlane(t, 10);
+    g.maxc = w8 & 0xffffu;
     g.compl_ = (u64)(w8 >> 16) | ((u64)w9 << 16);
     g.pscore = (i32)(int16_t)(w10 & 0xffffu);
     g.moves = w10 >> 16;
+    g.wi0 = g.wi1 = 0;
 }
 
 AZ_FN void game_store(const Game &g, uint8_t *rec)
@@ -195,25 +198,25 @@ AZ_FN void game_store(const Game &g, uint8_t *rec)
     u32 flags = (g.cur & 7u) | ((g.nfp & 7u) << 3) | ((g.eog & 1u) << 6);
     vu32 a = writelane(g.cs, flags, 31);
     st_u8(rec, l, a, l < 32u);
-    vu32 b = writelane(writelane(g.cp, g.floor_[0], 50), g.floor_[1], 51);
+    vu32 b = writelane(writelane(g.cp, g.floor0, 50), g.floor1, 51);
     st_u8(rec + 32, l, b, l < 52u);
     vu32 t = splat(0u);
-    t = writelane(t, g.wall[0], 0);
-    t = writelane(t, g.wall[1], 1);
-    t = writelane(t, ((u32)g.score[0] & 0xffffu) | ((u32)g.score[1] << 16), 2);
+    t = writelane(t, g.wall0, 0);
+    t = writelane(t, g.wall1, 1);
+    t = writelane(t, ((u32)g.score0 & 0xffffu) | ((u32)g.score1 << 16), 2);
     t = writelane(t, (u32)g.box, 3);
     t = writelane(t, (u32)((g.box >> 32) & 0xffu) | ((u32)g.lid << 8), 4);
     t = writelane(t, (u32)((g.lid >> 24) & 0xffffu) | (g.turn << 16), 5);
-    t = writelane(t, (g.fps[0] & 0xffffu) | (g.fps[1] << 16), 6);
-    t = writelane(t, ((u32)g.fpen[0] & 0xffffu) | ((u32)g.fpen[1] << 16), 7);
-    t = writelane(t, (g.maxc[0] & 0xffu) | ((g.maxc[1] & 0xffu) << 8) | ((u32)(g.compl_ & 0xffffu) << 16), 8);
+    t = writelane(t, g.fps, 6);
+    t = writelane(t, g.fpen, 7);
+    t = writelane(t, (g.maxc & 0xffffu) | ((u32)(g.compl_ & 0xffffu) << 16), 8);
     t = writelane(t, (u32)(g.compl_ >> 16), 9);
     t = writelane(t, ((u32)g.pscore & 0xffffu) | (g.moves << 16), 10);
     st_u32((u32 *)(rec + 84), l, t, l < 11u);
 }
 
 // ---- legal-move mask: azul.py:162-176 over all 180 actions (game_runner.py:113-117) ----
-struct Mask { u64 m[3]; };   // bit (a & 63) of m[a >> 6]
+struct Mask { u64 m0, m1, m2; };   // action a: bit (a & 63) of word (a >> 6)
 
 AZ_FN u32 sources_board(const Game &g) { return (u32)ballot(g.cs != 0u) & 0x7fffffffu; }
 
@@ -223,7 +226,7 @@ AZ_FN void legal_mask(const Game &g, const LaneConst &k, Mask &out)
     u64 PL = ballot(g.cp != 0u);
     u32 me = me_index(g);
     u32 pme = (u32)(PL >> (25u * me)) & 0x1ffffffu;
-    u32 wl = g.wall[me];
+    u32 wl = me ? g.wall1 : g.wall0;
     u32 ok = 0x80000000u;                            // bit 31: "floor row" accepts everything
     for (u32 r = 0; r < 5; r++) {
         u32 rb = (pme >> (5u * r)) & 31u;              // colours already lying on row r
@@ -231,22 +234,34 @@ AZ_FN void legal_mask(const Game &g, const LaneConst &k, Mask &out)
         okr &= ~(wl >> (5u * r)) & 31u;                // azul.py:174
         ok |= okr << (5u * r);
     }
-    for (u32 w = 0; w < 3; w++)
-        out.m[w] = ballot((((B >> (k.spos[w] & 31u)) & (ok >> (k.okpos[w] & 31u))) & 1u) != 0u);
+    out.m0 = ballot((((B >> (k.spos[0] & 31u)) & (ok >> (k.okpos[0] & 31u))) & 1u) != 0u);
+    out.m1 = ballot((((B >> (k.spos[1] & 31u)) & (ok >> (k.okpos[1] & 31u))) & 1u) != 0u);
+    out.m2 = ballot((((B >> (k.spos[2] & 31u)) & (ok >> (k.okpos[2] & 31u))) & 1u) != 0u);
 }
 
-AZ_FN u32 mask_test(const Mask &m, u32 a) { return (u32)(m.m[a >> 6] >> (a & 63u)) & 1u; }
-AZ_FN u32 mask_count(const Mask &m) { return popc64(m.m[0]) + popc64(m.m[1]) + popc64(m.m[2]); }
+AZ_FN u64 mask_word(const Mask &m, u32 w) { return w == 0u ? m.m0 : (w == 1u ? m.m1 : m.m2); }
+AZ_FN u32 mask_test(const Mask &m, u32 a) { return (u32)(mask_word(m, a >> 6) >> (a & 63u)) & 1u; }
+AZ_FN u32 mask_count(const Mask &m) { return popc64(m.m0) + popc64(m.m1) + popc64(m.m2); }
+
+AZ_FN vu32 lane_bit(u64 m)
+{
+    vu32 l = lane();
+    u32 lo = (u32)m, hi = (u32)(m >> 32);
+    return sel(l < 32u, (lo >> (l & 31u)) & 1u, (hi >> (l & 31u)) & 1u);
+}
 
 AZ_FN void mask_write(const Mask &m, uint8_t *out)
 {
     vu32 l = lane();
-    for (u32 w = 0; w < 3; w++) {
-        vu32 a = l + w * 64u;
-        u32 lo = (u32)m.m[w], hi = (u32)(m.m[w] >> 32);
-        vu32 v = sel(l < 32u, (lo >> (l & 31u)) & 1u, (hi >> (l & 31u)) & 1u);
-        st_u8(out, a, v, a < 180u);
-    }
+    st_u8(out, l, lane_bit(m.m0), l < 64u);
+    st_u8(out, l + 64u, lane_bit(m.m1), l < 64u);
+    st_u8(out, l + 128u, lane_bit(m.m2), l < 52u);
+}
+
+AZ_FN void mask_write_bits(const Mask &m, u64 *out)
+{
+    // bit-packed form (24 bytes per game): what the multi-GPU trajectory all-gather ships
+    AZ_LANE0(out[0] = m.m0; out[1] = m.m1; out[2] = m.m2);
 }
 
 // ---- RandomAgent: game_runner.py:87-97 + random.choices (random.py:506-541) ----
@@ -256,8 +271,8 @@ AZ_FN double tseq(const double *T, u32 J, u32 k) { return (k <= J) ? T[k * T_COL
 
 AZ_FN i32 random_agent(const Mask &m, Rng &r, const double *T)
 {
-    u32 c0 = popc64(m.m[0]), c1 = popc64(m.m[1]), c2 = popc64(m.m[2]);
-    u32 J = popc64(m.m[0] & 0x3fffffffull);           // legal floor moves (a < 30, weight 0.01)
+    u32 c0 = popc64(m.m0), c1 = popc64(m.m1), c2 = popc64(m.m2);
+    u32 J = popc64(m.m0 & 0x3fffffffull);             // legal floor moves (a < 30, weight 0.01)
     u32 L = c0 + c1 + c2;
     if (L == 0u) return -1;                            // ValueError in the reference, raised before random()
     double total = tseq(T, J, L) + 0.0;
@@ -277,24 +292,23 @@ AZ_FN i32 random_agent(const Mask &m, Rng &r, const double *T)
     if (kg <= c0) { w = 0; rank = kg - 1u; }
     else if (kg <= c0 + c1) { w = 1; rank = kg - 1u - c0; }
     else { w = 2; rank = kg - 1u - c0 - c1; }
-    u64 mw = m.m[w];
-    vu32 l = lane();
-    u32 lo = (u32)mw, hi = (u32)(mw >> 32);
-    vu32 bit = sel(l < 32u, (lo >> (l & 31u)) & 1u, (hi >> (l & 31u)) & 1u);
-    u64 hit = ballot((bit != 0u) & (mbcnt(mw) == rank));
+    u64 mw = mask_word(m, w);
+    u64 hit = ballot((lane_bit(mw) != 0u) & (mbcnt(mw) == rank));
     return (i32)(w * 64u + ctz64(hit));
 }
 
 // ---- move: azul.py:118-161 ----
 AZ_FN void add_to_floor(Game &g, u32 p, u32 n)
 {
-    u32 f = g.floor_[p] + n;                           // azul.py:119-123
-    g.floor_[p] = (f < 7u) ? f : 7u;
+    u32 f = (p ? g.floor1 : g.floor0) + n;              // azul.py:119-123
+    f = (f < 7u) ? f : 7u;
+    if (p) g.floor1 = f; else g.floor0 = f;
 }
 
 AZ_FN void byte_add(u64 &v, u32 idx, u32 n) { v += (u64)n << (8u * idx); }
 
-AZ_FN void do_move(Game &g, const Rules &rules, u32 d, u32 c, u32 row)
+template <bool LID>
+AZ_FN void do_move(Game &g, u32 d, u32 c, u32 row)
 {
     u32 me = me_index(g);
     vu32 l = lane();
@@ -324,11 +338,11 @@ AZ_FN void do_move(Game &g, const Rules &rules, u32 d, u32 c, u32 row)
         } else {
             g.cp = writelane(g.cp, row, cell);                         // :152
             add_to_floor(g, me, (u32)(-overflow));                     // :154
-            if (rules.tile_pool == POOL_LID) byte_add(g.lid, c, (u32)(-overflow));   // :156-157
+            if (LID) byte_add(g.lid, c, (u32)(-overflow));             // :156-157
         }
     } else {
         add_to_floor(g, me, n);                                        // :159
-        if (rules.tile_pool == POOL_LID) byte_add(g.lid, c, n);        // :160-161
+        if (LID) byte_add(g.lid, c, n);                                // :160-161
     }
 }
 
@@ -359,20 +373,22 @@ AZ_FN u32 column_board(u32 col)
 
 AZ_FN bool any_row_full(u32 w) { return ((w & (w >> 1) & (w >> 2) & (w >> 3) & (w >> 4)) & 0x108421u) != 0u; }
 
-AZ_FN bool is_end_of_game(const Game &g) { return any_row_full(g.wall[0]) || any_row_full(g.wall[1]); }   // azul.py:184-191
+AZ_FN bool is_end_of_game(const Game &g) { return any_row_full(g.wall0) || any_row_full(g.wall1); }   // azul.py:184-191
 
 AZ_FN u64 full_lines(const Game &g, const LaneConst &k) { return ballot(g.cp == k.rowp1); }              // azul.py:216
 
-template <bool REAL>
-AZ_FN i32 score_player(Game &g, const Rules &rules, u32 p, u64 F)
+// one player's count_floor + count_wall; REAL commits walls/score/statistics, otherwise only the score is returned
+template <bool REAL, bool LID, u32 P>
+AZ_FN i32 score_player(Game &g, u64 F)
 {
     // count_floor (azul.py:200-210): 0,-1,-2,-4,-6,-8,-11,-14
-    u32 f = g.floor_[p] > 7u ? 7u : g.floor_[p];
+    u32 f0 = P ? g.floor1 : g.floor0;
+    u32 f = f0 > 7u ? 7u : f0;
     i32 pen = -(i32)((0x0e0b080604020100ull >> (8u * f)) & 0xffu);
-    u32 fp = (u32)(F >> (25u * p)) & 0x1ffffffu;
-    u32 w = g.wall[p];
+    u32 fp = (u32)(F >> (25u * P)) & 0x1ffffffu;
+    u32 w = P ? g.wall1 : g.wall0;
     i32 cnt = 0;
-    u32 mc = g.maxc[p];
+    u32 mc = (g.maxc >> (8u * P)) & 0xffu;
     u64 cl = g.compl_;
     u64 lid = g.lid;
     while (fp) {                                         // ascending (row, colour) == azul.py:213-214
@@ -380,7 +396,7 @@ AZ_FN i32 score_player(Game &g, const Rules &rules, u32 p, u64 F)
         fp &= fp - 1u;
         u32 r = (i * 205u) >> 10, c = i - 5u * r;
         w |= 1u << i;                                    // :219
-        if (rules.tile_pool == POOL_LID) byte_add(lid, c, r);     // :220-222
+        if (LID) byte_add(lid, c, r);                    // :220-222
         u32 col = c + r; if (col >= 5u) col -= 5u;       // to_wall_position
         u32 rowbits = (w >> (5u * r)) & 31u;
         u32 h = ((rowbits << r) | (rowbits >> (5u - r))) & 31u;   // row r in board-column order
@@ -392,55 +408,70 @@ AZ_FN i32 score_player(Game &g, const Rules &rules, u32 p, u64 F)
         u32 pos = (hr == 1u && vr == 1u) ? 1u : ((hr > 1u && vr > 1u) ? hr + vr : hr + vr - 1u);   // :258-263
         if (pos > mc) mc = pos;                          // :264
         u32 bonus = 0;
-        if (rowbits == 31u) { bonus += 2u; cl += 1ull << (8u * (3u * p + 0u)); }                    // :266-272
-        if (((w >> c) & 0x108421u) == 0x108421u) { bonus += 10u; cl += 1ull << (8u * (3u * p + 1u)); }   // :274-280
-        if (v == 31u) { bonus += 7u; cl += 1ull << (8u * (3u * p + 2u)); }                          // :282-288
+        if (rowbits == 31u) { bonus += 2u; cl += 1ull << (8u * (3u * P + 0u)); }                    // :266-272
+        if (((w >> c) & 0x108421u) == 0x108421u) { bonus += 10u; cl += 1ull << (8u * (3u * P + 1u)); }   // :274-280
+        if (v == 31u) { bonus += 7u; cl += 1ull << (8u * (3u * P + 2u)); }                          // :282-288
         cnt += (i32)(pos + bonus);
     }
-    i32 s = g.score[p] + pen + cnt;                      // :292
+    i32 s = (P ? g.score1 : g.score0) + pen + cnt;       // :292
     if (s < 0) s = 0;                                    // :294-295
     if (REAL) {
-        g.score[p] = s;
-        g.fpen[p] += pen;                                // :208
-        g.floor_[p] = 0;                                 // :209
-        g.wall[p] = w;
-        g.maxc[p] = mc;
+        if (P) { g.score1 = s; g.floor1 = 0; g.wall1 = w; }       // :209
+        else { g.score0 = s; g.floor0 = 0; g.wall0 = w; }
+        u32 old = (g.fpen >> (16u * P)) & 0xffffu;                // :208
+        g.fpen = (g.fpen & ~(0xffffu << (16u * P))) | ((((u32)((i32)(int16_t)old + pen)) & 0xffffu) << (16u * P));
+        g.maxc = (g.maxc & ~(0xffu << (8u * P))) | (mc << (8u * P));
         g.compl_ = cl;
         g.lid = lid;
     }
     return s;
 }
 
-AZ_FN void count_score(Game &g, const Rules &rules, const LaneConst &k)
+template <bool LID>
+AZ_FN void count_score(Game &g, const LaneConst &k)
 {
     u64 F = full_lines(g, k);
-    score_player<true>(g, rules, 0, F);
-    score_player<true>(g, rules, 1, F);
+    g.wi0 = score_player<true, LID, 0>(g, F);
+    g.wi1 = score_player<true, LID, 1>(g, F);
     g.cp = sel(g.cp == k.rowp1, splat(0u), g.cp);        // :218
 }
 
-AZ_FN i32 potential(Game &g, const Rules &rules, const LaneConst &k)
+// what-if scores (game_runner.py:48-50: deepcopy + count_score).  A move only changes the MOVER's pattern
+// lines and floor, so the other player's cached value stays valid; real scoring leaves what-if == score.
+template <bool LID>
+AZ_FN void whatif_refresh(Game &g, const LaneConst &k, u32 which /* 0, 1, or 2 = both */)
 {
-    // game_runner.py:48-50: score difference "as if the round were scored now", state untouched
     u64 F = full_lines(g, k);
-    return score_player<false>(g, rules, 0, F) - score_player<false>(g, rules, 1, F);
+    if (which != 1u) g.wi0 = score_player<false, LID, 0>(g, F);
+    if (which != 0u) g.wi1 = score_player<false, LID, 1>(g, F);
+}
+
+template <bool LID>
+AZ_FN i32 potential(Game &g, const LaneConst &k)
+{
+    whatif_refresh<LID>(g, k, 2u);
+    return g.wi0 - g.wi1;
 }
 
 // ---- new_round: azul.py:64-89 ----
 AZ_FN u32 byte_sum5(u64 v) { return (u32)(((v & 0xffffffffffull) * 0x0101010101ull) >> 32) & 0xffu; }
 
-AZ_FN u32 new_round(Game &g, const Rules &rules, Rng &r)
+template <bool LID>
+AZ_FN u32 new_round(Game &g, Rng &r)
 {
     g.cur = g.nfp;
-    g.fps[g.nfp == 0u ? 1u : g.nfp - 1u] += 1u;          // :67 (numpy [-1] when nfp == 0)
+    g.fps += (g.nfp == 1u) ? 1u : 0x10000u;              // :67 (numpy [-1] == player 2 when nfp == 0)
     g.turn += 1u;
     g.nfp = 0;
     vu32 l = lane();
     g.cs = sel(l == 30u, splat(1u), splat(0u));          // :71,:73
+#if AZ_DEVICE_BUILD
+#pragma unroll 1
+#endif
     for (u32 t = 0; t < 20u; t++) {
         u32 disp = t >> 2;
         u32 color;
-        if (rules.tile_pool == POOL_RANDOM) {
+        if (!LID) {
             color = rng_below(r, 5u, 3u);                // :78 randrange(0,5,1)
         } else {
             if (byte_sum5(g.box) == 0u) { g.box = g.lid; g.lid = 0; }     // :81-83
@@ -465,22 +496,25 @@ AZ_FN u32 new_round(Game &g, const Rules &rules, Rng &r)
 }
 
 // ---- Azul.__init__ + GameRunner reset bookkeeping: azul.py:18-61, game_runner.py:76-82 ----
-AZ_FN void game_ctor(Game &g, const Rules &rules, Rng &r)
+template <bool LID>
+AZ_FN void game_ctor(Game &g, u32 first_player, Rng &r)
 {
     g.cs = splat(0u); g.cp = splat(0u);
-    g.wall[0] = g.wall[1] = 0; g.score[0] = g.score[1] = 0; g.floor_[0] = g.floor_[1] = 0;
+    g.wall0 = g.wall1 = 0; g.score0 = g.score1 = 0; g.floor0 = g.floor1 = 0;
     g.cur = 0; g.eog = 0; g.turn = 0;
-    g.fps[0] = g.fps[1] = 0; g.fpen[0] = g.fpen[1] = 0; g.maxc[0] = g.maxc[1] = 0; g.compl_ = 0;
-    if (rules.first_player == 0u) g.nfp = 1u + rng_below(r, 2u, 2u);     // random.choice([1,2]) (:37)
-    else g.nfp = rules.first_player;
-    if (rules.tile_pool == POOL_LID) { g.box = 0x1414141414ull; g.lid = 0; }   // :51-52
+    g.fps = 0; g.fpen = 0; g.maxc = 0; g.compl_ = 0;
+    g.wi0 = g.wi1 = 0;
+    if (first_player == 0u) g.nfp = 1u + rng_below(r, 2u, 2u);           // random.choice([1,2]) (:37)
+    else g.nfp = first_player;
+    if (LID) { g.box = 0x1414141414ull; g.lid = 0; }                      // :51-52
     else { g.box = 0; g.lid = 0; }
 }
 
-AZ_FN u32 episode_reset(Game &g, const Rules &rules, Rng &r)
+template <bool LID>
+AZ_FN u32 episode_reset(Game &g, u32 first_player, Rng &r)
 {
-    game_ctor(g, rules, r);
-    u32 st = new_round(g, rules, r);
+    game_ctor<LID>(g, first_player, r);
+    u32 st = new_round<LID>(g, r);
     g.pscore = 0;
     g.moves = 0;
     return st;
@@ -492,34 +526,49 @@ AZ_FN void decode_action(u32 a, u32 &d, u32 &c, u32 &row)
     d = a % 6u; c = (a / 6u) % 5u; row = a / 30u;       // game_runner.py:107-111
 }
 
-AZ_FN u32 apply_step(Game &g, const Rules &rules, const LaneConst &k, Rng &r, u32 a)
+// move + end-of-round bookkeeping; returns true when a new round has to be dealt (azul.py:304-313)
+template <bool LID>
+AZ_FN bool move_and_score(Game &g, const LaneConst &k, u32 a)
 {
     u32 d, c, row;
     decode_action(a, d, c, row);
-    do_move(g, rules, d, c, row);                        // :304
+    u32 me = me_index(g);
+    do_move<LID>(g, d, c, row);                          // :304
     if (sources_board(g) == 0u) {                        // :306 (the token counts)
-        count_score(g, rules, k);                        // :307
-        if (is_end_of_game(g)) g.eog = 1;                // :308-309
-        else return new_round(g, rules, r);              // :311
-    } else {
-        g.cur = (g.cur < 2u) ? g.cur + 1u : 1u;          // :313 next_player
+        count_score<LID>(g, k);                          // :307
+        if (is_end_of_game(g)) { g.eog = 1; return false; }   // :308-309
+        return true;                                     // :311
     }
+    whatif_refresh<LID>(g, k, me);
+    g.cur = (g.cur < 2u) ? g.cur + 1u : 1u;              // :313 next_player
+    return false;
+}
+
+template <bool LID>
+AZ_FN u32 apply_step(Game &g, const LaneConst &k, Rng &r, u32 a)
+{
+    if (move_and_score<LID>(g, k, a)) return new_round<LID>(g, r);
     return ST_OK;
 }
 
-AZ_FN u32 checked_step(Game &g, const Rules &rules, const LaneConst &k, Rng &r, i32 a)
+template <bool LID>
+AZ_FN u32 checked_step(Game &g, const LaneConst &k, Rng &r, i32 a)
 {
     if (g.eog) return ST_GAME_ENDED;                     // :298-299
     if (a < 0 || a >= 180) return ST_BAD_ACTION;
     Mask m;
     legal_mask(g, k, m);
     if (!mask_test(m, (u32)a)) return ST_ILLEGAL_MOVE;   // :301-302, state untouched
-    return apply_step(g, rules, k, r, (u32)a);
+    return apply_step<LID>(g, k, r, (u32)a);
 }
 
 // ---- GameRunner.step with the default RandomAgent opponent: game_runner.py:43-55 ----
-AZ_FN u32 runner_opponent_loop(Game &g, const Rules &rules, const LaneConst &k, Rng &r, const double *T, bool until_player1_only)
+template <bool LID>
+AZ_FN u32 runner_opponent_loop(Game &g, const LaneConst &k, Rng &r, const double *T, bool until_player1_only)
 {
+#if AZ_DEVICE_BUILD
+#pragma unroll 1
+#endif
     for (u32 guard = 0; guard < 4096u; guard++) {
         Mask m;
         legal_mask(g, k, m);
@@ -529,23 +578,24 @@ AZ_FN u32 runner_opponent_loop(Game &g, const Rules &rules, const LaneConst &k, 
         i32 a = random_agent(m, r, T);                   // opponent_move, :37-42
         if (a < 0) return ST_STUCK;
         if (g.eog) return ST_GAME_ENDED;
-        u32 st = apply_step(g, rules, k, r, (u32)a);
+        u32 st = apply_step<LID>(g, k, r, (u32)a);
         if (st) return st;
         g.moves += 1u;
     }
     return ST_OK;
 }
 
-AZ_FN u32 runner_step(Game &g, const Rules &rules, const LaneConst &k, Rng &r, const double *T, i32 a, i32 &reward, u32 &done)
+template <bool LID>
+AZ_FN u32 runner_step(Game &g, const LaneConst &k, Rng &r, const double *T, i32 a, i32 &reward, u32 &done)
 {
     reward = 0;
     done = is_end_of_game(g) ? 1u : 0u;
-    u32 st = checked_step(g, rules, k, r, a);            // :44
+    u32 st = checked_step<LID>(g, k, r, a);              // :44
     if (st) return st;
     g.moves += 1u;                                       // :45
-    st = runner_opponent_loop(g, rules, k, r, T, false); // :46-47
+    st = runner_opponent_loop<LID>(g, k, r, T, false);   // :46-47
     if (st) return st;
-    i32 phi = potential(g, rules, k);                    // :48-50
+    i32 phi = potential<LID>(g, k);                      // :48-50
     reward = phi - g.pscore;                             // :51
     g.pscore = phi;                                      // :52
     done = is_end_of_game(g) ? 1u : 0u;                  // :55
@@ -558,6 +608,9 @@ AZ_FN void observe(const Game &g, u32 persp, float *out)
     vu32 l = lane();
     u32 o0 = persp & 1u, o1 = o0 ^ 1u;
     u32 pnfp = g.nfp > 0u ? (((g.nfp - 1u - o0) & 1u) + 1u) : 0u;     // :58-61
+    u32 wall_a = o0 ? g.wall1 : g.wall0, wall_b = o0 ? g.wall0 : g.wall1;
+    u32 floor_a = o0 ? g.floor1 : g.floor0, floor_b = o0 ? g.floor0 : g.floor1;
+    i32 score_a = o0 ? g.score1 : g.score0, score_b = o0 ? g.score0 : g.score1;
     // j = 0..63: displays+centre (cs lanes 0..30), then pattern_lines[order]
     {
         vu32 j = l;
@@ -572,57 +625,63 @@ AZ_FN void observe(const Game &g, u32 persp, float *out)
         vu32 pc = j - 56u;                                             // cell of order[1] for j <= 80
         vu32 pv = bperm(g.cp, pc + 25u * o1);
         vu32 wb = j - 81u;                                             // wall bit index 0..46 (two boards of 25)
-        vu32 wsel = sel(wb < 25u, splat(g.wall[o0]), splat(g.wall[o1]));
+        vu32 wsel = sel(wb < 25u, splat(wall_a), splat(wall_b));
         vu32 wv_ = (wsel >> (sel(wb < 25u, wb, wb - 25u) & 31u)) & 1u;
         st_f32(out, j, sel(j <= 80u, pv, wv_), j < 128u);
     }
     // j = 128..135: last three wall bits of order[1], floors, scores, next first player
     {
         vu32 j = l + 128u;
-        vu32 v = (g.wall[o1] >> ((l + 22u) & 31u)) & 1u;
-        v = sel(l == 3u, splat(g.floor_[o0]), v);
-        v = sel(l == 4u, splat(g.floor_[o1]), v);
-        v = sel(l == 5u, splat((u32)g.score[o0]), v);
-        v = sel(l == 6u, splat((u32)g.score[o1]), v);
+        vu32 v = (wall_b >> ((l + 22u) & 31u)) & 1u;
+        v = sel(l == 3u, splat(floor_a), v);
+        v = sel(l == 4u, splat(floor_b), v);
+        v = sel(l == 5u, splat((u32)score_a), v);
+        v = sel(l == 6u, splat((u32)score_b), v);
         v = sel(l == 7u, splat(pnfp), v);
         st_f32(out, j, v, l < 8u);
     }
 }
 
 // ---- get_statistics: azul.py:314-315 (ten values per finished game, key order of game_runner.py:12) ----
-AZ_FN void game_statistics(const Game &g, double out[10])
+AZ_FN double game_stat(const Game &g, u32 q)
 {
-    out[0] = (double)g.score[0];
-    out[1] = (double)g.score[1];
-    out[2] = (double)g.turn;
-    out[3] = (double)g.fps[0] / ((double)g.fps[0] + (double)g.fps[1]) * 100;
-    out[4] = -(double)g.fpen[0];
-    out[5] = (double)g.maxc[0];
-    out[6] = (double)(g.compl_ & 0xffu);
-    out[7] = (double)((g.compl_ >> 16) & 0xffu);
-    out[8] = (double)((g.compl_ >> 8) & 0xffu);
-    out[9] = g.score[0] > g.score[1] ? 1.0 : 0.0;
+    double f0 = (double)(g.fps & 0xffffu), f1 = (double)(g.fps >> 16);
+    switch (q) {
+    case 0: return (double)g.score0;
+    case 1: return (double)g.score1;
+    case 2: return (double)g.turn;
+    case 3: return f0 / (f0 + f1) * 100;
+    case 4: return -(double)(i32)(int16_t)(g.fpen & 0xffffu);
+    case 5: return (double)(g.maxc & 0xffu);
+    case 6: return (double)(g.compl_ & 0xffu);
+    case 7: return (double)((g.compl_ >> 16) & 0xffu);
+    case 8: return (double)((g.compl_ >> 8) & 0xffu);
+    default: return g.score0 > g.score1 ? 1.0 : 0.0;
+    }
 }
 
 // ---- random.seed(int): CPython init_by_array over the 32-bit words of the seed (one stream per THREAD) ----
 AZ_FN void seed_stream(u32 *mt, u64 seed)
 {
-    u32 key[2] = {(u32)(seed & 0xffffffffu), (u32)(seed >> 32)};
-    u32 len = key[1] ? 2u : 1u;
+    u32 key0 = (u32)(seed & 0xffffffffu), key1 = (u32)(seed >> 32);
+    u32 len = key1 ? 2u : 1u;
     u32 prev = 19650218u;
     mt[0] = prev;
     for (u32 i = 1; i < 624u; i++) { prev = 1812433253u * (prev ^ (prev >> 30)) + i; mt[i] = prev; }   // init_genrand
     u32 i = 1, j = 0;
+    prev = mt[0];
     for (u32 k = 624u; k; k--) {
-        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + j;
+        prev = (mt[i] ^ ((prev ^ (prev >> 30)) * 1664525u)) + (j ? key1 : key0) + j;
+        mt[i] = prev;
         i++; j++;
-        if (i >= 624u) { mt[0] = mt[623]; i = 1; }
+        if (i >= 624u) { mt[0] = prev; i = 1; }
         if (j >= len) j = 0;
     }
     for (u32 k = 623u; k; k--) {
-        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - i;
+        prev = (mt[i] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - i;
+        mt[i] = prev;
         i++;
-        if (i >= 624u) { mt[0] = mt[623]; i = 1; }
+        if (i >= 624u) { mt[0] = prev; i = 1; }
     }
     mt[0] = 0x80000000u;
 }
@@ -634,43 +693,56 @@ struct Counters {
     double *stat_sum;   // [10] get_statistics() summed over finished games
 };
 
-// returns 0 = move played, 1 = game ended with this move, 2 = stuck, 0x100|status on a rule error
-AZ_FN u32 selfplay_step(Game &g, const Rules &rules, const LaneConst &k, Rng &r, const double *T, const Counters &cnt,
-                        uint8_t *mask_out, i32 *action_out, i32 *reward_out, uint8_t *done_out, uint8_t *rec_out)
+// returns 0 = move played, 1 = game ended with this move, 2 = stuck, 0x100|status on a rule error.
+// Control flow keeps ONE copy of every heavy block (ctor, new_round) in the instruction stream.
+template <bool LID>
+AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, const double *T, const Counters &cnt,
+                        uint8_t *mask_out, u64 *maskbits_out, i32 *action_out, i32 *reward_out, uint8_t *done_out, uint8_t *rec_out)
 {
     Mask m;
     legal_mask(g, k, m);
     if (mask_out) mask_write(m, mask_out);
+    if (maskbits_out) mask_write_bits(m, maskbits_out);
     i32 a = g.eog ? -2 : random_agent(m, r, T);
-    if (a < 0) {
-        // stuck (or handed an already finished game): report, then start the next episode
-        if (action_out) AZ_LANE0(*action_out = -1);
-        if (reward_out) AZ_LANE0(*reward_out = 0);
-        if (done_out) AZ_LANE0(*done_out = 2);
+    bool deal = false;                 // a new round has to be dealt
+    if (a >= 0) {
+        deal = move_and_score<LID>(g, k, (u32)a);
+        g.moves += 1u;
+    }
+    u32 result = 0, st = ST_OK;
+#if AZ_DEVICE_BUILD
+#pragma unroll 1
+#endif
+    for (u32 pass = 0; pass < 2u; pass++) {
+        if (deal) { st = new_round<LID>(g, r); deal = false; if (st) break; }
+        if (pass == 1u) break;
+        i32 reward = 0;
+        u32 dn;
+        if (a >= 0) {
+            i32 phi = g.wi0 - g.wi1;
+            reward = phi - g.pscore;
+            g.pscore = phi;
+            dn = is_end_of_game(g) ? 1u : 0u;
+        } else {
+            dn = 2u;                   // stuck (or handed an already finished game): report, restart the slot
+            AZ_LANE0(*cnt.stuck += 1u);
+        }
+        if (action_out) AZ_LANE0(*action_out = (a >= 0 ? a : -1));
+        if (reward_out) AZ_LANE0(*reward_out = reward);
+        if (done_out) AZ_LANE0(*done_out = (uint8_t)dn);
         if (rec_out) game_store(g, rec_out);
-        AZ_LANE0(*cnt.stuck += 1u);
-        u32 st = episode_reset(g, rules, r);
-        return st ? (0x100u | st) : 2u;
+        result = dn;
+        if (dn == 0u) break;
+        if (dn == 1u) {
+            for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(cnt.stat_sum[q] += sv); }
+            AZ_LANE0(*cnt.episodes += 1ull);
+        }
+        game_ctor<LID>(g, first_player, r);               // GameRunner.reset(): Azul(rules) ... new_round()
+        g.pscore = 0;
+        g.moves = 0;
+        deal = true;
     }
-    u32 st = apply_step(g, rules, k, r, (u32)a);
-    g.moves += 1u;
-    i32 phi = potential(g, rules, k);
-    i32 reward = phi - g.pscore;
-    g.pscore = phi;
-    u32 dn = is_end_of_game(g) ? 1u : 0u;
-    if (action_out) AZ_LANE0(*action_out = a);
-    if (reward_out) AZ_LANE0(*reward_out = reward);
-    if (done_out) AZ_LANE0(*done_out = (uint8_t)dn);
-    if (rec_out) game_store(g, rec_out);
-    if (st) return 0x100u | st;
-    if (dn) {
-        double s[10];
-        game_statistics(g, s);
-        AZ_LANE0(for (int q = 0; q < 10; q++) cnt.stat_sum[q] += s[q]; *cnt.episodes += 1ull);
-        st = episode_reset(g, rules, r);
-        if (st) return 0x100u | st;
-    }
-    return dn;
+    return st ? (0x100u | st) : result;
 }
 
 } // namespace az

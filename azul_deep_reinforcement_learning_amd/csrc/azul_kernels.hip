@@ -69,6 +69,13 @@ __global__ void __launch_bounds__(64) azul_seed_kernel(BatchDev b, u64 seed_base
     b.mtpos[g] = 624u;
 }
 
+static __device__ __forceinline__ bool op_needs_rng(int op)
+{
+    return op == OP_INIT || op == OP_NEW_ROUND || op == OP_STEP || op == OP_RUNNER_INIT || op == OP_RUNNER_RESET ||
+           op == OP_RUNNER_STEP || op == OP_RANDOM_ACTION;
+}
+
+template <bool LID>
 __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
 {
     __shared__ u32 mt_lds[624];
@@ -82,50 +89,51 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
     u32 st = ST_OK;
     if (act && a.op != OP_QUERY) {
         Rng r;
-        rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]);
+        r.gmt = b.mt + (size_t)gi * 624u; r.lds = mt_lds; r.pos = b.mtpos[gi]; r.dirty = 0;
+        const bool use_rng = op_needs_rng(a.op);
+        if (use_rng) rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]);
         bool dirty_state = true;
         switch (a.op) {
         case OP_INIT:
-            game_ctor(g, b.rules, r);
+            game_ctor<LID>(g, b.rules.first_player, r);
             break;
         case OP_NEW_ROUND:
-            st = new_round(g, b.rules, r);
+            st = new_round<LID>(g, r);
             break;
         case OP_MOVE: {
             i32 av = a.actions[gi];
             if (av < 0 || av >= 180) { st = ST_BAD_ACTION; dirty_state = false; break; }
             u32 d, c, row;
             decode_action((u32)av, d, c, row);
-            do_move(g, b.rules, d, c, row);
+            do_move<LID>(g, d, c, row);
         } break;
         case OP_NEXT_PLAYER:
             g.cur = (g.cur < 2u) ? g.cur + 1u : 1u;
             break;
         case OP_COUNT_SCORE:
-            count_score(g, b.rules, k);
+            count_score<LID>(g, k);
             break;
         case OP_STEP:
-            st = checked_step(g, b.rules, k, r, a.actions[gi]);
+            st = checked_step<LID>(g, k, r, a.actions[gi]);
             dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION);
             break;
         case OP_RUNNER_INIT:
-            st = episode_reset(g, b.rules, r);
+            st = episode_reset<LID>(g, b.rules.first_player, r);
             break;
         case OP_RUNNER_RESET:
-            st = episode_reset(g, b.rules, r);
-            if (!st) st = runner_opponent_loop(g, b.rules, k, r, b.T, true);
+            st = episode_reset<LID>(g, b.rules.first_player, r);
+            if (!st) st = runner_opponent_loop<LID>(g, k, r, b.T, true);
             break;
         case OP_RUNNER_STEP: {
             i32 rew = 0;
             u32 dn = 0;
-            st = runner_step(g, b.rules, k, r, b.T, a.actions[gi], rew, dn);
+            st = runner_step<LID>(g, k, r, b.T, a.actions[gi], rew, dn);
             dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION);
             if (a.reward) AZ_LANE0(a.reward[gi] = rew);
             if (a.done) AZ_LANE0(a.done[gi] = (uint8_t)dn);
             if (!st && dn) {
-                double s[10];
-                game_statistics(g, s);
-                AZ_LANE0(for (int q = 0; q < 10; q++) b.stat_sum[(size_t)gi * 10 + q] += s[q]; b.episodes[gi] += 1ull);
+                for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(b.stat_sum[(size_t)gi * 10 + q] += sv); }
+                AZ_LANE0(b.episodes[gi] += 1ull);
             }
             if (st == ST_STUCK) AZ_LANE0(b.stuck[gi] += 1u);
         } break;
@@ -141,7 +149,7 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
             break;
         }
         if (dirty_state) game_store(g, rec);
-        rng_close(r, b.mtpos + gi);
+        if (use_rng) rng_close(r, b.mtpos + gi);
     }
     if (a.status && act) AZ_LANE0(a.status[gi] = (uint8_t)st);
     // queries on the post-op state
@@ -160,25 +168,25 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
         AZ_LANE0(a.flags[gi] = (uint8_t)f);
     }
     if (a.potential) {
-        i32 phi = potential(g, b.rules, k);
+        i32 phi = potential<LID>(g, k);
         AZ_LANE0(a.potential[gi] = phi);
     }
     if (a.stats) {
-        double s[10];
-        game_statistics(g, s);
-        AZ_LANE0(for (int q = 0; q < 10; q++) a.stats[(size_t)gi * 10 + q] = s[q]);
+        for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(a.stats[(size_t)gi * 10 + q] = sv); }
     }
 }
 
 struct TrajArgs {
     int n_steps;
     uint8_t *mask;     // [T][N][180]
+    u64 *maskbits;     // [T][N][3]
     i32 *action;       // [T][N]
     i32 *reward;       // [T][N]
     uint8_t *done;     // [T][N]
     uint8_t *rec;      // [T][N][128]
 };
 
+template <bool LID>
 __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs t)
 {
     __shared__ u32 mt_lds[624];
@@ -189,18 +197,21 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
     lane_consts(k);
     Game g;
     game_load(g, rec);
+    whatif_refresh<LID>(g, k, 2u);
     Rng r;
     rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]);
     Counters cnt = {b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10};
+#pragma unroll 1
     for (int s = 0; s < t.n_steps; s++) {
         const size_t row = (size_t)s * N + gi;
-        u32 f = selfplay_step(g, b.rules, k, r, b.T, cnt,
-                              t.mask ? t.mask + row * AZUL_NUM_ACTIONS : nullptr,
-                              t.action ? t.action + row : nullptr,
-                              t.reward ? t.reward + row : nullptr,
-                              t.done ? t.done + row : nullptr,
-                              t.rec ? t.rec + row * AZUL_RECORD_BYTES : nullptr);
-        if (f & 0x100u) break;      // rule error (box empty): leave the game as it is; status is visible in the record
+        u32 f = selfplay_step<LID>(g, b.rules.first_player, k, r, b.T, cnt,
+                                   t.mask ? t.mask + row * AZUL_NUM_ACTIONS : nullptr,
+                                   t.maskbits ? t.maskbits + row * 3 : nullptr,
+                                   t.action ? t.action + row : nullptr,
+                                   t.reward ? t.reward + row : nullptr,
+                                   t.done ? t.done + row : nullptr,
+                                   t.rec ? t.rec + row * AZUL_RECORD_BYTES : nullptr);
+        if (f & 0x100u) break;      // rule error (box empty): leave the game as it is
     }
     game_store(g, rec);
     rng_close(r, b.mtpos + gi);
@@ -368,7 +379,10 @@ int azul_batch_seed(azul_batch_t *b, uint64_t seed_base, const uint64_t *seeds_h
 static int launch_op(azul_batch_t *b, const OpArgs &a, void *stream)
 {
     if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
-    hipLaunchKernelGGL(azul_op_kernel, dim3(b->d.n), dim3(64), 0, (hipStream_t)stream, b->d, a);
+    if (b->d.rules.tile_pool == POOL_LID)
+        hipLaunchKernelGGL(azul_op_kernel<true>, dim3(b->d.n), dim3(64), 0, (hipStream_t)stream, b->d, a);
+    else
+        hipLaunchKernelGGL(azul_op_kernel<false>, dim3(b->d.n), dim3(64), 0, (hipStream_t)stream, b->d, a);
     HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }
@@ -482,13 +496,16 @@ int azul_batch_score_preview(azul_batch_t *b, int32_t *potential_dev, void *stre
     return launch_op(b, a, stream);
 }
 
-int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, int32_t *action_dev, int32_t *reward_dev,
-                        uint8_t *done_dev, uint8_t *rec_dev, void *stream)
+int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_t *maskbits_dev, int32_t *action_dev,
+                        int32_t *reward_dev, uint8_t *done_dev, uint8_t *rec_dev, void *stream)
 {
     if (!b || n_steps < 0) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: bad arguments");
     if (n_steps == 0) return AZUL_SUCCESS;
-    TrajArgs t = {n_steps, mask_dev, action_dev, reward_dev, done_dev, rec_dev};
-    hipLaunchKernelGGL(azul_selfplay_kernel, dim3(b->d.n), dim3(64), 0, (hipStream_t)stream, b->d, t);
+    TrajArgs t = {n_steps, mask_dev, (u64 *)maskbits_dev, action_dev, reward_dev, done_dev, rec_dev};
+    if (b->d.rules.tile_pool == POOL_LID)
+        hipLaunchKernelGGL(azul_selfplay_kernel<true>, dim3(b->d.n), dim3(64), 0, (hipStream_t)stream, b->d, t);
+    else
+        hipLaunchKernelGGL(azul_selfplay_kernel<false>, dim3(b->d.n), dim3(64), 0, (hipStream_t)stream, b->d, t);
     HIP_TRY(hipGetLastError());
     if (b->timing) b->timed_launches++;
     return AZUL_SUCCESS;

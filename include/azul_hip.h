@@ -137,13 +137,14 @@ int azul_batch_score_preview(azul_batch_t *b, int32_t *potential_dev /*[N]*/, vo
  * Advance every game by `n_steps` env moves in ONE launch: per move  mask -> RandomAgent -> Azul.step ->
  * reward (delta of the what-if potential) -> done, with auto-reset (GameRunner.reset semantics, same
  * stream) when a game ends.  Trajectory outputs are [n_steps][N]...; any may be NULL.
- *   mask_dev   uint8 [n_steps][N][180]   legal moves before the move
+ *   mask_dev     uint8  [n_steps][N][180] legal moves before the move
+ *   maskbits_dev uint64 [n_steps][N][3]   the same mask bit-packed (bit a&63 of word a>>6)
  *   action_dev int32 [n_steps][N]        chosen action (-1 when stuck)
  *   reward_dev int32 [n_steps][N]
  *   done_dev   uint8 [n_steps][N]        1 = game ended with this move, 2 = stuck (no move, reset)
  *   rec_dev    uint8 [n_steps][N][128]   record after the move, before the auto-reset (tests only)
  */
-int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, int32_t *action_dev,
+int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_t *maskbits_dev, int32_t *action_dev,
                         int32_t *reward_dev, uint8_t *done_dev, uint8_t *rec_dev, void *stream);
 /* per-game counters accumulated by selfplay / runner_step: episodes[N] u64, stuck[N] u32, stat sums [N][10] f64 (host copies; NULL to skip) */
 int azul_batch_counters(azul_batch_t *b, uint64_t *episodes_host, uint32_t *stuck_host, double *stat_sums_host, void *stream);

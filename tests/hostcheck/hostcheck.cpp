@@ -28,6 +28,29 @@ struct HostStream {
     Rules rules;
 };
 
+template <bool LID>
+static int advance(HostStream *h, int n_steps, uint8_t *mask, int32_t *action, int32_t *reward, uint8_t *done, uint8_t *rec_after)
+{
+    LaneConst k; lane_consts(k);
+    Game g; game_load(g, h->rec);
+    whatif_refresh<LID>(g, k, 2u);
+    Rng r; rng_open(r, h->mt, h->lds, h->pos);
+    Counters cnt = {&h->episodes, &h->stuck, h->stat_sum};
+    int rc = 0;
+    for (int t = 0; t < n_steps; t++) {
+        u32 f = selfplay_step<LID>(g, h->rules.first_player, k, r, table(), cnt,
+                                   mask ? mask + (size_t)t * 180 : 0, (u64 *)0, action ? action + t : 0, reward ? reward + t : 0,
+                                   done ? done + t : 0, rec_after ? rec_after + (size_t)t * 128 : 0);
+        if (f & 0x100u) { rc = (int)(f & 0xff); break; }
+    }
+    game_store(g, h->rec);
+    rng_close(r, &h->pos);
+    return rc;
+}
+
+
+#define BY_POOL(pool, call_true, call_false) ((pool) == POOL_LID ? (call_true) : (call_false))
+
 extern "C" {
 
 void hc_weight_table(double *out) { memcpy(out, table(), sizeof(g_T)); }
@@ -40,11 +63,9 @@ HostStream *hc_stream_new(unsigned long long seed, int first_player, int tile_po
     seed_stream(h->mt, seed);
     h->pos = 624;
     // GameRunner.__init__ then reset() (without pre-moves), like oz_stream_start
-    LaneConst k; lane_consts(k);
     Game g; memset(&g, 0, sizeof(g));
     Rng r; rng_open(r, h->mt, h->lds, h->pos);
-    episode_reset(g, h->rules, r);
-    episode_reset(g, h->rules, r);
+    for (int i = 0; i < 2; i++) BY_POOL(tile_pool, episode_reset<true>(g, h->rules.first_player, r), episode_reset<false>(g, h->rules.first_player, r));
     game_store(g, h->rec);
     rng_close(r, &h->pos);
     return h;
@@ -54,20 +75,8 @@ void hc_stream_free(HostStream *h) { free(h); }
 
 int hc_stream_advance(HostStream *h, int n_steps, uint8_t *mask, int32_t *action, int32_t *reward, uint8_t *done, uint8_t *rec_after)
 {
-    LaneConst k; lane_consts(k);
-    Game g; game_load(g, h->rec);
-    Rng r; rng_open(r, h->mt, h->lds, h->pos);
-    Counters cnt = {&h->episodes, &h->stuck, h->stat_sum};
-    int rc = 0;
-    for (int t = 0; t < n_steps; t++) {
-        u32 f = selfplay_step(g, h->rules, k, r, table(), cnt,
-                              mask ? mask + (size_t)t * 180 : 0, action ? action + t : 0, reward ? reward + t : 0,
-                              done ? done + t : 0, rec_after ? rec_after + (size_t)t * 128 : 0);
-        if (f & 0x100u) { rc = (int)(f & 0xff); break; }
-    }
-    game_store(g, h->rec);
-    rng_close(r, &h->pos);
-    return rc;
+    return BY_POOL(h->rules.tile_pool, advance<true>(h, n_steps, mask, action, reward, done, rec_after),
+                   advance<false>(h, n_steps, mask, action, reward, done, rec_after));
 }
 
 void hc_stream_get(HostStream *h, uint8_t *rec, u32 *mt, u32 *pos, u64 *episodes, u32 *stuck, double *stat_sum)
@@ -101,9 +110,8 @@ void hc_observe(const uint8_t *rec, int persp, float *out136)
 int hc_potential(const uint8_t *rec, int tile_pool)
 {
     LaneConst k; lane_consts(k);
-    Rules rules = {1, (u32)tile_pool};
     Game g; game_load(g, rec);
-    return potential(g, rules, k);
+    return BY_POOL(tile_pool, potential<true>(g, k), potential<false>(g, k));
 }
 
 int hc_flags(const uint8_t *rec)
@@ -115,29 +123,27 @@ int hc_flags(const uint8_t *rec)
 void hc_count_score(uint8_t *rec, int tile_pool)
 {
     LaneConst k; lane_consts(k);
-    Rules rules = {1, (u32)tile_pool};
     Game g; game_load(g, rec);
-    count_score(g, rules, k);
+    if (tile_pool == POOL_LID) count_score<true>(g, k); else count_score<false>(g, k);
     game_store(g, rec);
 }
 
 void hc_move(uint8_t *rec, int action, int tile_pool)
 {
-    Rules rules = {1, (u32)tile_pool};
     Game g; game_load(g, rec);
     u32 d, c, row; decode_action((u32)action, d, c, row);
-    do_move(g, rules, d, c, row);
+    if (tile_pool == POOL_LID) do_move<true>(g, d, c, row); else do_move<false>(g, d, c, row);
     game_store(g, rec);
 }
 
 int hc_step(uint8_t *rec, int action, int first_player, int tile_pool, u32 *mt, u32 *pos)
 {
     static u32 lds[624];
+    (void)first_player;
     LaneConst k; lane_consts(k);
-    Rules rules = {(u32)first_player, (u32)tile_pool};
     Game g; game_load(g, rec);
     Rng r; rng_open(r, mt, lds, *pos);
-    u32 st = checked_step(g, rules, k, r, action);
+    u32 st = BY_POOL(tile_pool, checked_step<true>(g, k, r, action), checked_step<false>(g, k, r, action));
     if (st != ST_ILLEGAL_MOVE && st != ST_GAME_ENDED && st != ST_BAD_ACTION) game_store(g, rec);
     rng_close(r, pos);
     return (int)st;
@@ -146,12 +152,12 @@ int hc_step(uint8_t *rec, int action, int first_player, int tile_pool, u32 *mt, 
 int hc_runner_step(uint8_t *rec, int action, int first_player, int tile_pool, u32 *mt, u32 *pos, int *reward, int *done)
 {
     static u32 lds[624];
+    (void)first_player;
     LaneConst k; lane_consts(k);
-    Rules rules = {(u32)first_player, (u32)tile_pool};
     Game g; game_load(g, rec);
     Rng r; rng_open(r, mt, lds, *pos);
     i32 rew = 0; u32 dn = 0;
-    u32 st = runner_step(g, rules, k, r, table(), action, rew, dn);
+    u32 st = BY_POOL(tile_pool, runner_step<true>(g, k, r, table(), action, rew, dn), runner_step<false>(g, k, r, table(), action, rew, dn));
     if (st != ST_ILLEGAL_MOVE && st != ST_GAME_ENDED && st != ST_BAD_ACTION) game_store(g, rec);
     rng_close(r, pos);
     *reward = rew; *done = (int)dn;
@@ -162,11 +168,10 @@ int hc_runner_reset(uint8_t *rec, int first_player, int tile_pool, u32 *mt, u32 
 {
     static u32 lds[624];
     LaneConst k; lane_consts(k);
-    Rules rules = {(u32)first_player, (u32)tile_pool};
     Game g; memset(&g, 0, sizeof(g));
     Rng r; rng_open(r, mt, lds, *pos);
-    u32 st = episode_reset(g, rules, r);
-    if (!st && !ctor_only) st = runner_opponent_loop(g, rules, k, r, table(), true);
+    u32 st = BY_POOL(tile_pool, episode_reset<true>(g, (u32)first_player, r), episode_reset<false>(g, (u32)first_player, r));
+    if (!st && !ctor_only) st = BY_POOL(tile_pool, runner_opponent_loop<true>(g, k, r, table(), true), runner_opponent_loop<false>(g, k, r, table(), true));
     game_store(g, rec);
     rng_close(r, pos);
     return (int)st;

@@ -7,3 +7,5 @@ game_runner.py); every rule evaluation runs in hand-written gfx950 kernels behin
 from .records import RECORD_DTYPE, STAT_KEYS  # noqa: F401
 from .codec import nn_serialize, nn_deserialize  # noqa: F401
 from .batch import BatchedAzul, IllegalRule, parse_rules  # noqa: F401
+from .azul import Azul, IllegalMove, GameEnded  # noqa: F401
+from .game_runner import GameRunner, RandomAgent, check_all_valid  # noqa: F401

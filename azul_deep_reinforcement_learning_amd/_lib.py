@@ -48,6 +48,7 @@ SIGNATURES = {
     "azul_batch_runner_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "azul_batch_observe": (_i, [_vp, _i, _vp, _vp]),
     "azul_batch_random_action": (_i, [_vp, _vp, _vp, _vp]),
+    "azul_batch_sample_mask": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "azul_batch_score_preview": (_i, [_vp, _vp, _vp]),
     "azul_batch_selfplay": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "azul_batch_counters": (_i, [_vp, _vp, _vp, _vp, _vp]),

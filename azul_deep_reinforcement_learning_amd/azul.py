@@ -1,0 +1,249 @@
+"""``Azul`` -- host-side mirror of the reference's rules class (azulnet/azul.py:17-315), backed by the GPU.
+
+Same constructor, attributes (numpy arrays that callers read AND write), methods, exceptions and JSON schema
+as the reference; every rule evaluation (new_round, move, is_legal_move, is_end_of_round, is_end_of_game,
+count_score, step, get_statistics) is one kernel launch through libazulhip.so on the current state of the
+attributes.  What stays on the host is bookkeeping only: rule parsing, attribute <-> record conversion, JSON
+I/O, ``__eq__``, and ``next_player`` / array shapes for the 3-4 player objects the reference can construct
+but never plays (SURVEY.md hazard H5; the kernels are two-player).
+"""
+import json
+import random
+
+import numpy as np
+
+from . import _lib as L
+from . import facade_backend as fb
+from .batch import IllegalRule, parse_rules
+from .records import RECORD_DTYPE, bits_to_walls, pack_flags, unpack_flags, walls_to_bits
+
+
+class IllegalMove(Exception):
+    pass
+
+
+class GameEnded(Exception):
+    pass
+
+
+_STATUS_EXC = {L.ILLEGAL_MOVE: IllegalMove, L.GAME_ENDED: GameEnded, L.BAD_ACTION: IllegalMove}
+
+
+class Azul:
+    def __init__(self, players=2, state_file=None, rules={}):
+        self.game_board_displays = np.zeros((5, 5), dtype=int)
+        self.game_board_center = np.zeros(6, dtype=int)
+        self.pattern_lines = np.zeros((players, 5, 5), dtype=int)
+        self.walls = np.zeros((players, 5, 5), dtype=bool)
+        self.floors = np.zeros(players, dtype=int)
+        self.score = np.zeros(players, dtype=int)
+        self.current_player = 0
+        self.players = players
+        self.end_of_game = False
+        self.turn_counter = 0
+        self.first_player_stats = np.zeros(players)
+        self.floor_penalty = np.zeros(players)
+        self.max_combo = np.zeros(players)
+        self.completed_lines = np.zeros((players, 3))
+        self.rules = rules
+        self._first_code, self._pool_code = parse_rules(rules, players)      # raises IllegalRule (azul.py:41,54)
+        if self._first_code == L.FIRST_RANDOM:
+            self.next_first_player = random.choice(list(range(1, players + 1)))   # azul.py:37, the global stream
+        else:
+            self.next_first_player = self._first_code
+        self.tile_pool = "Lid" if self._pool_code == L.POOL_LID else "Random"
+        if self.tile_pool == "Lid":
+            self.box_tiles = np.array([20, 20, 20, 20, 20])
+            self.lid_tiles = np.array([0, 0, 0, 0, 0])
+        if state_file is not None:
+            self.import_JSON(state_file)
+
+    # ------------------------------------------------------------------------------------------
+    # host bookkeeping
+    # ------------------------------------------------------------------------------------------
+    def __eq__(self, other):
+        # azul.py:62-63: box/lid/statistics/rules are not part of equality
+        return (np.array_equal(self.game_board_displays, other.game_board_displays)
+                and np.array_equal(self.game_board_center, other.game_board_center)
+                and np.array_equal(self.pattern_lines, other.pattern_lines)
+                and np.array_equal(self.walls, other.walls)
+                and np.array_equal(self.floors, other.floors)
+                and np.array_equal(self.score, other.score)
+                and self.current_player == other.current_player
+                and self.next_first_player == other.next_first_player
+                and self.players == other.players
+                and self.end_of_game == other.end_of_game
+                and self.turn_counter == other.turn_counter)
+
+    __hash__ = None
+
+    def import_JSON(self, path):
+        with open(path) as fh:
+            data = json.load(fh)
+        self.game_board_displays = np.array(data["game_board_displays"], dtype=int)
+        self.game_board_center = np.array(data["game_board_center"], dtype=int)
+        self.pattern_lines = np.array(data["pattern_lines"], dtype=int)
+        self.walls = np.array(data["walls"], dtype=bool)
+        self.floors = np.array(data["floors"], dtype=int)
+        self.score = np.array(data["score"], dtype=int)
+        self.current_player = data["current_player"]
+        self.next_first_player = data["next_first_player"]
+        self.players = data["players"]
+        self.turn_counter = data["turn_counter"]
+
+    def export_JSON(self, path):
+        data = {
+            "game_board_displays": np.asarray(self.game_board_displays).tolist(),
+            "game_board_center": np.asarray(self.game_board_center).tolist(),
+            "pattern_lines": np.asarray(self.pattern_lines).tolist(),
+            "walls": np.asarray(self.walls).tolist(),
+            "floors": np.asarray(self.floors).tolist(),
+            "score": np.asarray(self.score).tolist(),
+            "current_player": int(self.current_player),
+            "next_first_player": int(self.next_first_player),
+            "players": int(self.players),
+            "turn_counter": int(self.turn_counter),
+        }
+        with open(path, "w+") as fh:
+            fh.write(json.dumps(data))
+
+    # ------------------------------------------------------------------------------------------
+    # attributes <-> 128-byte record
+    # ------------------------------------------------------------------------------------------
+    def _backend(self):
+        if self.players != 2:
+            raise NotImplementedError("the MI355X kernels play two-player Azul; %d-player objects only support "
+                                      "construction, next_player and new_round" % self.players)
+        return fb.backend(self._first_code, self._pool_code)
+
+    def _to_record(self, runner=None):
+        rec = np.zeros((), dtype=RECORD_DTYPE)
+
+        def fit(name, value, lo, hi):
+            v = np.asarray(value)
+            if v.min() < lo or v.max() > hi:
+                raise ValueError("%s outside the range the GPU record holds [%d, %d]" % (name, lo, hi))
+            return v
+
+        rec["displays"] = fit("game_board_displays", self.game_board_displays, 0, 255)
+        rec["center"] = fit("game_board_center", self.game_board_center, 0, 255)
+        rec["flags"] = pack_flags(fit("current_player", self.current_player, 0, 2),
+                                  fit("next_first_player", self.next_first_player, 0, 2), self.end_of_game)
+        rec["pattern_lines"] = fit("pattern_lines", self.pattern_lines, 0, 255)
+        rec["floors"] = fit("floors", self.floors, 0, 7)
+        rec["walls"] = walls_to_bits(self.walls)
+        rec["score"] = fit("score", self.score, -32768, 32767)
+        if self.tile_pool == "Lid":
+            rec["box"] = fit("box_tiles", self.box_tiles, 0, 255)
+            rec["lid"] = fit("lid_tiles", self.lid_tiles, 0, 255)
+        rec["turn_counter"] = fit("turn_counter", self.turn_counter, 0, 65535)
+        rec["first_player_stats"] = fit("first_player_stats", self.first_player_stats, 0, 65535)
+        rec["floor_penalty"] = fit("floor_penalty", self.floor_penalty, -32768, 32767)
+        rec["max_combo"] = fit("max_combo", self.max_combo, 0, 255)
+        rec["completed_lines"] = fit("completed_lines", self.completed_lines, 0, 255)
+        if runner is not None:
+            rec["player_score"] = fit("player_score", runner.player_score, -32768, 32767)
+            rec["move_counter"] = fit("move_counter", runner.move_counter, 0, 65535)
+        return rec
+
+    def _from_record(self, rec, runner=None):
+        self.game_board_displays = rec["displays"].astype(int)
+        self.game_board_center = rec["center"].astype(int)
+        self.current_player, self.next_first_player, self.end_of_game = unpack_flags(rec["flags"])
+        self.pattern_lines = rec["pattern_lines"].astype(int)
+        self.floors = rec["floors"].astype(int)
+        self.walls = bits_to_walls(rec["walls"])
+        self.score = rec["score"].astype(int)
+        if self.tile_pool == "Lid":
+            self.box_tiles = rec["box"].astype(int)
+            self.lid_tiles = rec["lid"].astype(int)
+        self.turn_counter = int(rec["turn_counter"])
+        self.first_player_stats = rec["first_player_stats"].astype(float)
+        self.floor_penalty = rec["floor_penalty"].astype(float)
+        self.max_combo = rec["max_combo"].astype(float)
+        self.completed_lines = rec["completed_lines"].astype(float)
+        if runner is not None:
+            runner.player_score = int(rec["player_score"])
+            runner.move_counter = int(rec["move_counter"])
+
+    def _run(self, op, *args, draws=False, mutates=True, runner=None):
+        be = self._backend()
+        be.put(self._to_record(runner))
+        if draws:
+            be.push_rng()
+        out = getattr(be, op)(*args)
+        if draws:
+            be.pull_rng()
+        if mutates:
+            self._from_record(be.get(), runner)
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # rules (GPU)
+    # ------------------------------------------------------------------------------------------
+    def new_round(self):
+        if self.players != 2:
+            return self._new_round_many_players()
+        st = self._run("op_new_round", draws=True)
+        if st == L.BOX_EMPTY:
+            raise ValueError("Total of weights must be finite")      # what random.choices raises in the reference
+
+    def _new_round_many_players(self):
+        # azul.py:64-89 for the 3-4 player objects: per-player bookkeeping on the host, the factory draw on the GPU
+        nfp = self.next_first_player
+        proxy = Azul(rules={k: v for k, v in self.rules.items() if k != "first_player"})
+        if self.tile_pool == "Lid":
+            proxy.box_tiles, proxy.lid_tiles = self.box_tiles, self.lid_tiles
+        proxy.next_first_player = 1
+        proxy.new_round()
+        self.game_board_displays, self.game_board_center = proxy.game_board_displays, proxy.game_board_center
+        if self.tile_pool == "Lid":
+            self.box_tiles, self.lid_tiles = proxy.box_tiles, proxy.lid_tiles
+        self.current_player = nfp
+        self.first_player_stats[nfp - 1] += 1
+        self.turn_counter += 1
+        self.next_first_player = 0
+
+    def move(self, display, color, pattern):
+        self._run("op_move", display + 6 * color + 30 * pattern)
+
+    def is_legal_move(self, display, color, pattern):
+        mask = self._run("op_mask", mutates=False)
+        return bool(mask[display + 6 * color + 30 * pattern])
+
+    def legal_mask(self):
+        """All 180 is_legal_move answers at once (what check_all_valid returns)."""
+        return self._run("op_mask", mutates=False)
+
+    def next_player(self):
+        if self.players != 2:
+            self.current_player = self.current_player + 1 if self.current_player < self.players else 1   # azul.py:177-181
+            return
+        self._run("op_next_player")
+
+    def is_end_of_round(self):
+        return bool(self._run("op_flags", mutates=False) & L.FLAG_END_OF_ROUND)
+
+    def is_end_of_game(self):
+        return bool(self._run("op_flags", mutates=False) & L.FLAG_END_OF_GAME)
+
+    def count_score(self):
+        self._run("op_count_score")
+
+    def step(self, display, color, pattern):
+        st = self._run("op_step", display + 6 * color + 30 * pattern, draws=True)
+        if st in _STATUS_EXC:
+            raise _STATUS_EXC[st]
+        if st == L.BOX_EMPTY:
+            raise ValueError("Total of weights must be finite")
+
+    def get_statistics(self):
+        s = self._run("op_statistics", mutates=False)
+        keys = ["player_score", "opponent_score", "rounds", "percent_first_player", "floor_penalty", "max_combo",
+                "completed_rows", "completed_columns", "completed_colors", "win_percent"]
+        out = dict(zip(keys, (float(x) for x in s)))
+        out["win_percent"] = bool(out["win_percent"])
+        return out
+
+
+__all__ = ["Azul", "IllegalMove", "GameEnded", "IllegalRule"]

@@ -182,6 +182,13 @@ class BatchedAzul:
         L.check(L.lib.azul_batch_random_action(self._h, _ptr(self._dev(active, torch.uint8)), _ptr(a), self._stream()))
         return a
 
+    def sample_mask(self, mask, active=None):
+        """RandomAgent.get_a_output for caller-supplied masks [N][180] (one random.choices draw per game)."""
+        m = self._dev(mask, torch.uint8)
+        a = torch.full((self.n,), -1, dtype=torch.int32, device=self.device)
+        L.check(L.lib.azul_batch_sample_mask(self._h, _ptr(m), _ptr(self._dev(active, torch.uint8)), _ptr(a), self._stream()))
+        return a
+
     def score_preview(self):
         p = self._new((self.n,), torch.int32)
         L.check(L.lib.azul_batch_score_preview(self._h, _ptr(p), self._stream()))

@@ -41,13 +41,14 @@ struct BatchDev {
 
 enum {
     OP_QUERY = 0, OP_INIT, OP_NEW_ROUND, OP_MOVE, OP_NEXT_PLAYER, OP_COUNT_SCORE, OP_STEP,
-    OP_RUNNER_INIT, OP_RUNNER_RESET, OP_RUNNER_STEP, OP_RANDOM_ACTION
+    OP_RUNNER_INIT, OP_RUNNER_RESET, OP_RUNNER_STEP, OP_RANDOM_ACTION, OP_SAMPLE_MASK
 };
 
 struct OpArgs {
     int op;
     const i32 *actions;      // [N]   in  (MOVE / STEP / RUNNER_STEP)
     const uint8_t *active;   // [N]   in, optional
+    const uint8_t *mask_in;  // [N][180] in (SAMPLE_MASK)
     i32 *actions_out;        // [N]   out (RANDOM_ACTION)
     uint8_t *status;         // [N]   out
     i32 *reward;             // [N]   out
@@ -72,7 +73,7 @@ __global__ void __launch_bounds__(64) azul_seed_kernel(BatchDev b, u64 seed_base
 static __device__ __forceinline__ bool op_needs_rng(int op)
 {
     return op == OP_INIT || op == OP_NEW_ROUND || op == OP_STEP || op == OP_RUNNER_INIT || op == OP_RUNNER_RESET ||
-           op == OP_RUNNER_STEP || op == OP_RANDOM_ACTION;
+           op == OP_RUNNER_STEP || op == OP_RANDOM_ACTION || op == OP_SAMPLE_MASK;
 }
 
 template <bool LID>
@@ -140,6 +141,17 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
         case OP_RANDOM_ACTION: {
             Mask m;
             legal_mask(g, k, m);
+            i32 av = random_agent(m, r, b.T);
+            AZ_LANE0(a.actions_out[gi] = av);
+            dirty_state = false;
+        } break;
+        case OP_SAMPLE_MASK: {
+            const uint8_t *mi = a.mask_in + (size_t)gi * AZUL_NUM_ACTIONS;
+            vu32 l = lane();
+            Mask m;
+            m.m0 = ballot(ld_u8(mi, l, l < 64u) != 0u);
+            m.m1 = ballot(ld_u8(mi, l + 64u, l < 64u) != 0u);
+            m.m2 = ballot(ld_u8(mi, l + 128u, l < 52u) != 0u);
             i32 av = random_agent(m, r, b.T);
             AZ_LANE0(a.actions_out[gi] = av);
             dirty_state = false;
@@ -486,6 +498,13 @@ int azul_batch_random_action(azul_batch_t *b, const uint8_t *active_dev, int32_t
 {
     if (!actions_dev) return fail(AZUL_ERR_INVALID, "actions_dev is NULL");
     OpArgs a = op_args(OP_RANDOM_ACTION); a.active = active_dev; a.actions_out = actions_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_sample_mask(azul_batch_t *b, const uint8_t *mask_dev, const uint8_t *active_dev, int32_t *actions_dev, void *stream)
+{
+    if (!mask_dev || !actions_dev) return fail(AZUL_ERR_INVALID, "azul_batch_sample_mask: NULL pointer");
+    OpArgs a = op_args(OP_SAMPLE_MASK); a.mask_in = mask_dev; a.active = active_dev; a.actions_out = actions_dev;
     return launch_op(b, a, stream);
 }
 

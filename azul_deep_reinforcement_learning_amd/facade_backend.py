@@ -1,0 +1,108 @@
+"""Single-game bridge between the Python facade (azul.py / game_runner.py of this package) and the C ABI.
+
+A facade call = pack the object's numpy attributes into one 128-byte record, run ONE kernel on a 1-game
+batch, unpack.  Randomness stays the reference's: the process-global CPython ``random`` stream.  Before a
+call that draws, the generator's 624 words + index are pushed into the game's device stream
+(``azul_batch_set_rng``); afterwards the advanced state is pulled back and installed with
+``random.setstate`` -- so ``random.seed(1); Azul().new_round()`` gives the reference's board exactly
+(reference tests/test_azul.py:36-39) while every draw is computed on the GPU.
+"""
+import random
+
+import numpy as np
+
+from . import _lib as L
+
+
+class HipBackend:
+    """1-game BatchedAzul per rule set, created lazily on the current CUDA device."""
+
+    def __init__(self, first_player, tile_pool):
+        import torch
+        from .batch import BatchedAzul
+        if not torch.cuda.is_available():
+            raise RuntimeError("the Azul facade runs its rules on an MI355X through libazulhip.so; no GPU is visible "
+                               "(there is no CPU path)")
+        self.torch = torch
+        rules = {"first_player": "Random" if first_player == L.FIRST_RANDOM else int(first_player),
+                 "tile_pool": "Lid" if tile_pool == L.POOL_LID else "Random"}
+        self.env = BatchedAzul(1, rules=rules)
+
+    # --- RNG bridging -------------------------------------------------------------------------
+    def push_rng(self):
+        st = random.getstate()
+        words = np.array(st[1][:624], dtype=np.uint32)
+        self.env.set_rng(0, words, st[1][624])
+        self._gauss = st[2]
+
+    def pull_rng(self):
+        mt, pos = self.env.get_rng(0)
+        random.setstate((3, tuple(int(x) for x in mt) + (int(pos),), self._gauss))
+
+    # --- record in / out ------------------------------------------------------------------------
+    def put(self, rec):
+        self.env.set_records(rec)
+
+    def get(self):
+        return self.env.get_records()[0]
+
+    # --- operations (each one launch) -------------------------------------------------------------
+    def _one(self, t):
+        return t.cpu().numpy()[0]
+
+    def op_init(self):
+        self.env.init()
+
+    def op_new_round(self):
+        return int(self._one(self.env.new_round()))
+
+    def op_move(self, action):
+        self.env.move([action])
+
+    def op_next_player(self):
+        self.env.next_player()
+
+    def op_count_score(self):
+        self.env.count_score()
+
+    def op_step(self, action):
+        return int(self._one(self.env.azul_step([action])))
+
+    def op_flags(self):
+        return int(self._one(self.env.flags()))
+
+    def op_mask(self):
+        return self._one(self.env.get_valid_moves()).astype(bool)
+
+    def op_observe(self, perspective):
+        return self._one(self.env.get_state(perspective)).astype(np.int64)
+
+    def op_statistics(self):
+        return self._one(self.env.statistics())
+
+    def op_potential(self):
+        return int(self._one(self.env.score_preview()))
+
+    def op_runner_init(self):
+        return int(self._one(self.env.runner_init()))
+
+    def op_runner_reset(self):
+        return int(self._one(self.env.reset()))
+
+    def op_runner_step(self, action):
+        reward, done, st = self.env.step([action])
+        return int(self._one(reward)), bool(self._one(done)), int(self._one(st))
+
+    def op_sample_mask(self, mask):
+        return int(self._one(self.env.sample_mask(np.asarray(mask, dtype=np.uint8).reshape(1, 180))))
+
+
+_FACTORY = HipBackend      # tests/hostcheck swaps in its 64-lane host emulation of the SAME core for CPU-only logic checks
+_CACHE = {}
+
+
+def backend(first_player, tile_pool):
+    key = (_FACTORY, int(first_player), int(tile_pool))
+    if key not in _CACHE:
+        _CACHE[key] = _FACTORY(int(first_player), int(tile_pool))
+    return _CACHE[key]

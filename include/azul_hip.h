@@ -130,6 +130,9 @@ int azul_batch_runner_step(azul_batch_t *b, const int32_t *actions_dev, const ui
 int azul_batch_observe(azul_batch_t *b, int perspective, float *obs_dev /*[N][136]*/, void *stream);         /* get_state           game_runner.py:56-72 */
 int azul_batch_random_action(azul_batch_t *b, const uint8_t *active_dev, int32_t *actions_dev,
                              void *stream);                                                     /* RandomAgent.get_a_output game_runner.py:94-97 (-1: no legal move) */
+/* the same sampler on a caller-supplied legal mask (what RandomAgent.get_a_output receives, game_runner.py:94-97) */
+int azul_batch_sample_mask(azul_batch_t *b, const uint8_t *mask_dev /*[N][180]*/, const uint8_t *active_dev,
+                           int32_t *actions_dev, void *stream);
 int azul_batch_score_preview(azul_batch_t *b, int32_t *potential_dev /*[N]*/, void *stream);   /* deepcopy+count_score, score[0]-score[1]  game_runner.py:48-50 */
 
 /* ---- flat random-agent self-play (the benchmarked hot path) ----------------------------------- */

@@ -189,4 +189,53 @@ int hc_random_action(const uint8_t *rec, u32 *mt, u32 *pos)
     return a;
 }
 
+int hc_init(uint8_t *rec, int first_player, int tile_pool, u32 *mt, u32 *pos)
+{
+    static u32 lds[624];
+    Game g; game_load(g, rec);
+    Rng r; rng_open(r, mt, lds, *pos);
+    if (tile_pool == POOL_LID) game_ctor<true>(g, (u32)first_player, r); else game_ctor<false>(g, (u32)first_player, r);
+    game_store(g, rec);
+    rng_close(r, pos);
+    return 0;
+}
+
+int hc_new_round(uint8_t *rec, int tile_pool, u32 *mt, u32 *pos)
+{
+    static u32 lds[624];
+    Game g; game_load(g, rec);
+    Rng r; rng_open(r, mt, lds, *pos);
+    u32 st = BY_POOL(tile_pool, new_round<true>(g, r), new_round<false>(g, r));
+    game_store(g, rec);
+    rng_close(r, pos);
+    return (int)st;
+}
+
+void hc_next_player(uint8_t *rec)
+{
+    Game g; game_load(g, rec);
+    g.cur = (g.cur < 2u) ? g.cur + 1u : 1u;
+    game_store(g, rec);
+}
+
+void hc_statistics(const uint8_t *rec, double *out10)
+{
+    Game g; game_load(g, rec);
+    for (u32 q = 0; q < 10u; q++) out10[q] = game_stat(g, q);
+}
+
+int hc_sample_mask(const uint8_t *mask180, u32 *mt, u32 *pos)
+{
+    static u32 lds[624];
+    vu32 l = lane();
+    Mask m;
+    m.m0 = ballot(ld_u8(mask180, l, l < 64u) != 0u);
+    m.m1 = ballot(ld_u8(mask180, l + 64u, l < 64u) != 0u);
+    m.m2 = ballot(ld_u8(mask180, l + 128u, l < 52u) != 0u);
+    Rng r; rng_open(r, mt, lds, *pos);
+    i32 a = random_agent(m, r, table());
+    rng_close(r, pos);
+    return a;
+}
+
 } // extern "C"

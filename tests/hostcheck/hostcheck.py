@@ -28,9 +28,15 @@ def lib():
         L.hc_move.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.hc_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.hc_runner_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hc_runner_step.restype = C.c_int
         L.hc_runner_reset.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.hc_random_action.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.hc_weight_table.argtypes = [C.c_void_p]
+        L.hc_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.hc_new_round.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.hc_next_player.argtypes = [C.c_void_p]
+        L.hc_statistics.argtypes = [C.c_void_p, C.c_void_p]
+        L.hc_sample_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -65,3 +71,88 @@ class HostStream:
         ss = np.zeros(10, np.float64)
         lib().hc_stream_get(self.h, ptr(rec), ptr(mt), ptr(pos), ptr(ep), ptr(stuck), ptr(ss))
         return {"rec": rec, "mt": mt, "pos": int(pos[0]), "episodes": int(ep[0]), "stuck": int(stuck[0]), "stat_sum": ss}
+
+
+class EmuBackend:
+    """TEST-ONLY stand-in for azul_deep_reinforcement_learning_amd.facade_backend.HipBackend: the same device
+    core, compiled for the host with the 64-lane emulation.  Lets the facade's logic (and, in the build
+    container, the reference's own test files) run without a GPU.  Never selected by the product."""
+
+    def __init__(self, first_player, tile_pool):
+        self.fp, self.pool = int(first_player), int(tile_pool)
+        self.rec = np.zeros(128, np.uint8)
+        self.mt = np.zeros(624, np.uint32)
+        self.pos = np.array([624], np.uint32)
+        self._gauss = None
+
+    def push_rng(self):
+        import random
+        st = random.getstate()
+        self.mt[:] = np.array(st[1][:624], dtype=np.uint32)
+        self.pos[0] = st[1][624]
+        self._gauss = st[2]
+
+    def pull_rng(self):
+        import random
+        random.setstate((3, tuple(int(x) for x in self.mt) + (int(self.pos[0]),), self._gauss))
+
+    def put(self, rec):
+        self.rec[:] = np.frombuffer(np.asarray(rec).tobytes(), np.uint8)
+
+    def get(self):
+        from azul_deep_reinforcement_learning_amd.records import RECORD_DTYPE
+        return self.rec.copy().view(RECORD_DTYPE)[0]
+
+    def op_init(self):
+        lib().hc_init(ptr(self.rec), self.fp, self.pool, ptr(self.mt), ptr(self.pos))
+
+    def op_new_round(self):
+        return lib().hc_new_round(ptr(self.rec), self.pool, ptr(self.mt), ptr(self.pos))
+
+    def op_move(self, action):
+        lib().hc_move(ptr(self.rec), int(action), self.pool)
+
+    def op_next_player(self):
+        lib().hc_next_player(ptr(self.rec))
+
+    def op_count_score(self):
+        lib().hc_count_score(ptr(self.rec), self.pool)
+
+    def op_step(self, action):
+        return lib().hc_step(ptr(self.rec), int(action), self.fp, self.pool, ptr(self.mt), ptr(self.pos))
+
+    def op_flags(self):
+        return lib().hc_flags(ptr(self.rec))
+
+    def op_mask(self):
+        m = np.zeros(180, np.uint8)
+        lib().hc_mask(ptr(self.rec), ptr(m))
+        return m.astype(bool)
+
+    def op_observe(self, perspective):
+        o = np.zeros(136, np.float32)
+        lib().hc_observe(ptr(self.rec), int(perspective), ptr(o))
+        return o.astype(np.int64)
+
+    def op_statistics(self):
+        s = np.zeros(10, np.float64)
+        lib().hc_statistics(ptr(self.rec), ptr(s))
+        return s
+
+    def op_potential(self):
+        return lib().hc_potential(ptr(self.rec), self.pool)
+
+    def op_runner_init(self):
+        return lib().hc_runner_reset(ptr(self.rec), self.fp, self.pool, ptr(self.mt), ptr(self.pos), 1)
+
+    def op_runner_reset(self):
+        return lib().hc_runner_reset(ptr(self.rec), self.fp, self.pool, ptr(self.mt), ptr(self.pos), 0)
+
+    def op_runner_step(self, action):
+        rew, dn = C.c_int(0), C.c_int(0)
+        st = lib().hc_runner_step(ptr(self.rec), int(action), self.fp, self.pool, ptr(self.mt), ptr(self.pos), C.byref(rew), C.byref(dn))
+        return rew.value, bool(dn.value), st
+
+    def op_sample_mask(self, mask):
+        m = np.ascontiguousarray(np.asarray(mask, dtype=np.uint8).reshape(-1)[:180])
+        return lib().hc_sample_mask(ptr(m), ptr(self.mt), ptr(self.pos))

@@ -1,0 +1,275 @@
+"""GPU parity through the C ABI, one test per reference function:
+N games at once vs the oracle, bit for bit, on states harvested from seeded self-play."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as oz
+
+pytestmark = pytest.mark.gpu
+
+N = 192
+LID = {"first_player": "Random", "tile_pool": "Lid"}
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def harvest(n, pool=oz.POOL_LID, fp=oz.FIRST_RANDOM, seed0=400):
+    """n mid-game records (+ their oracle runners) at varied depths, incl. round rollovers and finished games."""
+    recs, runners = [], []
+    for i in range(n):
+        s = oz.Stream(seed0 + i, fp, pool)
+        depth = 1 + (i * 7) % 90
+        out = s.advance(depth)
+        rec = out["rec_after"][-1]          # state right after a move (may be a finished game: end_of_game set)
+        recs.append(rec)
+        runners.append(oz.unpack(rec, pool, fp))
+    return np.array(recs, dtype=oz.RECORD_DTYPE), runners
+
+
+def make_env(rules, recs):
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    env = BatchedAzul(len(recs), rules=rules)
+    env.set_records(recs)
+    return env
+
+
+def test_record_roundtrip_and_range_validation(torch_cuda):
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    from azul_deep_reinforcement_learning_amd._lib import AzulHipError
+    recs, _ = harvest(N)
+    env = make_env(LID, recs)
+    assert env.get_records().tobytes() == recs.tobytes()
+    bad = recs[:1].copy()
+    bad["floors"][0, 0] = 9
+    with pytest.raises(AzulHipError):
+        BatchedAzul(1).set_records(bad)
+
+
+def test_seed_matches_cpython_init_by_array(torch_cuda):
+    """R1: random.seed(int) for 32- and 64-bit seeds."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    seeds = np.array([0, 1, 12345, 2 ** 32 - 1, 2 ** 32, 2 ** 32 + 7, 2 ** 63 + 11, 99], dtype=np.uint64)
+    env = BatchedAzul(len(seeds))
+    env.seed(seeds=seeds)
+    for g, s in enumerate(seeds):
+        mt, pos = env.get_rng(g)
+        r = oz.seeded_rng(int(s))
+        assert np.array_equal(mt, np.ctypeslib.as_array(r.mt)) and pos == 624
+    env.seed(seed_base=5000)
+    mt, _ = env.get_rng(3)
+    assert np.array_equal(mt, np.ctypeslib.as_array(oz.seeded_rng(5003).mt))
+
+
+def test_legal_mask_observation_flags_potential_statistics(torch_cuda):
+    """A3/B5 check_all_valid, B2 get_state (both perspectives + current), A4 flags, B1 potential, A7 statistics."""
+    recs, runners = harvest(N)
+    env = make_env(LID, recs)
+    mask = env.get_valid_moves().cpu().numpy()
+    obs = [env.get_state(p).cpu().numpy() for p in (0, 1, 2)]
+    flags = env.flags().cpu().numpy()
+    phi = env.score_preview().cpu().numpy()
+    stats = env.statistics().cpu().numpy()
+    L = oz.lib()
+    for g, q in enumerate(runners):
+        assert np.array_equal(mask[g], oz.check_all_valid(q.game)), g
+        for p in (0, 1):
+            assert np.array_equal(obs[p][g].astype(np.int64), oz.get_state(q.game, p)), (g, p)
+        cur = q.game.current_player - 1 if q.game.current_player else 1
+        assert np.array_equal(obs[2][g].astype(np.int64), oz.get_state(q.game, cur)), g
+        assert bool(flags[g] & 1) == bool(L.oz_is_end_of_round(C.byref(q.game)))
+        assert bool(flags[g] & 2) == bool(L.oz_is_end_of_game(C.byref(q.game)))
+        assert bool(flags[g] & 4) == bool(q.game.end_of_game)
+        assert phi[g] == L.oz_potential(C.byref(q.game))
+        exp = oz.get_statistics(q.game)
+        assert np.array_equal(stats[g], np.array([exp[k] for k in oz.STAT_KEYS])), g
+
+
+def test_move_count_score_next_player(torch_cuda):
+    """A2 move (unchecked), A5 count_score, A4 next_player."""
+    recs, runners = harvest(N)
+    L = oz.lib()
+    env = make_env(LID, recs)
+    actions = np.zeros(N, dtype=np.int32)
+    for g, q in enumerate(runners):
+        legal = np.flatnonzero(oz.check_all_valid(q.game))
+        actions[g] = legal[(g * 13) % len(legal)] if len(legal) else 0
+        d, c, p = actions[g] % 6, (actions[g] // 6) % 5, actions[g] // 30
+        L.oz_move(C.byref(q.game), int(d), int(c), int(p))
+    env.move(actions)
+    assert env.get_records().tobytes() == np.array([oz.pack(q) for q in runners], dtype=oz.RECORD_DTYPE).tobytes()
+    env.count_score()
+    env.next_player()
+    for q in runners:
+        L.oz_count_score(C.byref(q.game))
+        L.oz_next_player(C.byref(q.game))
+    assert env.get_records().tobytes() == np.array([oz.pack(q) for q in runners], dtype=oz.RECORD_DTYPE).tobytes()
+
+
+@pytest.mark.parametrize("rules,fp,pool", [(LID, oz.FIRST_RANDOM, oz.POOL_LID), ({}, 1, oz.POOL_RANDOM)])
+def test_step_status_and_state(torch_cuda, rules, fp, pool):
+    """A6 Azul.step: OK / ILLEGAL_MOVE (state + stream untouched) / GAME_ENDED / BAD_ACTION, incl. new_round draws (A1)."""
+    recs, runners = harvest(N, pool, fp)
+    L = oz.lib()
+    env = make_env(rules, recs)
+    env.seed(seed_base=900)
+    rngs = [oz.seeded_rng(900 + g) for g in range(N)]
+    actions = np.zeros(N, dtype=np.int32)
+    exp_status = np.zeros(N, dtype=np.uint8)
+    for g, q in enumerate(runners):
+        mask = oz.check_all_valid(q.game)
+        kind = g % 4
+        if kind == 0 and (~mask).any():
+            a = int(np.flatnonzero(~mask)[g % (~mask).sum()])       # illegal
+        elif kind == 1:
+            a = 180 + g                                             # out of range
+        else:
+            legal = np.flatnonzero(mask)
+            a = int(legal[(g * 5) % len(legal)]) if len(legal) else 0
+        actions[g] = a
+        if q.game.end_of_game:
+            exp_status[g] = oz.GAME_ENDED
+        elif a >= 180:
+            exp_status[g] = 4
+        else:
+            d, c, p = a % 6, (a // 6) % 5, a // 30
+            exp_status[g] = L.oz_step(C.byref(q.game), d, c, p, C.byref(rngs[g]))
+    st = env.azul_step(actions).cpu().numpy()
+    assert np.array_equal(st, exp_status)
+    assert (st == oz.OK).sum() > N // 3 and (st == oz.ILLEGAL_MOVE).sum() > 5
+    assert env.get_records().tobytes() == np.array([oz.pack(q) for q in runners], dtype=oz.RECORD_DTYPE).tobytes()
+    for g in range(0, N, 17):
+        mt, pos = env.get_rng(g)
+        assert pos == rngs[g].idx and np.array_equal(mt, np.ctypeslib.as_array(rngs[g].mt))
+
+
+def test_new_round_and_init(torch_cuda):
+    """A1 new_round (Lid and Random pools), Azul.__init__ with the Random first-player rule (R2 _randbelow)."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    L = oz.lib()
+    for rules, fp, pool in [(LID, oz.FIRST_RANDOM, oz.POOL_LID), ({"first_player": "Random"}, oz.FIRST_RANDOM, oz.POOL_RANDOM)]:
+        env = BatchedAzul(64, rules=rules)
+        env.seed(seed_base=31)
+        env.init()
+        st = env.new_round().cpu().numpy()
+        assert not st.any()
+        env.new_round()
+        got = env.get_records()
+        for g in range(64):
+            r = oz.seeded_rng(31 + g)
+            q = oz.Runner()
+            q.first_player, q.tile_pool = fp, pool
+            assert L.oz_init(C.byref(q.game), 2, fp, pool, C.byref(r)) == 0
+            assert L.oz_new_round(C.byref(q.game), C.byref(r)) == 0
+            assert L.oz_new_round(C.byref(q.game), C.byref(r)) == 0
+            assert oz.pack(q).tobytes() == got[g].tobytes(), g
+
+
+def test_runner_init_reset_step_random_action(torch_cuda):
+    """B3 GameRunner.__init__/reset, B4 RandomAgent, B1 GameRunner.step (device opponent loop, reward, done)."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    L = oz.lib()
+    n = 128
+    env = BatchedAzul(n)
+    env.seed(seed_base=77)
+    assert not env.runner_init().cpu().numpy().any()
+    assert not env.reset().cpu().numpy().any()
+    rngs = [oz.seeded_rng(77 + g) for g in range(n)]
+    qs = [oz.Runner() for _ in range(n)]
+    for g in range(n):
+        assert L.oz_runner_init(C.byref(qs[g]), oz.FIRST_RANDOM, oz.POOL_LID, C.byref(rngs[g])) == 0
+        assert L.oz_runner_reset(C.byref(qs[g]), C.byref(rngs[g])) == 0
+    assert env.get_records().tobytes() == np.array([oz.pack(q) for q in qs], dtype=oz.RECORD_DTYPE).tobytes()
+    alive = np.ones(n, dtype=bool)
+    for it in range(45):
+        a = env.random_action(active=alive.astype(np.uint8)).cpu().numpy()
+        exp_a = np.full(n, -1, dtype=np.int32)
+        for g in np.flatnonzero(alive):
+            m8 = oz.check_all_valid(qs[g].game).astype(np.uint8)
+            exp_a[g] = L.oz_random_agent(m8.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(rngs[g]))
+        assert np.array_equal(a, exp_a), it
+        reward, done, st = env.step(np.where(alive, a, 0), active=alive.astype(np.uint8))
+        reward, done, st = reward.cpu().numpy(), done.cpu().numpy(), st.cpu().numpy()
+        for g in np.flatnonzero(alive):
+            rew, dn = C.c_int64(0), C.c_int(0)
+            assert L.oz_runner_step(C.byref(qs[g]), int(a[g]), C.byref(rngs[g]), C.byref(rew), C.byref(dn)) == 0
+            assert st[g] == 0 and reward[g] == rew.value and bool(done[g]) == bool(dn.value), (it, g)
+            if dn.value:
+                alive[g] = False
+        assert env.get_records().tobytes() == np.array([oz.pack(q) for q in qs], dtype=oz.RECORD_DTYPE).tobytes()
+        if not alive.any():
+            break
+    assert not alive.any()
+    cnt = env.counters()
+    assert cnt["episodes"].sum() == n
+
+
+def test_sample_mask_matches_recorded_reference_picks(torch_cuda, golden_dir):
+    """R3 random.choices on RandomAgent weights: 600 picks recorded from the reference, one stream."""
+    import os
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    p = np.load(os.path.join(golden_dir, "pyrandom.npz"))
+    env = BatchedAzul(1, rules={})
+    env.seed(seeds=np.array([2024], dtype=np.uint64))
+    for pm, pick in zip(p["choices_mask"], p["choices_mask_pick"]):
+        mask = np.unpackbits(pm, bitorder="little")[:180].reshape(1, 180)
+        assert int(env.sample_mask(mask).cpu().numpy()[0]) == int(pick)
+    _, pos = env.get_rng(0)
+    assert pos == int(p["choices_mask_words_end"])
+
+
+def test_stuck_game_is_reported_and_restarted(torch_cuda):
+    """Hazard H3: only the first-player token is left, nobody can move: status STUCK / done == 2, slot restarts."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    rec = np.zeros(2, dtype=oz.RECORD_DTYPE)
+    rec["center"][:, 5] = 1
+    rec["flags"] = 1 | (0 << 3)
+    rec["box"] = 20
+    env = BatchedAzul(2)
+    env.seed(seed_base=1)
+    env.set_records(rec)
+    assert not env.get_valid_moves().any()
+    assert (env.random_action().cpu().numpy() == -1).all()
+    t = env.alloc_trajectory(3)
+    env.selfplay(3, t["mask"], t["action"], t["reward"], t["done"])
+    assert (t["done"][0].cpu().numpy() == 2).all() and (t["action"][0].cpu().numpy() == -1).all()
+    assert (t["done"][1:].cpu().numpy() == 0).all() and (t["action"][1:].cpu().numpy() >= 0).all()
+    assert (env.counters()["stuck"] == 1).all()
+
+
+def test_full_size_invariants_and_sampled_parity(torch_cuda):
+    """BASELINE size (4096 games x 2048 moves): tile conservation per colour, score/flag sanity, and bit-exact
+    final records + RNG index for a sample of games (the oracle replays those in seconds)."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    n, steps = 4096, 2048
+    env = BatchedAzul(n)
+    env.seed(seed_base=0)
+    env.runner_init()
+    env.runner_init()
+    done_total = torch_cuda.zeros((), dtype=torch_cuda.int64, device="cuda")
+    t = env.alloc_trajectory(64)
+    for _ in range(steps // 64):
+        env.selfplay(64, None, t["action"], t["reward"], t["done"])
+        done_total += (t["done"] == 1).sum()
+    rec = env.get_records()
+    walls = np.stack([((rec["walls"][:, p, None] >> np.arange(25)) & 1).reshape(n, 5, 5).sum(axis=1) for p in (0, 1)], axis=1)
+    per_colour = (rec["displays"].sum(axis=1) + rec["center"][:, :5] + rec["pattern_lines"].sum(axis=(1, 2))
+                  + walls.sum(axis=1) + rec["box"] + rec["lid"])
+    # tiles discarded from completed lines go to the lid; floor tiles go to the lid when taken: 20 per colour always
+    assert (per_colour == 20).all()
+    assert (rec["score"] >= 0).all() and (rec["floors"] <= 7).all()
+    cnt = env.counters()
+    assert int(cnt["episodes"].sum()) == int(done_total.item()) and cnt["stuck"].sum() == 0
+    assert 30 < steps * n / max(int(cnt["episodes"].sum()), 1) < 90          # ~56 moves per game
+    for g in range(0, n, 293):
+        s = oz.Stream(g)
+        s.advance(steps, want_records=False)
+        assert s.record().tobytes() == rec[g].tobytes(), g
+        _, pos = env.get_rng(g)
+        assert pos == s.r.idx

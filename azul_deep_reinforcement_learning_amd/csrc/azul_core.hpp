@@ -25,7 +25,7 @@ using namespace wv;
 
 enum { ST_OK = 0, ST_ILLEGAL_MOVE = 1, ST_GAME_ENDED = 2, ST_STUCK = 3, ST_BAD_ACTION = 4, ST_BOX_EMPTY = 5 };
 enum { POOL_RANDOM = 0, POOL_LID = 1 };
-enum { T_COLS = 151, T_ROWS = 31 };   // RandomAgent cumulative-weight table, see build_weight_table()
+enum { T_ROWS = 31, T_BINADES = 8, T_WORDS = T_ROWS * T_BINADES + T_ROWS };   // RandomAgent weight table, see azul_tables.hpp
 
 struct Rules {
     u32 first_player;   // 0 = "Random", 1..2 = fixed
@@ -41,12 +41,23 @@ struct Rng {
     u32 *gmt;       // this game's 624 words in global memory
     u32 *lds;       // this wave's 624-word LDS window (staged whole when the stream is opened)
     u32 pos;        // CPython's `index` (0..624)
-    u32 dirty;      // window differs from global memory (a twist happened)
+    u32 dirty;      // LDS state differs from global memory (a twist happened)
+    u32 wbase;      // first word held by `win` (0x80000000: none)
+    vu32 win;       // lane i: TEMPERED output word wbase + i  (one readlane per random word)
 };
+
+AZ_FN vu32 temper_v(vu32 y)
+{
+    y = y ^ (y >> 11);
+    y = y ^ ((y << 7) & 0x9d2c5680u);
+    y = y ^ ((y << 15) & 0xefc60000u);
+    y = y ^ (y >> 18);
+    return y;
+}
 
 AZ_FN void rng_open(Rng &r, u32 *gmt, u32 *lds, u32 pos)
 {
-    r.gmt = gmt; r.lds = lds; r.pos = pos; r.dirty = 0;
+    r.gmt = gmt; r.lds = lds; r.pos = pos; r.dirty = 0; r.wbase = 0x80000000u; r.win = splat(0u);
 #if AZ_DEVICE_BUILD
 #pragma unroll 1
 #endif
@@ -79,18 +90,23 @@ AZ_FN void rng_twist(Rng &r)
     }
     r.dirty = 1;
     r.pos = 0;
+    r.wbase = 0x80000000u;
+}
+
+AZ_FN void rng_refill(Rng &r)
+{
+    if (r.pos >= 624u) rng_twist(r);
+    r.wbase = r.pos;
+    vu32 i = lane() + r.pos;
+    r.win = temper_v(lds_ld(r.lds, i, i < 624u));
 }
 
 AZ_FN u32 rng_u32(Rng &r)
 {
-    if (r.pos >= 624u) rng_twist(r);
-    u32 y = lds_ldu(r.lds, r.pos);
+    u32 off = r.pos - r.wbase;                          // wraps to a huge value when no window is loaded
+    if (AZ_UNLIKELY(off >= 64u || r.pos >= 624u)) { rng_refill(r); off = 0; }
     r.pos += 1;
-    y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= (y >> 18);
-    return y;
+    return readlane(r.win, off);
 }
 
 AZ_FN double rng_random(Rng &r)
@@ -139,13 +155,28 @@ struct Game {
     u64 compl_;             // byte 3p+k = completed_lines[p][k]
     i32 pscore;             // GameRunner.player_score
     u32 moves;              // GameRunner.move_counter
-    i32 wi0, wi1;           // cached "what-if" scores of the two players (derived; see whatif_refresh)
+    // derived, never stored: what-if scoring cache (game_runner.py:48-50) and wall status
+    i32 wc0, wc1;           // points the players' currently FULL pattern lines would earn (count_wall)
+    i32 wi0, wi1;           // what-if scores: max(0, score + floor penalty + wc)
+    u32 over;               // is_end_of_game(): some wall row is complete (walls only change at scoring)
 };
+
+constexpr u32 column_board_c(int col)
+{
+    u32 m = 0;
+    for (int j = 0; j < 5; j++) m |= 1u << (5 * j + ((col - j + 5) % 5));
+    return m;
+}
+static_assert(column_board_c(0) == 0x222201u && column_board_c(4) == 0x111110u, "column boards");
 
 struct LaneConst {
     vu32 spos[3];    // action a=64w+lane: cs lane of its source cell (31 = none)
     vu32 okpos[3];   // action a: bit of the "row accepts colour" board (31 = floor move, always ok)
     vu32 rowp1;      // cp lane l<50: row+1, else 0xff
+    // per pattern cell (lane l<50: player l/25, cell i=l%25, row r=i/5, colour c=i%5):
+    vu32 prow, pcol_, pbcol; // r, c, board column (c+r)%5
+    vu32 pbelow;             // bits 0..i of a 25-bit board ("this placement and everything scored before it")
+    vu32 pcolboard;          // wall cells lying in board column (c+r)%5
 };
 
 AZ_FN void lane_consts(LaneConst &k)
@@ -159,6 +190,14 @@ AZ_FN void lane_consts(LaneConst &k)
     }
     vu32 l = lane();
     k.rowp1 = sel(l < 50u, ((l % 25u) / 5u) + 1u, splat(0xffu));
+    vu32 i = l % 25u;
+    k.prow = i / 5u;
+    k.pcol_ = i % 5u;
+    vu32 bc = k.prow + k.pcol_;
+    k.pbcol = sel(bc >= 5u, bc - 5u, bc);
+    k.pbelow = (2u << i) - 1u;
+    k.pcolboard = sel(k.pbcol == 0u, splat(column_board_c(0)), sel(k.pbcol == 1u, splat(column_board_c(1)),
+                  sel(k.pbcol == 2u, splat(column_board_c(2)), sel(k.pbcol == 3u, splat(column_board_c(3)), splat(column_board_c(4))))));
 }
 
 AZ_FN u32 me_index(const Game &g) { return g.cur == 0u ? 1u : g.cur - 1u; }   // numpy [-1] before the first round
@@ -189,7 +228,7 @@ AZ_FN void game_load(Game &g, const uint8_t *rec)
     g.compl_ = (u64)(w8 >> 16) | ((u64)w9 << 16);
     g.pscore = (i32)(int16_t)(w10 & 0xffffu);
     g.moves = w10 >> 16;
-    g.wi0 = g.wi1 = 0;
+    g.wc0 = g.wc1 = 0; g.wi0 = g.wi1 = 0; g.over = 0;
 }
 
 AZ_FN void game_store(const Game &g, uint8_t *rec)
@@ -227,13 +266,14 @@ AZ_FN void legal_mask(const Game &g, const LaneConst &k, Mask &out)
     u32 me = me_index(g);
     u32 pme = (u32)(PL >> (25u * me)) & 0x1ffffffu;
     u32 wl = me ? g.wall1 : g.wall0;
-    u32 ok = 0x80000000u;                            // bit 31: "floor row" accepts everything
-    for (u32 r = 0; r < 5; r++) {
-        u32 rb = (pme >> (5u * r)) & 31u;              // colours already lying on row r
-        u32 okr = (rb == 0u) ? 31u : (((rb & (rb - 1u)) == 0u) ? rb : 0u);   // azul.py:172
-        okr &= ~(wl >> (5u * r)) & 31u;                // azul.py:174
-        ok |= okr << (5u * r);
-    }
+    // "row r accepts colour c": no OTHER colour lies on the row (azul.py:172) and the wall cell is free (:174);
+    // one lane per (row, colour), ballot -> 25-bit board; bit 31: the floor "row" accepts everything
+    vu32 l = lane();
+    vu32 rb = (pme >> (k.prow * 5u)) & 31u;            // colours already lying on my row
+    vu32 mine = (rb >> k.pcol_) & 1u;
+    vbool alone = (rb == 0u) | (((rb & (rb - 1u)) == 0u) & (mine != 0u));
+    vbool free_ = ((wl >> (l & 31u)) & 1u) == 0u;
+    u32 ok = ((u32)ballot(alone & free_ & (l < 25u)) & 0x1ffffffu) | 0x80000000u;
     out.m0 = ballot((((B >> (k.spos[0] & 31u)) & (ok >> (k.okpos[0] & 31u))) & 1u) != 0u);
     out.m1 = ballot((((B >> (k.spos[1] & 31u)) & (ok >> (k.okpos[1] & 31u))) & 1u) != 0u);
     out.m2 = ballot((((B >> (k.spos[2] & 31u)) & (ok >> (k.okpos[2] & 31u))) & 1u) != 0u);
@@ -255,195 +295,232 @@ AZ_FN void mask_write(const Mask &m, uint8_t *out)
     vu32 l = lane();
     st_u8(out, l, lane_bit(m.m0), l < 64u);
     st_u8(out, l + 64u, lane_bit(m.m1), l < 64u);
-    st_u8(out, l + 128u, lane_bit(m.m2), l < 52u);
+    st_u8(out, vmin(l, 51u) + 128u, lane_bit(m.m2 | ((m.m2 >> 51) & 1ull) * 0xfff8000000000000ull), l < 64u);   // lanes 52.. repeat lane 51
 }
 
 AZ_FN void mask_write_bits(const Mask &m, u64 *out)
 {
     // bit-packed form (24 bytes per game): what the multi-GPU trajectory all-gather ships
-    AZ_LANE0(out[0] = m.m0; out[1] = m.m1; out[2] = m.m2);
+    stu_u64(out, m.m0); stu_u64(out + 1, m.m1); stu_u64(out + 2, m.m2);
 }
 
 // ---- RandomAgent: game_runner.py:87-97 + random.choices (random.py:506-541) ----
-// T[J][m] = the fp64 value CPython's accumulate() reaches after J weights of 0.01 followed by m weights
-// of 1.0 (zeros in between add exactly nothing).  Strictly increasing in the number of legal actions.
-AZ_FN double tseq(const double *T, u32 J, u32 k) { return (k <= J) ? T[k * T_COLS] : T[J * T_COLS + (k - J)]; }
+// The cumulative weight CPython's accumulate() reaches after J weights of 0.01 (legal floor moves, a < 30)
+// and m weights of 1.0 is  T(J, 0) = S[J]  and, for m >= 1,  T(J, m) = m + Fr[J][floor(log2 m)]  EXACTLY:
+// adding 1.0 only rounds when the sum enters a new binade, so per J there are 8 distinct fractional parts
+// (azul_tables.hpp builds both tables with the very additions CPython performs; tests check all 31*151 sums).
+// The 248 + 31 doubles live in ten VGPRs per wave: no memory access on the sampling path.
+struct SampleTab {
+    vf64 fr0, fr1, fr2, fr3;   // Fr[J][b] at flat index e = 8J + b: register e >> 6, lane e & 63 (a row never straddles)
+    vf64 s;                    // S[J] in lane J
+};
 
-AZ_FN i32 random_agent(const Mask &m, Rng &r, const double *T)
+AZ_FN void sample_tab_load(SampleTab &t, const double *tab /* T_WORDS doubles: Fr[31][8] then S[31] */)
+{
+    vu32 l = lane();
+    t.fr0 = ld_f64(tab, l, l < 64u);
+    t.fr1 = ld_f64(tab, l + 64u, l < 64u);
+    t.fr2 = ld_f64(tab, l + 128u, l < 64u);
+    t.fr3 = ld_f64(tab, vmin(l, 55u) + 192u, l < 64u);
+    t.s = ld_f64(tab + T_ROWS * T_BINADES, vmin(l, 30u), l < 64u);
+}
+
+// cumulative weight after the k-th legal action (k = 0 -> 0.0); `row` holds Fr[J][.] at lanes lane0..lane0+7
+AZ_FN double tseq(const SampleTab &t, const vf64 &row, u32 lane0, u32 J, u32 k)
+{
+    u32 m = k > J ? k - J : 1u;
+    double hi = (double)m + readlane_d(row, lane0 + 31u - clz32(m));
+    double lo = readlane_d(t.s, k > J ? J : k);
+    return k > J ? hi : lo;
+}
+
+AZ_FN i32 random_agent(const Mask &m, Rng &r, const SampleTab &T)
 {
     u32 c0 = popc64(m.m0), c1 = popc64(m.m1), c2 = popc64(m.m2);
     u32 J = popc64(m.m0 & 0x3fffffffull);             // legal floor moves (a < 30, weight 0.01)
     u32 L = c0 + c1 + c2;
-    if (L == 0u) return -1;                            // ValueError in the reference, raised before random()
-    double total = tseq(T, J, L) + 0.0;
+    if (AZ_UNLIKELY(L == 0u)) return -1;               // ValueError in the reference, raised before random()
+    u32 q = J >> 3, lane0 = (J & 7u) * 8u;
+    vf64 row = self64(q == 0u, T.fr0, self64(q == 1u, T.fr1, self64(q == 2u, T.fr2, T.fr3)));
+    double total = tseq(T, row, lane0, J, L) + 0.0;
     double x = rng_random(r) * total;
     // bisect_right over the cumulative weights == smallest ordinal k with cum(k) > x
-    double sJ = T[J * T_COLS];
+    double sJ = readlane_d(T.s, J);
     u32 kg = (x < sJ) ? ((u32)(x * 100.0) + 1u) : (J + (u32)(x - sJ) + 1u);
-    if (kg < 1u) kg = 1u;
-    if (kg > L) kg = L;
+    kg = kg < 1u ? 1u : kg;
+    kg = kg > L ? L : kg;
     for (u32 it = 0; it < 400u; it++) {
-        if (x < tseq(T, J, kg - 1u) && kg > 1u) kg -= 1u;
-        else if (!(x < tseq(T, J, kg)) && kg < L) kg += 1u;
+        bool below = x < tseq(T, row, lane0, J, kg - 1u), inside = x < tseq(T, row, lane0, J, kg);
+        if (AZ_UNLIKELY(below && kg > 1u)) kg -= 1u;
+        else if (AZ_UNLIKELY(!inside && kg < L)) kg += 1u;
         else break;
     }
     // kg-th legal action
-    u32 w, rank;
-    if (kg <= c0) { w = 0; rank = kg - 1u; }
-    else if (kg <= c0 + c1) { w = 1; rank = kg - 1u - c0; }
-    else { w = 2; rank = kg - 1u - c0 - c1; }
-    u64 mw = mask_word(m, w);
+    u32 in0 = kg <= c0, in1 = kg <= c0 + c1;
+    u32 w = in0 ? 0u : (in1 ? 1u : 2u);
+    u32 rank = kg - 1u - (in0 ? 0u : (in1 ? c0 : c0 + c1));
+    u64 mw = in0 ? m.m0 : (in1 ? m.m1 : m.m2);
     u64 hit = ballot((lane_bit(mw) != 0u) & (mbcnt(mw) == rank));
     return (i32)(w * 64u + ctz64(hit));
 }
 
 // ---- move: azul.py:118-161 ----
-AZ_FN void add_to_floor(Game &g, u32 p, u32 n)
-{
-    u32 f = (p ? g.floor1 : g.floor0) + n;              // azul.py:119-123
-    f = (f < 7u) ? f : 7u;
-    if (p) g.floor1 = f; else g.floor0 = f;
-}
-
 AZ_FN void byte_add(u64 &v, u32 idx, u32 n) { v += (u64)n << (8u * idx); }
 
+// returns true when the targeted pattern line is full after the move (its wall pricing must be (re)computed).
+// Written with selects instead of branches: a taken branch costs a wave far more than the few extra lane ops.
 template <bool LID>
-AZ_FN void do_move(Game &g, u32 d, u32 c, u32 row)
+AZ_FN bool do_move(Game &g, u32 d, u32 c, u32 row)
 {
     u32 me = me_index(g);
     vu32 l = lane();
-    u32 n;
-    if (d != 0u) {
-        u32 db = 5u * (d - 1u);
-        n = readlane(g.cs, db + c);                                    // :127
-        vu32 moved = bperm(g.cs, l - 25u + db);                         // display cell of my colour, for centre lanes
-        vbool centre = (l >= 25u) & (l < 30u) & (l != 25u + c);
-        g.cs = sel(centre, g.cs + moved, g.cs);                        // :131
-        g.cs = sel((l >= db) & (l < db + 5u), splat(0u), g.cs);        // :129,:133
-    } else {
-        n = readlane(g.cs, 25u + c);                                   // :136
-        g.cs = writelane(g.cs, 0u, 25u + c);                           // :138
-        if (readlane(g.cs, 30) == 1u) {                                // :140-143
-            g.cs = writelane(g.cs, 0u, 30);
-            g.nfp = g.cur;
-            add_to_floor(g, me, 1u);
-        }
-    }
-    if (row != 0u) {
-        u32 cell = 25u * me + 5u * (row - 1u) + c;
-        u32 old = readlane(g.cp, cell);
-        i32 overflow = (i32)row - (i32)old - (i32)n;                   // :147
-        if (overflow >= 0) {
-            g.cp = writelane(g.cp, old + n, cell);                     // :150
-        } else {
-            g.cp = writelane(g.cp, row, cell);                         // :152
-            add_to_floor(g, me, (u32)(-overflow));                     // :154
-            if (LID) byte_add(g.lid, c, (u32)(-overflow));             // :156-157
-        }
-    } else {
-        add_to_floor(g, me, n);                                        // :159
-        if (LID) byte_add(g.lid, c, n);                                // :160-161
-    }
+    const bool from_display = d != 0u;
+    u32 db = from_display ? 5u * (d - 1u) : 0u;
+    u32 src = from_display ? db + c : 25u + c;                         // the source cell
+    u32 n = readlane(g.cs, src);                                       // :127 / :136
+    bool token = !from_display && readlane(g.cs, 30) == 1u;            // :140
+    // display: every other colour of that display slides into the centre (:131), the display empties (:129,:133)
+    vu32 moved = bperm(g.cs, l - 25u + db);
+    vbool centre = (l >= 25u) & (l < 30u) & (l != 25u + c) & from_display;
+    vbool gone = ((l >= db) & (l < db + 5u) & from_display) | (l == src) | ((l == 30u) & token);   // :138, :141
+    g.cs = sel(gone, splat(0u), sel(centre, g.cs + moved, g.cs));
+    g.nfp = token ? g.cur : g.nfp;                                     // :142
+    u32 fl = (me ? g.floor1 : g.floor0) + (token ? 1u : 0u);           // :143 (a token never overflows the cap alone)
+    fl = fl < 7u ? fl : 7u;
+    // pattern line or floor
+    u32 cell = 25u * me + 5u * ((row ? row : 1u) - 1u) + c;
+    u32 old = readlane(g.cp, cell);
+    i32 overflow = row ? (i32)row - (i32)old - (i32)n : -(i32)n;       // :147 ; floor move: everything "overflows"
+    u32 spill = overflow < 0 ? (u32)(-overflow) : 0u;
+    u32 newv = overflow < 0 ? row : old + n;                           // :150 / :152
+    g.cp = sel((l == cell) & (row != 0u), splat(newv), g.cp);
+    fl += spill;                                                       // :154 / :159
+    fl = fl < 7u ? fl : 7u;
+    if (me) g.floor1 = fl; else g.floor0 = fl;
+    if (LID) byte_add(g.lid, c, spill);                                // :156-157 / :160-161
+    return row != 0u && overflow <= 0;
 }
 
 // ---- scoring: azul.py:192-295 on 25-bit wall bitboards ----
-AZ_FN u32 run_length(u32 bits, u32 pos)
+AZ_FN u64 full_lines(const Game &g, const LaneConst &k) { return ballot(g.cp == k.rowp1); }              // azul.py:216
+
+// Vector half of count_wall (azul.py:211-290): EVERY pattern cell (lane = player, row, colour) prices "a tile
+// placed here now" against its player's wall plus the full lines that are scored before it (ascending row,
+// colour -- `pbelow`), so the sequential dependency of the reference loop is reproduced without a loop.
+struct ScoreVec {
+    vu32 val;        // pos_count + bonus_count of that placement
+    vu32 pos;        // pos_count alone (max_combo)
+    u64 rowdone, colordone, coldone;   // lanes whose placement completes a row / colour / column
+};
+
+AZ_FN vu32 run_length_v(vu32 bits, vu32 pos)
 {
-    // length of the run of ones in `bits` (5 bits) that contains bit `pos`
-    u32 up = ctz32(~(bits >> pos));                       // counts `pos` itself
-    u32 below = ~bits & ((1u << pos) - 1u);
-    u32 down = below ? (pos - (32u - clz32(below))) : pos;
+    vu32 up = vctz(~(bits >> pos));
+    vu32 below = ~bits & ((1u << pos) - 1u);
+    vu32 down = sel(below != 0u, pos + vclz(below | 1u) - 32u, pos);
     return up + down;
 }
 
-constexpr u32 column_board_c(int col)
+AZ_FN void score_vec(const Game &g, const LaneConst &k, u64 F, ScoreVec &s)
 {
-    u32 m = 0;
-    for (int j = 0; j < 5; j++) m |= 1u << (5 * j + ((col - j + 5) % 5));
-    return m;
+    vbool p1 = lane() >= 25u;
+    u32 f0 = (u32)F & 0x1ffffffu, f1 = (u32)(F >> 25) & 0x1ffffffu;
+    vu32 w = sel(p1, splat(g.wall1), splat(g.wall0)) | (sel(p1, splat(f1), splat(f0)) & k.pbelow);   // :219
+    vu32 rowbits = (w >> (k.prow * 5u)) & 31u;
+    vu32 h = ((rowbits << k.prow) | (rowbits >> (5u - k.prow))) & 31u;       // the row in board-column order
+    vu32 hr = run_length_v(h, k.pbcol);                                      // :230-242
+    vu32 wc = w & k.pcolboard;
+    vu32 t = wc | (wc >> 1) | (wc >> 2) | (wc >> 3) | (wc >> 4);
+    vu32 v = (((t & 0x108421u) * 0x111110u) >> 20) & 31u;                     // the board column, bit j = row j
+    vu32 vr = run_length_v(v, k.prow);                                       // :244-257
+    vu32 both = hr + vr;
+    s.pos = sel((hr == 1u) & (vr == 1u), splat(1u), sel((hr > 1u) & (vr > 1u), both, both - 1u));    // :258-263
+    vbool rd = rowbits == 31u;                                               // :266-272
+    vbool cd = ((w >> k.pcol_) & 0x108421u) == 0x108421u;                     // :274-280
+    vbool kd = v == 31u;                                                     // :282-288
+    s.val = s.pos + sel(rd, splat(2u), splat(0u)) + sel(cd, splat(10u), splat(0u)) + sel(kd, splat(7u), splat(0u));
+    s.rowdone = ballot(rd); s.colordone = ballot(cd); s.coldone = ballot(kd);
 }
-static_assert(column_board_c(0) == 0x222201u && column_board_c(4) == 0x111110u, "column boards");
 
-AZ_FN u32 column_board(u32 col)
+AZ_FN i32 floor_penalty(u32 floor_tiles)
 {
-    // wall cells (bit 5j + colour) that sit in board column `col`: colour = (col - j) mod 5  (azul.py:194-199)
-    return col == 0u ? column_board_c(0) : col == 1u ? column_board_c(1) : col == 2u ? column_board_c(2)
-         : col == 3u ? column_board_c(3) : column_board_c(4);
+    u32 f = floor_tiles > 7u ? 7u : floor_tiles;         // count_floor, azul.py:200-210: 0,-1,-2,-4,-6,-8,-11,-14
+    return -(i32)((0x0e0b080604020100ull >> (8u * f)) & 0xffu);
+}
+
+AZ_FN i32 clamp0(i32 s) { return s < 0 ? 0 : s; }       // azul.py:294-295
+
+// scalar half: the sum over this player's full lines (+ statistics / wall / lid commits when REAL)
+template <bool REAL, bool LID, u32 P>
+AZ_FN i32 wall_points(Game &g, u64 F, const ScoreVec &sv)
+{
+    u32 fp = (u32)(F >> (25u * P)) & 0x1ffffffu;
+    i32 cnt = 0;
+    u32 mc = (g.maxc >> (8u * P)) & 0xffu;
+    u32 rest = fp;
+    while (rest) {
+        u32 i = ctz32(rest);
+        rest &= rest - 1u;
+        cnt += (i32)readlane(sv.val, i + 25u * P);                           // :289
+        if (REAL) {
+            u32 ps = readlane(sv.pos, i + 25u * P);
+            if (ps > mc) mc = ps;                                            // :264
+            if (LID) { u32 r = (i * 205u) >> 10; byte_add(g.lid, i - 5u * r, r); }   // :220-222
+        }
+    }
+    if (REAL) {
+        if (P) g.wall1 |= fp; else g.wall0 |= fp;                            // :219
+        g.maxc = (g.maxc & ~(0xffu << (8u * P))) | (mc << (8u * P));
+        u64 mine = (u64)fp << (25u * P);
+        g.compl_ += ((u64)popc64(sv.rowdone & mine) << (8u * (3u * P + 0u)))   // :270
+                  + ((u64)popc64(sv.colordone & mine) << (8u * (3u * P + 1u))) // :278
+                  + ((u64)popc64(sv.coldone & mine) << (8u * (3u * P + 2u)));  // :286
+    }
+    return cnt;
 }
 
 AZ_FN bool any_row_full(u32 w) { return ((w & (w >> 1) & (w >> 2) & (w >> 3) & (w >> 4)) & 0x108421u) != 0u; }
-
-AZ_FN bool is_end_of_game(const Game &g) { return any_row_full(g.wall0) || any_row_full(g.wall1); }   // azul.py:184-191
-
-AZ_FN u64 full_lines(const Game &g, const LaneConst &k) { return ballot(g.cp == k.rowp1); }              // azul.py:216
-
-// one player's count_floor + count_wall; REAL commits walls/score/statistics, otherwise only the score is returned
-template <bool REAL, bool LID, u32 P>
-AZ_FN i32 score_player(Game &g, u64 F)
-{
-    // count_floor (azul.py:200-210): 0,-1,-2,-4,-6,-8,-11,-14
-    u32 f0 = P ? g.floor1 : g.floor0;
-    u32 f = f0 > 7u ? 7u : f0;
-    i32 pen = -(i32)((0x0e0b080604020100ull >> (8u * f)) & 0xffu);
-    u32 fp = (u32)(F >> (25u * P)) & 0x1ffffffu;
-    u32 w = P ? g.wall1 : g.wall0;
-    i32 cnt = 0;
-    u32 mc = (g.maxc >> (8u * P)) & 0xffu;
-    u64 cl = g.compl_;
-    u64 lid = g.lid;
-    while (fp) {                                         // ascending (row, colour) == azul.py:213-214
-        u32 i = ctz32(fp);
-        fp &= fp - 1u;
-        u32 r = (i * 205u) >> 10, c = i - 5u * r;
-        w |= 1u << i;                                    // :219
-        if (LID) byte_add(lid, c, r);                    // :220-222
-        u32 col = c + r; if (col >= 5u) col -= 5u;       // to_wall_position
-        u32 rowbits = (w >> (5u * r)) & 31u;
-        u32 h = ((rowbits << r) | (rowbits >> (5u - r))) & 31u;   // row r in board-column order
-        u32 hr = run_length(h, col);                     // :230-242
-        u32 wc = w & column_board(col);
-        u32 t = wc | (wc >> 1) | (wc >> 2) | (wc >> 3) | (wc >> 4);
-        u32 v = (u32)((((u64)(t & 0x108421u)) * 0x111110ull) >> 20) & 31u;   // column `col`, bit j = row j
-        u32 vr = run_length(v, r);                       // :244-257
-        u32 pos = (hr == 1u && vr == 1u) ? 1u : ((hr > 1u && vr > 1u) ? hr + vr : hr + vr - 1u);   // :258-263
-        if (pos > mc) mc = pos;                          // :264
-        u32 bonus = 0;
-        if (rowbits == 31u) { bonus += 2u; cl += 1ull << (8u * (3u * P + 0u)); }                    // :266-272
-        if (((w >> c) & 0x108421u) == 0x108421u) { bonus += 10u; cl += 1ull << (8u * (3u * P + 1u)); }   // :274-280
-        if (v == 31u) { bonus += 7u; cl += 1ull << (8u * (3u * P + 2u)); }                          // :282-288
-        cnt += (i32)(pos + bonus);
-    }
-    i32 s = (P ? g.score1 : g.score0) + pen + cnt;       // :292
-    if (s < 0) s = 0;                                    // :294-295
-    if (REAL) {
-        if (P) { g.score1 = s; g.floor1 = 0; g.wall1 = w; }       // :209
-        else { g.score0 = s; g.floor0 = 0; g.wall0 = w; }
-        u32 old = (g.fpen >> (16u * P)) & 0xffffu;                // :208
-        g.fpen = (g.fpen & ~(0xffffu << (16u * P))) | ((((u32)((i32)(int16_t)old + pen)) & 0xffffu) << (16u * P));
-        g.maxc = (g.maxc & ~(0xffu << (8u * P))) | (mc << (8u * P));
-        g.compl_ = cl;
-        g.lid = lid;
-    }
-    return s;
-}
+AZ_FN bool walls_end_game(const Game &g) { return any_row_full(g.wall0) || any_row_full(g.wall1); }   // azul.py:184-191
+AZ_FN bool is_end_of_game(const Game &g) { return g.over != 0u; }
 
 template <bool LID>
 AZ_FN void count_score(Game &g, const LaneConst &k)
 {
+    // azul.py:291-295 for both players, then the full lines are emptied (:218)
     u64 F = full_lines(g, k);
-    g.wi0 = score_player<true, LID, 0>(g, F);
-    g.wi1 = score_player<true, LID, 1>(g, F);
+    ScoreVec sv;
+    score_vec(g, k, F, sv);
+    i32 p0 = floor_penalty(g.floor0), p1 = floor_penalty(g.floor1);
+    g.score0 = clamp0(g.score0 + p0 + wall_points<true, LID, 0>(g, F, sv));
+    g.score1 = clamp0(g.score1 + p1 + wall_points<true, LID, 1>(g, F, sv));
+    g.fpen = (((u32)((i32)(int16_t)(g.fpen & 0xffffu) + p0)) & 0xffffu) |
+             ((((u32)((i32)(int16_t)(g.fpen >> 16) + p1)) & 0xffffu) << 16);   // :208
+    g.floor0 = g.floor1 = 0;                             // :209
     g.cp = sel(g.cp == k.rowp1, splat(0u), g.cp);        // :218
+    g.wc0 = g.wc1 = 0; g.wi0 = g.score0; g.wi1 = g.score1;
+    g.over = walls_end_game(g) ? 1u : 0u;
 }
 
-// what-if scores (game_runner.py:48-50: deepcopy + count_score).  A move only changes the MOVER's pattern
-// lines and floor, so the other player's cached value stays valid; real scoring leaves what-if == score.
+// What-if scores (game_runner.py:48-50: deepcopy + count_score).  A move only changes the MOVER's lines and
+// floor; the wall pricing of a player's full lines (wc) only changes when one more of his lines becomes full.
 template <bool LID>
 AZ_FN void whatif_refresh(Game &g, const LaneConst &k, u32 which /* 0, 1, or 2 = both */)
 {
     u64 F = full_lines(g, k);
-    if (which != 1u) g.wi0 = score_player<false, LID, 0>(g, F);
-    if (which != 0u) g.wi1 = score_player<false, LID, 1>(g, F);
+    ScoreVec sv;
+    score_vec(g, k, F, sv);
+    if (which != 1u) g.wc0 = wall_points<false, LID, 0>(g, F, sv);
+    if (which != 0u) g.wc1 = wall_points<false, LID, 1>(g, F, sv);
+    g.wi0 = clamp0(g.score0 + floor_penalty(g.floor0) + g.wc0);
+    g.wi1 = clamp0(g.score1 + floor_penalty(g.floor1) + g.wc1);
+}
+
+// derived fields after a record was loaded
+template <bool LID>
+AZ_FN void game_prime(Game &g, const LaneConst &k)
+{
+    g.over = walls_end_game(g) ? 1u : 0u;
+    whatif_refresh<LID>(g, k, 2u);
 }
 
 template <bool LID>
@@ -465,32 +542,51 @@ AZ_FN u32 new_round(Game &g, Rng &r)
     g.nfp = 0;
     vu32 l = lane();
     g.cs = sel(l == 30u, splat(1u), splat(0u));          // :71,:73
+    if (!LID) {
+#if AZ_DEVICE_BUILD
+#pragma unroll 1
+#endif
+        for (u32 t = 0; t < 20u; t++) {
+            u32 color = rng_below(r, 5u, 3u);            // :78 randrange(0,5,1)
+            g.cs = g.cs + sel(l == (t >> 2) * 5u + color, splat(1u), splat(0u));   // :88
+        }
+        return ST_OK;
+    }
+    // "Lid" pool: every draw is one random.choices -> exactly one random() = two MT words, so the 20 draws
+    // consume words pos..pos+39.  When they do not straddle a regeneration, all 40 are tempered and turned
+    // into the 20 uniform doubles by the lanes up front (lane t: draw t); otherwise word by word.
+    const bool batched = r.pos + 40u <= 624u;
+    vf64 rnd = mkrandom(splat(0u), splat(0u));
+    if (batched) {
+        vu32 wa = lds_ld(r.lds, r.pos + 2u * l, l < 20u), wb = lds_ld(r.lds, r.pos + 2u * l + 1u, l < 20u);
+        rnd = mkrandom(temper_v(wa), temper_v(wb));
+    }
+    u32 total = byte_sum5(g.box);
 #if AZ_DEVICE_BUILD
 #pragma unroll 1
 #endif
     for (u32 t = 0; t < 20u; t++) {
-        u32 disp = t >> 2;
-        u32 color;
-        if (!LID) {
-            color = rng_below(r, 5u, 3u);                // :78 randrange(0,5,1)
-        } else {
-            if (byte_sum5(g.box) == 0u) { g.box = g.lid; g.lid = 0; }     // :81-83
-            u32 total = byte_sum5(g.box);                // :85
+        if (AZ_UNLIKELY(total == 0u)) {                                              // :81-83, :85
+            g.box = g.lid; g.lid = 0; total = byte_sum5(g.box);
             if (total == 0u) return ST_BOX_EMPTY;
-            // weights = box_c / total (fp64), cumulative left-to-right, x = random() * cum[-1]   (:87, choices)
-            u32 blo = (u32)g.box, bhi = (u32)(g.box >> 32);
-            vu32 mine = sel(l < 4u, (blo >> ((l & 3u) * 8u)) & 0xffu, splat(bhi & 0xffu));
-            vf64 wq = divlanes(mine, (double)total);
-            double c0 = readlane_d(wq, 0);
-            double c1 = c0 + readlane_d(wq, 1);
-            double c2 = c1 + readlane_d(wq, 2);
-            double c3 = c2 + readlane_d(wq, 3);
-            double c4 = c3 + readlane_d(wq, 4);
-            double x = rng_random(r) * (c4 + 0.0);
-            color = (x < c0) ? 0u : (x < c1) ? 1u : (x < c2) ? 2u : (x < c3) ? 3u : 4u;   // bisect_right(cum, x, 0, 4)
-            g.box -= 1ull << (8u * color);               // :89
         }
-        g.cs = g.cs + sel(l == disp * 5u + color, splat(1u), splat(0u));   // :88
+        // weights = box_c / total (fp64), cumulative left-to-right, x = random() * cum[-1]   (:87, choices)
+        u32 blo = (u32)g.box, bhi = (u32)(g.box >> 32);
+        vu32 mine = sel(l < 4u, (blo >> ((l & 3u) * 8u)) & 0xffu, splat(bhi & 0xffu));
+        vf64 wq = divlanes(mine, (double)total);
+        double c0 = readlane_d(wq, 0);
+        double c1 = c0 + readlane_d(wq, 1);
+        double c2 = c1 + readlane_d(wq, 2);
+        double c3 = c2 + readlane_d(wq, 3);
+        double c4 = c3 + readlane_d(wq, 4);
+        double u;
+        if (batched) { u = readlane_d(rnd, t); r.pos += 2u; }
+        else u = rng_random(r);
+        double x = u * (c4 + 0.0);
+        u32 color = (u32)!(x < c0) + (u32)!(x < c1) + (u32)!(x < c2) + (u32)!(x < c3);    // bisect_right(cum, x, 0, 4): cum is non-decreasing
+        g.box -= 1ull << (8u * color);                   // :89
+        total -= 1u;
+        g.cs = g.cs + sel(l == (t >> 2) * 5u + color, splat(1u), splat(0u));   // :88
     }
     return ST_OK;
 }
@@ -503,7 +599,7 @@ AZ_FN void game_ctor(Game &g, u32 first_player, Rng &r)
     g.wall0 = g.wall1 = 0; g.score0 = g.score1 = 0; g.floor0 = g.floor1 = 0;
     g.cur = 0; g.eog = 0; g.turn = 0;
     g.fps = 0; g.fpen = 0; g.maxc = 0; g.compl_ = 0;
-    g.wi0 = g.wi1 = 0;
+    g.wc0 = g.wc1 = 0; g.wi0 = g.wi1 = 0; g.over = 0;
     if (first_player == 0u) g.nfp = 1u + rng_below(r, 2u, 2u);           // random.choice([1,2]) (:37)
     else g.nfp = first_player;
     if (LID) { g.box = 0x1414141414ull; g.lid = 0; }                      // :51-52
@@ -533,13 +629,15 @@ AZ_FN bool move_and_score(Game &g, const LaneConst &k, u32 a)
     u32 d, c, row;
     decode_action(a, d, c, row);
     u32 me = me_index(g);
-    do_move<LID>(g, d, c, row);                          // :304
+    bool filled = do_move<LID>(g, d, c, row);            // :304
     if (sources_board(g) == 0u) {                        // :306 (the token counts)
         count_score<LID>(g, k);                          // :307
         if (is_end_of_game(g)) { g.eog = 1; return false; }   // :308-309
         return true;                                     // :311
     }
-    whatif_refresh<LID>(g, k, me);
+    if (filled) whatif_refresh<LID>(g, k, me);
+    else if (me) g.wi1 = clamp0(g.score1 + floor_penalty(g.floor1) + g.wc1);
+    else g.wi0 = clamp0(g.score0 + floor_penalty(g.floor0) + g.wc0);
     g.cur = (g.cur < 2u) ? g.cur + 1u : 1u;              // :313 next_player
     return false;
 }
@@ -564,7 +662,7 @@ AZ_FN u32 checked_step(Game &g, const LaneConst &k, Rng &r, i32 a)
 
 // ---- GameRunner.step with the default RandomAgent opponent: game_runner.py:43-55 ----
 template <bool LID>
-AZ_FN u32 runner_opponent_loop(Game &g, const LaneConst &k, Rng &r, const double *T, bool until_player1_only)
+AZ_FN u32 runner_opponent_loop(Game &g, const LaneConst &k, Rng &r, const SampleTab &T, bool until_player1_only)
 {
 #if AZ_DEVICE_BUILD
 #pragma unroll 1
@@ -586,7 +684,7 @@ AZ_FN u32 runner_opponent_loop(Game &g, const LaneConst &k, Rng &r, const double
 }
 
 template <bool LID>
-AZ_FN u32 runner_step(Game &g, const LaneConst &k, Rng &r, const double *T, i32 a, i32 &reward, u32 &done)
+AZ_FN u32 runner_step(Game &g, const LaneConst &k, Rng &r, const SampleTab &T, i32 a, i32 &reward, u32 &done)
 {
     reward = 0;
     done = is_end_of_game(g) ? 1u : 0u;
@@ -695,17 +793,20 @@ struct Counters {
 
 // returns 0 = move played, 1 = game ended with this move, 2 = stuck, 0x100|status on a rule error.
 // Control flow keeps ONE copy of every heavy block (ctor, new_round) in the instruction stream.
-template <bool LID>
-AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, const double *T, const Counters &cnt,
+// OUT: 0 = no trajectory outputs, 1 = mask + maskbits + action + reward + done all present (rec absent),
+//      2 = any subset, checked at run time
+template <bool LID, int OUT>
+AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, const SampleTab &T, const Counters &cnt,
                         uint8_t *mask_out, u64 *maskbits_out, i32 *action_out, i32 *reward_out, uint8_t *done_out, uint8_t *rec_out)
 {
+#define AZ_HAS(p) (OUT == 1 ? true : (OUT == 0 ? false : (p) != nullptr))
     Mask m;
     legal_mask(g, k, m);
-    if (mask_out) mask_write(m, mask_out);
-    if (maskbits_out) mask_write_bits(m, maskbits_out);
+    if (AZ_HAS(mask_out)) mask_write(m, mask_out);
+    if (AZ_HAS(maskbits_out)) mask_write_bits(m, maskbits_out);
     i32 a = g.eog ? -2 : random_agent(m, r, T);
     bool deal = false;                 // a new round has to be dealt
-    if (a >= 0) {
+    if (!AZ_UNLIKELY(a < 0)) {
         deal = move_and_score<LID>(g, k, (u32)a);
         g.moves += 1u;
     }
@@ -727,10 +828,10 @@ AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, c
             dn = 2u;                   // stuck (or handed an already finished game): report, restart the slot
             AZ_LANE0(*cnt.stuck += 1u);
         }
-        if (action_out) AZ_LANE0(*action_out = (a >= 0 ? a : -1));
-        if (reward_out) AZ_LANE0(*reward_out = reward);
-        if (done_out) AZ_LANE0(*done_out = (uint8_t)dn);
-        if (rec_out) game_store(g, rec_out);
+        if (AZ_HAS(action_out)) stu_i32(action_out, a >= 0 ? a : -1);
+        if (AZ_HAS(reward_out)) stu_i32(reward_out, reward);
+        if (AZ_HAS(done_out)) stu_u8(done_out, dn);
+        if (OUT == 2 && rec_out) game_store(g, rec_out);
         result = dn;
         if (dn == 0u) break;
         if (dn == 1u) {
@@ -743,6 +844,7 @@ AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, c
         deal = true;
     }
     return st ? (0x100u | st) : result;
+#undef AZ_HAS
 }
 
 } // namespace az

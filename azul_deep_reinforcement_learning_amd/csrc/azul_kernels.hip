@@ -31,7 +31,7 @@ struct BatchDev {
     uint8_t *state;      // [N][128]
     u32 *mt;             // [N][624]
     u32 *mtpos;          // [N]
-    const double *T;     // [31][151]
+    const double *T;     // SampleTab source: Fr[31][8] then S[31]
     u64 *episodes;       // [N]
     u32 *stuck;          // [N]
     double *stat_sum;    // [N][10]
@@ -85,12 +85,15 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
     LaneConst k;
     lane_consts(k);
+    SampleTab tab;
+    sample_tab_load(tab, b.T);
     Game g;
     game_load(g, rec);
+    game_prime<LID>(g, k);
     u32 st = ST_OK;
     if (act && a.op != OP_QUERY) {
         Rng r;
-        r.gmt = b.mt + (size_t)gi * 624u; r.lds = mt_lds; r.pos = b.mtpos[gi]; r.dirty = 0;
+        r.gmt = b.mt + (size_t)gi * 624u; r.lds = mt_lds; r.pos = b.mtpos[gi]; r.dirty = 0; r.wbase = 0x80000000u; r.win = 0u;
         const bool use_rng = op_needs_rng(a.op);
         if (use_rng) rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]);
         bool dirty_state = true;
@@ -123,12 +126,12 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
             break;
         case OP_RUNNER_RESET:
             st = episode_reset<LID>(g, b.rules.first_player, r);
-            if (!st) st = runner_opponent_loop<LID>(g, k, r, b.T, true);
+            if (!st) st = runner_opponent_loop<LID>(g, k, r, tab, true);
             break;
         case OP_RUNNER_STEP: {
             i32 rew = 0;
             u32 dn = 0;
-            st = runner_step<LID>(g, k, r, b.T, a.actions[gi], rew, dn);
+            st = runner_step<LID>(g, k, r, tab, a.actions[gi], rew, dn);
             dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION);
             if (a.reward) AZ_LANE0(a.reward[gi] = rew);
             if (a.done) AZ_LANE0(a.done[gi] = (uint8_t)dn);
@@ -141,7 +144,7 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
         case OP_RANDOM_ACTION: {
             Mask m;
             legal_mask(g, k, m);
-            i32 av = random_agent(m, r, b.T);
+            i32 av = random_agent(m, r, tab);
             AZ_LANE0(a.actions_out[gi] = av);
             dirty_state = false;
         } break;
@@ -152,7 +155,7 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
             m.m0 = ballot(ld_u8(mi, l, l < 64u) != 0u);
             m.m1 = ballot(ld_u8(mi, l + 64u, l < 64u) != 0u);
             m.m2 = ballot(ld_u8(mi, l + 128u, l < 52u) != 0u);
-            i32 av = random_agent(m, r, b.T);
+            i32 av = random_agent(m, r, tab);
             AZ_LANE0(a.actions_out[gi] = av);
             dirty_state = false;
         } break;
@@ -198,7 +201,7 @@ struct TrajArgs {
     uint8_t *rec;      // [T][N][128]
 };
 
-template <bool LID>
+template <bool LID, int OUT>
 __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs t)
 {
     __shared__ u32 mt_lds[624];
@@ -207,23 +210,28 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
     LaneConst k;
     lane_consts(k);
+    SampleTab tab;
+    sample_tab_load(tab, b.T);
     Game g;
     game_load(g, rec);
-    whatif_refresh<LID>(g, k, 2u);
+    game_prime<LID>(g, k);
     Rng r;
     rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]);
     Counters cnt = {b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10};
+    // running output pointers: one 64-bit add per stream and step instead of row * stride multiplies
+    uint8_t *pm = t.mask ? t.mask + (size_t)gi * AZUL_NUM_ACTIONS : nullptr;
+    u64 *pb = t.maskbits ? t.maskbits + (size_t)gi * 3 : nullptr;
+    i32 *pa = t.action ? t.action + gi : nullptr;
+    i32 *pr = t.reward ? t.reward + gi : nullptr;
+    uint8_t *pd = t.done ? t.done + gi : nullptr;
+    uint8_t *pc = t.rec ? t.rec + (size_t)gi * AZUL_RECORD_BYTES : nullptr;
+    const size_t sm = pm ? N * AZUL_NUM_ACTIONS : 0, sb = pb ? N * 3 : 0, sa = pa ? N : 0, sr = pr ? N : 0, sd = pd ? N : 0,
+                 sc = pc ? N * AZUL_RECORD_BYTES : 0;            // a NULL stream stays NULL
 #pragma unroll 1
     for (int s = 0; s < t.n_steps; s++) {
-        const size_t row = (size_t)s * N + gi;
-        u32 f = selfplay_step<LID>(g, b.rules.first_player, k, r, b.T, cnt,
-                                   t.mask ? t.mask + row * AZUL_NUM_ACTIONS : nullptr,
-                                   t.maskbits ? t.maskbits + row * 3 : nullptr,
-                                   t.action ? t.action + row : nullptr,
-                                   t.reward ? t.reward + row : nullptr,
-                                   t.done ? t.done + row : nullptr,
-                                   t.rec ? t.rec + row * AZUL_RECORD_BYTES : nullptr);
+        u32 f = selfplay_step<LID, OUT>(g, b.rules.first_player, k, r, tab, cnt, pm, pb, pa, pr, pd, pc);
         if (f & 0x100u) break;      // rule error (box empty): leave the game as it is
+        pm += sm; pb += sb; pa += sa; pr += sr; pd += sd; pc += sc;
     }
     game_store(g, rec);
     rng_close(r, b.mtpos + gi);
@@ -274,12 +282,12 @@ int azul_batch_create(azul_batch_t **out, int n_games, int first_player, int til
     HIP_TRY(hipMalloc((void **)&b->d.state, N * AZUL_RECORD_BYTES));
     HIP_TRY(hipMalloc((void **)&b->d.mt, N * 624 * sizeof(u32)));
     HIP_TRY(hipMalloc((void **)&b->d.mtpos, N * sizeof(u32)));
-    HIP_TRY(hipMalloc((void **)&T, sizeof(double) * T_ROWS * T_COLS));
+    HIP_TRY(hipMalloc((void **)&T, sizeof(double) * T_WORDS));
     HIP_TRY(hipMalloc((void **)&b->d.episodes, N * sizeof(u64)));
     HIP_TRY(hipMalloc((void **)&b->d.stuck, N * sizeof(u32)));
     HIP_TRY(hipMalloc((void **)&b->d.stat_sum, N * 10 * sizeof(double)));
-    std::vector<double> hT((size_t)T_ROWS * T_COLS);
-    build_weight_table(hT.data());
+    std::vector<double> hT((size_t)T_WORDS);
+    if (!build_sample_tab(hT.data())) return fail(AZUL_ERR_INVALID, "weight-table decomposition check failed on this host");
     HIP_TRY(hipMemcpy(T, hT.data(), hT.size() * sizeof(double), hipMemcpyHostToDevice));
     b->d.T = T;
     HIP_TRY(hipMemset(b->d.state, 0, N * AZUL_RECORD_BYTES));
@@ -521,10 +529,16 @@ int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_
     if (!b || n_steps < 0) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: bad arguments");
     if (n_steps == 0) return AZUL_SUCCESS;
     TrajArgs t = {n_steps, mask_dev, (u64 *)maskbits_dev, action_dev, reward_dev, done_dev, rec_dev};
-    if (b->d.rules.tile_pool == POOL_LID)
-        hipLaunchKernelGGL(azul_selfplay_kernel<true>, dim3(b->d.n), dim3(64), 0, (hipStream_t)stream, b->d, t);
-    else
-        hipLaunchKernelGGL(azul_selfplay_kernel<false>, dim3(b->d.n), dim3(64), 0, (hipStream_t)stream, b->d, t);
+    const bool none = !mask_dev && !maskbits_dev && !action_dev && !reward_dev && !done_dev && !rec_dev;
+    const bool full = mask_dev && maskbits_dev && action_dev && reward_dev && done_dev && !rec_dev;
+    const dim3 grid(b->d.n), block(64);
+    const hipStream_t st = (hipStream_t)stream;
+#define AZ_LAUNCH(LID) do { \
+        if (none) hipLaunchKernelGGL((azul_selfplay_kernel<LID, 0>), grid, block, 0, st, b->d, t); \
+        else if (full) hipLaunchKernelGGL((azul_selfplay_kernel<LID, 1>), grid, block, 0, st, b->d, t); \
+        else hipLaunchKernelGGL((azul_selfplay_kernel<LID, 2>), grid, block, 0, st, b->d, t); } while (0)
+    if (b->d.rules.tile_pool == POOL_LID) AZ_LAUNCH(true); else AZ_LAUNCH(false);
+#undef AZ_LAUNCH
     HIP_TRY(hipGetLastError());
     if (b->timing) b->timed_launches++;
     return AZUL_SUCCESS;

@@ -7,17 +7,36 @@ namespace az {
 // RandomAgent (game_runner.py:87-97) hands random.choices the weights 0.01 (actions 0..29, pattern 0)
 // or 1.0 (actions 30..179) times the legal mask.  CPython accumulates them left to right in fp64, and
 // adding an exact 0.0 never changes the sum, so the cumulative weight after J legal floor moves and m
-// legal pattern moves is one of 31*151 doubles: T[J][0] = T[J-1][0] + 0.01, T[J][m] = T[J][m-1] + 1.0.
-// Built with the very IEEE additions CPython performs (this file is compiled without fast-math).
-static inline void build_weight_table(double *T)
+// legal pattern moves is T[J][m] with T[J][0] = T[J-1][0] + 0.01 and T[J][m] = T[J][m-1] + 1.0.
+// build_weight_table() performs exactly those IEEE additions (this file is compiled without fast-math).
+static inline void build_weight_table(double *T /* [31][151] */)
 {
     double s = 0.0;
-    for (int J = 0; J < T_ROWS; J++) {
+    for (int J = 0; J < 31; J++) {
         if (J > 0) s = s + 0.01;
         double c = s;
-        T[J * T_COLS] = c;
-        for (int m = 1; m < T_COLS; m++) { c = c + 1.0; T[J * T_COLS + m] = c; }
+        T[J * 151] = c;
+        for (int m = 1; m < 151; m++) { c = c + 1.0; T[J * 151 + m] = c; }
     }
+}
+
+// Compact form used by the kernels: Fr[J][b] = T[J][2^b] - 2^b (exact), S[J] = T[J][0]; then
+// T[J][m] == m + Fr[J][floor(log2 m)] for every m in 1..150.  Returns false if that identity ever failed.
+static inline bool build_sample_tab(double *tab /* T_WORDS */)
+{
+    double T[31 * 151];
+    build_weight_table(T);
+    for (int J = 0; J < 31; J++) {
+        for (int b = 0; b < 8; b++) tab[J * 8 + b] = T[J * 151 + (1 << b)] - (double)(1 << b);
+        tab[31 * 8 + J] = T[J * 151];
+    }
+    bool ok = true;
+    for (int J = 0; J < 31; J++)
+        for (int m = 1; m < 151; m++) {
+            int b = 31 - __builtin_clz((unsigned)m);
+            if ((double)m + tab[J * 8 + b] != T[J * 151 + m]) ok = false;
+        }
+    return ok;
 }
 
 } // namespace az

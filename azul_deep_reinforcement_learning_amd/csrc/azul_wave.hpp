@@ -52,6 +52,8 @@ AZ_FN vu32 mbcnt(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __bui
 // per-lane IEEE fp64 quotient num/den (den uniform); hipcc emits the correctly rounded
 // v_div_scale/v_rcp/v_fma/v_div_fmas/v_div_fixup sequence (no fast-math in this build)
 AZ_FN vf64 divlanes(vu32 num, double den) { return (double)num / den; }
+// CPython random_random() from two tempered words per lane: (a>>5, b>>6) -> (a*2^26 + b) / 2^53
+AZ_FN vf64 mkrandom(vu32 a, vu32 b) { return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0); }
 AZ_FN double readlane_d(vf64 v, u32 l)
 {
     u64 b = (u64)__double_as_longlong(v);
@@ -62,6 +64,8 @@ AZ_FN u32 popc64(u64 x) { return (u32)__builtin_popcountll(x); }
 AZ_FN u32 ctz64(u64 x) { return (u32)__builtin_ctzll(x); }
 AZ_FN u32 ctz32(u32 x) { return (u32)__builtin_ctz(x); }
 AZ_FN u32 clz32(u32 x) { return (u32)__builtin_clz(x); }
+AZ_FN vu32 vctz(vu32 x) { return (u32)__builtin_ctz(x); }      // x != 0
+AZ_FN vu32 vclz(vu32 x) { return (u32)__builtin_clz(x); }      // x != 0
 
 // memory (addresses: uniform base + per-lane offset)
 AZ_FN vu32 ld_u8(const uint8_t *base, vu32 off, vbool act) { return act ? (u32)base[off] : 0u; }
@@ -69,6 +73,7 @@ AZ_FN void st_u8(uint8_t *base, vu32 off, vu32 val, vbool act) { if (act) base[o
 AZ_FN vu32 ld_u32(const u32 *base, vu32 off, vbool act) { return act ? base[off] : 0u; }
 AZ_FN void st_u32(u32 *base, vu32 off, vu32 val, vbool act) { if (act) base[off] = val; }
 AZ_FN void st_f32(float *base, vu32 off, vu32 ival, vbool act) { if (act) base[off] = (float)(i32)ival; }
+AZ_FN vf64 ld_f64(const double *base, vu32 off, vbool act) { return act ? base[off] : 0.0; }
 // LDS (one private region per wave; a wave's DS operations execute in program order)
 AZ_FN vu32 lds_ld(const u32 *lds, vu32 idx, vbool act) { return act ? lds[idx] : 0u; }
 AZ_FN void lds_st(u32 *lds, vu32 idx, vu32 val, vbool act) { if (act) lds[idx] = val; }
@@ -76,6 +81,19 @@ AZ_FN u32  lds_ldu(const u32 *lds, u32 idx) { return __builtin_amdgcn_readfirstl
 AZ_FN void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 // run `stmt` on one lane only (uniform values -> memory)
 #define AZ_LANE0(stmt) do { if (wv::lane() == 0) { stmt; } } while (0)
+// store a uniform value from EVERY lane (same address, same data: one coalesced request, no exec masking, no branch)
+#ifdef AZ_STU_LANE0
+AZ_FN void stu_i32(i32 *p, i32 v) { if (lane() == 0) *p = v; }
+AZ_FN void stu_u8(uint8_t *p, u32 v) { if (lane() == 0) *p = (uint8_t)v; }
+AZ_FN void stu_u64(u64 *p, u64 v) { if (lane() == 0) *p = v; }
+#else
+AZ_FN void stu_i32(i32 *p, i32 v) { *p = v; }
+AZ_FN void stu_u8(uint8_t *p, u32 v) { *p = (uint8_t)v; }
+AZ_FN void stu_u64(u64 *p, u64 v) { *p = v; }
+#endif
+AZ_FN vf64 self64(bool c, vf64 a, vf64 b) { return c ? a : b; }
+AZ_FN vu32 vmin(vu32 a, u32 b) { return a < b ? a : b; }
+#define AZ_UNLIKELY(x) __builtin_expect(!!(x), 0)
 } // namespace wv
 
 #else
@@ -125,17 +143,27 @@ AZ_FN vu32 sel(const vbool &p, const vu32 &a, u32 b) { return sel(p, a, splat(b)
 AZ_FN vu32 sel(const vbool &p, u32 a, u32 b) { return sel(p, splat(a), splat(b)); }
 AZ_FN vu32 mbcnt(u64 m) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = (u32)__builtin_popcountll(m & ((1ull << i) - 1)); return r; }
 AZ_FN vf64 divlanes(const vu32 &num, double den) { vf64 r; for (int i = 0; i < 64; i++) r.v[i] = (double)num.v[i] / den; return r; }
+AZ_FN vf64 mkrandom(const vu32 &a, const vu32 &b)
+{
+    vf64 r;
+    for (int i = 0; i < 64; i++) r.v[i] = ((double)(a.v[i] >> 5) * 67108864.0 + (double)(b.v[i] >> 6)) * (1.0 / 9007199254740992.0);
+    return r;
+}
 AZ_FN double readlane_d(const vf64 &v, u32 l) { return v.v[l & 63]; }
 AZ_FN u32 popc64(u64 x) { return (u32)__builtin_popcountll(x); }
 AZ_FN u32 ctz64(u64 x) { return (u32)__builtin_ctzll(x); }
 AZ_FN u32 ctz32(u32 x) { return (u32)__builtin_ctz(x); }
 AZ_FN u32 clz32(u32 x) { return (u32)__builtin_clz(x); }
+AZ_FN vu32 vctz(const vu32 &x) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[i] ? (u32)__builtin_ctz(x.v[i]) : 32u; return r; }
+AZ_FN vu32 vclz(const vu32 &x) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[i] ? (u32)__builtin_clz(x.v[i]) : 32u; return r; }
+AZ_FN vu32 operator~(const vu32 &a) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = ~a.v[i]; return r; }
 
 AZ_FN vu32 ld_u8(const uint8_t *base, const vu32 &off, const vbool &act) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = act.v[i] ? base[off.v[i]] : 0u; return r; }
 AZ_FN void st_u8(uint8_t *base, const vu32 &off, const vu32 &val, const vbool &act) { for (int i = 0; i < 64; i++) if (act.v[i]) base[off.v[i]] = (uint8_t)val.v[i]; }
 AZ_FN vu32 ld_u32(const u32 *base, const vu32 &off, const vbool &act) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = act.v[i] ? base[off.v[i]] : 0u; return r; }
 AZ_FN void st_u32(u32 *base, const vu32 &off, const vu32 &val, const vbool &act) { for (int i = 0; i < 64; i++) if (act.v[i]) base[off.v[i]] = val.v[i]; }
 AZ_FN void st_f32(float *base, const vu32 &off, const vu32 &ival, const vbool &act) { for (int i = 0; i < 64; i++) if (act.v[i]) base[off.v[i]] = (float)(i32)ival.v[i]; }
+AZ_FN vf64 ld_f64(const double *base, const vu32 &off, const vbool &act) { vf64 r; for (int i = 0; i < 64; i++) r.v[i] = act.v[i] ? base[off.v[i]] : 0.0; return r; }
 AZ_FN vu32 lds_ld(const u32 *lds, const vu32 &idx, const vbool &act) { return ld_u32(lds, idx, act); }
 AZ_FN void lds_st(u32 *lds, const vu32 &idx, const vu32 &val, const vbool &act)
 {
@@ -145,5 +173,11 @@ AZ_FN void lds_st(u32 *lds, const vu32 &idx, const vu32 &val, const vbool &act)
 AZ_FN u32  lds_ldu(const u32 *lds, u32 idx) { return lds[idx]; }
 AZ_FN void lds_fence() {}
 #define AZ_LANE0(stmt) do { stmt; } while (0)
+AZ_FN void stu_i32(i32 *p, i32 v) { *p = v; }
+AZ_FN void stu_u8(uint8_t *p, u32 v) { *p = (uint8_t)v; }
+AZ_FN void stu_u64(u64 *p, u64 v) { *p = v; }
+AZ_FN vf64 self64(bool c, const vf64 &a, const vf64 &b) { return c ? a : b; }
+AZ_FN vu32 vmin(const vu32 &a, u32 b) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] < b ? a.v[i] : b; return r; }
+#define AZ_UNLIKELY(x) __builtin_expect(!!(x), 0)
 } // namespace wv
 #endif

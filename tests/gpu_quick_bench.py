@@ -8,9 +8,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 env = BatchedAzul(n)
 env.seed(0); env.runner_init(); env.runner_init()
-t = env.alloc_trajectory(T)
+t = env.alloc_trajectory(T, packed_mask=True)
 for _ in range(3):
-    env.selfplay(T, t["mask"], t["action"], t["reward"], t["done"])
+    env.selfplay(T, t["mask"], t["action"], t["reward"], t["done"], maskbits=t["maskbits"])
 torch.cuda.synchronize()
 for outputs in (True, False):
     env.timing_begin()
@@ -18,7 +18,7 @@ for outputs in (True, False):
     reps = 20
     for _ in range(reps):
         if outputs:
-            env.selfplay(T, t["mask"], t["action"], t["reward"], t["done"])
+            env.selfplay(T, t["mask"], t["action"], t["reward"], t["done"], maskbits=t["maskbits"])
         else:
             env.selfplay(T)
     ms, launches = env.timing_end()

@@ -9,12 +9,13 @@
 
 using namespace az;
 
-static double g_T[T_ROWS * T_COLS];
+static double g_T[T_WORDS];
+static SampleTab g_tab;
 static bool g_T_ready = false;
-static const double *table()
+static const SampleTab &table()
 {
-    if (!g_T_ready) { build_weight_table(g_T); g_T_ready = true; }
-    return g_T;
+    if (!g_T_ready) { build_sample_tab(g_T); sample_tab_load(g_tab, g_T); g_T_ready = true; }
+    return g_tab;
 }
 
 struct HostStream {
@@ -33,12 +34,12 @@ static int advance(HostStream *h, int n_steps, uint8_t *mask, int32_t *action, i
 {
     LaneConst k; lane_consts(k);
     Game g; game_load(g, h->rec);
-    whatif_refresh<LID>(g, k, 2u);
+    game_prime<LID>(g, k);
     Rng r; rng_open(r, h->mt, h->lds, h->pos);
     Counters cnt = {&h->episodes, &h->stuck, h->stat_sum};
     int rc = 0;
     for (int t = 0; t < n_steps; t++) {
-        u32 f = selfplay_step<LID>(g, h->rules.first_player, k, r, table(), cnt,
+        u32 f = selfplay_step<LID, 2>(g, h->rules.first_player, k, r, table(), cnt,
                                    mask ? mask + (size_t)t * 180 : 0, (u64 *)0, action ? action + t : 0, reward ? reward + t : 0,
                                    done ? done + t : 0, rec_after ? rec_after + (size_t)t * 128 : 0);
         if (f & 0x100u) { rc = (int)(f & 0xff); break; }
@@ -53,7 +54,8 @@ static int advance(HostStream *h, int n_steps, uint8_t *mask, int32_t *action, i
 
 extern "C" {
 
-void hc_weight_table(double *out) { memcpy(out, table(), sizeof(g_T)); }
+void hc_weight_table(double *out /* [31][151] */) { build_weight_table(out); }
+int hc_sample_tab_ok() { double t[T_WORDS]; return build_sample_tab(t) ? 1 : 0; }
 
 HostStream *hc_stream_new(unsigned long long seed, int first_player, int tile_pool)
 {
@@ -116,7 +118,9 @@ int hc_potential(const uint8_t *rec, int tile_pool)
 
 int hc_flags(const uint8_t *rec)
 {
+    LaneConst k; lane_consts(k);
     Game g; game_load(g, rec);
+    game_prime<false>(g, k);
     return (sources_board(g) == 0u ? 1 : 0) | (is_end_of_game(g) ? 2 : 0) | (g.eog ? 4 : 0);
 }
 
@@ -142,6 +146,7 @@ int hc_step(uint8_t *rec, int action, int first_player, int tile_pool, u32 *mt, 
     (void)first_player;
     LaneConst k; lane_consts(k);
     Game g; game_load(g, rec);
+    if (tile_pool == POOL_LID) game_prime<true>(g, k); else game_prime<false>(g, k);
     Rng r; rng_open(r, mt, lds, *pos);
     u32 st = BY_POOL(tile_pool, checked_step<true>(g, k, r, action), checked_step<false>(g, k, r, action));
     if (st != ST_ILLEGAL_MOVE && st != ST_GAME_ENDED && st != ST_BAD_ACTION) game_store(g, rec);
@@ -155,6 +160,7 @@ int hc_runner_step(uint8_t *rec, int action, int first_player, int tile_pool, u3
     (void)first_player;
     LaneConst k; lane_consts(k);
     Game g; game_load(g, rec);
+    if (tile_pool == POOL_LID) game_prime<true>(g, k); else game_prime<false>(g, k);
     Rng r; rng_open(r, mt, lds, *pos);
     i32 rew = 0; u32 dn = 0;
     u32 st = BY_POOL(tile_pool, runner_step<true>(g, k, r, table(), action, rew, dn), runner_step<false>(g, k, r, table(), action, rew, dn));

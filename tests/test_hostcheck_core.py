@@ -125,3 +125,5 @@ def test_weight_table_is_cpython_accumulate():
         assert T[J, 0] == (cum[J - 1] if J else 0.0)
         for m in (1, 2, 77, 150):
             assert T[J, m] == cum[J + m - 1]
+    # the kernels' compact form m + Fr[J][floor(log2 m)] reproduces all 31 x 150 sums exactly
+    assert hc.lib().hc_sample_tab_ok() == 1

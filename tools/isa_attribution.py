@@ -1,0 +1,33 @@
+import re,collections,sys
+kern=sys.argv[1] if len(sys.argv)>1 else '_Z20azul_selfplay_kernelILb1E'
+s=open('/tmp/asm/kg.s').read()
+files={}
+for m in re.finditer(r'\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', s):
+    files[int(m.group(1))]=(m.group(3) or m.group(2)).split('/')[-1]
+m=re.search(r'^'+re.escape(kern)+r'\w*:[^\n]*$(.*?)^\.Lfunc_end', s, re.S|re.M)
+body=m.group(1).split('\n')
+cur=None; cnt=collections.Counter(); scnt=collections.Counter(); vcnt=collections.Counter()
+for l in body:
+    t=l.strip()
+    m=re.match(r'\.loc\s+(\d+)\s+(\d+)', t)
+    if m: cur=(files.get(int(m.group(1)),'?'), int(m.group(2))); continue
+    if not t or t.startswith(('.',';')) or t.endswith(':'): continue
+    op=t.split()[0]
+    cnt[cur]+=1
+    if op.startswith('s_'): scnt[cur]+=1
+    if op.startswith('v_'): vcnt[cur]+=1
+src={f:open('/root/repo/azul_deep_reinforcement_learning_amd/csrc/'+f).read().split('\n') for f in ('azul_core.hpp','azul_kernels.hip','azul_wave.hpp')}
+print("total", sum(cnt.values()), "scalar", sum(scnt.values()), "vector", sum(vcnt.values()))
+# group by function: find enclosing function name by scanning backwards for 'AZ_FN'
+def func_of(f,ln):
+    if f not in src: return f
+    for i in range(ln-1,-1,-1):
+        L=src[f][i]
+        if L.startswith('AZ_FN') or L.startswith('__global__') or 'AZ_FN' in L[:20]:
+            mm=re.search(r'(\w+)\s*\(', L); return mm.group(1) if mm else L[:30]
+    return f
+byf=collections.Counter(); byfs=collections.Counter()
+for k,c in cnt.items():
+    if k is None: continue
+    fn=func_of(*k); byf[fn]+=c; byfs[fn]+=scnt[k]
+for fn,c in byf.most_common(40): print("%5d total %5d scalar  %s"%(c,byfs[fn],fn))

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/<tag>/ (written by tools/profile_gpu.sh) into profiles/<name>_*.{csv,json,md}."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag, name = sys.argv[1], sys.argv[2]
+src = os.path.join("gpurun_out", tag)
+dst = "profiles"
+os.makedirs(dst, exist_ok=True)
+
+
+def counters(sub, kernel_filter):
+    out = collections.defaultdict(list)
+    files = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+    if not files:
+        return {}
+    for r in csv.DictReader(open(files[0])):
+        if kernel_filter in r["Kernel_Name"]:
+            out[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {"n": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)} for k, v in out.items()}
+
+
+stats_file = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+shutil.copyfile(stats_file, os.path.join(dst, "%s_kernel_stats.csv" % name))
+rows = list(csv.DictReader(open(stats_file)))
+sp = [r for r in rows if "selfplay" in r["Name"]][0]
+bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+shutil.copyfile(os.path.join(src, "bench.json"), os.path.join(dst, "%s_bench.json" % name))
+
+summary = {"tag": tag, "selfplay_kernel": {"calls": int(sp["Calls"]), "avg_ns": float(sp["AverageNs"]),
+                                             "min_ns": float(sp["MinNs"]), "max_ns": float(sp["MaxNs"])}}
+pmc = {}
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_grbm"):
+    pmc.update(counters(sub, "selfplay"))
+summary["pmc_per_launch"] = pmc
+calib = {}
+for sub, key in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
+    files = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+    if files:
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(files[0])):
+            agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in agg.items():
+            calib["%s:%s" % (k, c)] = sum(v) / len(v)
+summary["calibration_raw_KB"] = calib
+GiB = float(1 << 30)
+fac = {}
+if "calib_read_u32:FETCH_SIZE" in calib:
+    fac["fetch_bytes_per_counted_KB_u32_reads"] = GiB / calib["calib_read_u32:FETCH_SIZE"]
+if "calib_write_u8_rows:WRITE_SIZE" in calib:
+    fac["write_bytes_per_counted_KB_u8_rows"] = (GiB // 180 * 180) / calib["calib_write_u8_rows:WRITE_SIZE"]
+if "calib_write_u32:WRITE_SIZE" in calib:
+    fac["write_bytes_per_counted_KB_u32"] = GiB / calib["calib_write_u32:WRITE_SIZE"]
+summary["calibration_factors"] = fac
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    f = pmc["FETCH_SIZE"]["mean"] * fac.get("fetch_bytes_per_counted_KB_u32_reads", 1024.0)
+    w = pmc["WRITE_SIZE"]["mean"] * fac.get("write_bytes_per_counted_KB_u8_rows", 1024.0)
+    summary["hbm_bytes_per_launch"] = {"fetch": f, "write": w, "total": f + w,
+                                        "note": "counter KB x calibration factor measured in this path's access widths"}
+    json.dump({"bytes_per_launch": f + w, "fetch": f, "write": w, "source": "profiles/%s_summary.json" % name,
+               "launch": "azul_selfplay_kernel, 4096 games x 64 moves"}, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+waves_steps = 4096 * 64
+if "SQ_INSTS_VALU" in pmc:
+    summary["per_wave_step"] = {k: pmc[k]["mean"] / waves_steps for k in pmc if k.startswith("SQ_")}
+summary["bench"] = {k: bench[k] for k in ("value", "ms_per_step", "roofline", "cpu_baseline") if k in bench}
+json.dump(summary, open(os.path.join(dst, "%s_summary.json" % name), "w"), indent=1)
+print(json.dumps(summary, indent=1))

@@ -50,6 +50,7 @@ def cpu_baseline(games, seed_base):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = int(os.environ.get("AZUL_CPU_THREADS", min(cores, 16)))     # a 1-GPU box shares 16 host cores
     streams, steps = min(games, 1024), 6000
     oz.bench_selfplay(seed_base, min(streams, 64), 200, cores)           # warm the pages
     t0 = time.perf_counter()

@@ -233,6 +233,10 @@ class BatchedAzul:
     def reset_counters(self):
         L.check(L.lib.azul_batch_reset_counters(self._h, self._stream()))
 
+    def set_draw_margin(self, margin):
+        """Test knob: widen the window in which the factory draw falls back to the literal fp64 computation."""
+        L.check(L.lib.azul_batch_set_draw_margin(self._h, int(margin)))
+
     def timing_begin(self):
         L.check(L.lib.azul_timing_begin(self._h, self._stream()))
 

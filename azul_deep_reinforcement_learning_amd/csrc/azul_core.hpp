@@ -25,6 +25,9 @@ using namespace wv;
 
 enum { ST_OK = 0, ST_ILLEGAL_MOVE = 1, ST_GAME_ENDED = 2, ST_STUCK = 3, ST_BAD_ACTION = 4, ST_BOX_EMPTY = 5 };
 enum { POOL_RANDOM = 0, POOL_LID = 1 };
+#ifndef AZ_DRAW_MARGIN
+#define AZ_DRAW_MARGIN 8192ull      // see new_round(): > 21.1 * 255, the largest possible fp64 disagreement window
+#endif
 enum { T_ROWS = 31, T_BINADES = 8, T_WORDS = T_ROWS * T_BINADES + T_ROWS };   // RandomAgent weight table, see azul_tables.hpp
 
 struct Rules {
@@ -43,6 +46,7 @@ struct Rng {
     u32 pos;        // CPython's `index` (0..624)
     u32 dirty;      // LDS state differs from global memory (a twist happened)
     u32 wbase;      // first word held by `win` (0x80000000: none)
+    u64 margin;     // factory-draw disagreement window (new_round); AZ_DRAW_MARGIN unless a test widens it
     vu32 win;       // lane i: TEMPERED output word wbase + i  (one readlane per random word)
 };
 
@@ -57,7 +61,7 @@ AZ_FN vu32 temper_v(vu32 y)
 
 AZ_FN void rng_open(Rng &r, u32 *gmt, u32 *lds, u32 pos)
 {
-    r.gmt = gmt; r.lds = lds; r.pos = pos; r.dirty = 0; r.wbase = 0x80000000u; r.win = splat(0u);
+    r.gmt = gmt; r.lds = lds; r.pos = pos; r.dirty = 0; r.wbase = 0x80000000u; r.win = splat(0u); r.margin = AZ_DRAW_MARGIN;
 #if AZ_DEVICE_BUILD
 #pragma unroll 1
 #endif
@@ -552,40 +556,61 @@ AZ_FN u32 new_round(Game &g, Rng &r)
         }
         return ST_OK;
     }
-    // "Lid" pool: every draw is one random.choices -> exactly one random() = two MT words, so the 20 draws
-    // consume words pos..pos+39.  When they do not straddle a regeneration, all 40 are tempered and turned
-    // into the 20 uniform doubles by the lanes up front (lane t: draw t); otherwise word by word.
+    // "Lid" pool (azul.py:79-89): every draw is one random.choices over weights box_c / total -> exactly one
+    // random() = two MT words, so the 20 draws consume words pos..pos+39.  When they do not straddle a
+    // regeneration, all 40 are tempered by the lanes up front (lane t: the 53-bit integer K of draw t,
+    // random() == K / 2^53); otherwise word by word.
+    //
+    // Deciding a draw.  CPython returns  #{c < 4 : cum_c <= x}  with cum_c the left-to-right fp64 sum of
+    // fl(box_j / total) and x = fl(random() * cum_4).  In exact arithmetic that is  P_c / T <= K / 2^53, i.e.
+    // P_c * 2^53 <= K * T  (P_c = box_0 + .. + box_c, T = total).  All fp64 roundings together move cum_c and x by
+    // less than 21.1 * 2^-53 (five quotients, four sums, one product, all <= 1 + 2^-50), so the fp64 decision can
+    // differ from the exact one only if |K*T - P_c*2^53| <= 21.1 * T <= 5381.  P_c * 2^53 is a multiple of 2^32: when
+    // no multiple of 2^32 lies within AZ_DRAW_MARGIN = 8192 of K*T the integer comparison IS CPython's answer;
+    // otherwise (about 4 draws in a million) the draw is decided by the literal fp64 computation below.
     const bool batched = r.pos + 40u <= 624u;
-    vf64 rnd = mkrandom(splat(0u), splat(0u));
+    vu32 klo = splat(0u), khi = splat(0u);
     if (batched) {
-        vu32 wa = lds_ld(r.lds, r.pos + 2u * l, l < 20u), wb = lds_ld(r.lds, r.pos + 2u * l + 1u, l < 20u);
-        rnd = mkrandom(temper_v(wa), temper_v(wb));
+        vu32 wa = temper_v(lds_ld(r.lds, r.pos + 2u * l, l < 20u)) >> 5, wb = temper_v(lds_ld(r.lds, r.pos + 2u * l + 1u, l < 20u)) >> 6;
+        klo = (wa << 26) | wb;
+        khi = wa >> 6;
     }
-    u32 total = byte_sum5(g.box);
+    u64 P = ((g.box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;     // byte c = box_0 + .. + box_c
 #if AZ_DEVICE_BUILD
 #pragma unroll 1
 #endif
     for (u32 t = 0; t < 20u; t++) {
+        u32 total = (u32)(P >> 32) & 0xffu;
         if (AZ_UNLIKELY(total == 0u)) {                                              // :81-83, :85
-            g.box = g.lid; g.lid = 0; total = byte_sum5(g.box);
+            g.box = g.lid; g.lid = 0;
+            P = ((g.box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;
+            total = (u32)(P >> 32) & 0xffu;
             if (total == 0u) return ST_BOX_EMPTY;
         }
-        // weights = box_c / total (fp64), cumulative left-to-right, x = random() * cum[-1]   (:87, choices)
-        u32 blo = (u32)g.box, bhi = (u32)(g.box >> 32);
-        vu32 mine = sel(l < 4u, (blo >> ((l & 3u) * 8u)) & 0xffu, splat(bhi & 0xffu));
-        vf64 wq = divlanes(mine, (double)total);
-        double c0 = readlane_d(wq, 0);
-        double c1 = c0 + readlane_d(wq, 1);
-        double c2 = c1 + readlane_d(wq, 2);
-        double c3 = c2 + readlane_d(wq, 3);
-        double c4 = c3 + readlane_d(wq, 4);
-        double u;
-        if (batched) { u = readlane_d(rnd, t); r.pos += 2u; }
-        else u = rng_random(r);
-        double x = u * (c4 + 0.0);
-        u32 color = (u32)!(x < c0) + (u32)!(x < c1) + (u32)!(x < c2) + (u32)!(x < c3);    // bisect_right(cum, x, 0, 4): cum is non-decreasing
+        u32 Klo, Khi;
+        if (batched) { Klo = readlane(klo, t); Khi = readlane(khi, t); r.pos += 2u; }
+        else { u32 a27 = rng_u32(r) >> 5, b26 = rng_u32(r) >> 6; Klo = (a27 << 26) | b26; Khi = a27 >> 6; }
+        u64 KT = (u64)Klo * total + (((u64)Khi * total) << 32);
+        u32 color;
+        if (!AZ_UNLIKELY(((KT - r.margin) >> 32) != ((KT + r.margin) >> 32))) {
+            vu32 pc = ((u32)P >> ((l & 3u) * 8u)) & 0xffu;
+            color = popc64(ballot(((pc << 21) <= (u32)(KT >> 32)) & (l < 4u)));
+        } else {
+            // weights = box_c / total (fp64), cumulative left-to-right, x = random() * cum[-1]   (:87, choices)
+            u32 blo = (u32)g.box, bhi = (u32)(g.box >> 32);
+            vu32 mine = sel(l < 4u, (blo >> ((l & 3u) * 8u)) & 0xffu, splat(bhi & 0xffu));
+            vf64 wq = divlanes(mine, (double)total);
+            double c0 = readlane_d(wq, 0);
+            double c1 = c0 + readlane_d(wq, 1);
+            double c2 = c1 + readlane_d(wq, 2);
+            double c3 = c2 + readlane_d(wq, 3);
+            double c4 = c3 + readlane_d(wq, 4);
+            double u = ((double)Khi * 4294967296.0 + (double)Klo) * (1.0 / 9007199254740992.0);
+            double x = u * (c4 + 0.0);
+            color = (u32)!(x < c0) + (u32)!(x < c1) + (u32)!(x < c2) + (u32)!(x < c3);    // bisect_right(cum, x, 0, 4)
+        }
         g.box -= 1ull << (8u * color);                   // :89
-        total -= 1u;
+        P -= (0x0101010101ull << (8u * color)) & 0xffffffffffull;
         g.cs = g.cs + sel(l == (t >> 2) * 5u + color, splat(1u), splat(0u));   // :88
     }
     return ST_OK;

@@ -37,6 +37,7 @@ struct BatchDev {
     double *stat_sum;    // [N][10]
     u32 n;
     Rules rules;
+    u64 draw_margin;     // AZ_DRAW_MARGIN; tests widen it to force the literal fp64 factory draw
 };
 
 enum {
@@ -93,9 +94,9 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
     u32 st = ST_OK;
     if (act && a.op != OP_QUERY) {
         Rng r;
-        r.gmt = b.mt + (size_t)gi * 624u; r.lds = mt_lds; r.pos = b.mtpos[gi]; r.dirty = 0; r.wbase = 0x80000000u; r.win = 0u;
+        r.gmt = b.mt + (size_t)gi * 624u; r.lds = mt_lds; r.pos = b.mtpos[gi]; r.dirty = 0; r.wbase = 0x80000000u; r.win = 0u; r.margin = b.draw_margin;
         const bool use_rng = op_needs_rng(a.op);
-        if (use_rng) rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]);
+        if (use_rng) { rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]); r.margin = b.draw_margin; }
         bool dirty_state = true;
         switch (a.op) {
         case OP_INIT:
@@ -217,6 +218,7 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
     game_prime<LID>(g, k);
     Rng r;
     rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]);
+    r.margin = b.draw_margin;
     Counters cnt = {b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10};
     // running output pointers: one 64-bit add per stream and step instead of row * stride multiplies
     uint8_t *pm = t.mask ? t.mask + (size_t)gi * AZUL_NUM_ACTIONS : nullptr;
@@ -278,6 +280,7 @@ int azul_batch_create(azul_batch_t **out, int n_games, int first_player, int til
     b->d.n = (u32)n_games;
     b->d.rules.first_player = (u32)first_player;
     b->d.rules.tile_pool = (u32)tile_pool;
+    b->d.draw_margin = AZ_DRAW_MARGIN;
     double *T = nullptr;
     HIP_TRY(hipMalloc((void **)&b->d.state, N * AZUL_RECORD_BYTES));
     HIP_TRY(hipMalloc((void **)&b->d.mt, N * 624 * sizeof(u32)));
@@ -562,6 +565,13 @@ int azul_batch_reset_counters(azul_batch_t *b, void *stream)
     HIP_TRY(hipMemsetAsync(b->d.episodes, 0, N * sizeof(u64), (hipStream_t)stream));
     HIP_TRY(hipMemsetAsync(b->d.stuck, 0, N * sizeof(u32), (hipStream_t)stream));
     HIP_TRY(hipMemsetAsync(b->d.stat_sum, 0, N * 10 * sizeof(double), (hipStream_t)stream));
+    return AZUL_SUCCESS;
+}
+
+int azul_batch_set_draw_margin(azul_batch_t *b, uint64_t margin)
+{
+    if (!b || margin < AZ_DRAW_MARGIN || margin > 0x7fffffffull) return fail(AZUL_ERR_INVALID, "margin must be in [8192, 2^31)");
+    b->d.draw_margin = margin;
     return AZUL_SUCCESS;
 }
 

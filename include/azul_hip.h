@@ -153,6 +153,11 @@ int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_
 int azul_batch_counters(azul_batch_t *b, uint64_t *episodes_host, uint32_t *stuck_host, double *stat_sums_host, void *stream);
 int azul_batch_reset_counters(azul_batch_t *b, void *stream);
 
+/* TEST KNOB: the factory draw decides a colour in integer arithmetic unless K*T lies within `margin` of a multiple of
+ * 2^32 (then by the literal fp64 computation).  Default 8192 (proved sufficient); a wider margin only sends
+ * more draws through the fp64 path -- results are identical, tests use it to exercise that path.  Range [8192, 2^31). */
+int azul_batch_set_draw_margin(azul_batch_t *b, uint64_t margin);
+
 /* average device time (ms) of the last azul_batch_selfplay launches, measured with hipEvents on the launch stream:
  * call azul_timing_begin, launch any number of selfplay calls, then azul_timing_end (synchronises the stream). */
 int azul_timing_begin(azul_batch_t *b, void *stream);

@@ -86,3 +86,22 @@ def test_selfplay_without_outputs_matches(torch_cuda):
     b.selfplay(150)
     torch_cuda.cuda.synchronize()
     assert a.get_records().tobytes() == b.get_records().tobytes()
+
+
+def test_factory_draw_fp64_path_equals_integer_path(torch_cuda):
+    """Both decision paths of the Lid factory draw (integer fast path / literal fp64) give the oracle's games."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    n, steps = 64, 400
+    a, b = BatchedAzul(n), BatchedAzul(n)
+    b.set_draw_margin(0x7fffffff)            # every draw near a multiple of 2^32 within 2^31: always the fp64 path
+    _start(a, 321)
+    _start(b, 321)
+    a.selfplay(steps)
+    b.selfplay(steps)
+    torch_cuda.cuda.synchronize()
+    ra, rb = a.get_records(), b.get_records()
+    assert ra.tobytes() == rb.tobytes()
+    for g in range(0, n, 7):
+        s = oz.Stream(321 + g)
+        s.advance(steps, want_records=False)
+        assert s.record().tobytes() == ra[g].tobytes()

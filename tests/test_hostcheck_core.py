@@ -127,3 +127,23 @@ def test_weight_table_is_cpython_accumulate():
             assert T[J, m] == cum[J + m - 1]
     # the kernels' compact form m + Fr[J][floor(log2 m)] reproduces all 31 x 150 sums exactly
     assert hc.lib().hc_sample_tab_ok() == 1
+
+
+def test_factory_draw_literal_fp64_build_matches_oracle():
+    """libhostcheck_fp.so = the same core with the integer fast path of the factory draw disabled."""
+    import os
+    import subprocess
+    here = os.path.dirname(hc.__file__)
+    subprocess.check_call(["make", "-s", "-C", here, "libhostcheck_fp.so"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(os.path.join(here, "libhostcheck_fp.so"))
+    L.hc_stream_new.restype = C.c_void_p
+    L.hc_stream_new.argtypes = [C.c_ulonglong, C.c_int, C.c_int]
+    L.hc_stream_advance.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    for seed in range(4):
+        h = L.hc_stream_new(seed, 0, 1)
+        n = 600
+        act = np.zeros(n, np.int32)
+        rec = np.zeros((n, 128), np.uint8)
+        assert L.hc_stream_advance(h, n, None, hc.ptr(act), None, None, hc.ptr(rec)) == 0
+        eo = oz.Stream(seed, 0, 1).advance(n)
+        assert np.array_equal(eo["action"], act) and eo["rec_after"].tobytes() == rec.tobytes()

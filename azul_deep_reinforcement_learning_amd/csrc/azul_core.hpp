@@ -259,7 +259,10 @@ AZ_FN void game_store(const Game &g, uint8_t *rec)
 }
 
 // ---- legal-move mask: azul.py:162-176 over all 180 actions (game_runner.py:113-117) ----
-struct Mask { u64 m0, m1, m2; };   // action a: bit (a & 63) of word (a >> 6)
+struct Mask {
+    u64 m0, m1, m2;      // action a: bit (a & 63) of word (a >> 6)
+    vu32 b0, b1, b2;     // the same bits as 0/1 per lane (lane = a & 63): what the byte mask stores
+};
 
 AZ_FN u32 sources_board(const Game &g) { return (u32)ballot(g.cs != 0u) & 0x7fffffffu; }
 
@@ -278,9 +281,12 @@ AZ_FN void legal_mask(const Game &g, const LaneConst &k, Mask &out)
     vbool alone = (rb == 0u) | (((rb & (rb - 1u)) == 0u) & (mine != 0u));
     vbool free_ = ((wl >> (l & 31u)) & 1u) == 0u;
     u32 ok = ((u32)ballot(alone & free_ & (l < 25u)) & 0x1ffffffu) | 0x80000000u;
-    out.m0 = ballot((((B >> (k.spos[0] & 31u)) & (ok >> (k.okpos[0] & 31u))) & 1u) != 0u);
-    out.m1 = ballot((((B >> (k.spos[1] & 31u)) & (ok >> (k.okpos[1] & 31u))) & 1u) != 0u);
-    out.m2 = ballot((((B >> (k.spos[2] & 31u)) & (ok >> (k.okpos[2] & 31u))) & 1u) != 0u);
+    out.b0 = ((B >> (k.spos[0] & 31u)) & (ok >> (k.okpos[0] & 31u))) & 1u;
+    out.b1 = ((B >> (k.spos[1] & 31u)) & (ok >> (k.okpos[1] & 31u))) & 1u;
+    out.b2 = ((B >> (k.spos[2] & 31u)) & (ok >> (k.okpos[2] & 31u))) & 1u;
+    out.m0 = ballot(out.b0 != 0u);
+    out.m1 = ballot(out.b1 != 0u);
+    out.m2 = ballot(out.b2 != 0u);
 }
 
 AZ_FN u64 mask_word(const Mask &m, u32 w) { return w == 0u ? m.m0 : (w == 1u ? m.m1 : m.m2); }
@@ -297,9 +303,9 @@ AZ_FN vu32 lane_bit(u64 m)
 AZ_FN void mask_write(const Mask &m, uint8_t *out)
 {
     vu32 l = lane();
-    st_u8(out, l, lane_bit(m.m0), l < 64u);
-    st_u8(out, l + 64u, lane_bit(m.m1), l < 64u);
-    st_u8(out, vmin(l, 51u) + 128u, lane_bit(m.m2 | ((m.m2 >> 51) & 1ull) * 0xfff8000000000000ull), l < 64u);   // lanes 52.. repeat lane 51
+    st_u8(out, l, m.b0, l < 64u);
+    st_u8(out, l + 64u, m.b1, l < 64u);
+    st_u8(out, vmin(l, 51u) + 128u, sel(l < 52u, m.b2, splat((u32)(m.m2 >> 51) & 1u)), l < 64u);   // lanes 52.. repeat lane 51
 }
 
 AZ_FN void mask_write_bits(const Mask &m, u64 *out)
@@ -350,21 +356,39 @@ AZ_FN i32 random_agent(const Mask &m, Rng &r, const SampleTab &T)
     double x = rng_random(r) * total;
     // bisect_right over the cumulative weights == smallest ordinal k with cum(k) > x
     double sJ = readlane_d(T.s, J);
-    u32 kg = (x < sJ) ? ((u32)(x * 100.0) + 1u) : (J + (u32)(x - sJ) + 1u);
-    kg = kg < 1u ? 1u : kg;
-    kg = kg > L ? L : kg;
-    for (u32 it = 0; it < 400u; it++) {
-        bool below = x < tseq(T, row, lane0, J, kg - 1u), inside = x < tseq(T, row, lane0, J, kg);
-        if (AZ_UNLIKELY(below && kg > 1u)) kg -= 1u;
-        else if (AZ_UNLIKELY(!inside && kg < L)) kg += 1u;
-        else break;
+    u32 kg;
+    if (AZ_UNLIKELY(x < sJ)) {
+        // inside the 0.01-weight floor moves (rare unless nothing else is legal): generic search
+        kg = (u32)(x * 100.0) + 1u;
+        kg = kg > J ? J : kg;
+        for (u32 it = 0; it < 64u; it++) {
+            bool below = x < tseq(T, row, lane0, J, kg - 1u), inside = x < tseq(T, row, lane0, J, kg);
+            if (below && kg > 1u) kg -= 1u;
+            else if (!inside && kg < L) kg += 1u;
+            else break;
+        }
+    } else {
+        // pattern moves: cum(J + m) = m + Fr[J][ilog2 m]; the guess from x is off by at most one
+        u32 M = L - J;                                   // >= 1 here because x >= sJ implies total > sJ
+        u32 mg = (u32)(x - sJ) + 1u;
+        mg = mg > M ? M : mg;
+        for (u32 it = 0; it < 256u; it++) {
+            u32 ml = mg - 1u;
+            double lo = ml ? (double)ml + readlane_d(row, lane0 + 31u - clz32(ml | 1u)) : sJ;
+            double hi = (double)mg + readlane_d(row, lane0 + 31u - clz32(mg));
+            if (AZ_UNLIKELY(x < lo && mg > 1u)) mg -= 1u;
+            else if (AZ_UNLIKELY(!(x < hi) && mg < M)) mg += 1u;
+            else break;
+        }
+        kg = J + mg;
     }
     // kg-th legal action
     u32 in0 = kg <= c0, in1 = kg <= c0 + c1;
     u32 w = in0 ? 0u : (in1 ? 1u : 2u);
     u32 rank = kg - 1u - (in0 ? 0u : (in1 ? c0 : c0 + c1));
     u64 mw = in0 ? m.m0 : (in1 ? m.m1 : m.m2);
-    u64 hit = ballot((lane_bit(mw) != 0u) & (mbcnt(mw) == rank));
+    vu32 bw = sel(splat(in0) != 0u, m.b0, sel(splat(in1) != 0u, m.b1, m.b2));
+    u64 hit = ballot((bw != 0u) & (mbcnt(mw) == rank));
     return (i32)(w * 64u + ctz64(hit));
 }
 
@@ -576,10 +600,33 @@ AZ_FN u32 new_round(Game &g, Rng &r)
         khi = wa >> 6;
     }
     u64 P = ((g.box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;     // byte c = box_0 + .. + box_c
+    // When the box holds at least 20 tiles no refill can happen: draw t sees total T0 - t, so K*T and the margin
+    // test of all 20 draws are evaluated by the lanes before the sequential loop.
+    const u32 T0 = (u32)(P >> 32) & 0xffu;
+    const bool pre = batched && T0 >= 20u;
+    vu32 kthi = splat(0u);
+    u64 risky = 0;
+    if (pre) {
+        vu32 tt = T0 - l;                                 // valid for l < 20
+        vu32 lo = klo * tt, hi = khi * tt + vmulhi(klo, tt);
+        u32 mg = (u32)r.margin;                           // margin < 2^31
+        // a multiple of 2^32 within `margin` of K*T  <=>  lo < margin  or  lo >= 2^32 - margin
+        risky = ballot(((lo < mg) | (lo >= 0u - mg)) & (l < 20u));
+        kthi = hi;
+    }
 #if AZ_DEVICE_BUILD
 #pragma unroll 1
 #endif
     for (u32 t = 0; t < 20u; t++) {
+        if (pre && !AZ_UNLIKELY((risky >> t) & 1ull)) {
+            vu32 pc = ((u32)P >> ((l & 3u) * 8u)) & 0xffu;
+            u32 color = popc64(ballot(((pc << 21) <= readlane(kthi, t)) & (l < 4u)));
+            r.pos += 2u;
+            g.box -= 1ull << (8u * color);               // :89
+            P -= (0x0101010101ull << (8u * color)) & 0xffffffffffull;
+            g.cs = g.cs + sel(l == (t >> 2) * 5u + color, splat(1u), splat(0u));   // :88
+            continue;
+        }
         u32 total = (u32)(P >> 32) & 0xffu;
         if (AZ_UNLIKELY(total == 0u)) {                                              // :81-83, :85
             g.box = g.lid; g.lid = 0;
@@ -818,17 +865,57 @@ struct Counters {
 
 // returns 0 = move played, 1 = game ended with this move, 2 = stuck, 0x100|status on a rule error.
 // Control flow keeps ONE copy of every heavy block (ctor, new_round) in the instruction stream.
-// OUT: 0 = no trajectory outputs, 1 = mask + maskbits + action + reward + done all present (rec absent),
-//      2 = any subset, checked at run time
+// Trajectory streams of the self-play kernel.  OUT == 1 (every stream present, the benchmarked form) keeps them as
+// per-lane pointers; OUT == 2 (any subset, run-time checked, plus the test-only record stream) as scalar pointers.
+struct OutV {
+    vptr p32;    // lane 1: reward[t][g], every other lane: action[t][g]
+    vptr p8;     // done[t][g]
+    vptr p64;    // maskbits[t][g][min(lane, 2)]
+    vptr pm;     // mask[t][g][lane]  (bytes 0..63; bytes 64..127 through the +64 immediate)
+    vptr pm2;    // mask[t][g][128 + min(lane, 51)]
+    u32 s32, s8, s64, sm;   // byte strides between consecutive moves
+};
+
+AZ_FN void outv_open(OutV &o, u32 gi, u32 n, uint8_t *mask, u64 *maskbits, i32 *action, i32 *reward, uint8_t *done)
+{
+    vu32 l = lane();
+    o.p32 = vptr_sel(l == 1u, vptr_splat(reward + gi), vptr_splat(action + gi));
+    o.p8 = vptr_splat(done + gi);
+    o.p64 = vptr_off(vptr_splat(maskbits + (size_t)gi * 3), vmin(l, 2u) * 8u);
+    o.pm = vptr_off(vptr_splat(mask + (size_t)gi * 180), l);
+    o.pm2 = vptr_off(vptr_splat(mask + (size_t)gi * 180 + 128), vmin(l, 51u));
+    o.s32 = n * 4u; o.s8 = n; o.s64 = n * 24u; o.sm = n * 180u;
+}
+
+AZ_FN void outv_next(OutV &o)
+{
+    o.p32 = vptr_add(o.p32, o.s32); o.p8 = vptr_add(o.p8, o.s8); o.p64 = vptr_add(o.p64, o.s64);
+    o.pm = vptr_add(o.pm, o.sm); o.pm2 = vptr_add(o.pm2, o.sm);
+}
+
+struct OutS { uint8_t *mask; u64 *maskbits; i32 *action; i32 *reward; uint8_t *done; uint8_t *rec; };
+
+// OUT: 0 = no trajectory outputs, 1 = all five streams through OutV, 2 = any subset through OutS (run-time checks)
+// returns 0 = move played, 1 = game ended with this move, 2 = stuck, 0x100|status on a rule error.
+// Control flow keeps ONE copy of every heavy block (ctor, new_round) in the instruction stream.
 template <bool LID, int OUT>
 AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, const SampleTab &T, const Counters &cnt,
-                        uint8_t *mask_out, u64 *maskbits_out, i32 *action_out, i32 *reward_out, uint8_t *done_out, uint8_t *rec_out)
+                        const OutV &ov, const OutS &os)
 {
-#define AZ_HAS(p) (OUT == 1 ? true : (OUT == 0 ? false : (p) != nullptr))
     Mask m;
     legal_mask(g, k, m);
-    if (AZ_HAS(mask_out)) mask_write(m, mask_out);
-    if (AZ_HAS(maskbits_out)) mask_write_bits(m, maskbits_out);
+    if (OUT == 1) {
+        vu32 l = lane();
+        vst_u8(ov.pm, m.b0);
+        vst_u8_at(ov.pm, 64, m.b1);
+        vst_u8(ov.pm2, sel(l < 52u, m.b2, splat((u32)(m.m2 >> 51) & 1u)));
+        vu32 lo = sel(l == 0u, splat((u32)m.m0), sel(l == 1u, splat((u32)m.m1), splat((u32)m.m2)));
+        vu32 hi = sel(l == 0u, splat((u32)(m.m0 >> 32)), sel(l == 1u, splat((u32)(m.m1 >> 32)), splat((u32)(m.m2 >> 32))));
+        vst_u64(ov.p64, lo, hi);
+    } else if (OUT == 2) {
+        if (os.mask) mask_write(m, os.mask);
+        if (os.maskbits) mask_write_bits(m, os.maskbits);
+    }
     i32 a = g.eog ? -2 : random_agent(m, r, T);
     bool deal = false;                 // a new round has to be dealt
     if (!AZ_UNLIKELY(a < 0)) {
@@ -853,10 +940,15 @@ AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, c
             dn = 2u;                   // stuck (or handed an already finished game): report, restart the slot
             AZ_LANE0(*cnt.stuck += 1u);
         }
-        if (AZ_HAS(action_out)) stu_i32(action_out, a >= 0 ? a : -1);
-        if (AZ_HAS(reward_out)) stu_i32(reward_out, reward);
-        if (AZ_HAS(done_out)) stu_u8(done_out, dn);
-        if (OUT == 2 && rec_out) game_store(g, rec_out);
+        if (OUT == 1) {
+            vst_u32(ov.p32, sel(lane() == 1u, splat((u32)reward), splat((u32)(a >= 0 ? a : -1))));
+            vst_u8(ov.p8, splat(dn));
+        } else if (OUT == 2) {
+            if (os.action) stu_i32(os.action, a >= 0 ? a : -1);
+            if (os.reward) stu_i32(os.reward, reward);
+            if (os.done) stu_u8(os.done, dn);
+            if (os.rec) game_store(g, os.rec);
+        }
         result = dn;
         if (dn == 0u) break;
         if (dn == 1u) {
@@ -869,7 +961,6 @@ AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, c
         deal = true;
     }
     return st ? (0x100u | st) : result;
-#undef AZ_HAS
 }
 
 } // namespace az

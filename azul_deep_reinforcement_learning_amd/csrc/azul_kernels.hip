@@ -153,9 +153,10 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
             const uint8_t *mi = a.mask_in + (size_t)gi * AZUL_NUM_ACTIONS;
             vu32 l = lane();
             Mask m;
-            m.m0 = ballot(ld_u8(mi, l, l < 64u) != 0u);
-            m.m1 = ballot(ld_u8(mi, l + 64u, l < 64u) != 0u);
-            m.m2 = ballot(ld_u8(mi, l + 128u, l < 52u) != 0u);
+            m.b0 = ld_u8(mi, l, l < 64u) != 0u ? 1u : 0u;
+            m.b1 = ld_u8(mi, l + 64u, l < 64u) != 0u ? 1u : 0u;
+            m.b2 = ld_u8(mi, l + 128u, l < 52u) != 0u ? 1u : 0u;
+            m.m0 = ballot(m.b0 != 0u); m.m1 = ballot(m.b1 != 0u); m.m2 = ballot(m.b2 != 0u);
             i32 av = random_agent(m, r, tab);
             AZ_LANE0(a.actions_out[gi] = av);
             dirty_state = false;
@@ -220,20 +221,30 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
     rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]);
     r.margin = b.draw_margin;
     Counters cnt = {b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10};
-    // running output pointers: one 64-bit add per stream and step instead of row * stride multiplies
-    uint8_t *pm = t.mask ? t.mask + (size_t)gi * AZUL_NUM_ACTIONS : nullptr;
-    u64 *pb = t.maskbits ? t.maskbits + (size_t)gi * 3 : nullptr;
-    i32 *pa = t.action ? t.action + gi : nullptr;
-    i32 *pr = t.reward ? t.reward + gi : nullptr;
-    uint8_t *pd = t.done ? t.done + gi : nullptr;
-    uint8_t *pc = t.rec ? t.rec + (size_t)gi * AZUL_RECORD_BYTES : nullptr;
-    const size_t sm = pm ? N * AZUL_NUM_ACTIONS : 0, sb = pb ? N * 3 : 0, sa = pa ? N : 0, sr = pr ? N : 0, sd = pd ? N : 0,
-                 sc = pc ? N * AZUL_RECORD_BYTES : 0;            // a NULL stream stays NULL
+    OutV ov;
+    OutS os = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t sm = 0, sb = 0, sa = 0, sr = 0, sd = 0, sc = 0;
+    if (OUT == 1) {
+        outv_open(ov, gi, b.n, t.mask, t.maskbits, t.action, t.reward, t.done);
+    } else {
+        outv_open(ov, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (OUT == 2) {
+            os.mask = t.mask ? t.mask + (size_t)gi * AZUL_NUM_ACTIONS : nullptr;
+            os.maskbits = t.maskbits ? t.maskbits + (size_t)gi * 3 : nullptr;
+            os.action = t.action ? t.action + gi : nullptr;
+            os.reward = t.reward ? t.reward + gi : nullptr;
+            os.done = t.done ? t.done + gi : nullptr;
+            os.rec = t.rec ? t.rec + (size_t)gi * AZUL_RECORD_BYTES : nullptr;
+            sm = os.mask ? N * AZUL_NUM_ACTIONS : 0; sb = os.maskbits ? N * 3 : 0; sa = os.action ? N : 0;
+            sr = os.reward ? N : 0; sd = os.done ? N : 0; sc = os.rec ? N * AZUL_RECORD_BYTES : 0;   // a NULL stream stays NULL
+        }
+    }
 #pragma unroll 1
     for (int s = 0; s < t.n_steps; s++) {
-        u32 f = selfplay_step<LID, OUT>(g, b.rules.first_player, k, r, tab, cnt, pm, pb, pa, pr, pd, pc);
+        u32 f = selfplay_step<LID, OUT>(g, b.rules.first_player, k, r, tab, cnt, ov, os);
         if (f & 0x100u) break;      // rule error (box empty): leave the game as it is
-        pm += sm; pb += sb; pa += sa; pr += sr; pd += sd; pc += sc;
+        if (OUT == 1) outv_next(ov);
+        if (OUT == 2) { os.mask += sm; os.maskbits += sb; os.action += sa; os.reward += sr; os.done += sd; os.rec += sc; }
     }
     game_store(g, rec);
     rng_close(r, b.mtpos + gi);

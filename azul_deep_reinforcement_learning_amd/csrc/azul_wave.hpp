@@ -64,6 +64,7 @@ AZ_FN u32 popc64(u64 x) { return (u32)__builtin_popcountll(x); }
 AZ_FN u32 ctz64(u64 x) { return (u32)__builtin_ctzll(x); }
 AZ_FN u32 ctz32(u32 x) { return (u32)__builtin_ctz(x); }
 AZ_FN u32 clz32(u32 x) { return (u32)__builtin_clz(x); }
+AZ_FN vu32 vmulhi(vu32 a, vu32 b) { return __umulhi(a, b); }
 AZ_FN vu32 vctz(vu32 x) { return (u32)__builtin_ctz(x); }      // x != 0
 AZ_FN vu32 vclz(vu32 x) { return (u32)__builtin_clz(x); }      // x != 0
 
@@ -93,6 +94,17 @@ AZ_FN void stu_u64(u64 *p, u64 v) { *p = v; }
 #endif
 AZ_FN vf64 self64(bool c, vf64 a, vf64 b) { return c ? a : b; }
 AZ_FN vu32 vmin(vu32 a, u32 b) { return a < b ? a : b; }
+// per-lane pointers (a VGPR pair on the device): trajectory streams advance with ONE vector add per step and are
+// written by all lanes (lanes without a value of their own repeat a neighbour's address AND data)
+typedef u64 vptr;
+AZ_FN vptr vptr_splat(const void *p) { return (u64)p; }
+AZ_FN vptr vptr_sel(vbool c, vptr a, vptr b) { return c ? a : b; }
+AZ_FN vptr vptr_off(vptr p, vu32 bytes) { return p + bytes; }
+AZ_FN vptr vptr_add(vptr p, u64 bytes) { return p + bytes; }
+AZ_FN void vst_u32(vptr p, vu32 v) { *(u32 *)p = v; }
+AZ_FN void vst_u8(vptr p, vu32 v) { *(uint8_t *)p = (uint8_t)v; }
+AZ_FN void vst_u8_at(vptr p, u32 imm, vu32 v) { ((uint8_t *)p)[imm] = (uint8_t)v; }
+AZ_FN void vst_u64(vptr p, vu32 lo, vu32 hi) { *(u64 *)p = ((u64)hi << 32) | lo; }
 #define AZ_UNLIKELY(x) __builtin_expect(!!(x), 0)
 } // namespace wv
 
@@ -154,6 +166,7 @@ AZ_FN u32 popc64(u64 x) { return (u32)__builtin_popcountll(x); }
 AZ_FN u32 ctz64(u64 x) { return (u32)__builtin_ctzll(x); }
 AZ_FN u32 ctz32(u32 x) { return (u32)__builtin_ctz(x); }
 AZ_FN u32 clz32(u32 x) { return (u32)__builtin_clz(x); }
+AZ_FN vu32 vmulhi(const vu32 &a, const vu32 &b) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = (u32)(((u64)a.v[i] * b.v[i]) >> 32); return r; }
 AZ_FN vu32 vctz(const vu32 &x) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[i] ? (u32)__builtin_ctz(x.v[i]) : 32u; return r; }
 AZ_FN vu32 vclz(const vu32 &x) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = x.v[i] ? (u32)__builtin_clz(x.v[i]) : 32u; return r; }
 AZ_FN vu32 operator~(const vu32 &a) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = ~a.v[i]; return r; }
@@ -178,6 +191,15 @@ AZ_FN void stu_u8(uint8_t *p, u32 v) { *p = (uint8_t)v; }
 AZ_FN void stu_u64(u64 *p, u64 v) { *p = v; }
 AZ_FN vf64 self64(bool c, const vf64 &a, const vf64 &b) { return c ? a : b; }
 AZ_FN vu32 vmin(const vu32 &a, u32 b) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] < b ? a.v[i] : b; return r; }
+struct vptr { uintptr_t v[64]; };
+AZ_FN vptr vptr_splat(const void *p) { vptr r; for (int i = 0; i < 64; i++) r.v[i] = (uintptr_t)p; return r; }
+AZ_FN vptr vptr_sel(const vbool &c, const vptr &a, const vptr &b) { vptr r; for (int i = 0; i < 64; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
+AZ_FN vptr vptr_off(const vptr &p, const vu32 &bytes) { vptr r; for (int i = 0; i < 64; i++) r.v[i] = p.v[i] + bytes.v[i]; return r; }
+AZ_FN vptr vptr_add(const vptr &p, u64 bytes) { vptr r; for (int i = 0; i < 64; i++) r.v[i] = p.v[i] + bytes; return r; }
+AZ_FN void vst_u32(const vptr &p, const vu32 &v) { for (int i = 0; i < 64; i++) *(u32 *)p.v[i] = v.v[i]; }
+AZ_FN void vst_u8(const vptr &p, const vu32 &v) { for (int i = 0; i < 64; i++) *(uint8_t *)p.v[i] = (uint8_t)v.v[i]; }
+AZ_FN void vst_u8_at(const vptr &p, u32 imm, const vu32 &v) { for (int i = 0; i < 64; i++) ((uint8_t *)p.v[i])[imm] = (uint8_t)v.v[i]; }
+AZ_FN void vst_u64(const vptr &p, const vu32 &lo, const vu32 &hi) { for (int i = 0; i < 64; i++) *(u64 *)p.v[i] = ((u64)hi.v[i] << 32) | lo.v[i]; }
 #define AZ_UNLIKELY(x) __builtin_expect(!!(x), 0)
 } // namespace wv
 #endif

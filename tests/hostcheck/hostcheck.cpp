@@ -38,11 +38,23 @@ static int advance(HostStream *h, int n_steps, uint8_t *mask, int32_t *action, i
     Rng r; rng_open(r, h->mt, h->lds, h->pos);
     Counters cnt = {&h->episodes, &h->stuck, h->stat_sum};
     int rc = 0;
+    // both output forms are exercised: the scalar-pointer form (OUT == 2) into the caller's arrays and, when every
+    // stream is requested, the per-lane-pointer form (OUT == 1) -- the caller's arrays are [t][1 game] here
+    const bool full = mask && action && reward && done && !rec_after;
+    static u64 bits_sink[3 * 4096];
+    OutV ov;
+    outv_open(ov, 0, 1, mask ? mask : (uint8_t *)bits_sink, bits_sink, action, reward, done);
+    OutS os = {mask, nullptr, action, reward, done, rec_after};
     for (int t = 0; t < n_steps; t++) {
-        u32 f = selfplay_step<LID, 2>(g, h->rules.first_player, k, r, table(), cnt,
-                                   mask ? mask + (size_t)t * 180 : 0, (u64 *)0, action ? action + t : 0, reward ? reward + t : 0,
-                                   done ? done + t : 0, rec_after ? rec_after + (size_t)t * 128 : 0);
+        u32 f = full ? selfplay_step<LID, 1>(g, h->rules.first_player, k, r, table(), cnt, ov, os)
+                     : selfplay_step<LID, 2>(g, h->rules.first_player, k, r, table(), cnt, ov, os);
         if (f & 0x100u) { rc = (int)(f & 0xff); break; }
+        if (full) outv_next(ov);
+        if (os.mask) os.mask += 180;
+        if (os.action) os.action += 1;
+        if (os.reward) os.reward += 1;
+        if (os.done) os.done += 1;
+        if (os.rec) os.rec += 128;
     }
     game_store(g, h->rec);
     rng_close(r, &h->pos);
@@ -235,9 +247,10 @@ int hc_sample_mask(const uint8_t *mask180, u32 *mt, u32 *pos)
     static u32 lds[624];
     vu32 l = lane();
     Mask m;
-    m.m0 = ballot(ld_u8(mask180, l, l < 64u) != 0u);
-    m.m1 = ballot(ld_u8(mask180, l + 64u, l < 64u) != 0u);
-    m.m2 = ballot(ld_u8(mask180, l + 128u, l < 52u) != 0u);
+    m.b0 = sel(ld_u8(mask180, l, l < 64u) != 0u, splat(1u), splat(0u));
+    m.b1 = sel(ld_u8(mask180, l + 64u, l < 64u) != 0u, splat(1u), splat(0u));
+    m.b2 = sel(ld_u8(mask180, l + 128u, l < 52u) != 0u, splat(1u), splat(0u));
+    m.m0 = ballot(m.b0 != 0u); m.m1 = ballot(m.b1 != 0u); m.m2 = ballot(m.b2 != 0u);
     Rng r; rng_open(r, mt, lds, *pos);
     i32 a = random_agent(m, r, table());
     rng_close(r, pos);

@@ -54,9 +54,10 @@ class HostStream:
             lib().hc_stream_free(self.h)
             self.h = None
 
-    def advance(self, n):
+    def advance(self, n, want_records=True):
+        """want_records=False takes the per-lane-pointer output path (OUT == 1, n <= 4096)."""
         out = {"mask": np.zeros((n, 180), np.uint8), "action": np.zeros(n, np.int32), "reward": np.zeros(n, np.int32),
-               "done": np.zeros(n, np.uint8), "rec_after": np.zeros((n, 128), np.uint8)}
+               "done": np.zeros(n, np.uint8), "rec_after": np.zeros((n, 128), np.uint8) if want_records else None}
         rc = lib().hc_stream_advance(self.h, n, ptr(out["mask"]), ptr(out["action"]), ptr(out["reward"]),
                                      ptr(out["done"]), ptr(out["rec_after"]))
         assert rc == 0, rc

@@ -147,3 +147,12 @@ def test_factory_draw_literal_fp64_build_matches_oracle():
         assert L.hc_stream_advance(h, n, None, hc.ptr(act), None, None, hc.ptr(rec)) == 0
         eo = oz.Stream(seed, 0, 1).advance(n)
         assert np.array_equal(eo["action"], act) and eo["rec_after"].tobytes() == rec.tobytes()
+
+
+def test_vector_pointer_output_path():
+    """OUT == 1 (per-lane trajectory pointers, all-lane stores) writes the same streams as the scalar form."""
+    for seed, fp, pool in [(9, 0, 1), (10, 1, 0)]:
+        o = oz.Stream(seed, fp, pool).advance(900)
+        h = hc.HostStream(seed, fp, pool).advance(900, want_records=False)
+        for key in ("mask", "action", "reward", "done"):
+            assert np.array_equal(o[key], h[key]), key

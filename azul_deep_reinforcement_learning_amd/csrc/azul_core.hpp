@@ -321,27 +321,30 @@ AZ_FN void mask_write_bits(const Mask &m, u64 *out)
 // (azul_tables.hpp builds both tables with the very additions CPython performs; tests check all 31*151 sums).
 // The 248 + 31 doubles live in ten VGPRs per wave: no memory access on the sampling path.
 struct SampleTab {
-    vf64 fr0, fr1, fr2, fr3;   // Fr[J][b] at flat index e = 8J + b: register e >> 6, lane e & 63 (a row never straddles)
+    const double *fr;          // LDS: Fr[J][b] at 8J + b (248 doubles, staged once per wave)
     vf64 s;                    // S[J] in lane J
 };
 
-AZ_FN void sample_tab_load(SampleTab &t, const double *tab /* T_WORDS doubles: Fr[31][8] then S[31] */)
+AZ_FN void sample_tab_load(SampleTab &t, const double *tab /* T_WORDS doubles: Fr[31][8] then S[31] */, double *lds_fr)
 {
     vu32 l = lane();
-    t.fr0 = ld_f64(tab, l, l < 64u);
-    t.fr1 = ld_f64(tab, l + 64u, l < 64u);
-    t.fr2 = ld_f64(tab, l + 128u, l < 64u);
-    t.fr3 = ld_f64(tab, vmin(l, 55u) + 192u, l < 64u);
+    for (u32 q = 0; q < 4u; q++) {
+        vu32 i = l + q * 64u;
+        lds_st_f64(lds_fr, i, ld_f64(tab, i, i < 248u), i < 248u);
+    }
+    lds_fence();
+    t.fr = lds_fr;
     t.s = ld_f64(tab + T_ROWS * T_BINADES, vmin(l, 30u), l < 64u);
 }
 
-// cumulative weight after the k-th legal action (k = 0 -> 0.0); `row` holds Fr[J][.] at lanes lane0..lane0+7
-AZ_FN double tseq(const SampleTab &t, const vf64 &row, u32 lane0, u32 J, u32 k)
+// cumulative weight after m >= 1 pattern moves on top of J floor moves
+AZ_FN double tpat(const SampleTab &t, u32 J, u32 m) { return (double)m + lds_ldu_f64(t.fr, 8u * J + 31u - clz32(m)); }
+
+// cumulative weight after the k-th legal action (k = 0 -> 0.0)
+AZ_FN double tseq(const SampleTab &t, u32 J, u32 k)
 {
-    u32 m = k > J ? k - J : 1u;
-    double hi = (double)m + readlane_d(row, lane0 + 31u - clz32(m));
-    double lo = readlane_d(t.s, k > J ? J : k);
-    return k > J ? hi : lo;
+    if (k <= J) return readlane_d(t.s, k);
+    return tpat(t, J, k - J);
 }
 
 AZ_FN i32 random_agent(const Mask &m, Rng &r, const SampleTab &T)
@@ -350,35 +353,40 @@ AZ_FN i32 random_agent(const Mask &m, Rng &r, const SampleTab &T)
     u32 J = popc64(m.m0 & 0x3fffffffull);             // legal floor moves (a < 30, weight 0.01)
     u32 L = c0 + c1 + c2;
     if (AZ_UNLIKELY(L == 0u)) return -1;               // ValueError in the reference, raised before random()
-    u32 q = J >> 3, lane0 = (J & 7u) * 8u;
-    vf64 row = self64(q == 0u, T.fr0, self64(q == 1u, T.fr1, self64(q == 2u, T.fr2, T.fr3)));
-    double total = tseq(T, row, lane0, J, L) + 0.0;
+    u32 M = L - J;
+    double sJ = readlane_d(T.s, J);
+    double total = (M ? tpat(T, J, M) : sJ) + 0.0;
     double x = rng_random(r) * total;
     // bisect_right over the cumulative weights == smallest ordinal k with cum(k) > x
-    double sJ = readlane_d(T.s, J);
     u32 kg;
     if (AZ_UNLIKELY(x < sJ)) {
         // inside the 0.01-weight floor moves (rare unless nothing else is legal): generic search
         kg = (u32)(x * 100.0) + 1u;
         kg = kg > J ? J : kg;
         for (u32 it = 0; it < 64u; it++) {
-            bool below = x < tseq(T, row, lane0, J, kg - 1u), inside = x < tseq(T, row, lane0, J, kg);
+            bool below = x < tseq(T, J, kg - 1u), inside = x < tseq(T, J, kg);
             if (below && kg > 1u) kg -= 1u;
             else if (!inside && kg < L) kg += 1u;
             else break;
         }
     } else {
-        // pattern moves: cum(J + m) = m + Fr[J][ilog2 m]; the guess from x is off by at most one
-        u32 M = L - J;                                   // >= 1 here because x >= sJ implies total > sJ
-        u32 mg = (u32)(x - sJ) + 1u;
-        mg = mg > M ? M : mg;
-        for (u32 it = 0; it < 256u; it++) {
-            u32 ml = mg - 1u;
-            double lo = ml ? (double)ml + readlane_d(row, lane0 + 31u - clz32(ml | 1u)) : sJ;
-            double hi = (double)mg + readlane_d(row, lane0 + 31u - clz32(mg));
-            if (AZ_UNLIKELY(x < lo && mg > 1u)) mg -= 1u;
-            else if (AZ_UNLIKELY(!(x < hi) && mg < M)) mg += 1u;
-            else break;
+        // pattern moves: cum(J + m) = m + Fr[J][ilog2 m] with |Fr - S[J]| < 2^-44 (a handful of half-ulp roundings
+        // below 256), and d = x - S[J] carries an fp64 error below 2^-45: whenever d is further than 1e-9 from an
+        // integer, floor(d) + 1 IS the ordinal; otherwise the exact table values decide.
+        double d = x - sJ;
+        u32 fl = (u32)d;
+        double fr = d - (double)fl;
+        u32 mg = fl + 1u;
+        if (AZ_UNLIKELY(!(fr > 1e-9 && fr < 1.0 - 1e-9) || mg > M)) {
+            mg = mg > M ? M : mg;
+            for (u32 it = 0; it < 256u; it++) {
+                u32 ml = mg - 1u;
+                double lo = ml ? tpat(T, J, ml) : sJ;
+                double hi = tpat(T, J, mg);
+                if (x < lo && mg > 1u) mg -= 1u;
+                else if (!(x < hi) && mg < M) mg += 1u;
+                else break;
+            }
         }
         kg = J + mg;
     }

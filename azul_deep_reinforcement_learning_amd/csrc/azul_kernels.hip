@@ -81,13 +81,14 @@ template <bool LID>
 __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
 {
     __shared__ u32 mt_lds[624];
+    __shared__ double fr_lds[T_ROWS * T_BINADES];
     const u32 gi = blockIdx.x;
     const bool act = a.active ? (a.active[gi] != 0) : true;
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
     LaneConst k;
     lane_consts(k);
     SampleTab tab;
-    sample_tab_load(tab, b.T);
+    sample_tab_load(tab, b.T, fr_lds);
     Game g;
     game_load(g, rec);
     game_prime<LID>(g, k);
@@ -207,13 +208,14 @@ template <bool LID, int OUT>
 __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs t)
 {
     __shared__ u32 mt_lds[624];
+    __shared__ double fr_lds[T_ROWS * T_BINADES];
     const u32 gi = blockIdx.x;
     const size_t N = b.n;
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
     LaneConst k;
     lane_consts(k);
     SampleTab tab;
-    sample_tab_load(tab, b.T);
+    sample_tab_load(tab, b.T, fr_lds);
     Game g;
     game_load(g, rec);
     game_prime<LID>(g, k);

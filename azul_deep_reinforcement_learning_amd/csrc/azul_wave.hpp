@@ -80,6 +80,8 @@ AZ_FN vu32 lds_ld(const u32 *lds, vu32 idx, vbool act) { return act ? lds[idx] :
 AZ_FN void lds_st(u32 *lds, vu32 idx, vu32 val, vbool act) { if (act) lds[idx] = val; }
 AZ_FN u32  lds_ldu(const u32 *lds, u32 idx) { return __builtin_amdgcn_readfirstlane(lds[idx]); }
 AZ_FN void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+AZ_FN double lds_ldu_f64(const double *lds, u32 idx) { return lds[idx]; }
+AZ_FN void lds_st_f64(double *lds, vu32 idx, vf64 v, vbool act) { if (act) lds[idx] = v; }
 // run `stmt` on one lane only (uniform values -> memory)
 #define AZ_LANE0(stmt) do { if (wv::lane() == 0) { stmt; } } while (0)
 // store a uniform value from EVERY lane (same address, same data: one coalesced request, no exec masking, no branch)
@@ -185,6 +187,8 @@ AZ_FN void lds_st(u32 *lds, const vu32 &idx, const vu32 &val, const vbool &act)
 }
 AZ_FN u32  lds_ldu(const u32 *lds, u32 idx) { return lds[idx]; }
 AZ_FN void lds_fence() {}
+AZ_FN double lds_ldu_f64(const double *lds, u32 idx) { return lds[idx]; }
+AZ_FN void lds_st_f64(double *lds, const vu32 &idx, const vf64 &v, const vbool &act) { for (int i = 0; i < 64; i++) if (act.v[i]) lds[idx.v[i]] = v.v[i]; }
 #define AZ_LANE0(stmt) do { stmt; } while (0)
 AZ_FN void stu_i32(i32 *p, i32 v) { *p = v; }
 AZ_FN void stu_u8(uint8_t *p, u32 v) { *p = (uint8_t)v; }

@@ -10,11 +10,12 @@
 using namespace az;
 
 static double g_T[T_WORDS];
+static double g_fr[T_ROWS * T_BINADES];
 static SampleTab g_tab;
 static bool g_T_ready = false;
 static const SampleTab &table()
 {
-    if (!g_T_ready) { build_sample_tab(g_T); sample_tab_load(g_tab, g_T); g_T_ready = true; }
+    if (!g_T_ready) { build_sample_tab(g_T); sample_tab_load(g_tab, g_T, g_fr); g_T_ready = true; }
     return g_tab;
 }
 

@@ -45,7 +45,8 @@ struct Rng {
     u32 *lds;       // this wave's 624-word LDS window (staged whole when the stream is opened)
     u32 pos;        // CPython's `index` (0..624)
     u32 dirty;      // LDS state differs from global memory (a twist happened)
-    u32 wbase;      // first word held by `win` (0x80000000: none)
+    u32 wbase;      // first word held by `win`
+    u32 wend;       // one past the last word `win` can serve (0: no window loaded)
     u64 margin;     // factory-draw disagreement window (new_round); AZ_DRAW_MARGIN unless a test widens it
     vu32 win;       // lane i: TEMPERED output word wbase + i  (one readlane per random word)
 };
@@ -61,7 +62,7 @@ AZ_FN vu32 temper_v(vu32 y)
 
 AZ_FN void rng_open(Rng &r, u32 *gmt, u32 *lds, u32 pos)
 {
-    r.gmt = gmt; r.lds = lds; r.pos = pos; r.dirty = 0; r.wbase = 0x80000000u; r.win = splat(0u); r.margin = AZ_DRAW_MARGIN;
+    r.gmt = gmt; r.lds = lds; r.pos = pos; r.dirty = 0; r.wbase = 0; r.wend = 0; r.win = splat(0u); r.margin = AZ_DRAW_MARGIN;
 #if AZ_DEVICE_BUILD
 #pragma unroll 1
 #endif
@@ -94,23 +95,24 @@ AZ_FN void rng_twist(Rng &r)
     }
     r.dirty = 1;
     r.pos = 0;
-    r.wbase = 0x80000000u;
+    r.wend = 0;
 }
 
 AZ_FN void rng_refill(Rng &r)
 {
     if (r.pos >= 624u) rng_twist(r);
     r.wbase = r.pos;
+    r.wend = r.pos + 64u < 624u ? r.pos + 64u : 624u;
     vu32 i = lane() + r.pos;
     r.win = temper_v(lds_ld(r.lds, i, i < 624u));
 }
 
 AZ_FN u32 rng_u32(Rng &r)
 {
-    u32 off = r.pos - r.wbase;                          // wraps to a huge value when no window is loaded
-    if (AZ_UNLIKELY(off >= 64u || r.pos >= 624u)) { rng_refill(r); off = 0; }
+    if (AZ_UNLIKELY(r.pos >= r.wend)) rng_refill(r);    // window exhausted, state exhausted (pos == 624) or none yet
+    u32 y = readlane(r.win, r.pos - r.wbase);
     r.pos += 1;
-    return readlane(r.win, off);
+    return y;
 }
 
 AZ_FN double rng_random(Rng &r)

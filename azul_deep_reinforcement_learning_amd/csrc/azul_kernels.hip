@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
     u32 st = ST_OK;
     if (act && a.op != OP_QUERY) {
         Rng r;
-        r.gmt = b.mt + (size_t)gi * 624u; r.lds = mt_lds; r.pos = b.mtpos[gi]; r.dirty = 0; r.wbase = 0x80000000u; r.win = 0u; r.margin = b.draw_margin;
+        r.gmt = b.mt + (size_t)gi * 624u; r.lds = mt_lds; r.pos = b.mtpos[gi]; r.dirty = 0; r.wbase = 0; r.wend = 0; r.win = 0u; r.margin = b.draw_margin;
         const bool use_rng = op_needs_rng(a.op);
         if (use_rng) { rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]); r.margin = b.draw_margin; }
         bool dirty_state = true;

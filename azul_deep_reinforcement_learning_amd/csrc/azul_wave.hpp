@@ -103,10 +103,12 @@ AZ_FN vptr vptr_splat(const void *p) { return (u64)p; }
 AZ_FN vptr vptr_sel(vbool c, vptr a, vptr b) { return c ? a : b; }
 AZ_FN vptr vptr_off(vptr p, vu32 bytes) { return p + bytes; }
 AZ_FN vptr vptr_add(vptr p, u64 bytes) { return p + bytes; }
-AZ_FN void vst_u32(vptr p, vu32 v) { *(u32 *)p = v; }
-AZ_FN void vst_u8(vptr p, vu32 v) { *(uint8_t *)p = (uint8_t)v; }
-AZ_FN void vst_u8_at(vptr p, u32 imm, vu32 v) { ((uint8_t *)p)[imm] = (uint8_t)v; }
-AZ_FN void vst_u64(vptr p, vu32 lo, vu32 hi) { *(u64 *)p = ((u64)hi << 32) | lo; }
+// (explicit global address space: a plain integer->pointer cast would compile to slower flat_store instructions)
+#define AZ_GLOBAL __attribute__((address_space(1)))
+AZ_FN void vst_u32(vptr p, vu32 v) { *(AZ_GLOBAL u32 *)p = v; }
+AZ_FN void vst_u8(vptr p, vu32 v) { *(AZ_GLOBAL uint8_t *)p = (uint8_t)v; }
+AZ_FN void vst_u8_at(vptr p, u32 imm, vu32 v) { ((AZ_GLOBAL uint8_t *)p)[imm] = (uint8_t)v; }
+AZ_FN void vst_u64(vptr p, vu32 lo, vu32 hi) { *(AZ_GLOBAL u64 *)p = ((u64)hi << 32) | lo; }
 #define AZ_UNLIKELY(x) __builtin_expect(!!(x), 0)
 } // namespace wv
 

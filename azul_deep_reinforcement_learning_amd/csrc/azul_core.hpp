@@ -63,14 +63,16 @@ AZ_FN vu32 temper_v(vu32 y)
 AZ_FN void rng_open(Rng &r, u32 *gmt, u32 *lds, u32 pos)
 {
     r.gmt = gmt; r.lds = lds; r.pos = pos; r.dirty = 0; r.wbase = 0; r.wend = 0; r.win = splat(0u); r.margin = AZ_DRAW_MARGIN;
-#if AZ_DEVICE_BUILD
-#pragma unroll 1
-#endif
-    for (u32 k = 0; k < 10; k++) {                      // 10 coalesced 256-byte loads
-        vu32 i = lane() + k * 64u;
-        vu32 w = ld_u32(gmt, i, i < 624u);
-        lds_st(lds, i, w, i < 624u);
-    }
+    // ten coalesced 256-byte loads, all in flight before the first LDS write (one memory latency, not ten)
+    vu32 l = lane();
+    vu32 w0 = ld_u32(gmt, l, l < 64u), w1 = ld_u32(gmt, l + 64u, l < 64u), w2 = ld_u32(gmt, l + 128u, l < 64u),
+         w3 = ld_u32(gmt, l + 192u, l < 64u), w4 = ld_u32(gmt, l + 256u, l < 64u), w5 = ld_u32(gmt, l + 320u, l < 64u),
+         w6 = ld_u32(gmt, l + 384u, l < 64u), w7 = ld_u32(gmt, l + 448u, l < 64u), w8 = ld_u32(gmt, l + 512u, l < 64u),
+         w9 = ld_u32(gmt, l + 576u, l < 48u);
+    lds_st(lds, l, w0, l < 64u); lds_st(lds, l + 64u, w1, l < 64u); lds_st(lds, l + 128u, w2, l < 64u);
+    lds_st(lds, l + 192u, w3, l < 64u); lds_st(lds, l + 256u, w4, l < 64u); lds_st(lds, l + 320u, w5, l < 64u);
+    lds_st(lds, l + 384u, w6, l < 64u); lds_st(lds, l + 448u, w7, l < 64u); lds_st(lds, l + 512u, w8, l < 64u);
+    lds_st(lds, l + 576u, w9, l < 48u);
     lds_fence();
 }
 

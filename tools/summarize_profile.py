@@ -63,8 +63,8 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     summary["hbm_bytes_per_launch"] = {"fetch": f, "write": w, "total": f + w,
                                         "note": "counter KB x calibration factor measured in this path's access widths"}
     json.dump({"bytes_per_launch": f + w, "fetch": f, "write": w, "source": "profiles/%s_summary.json" % name,
-               "launch": "azul_selfplay_kernel, 4096 games x 64 moves"}, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
-waves_steps = 4096 * 64
+               "launch": "azul_selfplay_kernel, %d games x %d moves" % (bench["config"]["games_per_gpu"], bench["config"]["moves_per_launch"])}, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+waves_steps = bench["config"]["games_per_gpu"] * bench["config"]["moves_per_launch"]
 if "SQ_INSTS_VALU" in pmc:
     summary["per_wave_step"] = {k: pmc[k]["mean"] / waves_steps for k in pmc if k.startswith("SQ_")}
 summary["bench"] = {k: bench[k] for k in ("value", "ms_per_step", "roofline", "cpu_baseline") if k in bench}

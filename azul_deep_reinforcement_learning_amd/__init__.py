@@ -9,3 +9,5 @@ from .codec import nn_serialize, nn_deserialize  # noqa: F401
 from .batch import BatchedAzul, IllegalRule, parse_rules  # noqa: F401
 from .azul import Azul, IllegalMove, GameEnded  # noqa: F401
 from .game_runner import GameRunner, RandomAgent, check_all_valid  # noqa: F401
+from .policy import BatchedActorCritic, IllegalMask  # noqa: F401
+from .rollout import PolicyRollout  # noqa: F401

@@ -194,6 +194,20 @@ class BatchedAzul:
         L.check(L.lib.azul_batch_score_preview(self._h, _ptr(p), self._stream()))
         return p
 
+    # -- policy-driven self-play (config 3) ----------------------------------------------------------
+    def observe_all(self, perspective=L.PERSP_CURRENT, obs=None, mask=None, player=None):
+        obs = self._new((self.n, L.OBS_SIZE), torch.float32) if obs is None else obs
+        mask = self._new((self.n, L.NUM_ACTIONS), torch.uint8) if mask is None else mask
+        player = self._new((self.n,), torch.uint8) if player is None else player
+        L.check(L.lib.azul_batch_observe_all(self._h, int(perspective), _ptr(obs), _ptr(mask), _ptr(player), self._stream()))
+        return obs, mask, player
+
+    def policy_step(self, actions, reward, done, status, obs_next, mask_next, player_next, perspective=L.PERSP_CURRENT, active=None):
+        """One fused env move with caller-chosen actions (all arguments are preallocated device tensors)."""
+        L.check(L.lib.azul_batch_policy_step(self._h, _ptr(actions), _ptr(self._dev(active, torch.uint8)), _ptr(reward), _ptr(done),
+                                             _ptr(status), int(perspective), _ptr(obs_next), _ptr(mask_next), _ptr(player_next),
+                                             self._stream()))
+
     # -- flat self-play rollout -------------------------------------------------------------------
     def selfplay(self, n_steps, mask=None, action=None, reward=None, done=None, records=None, maskbits=None):
         """`n_steps` env moves for every game in one launch; outputs are preallocated tensors or None."""

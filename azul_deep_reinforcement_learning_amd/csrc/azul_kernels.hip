@@ -42,7 +42,7 @@ struct BatchDev {
 
 enum {
     OP_QUERY = 0, OP_INIT, OP_NEW_ROUND, OP_MOVE, OP_NEXT_PLAYER, OP_COUNT_SCORE, OP_STEP,
-    OP_RUNNER_INIT, OP_RUNNER_RESET, OP_RUNNER_STEP, OP_RANDOM_ACTION, OP_SAMPLE_MASK
+    OP_RUNNER_INIT, OP_RUNNER_RESET, OP_RUNNER_STEP, OP_RANDOM_ACTION, OP_SAMPLE_MASK, OP_POLICY_STEP
 };
 
 struct OpArgs {
@@ -60,6 +60,7 @@ struct OpArgs {
     uint8_t *flags;          // [N]   out
     i32 *potential;          // [N]   out
     double *stats;           // [N][10] out
+    uint8_t *player;         // [N]   out: current_player after the op
 };
 
 __global__ void __launch_bounds__(64) azul_seed_kernel(BatchDev b, u64 seed_base, const u64 *seeds)
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(64) azul_seed_kernel(BatchDev b, u64 seed_base
 static __device__ __forceinline__ bool op_needs_rng(int op)
 {
     return op == OP_INIT || op == OP_NEW_ROUND || op == OP_STEP || op == OP_RUNNER_INIT || op == OP_RUNNER_RESET ||
-           op == OP_RUNNER_STEP || op == OP_RANDOM_ACTION || op == OP_SAMPLE_MASK;
+           op == OP_RUNNER_STEP || op == OP_RANDOM_ACTION || op == OP_SAMPLE_MASK || op == OP_POLICY_STEP;
 }
 
 template <bool LID>
@@ -150,6 +151,53 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
             AZ_LANE0(a.actions_out[gi] = av);
             dirty_state = false;
         } break;
+        case OP_POLICY_STEP: {
+            // one env move of policy-driven self-play: Azul.step (azul.py:296-313) for the current player, the
+            // shaped reward of game_runner.py:48-52 per move, done, and the auto-reset of game_runner.py:76-82
+            i32 rew = 0;
+            u32 dn = 0;
+            const i32 av = a.actions[gi];
+            bool stuck = false;
+            if (av < 0 && !g.eog) {                      // "no action": legitimate only when nothing is legal (hazard H3)
+                Mask m;
+                legal_mask(g, k, m);
+                stuck = mask_count(m) == 0u;
+            }
+            if (stuck) {
+                AZ_LANE0(b.stuck[gi] += 1u);
+                dn = 2u;
+                st = episode_reset<LID>(g, b.rules.first_player, r);
+                game_prime<LID>(g, k);
+                if (!st) st = ST_STUCK;
+                dirty_state = true;
+                if (a.reward) AZ_LANE0(a.reward[gi] = 0);
+                if (a.done) AZ_LANE0(a.done[gi] = (uint8_t)dn);
+                break;
+            }
+            st = checked_step<LID>(g, k, r, av);
+            dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION);
+            if (dirty_state) {
+                g.moves += 1u;
+                i32 phi = potential<LID>(g, k);
+                rew = phi - g.pscore;
+                g.pscore = phi;
+                dn = is_end_of_game(g) ? 1u : 0u;
+                if (dn && st == ST_OK) {
+                    for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(b.stat_sum[(size_t)gi * 10 + q] += sv); }
+                    AZ_LANE0(b.episodes[gi] += 1ull);
+                    st = episode_reset<LID>(g, b.rules.first_player, r);
+                    game_prime<LID>(g, k);
+                }
+            } else if (st == ST_GAME_ENDED) {
+                // a finished game handed in (e.g. after set_state): restart the slot, report done
+                dn = 1u;
+                st = episode_reset<LID>(g, b.rules.first_player, r);
+                game_prime<LID>(g, k);
+                dirty_state = true;
+            }
+            if (a.reward) AZ_LANE0(a.reward[gi] = rew);
+            if (a.done) AZ_LANE0(a.done[gi] = (uint8_t)dn);
+        } break;
         case OP_SAMPLE_MASK: {
             const uint8_t *mi = a.mask_in + (size_t)gi * AZUL_NUM_ACTIONS;
             vu32 l = lane();
@@ -192,7 +240,28 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
     if (a.stats) {
         for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(a.stats[(size_t)gi * 10 + q] = sv); }
     }
+    if (a.player) AZ_LANE0(a.player[gi] = (uint8_t)g.cur);
 }
+
+// Discounted returns over the time-major trajectory of one launch window (reference loop: nn_runner.py:70-76,
+// qval = reward + gamma * qval backwards within an episode).  One thread per game walks its column backwards;
+// `done[t][g] != 0` ends an episode at move t; `carry[g]` holds the return flowing in from the NEXT window
+// (0 for a window that ends with finished episodes), and receives the value flowing out of this window's start.
+__global__ void __launch_bounds__(256) azul_returns_kernel(const i32 *reward, const uint8_t *done, float *out, float *carry,
+                                                           float gamma, int n_steps, u32 n)
+{
+    u32 g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= n) return;
+    float q = carry ? carry[g] : 0.f;
+    for (int t = n_steps - 1; t >= 0; t--) {
+        size_t i = (size_t)t * n + g;
+        if (done[i]) q = 0.f;
+        q = (float)reward[i] + gamma * q;
+        out[i] = q;
+    }
+    if (carry) carry[g] = q;
+}
+
 
 struct TrajArgs {
     int n_steps;
@@ -523,6 +592,35 @@ int azul_batch_random_action(azul_batch_t *b, const uint8_t *active_dev, int32_t
     if (!actions_dev) return fail(AZUL_ERR_INVALID, "actions_dev is NULL");
     OpArgs a = op_args(OP_RANDOM_ACTION); a.active = active_dev; a.actions_out = actions_dev;
     return launch_op(b, a, stream);
+}
+
+int azul_batch_policy_step(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *active_dev, int32_t *reward_dev,
+                           uint8_t *done_dev, uint8_t *status_dev, int perspective, float *obs_next_dev,
+                           uint8_t *mask_next_dev, uint8_t *player_next_dev, void *stream)
+{
+    if (!actions_dev || perspective < 0 || perspective > 2) return fail(AZUL_ERR_INVALID, "azul_batch_policy_step: bad arguments");
+    OpArgs a = op_args(OP_POLICY_STEP);
+    a.actions = actions_dev; a.active = active_dev; a.reward = reward_dev; a.done = done_dev; a.status = status_dev;
+    a.persp = perspective; a.obs = obs_next_dev; a.mask = mask_next_dev; a.player = player_next_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_observe_all(azul_batch_t *b, int perspective, float *obs_dev, uint8_t *mask_dev, uint8_t *player_dev, void *stream)
+{
+    if (perspective < 0 || perspective > 2) return fail(AZUL_ERR_INVALID, "azul_batch_observe_all: bad perspective");
+    OpArgs a = op_args(OP_QUERY); a.persp = perspective; a.obs = obs_dev; a.mask = mask_dev; a.player = player_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, float *returns_dev, float *carry_dev,
+                            float gamma, int n_steps, int n_games, void *stream)
+{
+    if (!reward_dev || !done_dev || !returns_dev || n_steps < 0 || n_games <= 0) return fail(AZUL_ERR_INVALID, "azul_discounted_returns: bad arguments");
+    if (n_steps == 0) return AZUL_SUCCESS;
+    hipLaunchKernelGGL(azul_returns_kernel, dim3(((u32)n_games + 255u) / 256u), dim3(256), 0, (hipStream_t)stream,
+                       reward_dev, done_dev, returns_dev, carry_dev, gamma, n_steps, (u32)n_games);
+    HIP_TRY(hipGetLastError());
+    return AZUL_SUCCESS;
 }
 
 int azul_batch_sample_mask(azul_batch_t *b, const uint8_t *mask_dev, const uint8_t *active_dev, int32_t *actions_dev, void *stream)

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""bench_policy.py -- BASELINE configs[2]: 4096 concurrent games, ActorCritic(136,180,hidden 180) policy on
+PyTorch-ROCm interleaved with the env step on separate HIP streams, 1 MI355X.  Not the driver's headline bench
+(that is bench.py / configs[1]); prints one JSON line with env steps/s for the policy-driven rollout.
+
+    python bench_policy.py [--games 4096] [--parts 2] [--window 32] [--windows 20] [--no-graph]
+"""
+import argparse
+import json
+import sys
+import time
+
+sys.path.insert(0, __file__.rsplit("/", 1)[0])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--games", type=int, default=4096)
+    ap.add_argument("--parts", type=int, default=2)
+    ap.add_argument("--window", type=int, default=32)
+    ap.add_argument("--windows", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-obs-record", action="store_true")
+    a = ap.parse_args()
+    import torch
+    from azul_deep_reinforcement_learning_amd import BatchedActorCritic, PolicyRollout
+    torch.manual_seed(0)
+    net = BatchedActorCritic(136, 180, 180)
+    ro = PolicyRollout(net, n_games=a.games, parts=a.parts, window=a.window, use_graph=not a.no_graph,
+                       record_obs=not a.no_obs_record)
+    for _ in range(3):
+        ro.run_window()
+    ro.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.windows):
+        ro.run_window()
+    ro.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    moves = a.games * a.window * a.windows
+    c = ro.counters()
+    print(json.dumps({"metric": "Azul env steps/sec (ActorCritic policy self-play, trajectories recorded)", "value": moves / dt,
+                      "unit": "env steps/s", "n_gpus": 1, "config": {"workload": "BASELINE configs[2]", "games": a.games,
+                      "stream_parts": a.parts, "moves_per_graph": a.window, "hip_graph": ro.use_graph,
+                      "graph_error": ro.graph_error}, "ms_per_step": dt / (a.window * a.windows) * 1e3,
+                      "episodes_finished": c["episodes"], "stuck": c["stuck"], "dtype": "fp32 policy / u8 env", "data": "synthetic"}))
+
+
+if __name__ == "__main__":
+    main()

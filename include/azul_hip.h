@@ -135,6 +135,22 @@ int azul_batch_sample_mask(azul_batch_t *b, const uint8_t *mask_dev /*[N][180]*/
                            int32_t *actions_dev, void *stream);
 int azul_batch_score_preview(azul_batch_t *b, int32_t *potential_dev /*[N]*/, void *stream);   /* deepcopy+count_score, score[0]-score[1]  game_runner.py:48-50 */
 
+/* ---- policy-driven self-play (BASELINE configs[2]; callers: agent.py:64-81, nn_runner.py:17-47) ---------------- */
+/* One env move for every game with caller-chosen actions, fused: Azul.step for the current player (azul.py:296-313) ->
+ * per-move shaped reward (delta of the what-if potential, game_runner.py:48-52) -> done -> statistics + auto-reset of
+ * finished games (game_runner.py:76-82) -> the NEXT decision's inputs: observation from `perspective`
+ * (game_runner.py:56-72), legal mask (game_runner.py:113-117) and the player to move.  An illegal action leaves the
+ * game untouched (status AZUL_ILLEGAL_MOVE, reward 0) and still returns that game's current observation and mask. */
+int azul_batch_policy_step(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *active_dev, int32_t *reward_dev,
+                           uint8_t *done_dev, uint8_t *status_dev, int perspective, float *obs_next_dev /*[N][136]*/,
+                           uint8_t *mask_next_dev /*[N][180]*/, uint8_t *player_next_dev /*[N]*/, void *stream);
+/* observation + mask + player to move in one launch (the first decision of a rollout) */
+int azul_batch_observe_all(azul_batch_t *b, int perspective, float *obs_dev, uint8_t *mask_dev, uint8_t *player_dev, void *stream);
+/* discounted returns q[t] = r[t] + gamma * q[t+1] within episodes over a time-major window [n_steps][n_games]
+ * (nn_runner.py:70-76); done[t][g] != 0 closes an episode at move t; carry_dev[n_games] (optional) chains windows. */
+int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, float *returns_dev, float *carry_dev,
+                            float gamma, int n_steps, int n_games, void *stream);
+
 /* ---- flat random-agent self-play (the benchmarked hot path) ----------------------------------- */
 /*
  * Advance every game by `n_steps` env moves in ONE launch: per move  mask -> RandomAgent -> Azul.step ->

@@ -241,12 +241,35 @@ def gen_boards():
     print("wrote boards.npz + %d resource json files" % len(names))
 
 
+def gen_policy_contract():
+    """(state_dict, obs, mask) -> (probs, log_probs, value) of the reference's ActorCritic (model.py:12-41)."""
+    from azulnet import ActorCritic
+    torch.manual_seed(0)
+    net = ActorCritic(136, 180)
+    rs = np.random.RandomState(3)
+    obs = rs.randint(0, 5, size=(64, 136)).astype(np.float32)
+    mask = rs.rand(64, 180) < 0.15
+    mask[np.arange(64), rs.randint(0, 180, 64)] = True
+    with torch.no_grad():
+        value = net.forward_critic(torch.from_numpy(obs)).numpy()
+        probs, logp = net.forward_actor(torch.from_numpy(obs), torch.from_numpy(mask))
+    blob = {"obs": obs, "mask": mask, "value": value, "probs": probs.numpy(), "logp": logp.numpy()}
+    for k, v in net.state_dict().items():
+        blob["sd_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "policy_contract.npz"), **blob)
+    print("wrote policy_contract.npz")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("reference:", os.path.dirname(azulnet.__file__))
+    if len(sys.argv) > 1 and sys.argv[1] == "policy":
+        gen_policy_contract()
+        return
     gen_rng()
     gen_boards()
     gen_trajectories()
+    gen_policy_contract()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,151 @@
+"""Row N1: policy bridge for BASELINE configs[2] -- ActorCritic contract, fused policy_step,
+discounted returns, two-stream rollout.  Golden (weights, obs, mask) -> (probs, log-probs, value) triples come from
+the reference's own model.py (tests/golden/policy_contract.npz, oracle/gen_golden.py)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as oz
+
+
+@pytest.fixture(scope="module")
+def contract(golden_dir):
+    return np.load(os.path.join(golden_dir, "policy_contract.npz"))
+
+
+def _net(contract, device):
+    from azul_deep_reinforcement_learning_amd.policy import BatchedActorCritic
+    sd = {k[3:]: torch.from_numpy(contract[k]) for k in contract.files if k.startswith("sd_")}
+    return BatchedActorCritic.from_reference(sd).to(device)
+
+
+def test_actor_critic_contract_cpu(contract):
+    """Same parameter names / shapes / outputs as the reference module (82,081 parameters)."""
+    from azul_deep_reinforcement_learning_amd.policy import BatchedActorCritic, IllegalMask
+    net = _net(contract, "cpu")
+    assert sum(p.numel() for p in net.parameters()) == 82081
+    obs, mask = torch.from_numpy(contract["obs"]), torch.from_numpy(contract["mask"])
+    with torch.no_grad():
+        value = net.forward_critic(obs)
+        probs, logp = net.forward_actor(obs, mask)
+    assert value.shape == (64, 1) and probs.shape == (64, 180)
+    assert torch.allclose(value, torch.from_numpy(contract["value"]), atol=1e-5)
+    assert torch.allclose(probs, torch.from_numpy(contract["probs"]), atol=1e-6)
+    finite = torch.from_numpy(contract["mask"])
+    assert torch.allclose(logp[finite], torch.from_numpy(contract["logp"])[finite], atol=1e-5)
+    assert torch.isinf(logp[~finite]).all() and (probs[~finite] == 0).all()
+    assert torch.allclose(probs.sum(dim=1), torch.ones(64), atol=1e-5)
+    one = torch.zeros(1, 180, dtype=torch.bool)
+    one[0, 1] = True
+    assert net.forward_actor(obs[:1], one)[0][0, 1] == 1            # reference tests/test_model.py:27-35
+    with pytest.raises(IllegalMask):
+        net.forward_actor(obs[:1], torch.zeros(1, 180, dtype=torch.bool), check=True)   # tests/test_model.py:36-39
+    assert set(BatchedActorCritic().state_dict()) == {k[3:] for k in contract.files if k.startswith("sd_")}
+
+
+@pytest.mark.gpu
+def test_actor_critic_contract_gpu(contract):
+    net = _net(contract, "cuda")
+    obs, mask = torch.from_numpy(contract["obs"]).cuda(), torch.from_numpy(contract["mask"]).cuda()
+    with torch.no_grad():
+        value = net.forward_critic(obs).cpu()
+        probs, logp = [x.cpu() for x in net.forward_actor(obs, mask)]
+    # fp32 GEMM accumulation order differs on the GPU: tolerance, not bit-exactness
+    assert torch.allclose(value, torch.from_numpy(contract["value"]), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(probs, torch.from_numpy(contract["probs"]), atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_discounted_returns_matches_reference_loop():
+    from azul_deep_reinforcement_learning_amd import _lib as L
+    T, n, gamma = 57, 300, 0.99
+    rs = np.random.RandomState(0)
+    reward = rs.randint(-30, 25, size=(T, n)).astype(np.int32)
+    done = (rs.rand(T, n) < 0.03).astype(np.uint8)
+    exp = np.zeros((T, n), dtype=np.float64)
+    for g in range(n):
+        q = 0.0
+        for t in reversed(range(T)):                 # nn_runner.py:72-76, restarted at every episode end
+            if done[t, g]:
+                q = 0.0
+            q = reward[t, g] + gamma * q
+            exp[t, g] = q
+    r, d = torch.from_numpy(reward).cuda(), torch.from_numpy(done).cuda()
+    out = torch.zeros(T, n, device="cuda")
+    L.check(L.lib.azul_discounted_returns(C.c_void_p(r.data_ptr()), C.c_void_p(d.data_ptr()), C.c_void_p(out.data_ptr()), None,
+                                          C.c_float(gamma), T, n, None))
+    torch.cuda.synchronize()
+    assert np.allclose(out.cpu().numpy(), exp, rtol=1e-5, atol=1e-3)     # fp32 recurrence vs fp64
+
+
+def _oracle_replay(rec, mt, pos, fp, pool, actions):
+    """Flat policy-driven self-play in the oracle from a given record + CPython stream, with auto-reset."""
+    L = oz.lib()
+    q = oz.unpack(rec, pool, fp)
+    r = oz.Rng()
+    L.oz_rng_set(C.byref(r), mt.ctypes.data_as(C.POINTER(C.c_uint32)), int(pos))
+    out = {"mask": [], "obs": [], "player": [], "reward": [], "done": []}
+    for a in actions:
+        out["mask"].append(oz.check_all_valid(q.game))
+        cur = q.game.current_player
+        out["player"].append(cur)
+        out["obs"].append(oz.get_state(q.game, cur - 1))
+        d, c, p = int(a) % 6, (int(a) // 6) % 5, int(a) // 30
+        assert L.oz_step(C.byref(q.game), d, c, p, C.byref(r)) == 0
+        q.move_counter += 1
+        phi = L.oz_potential(C.byref(q.game))
+        out["reward"].append(phi - q.player_score)
+        q.player_score = phi
+        dn = bool(L.oz_is_end_of_game(C.byref(q.game)))
+        out["done"].append(dn)
+        if dn:
+            assert L.oz_runner_init(C.byref(q), fp, pool, C.byref(r)) == 0
+    return out, oz.pack(q)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_policy_rollout_replays_exactly_through_the_oracle(contract, use_graph):
+    """Everything the rollout records about the ENV (mask, observation, player, reward, done, final state) must be
+    what the oracle computes when it is fed the actions the policy sampled -- for both stream parts, eager launches
+    and HIP-graph replays alike."""
+    from azul_deep_reinforcement_learning_amd import PolicyRollout
+    torch.manual_seed(1)
+    net = _net(contract, "cuda")
+    T, n = 40, 64
+    ro = PolicyRollout(net, n_games=n, parts=2, seed_base=500, window=T, use_graph=use_graph)
+    assert ro.use_graph == use_graph, ro.graph_error
+    start = [(env.get_records(), [env.get_rng(g) for g in range(ro.h)]) for env in ro.envs]
+    windows = []
+    for _ in range(2):
+        tr = ro.run_window()
+        ro.synchronize()
+        windows.append([{k: v.cpu().numpy().copy() for k, v in part.items()} for part in tr])
+    finals = [env.get_records() for env in ro.envs]
+    for p in (0, 1):
+        for g in range(0, ro.h, 5):
+            acts = np.concatenate([w[p]["action"][:, g] for w in windows])
+            assert (acts >= 0).all()
+            mt, pos = start[p][1][g]
+            exp, final = _oracle_replay(start[p][0][g], mt, pos, oz.FIRST_RANDOM, oz.POOL_LID, acts)
+            got_mask = np.concatenate([w[p]["mask"][:, g] for w in windows]).astype(bool)
+            assert np.array_equal(got_mask, np.array(exp["mask"]))
+            assert np.array_equal(np.concatenate([w[p]["obs"][:, g] for w in windows]).astype(np.int64), np.array(exp["obs"]))
+            assert np.array_equal(np.concatenate([w[p]["player"][:, g] for w in windows]), np.array(exp["player"]))
+            assert np.array_equal(np.concatenate([w[p]["reward"][:, g] for w in windows]), np.array(exp["reward"]))
+            assert np.array_equal(np.concatenate([w[p]["done"][:, g] for w in windows]).astype(bool), np.array(exp["done"]))
+            assert final.tobytes() == finals[p][g].tobytes()
+    # policy-side records are self-consistent: the sampled action is legal, log_prob/entropy finite, returns follow the scan
+    for w in windows:
+        for part in w:
+            a = part["action"].astype(np.int64)
+            assert np.take_along_axis(part["mask"], a[..., None], axis=2).all()
+            assert np.isfinite(part["log_prob"]).all() and np.isfinite(part["entropy"]).all() and (part["entropy"] >= 0).all()
+            q = np.zeros(ro.h)
+            for t in reversed(range(T)):
+                q = np.where(part["done"][t] != 0, 0.0, q)
+                q = part["reward"][t] + 0.99 * q
+                assert np.allclose(part["returns"][t], q, rtol=1e-4, atol=1e-2)

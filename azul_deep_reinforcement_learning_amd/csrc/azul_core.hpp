@@ -180,6 +180,7 @@ static_assert(column_board_c(0) == 0x222201u && column_board_c(4) == 0x111110u, 
 struct LaneConst {
     vu32 spos[3];    // action a=64w+lane: cs lane of its source cell (31 = none)
     vu32 okpos[3];   // action a: bit of the "row accepts colour" board (31 = floor move, always ok)
+    vu32 acode[3];   // action a=64w+lane decoded once: src cell | display base << 5 | colour << 10 | row << 13 | from_display << 16
     vu32 rowp1;      // cp lane l<50: row+1, else 0xff
     // per pattern cell (lane l<50: player l/25, cell i=l%25, row r=i/5, colour c=i%5):
     vu32 prow, pcol_, pbcol; // r, c, board column (c+r)%5
@@ -195,6 +196,8 @@ AZ_FN void lane_consts(LaneConst &k)
         vu32 sp = sel(d == 0u, c + 25u, (d - 1u) * 5u + c);
         k.spos[w] = sel(a < 180u, sp, splat(31u));
         k.okpos[w] = sel(r == 0u, splat(31u), (r - 1u) * 5u + c);
+        vu32 db = sel(d == 0u, splat(0u), (d - 1u) * 5u);
+        k.acode[w] = sp | (db << 5) | (c << 10) | (r << 13) | (sel(d == 0u, splat(0u), splat(1u)) << 16);
     }
     vu32 l = lane();
     k.rowp1 = sel(l < 50u, ((l % 25u) / 5u) + 1u, splat(0xffu));
@@ -351,8 +354,9 @@ AZ_FN double tseq(const SampleTab &t, u32 J, u32 k)
     return tpat(t, J, k - J);
 }
 
-AZ_FN i32 random_agent(const Mask &m, Rng &r, const SampleTab &T)
+AZ_FN i32 random_agent(const Mask &m, Rng &r, const SampleTab &T, const LaneConst &k, u32 &code)
 {
+    code = 0;
     u32 c0 = popc64(m.m0), c1 = popc64(m.m1), c2 = popc64(m.m2);
     u32 J = popc64(m.m0 & 0x3fffffffull);             // legal floor moves (a < 30, weight 0.01)
     u32 L = c0 + c1 + c2;
@@ -401,7 +405,9 @@ AZ_FN i32 random_agent(const Mask &m, Rng &r, const SampleTab &T)
     u64 mw = in0 ? m.m0 : (in1 ? m.m1 : m.m2);
     vu32 bw = sel(splat(in0) != 0u, m.b0, sel(splat(in1) != 0u, m.b1, m.b2));
     u64 hit = ballot((bw != 0u) & (mbcnt(mw) == rank));
-    return (i32)(w * 64u + ctz64(hit));
+    u32 ln = ctz64(hit);
+    code = readlane(sel(splat(in0) != 0u, k.acode[0], sel(splat(in1) != 0u, k.acode[1], k.acode[2])), ln);
+    return (i32)(w * 64u + ln);
 }
 
 // ---- move: azul.py:118-161 ----
@@ -409,14 +415,21 @@ AZ_FN void byte_add(u64 &v, u32 idx, u32 n) { v += (u64)n << (8u * idx); }
 
 // returns true when the targeted pattern line is full after the move (its wall pricing must be (re)computed).
 // Written with selects instead of branches: a taken branch costs a wave far more than the few extra lane ops.
+AZ_FN u32 action_code(u32 a)
+{
+    // the same packing as LaneConst::acode, for an action given by number (game_runner.py:107-111)
+    u32 d = a % 6u, c = (a / 6u) % 5u, row = a / 30u;
+    u32 db = d ? 5u * (d - 1u) : 0u;
+    return (d ? db + c : 25u + c) | (db << 5) | (c << 10) | (row << 13) | ((d ? 1u : 0u) << 16);
+}
+
 template <bool LID>
-AZ_FN bool do_move(Game &g, u32 d, u32 c, u32 row)
+AZ_FN bool do_move(Game &g, u32 code)
 {
     u32 me = me_index(g);
     vu32 l = lane();
-    const bool from_display = d != 0u;
-    u32 db = from_display ? 5u * (d - 1u) : 0u;
-    u32 src = from_display ? db + c : 25u + c;                         // the source cell
+    const u32 src = code & 31u, db = (code >> 5) & 31u, c = (code >> 10) & 7u, row = (code >> 13) & 7u;   // the source cell, ...
+    const bool from_display = (code >> 16) != 0u;
     u32 n = readlane(g.cs, src);                                       // :127 / :136
     bool token = !from_display && readlane(g.cs, 30) == 1u;            // :140
     // display: every other colour of that display slides into the centre (:131), the display empties (:129,:133)
@@ -708,12 +721,10 @@ AZ_FN void decode_action(u32 a, u32 &d, u32 &c, u32 &row)
 
 // move + end-of-round bookkeeping; returns true when a new round has to be dealt (azul.py:304-313)
 template <bool LID>
-AZ_FN bool move_and_score(Game &g, const LaneConst &k, u32 a)
+AZ_FN bool move_and_score(Game &g, const LaneConst &k, u32 code)
 {
-    u32 d, c, row;
-    decode_action(a, d, c, row);
     u32 me = me_index(g);
-    bool filled = do_move<LID>(g, d, c, row);            // :304
+    bool filled = do_move<LID>(g, code);                 // :304
     if (sources_board(g) == 0u) {                        // :306 (the token counts)
         count_score<LID>(g, k);                          // :307
         if (is_end_of_game(g)) { g.eog = 1; return false; }   // :308-309
@@ -727,9 +738,9 @@ AZ_FN bool move_and_score(Game &g, const LaneConst &k, u32 a)
 }
 
 template <bool LID>
-AZ_FN u32 apply_step(Game &g, const LaneConst &k, Rng &r, u32 a)
+AZ_FN u32 apply_step(Game &g, const LaneConst &k, Rng &r, u32 code)
 {
-    if (move_and_score<LID>(g, k, a)) return new_round<LID>(g, r);
+    if (move_and_score<LID>(g, k, code)) return new_round<LID>(g, r);
     return ST_OK;
 }
 
@@ -741,7 +752,7 @@ AZ_FN u32 checked_step(Game &g, const LaneConst &k, Rng &r, i32 a)
     Mask m;
     legal_mask(g, k, m);
     if (!mask_test(m, (u32)a)) return ST_ILLEGAL_MOVE;   // :301-302, state untouched
-    return apply_step<LID>(g, k, r, (u32)a);
+    return apply_step<LID>(g, k, r, action_code((u32)a));
 }
 
 // ---- GameRunner.step with the default RandomAgent opponent: game_runner.py:43-55 ----
@@ -757,10 +768,11 @@ AZ_FN u32 runner_opponent_loop(Game &g, const LaneConst &k, Rng &r, const Sample
         bool keep = until_player1_only ? (g.cur != 1u)
                                        : ((g.cur != 1u || mask_count(m) < 2u) && !is_end_of_game(g));   // :46 / :84
         if (!keep) break;
-        i32 a = random_agent(m, r, T);                   // opponent_move, :37-42
+        u32 code;
+        i32 a = random_agent(m, r, T, k, code);          // opponent_move, :37-42
         if (a < 0) return ST_STUCK;
         if (g.eog) return ST_GAME_ENDED;
-        u32 st = apply_step<LID>(g, k, r, (u32)a);
+        u32 st = apply_step<LID>(g, k, r, code);
         if (st) return st;
         g.moves += 1u;
     }
@@ -928,10 +940,11 @@ AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, c
         if (os.mask) mask_write(m, os.mask);
         if (os.maskbits) mask_write_bits(m, os.maskbits);
     }
-    i32 a = g.eog ? -2 : random_agent(m, r, T);
+    u32 code = 0;
+    i32 a = g.eog ? -2 : random_agent(m, r, T, k, code);
     bool deal = false;                 // a new round has to be dealt
     if (!AZ_UNLIKELY(a < 0)) {
-        deal = move_and_score<LID>(g, k, (u32)a);
+        deal = move_and_score<LID>(g, k, code);
         g.moves += 1u;
     }
     u32 result = 0, st = ST_OK;

@@ -110,9 +110,7 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
         case OP_MOVE: {
             i32 av = a.actions[gi];
             if (av < 0 || av >= 180) { st = ST_BAD_ACTION; dirty_state = false; break; }
-            u32 d, c, row;
-            decode_action((u32)av, d, c, row);
-            do_move<LID>(g, d, c, row);
+            do_move<LID>(g, action_code((u32)av));
         } break;
         case OP_NEXT_PLAYER:
             g.cur = (g.cur < 2u) ? g.cur + 1u : 1u;
@@ -147,7 +145,8 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
         case OP_RANDOM_ACTION: {
             Mask m;
             legal_mask(g, k, m);
-            i32 av = random_agent(m, r, tab);
+            u32 code;
+            i32 av = random_agent(m, r, tab, k, code);
             AZ_LANE0(a.actions_out[gi] = av);
             dirty_state = false;
         } break;
@@ -206,7 +205,8 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
             m.b1 = ld_u8(mi, l + 64u, l < 64u) != 0u ? 1u : 0u;
             m.b2 = ld_u8(mi, l + 128u, l < 52u) != 0u ? 1u : 0u;
             m.m0 = ballot(m.b0 != 0u); m.m1 = ballot(m.b1 != 0u); m.m2 = ballot(m.b2 != 0u);
-            i32 av = random_agent(m, r, tab);
+            u32 code;
+            i32 av = random_agent(m, r, tab, k, code);
             AZ_LANE0(a.actions_out[gi] = av);
             dirty_state = false;
         } break;

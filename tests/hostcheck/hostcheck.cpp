@@ -148,8 +148,7 @@ void hc_count_score(uint8_t *rec, int tile_pool)
 void hc_move(uint8_t *rec, int action, int tile_pool)
 {
     Game g; game_load(g, rec);
-    u32 d, c, row; decode_action((u32)action, d, c, row);
-    if (tile_pool == POOL_LID) do_move<true>(g, d, c, row); else do_move<false>(g, d, c, row);
+    if (tile_pool == POOL_LID) do_move<true>(g, action_code((u32)action)); else do_move<false>(g, action_code((u32)action));
     game_store(g, rec);
 }
 
@@ -203,7 +202,8 @@ int hc_random_action(const uint8_t *rec, u32 *mt, u32 *pos)
     Game g; game_load(g, rec);
     Rng r; rng_open(r, mt, lds, *pos);
     Mask m; legal_mask(g, k, m);
-    i32 a = random_agent(m, r, table());
+    u32 code;
+    i32 a = random_agent(m, r, table(), k, code);
     rng_close(r, pos);
     return a;
 }
@@ -253,7 +253,9 @@ int hc_sample_mask(const uint8_t *mask180, u32 *mt, u32 *pos)
     m.b2 = sel(ld_u8(mask180, l + 128u, l < 52u) != 0u, splat(1u), splat(0u));
     m.m0 = ballot(m.b0 != 0u); m.m1 = ballot(m.b1 != 0u); m.m2 = ballot(m.b2 != 0u);
     Rng r; rng_open(r, mt, lds, *pos);
-    i32 a = random_agent(m, r, table());
+    LaneConst k; lane_consts(k);
+    u32 code;
+    i32 a = random_agent(m, r, table(), k, code);
     rng_close(r, pos);
     return a;
 }

@@ -88,11 +88,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # AZUL_BENCH_BACKEND=gloo is a REHEARSAL mode for boxes with fewer GPUs than ranks (ranks share devices, the
+    # all-gather goes through gloo); the driver's multi-GPU runs use the default: nccl (= RCCL over xGMI), one GPU per rank.
+    backend = os.environ.get("AZUL_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from azul_deep_reinforcement_learning_amd import BatchedAzul
     from azul_deep_reinforcement_learning_amd.parallel import TrajectoryGather
@@ -168,7 +176,8 @@ def main():
                                    "rules Lid + random first player, seeds base+global_id, auto-reset" % G,
                        "games_per_gpu": G, "global_games": G * world, "moves_per_launch": T,
                        "parallelism": "games sharded by global id; %s" %
-                                      ("RCCL all-gather of trajectory buffers overlapped on a side stream" if gather else "no collective")},
+                                      (("%s all-gather of trajectory buffers overlapped with the next launch" %
+                                        ("RCCL" if backend == "nccl" else backend)) if gather else "no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "azul_selfplay_kernel", "avg_launch_ms": avg_launch_s * 1e3,

@@ -300,13 +300,6 @@ AZ_FN u64 mask_word(const Mask &m, u32 w) { return w == 0u ? m.m0 : (w == 1u ? m
 AZ_FN u32 mask_test(const Mask &m, u32 a) { return (u32)(mask_word(m, a >> 6) >> (a & 63u)) & 1u; }
 AZ_FN u32 mask_count(const Mask &m) { return popc64(m.m0) + popc64(m.m1) + popc64(m.m2); }
 
-AZ_FN vu32 lane_bit(u64 m)
-{
-    vu32 l = lane();
-    u32 lo = (u32)m, hi = (u32)(m >> 32);
-    return sel(l < 32u, (lo >> (l & 31u)) & 1u, (hi >> (l & 31u)) & 1u);
-}
-
 AZ_FN void mask_write(const Mask &m, uint8_t *out)
 {
     vu32 l = lane();
@@ -714,11 +707,6 @@ AZ_FN u32 episode_reset(Game &g, u32 first_player, Rng &r)
 }
 
 // ---- step: azul.py:296-313 (legality is checked by the caller against the mask) ----
-AZ_FN void decode_action(u32 a, u32 &d, u32 &c, u32 &row)
-{
-    d = a % 6u; c = (a / 6u) % 5u; row = a / 30u;       // game_runner.py:107-111
-}
-
 // move + end-of-round bookkeeping; returns true when a new round has to be dealt (azul.py:304-313)
 template <bool LID>
 AZ_FN bool move_and_score(Game &g, const LaneConst &k, u32 code)

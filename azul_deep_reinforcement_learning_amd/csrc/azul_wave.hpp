@@ -34,13 +34,6 @@ typedef double vf64;
 
 AZ_FN vu32 lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 AZ_FN u64  ballot(vbool p) { return __builtin_amdgcn_ballot_w64(p); }
-AZ_FN u32  uni(u32 x) { return __builtin_amdgcn_readfirstlane(x); }
-AZ_FN u64  uni64(u64 x)
-{
-    u32 lo = __builtin_amdgcn_readfirstlane((u32)x), hi = __builtin_amdgcn_readfirstlane((u32)(x >> 32));
-    return ((u64)hi << 32) | lo;
-}
-AZ_FN double unid(double x) { return __longlong_as_double((long long)uni64((u64)__double_as_longlong(x))); }
 AZ_FN u32  readlane(vu32 v, u32 l) { return __builtin_amdgcn_readlane(v, l); }
 // (clang exposes no writelane builtin for this target; compare+select is one v_cmp + one v_cndmask)
 AZ_FN vu32 writelane(vu32 v, u32 val, u32 l) { return lane() == l ? val : v; }
@@ -147,9 +140,6 @@ AZ_FN vbool operator!(const vbool &a) { vbool r; for (int i = 0; i < 64; i++) r.
 AZ_FN vbool operator&(const vbool &a, bool b) { vbool r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] && b; return r; }
 
 AZ_FN u64  ballot(const vbool &p) { u64 m = 0; for (int i = 0; i < 64; i++) if (p.v[i]) m |= 1ull << i; return m; }
-AZ_FN u32  uni(u32 x) { return x; }
-AZ_FN u64  uni64(u64 x) { return x; }
-AZ_FN double unid(double x) { return x; }
 AZ_FN u32  readlane(const vu32 &v, u32 l) { return v.v[l & 63]; }
 AZ_FN vu32 writelane(vu32 v, u32 val, u32 l) { v.v[l & 63] = val; return v; }
 AZ_FN vu32 bperm(const vu32 &v, const vu32 &idx) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = v.v[idx.v[i] & 63]; return r; }

@@ -424,7 +424,7 @@ AZ_FN bool do_move(Game &g, u32 code)
     const u32 src = code & 31u, db = (code >> 5) & 31u, c = (code >> 10) & 7u, row = (code >> 13) & 7u;   // the source cell, ...
     const bool from_display = (code >> 16) != 0u;
     u32 n = readlane(g.cs, src);                                       // :127 / :136
-    bool token = !from_display && readlane(g.cs, 30) == 1u;            // :140
+    bool token = (!from_display) & (readlane(g.cs, 30) == 1u);         // :140 (no short-circuit: a branch costs more)
     // display: every other colour of that display slides into the centre (:131), the display empties (:129,:133)
     vu32 moved = bperm(g.cs, l - 25u + db);
     vbool centre = (l >= 25u) & (l < 30u) & (l != 25u + c) & from_display;
@@ -442,9 +442,10 @@ AZ_FN bool do_move(Game &g, u32 code)
     g.cp = sel((l == cell) & (row != 0u), splat(newv), g.cp);
     fl += spill;                                                       // :154 / :159
     fl = fl < 7u ? fl : 7u;
-    if (me) g.floor1 = fl; else g.floor0 = fl;
+    g.floor0 = me ? g.floor0 : fl;
+    g.floor1 = me ? fl : g.floor1;
     if (LID) byte_add(g.lid, c, spill);                                // :156-157 / :160-161
-    return row != 0u && overflow <= 0;
+    return (row != 0u) & (overflow <= 0);
 }
 
 // ---- scoring: azul.py:192-295 on 25-bit wall bitboards ----
@@ -719,8 +720,11 @@ AZ_FN bool move_and_score(Game &g, const LaneConst &k, u32 code)
         return true;                                     // :311
     }
     if (filled) whatif_refresh<LID>(g, k, me);
-    else if (me) g.wi1 = clamp0(g.score1 + floor_penalty(g.floor1) + g.wc1);
-    else g.wi0 = clamp0(g.score0 + floor_penalty(g.floor0) + g.wc0);
+    else {
+        i32 w = clamp0((me ? g.score1 : g.score0) + floor_penalty(me ? g.floor1 : g.floor0) + (me ? g.wc1 : g.wc0));
+        g.wi0 = me ? g.wi0 : w;
+        g.wi1 = me ? w : g.wi1;
+    }
     g.cur = (g.cur < 2u) ? g.cur + 1u : 1u;              // :313 next_player
     return false;
 }

@@ -180,7 +180,7 @@ static_assert(column_board_c(0) == 0x222201u && column_board_c(4) == 0x111110u, 
 struct LaneConst {
     vu32 spos[3];    // action a=64w+lane: cs lane of its source cell (31 = none)
     vu32 okpos[3];   // action a: bit of the "row accepts colour" board (31 = floor move, always ok)
-    vu32 acode[3];   // action a=64w+lane decoded once: src cell | display base << 5 | colour << 10 | row << 13 | from_display << 16
+    vu32 acode[3];   // action a=64w+lane decoded once: src cell | display base << 5 | colour << 10 | row << 13 | from_display << 16 | a << 17
     vu32 rowp1;      // cp lane l<50: row+1, else 0xff
     // per pattern cell (lane l<50: player l/25, cell i=l%25, row r=i/5, colour c=i%5):
     vu32 prow, pcol_, pbcol; // r, c, board column (c+r)%5
@@ -197,7 +197,7 @@ AZ_FN void lane_consts(LaneConst &k)
         k.spos[w] = sel(a < 180u, sp, splat(31u));
         k.okpos[w] = sel(r == 0u, splat(31u), (r - 1u) * 5u + c);
         vu32 db = sel(d == 0u, splat(0u), (d - 1u) * 5u);
-        k.acode[w] = sp | (db << 5) | (c << 10) | (r << 13) | (sel(d == 0u, splat(0u), splat(1u)) << 16);
+        k.acode[w] = sp | (db << 5) | (c << 10) | (r << 13) | (sel(d == 0u, splat(0u), splat(1u)) << 16) | (a << 17);
     }
     vu32 l = lane();
     k.rowp1 = sel(l < 50u, ((l % 25u) / 5u) + 1u, splat(0xffu));
@@ -391,16 +391,14 @@ AZ_FN i32 random_agent(const Mask &m, Rng &r, const SampleTab &T, const LaneCons
         }
         kg = J + mg;
     }
-    // kg-th legal action
-    u32 in0 = kg <= c0, in1 = kg <= c0 + c1;
-    u32 w = in0 ? 0u : (in1 ? 1u : 2u);
-    u32 rank = kg - 1u - (in0 ? 0u : (in1 ? c0 : c0 + c1));
-    u64 mw = in0 ? m.m0 : (in1 ? m.m1 : m.m2);
-    vu32 bw = sel(splat(in0) != 0u, m.b0, sel(splat(in1) != 0u, m.b1, m.b2));
-    u64 hit = ballot((bw != 0u) & (mbcnt(mw) == rank));
-    u32 ln = ctz64(hit);
-    code = readlane(sel(splat(in0) != 0u, k.acode[0], sel(splat(in1) != 0u, k.acode[1], k.acode[2])), ln);
-    return (i32)(w * 64u + ln);
+    // kg-th legal action: every lane ranks its own three actions (prefix popcounts), the one with rank kg answers
+    u32 want = kg - 1u;
+    vbool p0 = (m.b0 != 0u) & (mbcnt(m.m0) == want);
+    vbool p1 = (m.b1 != 0u) & (mbcnt(m.m1) + c0 == want);
+    vbool p2 = (m.b2 != 0u) & (mbcnt(m.m2) + (c0 + c1) == want);
+    u32 ln = ctz64(ballot(p0 | p1 | p2));
+    code = readlane(sel(p0, k.acode[0], sel(p1, k.acode[1], k.acode[2])), ln);
+    return (i32)(code >> 17);
 }
 
 // ---- move: azul.py:118-161 ----
@@ -413,7 +411,7 @@ AZ_FN u32 action_code(u32 a)
     // the same packing as LaneConst::acode, for an action given by number (game_runner.py:107-111)
     u32 d = a % 6u, c = (a / 6u) % 5u, row = a / 30u;
     u32 db = d ? 5u * (d - 1u) : 0u;
-    return (d ? db + c : 25u + c) | (db << 5) | (c << 10) | (row << 13) | ((d ? 1u : 0u) << 16);
+    return (d ? db + c : 25u + c) | (db << 5) | (c << 10) | (row << 13) | ((d ? 1u : 0u) << 16) | (a << 17);
 }
 
 template <bool LID>
@@ -422,7 +420,7 @@ AZ_FN bool do_move(Game &g, u32 code)
     u32 me = me_index(g);
     vu32 l = lane();
     const u32 src = code & 31u, db = (code >> 5) & 31u, c = (code >> 10) & 7u, row = (code >> 13) & 7u;   // the source cell, ...
-    const bool from_display = (code >> 16) != 0u;
+    const bool from_display = ((code >> 16) & 1u) != 0u;
     u32 n = readlane(g.cs, src);                                       // :127 / :136
     bool token = (!from_display) & (readlane(g.cs, 30) == 1u);         // :140 (no short-circuit: a branch costs more)
     // display: every other colour of that display slides into the centre (:131), the display empties (:129,:133)

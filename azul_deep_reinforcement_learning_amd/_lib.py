@@ -53,7 +53,7 @@ SIGNATURES = {
     "azul_discounted_returns": (_i, [_vp, _vp, _vp, _vp, C.c_float, _i, _i, _vp]),
     "azul_batch_sample_mask": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "azul_batch_score_preview": (_i, [_vp, _vp, _vp]),
-    "azul_batch_selfplay": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "azul_batch_selfplay": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "azul_batch_counters": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "azul_batch_reset_counters": (_i, [_vp, _vp]),
     "azul_batch_set_draw_margin": (_i, [_vp, _u64]),

@@ -209,29 +209,23 @@ class BatchedAzul:
                                              self._stream()))
 
     # -- flat self-play rollout -------------------------------------------------------------------
-    def selfplay(self, n_steps, mask=None, action=None, reward=None, done=None, records=None, maskbits=None):
+    def selfplay(self, n_steps, mask=None, action=None, reward=None, done=None, records=None, maskbits=None, packed=None):
         """`n_steps` env moves for every game in one launch; outputs are preallocated tensors or None."""
         L.check(L.lib.azul_batch_selfplay(self._h, int(n_steps), _ptr(mask), _ptr(maskbits), _ptr(action), _ptr(reward),
-                                          _ptr(done), _ptr(records), self._stream()))
+                                          _ptr(done), _ptr(packed), _ptr(records), self._stream()))
 
     def alloc_trajectory(self, n_steps, with_records=False, packed_mask=False):
-        """Trajectory buffers [n_steps][N]....  With `packed_mask` the compact record (maskbits 24 B + action 4 +
-        reward 4 + done 1 per move) lives in ONE contiguous byte buffer `flat`, so that a single all-gather ships it."""
+        """Trajectory buffers [n_steps][N]....  With `packed_mask` also the bit-packed mask `maskbits` (int64 [T][N][3])
+        and the compact per-move record `packed` (int32 [T][N]: action | done << 8 | reward << 16) -- the two
+        contiguous arrays the multi-GPU all-gather ships."""
         n = self.n
-        t = {"mask": self._new((n_steps, n, L.NUM_ACTIONS), torch.uint8)}
+        t = {"mask": self._new((n_steps, n, L.NUM_ACTIONS), torch.uint8),
+             "action": self._new((n_steps, n), torch.int32),
+             "reward": self._new((n_steps, n), torch.int32),
+             "done": self._new((n_steps, n), torch.uint8)}
         if packed_mask:
-            sizes = [n_steps * n * 24, n_steps * n * 4, n_steps * n * 4, n_steps * n]
-            flat = torch.zeros(sum(sizes), dtype=torch.uint8, device=self.device)
-            o = np.cumsum([0] + sizes)
-            t["flat"] = flat
-            t["maskbits"] = flat[o[0]:o[1]].view(torch.int64).view(n_steps, n, 3)
-            t["action"] = flat[o[1]:o[2]].view(torch.int32).view(n_steps, n)
-            t["reward"] = flat[o[2]:o[3]].view(torch.int32).view(n_steps, n)
-            t["done"] = flat[o[3]:o[4]].view(n_steps, n)
-        else:
-            t["action"] = self._new((n_steps, n), torch.int32)
-            t["reward"] = self._new((n_steps, n), torch.int32)
-            t["done"] = self._new((n_steps, n), torch.uint8)
+            t["maskbits"] = torch.zeros((n_steps, n, 3), dtype=torch.int64, device=self.device)
+            t["packed"] = torch.zeros((n_steps, n), dtype=torch.int32, device=self.device)
         if with_records:
             t["records"] = self._new((n_steps, n, L.RECORD_BYTES), torch.uint8)
         return t

@@ -882,7 +882,7 @@ struct Counters {
 // Trajectory streams of the self-play kernel.  OUT == 1 (every stream present, the benchmarked form) keeps them as
 // per-lane pointers; OUT == 2 (any subset, run-time checked, plus the test-only record stream) as scalar pointers.
 struct OutV {
-    vptr p32;    // lane 1: reward[t][g], every other lane: action[t][g]
+    vptr p32;    // lane 1: reward[t][g], lane 2: packed[t][g], every other lane: action[t][g]
     vptr p8;     // done[t][g]
     vptr p64;    // maskbits[t][g][min(lane, 2)]
     vptr pm;     // mask[t][g][lane]  (bytes 0..63; bytes 64..127 through the +64 immediate)
@@ -890,10 +890,10 @@ struct OutV {
     u32 s32, s8, s64, sm;   // byte strides between consecutive moves
 };
 
-AZ_FN void outv_open(OutV &o, u32 gi, u32 n, uint8_t *mask, u64 *maskbits, i32 *action, i32 *reward, uint8_t *done)
+AZ_FN void outv_open(OutV &o, u32 gi, u32 n, uint8_t *mask, u64 *maskbits, i32 *action, i32 *reward, uint8_t *done, u32 *packed)
 {
     vu32 l = lane();
-    o.p32 = vptr_sel(l == 1u, vptr_splat(reward + gi), vptr_splat(action + gi));
+    o.p32 = vptr_sel(l == 1u, vptr_splat(reward + gi), vptr_sel(l == 2u, vptr_splat(packed + gi), vptr_splat(action + gi)));
     o.p8 = vptr_splat(done + gi);
     o.p64 = vptr_off(vptr_splat(maskbits + (size_t)gi * 3), vmin(l, 2u) * 8u);
     o.pm = vptr_off(vptr_splat(mask + (size_t)gi * 180), l);
@@ -907,7 +907,10 @@ AZ_FN void outv_next(OutV &o)
     o.pm = vptr_add(o.pm, o.sm); o.pm2 = vptr_add(o.pm2, o.sm);
 }
 
-struct OutS { uint8_t *mask; u64 *maskbits; i32 *action; i32 *reward; uint8_t *done; uint8_t *rec; };
+struct OutS { uint8_t *mask; u64 *maskbits; i32 *action; i32 *reward; uint8_t *done; uint8_t *rec; u32 *packed; };
+
+// compact trajectory record of one move (what the multi-GPU all-gather ships): action (0xff = none) | done << 8 | reward << 16
+AZ_FN u32 pack_move(i32 a, u32 dn, i32 reward) { return ((u32)(a >= 0 ? a : 0xff) & 0xffu) | ((dn & 0xffu) << 8) | (((u32)reward & 0xffffu) << 16); }
 
 // OUT: 0 = no trajectory outputs, 1 = all five streams through OutV, 2 = any subset through OutS (run-time checks)
 // returns 0 = move played, 1 = game ended with this move, 2 = stuck, 0x100|status on a rule error.
@@ -956,12 +959,14 @@ AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, c
             AZ_LANE0(*cnt.stuck += 1u);
         }
         if (OUT == 1) {
-            vst_u32(ov.p32, sel(lane() == 1u, splat((u32)reward), splat((u32)(a >= 0 ? a : -1))));
+            vu32 l = lane();
+            vst_u32(ov.p32, sel(l == 1u, splat((u32)reward), sel(l == 2u, splat(pack_move(a, dn, reward)), splat((u32)(a >= 0 ? a : -1)))));
             vst_u8(ov.p8, splat(dn));
         } else if (OUT == 2) {
             if (os.action) stu_i32(os.action, a >= 0 ? a : -1);
             if (os.reward) stu_i32(os.reward, reward);
             if (os.done) stu_u8(os.done, dn);
+            if (os.packed) stu_i32((i32 *)os.packed, (i32)pack_move(a, dn, reward));
             if (os.rec) game_store(g, os.rec);
         }
         result = dn;

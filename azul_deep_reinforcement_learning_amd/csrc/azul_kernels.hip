@@ -271,6 +271,7 @@ struct TrajArgs {
     i32 *reward;       // [T][N]
     uint8_t *done;     // [T][N]
     uint8_t *rec;      // [T][N][128]
+    u32 *packed;       // [T][N]
 };
 
 template <bool LID, int OUT>
@@ -293,12 +294,12 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
     r.margin = b.draw_margin;
     Counters cnt = {b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10};
     OutV ov;
-    OutS os = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t sm = 0, sb = 0, sa = 0, sr = 0, sd = 0, sc = 0;
+    OutS os = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t sm = 0, sb = 0, sa = 0, sr = 0, sd = 0, sc = 0, sp = 0;
     if (OUT == 1) {
-        outv_open(ov, gi, b.n, t.mask, t.maskbits, t.action, t.reward, t.done);
+        outv_open(ov, gi, b.n, t.mask, t.maskbits, t.action, t.reward, t.done, t.packed);
     } else {
-        outv_open(ov, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+        outv_open(ov, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
         if (OUT == 2) {
             os.mask = t.mask ? t.mask + (size_t)gi * AZUL_NUM_ACTIONS : nullptr;
             os.maskbits = t.maskbits ? t.maskbits + (size_t)gi * 3 : nullptr;
@@ -306,6 +307,8 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
             os.reward = t.reward ? t.reward + gi : nullptr;
             os.done = t.done ? t.done + gi : nullptr;
             os.rec = t.rec ? t.rec + (size_t)gi * AZUL_RECORD_BYTES : nullptr;
+            os.packed = t.packed ? t.packed + gi : nullptr;
+            sp = os.packed ? N : 0;
             sm = os.mask ? N * AZUL_NUM_ACTIONS : 0; sb = os.maskbits ? N * 3 : 0; sa = os.action ? N : 0;
             sr = os.reward ? N : 0; sd = os.done ? N : 0; sc = os.rec ? N * AZUL_RECORD_BYTES : 0;   // a NULL stream stays NULL
         }
@@ -315,7 +318,7 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
         u32 f = selfplay_step<LID, OUT>(g, b.rules.first_player, k, r, tab, cnt, ov, os);
         if (f & 0x100u) break;      // rule error (box empty): leave the game as it is
         if (OUT == 1) outv_next(ov);
-        if (OUT == 2) { os.mask += sm; os.maskbits += sb; os.action += sa; os.reward += sr; os.done += sd; os.rec += sc; }
+        if (OUT == 2) { os.mask += sm; os.maskbits += sb; os.action += sa; os.reward += sr; os.done += sd; os.rec += sc; os.packed += sp; }
     }
     game_store(g, rec);
     rng_close(r, b.mtpos + gi);
@@ -638,13 +641,13 @@ int azul_batch_score_preview(azul_batch_t *b, int32_t *potential_dev, void *stre
 }
 
 int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_t *maskbits_dev, int32_t *action_dev,
-                        int32_t *reward_dev, uint8_t *done_dev, uint8_t *rec_dev, void *stream)
+                        int32_t *reward_dev, uint8_t *done_dev, uint32_t *packed_dev, uint8_t *rec_dev, void *stream)
 {
     if (!b || n_steps < 0) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: bad arguments");
     if (n_steps == 0) return AZUL_SUCCESS;
-    TrajArgs t = {n_steps, mask_dev, (u64 *)maskbits_dev, action_dev, reward_dev, done_dev, rec_dev};
-    const bool none = !mask_dev && !maskbits_dev && !action_dev && !reward_dev && !done_dev && !rec_dev;
-    const bool full = mask_dev && maskbits_dev && action_dev && reward_dev && done_dev && !rec_dev;
+    TrajArgs t = {n_steps, mask_dev, (u64 *)maskbits_dev, action_dev, reward_dev, done_dev, rec_dev, packed_dev};
+    const bool none = !mask_dev && !maskbits_dev && !action_dev && !reward_dev && !done_dev && !rec_dev && !packed_dev;
+    const bool full = mask_dev && maskbits_dev && action_dev && reward_dev && done_dev && packed_dev && !rec_dev;
     const dim3 grid(b->d.n), block(64);
     const hipStream_t st = (hipStream_t)stream;
 #define AZ_LAUNCH(LID) do { \

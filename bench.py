@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--seed-base", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL trajectory all-gather")
+    ap.add_argument("--gather-masks", action="store_true", help="N>1: also ship the bit-packed legal masks (24 B/move)")
     return ap.parse_args()
 
 
@@ -112,7 +113,7 @@ def main():
     env.runner_init()                                    # GameRunner()
     env.runner_init()                                    # reset()   (DESIGN.md "stream semantics")
     bufs = [env.alloc_trajectory(T, packed_mask=True) for _ in range(2)]
-    gather = TrajectoryGather(world, dev) if (world > 1 and not args.no_gather) else None
+    gather = TrajectoryGather(world, dev, with_masks=args.gather_masks) if (world > 1 and not args.no_gather) else None
 
     def run(n_steps, timed):
         done_steps, i = 0, 0
@@ -121,7 +122,7 @@ def main():
             b = bufs[i & 1]
             if gather is not None:
                 gather.wait_buffer_free(i & 1)           # the all-gather that last read this buffer has finished
-            env.selfplay(t, b["mask"], b["action"], b["reward"], b["done"], maskbits=b["maskbits"])
+            env.selfplay(t, b["mask"], b["action"], b["reward"], b["done"], maskbits=b["maskbits"], packed=b["packed"])
             if gather is not None:
                 gather.launch(i & 1, b, t)               # side stream, overlaps the next launch
             done_steps += t
@@ -176,8 +177,8 @@ def main():
                                    "rules Lid + random first player, seeds base+global_id, auto-reset" % G,
                        "games_per_gpu": G, "global_games": G * world, "moves_per_launch": T,
                        "parallelism": "games sharded by global id; %s" %
-                                      (("%s all-gather of trajectory buffers overlapped with the next launch" %
-                                        ("RCCL" if backend == "nccl" else backend)) if gather else "no collective")},
+                                      (("%s all-gather of the compact trajectory records%s, issued async behind each launch" %
+                                        ("RCCL" if backend == "nccl" else backend, " + mask bits" if args.gather_masks else "")) if gather else "no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "azul_selfplay_kernel", "avg_launch_ms": avg_launch_s * 1e3,

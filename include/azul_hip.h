@@ -161,10 +161,11 @@ int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, 
  *   action_dev int32 [n_steps][N]        chosen action (-1 when stuck)
  *   reward_dev int32 [n_steps][N]
  *   done_dev   uint8 [n_steps][N]        1 = game ended with this move, 2 = stuck (no move, reset)
+ *   packed_dev uint32 [n_steps][N]       compact record: action (0xff = none) | done << 8 | (reward & 0xffff) << 16
  *   rec_dev    uint8 [n_steps][N][128]   record after the move, before the auto-reset (tests only)
  */
 int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_t *maskbits_dev, int32_t *action_dev,
-                        int32_t *reward_dev, uint8_t *done_dev, uint8_t *rec_dev, void *stream);
+                        int32_t *reward_dev, uint8_t *done_dev, uint32_t *packed_dev, uint8_t *rec_dev, void *stream);
 /* per-game counters accumulated by selfplay / runner_step: episodes[N] u64, stuck[N] u32, stat sums [N][10] f64 (host copies; NULL to skip) */
 int azul_batch_counters(azul_batch_t *b, uint64_t *episodes_host, uint32_t *stuck_host, double *stat_sums_host, void *stream);
 int azul_batch_reset_counters(azul_batch_t *b, void *stream);

@@ -10,7 +10,7 @@ env = BatchedAzul(n)
 env.seed(0); env.runner_init(); env.runner_init()
 t = env.alloc_trajectory(T, packed_mask=True)
 for _ in range(3):
-    env.selfplay(T, t["mask"], t["action"], t["reward"], t["done"], maskbits=t["maskbits"])
+    env.selfplay(T, t["mask"], t["action"], t["reward"], t["done"], maskbits=t["maskbits"], packed=t["packed"])
 torch.cuda.synchronize()
 for outputs in (True, False):
     env.timing_begin()
@@ -18,7 +18,7 @@ for outputs in (True, False):
     reps = 20
     for _ in range(reps):
         if outputs:
-            env.selfplay(T, t["mask"], t["action"], t["reward"], t["done"], maskbits=t["maskbits"])
+            env.selfplay(T, t["mask"], t["action"], t["reward"], t["done"], maskbits=t["maskbits"], packed=t["packed"])
         else:
             env.selfplay(T)
     ms, launches = env.timing_end()

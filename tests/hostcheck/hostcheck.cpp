@@ -44,8 +44,9 @@ static int advance(HostStream *h, int n_steps, uint8_t *mask, int32_t *action, i
     const bool full = mask && action && reward && done && !rec_after;
     static u64 bits_sink[3 * 4096];
     OutV ov;
-    outv_open(ov, 0, 1, mask ? mask : (uint8_t *)bits_sink, bits_sink, action, reward, done);
-    OutS os = {mask, nullptr, action, reward, done, rec_after};
+    static u32 packed_sink[4096];
+    outv_open(ov, 0, 1, mask ? mask : (uint8_t *)bits_sink, bits_sink, action, reward, done, packed_sink);
+    OutS os = {mask, nullptr, action, reward, done, rec_after, nullptr};
     for (int t = 0; t < n_steps; t++) {
         u32 f = full ? selfplay_step<LID, 1>(g, h->rules.first_player, k, r, table(), cnt, ov, os)
                      : selfplay_step<LID, 2>(g, h->rules.first_player, k, r, table(), cnt, ov, os);

@@ -13,27 +13,23 @@ import torch.multiprocessing as mp
 G, T = 8, 40       # games per rank, moves per chunk
 
 
-def _flat_from_oracle(rank, chunk):
+def _bufs_from_oracle(rank, chunk):
     from azul_deep_reinforcement_learning_amd.parallel import shard_seed_base
     from oracle import oracle as oz
     base = shard_seed_base(100, G, rank)
-    sizes = [T * G * 24, T * G * 4, T * G * 4, T * G]
-    flat = torch.zeros(sum(sizes), dtype=torch.uint8)
-    o = np.cumsum([0] + sizes)
-    maskbits = flat[o[0]:o[1]].view(torch.int64).view(T, G, 3)
-    action = flat[o[1]:o[2]].view(torch.int32).view(T, G)
-    reward = flat[o[2]:o[3]].view(torch.int32).view(T, G)
-    done = flat[o[3]:o[4]].view(T, G)
+    maskbits = torch.zeros(T, G, 3, dtype=torch.int64)
+    packed = torch.zeros(T, G, dtype=torch.int32)
     for g in range(G):
         s = oz.Stream(base + g)
         s.advance(chunk * T, want_records=False)
         out = s.advance(T, want_records=False)
         bits = np.packbits(np.pad(out["mask"], ((0, 0), (0, 12))), axis=1, bitorder="little").view(np.int64)
         maskbits[:, g, :] = torch.from_numpy(bits.copy())
-        action[:, g] = torch.from_numpy(out["action"])
-        reward[:, g] = torch.from_numpy(out["reward"])
-        done[:, g] = torch.from_numpy(out["done"])
-    return {"flat": flat, "maskbits": maskbits, "action": action, "reward": reward, "done": done}
+        a = np.where(out["action"] < 0, 0xFF, out["action"]).astype(np.uint32) & 0xFF
+        p = a | (out["done"].astype(np.uint32) << 8) | ((out["reward"].astype(np.int64) & 0xFFFF).astype(np.uint32) << 16)
+        packed[:, g] = torch.from_numpy(p.astype(np.uint32).view(np.int32))
+    return {"maskbits": maskbits, "packed": packed,
+            "action": torch.zeros(0), "reward": torch.zeros(0), "done": torch.zeros(0)}, out
 
 
 def _worker(rank, world, port, q):
@@ -41,17 +37,15 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from azul_deep_reinforcement_learning_amd.parallel import TrajectoryGather
-    tg = TrajectoryGather(world, torch.device("cpu"))
-    bufs = []
+    tg = TrajectoryGather(world, torch.device("cpu"), with_masks=True)
     for chunk in range(3):                       # double-buffered like bench.py
         slot = chunk & 1
         tg.wait_buffer_free(slot)
-        b = _flat_from_oracle(rank, chunk)
-        bufs.append(b)
+        b, _ = _bufs_from_oracle(rank, chunk)
         tg.launch(slot, b, T)
     tg.finish()
     got = tg.gathered(0, T, G)                   # slot 0 holds chunk 2
-    q.put((rank, {k: v.numpy() for k, v in got.items()}))
+    q.put((rank, {k: v.numpy().copy() for k, v in got.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,14 +66,19 @@ def test_trajectory_allgather_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     # every rank sees the same gathered data, and slice r equals what a single process computes for rank r
-    for key in ("maskbits", "action", "reward", "done"):
+    from azul_deep_reinforcement_learning_amd.parallel import unpack_moves
+    for key in ("maskbits", "packed"):
         assert np.array_equal(results[0][key], results[1][key])
     for r in range(world):
-        exp = _flat_from_oracle(r, 2)
-        for key in ("maskbits", "action", "reward", "done"):
+        exp, _ = _bufs_from_oracle(r, 2)
+        for key in ("maskbits", "packed"):
             assert np.array_equal(results[0][key][r], exp[key].numpy()), (r, key)
-    # invariance to the GPU count: global game 8+3 (rank 1, local 3) is the same stream as a 1-rank run of 16 games
+    # the compact record decodes back to (action, done, reward); invariance to the GPU count: global game 8+3
+    # (rank 1, local 3) is the same stream as game 11 of a 1-rank run
     from oracle import oracle as oz
     s1 = oz.Stream(100 + 8 + 3)
     s1.advance(2 * T, want_records=False)
-    assert np.array_equal(s1.advance(T, want_records=False)["action"], results[0]["action"][1][:, 3])
+    ref = s1.advance(T, want_records=False)
+    action, done, reward = unpack_moves(torch.from_numpy(results[0]["packed"][1][:, 3].copy()))
+    assert np.array_equal(action.numpy(), ref["action"]) and np.array_equal(done.numpy(), ref["done"])
+    assert np.array_equal(reward.numpy(), ref["reward"])

@@ -105,3 +105,18 @@ def test_factory_draw_fp64_path_equals_integer_path(torch_cuda):
         s = oz.Stream(321 + g)
         s.advance(steps, want_records=False)
         assert s.record().tobytes() == ra[g].tobytes()
+
+
+def test_packed_record_and_maskbits_match_plain_outputs(torch_cuda):
+    """The compact 4-byte record and the bit-packed mask (what the all-gather ships) carry the plain outputs."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    from azul_deep_reinforcement_learning_amd.parallel import unpack_moves
+    env = BatchedAzul(128)
+    _start(env, 900)
+    t = env.alloc_trajectory(300, packed_mask=True)
+    env.selfplay(300, t["mask"], t["action"], t["reward"], t["done"], maskbits=t["maskbits"], packed=t["packed"])
+    torch_cuda.cuda.synchronize()
+    action, done, reward = unpack_moves(t["packed"])
+    assert torch_cuda.equal(action, t["action"]) and torch_cuda.equal(done, t["done"]) and torch_cuda.equal(reward, t["reward"])
+    bits = t["maskbits"].cpu().numpy().view(np.uint8).reshape(300, 128, 24)
+    assert np.array_equal(np.unpackbits(bits, axis=2, bitorder="little")[:, :, :180], t["mask"].cpu().numpy())

@@ -57,6 +57,7 @@ SIGNATURES = {
     "azul_batch_counters": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "azul_batch_reset_counters": (_i, [_vp, _vp]),
     "azul_batch_set_draw_margin": (_i, [_vp, _u64]),
+    "azul_batch_segment_profile": (_i, [_vp, _vp, _i, _i]),
     "azul_timing_begin": (_i, [_vp, _vp]),
     "azul_timing_end": (_i, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(_i)]),
 }

@@ -30,6 +30,18 @@ enum { POOL_RANDOM = 0, POOL_LID = 1 };
 #endif
 enum { T_ROWS = 31, T_BINADES = 8, T_WORDS = T_ROWS * T_BINADES + T_ROWS };   // RandomAgent weight table, see azul_tables.hpp
 
+// ---- optional in-kernel segment stamps (diagnostic build only: -DAZ_PROFILE_SEGMENTS; cdna_hip_programming.md 7) ----
+// s_memtime deltas are accumulated per segment and added to a global buffer when the wave ends.  The real kernel
+// contains no stamp; never quote the diagnostic build's run time, only its SHARES (tools/segment_profile.py).
+enum { SEG_MASK = 0, SEG_SAMPLE, SEG_MOVE, SEG_AFTERMOVE, SEG_TAIL, SEG_NEWROUND, SEG_SCORE, SEG_RESET, SEG_LOOP, SEG_COUNT };
+#if defined(AZ_PROFILE_SEGMENTS) && AZ_DEVICE_BUILD
+struct SegProf { u64 last; u64 acc[SEG_COUNT]; };
+#define AZ_STAMP(seg) do { u64 now_ = __builtin_amdgcn_s_memtime(); prof_->acc[seg] += now_ - prof_->last; prof_->last = now_; } while (0)
+#else
+struct SegProf { int unused; };
+#define AZ_STAMP(seg) do { } while (0)
+#endif
+
 struct Rules {
     u32 first_player;   // 0 = "Random", 1..2 = fixed
     u32 tile_pool;      // POOL_RANDOM / POOL_LID
@@ -708,12 +720,15 @@ AZ_FN u32 episode_reset(Game &g, u32 first_player, Rng &r)
 // ---- step: azul.py:296-313 (legality is checked by the caller against the mask) ----
 // move + end-of-round bookkeeping; returns true when a new round has to be dealt (azul.py:304-313)
 template <bool LID>
-AZ_FN bool move_and_score(Game &g, const LaneConst &k, u32 code)
+AZ_FN bool move_and_score(Game &g, const LaneConst &k, u32 code, SegProf *prof_ = nullptr)
 {
+    (void)prof_;
     u32 me = me_index(g);
     bool filled = do_move<LID>(g, code);                 // :304
+    AZ_STAMP(SEG_MOVE);
     if (sources_board(g) == 0u) {                        // :306 (the token counts)
         count_score<LID>(g, k);                          // :307
+        AZ_STAMP(SEG_SCORE);
         if (is_end_of_game(g)) { g.eog = 1; return false; }   // :308-309
         return true;                                     // :311
     }
@@ -917,8 +932,10 @@ AZ_FN u32 pack_move(i32 a, u32 dn, i32 reward) { return ((u32)(a >= 0 ? a : 0xff
 // Control flow keeps ONE copy of every heavy block (ctor, new_round) in the instruction stream.
 template <bool LID, int OUT>
 AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, const SampleTab &T, const Counters &cnt,
-                        const OutV &ov, const OutS &os)
+                        const OutV &ov, const OutS &os, SegProf *prof_ = nullptr)
 {
+    (void)prof_;
+    AZ_STAMP(SEG_LOOP);
     Mask m;
     legal_mask(g, k, m);
     if (OUT == 1) {
@@ -933,19 +950,22 @@ AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, c
         if (os.mask) mask_write(m, os.mask);
         if (os.maskbits) mask_write_bits(m, os.maskbits);
     }
+    AZ_STAMP(SEG_MASK);
     u32 code = 0;
     i32 a = g.eog ? -2 : random_agent(m, r, T, k, code);
+    AZ_STAMP(SEG_SAMPLE);
     bool deal = false;                 // a new round has to be dealt
     if (!AZ_UNLIKELY(a < 0)) {
-        deal = move_and_score<LID>(g, k, code);
+        deal = move_and_score<LID>(g, k, code, prof_);
         g.moves += 1u;
     }
+    AZ_STAMP(SEG_AFTERMOVE);
     u32 result = 0, st = ST_OK;
 #if AZ_DEVICE_BUILD
 #pragma unroll 1
 #endif
     for (u32 pass = 0; pass < 2u; pass++) {
-        if (deal) { st = new_round<LID>(g, r); deal = false; if (st) break; }
+        if (deal) { st = new_round<LID>(g, r); deal = false; AZ_STAMP(SEG_NEWROUND); if (st) break; }
         if (pass == 1u) break;
         i32 reward = 0;
         u32 dn;
@@ -970,6 +990,7 @@ AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, c
             if (os.rec) game_store(g, os.rec);
         }
         result = dn;
+        AZ_STAMP(SEG_TAIL);
         if (dn == 0u) break;
         if (dn == 1u) {
             for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(cnt.stat_sum[q] += sv); }
@@ -979,6 +1000,7 @@ AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, c
         g.pscore = 0;
         g.moves = 0;
         deal = true;
+        AZ_STAMP(SEG_RESET);
     }
     return st ? (0x100u | st) : result;
 }

@@ -38,6 +38,7 @@ struct BatchDev {
     u32 n;
     Rules rules;
     u64 draw_margin;     // AZ_DRAW_MARGIN; tests widen it to force the literal fp64 factory draw
+    u64 *prof;           // [SEG_COUNT] segment cycle sums (only written by the -DAZ_PROFILE_SEGMENTS diagnostic build)
 };
 
 enum {
@@ -313,13 +314,24 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
             sr = os.reward ? N : 0; sd = os.done ? N : 0; sc = os.rec ? N * AZUL_RECORD_BYTES : 0;   // a NULL stream stays NULL
         }
     }
+#if defined(AZ_PROFILE_SEGMENTS)
+    SegProf prof;
+    for (int q = 0; q < SEG_COUNT; q++) prof.acc[q] = 0;
+    prof.last = __builtin_amdgcn_s_memtime();
+    SegProf *pp = &prof;
+#else
+    SegProf *pp = nullptr;
+#endif
 #pragma unroll 1
     for (int s = 0; s < t.n_steps; s++) {
-        u32 f = selfplay_step<LID, OUT>(g, b.rules.first_player, k, r, tab, cnt, ov, os);
+        u32 f = selfplay_step<LID, OUT>(g, b.rules.first_player, k, r, tab, cnt, ov, os, pp);
         if (f & 0x100u) break;      // rule error (box empty): leave the game as it is
         if (OUT == 1) outv_next(ov);
         if (OUT == 2) { os.mask += sm; os.maskbits += sb; os.action += sa; os.reward += sr; os.done += sd; os.rec += sc; os.packed += sp; }
     }
+#if defined(AZ_PROFILE_SEGMENTS)
+    if (wv::lane() == 0) for (int q = 0; q < SEG_COUNT; q++) atomicAdd((unsigned long long *)(b.prof + q), (unsigned long long)prof.acc[q]);
+#endif
     game_store(g, rec);
     rng_close(r, b.mtpos + gi);
 }
@@ -374,6 +386,8 @@ int azul_batch_create(azul_batch_t **out, int n_games, int first_player, int til
     HIP_TRY(hipMalloc((void **)&b->d.episodes, N * sizeof(u64)));
     HIP_TRY(hipMalloc((void **)&b->d.stuck, N * sizeof(u32)));
     HIP_TRY(hipMalloc((void **)&b->d.stat_sum, N * 10 * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&b->d.prof, SEG_COUNT * sizeof(u64)));
+    HIP_TRY(hipMemset(b->d.prof, 0, SEG_COUNT * sizeof(u64)));
     std::vector<double> hT((size_t)T_WORDS);
     if (!build_sample_tab(hT.data())) return fail(AZUL_ERR_INVALID, "weight-table decomposition check failed on this host");
     HIP_TRY(hipMemcpy(T, hT.data(), hT.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -396,7 +410,7 @@ int azul_batch_create(azul_batch_t **out, int n_games, int first_player, int til
 int azul_batch_destroy(azul_batch_t *b)
 {
     if (!b) return AZUL_SUCCESS;
-    void *bufs[] = {b->d.state, b->d.mt, b->d.mtpos, (void *)b->d.T, b->d.episodes, b->d.stuck, b->d.stat_sum};
+    void *bufs[] = {b->d.state, b->d.mt, b->d.mtpos, (void *)b->d.T, b->d.episodes, b->d.stuck, b->d.stat_sum, b->d.prof};
     for (void *p : bufs) (void)hipFree(p);
     (void)hipEventDestroy(b->ev0);
     (void)hipEventDestroy(b->ev1);
@@ -686,6 +700,16 @@ int azul_batch_set_draw_margin(azul_batch_t *b, uint64_t margin)
 {
     if (!b || margin < AZ_DRAW_MARGIN || margin > 0x7fffffffull) return fail(AZUL_ERR_INVALID, "margin must be in [8192, 2^31)");
     b->d.draw_margin = margin;
+    return AZUL_SUCCESS;
+}
+
+int azul_batch_segment_profile(azul_batch_t *b, uint64_t *cycles_host, int n, int reset)
+{
+    if (!b || !cycles_host || n < 1) return fail(AZUL_ERR_INVALID, "azul_batch_segment_profile: bad arguments");
+    if (n > SEG_COUNT) n = SEG_COUNT;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(cycles_host, b->d.prof, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(b->d.prof, 0, SEG_COUNT * sizeof(u64)));
     return AZUL_SUCCESS;
 }
 

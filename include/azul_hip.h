@@ -175,6 +175,11 @@ int azul_batch_reset_counters(azul_batch_t *b, void *stream);
  * more draws through the fp64 path -- results are identical, tests use it to exercise that path.  Range [8192, 2^31). */
 int azul_batch_set_draw_margin(azul_batch_t *b, uint64_t margin);
 
+/* DIAGNOSTIC: per-segment cycle sums of the self-play kernel (mask, sample, move, after-move, tail, new round, scoring,
+ * reset, loop).  Only a library built with -DAZ_PROFILE_SEGMENTS stamps them (tools/segment_profile.sh); the shipped
+ * build returns zeros.  Synchronises the device. */
+int azul_batch_segment_profile(azul_batch_t *b, uint64_t *cycles_host, int n, int reset);
+
 /* average device time (ms) of the last azul_batch_selfplay launches, measured with hipEvents on the launch stream:
  * call azul_timing_begin, launch any number of selfplay calls, then azul_timing_end (synchronises the stream). */
 int azul_timing_begin(azul_batch_t *b, void *stream);

@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=4096)
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--games", type=int, default=4096, help="games per GPU (BASELINE configs[1]: 4096)")
-    ap.add_argument("--chunk", type=int, default=256, help="env moves per game per kernel launch")
+    ap.add_argument("--chunk", type=int, default=512, help="env moves per game per kernel launch")
     ap.add_argument("--seed-base", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL trajectory all-gather")

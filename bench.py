@@ -165,7 +165,8 @@ def main():
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("bytes_per_launch")
+                tj = json.load(open(tf))     # PMC-measured HBM bytes per env move (profiles/), scaled to this run's launch size
+                traffic = tj["bytes_per_move"] * G * steps_per_launch
             except Exception:
                 traffic = None
         out = {

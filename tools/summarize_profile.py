@@ -38,6 +38,7 @@ pmc = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_grbm"):
     pmc.update(counters(sub, "selfplay"))
 summary["pmc_per_launch"] = pmc
+waves_steps_for_traffic = bench["config"]["games_per_gpu"] * bench["config"]["moves_per_launch"]
 calib = {}
 for sub, key in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
     files = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
@@ -63,6 +64,8 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     summary["hbm_bytes_per_launch"] = {"fetch": f, "write": w, "total": f + w,
                                         "note": "counter KB x calibration factor measured in this path's access widths"}
     json.dump({"bytes_per_launch": f + w, "fetch": f, "write": w, "source": "profiles/%s_summary.json" % name,
+               "games": bench["config"]["games_per_gpu"], "moves_per_launch": bench["config"]["moves_per_launch"],
+               "bytes_per_move": (f + w) / waves_steps_for_traffic,
                "launch": "azul_selfplay_kernel, %d games x %d moves" % (bench["config"]["games_per_gpu"], bench["config"]["moves_per_launch"])}, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 waves_steps = bench["config"]["games_per_gpu"] * bench["config"]["moves_per_launch"]
 if "SQ_INSTS_VALU" in pmc:

@@ -273,3 +273,44 @@ def test_full_size_invariants_and_sampled_parity(torch_cuda):
         assert s.record().tobytes() == rec[g].tobytes(), g
         _, pos = env.get_rng(g)
         assert pos == s.r.idx
+
+
+@pytest.mark.parametrize("n", [1, 3, 65, 1000])
+def test_odd_batch_sizes_and_empty_calls(torch_cuda, n):
+    """Ragged / tiny batches, zero-length rollouts, all-inactive masks: every game still matches its oracle stream."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    env = BatchedAzul(n)
+    env.seed(seed_base=42)
+    env.runner_init()
+    env.runner_init()
+    before = env.get_records().tobytes()
+    env.selfplay(0)                                                   # no-op
+    st = env.azul_step(np.zeros(n, dtype=np.int32), active=np.zeros(n, dtype=np.uint8)).cpu().numpy()
+    assert not st.any() and env.get_records().tobytes() == before     # nobody active: nothing changes
+    t = env.alloc_trajectory(70)
+    env.selfplay(70, t["mask"], t["action"], t["reward"], t["done"])
+    rec = env.get_records()
+    act = t["action"].cpu().numpy()
+    for g in sorted(set([0, n // 2, n - 1])):
+        s = oz.Stream(42 + g)
+        o = s.advance(70, want_records=False)
+        assert np.array_equal(o["action"], act[:, g]) and s.record().tobytes() == rec[g].tobytes()
+
+
+def test_api_misuse_returns_errors(torch_cuda):
+    import ctypes
+    from azul_deep_reinforcement_learning_amd import BatchedAzul, _lib as L
+    from azul_deep_reinforcement_learning_amd._lib import AzulHipError
+    h = ctypes.c_void_p()
+    assert L.lib.azul_batch_create(ctypes.byref(h), 0, 0, 1) == L.ERR_INVALID
+    assert L.lib.azul_batch_create(ctypes.byref(h), 4, 3, 1) == L.ERR_RULE          # first_player 3 (azul.py:41)
+    assert L.lib.azul_batch_create(ctypes.byref(h), 4, 1, 7) == L.ERR_RULE          # unknown tile pool (azul.py:54)
+    env = BatchedAzul(4)
+    with pytest.raises(AzulHipError):
+        env.get_records(2, 5)                                                       # range outside the batch
+    with pytest.raises(AzulHipError):
+        env.set_rng(0, np.zeros(624, dtype=np.uint32), 700)                         # index beyond 624
+    with pytest.raises(AzulHipError):
+        env.set_draw_margin(10)
+    assert L.lib.azul_batch_legal_mask(env._h, None, None) == L.ERR_INVALID
+    assert b"NULL" in L.lib.azul_last_error_string() or b"null" in L.lib.azul_last_error_string().lower()

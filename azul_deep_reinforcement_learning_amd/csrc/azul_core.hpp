@@ -643,19 +643,32 @@ AZ_FN u32 new_round(Game &g, Rng &r)
         risky = ballot(((lo < mg) | (lo >= 0u - mg)) & (l < 20u));
         kthi = hi;
     }
+    if (pre && !AZ_UNLIKELY(risky != 0ull)) {
+        // the common round: twenty branch-free integer draws, one display (four draws) per loop trip
+        u32 plo = (u32)P;                                  // prefix sums of colours 0..3 (the only ones compared)
+        vu32 sh = (l & 3u) * 8u;
+#if AZ_DEVICE_BUILD
+#pragma unroll 1
+#endif
+        for (u32 d = 0; d < 5u; d++) {
+#if AZ_DEVICE_BUILD
+#pragma unroll
+#endif
+            for (u32 j = 0; j < 4u; j++) {
+                vu32 pc = (plo >> sh) & 0xffu;
+                u32 color = popc64(ballot(((pc << 21) <= readlane(kthi, d * 4u + j)) & (l < 4u)));
+                g.box -= 1ull << (8u * color);               // :89
+                plo -= (u32)(0x0101010101ull << (8u * color));   // colours >= `color` lose one tile from their prefix (colour 4: no-op)
+                g.cs = g.cs + sel(l == d * 5u + color, splat(1u), splat(0u));   // :88
+            }
+        }
+        r.pos += 40u;
+        return ST_OK;
+    }
 #if AZ_DEVICE_BUILD
 #pragma unroll 1
 #endif
     for (u32 t = 0; t < 20u; t++) {
-        if (pre && !AZ_UNLIKELY((risky >> t) & 1ull)) {
-            vu32 pc = ((u32)P >> ((l & 3u) * 8u)) & 0xffu;
-            u32 color = popc64(ballot(((pc << 21) <= readlane(kthi, t)) & (l < 4u)));
-            r.pos += 2u;
-            g.box -= 1ull << (8u * color);               // :89
-            P -= (0x0101010101ull << (8u * color)) & 0xffffffffffull;
-            g.cs = g.cs + sel(l == (t >> 2) * 5u + color, splat(1u), splat(0u));   // :88
-            continue;
-        }
         u32 total = (u32)(P >> 32) & 0xffu;
         if (AZ_UNLIKELY(total == 0u)) {                                              // :81-83, :85
             g.box = g.lid; g.lid = 0;

@@ -906,7 +906,6 @@ struct Counters {
 };
 
 // returns 0 = move played, 1 = game ended with this move, 2 = stuck, 0x100|status on a rule error.
-// Control flow keeps ONE copy of every heavy block (ctor, new_round) in the instruction stream.
 // Trajectory streams of the self-play kernel.  OUT == 1 (every stream present, the benchmarked form) keeps them as
 // per-lane pointers; OUT == 2 (any subset, run-time checked, plus the test-only record stream) as scalar pointers.
 struct OutV {
@@ -940,9 +939,25 @@ struct OutS { uint8_t *mask; u64 *maskbits; i32 *action; i32 *reward; uint8_t *d
 // compact trajectory record of one move (what the multi-GPU all-gather ships): action (0xff = none) | done << 8 | reward << 16
 AZ_FN u32 pack_move(i32 a, u32 dn, i32 reward) { return ((u32)(a >= 0 ? a : 0xff) & 0xffu) | ((dn & 0xffu) << 8) | (((u32)reward & 0xffffu) << 16); }
 
+// per-move trajectory outputs (action, reward, done, compact record; record snapshot in the test form)
+template <int OUT>
+AZ_FN void selfplay_outputs(const Game &g, const OutV &ov, const OutS &os, i32 a, i32 reward, u32 dn)
+{
+    if (OUT == 1) {
+        vu32 l = lane();
+        vst_u32(ov.p32, sel(l == 1u, splat((u32)reward), sel(l == 2u, splat(pack_move(a, dn, reward)), splat((u32)(a >= 0 ? a : -1)))));
+        vst_u8(ov.p8, splat(dn));
+    } else if (OUT == 2) {
+        if (os.action) stu_i32(os.action, a >= 0 ? a : -1);
+        if (os.reward) stu_i32(os.reward, reward);
+        if (os.done) stu_u8(os.done, dn);
+        if (os.packed) stu_i32((i32 *)os.packed, (i32)pack_move(a, dn, reward));
+        if (os.rec) game_store(g, os.rec);
+    }
+}
+
 // OUT: 0 = no trajectory outputs, 1 = all five streams through OutV, 2 = any subset through OutS (run-time checks)
 // returns 0 = move played, 1 = game ended with this move, 2 = stuck, 0x100|status on a rule error.
-// Control flow keeps ONE copy of every heavy block (ctor, new_round) in the instruction stream.
 template <bool LID, int OUT>
 AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, const SampleTab &T, const Counters &cnt,
                         const OutV &ov, const OutS &os, SegProf *prof_ = nullptr)
@@ -967,55 +982,41 @@ AZ_FN u32 selfplay_step(Game &g, u32 first_player, const LaneConst &k, Rng &r, c
     u32 code = 0;
     i32 a = g.eog ? -2 : random_agent(m, r, T, k, code);
     AZ_STAMP(SEG_SAMPLE);
-    bool deal = false;                 // a new round has to be dealt
-    if (!AZ_UNLIKELY(a < 0)) {
-        deal = move_and_score<LID>(g, k, code, prof_);
-        g.moves += 1u;
-    }
-    AZ_STAMP(SEG_AFTERMOVE);
-    u32 result = 0, st = ST_OK;
-#if AZ_DEVICE_BUILD
-#pragma unroll 1
-#endif
-    for (u32 pass = 0; pass < 2u; pass++) {
-        if (deal) { st = new_round<LID>(g, r); deal = false; AZ_STAMP(SEG_NEWROUND); if (st) break; }
-        if (pass == 1u) break;
-        i32 reward = 0;
-        u32 dn;
-        if (a >= 0) {
-            i32 phi = g.wi0 - g.wi1;
-            reward = phi - g.pscore;
-            g.pscore = phi;
-            dn = is_end_of_game(g) ? 1u : 0u;
-        } else {
-            dn = 2u;                   // stuck (or handed an already finished game): report, restart the slot
-            AZ_LANE0(*cnt.stuck += 1u);
-        }
-        if (OUT == 1) {
-            vu32 l = lane();
-            vst_u32(ov.p32, sel(l == 1u, splat((u32)reward), sel(l == 2u, splat(pack_move(a, dn, reward)), splat((u32)(a >= 0 ? a : -1)))));
-            vst_u8(ov.p8, splat(dn));
-        } else if (OUT == 2) {
-            if (os.action) stu_i32(os.action, a >= 0 ? a : -1);
-            if (os.reward) stu_i32(os.reward, reward);
-            if (os.done) stu_u8(os.done, dn);
-            if (os.packed) stu_i32((i32 *)os.packed, (i32)pack_move(a, dn, reward));
-            if (os.rec) game_store(g, os.rec);
-        }
-        result = dn;
-        AZ_STAMP(SEG_TAIL);
-        if (dn == 0u) break;
-        if (dn == 1u) {
-            for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(cnt.stat_sum[q] += sv); }
-            AZ_LANE0(*cnt.episodes += 1ull);
-        }
+    // Straight-line common path (a move, sometimes followed by a new round); the two rare exits (stuck slot,
+    // finished game) restart the episode out of line.
+    if (AZ_UNLIKELY(a < 0)) {
+        // stuck (or handed an already finished game): report, restart the slot
+        AZ_LANE0(*cnt.stuck += 1u);
+        selfplay_outputs<OUT>(g, ov, os, -1, 0, 2u);
         game_ctor<LID>(g, first_player, r);               // GameRunner.reset(): Azul(rules) ... new_round()
         g.pscore = 0;
         g.moves = 0;
-        deal = true;
-        AZ_STAMP(SEG_RESET);
+        u32 st0 = new_round<LID>(g, r);
+        return st0 ? (0x100u | st0) : 2u;
     }
-    return st ? (0x100u | st) : result;
+    bool deal = move_and_score<LID>(g, k, code, prof_);
+    g.moves += 1u;
+    AZ_STAMP(SEG_AFTERMOVE);
+    u32 st = ST_OK;
+    if (deal) { st = new_round<LID>(g, r); AZ_STAMP(SEG_NEWROUND); }
+    i32 phi = g.wi0 - g.wi1;
+    i32 reward = phi - g.pscore;
+    g.pscore = phi;
+    u32 dn = is_end_of_game(g) ? 1u : 0u;
+    selfplay_outputs<OUT>(g, ov, os, a, reward, dn);
+    AZ_STAMP(SEG_TAIL);
+    if (AZ_UNLIKELY(st != ST_OK)) return 0x100u | st;
+    if (AZ_UNLIKELY(dn != 0u)) {
+        for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(cnt.stat_sum[q] += sv); }
+        AZ_LANE0(*cnt.episodes += 1ull);
+        game_ctor<LID>(g, first_player, r);               // GameRunner.reset(): Azul(rules) ... new_round()
+        g.pscore = 0;
+        g.moves = 0;
+        st = new_round<LID>(g, r);
+        AZ_STAMP(SEG_RESET);
+        if (st) return 0x100u | st;
+    }
+    return dn;
 }
 
 } // namespace az

@@ -560,14 +560,33 @@ AZ_FN void count_score(Game &g, const LaneConst &k)
 
 // What-if scores (game_runner.py:48-50: deepcopy + count_score).  A move only changes the MOVER's lines and
 // floor; the wall pricing of a player's full lines (wc) only changes when one more of his lines becomes full.
+AZ_FN i32 wall_points_of(const ScoreVec &sv, u64 F, u32 p)
+{
+    // sum of the placement values of player p's full lines (no commits): one readlane per full line
+    u32 rest = (u32)(F >> (25u * p)) & 0x1ffffffu;
+    i32 cnt = 0;
+    while (rest) {
+        u32 i = ctz32(rest);
+        rest &= rest - 1u;
+        cnt += (i32)readlane(sv.val, i + 25u * p);
+    }
+    return cnt;
+}
+
 template <bool LID>
 AZ_FN void whatif_refresh(Game &g, const LaneConst &k, u32 which /* 0, 1, or 2 = both */)
 {
     u64 F = full_lines(g, k);
     ScoreVec sv;
     score_vec(g, k, F, sv);
-    if (which != 1u) g.wc0 = wall_points<false, LID, 0>(g, F, sv);
-    if (which != 0u) g.wc1 = wall_points<false, LID, 1>(g, F, sv);
+    if (which == 2u) {
+        g.wc0 = wall_points_of(sv, F, 0);
+        g.wc1 = wall_points_of(sv, F, 1);
+    } else {
+        i32 w = wall_points_of(sv, F, which);
+        g.wc0 = which ? g.wc0 : w;
+        g.wc1 = which ? w : g.wc1;
+    }
     g.wi0 = clamp0(g.score0 + floor_penalty(g.floor0) + g.wc0);
     g.wi1 = clamp0(g.score1 + floor_penalty(g.floor1) + g.wc1);
 }

@@ -2,14 +2,20 @@
 ``NNRunner.run_episode`` (azulnet/nn_runner.py:17-47) and of the action sampling in ``Agent.get_ac_output``
 (azulnet/agent.py:64-81).
 
-The batch is split into independent parts, each with its own HIP stream: while the env kernel of one part runs
-(`azul_batch_policy_step`: Azul.step + reward + done + auto-reset + next observation/mask in ONE launch), the
-GEMMs/softmax/sampling of the other part run on theirs.  A window of `T` moves is captured once into a HIP graph
-per part (no per-kernel host launch cost) and replayed; results are identical with `use_graph=False`.
+Per move and part of the batch (each part has its own HIP stream):
+    hidden = relu([critic_linear1 | actor_linear1](obs))          one GEMM for both first layers   (rocBLAS/hipBLASLt)
+    value  = critic_linear2(hidden[:, :H])                          written straight into the trajectory slot
+    logits = actor_linear2(hidden[:, H:])
+    azul_policy_head   masked softmax + categorical sample + log-prob + entropy        one launch, one wave per game
+    azul_batch_policy_step   Azul.step + reward + done + auto-reset + NEXT obs / mask / player   one launch
+Nothing is copied: the env writes the next observation and mask into slot t+1 of the trajectory, the head writes
+action / log-prob / entropy into slot t.  A window of `T` moves is captured once into a HIP graph per part and
+replayed (the Philox step counter lives in device memory); results are identical with `use_graph=False`.
+`fused_head=False` keeps the all-PyTorch sampling path (torch.multinomial) for comparison.
 
 Per (move t, game g) the record holds what the reference's run_episode keeps per agent step (C1 in SURVEY.md 8a):
 observation, legal mask, action, reward, done, value, log-prob of the action and the entropy term
-`-mean(log p over legal actions)` (nn_runner.py:36-40), plus the player who moved.
+`-mean(log p over legal actions)` (nn_runner.py:36-40), plus the player who moved and the discounted returns.
 """
 import ctypes as C
 
@@ -19,38 +25,44 @@ from . import _lib as L
 from .batch import BatchedAzul
 
 
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
 class PolicyRollout:
     def __init__(self, policy, n_games=4096, parts=2, rules={"first_player": "Random", "tile_pool": "Lid"}, seed_base=0,
-                 device=None, window=32, use_graph=True, record_obs=True):
+                 device=None, window=32, use_graph=True, record_obs=True, fused_head=True, sample_seed=0x5EED):
         assert n_games % parts == 0
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.policy = policy.to(self.device).eval()
         self.n, self.parts, self.h, self.T = n_games, parts, n_games // parts, window
-        self.record_obs = record_obs
-        self.envs, self.streams, self.buf, self.traj, self.graphs = [], [], [], [], []
+        self.record_obs = record_obs          # kept for API compatibility: observations always live in the trajectory slots
+        self.fused_head = fused_head
+        self.sample_seed = int(sample_seed)
+        self.envs, self.streams, self.work, self.traj, self.graphs = [], [], [], [], []
+        self.refresh_weights()
+        d, h, T = self.device, self.h, window
         for p in range(parts):
-            env = BatchedAzul(self.h, rules=rules, device=self.device)
-            env.seed(seed_base + p * self.h)                       # seeds follow the global game id
+            env = BatchedAzul(h, rules=rules, device=d)
+            env.seed(seed_base + p * h)                            # seeds follow the global game id
             env.runner_init()                                      # GameRunner()
             env.runner_init()                                      # reset() without pre-moves (flat self-play)
             self.envs.append(env)
-            self.streams.append(torch.cuda.Stream(device=self.device))
-            d, h, T = self.device, self.h, window
-            b = {"obs": torch.zeros(h, L.OBS_SIZE, device=d), "mask": torch.zeros(h, L.NUM_ACTIONS, dtype=torch.uint8, device=d),
-                 "player": torch.zeros(h, dtype=torch.uint8, device=d), "action": torch.zeros(h, dtype=torch.int32, device=d),
-                 "status": torch.zeros(h, dtype=torch.uint8, device=d)}
-            t = {"action": torch.zeros(T, h, dtype=torch.int32, device=d), "reward": torch.zeros(T, h, dtype=torch.int32, device=d),
-                 "done": torch.zeros(T, h, dtype=torch.uint8, device=d), "player": torch.zeros(T, h, dtype=torch.uint8, device=d),
-                 "value": torch.zeros(T, h, device=d), "log_prob": torch.zeros(T, h, device=d), "entropy": torch.zeros(T, h, device=d),
-                 "mask": torch.zeros(T, h, L.NUM_ACTIONS, dtype=torch.uint8, device=d),
-                 "returns": torch.zeros(T, h, device=d), "carry": torch.zeros(h, device=d)}
-            if record_obs:
-                t["obs"] = torch.zeros(T, h, L.OBS_SIZE, device=d)
-            self.buf.append(b)
+            self.streams.append(torch.cuda.Stream(device=d))
+            t = {"obs": torch.zeros(T + 1, h, L.OBS_SIZE, device=d), "mask": torch.zeros(T + 1, h, L.NUM_ACTIONS, dtype=torch.uint8, device=d),
+                 "player": torch.zeros(T + 1, h, dtype=torch.uint8, device=d),
+                 "action": torch.zeros(T, h, dtype=torch.int32, device=d), "reward": torch.zeros(T, h, dtype=torch.int32, device=d),
+                 "done": torch.zeros(T, h, dtype=torch.uint8, device=d),
+                 "value": torch.zeros(T, h, 1, device=d), "log_prob": torch.zeros(T, h, device=d), "entropy": torch.zeros(T, h, device=d),
+                 "returns": torch.zeros(T, h, device=d)}
+            w = {"hidden": torch.zeros(h, 2 * self.H, device=d), "logits": torch.zeros(h, L.NUM_ACTIONS, device=d),
+                 "status": torch.zeros(h, dtype=torch.uint8, device=d),
+                 "counter": torch.full((1,), p << 40, dtype=torch.int64, device=d)}          # disjoint Philox blocks per part
             self.traj.append(t)
+            self.work.append(w)
             with torch.cuda.stream(self.streams[p]):
-                env.observe_all(L.PERSP_CURRENT, b["obs"], b["mask"], b["player"])
-        torch.cuda.synchronize(self.device)
+                env.observe_all(L.PERSP_CURRENT, t["obs"][T], t["mask"][T], t["player"][T])    # becomes slot 0 of the first window
+        torch.cuda.synchronize(d)
         self.use_graph = use_graph
         self.graph_error = None
         if use_graph:
@@ -60,38 +72,53 @@ class PolicyRollout:
                 self.graph_error = repr(e)
                 self.graphs = []
                 self.use_graph = False
-                torch.cuda.synchronize(self.device)
+                torch.cuda.synchronize(d)
+
+    def refresh_weights(self):
+        """(Re)build the fused first-layer weight from the policy's parameters (call after an optimiser step)."""
+        pol = self.policy
+        with torch.no_grad():
+            self.H = pol.critic_linear1.out_features
+            self.w1t = torch.cat([pol.critic_linear1.weight, pol.actor_linear1.weight], dim=0).t().contiguous()
+            self.b1 = torch.cat([pol.critic_linear1.bias, pol.actor_linear1.bias]).contiguous()
+            self.w2c_t = pol.critic_linear2.weight.t().contiguous()
+            self.w2a_t = pol.actor_linear2.weight.t().contiguous()
 
     # one move of one part, enqueued on the current stream
     def _move(self, p, t):
-        env, b, tr = self.envs[p], self.buf[p], self.traj[p]
-        obs, mask = b["obs"], b["mask"]
+        env, tr, w = self.envs[p], self.traj[p], self.work[p]
+        obs, mask, H = tr["obs"][t], tr["mask"][t], self.H
+        pol = self.policy
         with torch.no_grad():
-            value = self.policy.forward_critic(obs)                              # agent.py:66
-            probs, logp = self.policy.forward_actor(obs, mask)                   # agent.py:67
-            legal = mask.bool()
-            any_legal = legal.any(dim=1)
-            safe = torch.where(any_legal.unsqueeze(1), probs, torch.full_like(probs, 1.0 / probs.shape[1]))
-            action = torch.multinomial(safe, 1).squeeze(1)                       # agent.py:69 (np.random.choice(p=probs))
-            lp = logp.gather(1, action.unsqueeze(1)).squeeze(1)                  # nn_runner.py:32
-            ent = -(torch.where(legal, logp, torch.zeros_like(logp)).sum(dim=1) / legal.sum(dim=1).clamp(min=1))   # :36-40
-            b["action"].copy_(torch.where(any_legal, action, torch.full_like(action, -1)).to(torch.int32))
-        if self.record_obs:
-            tr["obs"][t].copy_(obs)
-        tr["mask"][t].copy_(mask)
-        tr["player"][t].copy_(b["player"])
-        tr["action"][t].copy_(b["action"])
-        tr["value"][t].copy_(value.squeeze(1))
-        tr["log_prob"][t].copy_(lp)
-        tr["entropy"][t].copy_(ent)
-        env.policy_step(b["action"], tr["reward"][t], tr["done"][t], b["status"], b["obs"], b["mask"], b["player"])
+            torch.addmm(self.b1, obs, self.w1t, out=w["hidden"])
+            w["hidden"].relu_()
+            torch.addmm(pol.critic_linear2.bias, w["hidden"][:, :H], self.w2c_t, out=tr["value"][t])          # agent.py:66
+            torch.addmm(pol.actor_linear2.bias, w["hidden"][:, H:], self.w2a_t, out=w["logits"])               # agent.py:67
+            if self.fused_head:
+                L.check(L.lib.azul_policy_head(_p(w["logits"]), _p(mask), self.sample_seed, 0, _p(w["counter"]), self.h,
+                                               _p(tr["action"][t]), _p(tr["log_prob"][t]), _p(tr["entropy"][t]),
+                                               C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+                w["counter"].add_(1)
+            else:
+                legal = mask.bool()
+                logits = w["logits"].masked_fill(~legal, float("-inf"))
+                logp = torch.log_softmax(logits, dim=1)
+                any_legal = legal.any(dim=1)
+                safe = torch.where(any_legal.unsqueeze(1), logp.exp(), torch.full_like(logp, 1.0 / logp.shape[1]))
+                action = torch.multinomial(safe, 1).squeeze(1)                                               # agent.py:69
+                tr["log_prob"][t].copy_(logp.gather(1, action.unsqueeze(1)).squeeze(1))                       # nn_runner.py:32
+                tr["entropy"][t].copy_(-(torch.where(legal, logp, torch.zeros_like(logp)).sum(dim=1) / legal.sum(dim=1).clamp(min=1)))
+                tr["action"][t].copy_(torch.where(any_legal, action, torch.full_like(action, -1)).to(torch.int32))
+        env.policy_step(tr["action"][t], tr["reward"][t], tr["done"][t], w["status"], tr["obs"][t + 1], tr["mask"][t + 1], tr["player"][t + 1])
 
     def _window(self, p, gamma):
-        for t in range(self.T):
+        tr, T = self.traj[p], self.T
+        tr["obs"][0].copy_(tr["obs"][T])
+        tr["mask"][0].copy_(tr["mask"][T])
+        tr["player"][0].copy_(tr["player"][T])
+        for t in range(T):
             self._move(p, t)
-        tr = self.traj[p]
-        L.check(L.lib.azul_discounted_returns(C.c_void_p(tr["reward"].data_ptr()), C.c_void_p(tr["done"].data_ptr()),
-                                              C.c_void_p(tr["returns"].data_ptr()), None, C.c_float(gamma), self.T, self.h,
+        L.check(L.lib.azul_discounted_returns(_p(tr["reward"]), _p(tr["done"]), _p(tr["returns"]), None, C.c_float(gamma), T, self.h,
                                               C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
     def _capture(self, gamma=0.99):
@@ -108,7 +135,8 @@ class PolicyRollout:
         torch.cuda.synchronize(self.device)
 
     def run_window(self, gamma=0.99):
-        """Advance every game by `window` moves; returns the per-part trajectory dicts (views into static buffers)."""
+        """Advance every game by `window` moves; returns the per-part trajectory dicts (views into static buffers;
+        `obs`, `mask`, `player` have T+1 slots: slot t is what the policy saw at move t)."""
         if self.use_graph and gamma != getattr(self, "gamma", gamma):
             raise ValueError("gamma is baked into the captured graph")
         for p in range(self.parts):

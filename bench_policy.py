@@ -21,13 +21,14 @@ def main():
     ap.add_argument("--windows", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-obs-record", action="store_true")
+    ap.add_argument("--torch-head", action="store_true", help="sample with torch.multinomial instead of the fused head kernel")
     a = ap.parse_args()
     import torch
     from azul_deep_reinforcement_learning_amd import BatchedActorCritic, PolicyRollout
     torch.manual_seed(0)
     net = BatchedActorCritic(136, 180, 180)
     ro = PolicyRollout(net, n_games=a.games, parts=a.parts, window=a.window, use_graph=not a.no_graph,
-                       record_obs=not a.no_obs_record)
+                       record_obs=not a.no_obs_record, fused_head=not a.torch_head)
     for _ in range(3):
         ro.run_window()
     ro.synchronize()
@@ -42,7 +43,7 @@ def main():
     c = ro.counters()
     print(json.dumps({"metric": "Azul env steps/sec (ActorCritic policy self-play, trajectories recorded)", "value": moves / dt,
                       "unit": "env steps/s", "n_gpus": 1, "config": {"workload": "BASELINE configs[2]", "games": a.games,
-                      "stream_parts": a.parts, "moves_per_graph": a.window, "hip_graph": ro.use_graph,
+                      "stream_parts": a.parts, "moves_per_graph": a.window, "hip_graph": ro.use_graph, "fused_head": ro.fused_head,
                       "graph_error": ro.graph_error}, "ms_per_step": dt / (a.window * a.windows) * 1e3,
                       "episodes_finished": c["episodes"], "stuck": c["stuck"], "dtype": "fp32 policy / u8 env", "data": "synthetic"}))
 

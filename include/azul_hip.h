@@ -146,6 +146,12 @@ int azul_batch_policy_step(azul_batch_t *b, const int32_t *actions_dev, const ui
                            uint8_t *mask_next_dev /*[N][180]*/, uint8_t *player_next_dev /*[N]*/, void *stream);
 /* observation + mask + player to move in one launch (the first decision of a rollout) */
 int azul_batch_observe_all(azul_batch_t *b, int perspective, float *obs_dev, uint8_t *mask_dev, uint8_t *player_dev, void *stream);
+/* policy head for a batch of action logits [N][180] + legal masks [N][180]: masked softmax, ONE categorical sample per game
+ * (agent.py:64-72), the log-probability of that action and the entropy term -mean(log p over legal actions)
+ * (nn_runner.py:32-40).  fp32; randomness = Philox4x32-10(seed, counter [+ *counter_dev], game): keep the step counter in
+ * device memory (counter_dev) when the call is replayed from a HIP graph.  Rows without a legal action give -1. */
+int azul_policy_head(const float *logits_dev, const uint8_t *mask_dev, uint64_t seed, uint64_t counter, const uint64_t *counter_dev,
+                     int n_games, int32_t *action_dev, float *logp_dev, float *entropy_dev, void *stream);
 /* discounted returns q[t] = r[t] + gamma * q[t+1] within episodes over a time-major window [n_steps][n_games]
  * (nn_runner.py:70-76); done[t][g] != 0 closes an episode at move t; carry_dev[n_games] (optional) chains windows. */
 int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, float *returns_dev, float *carry_dev,

@@ -107,8 +107,8 @@ def _oracle_replay(rec, mt, pos, fp, pool, actions):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_policy_rollout_replays_exactly_through_the_oracle(contract, use_graph):
+@pytest.mark.parametrize("use_graph,fused", [(False, True), (True, True), (False, False)])
+def test_policy_rollout_replays_exactly_through_the_oracle(contract, use_graph, fused):
     """Everything the rollout records about the ENV (mask, observation, player, reward, done, final state) must be
     what the oracle computes when it is fed the actions the policy sampled -- for both stream parts, eager launches
     and HIP-graph replays alike."""
@@ -116,7 +116,7 @@ def test_policy_rollout_replays_exactly_through_the_oracle(contract, use_graph):
     torch.manual_seed(1)
     net = _net(contract, "cuda")
     T, n = 40, 64
-    ro = PolicyRollout(net, n_games=n, parts=2, seed_base=500, window=T, use_graph=use_graph)
+    ro = PolicyRollout(net, n_games=n, parts=2, seed_base=500, window=T, use_graph=use_graph, fused_head=fused)
     assert ro.use_graph == use_graph, ro.graph_error
     start = [(env.get_records(), [env.get_rng(g) for g in range(ro.h)]) for env in ro.envs]
     windows = []
@@ -131,10 +131,10 @@ def test_policy_rollout_replays_exactly_through_the_oracle(contract, use_graph):
             assert (acts >= 0).all()
             mt, pos = start[p][1][g]
             exp, final = _oracle_replay(start[p][0][g], mt, pos, oz.FIRST_RANDOM, oz.POOL_LID, acts)
-            got_mask = np.concatenate([w[p]["mask"][:, g] for w in windows]).astype(bool)
+            got_mask = np.concatenate([w[p]["mask"][:T, g] for w in windows]).astype(bool)
             assert np.array_equal(got_mask, np.array(exp["mask"]))
-            assert np.array_equal(np.concatenate([w[p]["obs"][:, g] for w in windows]).astype(np.int64), np.array(exp["obs"]))
-            assert np.array_equal(np.concatenate([w[p]["player"][:, g] for w in windows]), np.array(exp["player"]))
+            assert np.array_equal(np.concatenate([w[p]["obs"][:T, g] for w in windows]).astype(np.int64), np.array(exp["obs"]))
+            assert np.array_equal(np.concatenate([w[p]["player"][:T, g] for w in windows]), np.array(exp["player"]))
             assert np.array_equal(np.concatenate([w[p]["reward"][:, g] for w in windows]), np.array(exp["reward"]))
             assert np.array_equal(np.concatenate([w[p]["done"][:, g] for w in windows]).astype(bool), np.array(exp["done"]))
             assert final.tobytes() == finals[p][g].tobytes()
@@ -142,10 +142,60 @@ def test_policy_rollout_replays_exactly_through_the_oracle(contract, use_graph):
     for w in windows:
         for part in w:
             a = part["action"].astype(np.int64)
-            assert np.take_along_axis(part["mask"], a[..., None], axis=2).all()
+            assert np.take_along_axis(part["mask"][:T], a[..., None], axis=2).all()
             assert np.isfinite(part["log_prob"]).all() and np.isfinite(part["entropy"]).all() and (part["entropy"] >= 0).all()
             q = np.zeros(ro.h)
             for t in reversed(range(T)):
                 q = np.where(part["done"][t] != 0, 0.0, q)
                 q = part["reward"][t] + 0.99 * q
                 assert np.allclose(part["returns"][t], q, rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.gpu
+def test_policy_head_matches_torch_and_samples_the_distribution(contract):
+    """azul_policy_head vs PyTorch: log-prob of the chosen action and the entropy term within fp32 tolerance, sampled
+    actions always legal, and the empirical distribution of many draws follows softmax(logits | mask)."""
+    from azul_deep_reinforcement_learning_amd import _lib as L
+    rs = np.random.RandomState(5)
+    n = 256
+    logits = torch.from_numpy(rs.randn(n, 180).astype(np.float32) * 2).cuda()
+    mask_np = rs.rand(n, 180) < 0.2
+    mask_np[np.arange(n), rs.randint(0, 180, n)] = True
+    mask_np[7] = False                                     # a stuck row
+    mask = torch.from_numpy(mask_np.astype(np.uint8)).cuda()
+    action = torch.zeros(n, dtype=torch.int32, device="cuda")
+    logp = torch.zeros(n, device="cuda")
+    ent = torch.zeros(n, device="cuda")
+    ref_logp = torch.log_softmax(logits.masked_fill(~mask.bool(), float("-inf")), dim=1)
+    ref_ent = -(torch.where(mask.bool(), ref_logp, torch.zeros_like(ref_logp)).sum(1) / mask.sum(1).clamp(min=1))
+    counts = torch.zeros(180, device="cuda")
+    draws = 4000
+    for c in range(draws):
+        L.check(L.lib.azul_policy_head(C.c_void_p(logits.data_ptr()), C.c_void_p(mask.data_ptr()), 1234, c, None, n,
+                                       C.c_void_p(action.data_ptr()), C.c_void_p(logp.data_ptr()), C.c_void_p(ent.data_ptr()), None))
+        if c < 3:
+            a = action.long()
+            assert a[7] == -1 and logp[7] == 0 and ent[7] == 0
+            rows = torch.arange(n, device="cuda")
+            keep = rows != 7
+            assert mask.bool()[rows[keep], a[keep]].all()
+            assert torch.allclose(logp[keep], ref_logp[rows[keep], a[keep]], atol=2e-5, rtol=1e-5)
+            assert torch.allclose(ent[keep], ref_ent[keep], atol=2e-5, rtol=1e-5)
+        counts[action[0].long()] += 1
+    torch.cuda.synchronize()
+    p0 = ref_logp[0].exp().cpu().numpy()
+    emp = (counts / draws).cpu().numpy()
+    legal = mask_np[0]
+    assert emp[~legal].sum() == 0
+    # chi-square over the legal actions of row 0 (expected counts >= ~5 for the bulk): loose 5-sigma style bound
+    e = p0[legal] * draws
+    chi2 = float((((emp[legal] * draws) - e) ** 2 / np.maximum(e, 1e-9)).sum())
+    dof = int(legal.sum()) - 1
+    assert chi2 < dof + 6 * np.sqrt(2 * dof) + 10, (chi2, dof)
+    # a different counter or seed gives a different (but reproducible) stream
+    L.check(L.lib.azul_policy_head(C.c_void_p(logits.data_ptr()), C.c_void_p(mask.data_ptr()), 1234, 17, None, n,
+                                   C.c_void_p(action.data_ptr()), C.c_void_p(logp.data_ptr()), C.c_void_p(ent.data_ptr()), None))
+    a1 = action.clone()
+    L.check(L.lib.azul_policy_head(C.c_void_p(logits.data_ptr()), C.c_void_p(mask.data_ptr()), 1234, 17, None, n,
+                                   C.c_void_p(action.data_ptr()), C.c_void_p(logp.data_ptr()), C.c_void_p(ent.data_ptr()), None))
+    assert torch.equal(a1, action)

@@ -120,3 +120,57 @@ def test_packed_record_and_maskbits_match_plain_outputs(torch_cuda):
     assert torch_cuda.equal(action, t["action"]) and torch_cuda.equal(done, t["done"]) and torch_cuda.equal(reward, t["reward"])
     bits = t["maskbits"].cpu().numpy().view(np.uint8).reshape(300, 128, 24)
     assert np.array_equal(np.unpackbits(bits, axis=2, bitorder="little")[:, :, :180], t["mask"].cpu().numpy())
+
+
+def test_long_run_soak_many_regenerations(torch_cuda):
+    """65,536 moves per game (about 1,150 episodes and 650 MT19937 regenerations per stream): sampled games still
+    equal the oracle bit for bit -- final record, RNG words, index, episode count and summed statistics."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    n, steps = 256, 65536
+    env = BatchedAzul(n)
+    _start(env, 31337)
+    for _ in range(steps // 4096):
+        env.selfplay(4096)
+    torch_cuda.cuda.synchronize()
+    rec = env.get_records()
+    cnt = env.counters()
+    for g in (0, 101, 255):
+        s = oz.Stream(31337 + g)
+        s.advance(steps, want_records=False)
+        assert s.record().tobytes() == rec[g].tobytes(), g
+        mt, pos = env.get_rng(g)
+        omt, opos = s.rng_state()
+        assert pos == opos and np.array_equal(mt, omt)
+        assert int(cnt["episodes"][g]) == int(s.episodes.value) > 1000
+        assert np.array_equal(cnt["stat_sums"][g], s.stats_sum)
+
+
+def test_policy_step_handles_stuck_and_finished_slots(torch_cuda):
+    """azul_batch_policy_step: action -1 on a slot without legal moves -> done == 2 / STUCK and a fresh episode; a
+    finished game handed in restarts too; a legal action on a normal slot plays."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul, _lib as L
+    env = BatchedAzul(3)
+    env.seed(seed_base=9)
+    env.runner_init()
+    env.runner_init()
+    rec = env.get_records()
+    rec[0]["displays"] = 0
+    rec[0]["center"] = [0, 0, 0, 0, 0, 1]          # only the token left: nobody can move (hazard H3)
+    rec[1]["flags"] = rec[1]["flags"] | 0x40       # end_of_game flag set
+    env.set_records(rec)
+    obs, mask, player = env.observe_all()
+    m = mask.cpu().numpy()
+    assert not m[0].any() and m[2].any()
+    actions = torch_cuda.tensor([-1, 0, int(np.flatnonzero(m[2])[0])], dtype=torch_cuda.int32, device="cuda")
+    reward = torch_cuda.zeros(3, dtype=torch_cuda.int32, device="cuda")
+    done = torch_cuda.zeros(3, dtype=torch_cuda.uint8, device="cuda")
+    status = torch_cuda.zeros(3, dtype=torch_cuda.uint8, device="cuda")
+    env.policy_step(actions, reward, done, status, obs, mask, player)
+    d, st = done.cpu().numpy(), status.cpu().numpy()
+    assert d[0] == 2 and st[0] == L.STUCK and d[1] == 1 and d[2] == 0 and st[2] == L.OK
+    after = env.get_records()
+    for g in (0, 1):                               # both restarted: fresh round, zeroed runner fields
+        assert after[g]["displays"].sum() == 20 and after[g]["move_counter"] == 0 and after[g]["turn_counter"] == 1
+    assert after[2]["move_counter"] == rec[2]["move_counter"] + 1
+    assert mask.cpu().numpy()[0].any()             # the returned mask already belongs to the new episode
+    assert env.counters()["stuck"][0] == 1

@@ -131,8 +131,18 @@ AZ_FN u32 rng_u32(Rng &r)
 
 AZ_FN double rng_random(Rng &r)
 {
-    u32 a = rng_u32(r) >> 5, b = rng_u32(r) >> 6;
-    return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+    // random_random(): two consecutive words; one window check serves both when they sit in the same window
+    u32 a, b;
+    if (!AZ_UNLIKELY(r.pos + 2u > r.wend)) {
+        u32 off = r.pos - r.wbase;
+        a = readlane(r.win, off);
+        b = readlane(r.win, off + 1u);
+        r.pos += 2u;
+    } else {
+        a = rng_u32(r);
+        b = rng_u32(r);
+    }
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
 }
 
 AZ_FN u32 rng_below(Rng &r, u32 n, u32 bits)

@@ -208,6 +208,13 @@ class BatchedAzul:
                                              _ptr(status), int(perspective), _ptr(obs_next), _ptr(mask_next), _ptr(player_next),
                                              self._stream()))
 
+    def agent_step(self, actions, reward, done, status, obs_next, mask_next, player_next=None, perspective=0, active=None):
+        """One AGENT step of NNRunner.run_episode (GameRunner.step incl. the opponent's replies; GameRunner.reset() when
+        the episode ends) + the next decision's observation / mask; all arguments are preallocated device tensors."""
+        L.check(L.lib.azul_batch_agent_step(self._h, _ptr(actions), _ptr(self._dev(active, torch.uint8)), _ptr(reward), _ptr(done),
+                                            _ptr(status), int(perspective), _ptr(obs_next), _ptr(mask_next), _ptr(player_next),
+                                            self._stream()))
+
     # -- flat self-play rollout -------------------------------------------------------------------
     def selfplay(self, n_steps, mask=None, action=None, reward=None, done=None, records=None, maskbits=None, packed=None):
         """`n_steps` env moves for every game in one launch; outputs are preallocated tensors or None."""

@@ -43,7 +43,7 @@ struct BatchDev {
 
 enum {
     OP_QUERY = 0, OP_INIT, OP_NEW_ROUND, OP_MOVE, OP_NEXT_PLAYER, OP_COUNT_SCORE, OP_STEP,
-    OP_RUNNER_INIT, OP_RUNNER_RESET, OP_RUNNER_STEP, OP_RANDOM_ACTION, OP_SAMPLE_MASK, OP_POLICY_STEP
+    OP_RUNNER_INIT, OP_RUNNER_RESET, OP_RUNNER_STEP, OP_RANDOM_ACTION, OP_SAMPLE_MASK, OP_POLICY_STEP, OP_AGENT_STEP
 };
 
 struct OpArgs {
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(64) azul_seed_kernel(BatchDev b, u64 seed_base
 static __device__ __forceinline__ bool op_needs_rng(int op)
 {
     return op == OP_INIT || op == OP_NEW_ROUND || op == OP_STEP || op == OP_RUNNER_INIT || op == OP_RUNNER_RESET ||
-           op == OP_RUNNER_STEP || op == OP_RANDOM_ACTION || op == OP_SAMPLE_MASK || op == OP_POLICY_STEP;
+           op == OP_RUNNER_STEP || op == OP_RANDOM_ACTION || op == OP_SAMPLE_MASK || op == OP_POLICY_STEP || op == OP_AGENT_STEP;
 }
 
 template <bool LID>
@@ -194,6 +194,30 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
                 st = episode_reset<LID>(g, b.rules.first_player, r);
                 game_prime<LID>(g, k);
                 dirty_state = true;
+            }
+            if (a.reward) AZ_LANE0(a.reward[gi] = rew);
+            if (a.done) AZ_LANE0(a.done[gi] = (uint8_t)dn);
+        } break;
+        case OP_AGENT_STEP: {
+            // one AGENT step of NNRunner.run_episode (nn_runner.py:24-29): GameRunner.step -- the agent's move, the
+            // opponent's RandomAgent replies, the shaped reward, done (game_runner.py:43-55) -- and, when the episode
+            // ends, the GameRunner.reset() that opens the next run_episode (nn_runner.py:20 -> game_runner.py:76-82,
+            // incl. the opponent's opening moves), so the observation / mask written below are the next decision's
+            i32 rew = 0;
+            u32 dn = 0;
+            st = runner_step<LID>(g, k, r, tab, a.actions[gi], rew, dn);
+            dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_BAD_ACTION);
+            if (st == ST_STUCK) { AZ_LANE0(b.stuck[gi] += 1u); dn = 2u; rew = 0; }       // hazard H3: nobody can move
+            else if (st == ST_GAME_ENDED) dn = 1u;       // a finished game handed in: restart the slot, report done
+            else if (st == ST_OK && dn) {
+                for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(b.stat_sum[(size_t)gi * 10 + q] += sv); }
+                AZ_LANE0(b.episodes[gi] += 1ull);
+            }
+            if (dirty_state && dn) {
+                u32 st2 = episode_reset<LID>(g, b.rules.first_player, r);
+                game_prime<LID>(g, k);
+                if (!st2) st2 = runner_opponent_loop<LID>(g, k, r, tab, true);
+                if (st == ST_OK) st = st2;
             }
             if (a.reward) AZ_LANE0(a.reward[gi] = rew);
             if (a.done) AZ_LANE0(a.done[gi] = (uint8_t)dn);
@@ -713,6 +737,17 @@ int azul_batch_policy_step(azul_batch_t *b, const int32_t *actions_dev, const ui
 {
     if (!actions_dev || perspective < 0 || perspective > 2) return fail(AZUL_ERR_INVALID, "azul_batch_policy_step: bad arguments");
     OpArgs a = op_args(OP_POLICY_STEP);
+    a.actions = actions_dev; a.active = active_dev; a.reward = reward_dev; a.done = done_dev; a.status = status_dev;
+    a.persp = perspective; a.obs = obs_next_dev; a.mask = mask_next_dev; a.player = player_next_dev;
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_agent_step(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *active_dev, int32_t *reward_dev,
+                          uint8_t *done_dev, uint8_t *status_dev, int perspective, float *obs_next_dev,
+                          uint8_t *mask_next_dev, uint8_t *player_next_dev, void *stream)
+{
+    if (!actions_dev || perspective < 0 || perspective > 2) return fail(AZUL_ERR_INVALID, "azul_batch_agent_step: bad arguments");
+    OpArgs a = op_args(OP_AGENT_STEP);
     a.actions = actions_dev; a.active = active_dev; a.reward = reward_dev; a.done = done_dev; a.status = status_dev;
     a.persp = perspective; a.obs = obs_next_dev; a.mask = mask_next_dev; a.player = player_next_dev;
     return launch_op(b, a, stream);

@@ -1,0 +1,100 @@
+"""A2C learner for batched rollouts: the reference's ``Agent.update`` (azulnet/agent.py:39-62) and the batch assembly of
+``NNRunner.train`` (azulnet/nn_runner.py:57-79), restated for whole trajectory windows and for data-parallel ranks.
+
+Loss, exactly as the reference writes it (agent.py:45-58), over the n samples of a batch:
+    advantage    = qvals - values
+    actor_loss   = mean(-log_prob(action) * advantage)          (advantage NOT detached, like the reference)
+    critic_loss  = mean(advantage^2)
+    entropy_loss = mean(-mean(log p over legal actions))        (nn_runner.py:36-40; coefficient +0.1, sic)
+    ac_loss      = 1 * actor_loss + 0.5 * critic_loss + 0.1 * entropy_loss
+then one Adam step (lr 3e-4).  The reference evaluates the network once per agent step while it plays and keeps the autograd
+graph; here the rollout runs without autograd and the learner re-evaluates the network on the recorded (observation, mask,
+action) samples in one batched forward, which yields the same values, log-probabilities and gradients.
+
+Data parallel (one process per GPU): every rank holds the samples of its own games; the loss terms are SUMS over the local
+samples divided by the GLOBAL sample count, and gradients are summed over ranks (one flat all-reduce over RCCL), so the
+update equals the single-process update on the union of all ranks' samples whatever the per-rank counts are.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ACTOR_COEFF, CRITIC_COEFF, ENTROPY_COEFF = 1.0, 0.5, 0.1        # agent.py:47-49
+
+
+def complete_episode_samples(done):
+    """[T, N] done flags of a window -> bool [T, N]: the steps whose episode ENDS inside the window, i.e. whose discounted
+    return (nn_runner.py:70-76) is exact without bootstrapping.  Steps after a game's last `done` are left for a later window."""
+    d = done != 0
+    return torch.flip(torch.cummax(torch.flip(d, dims=[0]).to(torch.uint8), dim=0).values, dims=[0]).bool()
+
+
+class A2CLearner:
+    def __init__(self, policy, learning_rate=3e-4, gamma=0.99, process_group=None, distributed=None):
+        self.policy = policy
+        self.gamma = gamma
+        self.optimizer = torch.optim.Adam(policy.parameters(), lr=learning_rate)        # agent.py:37
+        self.group = process_group
+        self.distributed = (dist.is_available() and dist.is_initialized()) if distributed is None else distributed
+        self.statistics = {"actor_loss": [], "critic_loss": [], "entropy_loss": [], "ac_loss": [], "samples": []}
+
+    def loss_terms(self, obs, mask, action, qvals, weight=None, n_total=None):
+        """obs [n,136] f32, mask [n,180] bool/u8, action [n] int, qvals [n] -> the four loss terms of agent.py:51-57.
+        `weight` [n] (0/1) drops samples without changing shapes; `n_total` is the divisor (default: the local count)."""
+        pol = self.policy
+        legal = mask.bool()
+        values = pol.forward_critic(obs).squeeze(1)
+        _, logp = pol.forward_actor(obs, legal)
+        log_prob = logp.gather(1, action.long().clamp(min=0).unsqueeze(1)).squeeze(1)                 # nn_runner.py:32
+        entropy = -(torch.where(legal, logp, torch.zeros_like(logp)).sum(dim=1) / legal.sum(dim=1).clamp(min=1))   # :36-40
+        advantage = qvals.to(values.dtype) - values
+        w = torch.ones_like(values) if weight is None else weight.to(values.dtype)
+        n = w.sum() if n_total is None else n_total
+        actor_loss = (-log_prob * advantage * w).sum() / n
+        critic_loss = (advantage.pow(2) * w).sum() / n
+        entropy_loss = (entropy * w).sum() / n
+        ac_loss = ACTOR_COEFF * actor_loss + CRITIC_COEFF * critic_loss + ENTROPY_COEFF * entropy_loss
+        return actor_loss, critic_loss, entropy_loss, ac_loss
+
+    def update(self, obs, mask, action, qvals, weight=None):
+        """One optimiser step on the given samples (this rank's share when distributed).  Returns the loss terms (global means)."""
+        n_local = torch.as_tensor(float(obs.shape[0]) if weight is None else weight.sum(), dtype=torch.float32, device=obs.device).reshape(1)
+        n_total = n_local.clone()
+        if self.distributed:
+            dist.all_reduce(n_total, group=self.group)
+        # rows without a legal action (stuck games) carry no sample
+        legal_any = mask.bool().any(dim=1)
+        w = legal_any.to(torch.float32) if weight is None else weight.to(torch.float32) * legal_any
+        a, c, e, loss = self.loss_terms(obs, mask, action, qvals, w, n_total.squeeze(0))
+        self.optimizer.zero_grad(set_to_none=False)
+        loss.backward()
+        stats = torch.stack([a.detach(), c.detach(), e.detach(), loss.detach()])
+        if self.distributed:
+            params = [p for p in self.policy.parameters() if p.grad is not None]
+            flat = torch.cat([p.grad.reshape(-1) for p in params] + [stats])           # one bucket: ~86k floats
+            dist.all_reduce(flat, group=self.group)
+            o = 0
+            for p in params:
+                p.grad.copy_(flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
+            stats = flat[o:]
+        self.optimizer.step()
+        out = {"actor_loss": stats[0], "critic_loss": stats[1], "entropy_loss": stats[2], "ac_loss": stats[3], "samples": n_total.squeeze(0)}
+        for k2, v in out.items():
+            self.statistics[k2].append(v)
+        return out
+
+    def update_from_windows(self, trajectories, complete_only=True):
+        """`trajectories`: the per-part dicts PolicyRollout.run_window returns (opponent="random": every record is one agent
+        step).  Uses the steps whose episode finished inside the window (exact Monte-Carlo returns, the reference's qvals)."""
+        obs, mask, action, ret, w = [], [], [], [], []
+        for tr in trajectories:
+            T = tr["action"].shape[0]
+            keep = complete_episode_samples(tr["done"]) if complete_only else torch.ones_like(tr["done"], dtype=torch.bool)
+            keep = keep & (tr["action"] >= 0)
+            obs.append(tr["obs"][:T].reshape(-1, tr["obs"].shape[-1]))
+            mask.append(tr["mask"][:T].reshape(-1, tr["mask"].shape[-1]))
+            action.append(tr["action"].reshape(-1))
+            ret.append(tr["returns"].reshape(-1))
+            w.append(keep.reshape(-1))
+        return self.update(torch.cat(obs), torch.cat(mask), torch.cat(action), torch.cat(ret), torch.cat(w).to(torch.float32))

@@ -31,8 +31,13 @@ def _p(t):
 
 class PolicyRollout:
     def __init__(self, policy, n_games=4096, parts=2, rules={"first_player": "Random", "tile_pool": "Lid"}, seed_base=0,
-                 device=None, window=32, use_graph=True, record_obs=True, fused_head=True, sample_seed=0x5EED):
+                 device=None, window=32, use_graph=True, record_obs=True, fused_head=True, sample_seed=0x5EED, opponent=None):
+        """opponent=None: the policy moves for both players (flat self-play, one record per env move).
+        opponent="random": the reference's training setup -- the policy is player 1 of GameRunner, the opponent a RandomAgent
+        inside the env step (game_runner.py:43-47); one record per AGENT step, observations from the agent's perspective."""
         assert n_games % parts == 0
+        assert opponent in (None, "random")
+        self.opponent = opponent
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.policy = policy.to(self.device).eval()
         self.n, self.parts, self.h, self.T = n_games, parts, n_games // parts, window
@@ -46,7 +51,10 @@ class PolicyRollout:
             env = BatchedAzul(h, rules=rules, device=d)
             env.seed(seed_base + p * h)                            # seeds follow the global game id
             env.runner_init()                                      # GameRunner()
-            env.runner_init()                                      # reset() without pre-moves (flat self-play)
+            if opponent == "random":
+                env.reset()                                        # GameRunner.reset(): the opponent opens when it starts
+            else:
+                env.runner_init()                                  # reset() without pre-moves (flat self-play)
             self.envs.append(env)
             self.streams.append(torch.cuda.Stream(device=d))
             t = {"obs": torch.zeros(T + 1, h, L.OBS_SIZE, device=d), "mask": torch.zeros(T + 1, h, L.NUM_ACTIONS, dtype=torch.uint8, device=d),
@@ -61,7 +69,7 @@ class PolicyRollout:
             self.traj.append(t)
             self.work.append(w)
             with torch.cuda.stream(self.streams[p]):
-                env.observe_all(L.PERSP_CURRENT, t["obs"][T], t["mask"][T], t["player"][T])    # becomes slot 0 of the first window
+                env.observe_all(self._persp(), t["obs"][T], t["mask"][T], t["player"][T])     # becomes slot 0 of the first window
         torch.cuda.synchronize(d)
         self.use_graph = use_graph
         self.graph_error = None
@@ -74,15 +82,23 @@ class PolicyRollout:
                 self.use_graph = False
                 torch.cuda.synchronize(d)
 
+    def _persp(self):
+        return 0 if self.opponent == "random" else L.PERSP_CURRENT     # NNRunner observes with perspective 0 (game_runner.py:56)
+
     def refresh_weights(self):
-        """(Re)build the fused first-layer weight from the policy's parameters (call after an optimiser step)."""
+        """(Re)build the fused first-layer weights from the policy's parameters -- call after every optimiser step.  The
+        staging tensors are updated IN PLACE: a captured HIP graph keeps reading the same addresses."""
         pol = self.policy
         with torch.no_grad():
             self.H = pol.critic_linear1.out_features
-            self.w1t = torch.cat([pol.critic_linear1.weight, pol.actor_linear1.weight], dim=0).t().contiguous()
-            self.b1 = torch.cat([pol.critic_linear1.bias, pol.actor_linear1.bias]).contiguous()
-            self.w2c_t = pol.critic_linear2.weight.t().contiguous()
-            self.w2a_t = pol.actor_linear2.weight.t().contiguous()
+            fresh = {"w1t": torch.cat([pol.critic_linear1.weight, pol.actor_linear1.weight], dim=0).t(),
+                     "b1": torch.cat([pol.critic_linear1.bias, pol.actor_linear1.bias]),
+                     "w2c_t": pol.critic_linear2.weight.t(), "w2a_t": pol.actor_linear2.weight.t()}
+            for name, v in fresh.items():
+                if hasattr(self, name):
+                    getattr(self, name).copy_(v)
+                else:
+                    setattr(self, name, v.contiguous().clone())
 
     # one move of one part, enqueued on the current stream
     def _move(self, p, t):
@@ -109,7 +125,10 @@ class PolicyRollout:
                 tr["log_prob"][t].copy_(logp.gather(1, action.unsqueeze(1)).squeeze(1))                       # nn_runner.py:32
                 tr["entropy"][t].copy_(-(torch.where(legal, logp, torch.zeros_like(logp)).sum(dim=1) / legal.sum(dim=1).clamp(min=1)))
                 tr["action"][t].copy_(torch.where(any_legal, action, torch.full_like(action, -1)).to(torch.int32))
-        env.policy_step(tr["action"][t], tr["reward"][t], tr["done"][t], w["status"], tr["obs"][t + 1], tr["mask"][t + 1], tr["player"][t + 1])
+        if self.opponent == "random":
+            env.agent_step(tr["action"][t], tr["reward"][t], tr["done"][t], w["status"], tr["obs"][t + 1], tr["mask"][t + 1], tr["player"][t + 1])
+        else:
+            env.policy_step(tr["action"][t], tr["reward"][t], tr["done"][t], w["status"], tr["obs"][t + 1], tr["mask"][t + 1], tr["player"][t + 1])
 
     def _window(self, p, gamma):
         tr, T = self.traj[p], self.T

@@ -4,6 +4,8 @@ PyTorch-ROCm interleaved with the env step on separate HIP streams, 1 MI355X.  N
 (that is bench.py / configs[1]); prints one JSON line with env steps/s for the policy-driven rollout.
 
     python bench_policy.py [--games 4096] [--parts 2] [--window 32] [--windows 20] [--no-graph]
+    python bench_policy.py --train          # the reference's training setup (NNRunner.train): policy vs RandomAgent opponent,
+                                            # one A2C update (learner.py) per window; N>1 under torch.distributed.run
 """
 import argparse
 import json
@@ -22,9 +24,12 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-obs-record", action="store_true")
     ap.add_argument("--torch-head", action="store_true", help="sample with torch.multinomial instead of the fused head kernel")
+    ap.add_argument("--train", action="store_true", help="policy vs RandomAgent opponent + one A2C update per window")
     a = ap.parse_args()
     import torch
     from azul_deep_reinforcement_learning_amd import BatchedActorCritic, PolicyRollout
+    if a.train:
+        return train(a)
     torch.manual_seed(0)
     net = BatchedActorCritic(136, 180, 180)
     ro = PolicyRollout(net, n_games=a.games, parts=a.parts, window=a.window, use_graph=not a.no_graph,
@@ -46,6 +51,61 @@ def main():
                       "stream_parts": a.parts, "moves_per_graph": a.window, "hip_graph": ro.use_graph, "fused_head": ro.fused_head,
                       "graph_error": ro.graph_error}, "ms_per_step": dt / (a.window * a.windows) * 1e3,
                       "episodes_finished": c["episodes"], "stuck": c["stuck"], "dtype": "fp32 policy / u8 env", "data": "synthetic"}))
+
+
+def train(a):
+    """Row N2: batched NNRunner.train -- rollout windows against the RandomAgent opponent, A2C update per window,
+    gradients all-reduced over the ranks (one process per GPU)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from azul_deep_reinforcement_learning_amd import BatchedActorCritic, PolicyRollout
+    from azul_deep_reinforcement_learning_amd.learner import A2CLearner
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("AZUL_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+    torch.manual_seed(0)                                    # same initial weights on every rank
+    net = BatchedActorCritic(136, 180, 180)
+    ro = PolicyRollout(net, n_games=a.games, parts=a.parts, window=a.window, use_graph=not a.no_graph, fused_head=not a.torch_head,
+                       opponent="random", seed_base=rank * a.games, sample_seed=0x5EED + rank)
+    learner = A2CLearner(net)
+
+    def one_window():
+        tr = ro.run_window()
+        ro.synchronize()
+        out = learner.update_from_windows(tr)
+        ro.refresh_weights()
+        return out
+
+    for _ in range(3):
+        one_window()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    e0 = ro.counters()["episodes"]
+    t0 = time.perf_counter()
+    for _ in range(a.windows):
+        out = one_window()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    c = ro.counters()
+    stats = learner.statistics
+    if rank == 0:
+        print(json.dumps({"metric": "A2C training throughput (policy vs RandomAgent opponent, one update per window)",
+                          "value": a.games * world * a.window * a.windows / dt, "unit": "agent steps/s", "n_gpus": world,
+                          "updates_per_s": a.windows / dt, "samples_per_update": float(out["samples"]),
+                          "episodes_per_s_rank0": (c["episodes"] - e0) / dt,
+                          "config": {"workload": "NNRunner.train batched: %d games/GPU, window %d agent steps" % (a.games, a.window),
+                                     "hip_graph": ro.use_graph, "graph_error": ro.graph_error},
+                          "first_losses": {k: float(stats[k][0]) for k in ("actor_loss", "critic_loss", "entropy_loss")},
+                          "last_losses": {k: float(stats[k][-1]) for k in ("actor_loss", "critic_loss", "entropy_loss")},
+                          "dtype": "fp32 policy / u8 env", "data": "synthetic"}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

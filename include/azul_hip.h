@@ -144,6 +144,13 @@ int azul_batch_score_preview(azul_batch_t *b, int32_t *potential_dev /*[N]*/, vo
 int azul_batch_policy_step(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *active_dev, int32_t *reward_dev,
                            uint8_t *done_dev, uint8_t *status_dev, int perspective, float *obs_next_dev /*[N][136]*/,
                            uint8_t *mask_next_dev /*[N][180]*/, uint8_t *player_next_dev /*[N]*/, void *stream);
+/* one AGENT step of NNRunner.run_episode for every game (nn_runner.py:24-29): GameRunner.step (game_runner.py:43-55: the
+ * agent's move, the opponent's RandomAgent replies, shaped reward, done) and, when the episode ends, the GameRunner.reset()
+ * that opens the next run_episode (nn_runner.py:20, game_runner.py:76-82, incl. the opponent's opening moves); then the NEXT
+ * decision's observation / mask / player.  done = 2 and status STUCK when nobody could move (slot restarted, reward 0). */
+int azul_batch_agent_step(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *active_dev, int32_t *reward_dev,
+                          uint8_t *done_dev, uint8_t *status_dev, int perspective, float *obs_next_dev /*[N][136]*/,
+                          uint8_t *mask_next_dev /*[N][180]*/, uint8_t *player_next_dev /*[N]*/, void *stream);
 /* observation + mask + player to move in one launch (the first decision of a rollout) */
 int azul_batch_observe_all(azul_batch_t *b, int perspective, float *obs_dev, uint8_t *mask_dev, uint8_t *player_dev, void *stream);
 /* policy head for a batch of action logits [N][180] + legal masks [N][180]: masked softmax, ONE categorical sample per game

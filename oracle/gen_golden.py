@@ -260,16 +260,53 @@ def gen_policy_contract():
     print("wrote policy_contract.npz")
 
 
+def gen_a2c_update():
+    """Agent.update (agent.py:39-62) on fixed inputs: the four loss terms and the parameters after ONE Adam step."""
+    from azulnet import Agent
+    torch.manual_seed(0)
+    agent = Agent()
+    rs = np.random.RandomState(9)
+    n = 48
+    obs = torch.from_numpy(rs.randint(0, 5, size=(n, 136)).astype(np.float32))
+    mask = rs.rand(n, 180) < 0.2
+    mask[np.arange(n), rs.randint(0, 180, n)] = True
+    mask_t = torch.from_numpy(mask)
+    actions = np.array([rs.choice(np.flatnonzero(mask[i])) for i in range(n)])
+    qvals = rs.randn(n, 1).astype(np.float64) * 5
+    sd_before = {k: v.clone().numpy() for k, v in agent.ac_net.state_dict().items()}
+    values, log_probs, entropy = [], [], []
+    for i in range(n):                                   # the shapes NNRunner.run_episode produces (nn_runner.py:26-44)
+        value = agent.ac_net.forward_critic(obs[i:i + 1])
+        _, logp = agent.ac_net.forward_actor(obs[i:i + 1], mask_t[i:i + 1])
+        values.append(value)
+        log_probs.append(logp.squeeze(0)[actions[i]])
+        entropy.append(-logp.masked_select(mask_t[i:i + 1]).mean())
+    agent.update(qvals, [0.0], values, log_probs, entropy)
+    st = agent.agent_statistics.statisticsBuffer
+    blob = {"obs": obs.numpy(), "mask": mask, "actions": actions, "qvals": qvals,
+            "actor_loss": st["actor_loss"], "critic_loss": st["critic_loss"], "entropy_loss": st["entropy_loss"], "ac_loss": st["ac_loss"]}
+    for k, v in sd_before.items():
+        blob["before_" + k] = v
+    for k, v in agent.ac_net.state_dict().items():
+        blob["after_" + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "a2c_update.npz"), **blob)
+    print("wrote a2c_update.npz")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("reference:", os.path.dirname(azulnet.__file__))
     if len(sys.argv) > 1 and sys.argv[1] == "policy":
         gen_policy_contract()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "a2c":
+        gen_a2c_update()
+        return
     gen_rng()
     gen_boards()
     gen_trajectories()
     gen_policy_contract()
+    gen_a2c_update()
 
 
 if __name__ == "__main__":

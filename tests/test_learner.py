@@ -1,0 +1,216 @@
+"""Row N2: the A2C update.  Golden: the reference's own Agent.update (azulnet/agent.py:39-62) run on fixed
+samples -- its four loss terms and every parameter after ONE Adam step (tests/golden/a2c_update.npz, oracle/gen_golden.py a2c).
+The data-parallel form must land on the same parameters whatever the split of the samples over the ranks."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as oz
+
+
+def _golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "a2c_update.npz"))
+
+
+def _net_from(g, prefix, device="cpu"):
+    from azul_deep_reinforcement_learning_amd.policy import BatchedActorCritic
+    sd = {k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)}
+    return BatchedActorCritic.from_reference(sd).to(device)
+
+
+def _samples(g, lo, hi, device="cpu"):
+    return (torch.from_numpy(g["obs"][lo:hi]).to(device), torch.from_numpy(g["mask"][lo:hi]).to(device),
+            torch.from_numpy(g["actions"][lo:hi]).to(device), torch.from_numpy(g["qvals"][lo:hi, 0]).float().to(device))
+
+
+def _check_after(net, g, atol=2e-6):
+    for k, v in net.state_dict().items():
+        assert torch.allclose(v.cpu(), torch.from_numpy(g["after_" + k]), rtol=0, atol=atol), k
+
+
+def test_update_matches_the_reference_agent_update(golden_dir):
+    from azul_deep_reinforcement_learning_amd.learner import A2CLearner
+    g = _golden(golden_dir)
+    net = _net_from(g, "before_")
+    learner = A2CLearner(net, distributed=False)
+    out = learner.update(*_samples(g, 0, 48))
+    for k in ("actor_loss", "critic_loss", "entropy_loss", "ac_loss"):
+        assert np.isclose(float(out[k]), float(g[k][0]), rtol=2e-5, atol=1e-6), (k, float(out[k]), g[k])
+    assert int(out["samples"]) == 48
+    _check_after(net, g)
+    # the parameters really moved (Adam's first step is +-lr per coordinate wherever the gradient is non-zero)
+    moved = max(float((net.state_dict()[k] - torch.from_numpy(g["before_" + k])).abs().max()) for k in net.state_dict())
+    assert 2.9e-4 < moved < 3.1e-4
+
+
+def test_weights_drop_samples_without_changing_the_update(golden_dir):
+    """Masked-out rows (weight 0: unfinished episodes of a window) must not contribute."""
+    from azul_deep_reinforcement_learning_amd.learner import A2CLearner
+    g = _golden(golden_dir)
+    net = _net_from(g, "before_")
+    obs, mask, act, q = _samples(g, 0, 48)
+    rs = np.random.RandomState(3)
+    junk = 17
+    obs2 = torch.cat([obs, torch.from_numpy(rs.randint(0, 5, size=(junk, 136)).astype(np.float32))])
+    mask2 = torch.cat([mask, torch.ones(junk, 180, dtype=torch.bool)])
+    act2 = torch.cat([act, torch.zeros(junk, dtype=act.dtype)])
+    q2 = torch.cat([q, torch.full((junk,), 1e3)])
+    w = torch.cat([torch.ones(48), torch.zeros(junk)])
+    perm = torch.from_numpy(rs.permutation(48 + junk))
+    A2CLearner(net, distributed=False).update(obs2[perm], mask2[perm], act2[perm], q2[perm], w[perm])
+    _check_after(net, g, atol=5e-6)
+
+
+def test_complete_episode_samples():
+    from azul_deep_reinforcement_learning_amd.learner import complete_episode_samples
+    done = torch.tensor([[0, 0, 1, 0], [1, 0, 0, 0], [0, 0, 2, 0], [0, 0, 0, 0]], dtype=torch.uint8)     # [T=4, N=4]
+    keep = complete_episode_samples(done)
+    assert keep.tolist() == [[True, False, True, False], [True, False, True, False], [False, False, True, False], [False] * 4]
+
+
+def _dp_worker(rank, world, port, golden_dir, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from azul_deep_reinforcement_learning_amd.learner import A2CLearner
+    g = _golden(golden_dir)
+    net = _net_from(g, "before_")
+    lo, hi = (0, 13) if rank == 0 else (13, 48)            # deliberately uneven shares
+    out = A2CLearner(net).update(*_samples(g, lo, hi))
+    q.put((rank, {k: v.numpy().copy() for k, v in net.state_dict().items()}, {k: float(v) for k, v in out.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_update_equals_the_single_process_update(golden_dir):
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, golden_dir, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = _golden(golden_dir)
+    for rank, sd, out in res:
+        for k, v in sd.items():
+            assert np.allclose(v, g["after_" + k], rtol=0, atol=2e-6), (rank, k)
+        for k in ("actor_loss", "critic_loss", "entropy_loss", "ac_loss"):
+            assert np.isclose(out[k], float(g[k][0]), rtol=2e-5, atol=1e-6), (rank, k)
+        assert out["samples"] == 48
+
+
+# ---------------------------------------------------------------- GPU: agent step + rollout vs random opponent + learner
+def _pick(mask_row, it, g):
+    legal = np.flatnonzero(mask_row)
+    return int(legal[(it * 7 + g * 3) % len(legal)])
+
+
+@pytest.mark.gpu
+def test_agent_step_matches_oracle_over_several_episodes():
+    """azul_batch_agent_step == GameRunner.step + (at episode end) GameRunner.reset, bit for bit: reward, done, the next
+    observation and mask, the game records and the RNG position, for 96 games x 130 agent steps (3+ episodes each)."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    L = oz.lib()
+    n, steps = 96, 130
+    env = BatchedAzul(n)
+    env.seed(seed_base=9000)
+    env.runner_init()
+    env.reset()
+    rngs = [oz.seeded_rng(9000 + g) for g in range(n)]
+    qs = [oz.Runner() for _ in range(n)]
+    for g in range(n):
+        assert L.oz_runner_init(C.byref(qs[g]), oz.FIRST_RANDOM, oz.POOL_LID, C.byref(rngs[g])) == 0
+        assert L.oz_runner_reset(C.byref(qs[g]), C.byref(rngs[g])) == 0
+    dev = env.device
+    obs, mask, player = env.observe_all(0)
+    reward = torch.zeros(n, dtype=torch.int32, device=dev)
+    done = torch.zeros(n, dtype=torch.uint8, device=dev)
+    status = torch.zeros(n, dtype=torch.uint8, device=dev)
+    episodes = 0
+    for it in range(steps):
+        m = mask.cpu().numpy().astype(bool)
+        o = obs.cpu().numpy()
+        for g in range(n):
+            assert np.array_equal(m[g], oz.check_all_valid(qs[g].game)), (it, g)
+            assert np.array_equal(o[g].astype(np.int64), oz.get_state(qs[g].game, 0)), (it, g)
+        a = np.array([_pick(m[g], it, g) for g in range(n)], dtype=np.int32)
+        env.agent_step(torch.from_numpy(a).to(dev), reward, done, status, obs, mask, player)
+        r_, d_, s_ = reward.cpu().numpy(), done.cpu().numpy(), status.cpu().numpy()
+        for g in range(n):
+            rew, dn = C.c_int64(0), C.c_int(0)
+            assert L.oz_runner_step(C.byref(qs[g]), int(a[g]), C.byref(rngs[g]), C.byref(rew), C.byref(dn)) == 0
+            assert s_[g] == 0 and r_[g] == rew.value and bool(d_[g]) == bool(dn.value), (it, g)
+            if dn.value:
+                episodes += 1
+                assert L.oz_runner_reset(C.byref(qs[g]), C.byref(rngs[g])) == 0
+        if it % 16 == 15 or it == steps - 1:
+            assert env.get_records().tobytes() == np.array([oz.pack(q) for q in qs], dtype=oz.RECORD_DTYPE).tobytes(), it
+    assert (player.cpu().numpy() == 1).all()
+    assert episodes >= 2 * n and int(env.counters()["episodes"].sum()) == episodes
+    for g in range(0, n, 7):
+        _, pos = env.get_rng(g)
+        assert pos == rngs[g].idx
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_rollout_against_random_opponent_and_learner_step(golden_dir, use_graph):
+    """PolicyRollout(opponent="random") = batched NNRunner.run_episode: every record is an agent step replayable through
+    the oracle; the learner consumes the window, and the next window is played with the UPDATED weights (graph or not)."""
+    from azul_deep_reinforcement_learning_amd import PolicyRollout
+    from azul_deep_reinforcement_learning_amd.learner import A2CLearner, complete_episode_samples
+    L = oz.lib()
+    g0 = _golden(golden_dir)
+    net = _net_from(g0, "before_", "cuda")
+    T, n = 48, 64
+    ro = PolicyRollout(net, n_games=n, parts=2, seed_base=321, window=T, use_graph=use_graph, opponent="random")
+    assert ro.use_graph == use_graph, ro.graph_error
+    learner = A2CLearner(net, distributed=False)
+    start = [(env.get_records(), [env.get_rng(g) for g in range(ro.h)]) for env in ro.envs]
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    windows = []
+    for wi in range(2):
+        tr = ro.run_window()
+        ro.synchronize()
+        windows.append([{k: v.cpu().numpy().copy() for k, v in part.items()} for part in tr])
+        # values recorded while playing == the CURRENT network on the recorded observations
+        for part in tr:
+            with torch.no_grad():
+                v = net.forward_critic(part["obs"][:T].reshape(-1, 136)).reshape(T, ro.h, 1)
+            assert torch.allclose(v, part["value"], rtol=1e-4, atol=1e-4), wi
+        out = learner.update_from_windows(tr)
+        ro.refresh_weights()
+        keep = sum(int(complete_episode_samples(part["done"]).sum()) for part in tr)
+        assert int(out["samples"]) == keep and keep > 0
+        assert all(np.isfinite(float(out[k])) for k in ("actor_loss", "critic_loss", "entropy_loss", "ac_loss"))
+    assert any(not torch.equal(before[k], v) for k, v in net.state_dict().items())
+    # env side: replay the sampled agent actions through the oracle's GameRunner
+    for p in (0, 1):
+        for g in range(0, ro.h, 4):
+            rec0, (mt, pos) = start[p][0][g], start[p][1][g]
+            q = oz.unpack(rec0, oz.POOL_LID, oz.FIRST_RANDOM)
+            r = oz.rng_from_python_state((3, tuple(int(x) for x in mt) + (int(pos),), None))
+            for wi, w in enumerate(windows):
+                part = w[p]
+                for t in range(T):
+                    assert np.array_equal(part["mask"][t, g].astype(bool), oz.check_all_valid(q.game)), (p, g, wi, t)
+                    assert np.array_equal(part["obs"][t, g].astype(np.int64), oz.get_state(q.game, 0))
+                    rew, dn = C.c_int64(0), C.c_int(0)
+                    assert L.oz_runner_step(C.byref(q), int(part["action"][t, g]), C.byref(r), C.byref(rew), C.byref(dn)) == 0
+                    assert part["reward"][t, g] == rew.value and bool(part["done"][t, g]) == bool(dn.value)
+                    if dn.value:
+                        assert L.oz_runner_reset(C.byref(q), C.byref(r)) == 0
+            assert oz.pack(q).tobytes() == ro.envs[p].get_records()[g].tobytes()

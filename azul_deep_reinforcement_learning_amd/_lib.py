@@ -52,6 +52,7 @@ SIGNATURES = {
     "azul_batch_agent_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "azul_batch_observe_all": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "azul_policy_head": (_i, [_vp, _vp, _u64, _u64, _vp, _i, _vp, _vp, _vp, _vp]),
+    "azul_policy_forward": (_i, [_vp] * 8 + [_i, _i, _i, _u64, _u64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "azul_discounted_returns": (_i, [_vp, _vp, _vp, _vp, C.c_float, _i, _i, _vp]),
     "azul_batch_sample_mask": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "azul_batch_score_preview": (_i, [_vp, _vp, _vp]),

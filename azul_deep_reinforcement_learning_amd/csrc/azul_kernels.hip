@@ -361,100 +361,7 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// policy head (row N1): masked softmax + categorical sample + log-prob + entropy term for one batch of logits.
-// Callers: Agent.get_ac_output (agent.py:64-72: softmax over legal actions, np.random.choice(p=probs)) and
-// NNRunner.run_episode (nn_runner.py:32-40: log-prob of the action, entropy = -mean(log p over legal actions)).
-// One wave per game; lane l owns actions 3l, 3l+1, 3l+2 (l < 60), so the inverse-CDF walk is in ascending action
-// order.  fp32 throughout (the reference computes these in fp32 torch); randomness: Philox4x32-10 keyed by
-// (seed, game) with the step counter as the block index -- not torch's or numpy's stream (documented in DESIGN.md).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox_round(u32 &c0, u32 &c1, u32 &c2, u32 &c3, u32 k0, u32 k1)
-{
-    const u32 M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    u32 hi0 = __umulhi(M0, c0), lo0 = M0 * c0, hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-    u32 n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-}
-
-__device__ __forceinline__ u32 philox_u32(u64 seed, u64 counter, u32 game)
-{
-    u32 c0 = (u32)counter, c1 = (u32)(counter >> 32), c2 = game, c3 = 0x415A554Cu;      // "AZUL"
-    u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
-    for (int i = 0; i < 10; i++) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
-    return c0;
-}
-
-__device__ __forceinline__ float wave_max(float v)
-{
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
-__device__ __forceinline__ float wave_sum(float v)
-{
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-__global__ void __launch_bounds__(64) azul_policy_head_kernel(const float *logits, const uint8_t *mask, u64 seed, u64 counter,
-                                                              const u64 *counter_dev, u32 n, i32 *action, float *logp, float *entropy)
-{
-    const u32 g = blockIdx.x, l = threadIdx.x;
-    if (counter_dev) counter += *counter_dev;            // device-resident step counter: graph replays draw fresh numbers
-    const float *lg = logits + (size_t)g * AZUL_NUM_ACTIONS;
-    const uint8_t *mk = mask + (size_t)g * AZUL_NUM_ACTIONS;
-    float x[3];
-    bool ok[3];
-    for (int j = 0; j < 3; j++) {
-        u32 a = 3u * l + (u32)j;
-        bool in = a < AZUL_NUM_ACTIONS;
-        ok[j] = in && mk[in ? a : 0] != 0;
-        x[j] = in ? lg[in ? a : 0] : 0.f;
-    }
-    const float NEG = -3.0e38f;
-    float m = wave_max(fmaxf(fmaxf(ok[0] ? x[0] : NEG, ok[1] ? x[1] : NEG), ok[2] ? x[2] : NEG));
-    u32 cnt = (u32)__popcll(__ballot(ok[0])) + (u32)__popcll(__ballot(ok[1])) + (u32)__popcll(__ballot(ok[2]));
-    if (cnt == 0u) {                                   // no legal action (stuck game): the rollout sends action -1
-        if (l == 0) { action[g] = -1; logp[g] = 0.f; entropy[g] = 0.f; }
-        return;
-    }
-    float e[3], z[3];
-    for (int j = 0; j < 3; j++) { z[j] = ok[j] ? x[j] - m : 0.f; e[j] = ok[j] ? __expf(z[j]) : 0.f; }
-    float mine = e[0] + e[1] + e[2];
-    float S = wave_sum(mine);
-    float logS = __logf(S);
-    float zsum = wave_sum(z[0] + z[1] + z[2]);
-    float ent = -(zsum / (float)cnt - logS);           // -mean(log p over legal actions)
-    // inverse CDF in ascending action order: exclusive prefix of the lane sums, then up to three steps inside the lane
-    float incl = mine;
-    for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(incl, o, 64); if ((int)l >= o) incl += t; }
-    float before = incl - mine;
-    float u = (float)(philox_u32(seed, counter, g) >> 8) * (1.0f / 16777216.0f);       // [0, 1), 24 bits
-    float target = u * S;
-    float c0 = before + e[0], c1 = c0 + e[1], c2 = c1 + e[2];
-    int pick = -1;
-    if (ok[0] && target < c0) pick = 0;
-    else if (ok[1] && target < c1) pick = 1;
-    else if (ok[2] && target < c2) pick = 2;
-    u64 hit = __ballot(pick >= 0);
-    int lane_sel, j_sel;
-    if (hit) {
-        lane_sel = __builtin_ctzll(hit);
-    } else {                                           // fp32 round-off pushed target past the last cumulative sum
-        u64 any = __ballot(ok[0] || ok[1] || ok[2]);
-        lane_sel = 63 - __builtin_clzll(any);
-        pick = ok[2] ? 2 : (ok[1] ? 1 : 0);
-    }
-    j_sel = __shfl(pick, lane_sel, 64);
-    float zsel = __shfl(j_sel == 0 ? z[0] : (j_sel == 1 ? z[1] : z[2]), lane_sel, 64);
-    if (l == 0) {
-        action[g] = 3 * lane_sel + j_sel;
-        logp[g] = zsel - logS;
-        entropy[g] = ent;
-    }
-    (void)n;
-}
+#include "azul_policy.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side: C ABI
@@ -775,8 +682,29 @@ int azul_policy_head(const float *logits_dev, const uint8_t *mask_dev, uint64_t 
                      int n_games, int32_t *action_dev, float *logp_dev, float *entropy_dev, void *stream)
 {
     if (!logits_dev || !mask_dev || !action_dev || !logp_dev || !entropy_dev || n_games <= 0) return fail(AZUL_ERR_INVALID, "azul_policy_head: bad arguments");
-    hipLaunchKernelGGL(azul_policy_head_kernel, dim3((u32)n_games), dim3(64), 0, (hipStream_t)stream, logits_dev, mask_dev,
+    if (((uintptr_t)mask_dev & 3u) != 0) return fail(AZUL_ERR_INVALID, "azul_policy_head: mask_dev must be 4-byte aligned");
+    hipLaunchKernelGGL(azul_policy_head_kernel, dim3(((u32)n_games + 3u) / 4u), dim3(64), 0, (hipStream_t)stream, logits_dev, mask_dev,
                        (u64)seed, (u64)counter, (const u64 *)counter_dev, (u32)n_games, action_dev, logp_dev, entropy_dev);
+    HIP_TRY(hipGetLastError());
+    return AZUL_SUCCESS;
+}
+
+int azul_policy_forward(const float *obs_dev, const uint8_t *mask_dev, const float *w1t_dev, const float *b1_dev, const float *w2c_dev,
+                        const float *b2c_dev, const float *w2a_t_dev, const float *b2a_dev, int num_inputs, int hidden_size, int num_actions,
+                        uint64_t seed, uint64_t counter, uint64_t *counter_dev, int advance_counter, int n_games, float *value_dev,
+                        int32_t *action_dev, float *logp_dev, float *entropy_dev, float *logits_dev, void *stream)
+{
+    if (num_inputs != PF_IN || hidden_size != PF_HID || num_actions != PF_ACT)
+        return fail(AZUL_ERR_INVALID, "azul_policy_forward: only ActorCritic(136, 180, hidden 180) is compiled in");
+    if (!obs_dev || !mask_dev || !w1t_dev || !b1_dev || !w2c_dev || !b2c_dev || !w2a_t_dev || !b2a_dev || !value_dev || !action_dev ||
+        !logp_dev || !entropy_dev || n_games <= 0 || advance_counter < 0)
+        return fail(AZUL_ERR_INVALID, "azul_policy_forward: bad arguments");
+    if (((uintptr_t)w1t_dev & 7u) != 0 || ((uintptr_t)mask_dev & 3u) != 0)
+        return fail(AZUL_ERR_INVALID, "azul_policy_forward: w1t_dev must be 8-byte aligned, mask_dev 4-byte aligned");
+    PolicyWeights W = {w1t_dev, b1_dev, w2c_dev, b2c_dev, w2a_t_dev, b2a_dev};
+    hipLaunchKernelGGL(azul_policy_forward_kernel, dim3(((u32)n_games + PF_GAMES - 1) / PF_GAMES), dim3(256), 0, (hipStream_t)stream,
+                       obs_dev, mask_dev, W, (u64)seed, (u64)counter, (u64 *)counter_dev, advance_counter, (u32)n_games, value_dev,
+                       action_dev, logp_dev, entropy_dev, logits_dev);
     HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }

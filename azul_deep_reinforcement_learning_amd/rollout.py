@@ -2,15 +2,15 @@
 ``NNRunner.run_episode`` (azulnet/nn_runner.py:17-47) and of the action sampling in ``Agent.get_ac_output``
 (azulnet/agent.py:64-81).
 
-Per move and part of the batch (each part has its own HIP stream):
-    hidden = relu([critic_linear1 | actor_linear1](obs))          one GEMM for both first layers   (rocBLAS/hipBLASLt)
-    value  = critic_linear2(hidden[:, :H])                          written straight into the trajectory slot
-    logits = actor_linear2(hidden[:, H:])
-    azul_policy_head   masked softmax + categorical sample + log-prob + entropy        one launch, one wave per game
-    azul_batch_policy_step   Azul.step + reward + done + auto-reset + NEXT obs / mask / player   one launch
-Nothing is copied: the env writes the next observation and mask into slot t+1 of the trajectory, the head writes
-action / log-prob / entropy into slot t.  A window of `T` moves is captured once into a HIP graph per part and
-replayed (the Philox step counter lives in device memory); results are identical with `use_graph=False`.
+Per move and part of the batch (each part has its own HIP stream) -- two launches:
+    azul_policy_forward      the whole ActorCritic forward on the f32 matrix cores (hidden = relu(obs @ [critic_linear1 |
+                             actor_linear1]), value, logits) + masked softmax + categorical sample + log-prob + entropy;
+                             value / action / log-prob / entropy land straight in trajectory slot t
+    azul_batch_policy_step   Azul.step + reward + done + auto-reset + NEXT obs / mask / player, written into slot t+1
+                             (opponent="random": azul_batch_agent_step, the reference's training setup)
+Nothing is copied.  A window of `T` moves is captured once into a HIP graph per part and replayed (the Philox step counter
+lives in device memory and is advanced by the forward launch itself); results are identical with `use_graph=False`.
+`fused_mlp=False` runs the network as PyTorch GEMMs (rocBLAS/hipBLASLt) + azul_policy_head (any network shape);
 `fused_head=False` keeps the all-PyTorch sampling path (torch.multinomial) for comparison.
 
 Per (move t, game g) the record holds what the reference's run_episode keeps per agent step (C1 in SURVEY.md 8a):
@@ -30,8 +30,8 @@ def _p(t):
 
 
 class PolicyRollout:
-    def __init__(self, policy, n_games=4096, parts=2, rules={"first_player": "Random", "tile_pool": "Lid"}, seed_base=0,
-                 device=None, window=32, use_graph=True, record_obs=True, fused_head=True, sample_seed=0x5EED, opponent=None):
+    def __init__(self, policy, n_games=4096, parts=1, rules={"first_player": "Random", "tile_pool": "Lid"}, seed_base=0,
+                 device=None, window=32, use_graph=True, record_obs=True, fused_head=True, sample_seed=0x5EED, opponent=None, fused_mlp=True):
         """opponent=None: the policy moves for both players (flat self-play, one record per env move).
         opponent="random": the reference's training setup -- the policy is player 1 of GameRunner, the opponent a RandomAgent
         inside the env step (game_runner.py:43-47); one record per AGENT step, observations from the agent's perspective."""
@@ -43,6 +43,9 @@ class PolicyRollout:
         self.n, self.parts, self.h, self.T = n_games, parts, n_games // parts, window
         self.record_obs = record_obs          # kept for API compatibility: observations always live in the trajectory slots
         self.fused_head = fused_head
+        # the one-launch forward (azul_policy_forward) is compiled for the reference's ActorCritic(136, 180, hidden 180)
+        self.fused_mlp = bool(fused_mlp and fused_head and policy.critic_linear1.in_features == L.OBS_SIZE and
+                              policy.critic_linear1.out_features == 180 and policy.actor_linear2.out_features == L.NUM_ACTIONS)
         self.sample_seed = int(sample_seed)
         self.envs, self.streams, self.work, self.traj, self.graphs = [], [], [], [], []
         self.refresh_weights()
@@ -65,7 +68,7 @@ class PolicyRollout:
                  "returns": torch.zeros(T, h, device=d)}
             w = {"hidden": torch.zeros(h, 2 * self.H, device=d), "logits": torch.zeros(h, L.NUM_ACTIONS, device=d),
                  "status": torch.zeros(h, dtype=torch.uint8, device=d),
-                 "counter": torch.full((1,), p << 40, dtype=torch.int64, device=d)}          # disjoint Philox blocks per part
+                 "counter": torch.tensor([p << 40, 0], dtype=torch.int64, device=d)}     # [0] Philox step counter (disjoint blocks per part), [1] launch ticket
             self.traj.append(t)
             self.work.append(w)
             with torch.cuda.stream(self.streams[p]):
@@ -93,7 +96,8 @@ class PolicyRollout:
             self.H = pol.critic_linear1.out_features
             fresh = {"w1t": torch.cat([pol.critic_linear1.weight, pol.actor_linear1.weight], dim=0).t(),
                      "b1": torch.cat([pol.critic_linear1.bias, pol.actor_linear1.bias]),
-                     "w2c_t": pol.critic_linear2.weight.t(), "w2a_t": pol.actor_linear2.weight.t()}
+                     "w2c_t": pol.critic_linear2.weight.t(), "w2a_t": pol.actor_linear2.weight.t(),
+                     "w2c": pol.critic_linear2.weight.reshape(-1)}
             for name, v in fresh.items():
                 if hasattr(self, name):
                     getattr(self, name).copy_(v)
@@ -105,6 +109,14 @@ class PolicyRollout:
         env, tr, w = self.envs[p], self.traj[p], self.work[p]
         obs, mask, H = tr["obs"][t], tr["mask"][t], self.H
         pol = self.policy
+        if self.fused_mlp:                                  # whole forward + head: one launch on the f32 matrix cores
+            L.check(L.lib.azul_policy_forward(_p(obs), _p(mask), _p(self.w1t), _p(self.b1), _p(self.w2c), _p(pol.critic_linear2.bias),
+                                              _p(self.w2a_t), _p(pol.actor_linear2.bias), L.OBS_SIZE, H, L.NUM_ACTIONS,
+                                              self.sample_seed, 0, _p(w["counter"]), 1, self.h, _p(tr["value"][t]), _p(tr["action"][t]),
+                                              _p(tr["log_prob"][t]), _p(tr["entropy"][t]), None,
+                                              C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+            self._env_step(p, t)
+            return
         with torch.no_grad():
             torch.addmm(self.b1, obs, self.w1t, out=w["hidden"])
             w["hidden"].relu_()
@@ -114,7 +126,7 @@ class PolicyRollout:
                 L.check(L.lib.azul_policy_head(_p(w["logits"]), _p(mask), self.sample_seed, 0, _p(w["counter"]), self.h,
                                                _p(tr["action"][t]), _p(tr["log_prob"][t]), _p(tr["entropy"][t]),
                                                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
-                w["counter"].add_(1)
+                w["counter"][:1].add_(1)
             else:
                 legal = mask.bool()
                 logits = w["logits"].masked_fill(~legal, float("-inf"))
@@ -125,6 +137,10 @@ class PolicyRollout:
                 tr["log_prob"][t].copy_(logp.gather(1, action.unsqueeze(1)).squeeze(1))                       # nn_runner.py:32
                 tr["entropy"][t].copy_(-(torch.where(legal, logp, torch.zeros_like(logp)).sum(dim=1) / legal.sum(dim=1).clamp(min=1)))
                 tr["action"][t].copy_(torch.where(any_legal, action, torch.full_like(action, -1)).to(torch.int32))
+        self._env_step(p, t)
+
+    def _env_step(self, p, t):
+        env, tr, w = self.envs[p], self.traj[p], self.work[p]
         if self.opponent == "random":
             env.agent_step(tr["action"][t], tr["reward"][t], tr["done"][t], w["status"], tr["obs"][t + 1], tr["mask"][t + 1], tr["player"][t + 1])
         else:

@@ -3,7 +3,7 @@
 PyTorch-ROCm interleaved with the env step on separate HIP streams, 1 MI355X.  Not the driver's headline bench
 (that is bench.py / configs[1]); prints one JSON line with env steps/s for the policy-driven rollout.
 
-    python bench_policy.py [--games 4096] [--parts 2] [--window 32] [--windows 20] [--no-graph]
+    python bench_policy.py [--games 4096] [--parts 1] [--window 32] [--windows 20] [--no-graph]
     python bench_policy.py --train          # the reference's training setup (NNRunner.train): policy vs RandomAgent opponent,
                                             # one A2C update (learner.py) per window; N>1 under torch.distributed.run
 """
@@ -18,12 +18,13 @@ sys.path.insert(0, __file__.rsplit("/", 1)[0])
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--games", type=int, default=4096)
-    ap.add_argument("--parts", type=int, default=2)
+    ap.add_argument("--parts", type=int, default=1)
     ap.add_argument("--window", type=int, default=32)
     ap.add_argument("--windows", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-obs-record", action="store_true")
     ap.add_argument("--torch-head", action="store_true", help="sample with torch.multinomial instead of the fused head kernel")
+    ap.add_argument("--torch-mlp", action="store_true", help="run the network as PyTorch GEMMs instead of azul_policy_forward")
     ap.add_argument("--train", action="store_true", help="policy vs RandomAgent opponent + one A2C update per window")
     a = ap.parse_args()
     import torch
@@ -33,7 +34,7 @@ def main():
     torch.manual_seed(0)
     net = BatchedActorCritic(136, 180, 180)
     ro = PolicyRollout(net, n_games=a.games, parts=a.parts, window=a.window, use_graph=not a.no_graph,
-                       record_obs=not a.no_obs_record, fused_head=not a.torch_head)
+                       record_obs=not a.no_obs_record, fused_head=not a.torch_head, fused_mlp=not a.torch_mlp)
     for _ in range(3):
         ro.run_window()
     ro.synchronize()
@@ -48,7 +49,7 @@ def main():
     c = ro.counters()
     print(json.dumps({"metric": "Azul env steps/sec (ActorCritic policy self-play, trajectories recorded)", "value": moves / dt,
                       "unit": "env steps/s", "n_gpus": 1, "config": {"workload": "BASELINE configs[2]", "games": a.games,
-                      "stream_parts": a.parts, "moves_per_graph": a.window, "hip_graph": ro.use_graph, "fused_head": ro.fused_head,
+                      "stream_parts": a.parts, "moves_per_graph": a.window, "hip_graph": ro.use_graph, "fused_head": ro.fused_head, "fused_mlp": ro.fused_mlp,
                       "graph_error": ro.graph_error}, "ms_per_step": dt / (a.window * a.windows) * 1e3,
                       "episodes_finished": c["episodes"], "stuck": c["stuck"], "dtype": "fp32 policy / u8 env", "data": "synthetic"}))
 
@@ -69,7 +70,7 @@ def train(a):
     torch.manual_seed(0)                                    # same initial weights on every rank
     net = BatchedActorCritic(136, 180, 180)
     ro = PolicyRollout(net, n_games=a.games, parts=a.parts, window=a.window, use_graph=not a.no_graph, fused_head=not a.torch_head,
-                       opponent="random", seed_base=rank * a.games, sample_seed=0x5EED + rank)
+                       fused_mlp=not a.torch_mlp, opponent="random", seed_base=rank * a.games, sample_seed=0x5EED + rank)
     learner = A2CLearner(net)
 
     def one_window():

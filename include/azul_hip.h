@@ -159,6 +159,19 @@ int azul_batch_observe_all(azul_batch_t *b, int perspective, float *obs_dev, uin
  * device memory (counter_dev) when the call is replayed from a HIP graph.  Rows without a legal action give -1. */
 int azul_policy_head(const float *logits_dev, const uint8_t *mask_dev, uint64_t seed, uint64_t counter, const uint64_t *counter_dev,
                      int n_games, int32_t *action_dev, float *logp_dev, float *entropy_dev, void *stream);
+/* The whole ActorCritic forward (model.py:12-41) + the head above in ONE launch, 16 games per workgroup on the f32 matrix cores
+ * (exact f32):  hidden = relu(obs @ w1t + b1), value = hidden[:, :H] . w2c + b2c, logits = hidden[:, H:] @ w2a_t + b2a, then
+ * azul_policy_head's sampling on the logits.  Weight layouts (k-major, i.e. nn.Linear.weight transposed):
+ *   w1t [num_inputs][2H]: columns 0..H-1 critic_linear1, H..2H-1 actor_linear1;  b1 [2H];  w2c [H] critic_linear2.weight;  b2c [1];
+ *   w2a_t [H][num_actions] actor_linear2.weight^T;  b2a [num_actions].   Only (136, H = 180, 180) is compiled in (the reference's
+ * net); other shapes return AZUL_ERR_INVALID.  counter_dev: optional uint64_t[2] in device memory -- [0] is added to `counter`
+ * and, when advance_counter > 0, advanced by that much by the launch itself (graph replays then draw fresh numbers without
+ * a host round trip); [1] is the launch's completion ticket and must start as 0.  logits_dev [N][180] is optional. */
+int azul_policy_forward(const float *obs_dev /*[N][136]*/, const uint8_t *mask_dev /*[N][180]*/, const float *w1t_dev, const float *b1_dev,
+                        const float *w2c_dev, const float *b2c_dev, const float *w2a_t_dev, const float *b2a_dev, int num_inputs,
+                        int hidden_size, int num_actions, uint64_t seed, uint64_t counter, uint64_t *counter_dev, int advance_counter,
+                        int n_games, float *value_dev /*[N]*/, int32_t *action_dev, float *logp_dev, float *entropy_dev,
+                        float *logits_dev, void *stream);
 /* discounted returns q[t] = r[t] + gamma * q[t+1] within episodes over a time-major window [n_steps][n_games]
  * (nn_runner.py:70-76); done[t][g] != 0 closes an episode at move t; carry_dev[n_games] (optional) chains windows. */
 int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, float *returns_dev, float *carry_dev,

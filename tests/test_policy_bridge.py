@@ -107,8 +107,8 @@ def _oracle_replay(rec, mt, pos, fp, pool, actions):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_graph,fused", [(False, True), (True, True), (False, False)])
-def test_policy_rollout_replays_exactly_through_the_oracle(contract, use_graph, fused):
+@pytest.mark.parametrize("use_graph,fused,mlp", [(False, True, True), (True, True, True), (True, True, False), (False, False, False)])
+def test_policy_rollout_replays_exactly_through_the_oracle(contract, use_graph, fused, mlp):
     """Everything the rollout records about the ENV (mask, observation, player, reward, done, final state) must be
     what the oracle computes when it is fed the actions the policy sampled -- for both stream parts, eager launches
     and HIP-graph replays alike."""
@@ -116,8 +116,9 @@ def test_policy_rollout_replays_exactly_through_the_oracle(contract, use_graph, 
     torch.manual_seed(1)
     net = _net(contract, "cuda")
     T, n = 40, 64
-    ro = PolicyRollout(net, n_games=n, parts=2, seed_base=500, window=T, use_graph=use_graph, fused_head=fused)
+    ro = PolicyRollout(net, n_games=n, parts=2, seed_base=500, window=T, use_graph=use_graph, fused_head=fused, fused_mlp=mlp)
     assert ro.use_graph == use_graph, ro.graph_error
+    assert ro.fused_mlp == mlp
     start = [(env.get_records(), [env.get_rng(g) for g in range(ro.h)]) for env in ro.envs]
     windows = []
     for _ in range(2):
@@ -199,3 +200,58 @@ def test_policy_head_matches_torch_and_samples_the_distribution(contract):
     L.check(L.lib.azul_policy_head(C.c_void_p(logits.data_ptr()), C.c_void_p(mask.data_ptr()), 1234, 17, None, n,
                                    C.c_void_p(action.data_ptr()), C.c_void_p(logp.data_ptr()), C.c_void_p(ent.data_ptr()), None))
     assert torch.equal(a1, action)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 16, 45, 2048])
+def test_fused_forward_matches_the_reference_network(contract, n):
+    """azul_policy_forward (f32 matrix cores, one launch) vs the PyTorch module carrying the reference's weights: value and
+    logits within f32 round-off, and the head's outputs equal to azul_policy_head run on the kernel's own logits (same Philox
+    stream => same action).  n = 1 / 45 exercise the ragged last tile; the weights/obs are asymmetric random data."""
+    from azul_deep_reinforcement_learning_amd import _lib as L
+    torch.manual_seed(n)
+    net = _net(contract, "cuda")
+    with torch.no_grad():                       # de-symmetrise: the golden net is a default init, give every bias a value
+        for p_ in net.parameters():
+            p_.add_(0.05 * torch.randn_like(p_))
+    rs = np.random.RandomState(n)
+    obs = torch.from_numpy(rs.randint(0, 6, size=(n, 136)).astype(np.float32)).cuda()
+    mask_np = rs.rand(n, 180) < 0.15
+    mask_np[np.arange(n), rs.randint(0, 180, n)] = True
+    if n > 20:
+        mask_np[7] = False                      # a stuck game: action -1
+    mask = torch.from_numpy(mask_np.astype(np.uint8)).cuda()
+    w1t = torch.cat([net.critic_linear1.weight, net.actor_linear1.weight], dim=0).t().contiguous()
+    b1 = torch.cat([net.critic_linear1.bias, net.actor_linear1.bias]).contiguous()
+    w2c = net.critic_linear2.weight.reshape(-1).contiguous()
+    w2a_t = net.actor_linear2.weight.t().contiguous()
+    value = torch.zeros(n, device="cuda")
+    action = torch.zeros(n, dtype=torch.int32, device="cuda")
+    logp = torch.zeros(n, device="cuda")
+    ent = torch.zeros(n, device="cuda")
+    logits = torch.zeros(n, 180, device="cuda")
+    counter = torch.tensor([5, 0], dtype=torch.int64, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for rep in range(2):                        # second launch: the device counter advanced by itself
+        L.check(L.lib.azul_policy_forward(p(obs), p(mask), p(w1t), p(b1), p(w2c), p(net.critic_linear2.bias), p(w2a_t),
+                                          p(net.actor_linear2.bias), 136, 180, 180, 77, 1000, p(counter), 1, n, p(value), p(action),
+                                          p(logp), p(ent), p(logits), None))
+        torch.cuda.synchronize()
+        assert counter.tolist() == [6 + rep, 0]
+        with torch.no_grad():
+            v_ref = net.forward_critic(obs).squeeze(1)
+            lg_ref = net.actor_linear2(torch.relu(net.actor_linear1(obs)))
+        assert torch.allclose(value, v_ref, rtol=1e-5, atol=2e-5)
+        assert torch.allclose(logits, lg_ref, rtol=1e-5, atol=2e-5)
+        a2 = torch.zeros_like(action)
+        lp2 = torch.zeros_like(logp)
+        e2 = torch.zeros_like(ent)
+        L.check(L.lib.azul_policy_head(p(logits), p(mask), 77, 1000 + 5 + rep, None, n, p(a2), p(lp2), p(e2), None))
+        torch.cuda.synchronize()
+        assert torch.equal(action, a2) and torch.equal(logp, lp2) and torch.equal(ent, e2)
+        a = action.cpu().numpy()
+        legal_rows = mask_np.any(axis=1)
+        assert (a[~legal_rows] == -1).all() and mask_np[np.flatnonzero(legal_rows), a[legal_rows]].all()
+    # other network shapes are refused, not silently mis-computed
+    assert L.lib.azul_policy_forward(p(obs), p(mask), p(w1t), p(b1), p(w2c), p(net.critic_linear2.bias), p(w2a_t), p(net.actor_linear2.bias),
+                                     136, 128, 180, 77, 0, None, 0, n, p(value), p(action), p(logp), p(ent), None, None) != 0

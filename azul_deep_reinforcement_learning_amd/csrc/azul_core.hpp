@@ -56,7 +56,7 @@ struct Rng {
     u32 *gmt;       // this game's 624 words in global memory
     u32 *lds;       // this wave's 624-word LDS window (staged whole when the stream is opened)
     u32 pos;        // CPython's `index` (0..624)
-    u32 dirty;      // LDS state differs from global memory (a twist happened)
+    u32 dirty;      // bit 0: LDS state differs from global memory (a twist happened); bit 1: state not staged into LDS yet
     u32 wbase;      // first word held by `win`
     u32 wend;       // one past the last word `win` can serve (0: no window loaded)
     u64 margin;     // factory-draw disagreement window (new_round); AZ_DRAW_MARGIN unless a test widens it
@@ -72,10 +72,11 @@ AZ_FN vu32 temper_v(vu32 y)
     return y;
 }
 
-AZ_FN void rng_open(Rng &r, u32 *gmt, u32 *lds, u32 pos)
+AZ_FN void rng_stage(Rng &r)
 {
-    r.gmt = gmt; r.lds = lds; r.pos = pos; r.dirty = 0; r.wbase = 0; r.wend = 0; r.win = splat(0u); r.margin = AZ_DRAW_MARGIN;
     // ten coalesced 256-byte loads, all in flight before the first LDS write (one memory latency, not ten)
+    const u32 *gmt = r.gmt;
+    u32 *lds = r.lds;
     vu32 l = lane();
     vu32 w0 = ld_u32(gmt, l, l < 64u), w1 = ld_u32(gmt, l + 64u, l < 64u), w2 = ld_u32(gmt, l + 128u, l < 64u),
          w3 = ld_u32(gmt, l + 192u, l < 64u), w4 = ld_u32(gmt, l + 256u, l < 64u), w5 = ld_u32(gmt, l + 320u, l < 64u),
@@ -86,6 +87,20 @@ AZ_FN void rng_open(Rng &r, u32 *gmt, u32 *lds, u32 pos)
     lds_st(lds, l + 384u, w6, l < 64u); lds_st(lds, l + 448u, w7, l < 64u); lds_st(lds, l + 512u, w8, l < 64u);
     lds_st(lds, l + 576u, w9, l < 48u);
     lds_fence();
+    r.dirty &= ~2u;
+}
+
+AZ_FN void rng_open(Rng &r, u32 *gmt, u32 *lds, u32 pos)
+{
+    r.gmt = gmt; r.lds = lds; r.pos = pos; r.dirty = 0; r.wbase = 0; r.wend = 0; r.win = splat(0u); r.margin = AZ_DRAW_MARGIN;
+    rng_stage(r);
+}
+
+// Like rng_open, but the 2.5 KB state is only fetched when the first random word is asked for: most single env steps
+// (everything but a round rollover, an episode reset or an opponent's move) never draw.
+AZ_FN void rng_attach(Rng &r, u32 *gmt, u32 *lds, u32 pos)
+{
+    r.gmt = gmt; r.lds = lds; r.pos = pos; r.dirty = 2u; r.wbase = 0; r.wend = 0; r.win = splat(0u); r.margin = AZ_DRAW_MARGIN;
 }
 
 AZ_FN void rng_twist(Rng &r)
@@ -114,6 +129,7 @@ AZ_FN void rng_twist(Rng &r)
 
 AZ_FN void rng_refill(Rng &r)
 {
+    if (AZ_UNLIKELY(r.dirty & 2u)) rng_stage(r);
     if (r.pos >= 624u) rng_twist(r);
     r.wbase = r.pos;
     r.wend = r.pos + 64u < 624u ? r.pos + 64u : 624u;
@@ -155,7 +171,7 @@ AZ_FN u32 rng_below(Rng &r, u32 n, u32 bits)
 
 AZ_FN void rng_close(Rng &r, u32 *pos_out)
 {
-    if (r.dirty) {
+    if (r.dirty & 1u) {
 #if AZ_DEVICE_BUILD
 #pragma unroll 1
 #endif
@@ -650,6 +666,7 @@ AZ_FN u32 new_round(Game &g, Rng &r)
     // differ from the exact one only if |K*T - P_c*2^53| <= 21.1 * T <= 5381.  P_c * 2^53 is a multiple of 2^32: when
     // no multiple of 2^32 lies within AZ_DRAW_MARGIN = 8192 of K*T the integer comparison IS CPython's answer;
     // otherwise (about 4 draws in a million) the draw is decided by the literal fp64 computation below.
+    if (AZ_UNLIKELY(r.dirty & 2u)) rng_stage(r);                 // lazily attached stream: the words are read from LDS below
     const bool batched = r.pos + 40u <= 624u;
     vu32 klo = splat(0u), khi = splat(0u);
     if (batched) {

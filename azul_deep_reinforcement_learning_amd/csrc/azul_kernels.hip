@@ -97,9 +97,10 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
     u32 st = ST_OK;
     if (act && a.op != OP_QUERY) {
         Rng r;
-        r.gmt = b.mt + (size_t)gi * 624u; r.lds = mt_lds; r.pos = b.mtpos[gi]; r.dirty = 0; r.wbase = 0; r.wend = 0; r.win = 0u; r.margin = b.draw_margin;
         const bool use_rng = op_needs_rng(a.op);
-        if (use_rng) { rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]); r.margin = b.draw_margin; }
+        // the 2.5 KB MT19937 state is staged into LDS lazily, by the first draw (most single steps never draw)
+        rng_attach(r, b.mt + (size_t)gi * 624u, mt_lds, use_rng ? b.mtpos[gi] : 0u);
+        r.margin = b.draw_margin;
         bool dirty_state = true;
         switch (a.op) {
         case OP_INIT:

@@ -160,7 +160,7 @@ int hc_step(uint8_t *rec, int action, int first_player, int tile_pool, u32 *mt, 
     LaneConst k; lane_consts(k);
     Game g; game_load(g, rec);
     if (tile_pool == POOL_LID) game_prime<true>(g, k); else game_prime<false>(g, k);
-    Rng r; rng_open(r, mt, lds, *pos);
+    Rng r; rng_attach(r, mt, lds, *pos);
     u32 st = BY_POOL(tile_pool, checked_step<true>(g, k, r, action), checked_step<false>(g, k, r, action));
     if (st != ST_ILLEGAL_MOVE && st != ST_GAME_ENDED && st != ST_BAD_ACTION) game_store(g, rec);
     rng_close(r, pos);
@@ -174,7 +174,7 @@ int hc_runner_step(uint8_t *rec, int action, int first_player, int tile_pool, u3
     LaneConst k; lane_consts(k);
     Game g; game_load(g, rec);
     if (tile_pool == POOL_LID) game_prime<true>(g, k); else game_prime<false>(g, k);
-    Rng r; rng_open(r, mt, lds, *pos);
+    Rng r; rng_attach(r, mt, lds, *pos);
     i32 rew = 0; u32 dn = 0;
     u32 st = BY_POOL(tile_pool, runner_step<true>(g, k, r, table(), action, rew, dn), runner_step<false>(g, k, r, table(), action, rew, dn));
     if (st != ST_ILLEGAL_MOVE && st != ST_GAME_ENDED && st != ST_BAD_ACTION) game_store(g, rec);
@@ -188,7 +188,7 @@ int hc_runner_reset(uint8_t *rec, int first_player, int tile_pool, u32 *mt, u32 
     static u32 lds[624];
     LaneConst k; lane_consts(k);
     Game g; memset(&g, 0, sizeof(g));
-    Rng r; rng_open(r, mt, lds, *pos);
+    Rng r; rng_attach(r, mt, lds, *pos);
     u32 st = BY_POOL(tile_pool, episode_reset<true>(g, (u32)first_player, r), episode_reset<false>(g, (u32)first_player, r));
     if (!st && !ctor_only) st = BY_POOL(tile_pool, runner_opponent_loop<true>(g, k, r, table(), true), runner_opponent_loop<false>(g, k, r, table(), true));
     game_store(g, rec);
@@ -201,7 +201,7 @@ int hc_random_action(const uint8_t *rec, u32 *mt, u32 *pos)
     static u32 lds[624];
     LaneConst k; lane_consts(k);
     Game g; game_load(g, rec);
-    Rng r; rng_open(r, mt, lds, *pos);
+    Rng r; rng_attach(r, mt, lds, *pos);
     Mask m; legal_mask(g, k, m);
     u32 code;
     i32 a = random_agent(m, r, table(), k, code);
@@ -213,7 +213,7 @@ int hc_init(uint8_t *rec, int first_player, int tile_pool, u32 *mt, u32 *pos)
 {
     static u32 lds[624];
     Game g; game_load(g, rec);
-    Rng r; rng_open(r, mt, lds, *pos);
+    Rng r; rng_attach(r, mt, lds, *pos);
     if (tile_pool == POOL_LID) game_ctor<true>(g, (u32)first_player, r); else game_ctor<false>(g, (u32)first_player, r);
     game_store(g, rec);
     rng_close(r, pos);
@@ -224,7 +224,7 @@ int hc_new_round(uint8_t *rec, int tile_pool, u32 *mt, u32 *pos)
 {
     static u32 lds[624];
     Game g; game_load(g, rec);
-    Rng r; rng_open(r, mt, lds, *pos);
+    Rng r; rng_attach(r, mt, lds, *pos);
     u32 st = BY_POOL(tile_pool, new_round<true>(g, r), new_round<false>(g, r));
     game_store(g, rec);
     rng_close(r, pos);
@@ -253,7 +253,7 @@ int hc_sample_mask(const uint8_t *mask180, u32 *mt, u32 *pos)
     m.b1 = sel(ld_u8(mask180, l + 64u, l < 64u) != 0u, splat(1u), splat(0u));
     m.b2 = sel(ld_u8(mask180, l + 128u, l < 52u) != 0u, splat(1u), splat(0u));
     m.m0 = ballot(m.b0 != 0u); m.m1 = ballot(m.b1 != 0u); m.m2 = ballot(m.b2 != 0u);
-    Rng r; rng_open(r, mt, lds, *pos);
+    Rng r; rng_attach(r, mt, lds, *pos);
     LaneConst k; lane_consts(k);
     u32 code;
     i32 a = random_agent(m, r, table(), k, code);

@@ -11,3 +11,5 @@ from .azul import Azul, IllegalMove, GameEnded  # noqa: F401
 from .game_runner import GameRunner, RandomAgent, check_all_valid  # noqa: F401
 from .policy import BatchedActorCritic, IllegalMask  # noqa: F401
 from .rollout import PolicyRollout  # noqa: F401
+from .learner import A2CLearner  # noqa: F401
+from .training import BatchedTrainer  # noqa: F401

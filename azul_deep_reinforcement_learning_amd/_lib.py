@@ -33,6 +33,8 @@ SIGNATURES = {
     "azul_batch_set_state": (_i, [_vp, _i, _i, _vp, _vp]),
     "azul_batch_get_rng": (_i, [_vp, _i, _vp, _vp, _vp]),
     "azul_batch_set_rng": (_i, [_vp, _i, _vp, _u32, _vp]),
+    "azul_batch_get_rng_range": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "azul_batch_set_rng_range": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "azul_batch_seed": (_i, [_vp, _u64, _vp, _vp]),
     "azul_batch_init": (_i, [_vp, _vp, _vp]),
     "azul_batch_new_round": (_i, [_vp, _vp, _vp, _vp]),

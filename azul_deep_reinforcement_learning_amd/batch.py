@@ -105,6 +105,40 @@ class BatchedAzul:
         mt = np.ascontiguousarray(mt, dtype=np.uint32)
         L.check(L.lib.azul_batch_set_rng(self._h, game, mt.ctypes.data_as(C.c_void_p), int(pos), self._stream()))
 
+    def get_rng_range(self, first=0, count=None):
+        """(mt [count][624] uint32, pos [count] uint32): every game's random.getstate() in one copy (checkpoints)."""
+        count = self.n - first if count is None else count
+        mt = np.zeros((count, 624), dtype=np.uint32)
+        pos = np.zeros(count, dtype=np.uint32)
+        L.check(L.lib.azul_batch_get_rng_range(self._h, first, count, mt.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p), self._stream()))
+        return mt, pos
+
+    def set_rng_range(self, mt, pos, first=0):
+        mt = np.ascontiguousarray(mt, dtype=np.uint32).reshape(-1, 624)
+        pos = np.ascontiguousarray(pos, dtype=np.uint32).reshape(-1)
+        if len(mt) != len(pos):
+            raise ValueError("mt and pos disagree on the number of games")
+        L.check(L.lib.azul_batch_set_rng_range(self._h, first, len(pos), mt.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p), self._stream()))
+
+    def export_json(self, path=None, first=0, count=None):
+        """Games as a list of dicts in the reference's JSON schema (azul.py:90-117) + the fields the schema lacks (`x_*`)."""
+        from .records import record_to_json
+        data = [record_to_json(r) for r in self.get_records(first, count)]
+        if path is not None:
+            import json
+            with open(path, "w") as fh:
+                json.dump(data, fh)
+        return data
+
+    def import_json(self, src, first=0):
+        """`src`: a path or the list export_json returns; games first.. are overwritten (RNG streams are left alone)."""
+        from .records import json_to_record
+        if isinstance(src, (str, bytes)):
+            import json
+            with open(src) as fh:
+                src = json.load(fh)
+        self.set_records(np.array([json_to_record(d) for d in src], dtype=RECORD_DTYPE), first)
+
     # -- Azul methods, batched --------------------------------------------------------------------
     def init(self, active=None):
         L.check(L.lib.azul_batch_init(self._h, _ptr(self._dev(active, torch.uint8)), self._stream()))

@@ -509,6 +509,29 @@ int azul_batch_set_rng(azul_batch_t *b, int game, const uint32_t *mt_host, uint3
     return AZUL_SUCCESS;
 }
 
+int azul_batch_get_rng_range(azul_batch_t *b, int first, int count, uint32_t *mt_host, uint32_t *pos_host, void *stream)
+{
+    if (int rc = check_range(b, first, count)) return rc;
+    if (count == 0) return AZUL_SUCCESS;
+    if (mt_host) HIP_TRY(hipMemcpyAsync(mt_host, b->d.mt + (size_t)first * 624, (size_t)count * 624 * sizeof(u32), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (pos_host) HIP_TRY(hipMemcpyAsync(pos_host, b->d.mtpos + first, (size_t)count * sizeof(u32), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return AZUL_SUCCESS;
+}
+
+int azul_batch_set_rng_range(azul_batch_t *b, int first, int count, const uint32_t *mt_host, const uint32_t *pos_host, void *stream)
+{
+    if (int rc = check_range(b, first, count)) return rc;
+    if (count == 0) return AZUL_SUCCESS;
+    if (!mt_host || !pos_host) return fail(AZUL_ERR_INVALID, "azul_batch_set_rng_range: need 624 words and an index per game");
+    for (int g = 0; g < count; g++)
+        if (pos_host[g] > 624u) return fail(AZUL_ERR_INVALID, "azul_batch_set_rng_range: index outside 0..624");
+    HIP_TRY(hipMemcpyAsync(b->d.mt + (size_t)first * 624, mt_host, (size_t)count * 624 * sizeof(u32), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(b->d.mtpos + first, pos_host, (size_t)count * sizeof(u32), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return AZUL_SUCCESS;
+}
+
 int azul_batch_seed(azul_batch_t *b, uint64_t seed_base, const uint64_t *seeds_host, void *stream)
 {
     if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");

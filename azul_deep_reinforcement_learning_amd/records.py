@@ -46,3 +46,53 @@ def walls_to_bits(walls):
 def bits_to_walls(bits):
     b = np.asarray(bits, dtype=np.uint32).reshape(2, 1)
     return (((b >> _WALL_SHIFTS) & 1) != 0).reshape(2, 5, 5)
+
+
+def record_to_json(rec):
+    """One 128-byte record -> the dict Azul.export_JSON writes (azul.py:106-117: ten keys) plus `x_*` keys for what the
+    reference's schema leaves out (tile pools, end_of_game flag, per-game statistics, GameRunner's score/move counters)."""
+    cur, nfp, eog = unpack_flags(rec["flags"])
+    d = {
+        "game_board_displays": rec["displays"].astype(int).tolist(),
+        "game_board_center": rec["center"].astype(int).tolist(),
+        "pattern_lines": rec["pattern_lines"].astype(int).tolist(),
+        "walls": bits_to_walls(rec["walls"]).astype(int).tolist(),
+        "floors": rec["floors"].astype(int).tolist(),
+        "score": rec["score"].astype(int).tolist(),
+        "current_player": int(cur),
+        "next_first_player": int(nfp),
+        "players": 2,
+        "turn_counter": int(rec["turn_counter"]),
+        "x_end_of_game": bool(eog),
+        "x_box_tiles": rec["box"].astype(int).tolist(),
+        "x_lid_tiles": rec["lid"].astype(int).tolist(),
+        "x_first_player_stats": rec["first_player_stats"].astype(int).tolist(),
+        "x_floor_penalty": rec["floor_penalty"].astype(int).tolist(),
+        "x_max_combo": rec["max_combo"].astype(int).tolist(),
+        "x_completed_lines": rec["completed_lines"].astype(int).tolist(),
+        "x_player_score": int(rec["player_score"]),
+        "x_move_counter": int(rec["move_counter"]),
+    }
+    return d
+
+
+def json_to_record(d):
+    """Inverse of record_to_json; a plain reference file (no `x_*` keys) loads with empty pools / zero statistics, like
+    Azul.import_JSON (azul.py:90-104), which restores exactly those ten keys."""
+    if int(d.get("players", 2)) != 2:
+        raise ValueError("the MI355X kernels play two-player Azul")
+    rec = np.zeros((), dtype=RECORD_DTYPE)
+    rec["displays"] = np.asarray(d["game_board_displays"])
+    rec["center"] = np.asarray(d["game_board_center"])
+    rec["pattern_lines"] = np.asarray(d["pattern_lines"])
+    rec["walls"] = walls_to_bits(np.asarray(d["walls"]))
+    rec["floors"] = np.asarray(d["floors"])
+    rec["score"] = np.asarray(d["score"])
+    rec["flags"] = pack_flags(d["current_player"], d["next_first_player"], d.get("x_end_of_game", False))
+    rec["turn_counter"] = d["turn_counter"]
+    for key, field in (("x_box_tiles", "box"), ("x_lid_tiles", "lid"), ("x_first_player_stats", "first_player_stats"),
+                       ("x_floor_penalty", "floor_penalty"), ("x_max_combo", "max_combo"), ("x_completed_lines", "completed_lines"),
+                       ("x_player_score", "player_score"), ("x_move_counter", "move_counter")):
+        if key in d:
+            rec[field] = np.asarray(d[key])
+    return rec

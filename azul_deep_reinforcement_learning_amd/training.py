@@ -1,0 +1,134 @@
+"""Batched ``NNRunner.train`` (azulnet/nn_runner.py:49-84) with the on-disk surface either side of the path (row N3):
+the CSV training log the reference intends to write, checkpoints, and resumable runs.
+
+One "batch" of the reference is `batch_size` sequential episodes followed by one `Agent.update`; here it is one rollout
+window of `window` agent steps for all `n_games` concurrent games (policy vs the RandomAgent opponent inside the env
+step) followed by one `A2CLearner.update` on the steps whose episode finished inside the window.
+
+CSV (nn_runner.py:51-54, 79-82): header ``batch`` + the five agent statistics keys (agent.py:13) + the ten game statistics
+keys (game_runner.py:12); one row per logged batch with the batch's means.  The reference's own writer dereferences
+``self.game_statistics``, which NNRunner does not have (it lives on the GameRunner), so that branch raises as soon as a
+net name is given; the columns and their order here are the ones that code spells out.
+  reward       mean over the batch of the per-episode reward sum (nn_runner.py:63) -- here: the window's total shaped
+               reward / episodes finished in the window
+  *_loss       the update's loss terms (agent.py:51-57)
+  game keys    means over the episodes finished in the window of Azul.get_statistics (azul.py:314-315), accumulated on
+               the device by the env step (win_percent etc. are per-episode 0/1 or counts, like the reference's buffers)
+
+Checkpoints (`save_checkpoint` / `load_checkpoint`): the policy's state_dict (the reference's parameter names: loads into
+`azulnet.model.ActorCritic` as is), the Adam state, every game's 128-byte record and CPython RNG state, the Philox step
+counters and the batch index -- a restored run replays the next window bit for bit.
+"""
+import csv
+import os
+
+import numpy as np
+import torch
+
+from .learner import A2CLearner, complete_episode_samples
+from .records import STAT_KEYS
+from .rollout import PolicyRollout
+
+AGENT_STAT_KEYS = ("reward", "actor_loss", "critic_loss", "entropy_loss", "ac_loss")          # agent.py:13
+
+
+class BatchedTrainer:
+    def __init__(self, policy, n_games=4096, window=32, parts=1, learning_rate=3e-4, gamma=0.99, seed_base=0, sample_seed=0x5EED,
+                 rules={"first_player": "Random", "tile_pool": "Lid"}, device=None, use_graph=True, results_dir="results"):
+        self.rollout = PolicyRollout(policy, n_games=n_games, parts=parts, rules=rules, seed_base=seed_base, device=device, window=window,
+                                     use_graph=use_graph, sample_seed=sample_seed, opponent="random")
+        self.learner = A2CLearner(self.rollout.policy, learning_rate=learning_rate, gamma=gamma)
+        self.gamma = gamma
+        self.results_dir = results_dir
+        self.batch = 0
+        self._stat_base = self._stat_totals()
+        self.history = {k: [] for k in ("batch",) + AGENT_STAT_KEYS + STAT_KEYS}
+
+    # ---- statistics ----------------------------------------------------------------------------------
+    def _stat_totals(self):
+        ep, sums = 0, np.zeros(len(STAT_KEYS))
+        for env in self.rollout.envs:
+            c = env.counters()
+            ep += int(c["episodes"].sum())
+            sums += np.asarray(c["stat_sums"]).reshape(-1, len(STAT_KEYS)).sum(axis=0)
+        return ep, sums
+
+    def _game_statistics(self):
+        """Means over the episodes finished since the last call (GameStatistics.get_stats, game_runner.py:17-22)."""
+        ep, sums = self._stat_totals()
+        ep0, sums0 = self._stat_base
+        self._stat_base = (ep, sums)
+        n = ep - ep0
+        return n, {k: (float(sums[i] - sums0[i]) / n if n else float("nan")) for i, k in enumerate(STAT_KEYS)}
+
+    # ---- one batch -----------------------------------------------------------------------------------
+    def run_batch(self):
+        tr = self.rollout.run_window(self.gamma)
+        self.rollout.synchronize()
+        out = self.learner.update_from_windows(tr)
+        self.rollout.refresh_weights()
+        self.batch += 1
+        episodes, game = self._game_statistics()
+        total_reward = sum(float(part["reward"].sum()) for part in tr)
+        row = {"batch": self.batch, "reward": total_reward / episodes if episodes else float("nan")}
+        row.update({k: float(out[k]) for k in AGENT_STAT_KEYS[1:]})
+        row.update(game)
+        for k, v in row.items():
+            self.history[k].append(v)
+        return row
+
+    def train(self, net_name=None, batches=1000, log_every=None, checkpoint_every=1000):
+        """nn_runner.py:49-84: `batches` updates; with a `net_name` the CSV log and the checkpoints go to results_dir."""
+        log_every = max(1, batches // 1000) if log_every is None else log_every             # nn_runner.py:79
+        path = None
+        if net_name is not None:
+            os.makedirs(self.results_dir, exist_ok=True)
+            path = os.path.join(self.results_dir, net_name + ".csv")
+            if self.batch == 0 or not os.path.exists(path):
+                with open(path, mode="w", newline="") as fh:                                # nn_runner.py:51-54
+                    csv.writer(fh, delimiter=",", quotechar='"', quoting=csv.QUOTE_MINIMAL).writerow(
+                        ["batch"] + list(AGENT_STAT_KEYS) + list(STAT_KEYS))
+        last = None
+        for _ in range(batches):
+            last = self.run_batch()
+            if path is not None and self.batch % log_every == 0:
+                with open(path, mode="a+", newline="") as fh:                               # nn_runner.py:80-82
+                    csv.writer(fh, delimiter=",", quotechar='"', quoting=csv.QUOTE_MINIMAL).writerow(
+                        [last["batch"]] + [last[k] for k in AGENT_STAT_KEYS] + [last[k] for k in STAT_KEYS])
+            if net_name is not None and self.batch % checkpoint_every == 0:                # nn_runner.py:83-84
+                self.save_checkpoint(os.path.join(self.results_dir, net_name + ".pt"))
+        return last
+
+    # ---- checkpoints ---------------------------------------------------------------------------------
+    def save_checkpoint(self, path):
+        ro = self.rollout
+        ro.synchronize()
+        envs = []
+        for p, env in enumerate(ro.envs):
+            mt, pos = env.get_rng_range()
+            envs.append({"records": env.get_records(), "mt": mt, "pos": pos,
+                         "counter": ro.work[p]["counter"].cpu().numpy().copy(),
+                         "next_obs": ro.traj[p]["obs"][ro.T].cpu(), "next_mask": ro.traj[p]["mask"][ro.T].cpu(),
+                         "next_player": ro.traj[p]["player"][ro.T].cpu()})
+        torch.save({"policy": ro.policy.state_dict(), "optimizer": self.learner.optimizer.state_dict(), "envs": envs,
+                    "batch": self.batch, "n_games": ro.n, "parts": ro.parts, "window": ro.T}, path)
+
+    def load_checkpoint(self, path):
+        ro = self.rollout
+        ck = torch.load(path, map_location=ro.device, weights_only=False)
+        if (ck["n_games"], ck["parts"], ck["window"]) != (ro.n, ro.parts, ro.T):
+            raise ValueError("checkpoint was written for n_games=%d parts=%d window=%d" % (ck["n_games"], ck["parts"], ck["window"]))
+        ro.synchronize()
+        ro.policy.load_state_dict(ck["policy"])
+        self.learner.optimizer.load_state_dict(ck["optimizer"])
+        ro.refresh_weights()
+        for p, (env, e) in enumerate(zip(ro.envs, ck["envs"])):
+            env.set_records(e["records"])
+            env.set_rng_range(e["mt"], e["pos"])
+            ro.work[p]["counter"].copy_(torch.from_numpy(e["counter"]))
+            ro.traj[p]["obs"][ro.T].copy_(e["next_obs"])
+            ro.traj[p]["mask"][ro.T].copy_(e["next_mask"])
+            ro.traj[p]["player"][ro.T].copy_(e["next_player"])
+        torch.cuda.synchronize(ro.device)
+        self.batch = int(ck["batch"])
+        self._stat_base = self._stat_totals()

@@ -107,6 +107,9 @@ int azul_batch_set_state(azul_batch_t *b, int first, int count, const void *reco
 /* random.getstate() / random.setstate() of one game's stream: 624 words + index */
 int azul_batch_get_rng(azul_batch_t *b, int game, uint32_t *mt_host, uint32_t *pos_host, void *stream);
 int azul_batch_set_rng(azul_batch_t *b, int game, const uint32_t *mt_host, uint32_t pos, void *stream);
+/* the same for games first .. first+count-1 (checkpoints): mt_host [count][624], pos_host [count] */
+int azul_batch_get_rng_range(azul_batch_t *b, int first, int count, uint32_t *mt_host, uint32_t *pos_host, void *stream);
+int azul_batch_set_rng_range(azul_batch_t *b, int first, int count, const uint32_t *mt_host, const uint32_t *pos_host, void *stream);
 /* random.seed(int) per game (CPython init_by_array): seed[g] = seeds_host[g], or seed_base + g when seeds_host is NULL */
 int azul_batch_seed(azul_batch_t *b, uint64_t seed_base, const uint64_t *seeds_host, void *stream);
 

@@ -31,7 +31,7 @@ def _p(t):
 
 class PolicyRollout:
     def __init__(self, policy, n_games=4096, parts=1, rules={"first_player": "Random", "tile_pool": "Lid"}, seed_base=0,
-                 device=None, window=32, use_graph=True, record_obs=True, fused_head=True, sample_seed=0x5EED, opponent=None, fused_mlp=True):
+                 device=None, window=32, use_graph=True, fused_head=True, sample_seed=0x5EED, opponent=None, fused_mlp=True):
         """opponent=None: the policy moves for both players (flat self-play, one record per env move).
         opponent="random": the reference's training setup -- the policy is player 1 of GameRunner, the opponent a RandomAgent
         inside the env step (game_runner.py:43-47); one record per AGENT step, observations from the agent's perspective."""
@@ -41,7 +41,6 @@ class PolicyRollout:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.policy = policy.to(self.device).eval()
         self.n, self.parts, self.h, self.T = n_games, parts, n_games // parts, window
-        self.record_obs = record_obs          # kept for API compatibility: observations always live in the trajectory slots
         self.fused_head = fused_head
         # the one-launch forward (azul_policy_forward) is compiled for the reference's ActorCritic(136, 180, hidden 180)
         self.fused_mlp = bool(fused_mlp and fused_head and policy.critic_linear1.in_features == L.OBS_SIZE and

@@ -52,7 +52,7 @@ def cpu_baseline(games, seed_base):
     except Exception:
         pass
     cores = int(os.environ.get("AZUL_CPU_THREADS", min(cores, 16)))     # a 1-GPU box shares 16 host cores
-    streams, steps = min(games, 1024), 6000
+    streams, steps = min(games, 1024), 16000            # ~16 M moves: 15-25 s of CPU work, ~1.5 s wall on 16 threads
     oz.bench_selfplay(seed_base, min(streams, 64), 200, cores)           # warm the pages
     t0 = time.perf_counter()
     moves, _ = oz.bench_selfplay(seed_base, streams, steps, cores)

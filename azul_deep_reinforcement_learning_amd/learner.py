@@ -43,8 +43,19 @@ class A2CLearner:
         `weight` [n] (0/1) drops samples without changing shapes; `n_total` is the divisor (default: the local count)."""
         pol = self.policy
         legal = mask.bool()
-        values = pol.forward_critic(obs).squeeze(1)
-        _, logp = pol.forward_actor(obs, legal)
+        if hasattr(pol, "critic_linear1") and hasattr(pol, "actor_linear1"):
+            # same arithmetic as forward_critic / forward_actor (model.py:22-41) with both first layers in ONE GEMM (and one
+            # weight-gradient GEMM in the backward pass): autograd splits the concatenated gradient back onto the two modules
+            H = pol.critic_linear1.out_features
+            w1 = torch.cat([pol.critic_linear1.weight, pol.actor_linear1.weight], dim=0)
+            b1 = torch.cat([pol.critic_linear1.bias, pol.actor_linear1.bias])
+            hidden = F.relu(F.linear(obs, w1, b1))
+            values = pol.critic_linear2(hidden[:, :H]).squeeze(1)
+            logits = pol.actor_linear2(hidden[:, H:]).masked_fill(~legal, float("-inf"))
+            logp = F.log_softmax(logits, dim=1)
+        else:
+            values = pol.forward_critic(obs).squeeze(1)
+            _, logp = pol.forward_actor(obs, legal)
         log_prob = logp.gather(1, action.long().clamp(min=0).unsqueeze(1)).squeeze(1)                 # nn_runner.py:32
         entropy = -(torch.where(legal, logp, torch.zeros_like(logp)).sum(dim=1) / legal.sum(dim=1).clamp(min=1))   # :36-40
         advantage = qvals.to(values.dtype) - values
@@ -57,8 +68,13 @@ class A2CLearner:
         return actor_loss, critic_loss, entropy_loss, ac_loss
 
     def update(self, obs, mask, action, qvals, weight=None):
-        """One optimiser step on the given samples (this rank's share when distributed).  Returns the loss terms (global means)."""
-        n_local = torch.as_tensor(float(obs.shape[0]) if weight is None else weight.sum(), dtype=torch.float32, device=obs.device).reshape(1)
+        """One optimiser step on the given samples (this rank's share when distributed).  Returns the loss terms (global means).
+        Rows with weight 0 are compacted away first (the network is not evaluated on them)."""
+        if weight is not None:
+            idx = torch.nonzero(weight > 0).squeeze(1)
+            obs, mask, action, qvals = obs.index_select(0, idx), mask.index_select(0, idx), action.index_select(0, idx), qvals.index_select(0, idx)
+            weight = None
+        n_local = torch.full((1,), float(obs.shape[0]), dtype=torch.float32, device=obs.device)
         n_total = n_local.clone()
         if self.distributed:
             dist.all_reduce(n_total, group=self.group)
@@ -87,14 +103,16 @@ class A2CLearner:
     def update_from_windows(self, trajectories, complete_only=True):
         """`trajectories`: the per-part dicts PolicyRollout.run_window returns (opponent="random": every record is one agent
         step).  Uses the steps whose episode finished inside the window (exact Monte-Carlo returns, the reference's qvals)."""
-        obs, mask, action, ret, w = [], [], [], [], []
+        obs, mask, action, ret = [], [], [], []
         for tr in trajectories:
             T = tr["action"].shape[0]
             keep = complete_episode_samples(tr["done"]) if complete_only else torch.ones_like(tr["done"], dtype=torch.bool)
             keep = keep & (tr["action"] >= 0)
-            obs.append(tr["obs"][:T].reshape(-1, tr["obs"].shape[-1]))
-            mask.append(tr["mask"][:T].reshape(-1, tr["mask"].shape[-1]))
-            action.append(tr["action"].reshape(-1))
-            ret.append(tr["returns"].reshape(-1))
-            w.append(keep.reshape(-1))
-        return self.update(torch.cat(obs), torch.cat(mask), torch.cat(action), torch.cat(ret), torch.cat(w).to(torch.float32))
+            idx = torch.nonzero(keep.reshape(-1)).squeeze(1)               # compact per part: the big buffers are read once
+            obs.append(tr["obs"][:T].reshape(-1, tr["obs"].shape[-1]).index_select(0, idx))
+            mask.append(tr["mask"][:T].reshape(-1, tr["mask"].shape[-1]).index_select(0, idx))
+            action.append(tr["action"].reshape(-1).index_select(0, idx))
+            ret.append(tr["returns"].reshape(-1).index_select(0, idx))
+        one = len(trajectories) == 1
+        return self.update(obs[0] if one else torch.cat(obs), mask[0] if one else torch.cat(mask),
+                           action[0] if one else torch.cat(action), ret[0] if one else torch.cat(ret))

@@ -1,6 +1,20 @@
-import re,collections,sys
-kern=sys.argv[1] if len(sys.argv)>1 else '_Z20azul_selfplay_kernelILb1E'
-s=open('/tmp/asm/kg.s').read()
+#!/usr/bin/env python3
+"""Static attribution of a kernel's ISA to source functions (via -g line info): which device function owns how many scalar /
+vector instructions.  Usage: tools/isa_attribution.py [mangled-kernel-prefix]   (compiles csrc/azul_kernels.hip with -g -S)."""
+import collections
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+kern=sys.argv[1] if len(sys.argv)>1 else '_Z20azul_selfplay_kernelILb1ELi1E'
+asm = os.path.join(ROOT, "gpurun_out", "azul_kernels_g.s")
+os.makedirs(os.path.dirname(asm), exist_ok=True)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-g", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                       "-Wno-unused-value", "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", asm,
+                       os.path.join(ROOT, "azul_deep_reinforcement_learning_amd", "csrc", "azul_kernels.hip")], stderr=subprocess.DEVNULL)
+s=open(asm).read()
 files={}
 for m in re.finditer(r'\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', s):
     files[int(m.group(1))]=(m.group(3) or m.group(2)).split('/')[-1]
@@ -16,7 +30,7 @@ for l in body:
     cnt[cur]+=1
     if op.startswith('s_'): scnt[cur]+=1
     if op.startswith('v_'): vcnt[cur]+=1
-src={f:open('/root/repo/azul_deep_reinforcement_learning_amd/csrc/'+f).read().split('\n') for f in ('azul_core.hpp','azul_kernels.hip','azul_wave.hpp')}
+src={f:open('/root/repo/azul_deep_reinforcement_learning_amd/csrc/'+f).read().split('\n') for f in ('azul_core.hpp','azul_kernels.hip','azul_wave.hpp','azul_policy.hpp','azul_tables.hpp')}
 print("total", sum(cnt.values()), "scalar", sum(scnt.values()), "vector", sum(vcnt.values()))
 # group by function: find enclosing function name by scanning backwards for 'AZ_FN'
 def func_of(f,ln):

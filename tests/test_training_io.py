@@ -75,14 +75,14 @@ def test_batched_json_and_rng_io(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_graph", [True, False])
-def test_trainer_csv_log_and_resume(tmp_path, golden_dir, use_graph):
+@pytest.mark.parametrize("use_graph,parts", [(True, 1), (False, 2)])
+def test_trainer_csv_log_and_resume(tmp_path, golden_dir, use_graph, parts):
     import torch
     from azul_deep_reinforcement_learning_amd import BatchedActorCritic
     from azul_deep_reinforcement_learning_amd.training import BatchedTrainer, AGENT_STAT_KEYS
     from azul_deep_reinforcement_learning_amd.records import STAT_KEYS
     torch.manual_seed(0)
-    kw = dict(n_games=256, window=40, use_graph=use_graph, results_dir=str(tmp_path))
+    kw = dict(n_games=256, window=40, use_graph=use_graph, parts=parts, results_dir=str(tmp_path))
     tr = BatchedTrainer(BatchedActorCritic(136, 180, 180), seed_base=10, **kw)
     last = tr.train(net_name="blue", batches=3, log_every=1, checkpoint_every=3)
     rows = list(csv.reader(open(os.path.join(str(tmp_path), "blue.csv"))))
@@ -104,15 +104,16 @@ def test_trainer_csv_log_and_resume(tmp_path, golden_dir, use_graph):
     # resume: a fresh trainer (other seeds, other weights) restored from the file replays the NEXT window bit for bit
     nxt = tr.rollout.run_window()
     tr.rollout.synchronize()
-    want = {k: v.clone() for k, v in nxt[0].items()}
+    want = [{k: v.clone() for k, v in part.items()} for part in nxt]
     torch.manual_seed(123)
     tr2 = BatchedTrainer(BatchedActorCritic(136, 180, 180), seed_base=5000, sample_seed=0x5EED, **kw)
     tr2.load_checkpoint(ck)
     assert tr2.batch == 3
     got = tr2.rollout.run_window()
     tr2.rollout.synchronize()
-    for k in ("obs", "mask", "player", "action", "reward", "done", "value", "log_prob", "entropy", "returns"):
-        assert torch.equal(want[k], got[0][k]), k
+    for p in range(parts):
+        for k in ("obs", "mask", "player", "action", "reward", "done", "value", "log_prob", "entropy", "returns"):
+            assert torch.equal(want[p][k], got[p][k]), (p, k)
     # and training continues from there, appending to the same log
     tr2.train(net_name="blue", batches=1, log_every=1, checkpoint_every=1000)
     rows = list(csv.reader(open(os.path.join(str(tmp_path), "blue.csv"))))

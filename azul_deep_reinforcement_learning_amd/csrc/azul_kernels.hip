@@ -79,6 +79,82 @@ static __device__ __forceinline__ bool op_needs_rng(int op)
            op == OP_RUNNER_STEP || op == OP_RANDOM_ACTION || op == OP_SAMPLE_MASK || op == OP_POLICY_STEP || op == OP_AGENT_STEP;
 }
 
+// One env move of policy-driven self-play on a primed, register-resident game: Azul.step (azul.py:296-313) for the current
+// player, the shaped reward of game_runner.py:48-52 per move, done, statistics and the auto-reset of game_runner.py:76-82.
+// Shared by the per-call kernel (OP_POLICY_STEP) and the persistent policy-rollout kernel.
+template <bool LID>
+__device__ __forceinline__ u32 env_policy_step(Game &g, const LaneConst &k, Rng &r, const BatchDev &b, u32 gi, i32 av, i32 &rew, u32 &dn,
+                                               bool &dirty_state)
+{
+    rew = 0;
+    dn = 0;
+    u32 st = ST_OK;
+    bool stuck = false;
+    if (av < 0 && !g.eog) {                      // "no action": legitimate only when nothing is legal (hazard H3)
+        Mask m;
+        legal_mask(g, k, m);
+        stuck = mask_count(m) == 0u;
+    }
+    if (stuck) {
+        AZ_LANE0(b.stuck[gi] += 1u);
+        dn = 2u;
+        st = episode_reset<LID>(g, b.rules.first_player, r);
+        game_prime<LID>(g, k);
+        if (!st) st = ST_STUCK;
+        dirty_state = true;
+        return st;
+    }
+    st = checked_step<LID>(g, k, r, av);
+    dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION);
+    if (dirty_state) {
+        g.moves += 1u;
+        i32 phi = potential<LID>(g, k);
+        rew = phi - g.pscore;
+        g.pscore = phi;
+        dn = is_end_of_game(g) ? 1u : 0u;
+        if (dn && st == ST_OK) {
+            for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(b.stat_sum[(size_t)gi * 10 + q] += sv); }
+            AZ_LANE0(b.episodes[gi] += 1ull);
+            st = episode_reset<LID>(g, b.rules.first_player, r);
+            game_prime<LID>(g, k);
+        }
+    } else if (st == ST_GAME_ENDED) {
+        // a finished game handed in (e.g. after set_state): restart the slot, report done
+        dn = 1u;
+        st = episode_reset<LID>(g, b.rules.first_player, r);
+        game_prime<LID>(g, k);
+        dirty_state = true;
+    }
+    return st;
+}
+
+// One AGENT step of NNRunner.run_episode (nn_runner.py:24-29): GameRunner.step -- the agent's move, the opponent's RandomAgent
+// replies, the shaped reward, done (game_runner.py:43-55) -- and, when the episode ends, the GameRunner.reset() that opens the
+// next run_episode (nn_runner.py:20 -> game_runner.py:76-82, incl. the opponent's opening moves), so the observation / mask
+// taken afterwards are the next decision's.
+template <bool LID>
+__device__ __forceinline__ u32 env_agent_step(Game &g, const LaneConst &k, Rng &r, const SampleTab &tab, const BatchDev &b, u32 gi, i32 av,
+                                              i32 &rew, u32 &dn, bool &dirty_state)
+{
+    rew = 0;
+    dn = 0;
+    u32 st = runner_step<LID>(g, k, r, tab, av, rew, dn);
+    dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_BAD_ACTION);
+    if (st == ST_STUCK) { AZ_LANE0(b.stuck[gi] += 1u); dn = 2u; rew = 0; }       // hazard H3: nobody can move
+    else if (st == ST_GAME_ENDED) dn = 1u;       // a finished game handed in: restart the slot, report done
+    else if (st == ST_OK && dn) {
+        for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(b.stat_sum[(size_t)gi * 10 + q] += sv); }
+        AZ_LANE0(b.episodes[gi] += 1ull);
+    }
+    if (dirty_state && dn) {
+        u32 st2 = episode_reset<LID>(g, b.rules.first_player, r);
+        game_prime<LID>(g, k);
+        if (!st2) st2 = runner_opponent_loop<LID>(g, k, r, tab, true);
+        if (st == ST_OK) st = st2;
+    }
+    return st;
+}
+
 template <bool LID>
 __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
 {
@@ -153,73 +229,16 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
             dirty_state = false;
         } break;
         case OP_POLICY_STEP: {
-            // one env move of policy-driven self-play: Azul.step (azul.py:296-313) for the current player, the
-            // shaped reward of game_runner.py:48-52 per move, done, and the auto-reset of game_runner.py:76-82
             i32 rew = 0;
             u32 dn = 0;
-            const i32 av = a.actions[gi];
-            bool stuck = false;
-            if (av < 0 && !g.eog) {                      // "no action": legitimate only when nothing is legal (hazard H3)
-                Mask m;
-                legal_mask(g, k, m);
-                stuck = mask_count(m) == 0u;
-            }
-            if (stuck) {
-                AZ_LANE0(b.stuck[gi] += 1u);
-                dn = 2u;
-                st = episode_reset<LID>(g, b.rules.first_player, r);
-                game_prime<LID>(g, k);
-                if (!st) st = ST_STUCK;
-                dirty_state = true;
-                if (a.reward) AZ_LANE0(a.reward[gi] = 0);
-                if (a.done) AZ_LANE0(a.done[gi] = (uint8_t)dn);
-                break;
-            }
-            st = checked_step<LID>(g, k, r, av);
-            dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION);
-            if (dirty_state) {
-                g.moves += 1u;
-                i32 phi = potential<LID>(g, k);
-                rew = phi - g.pscore;
-                g.pscore = phi;
-                dn = is_end_of_game(g) ? 1u : 0u;
-                if (dn && st == ST_OK) {
-                    for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(b.stat_sum[(size_t)gi * 10 + q] += sv); }
-                    AZ_LANE0(b.episodes[gi] += 1ull);
-                    st = episode_reset<LID>(g, b.rules.first_player, r);
-                    game_prime<LID>(g, k);
-                }
-            } else if (st == ST_GAME_ENDED) {
-                // a finished game handed in (e.g. after set_state): restart the slot, report done
-                dn = 1u;
-                st = episode_reset<LID>(g, b.rules.first_player, r);
-                game_prime<LID>(g, k);
-                dirty_state = true;
-            }
+            st = env_policy_step<LID>(g, k, r, b, gi, a.actions[gi], rew, dn, dirty_state);
             if (a.reward) AZ_LANE0(a.reward[gi] = rew);
             if (a.done) AZ_LANE0(a.done[gi] = (uint8_t)dn);
         } break;
         case OP_AGENT_STEP: {
-            // one AGENT step of NNRunner.run_episode (nn_runner.py:24-29): GameRunner.step -- the agent's move, the
-            // opponent's RandomAgent replies, the shaped reward, done (game_runner.py:43-55) -- and, when the episode
-            // ends, the GameRunner.reset() that opens the next run_episode (nn_runner.py:20 -> game_runner.py:76-82,
-            // incl. the opponent's opening moves), so the observation / mask written below are the next decision's
             i32 rew = 0;
             u32 dn = 0;
-            st = runner_step<LID>(g, k, r, tab, a.actions[gi], rew, dn);
-            dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_BAD_ACTION);
-            if (st == ST_STUCK) { AZ_LANE0(b.stuck[gi] += 1u); dn = 2u; rew = 0; }       // hazard H3: nobody can move
-            else if (st == ST_GAME_ENDED) dn = 1u;       // a finished game handed in: restart the slot, report done
-            else if (st == ST_OK && dn) {
-                for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(b.stat_sum[(size_t)gi * 10 + q] += sv); }
-                AZ_LANE0(b.episodes[gi] += 1ull);
-            }
-            if (dirty_state && dn) {
-                u32 st2 = episode_reset<LID>(g, b.rules.first_player, r);
-                game_prime<LID>(g, k);
-                if (!st2) st2 = runner_opponent_loop<LID>(g, k, r, tab, true);
-                if (st == ST_OK) st = st2;
-            }
+            st = env_agent_step<LID>(g, k, r, tab, b, gi, a.actions[gi], rew, dn, dirty_state);
             if (a.reward) AZ_LANE0(a.reward[gi] = rew);
             if (a.done) AZ_LANE0(a.done[gi] = (uint8_t)dn);
         } break;
@@ -729,6 +748,33 @@ int azul_policy_forward(const float *obs_dev, const uint8_t *mask_dev, const flo
     hipLaunchKernelGGL(azul_policy_forward_kernel, dim3(((u32)n_games + PF_GAMES - 1) / PF_GAMES), dim3(256), 0, (hipStream_t)stream,
                        obs_dev, mask_dev, W, (u64)seed, (u64)counter, (u64 *)counter_dev, advance_counter, (u32)n_games, value_dev,
                        action_dev, logp_dev, entropy_dev, logits_dev);
+    HIP_TRY(hipGetLastError());
+    return AZUL_SUCCESS;
+}
+
+int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random, const float *w1t_dev, const float *b1_dev,
+                              const float *w2c_dev, const float *b2c_dev, const float *w2a_t_dev, const float *b2a_dev, int num_inputs,
+                              int hidden_size, int num_actions, uint64_t seed, uint64_t counter, uint64_t *counter_dev, float *obs_dev,
+                              uint8_t *mask_dev, uint8_t *player_dev, int32_t *action_dev, int32_t *reward_dev, uint8_t *done_dev,
+                              float *value_dev, float *logp_dev, float *entropy_dev, uint8_t *status_dev, void *stream)
+{
+    if (!b || n_steps < 0) return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: bad arguments");
+    if (num_inputs != PF_IN || hidden_size != PF_HID || num_actions != PF_ACT)
+        return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: only ActorCritic(136, 180, hidden 180) is compiled in");
+    if (!w1t_dev || !b1_dev || !w2c_dev || !b2c_dev || !w2a_t_dev || !b2a_dev || !obs_dev || !mask_dev || !player_dev || !action_dev ||
+        !reward_dev || !done_dev || !value_dev || !logp_dev || !entropy_dev)
+        return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: NULL pointer");
+    if (((uintptr_t)w1t_dev & 7u) != 0) return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: w1t_dev must be 8-byte aligned");
+    PolicyWeights W = {w1t_dev, b1_dev, w2c_dev, b2c_dev, w2a_t_dev, b2a_dev};
+    RolloutArgs a = {n_steps, obs_dev, mask_dev, player_dev, action_dev, reward_dev, done_dev, value_dev, logp_dev, entropy_dev, status_dev,
+                     (u64)seed, (u64)counter, (u64 *)counter_dev};
+    const dim3 grid((b->d.n + PF_GAMES - 1) / PF_GAMES), block(64 * PR_WAVES);
+    const hipStream_t st = (hipStream_t)stream;
+    const bool lid = b->d.rules.tile_pool == POOL_LID;
+    if (lid && opponent_random) hipLaunchKernelGGL((azul_policy_rollout_kernel<true, true>), grid, block, 0, st, b->d, W, a);
+    else if (lid) hipLaunchKernelGGL((azul_policy_rollout_kernel<true, false>), grid, block, 0, st, b->d, W, a);
+    else if (opponent_random) hipLaunchKernelGGL((azul_policy_rollout_kernel<false, true>), grid, block, 0, st, b->d, W, a);
+    else hipLaunchKernelGGL((azul_policy_rollout_kernel<false, false>), grid, block, 0, st, b->d, W, a);
     HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }

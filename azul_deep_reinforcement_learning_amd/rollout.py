@@ -31,7 +31,7 @@ def _p(t):
 
 class PolicyRollout:
     def __init__(self, policy, n_games=4096, parts=1, rules={"first_player": "Random", "tile_pool": "Lid"}, seed_base=0,
-                 device=None, window=32, use_graph=True, fused_head=True, sample_seed=0x5EED, opponent=None, fused_mlp=True):
+                 device=None, window=32, use_graph=True, fused_head=True, sample_seed=0x5EED, opponent=None, fused_mlp=True, persistent=False):
         """opponent=None: the policy moves for both players (flat self-play, one record per env move).
         opponent="random": the reference's training setup -- the policy is player 1 of GameRunner, the opponent a RandomAgent
         inside the env step (game_runner.py:43-47); one record per AGENT step, observations from the agent's perspective."""
@@ -45,6 +45,8 @@ class PolicyRollout:
         # the one-launch forward (azul_policy_forward) is compiled for the reference's ActorCritic(136, 180, hidden 180)
         self.fused_mlp = bool(fused_mlp and fused_head and policy.critic_linear1.in_features == L.OBS_SIZE and
                               policy.critic_linear1.out_features == 180 and policy.actor_linear2.out_features == L.NUM_ACTIONS)
+        # persistent=True: the whole window runs in ONE launch per part (azul_batch_policy_rollout); same results
+        self.persistent = bool(persistent and self.fused_mlp)
         self.sample_seed = int(sample_seed)
         self.envs, self.streams, self.work, self.traj, self.graphs = [], [], [], [], []
         self.refresh_weights()
@@ -73,9 +75,9 @@ class PolicyRollout:
             with torch.cuda.stream(self.streams[p]):
                 env.observe_all(self._persp(), t["obs"][T], t["mask"][T], t["player"][T])     # becomes slot 0 of the first window
         torch.cuda.synchronize(d)
-        self.use_graph = use_graph
+        self.use_graph = use_graph and not self.persistent         # one launch per window needs no graph
         self.graph_error = None
-        if use_graph:
+        if self.use_graph:
             try:
                 self._capture()
             except Exception as e:          # capture is a launch-overhead optimisation only
@@ -147,6 +149,16 @@ class PolicyRollout:
 
     def _window(self, p, gamma):
         tr, T = self.traj[p], self.T
+        if self.persistent:
+            env, w, pol = self.envs[p], self.work[p], self.policy
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            L.check(L.lib.azul_batch_policy_rollout(
+                env._h, T, 1 if self.opponent == "random" else 0, _p(self.w1t), _p(self.b1), _p(self.w2c), _p(pol.critic_linear2.bias),
+                _p(self.w2a_t), _p(pol.actor_linear2.bias), L.OBS_SIZE, self.H, L.NUM_ACTIONS, self.sample_seed, 0, _p(w["counter"]),
+                _p(tr["obs"]), _p(tr["mask"]), _p(tr["player"]), _p(tr["action"]), _p(tr["reward"]), _p(tr["done"]), _p(tr["value"]),
+                _p(tr["log_prob"]), _p(tr["entropy"]), _p(w["status"]), st))
+            L.check(L.lib.azul_discounted_returns(_p(tr["reward"]), _p(tr["done"]), _p(tr["returns"]), None, C.c_float(gamma), T, self.h, st))
+            return
         tr["obs"][0].copy_(tr["obs"][T])
         tr["mask"][0].copy_(tr["mask"][T])
         tr["player"][0].copy_(tr["player"][T])

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--torch-head", action="store_true", help="sample with torch.multinomial instead of the fused head kernel")
     ap.add_argument("--torch-mlp", action="store_true", help="run the network as PyTorch GEMMs instead of azul_policy_forward")
+    ap.add_argument("--per-move", action="store_true", help="two launches per move (forward + env step) instead of one launch per window")
     ap.add_argument("--no-compare", action="store_true", help="skip the PyTorch-GEMM / two-stream comparison run")
     ap.add_argument("--train", action="store_true", help="policy vs RandomAgent opponent + one A2C update per window")
     a = ap.parse_args()
@@ -32,11 +33,11 @@ def main():
     if a.train:
         return train(a)
 
-    def measure(parts, fused_mlp):
+    def measure(parts, fused_mlp, persistent=False):
         torch.manual_seed(0)
         net = BatchedActorCritic(136, 180, 180)
         ro = PolicyRollout(net, n_games=a.games, parts=parts, window=a.window, use_graph=not a.no_graph,
-                           fused_head=not a.torch_head, fused_mlp=fused_mlp)
+                           fused_head=not a.torch_head, fused_mlp=fused_mlp, persistent=persistent)
         for _ in range(3):
             ro.run_window()
         ro.synchronize()
@@ -48,18 +49,22 @@ def main():
         torch.cuda.synchronize()
         return ro, time.perf_counter() - t0
 
-    ro, dt = measure(a.parts, not a.torch_mlp)
+    ro, dt = measure(a.parts, not a.torch_mlp, persistent=not a.per_move)
     moves = a.games * a.window * a.windows
     c = ro.counters()
     out = {"metric": "Azul env steps/sec (ActorCritic policy self-play, trajectories recorded)", "value": moves / dt,
            "unit": "env steps/s", "n_gpus": 1, "config": {"workload": "BASELINE configs[2]", "games": a.games,
-           "stream_parts": a.parts, "moves_per_graph": a.window, "hip_graph": ro.use_graph, "fused_head": ro.fused_head, "fused_mlp": ro.fused_mlp,
+           "stream_parts": a.parts, "moves_per_graph": a.window, "hip_graph": ro.use_graph, "fused_head": ro.fused_head, "fused_mlp": ro.fused_mlp, "one_launch_per_window": ro.persistent,
            "graph_error": ro.graph_error}, "ms_per_step": dt / (a.window * a.windows) * 1e3,
            "episodes_finished": c["episodes"], "stuck": c["stuck"], "dtype": "fp32 policy / u8 env", "data": "synthetic"}
     if not a.no_compare and not a.torch_mlp:
         # the configuration BASELINE.json words literally: model.py's network as PyTorch-ROCm GEMMs, interleaved with the env
         # step on two HIP streams (same trajectories recorded, same head kernel)
         del ro
+        if not a.per_move:
+            ro1, dt1 = measure(a.parts, True, persistent=False)
+            out["fused_forward_two_launches_per_move"] = {"value": moves / dt1, "unit": "env steps/s", "hip_graph": ro1.use_graph}
+            del ro1
         ro2, dt2 = measure(2, False)
         out["pytorch_rocm_policy_two_streams"] = {"value": moves / dt2, "unit": "env steps/s", "hip_graph": ro2.use_graph}
     print(json.dumps(out))
@@ -81,7 +86,8 @@ def train(a):
     torch.manual_seed(0)                                    # same initial weights on every rank
     net = BatchedActorCritic(136, 180, 180)
     ro = PolicyRollout(net, n_games=a.games, parts=a.parts, window=a.window, use_graph=not a.no_graph, fused_head=not a.torch_head,
-                       fused_mlp=not a.torch_mlp, opponent="random", seed_base=rank * a.games, sample_seed=0x5EED + rank)
+                       fused_mlp=not a.torch_mlp, persistent=not a.per_move, opponent="random", seed_base=rank * a.games,
+                       sample_seed=0x5EED + rank)
     learner = A2CLearner(net)
 
     def one_window():

@@ -175,6 +175,20 @@ int azul_policy_forward(const float *obs_dev /*[N][136]*/, const uint8_t *mask_d
                         int hidden_size, int num_actions, uint64_t seed, uint64_t counter, uint64_t *counter_dev, int advance_counter,
                         int n_games, float *value_dev /*[N]*/, int32_t *action_dev, float *logp_dev, float *entropy_dev,
                         float *logits_dev, void *stream);
+/* A whole WINDOW of policy-driven moves in one launch (the batched NNRunner.run_episode loop, nn_runner.py:17-47, without a
+ * kernel boundary per move): for t = 0 .. n_steps-1 every game's observation / mask / player are written to slot t, the network
+ * of azul_policy_forward is evaluated, an action is sampled (Philox counter `counter` + *counter_dev + t), and the env advances
+ * -- opponent_random = 0: Azul.step for the current player with auto-reset (like azul_batch_policy_step, perspective = current
+ * player); opponent_random = 1: GameRunner.step incl. the RandomAgent opponent's replies and GameRunner.reset() at episode end
+ * (like azul_batch_agent_step, perspective 0) -- then slot n_steps receives the state after the last move.  Games and RNG
+ * streams stay in registers / LDS for the whole launch.  Layouts are time-major: obs [T+1][N][136], mask [T+1][N][180],
+ * player [T+1][N], action / reward / done / value / logp / entropy [T][N]; status [N] (optional) is the last move's status.
+ * The results are bit-identical to n_steps x (azul_policy_forward + azul_batch_policy_step / _agent_step). */
+int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random, const float *w1t_dev, const float *b1_dev,
+                              const float *w2c_dev, const float *b2c_dev, const float *w2a_t_dev, const float *b2a_dev, int num_inputs,
+                              int hidden_size, int num_actions, uint64_t seed, uint64_t counter, uint64_t *counter_dev, float *obs_dev,
+                              uint8_t *mask_dev, uint8_t *player_dev, int32_t *action_dev, int32_t *reward_dev, uint8_t *done_dev,
+                              float *value_dev, float *logp_dev, float *entropy_dev, uint8_t *status_dev, void *stream);
 /* discounted returns q[t] = r[t] + gamma * q[t+1] within episodes over a time-major window [n_steps][n_games]
  * (nn_runner.py:70-76); done[t][g] != 0 closes an episode at move t; carry_dev[n_games] (optional) chains windows. */
 int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, float *returns_dev, float *carry_dev,

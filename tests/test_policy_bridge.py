@@ -255,3 +255,31 @@ def test_fused_forward_matches_the_reference_network(contract, n):
     # other network shapes are refused, not silently mis-computed
     assert L.lib.azul_policy_forward(p(obs), p(mask), p(w1t), p(b1), p(w2c), p(net.critic_linear2.bias), p(w2a_t), p(net.actor_linear2.bias),
                                      136, 128, 180, 77, 0, None, 0, n, p(value), p(action), p(logp), p(ent), None, None) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opponent,n", [(None, 100), ("random", 100), (None, 16), ("random", 2048)])
+def test_persistent_rollout_is_bit_identical_to_the_per_move_path(contract, opponent, n):
+    """azul_batch_policy_rollout (a whole window in one launch, games resident in registers / LDS) must reproduce the
+    two-launches-per-move path bit for bit: observations, masks, players, actions, rewards, dones, values, log-probs,
+    entropies, returns, the final game records and RNG positions -- over two windows, with a ragged last workgroup (n = 100)."""
+    from azul_deep_reinforcement_learning_amd import PolicyRollout
+    T = 45
+    runs = []
+    for persistent in (False, True):
+        torch.manual_seed(3)
+        net = _net(contract, "cuda")
+        ro = PolicyRollout(net, n_games=n, parts=1, seed_base=77, window=T, use_graph=False, opponent=opponent, persistent=persistent)
+        assert ro.persistent == persistent
+        wins = []
+        for _ in range(2):
+            tr = ro.run_window()
+            ro.synchronize()
+            wins.append({k: v.clone() for k, v in tr[0].items()})
+        runs.append((wins, ro.envs[0].get_records(), ro.envs[0].get_rng_range()[1], ro.counters(), ro.work[0]["counter"].tolist()))
+    (wa, ra, pa, ca, cta), (wb, rb, pb, cb, ctb) = runs
+    for wi in range(2):
+        for key in ("obs", "mask", "player", "action", "reward", "done", "value", "log_prob", "entropy", "returns"):
+            assert torch.equal(wa[wi][key], wb[wi][key]), (wi, key)
+    assert ra.tobytes() == rb.tobytes() and np.array_equal(pa, pb) and ca == cb and cta == ctb
+    assert ca["episodes"] > 0

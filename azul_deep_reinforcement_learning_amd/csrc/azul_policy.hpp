@@ -440,10 +440,18 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
     if (live) publish(0u);
     else { orow[l] = 0.f; orow[l + 64u] = 0.f; if (l < (u32)PF_IN - 128u) orow[l + 128u] = 0.f; if (l == 0u) { maskS[w][0] = 0; maskS[w][1] = 0; maskS[w][2] = 0; } }
 
+#if defined(AZ_PROFILE_SEGMENTS)
+    u64 pr_acc[6] = {0, 0, 0, 0, 0, 0}, pr_last = __builtin_amdgcn_s_memtime();
+#define PR_STAMP(i) do { u64 now_ = __builtin_amdgcn_s_memtime(); pr_acc[i] += now_ - pr_last; pr_last = now_; } while (0)
+#else
+#define PR_STAMP(i) do { } while (0)
+#endif
 #pragma unroll 1
     for (int t = 0; t < a.n_steps; t++) {
         const size_t row_t = (size_t)t * n;
+        PR_STAMP(0);                                     // own env step + publish
         __syncthreads();                                 // observations and mask bits of all 16 games are in LDS
+        PR_STAMP(1);                                     // waiting for the slowest env wave
         if (mm) {
             // layer 1: this wave owns hidden columns 32w + 2c + j (j = 0, 1): two 16x16 tiles with column stride 2
             pf_f32x4 acc0 = (pf_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -470,6 +478,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
             }
         }
         __syncthreads();
+        PR_STAMP(2);                                     // layer 1 (incl. barrier)
         if (mm) {
             // layer 2 (actor): logit column 16w + c
             pf_f32x4 acc = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
@@ -497,6 +506,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
             if (q == 0u && g0 + c < n) a.value[row_t + g0 + c] = sum + b2c_v;
         }
         __syncthreads();
+        PR_STAMP(3);                                     // layer 2 + critic (incl. barrier)
         if (w < 4u) {
             // head: this wave samples games 4w .. 4w+3 of the tile, 16 lanes each
             const u32 hrow = 4u * w + q, hg = g0 + hrow;
@@ -513,6 +523,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
                              a.entropy + row_t, actS + 4u * w);
         }
         __syncthreads();
+        PR_STAMP(4);                                     // head (incl. barrier)
         if (live) {
             const i32 av = actS[w];
             i32 rew = 0;
@@ -524,6 +535,9 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
             publish((u32)t + 1u);
         }
     }
+#if defined(AZ_PROFILE_SEGMENTS)
+    if (l == 0u && w == 5u) for (int i = 0; i < 5; i++) atomicAdd((unsigned long long *)(b.prof + i), (unsigned long long)pr_acc[i]);
+#endif
     if (live) {
         game_store(g, rec);
         rng_close(r, b.mtpos + gi);

@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 // the self-play kernel); per move
 //     env waves     publish observation (LDS + trajectory) and legal mask (LDS bits + trajectory bytes)
 //     waves 0..11   layer 1 on the f32 matrix cores (two 16x16 tiles each), then layer 2 (one tile each); wave 12: the critic
-//     waves 0..3    the head for four games each (masked softmax, sample, log-prob, entropy)
+//     waves 12..15  the head for four games each (masked softmax, sample, log-prob, entropy)
 //     env waves     Azul.step with the sampled action (OPP: + the RandomAgent opponent's replies), reward, done, auto-reset
 // with four workgroup barriers in between.  Arithmetic per output element is the same k-ordered fma chain as
 // azul_policy_forward_kernel and the env functions are the per-call kernel's, so the trajectories are bit-identical to the
@@ -368,7 +368,7 @@ struct RolloutArgs {
     u64 *counter_dev;    // optional [2]: [0] added to `counter`, advanced by n_steps; [1] completion ticket
 };
 
-constexpr u32 PR_WAVES = 16, PR_MM_WAVES = 12, PR_AHEAD = 8;
+constexpr u32 PR_WAVES = 16, PR_MM_WAVES = 12, PR_HEAD_WAVE0 = 12, PR_AHEAD = 8;
 
 template <bool LID, bool OPP>
 __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(BatchDev b, PolicyWeights W, RolloutArgs a)
@@ -507,9 +507,9 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
         }
         __syncthreads();
         PR_STAMP(3);                                     // layer 2 + critic (incl. barrier)
-        if (w < 4u) {
-            // head: this wave samples games 4w .. 4w+3 of the tile, 16 lanes each
-            const u32 hrow = 4u * w + q, hg = g0 + hrow;
+        if (w >= PR_HEAD_WAVE0) {
+            // head: waves 12..15 (idle during the matrix phases) sample four games each, 16 lanes per game
+            const u32 hw = w - PR_HEAD_WAVE0, hrow = 4u * hw + q, hg = g0 + hrow;
             float x[HEAD_PER_LANE];
             const float *lg = lgS + hrow * PF_LOG_STRIDE + (c < 15u ? 12u * c : 0u);
             for (int j = 0; j < HEAD_PER_LANE; j++) x[j] = lg[j];
@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
             if (off > 52u) field |= hi << (64u - off);
             const u32 okbits = c < 15u ? (u32)field & 0xfffu : 0u;
             policy_head_rows(x, okbits, a.seed, counter + (u64)t, hg < n ? hg : n - 1u, l, hg < n, a.action + row_t, a.logp + row_t,
-                             a.entropy + row_t, actS + 4u * w);
+                             a.entropy + row_t, actS + 4u * hw);
         }
         __syncthreads();
         PR_STAMP(4);                                     // head (incl. barrier)

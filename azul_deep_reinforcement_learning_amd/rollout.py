@@ -2,7 +2,9 @@
 ``NNRunner.run_episode`` (azulnet/nn_runner.py:17-47) and of the action sampling in ``Agent.get_ac_output``
 (azulnet/agent.py:64-81).
 
-Per move and part of the batch (each part has its own HIP stream) -- two launches:
+`persistent=True` (what the benches use): ONE launch per window and part -- azul_batch_policy_rollout keeps every game in
+registers for the whole window and interleaves network, sampling and env step inside the kernel.  Otherwise, per move and
+part of the batch (each part has its own HIP stream) -- two launches:
     azul_policy_forward      the whole ActorCritic forward on the f32 matrix cores (hidden = relu(obs @ [critic_linear1 |
                              actor_linear1]), value, logits) + masked softmax + categorical sample + log-prob + entropy;
                              value / action / log-prob / entropy land straight in trajectory slot t

@@ -34,9 +34,9 @@ AGENT_STAT_KEYS = ("reward", "actor_loss", "critic_loss", "entropy_loss", "ac_lo
 
 class BatchedTrainer:
     def __init__(self, policy, n_games=4096, window=32, parts=1, learning_rate=3e-4, gamma=0.99, seed_base=0, sample_seed=0x5EED,
-                 rules={"first_player": "Random", "tile_pool": "Lid"}, device=None, use_graph=True, results_dir="results"):
+                 rules={"first_player": "Random", "tile_pool": "Lid"}, device=None, use_graph=True, persistent=True, results_dir="results"):
         self.rollout = PolicyRollout(policy, n_games=n_games, parts=parts, rules=rules, seed_base=seed_base, device=device, window=window,
-                                     use_graph=use_graph, sample_seed=sample_seed, opponent="random")
+                                     use_graph=use_graph, sample_seed=sample_seed, opponent="random", persistent=persistent)
         self.learner = A2CLearner(self.rollout.policy, learning_rate=learning_rate, gamma=gamma)
         self.gamma = gamma
         self.results_dir = results_dir

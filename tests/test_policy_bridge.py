@@ -258,8 +258,10 @@ def test_fused_forward_matches_the_reference_network(contract, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("opponent,n", [(None, 100), ("random", 100), (None, 16), ("random", 2048)])
-def test_persistent_rollout_is_bit_identical_to_the_per_move_path(contract, opponent, n):
+@pytest.mark.parametrize("opponent,n,rules", [(None, 100, None), ("random", 100, None), (None, 16, None), ("random", 2048, None),
+                                              (None, 37, {"first_player": 2, "tile_pool": "Random"}),
+                                              ("random", 37, {"first_player": 1, "tile_pool": "Random"})])
+def test_persistent_rollout_is_bit_identical_to_the_per_move_path(contract, opponent, n, rules):
     """azul_batch_policy_rollout (a whole window in one launch, games resident in registers / LDS) must reproduce the
     two-launches-per-move path bit for bit: observations, masks, players, actions, rewards, dones, values, log-probs,
     entropies, returns, the final game records and RNG positions -- over two windows, with a ragged last workgroup (n = 100)."""
@@ -269,7 +271,8 @@ def test_persistent_rollout_is_bit_identical_to_the_per_move_path(contract, oppo
     for persistent in (False, True):
         torch.manual_seed(3)
         net = _net(contract, "cuda")
-        ro = PolicyRollout(net, n_games=n, parts=1, seed_base=77, window=T, use_graph=False, opponent=opponent, persistent=persistent)
+        kw = {} if rules is None else {"rules": rules}
+        ro = PolicyRollout(net, n_games=n, parts=1, seed_base=77, window=T, use_graph=False, opponent=opponent, persistent=persistent, **kw)
         assert ro.persistent == persistent
         wins = []
         for _ in range(2):

@@ -258,7 +258,7 @@ def test_fused_forward_matches_the_reference_network(contract, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("opponent,n,rules", [(None, 100, None), ("random", 100, None), (None, 16, None), ("random", 2048, None),
+@pytest.mark.parametrize("opponent,n,rules", [(None, 100, None), ("random", 100, None), (None, 16, None), ("random", 2048, None), (None, 4096, None),
                                               (None, 37, {"first_player": 2, "tile_pool": "Random"}),
                                               ("random", 37, {"first_player": 1, "tile_pool": "Random"})])
 def test_persistent_rollout_is_bit_identical_to_the_per_move_path(contract, opponent, n, rules):

@@ -382,6 +382,7 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
 
 
 #include "azul_policy.hpp"
+#include "azul_learner.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side: C ABI
@@ -775,6 +776,30 @@ int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random,
     else if (lid) hipLaunchKernelGGL((azul_policy_rollout_kernel<true, false>), grid, block, 0, st, b->d, W, a);
     else if (opponent_random) hipLaunchKernelGGL((azul_policy_rollout_kernel<false, true>), grid, block, 0, st, b->d, W, a);
     else hipLaunchKernelGGL((azul_policy_rollout_kernel<false, false>), grid, block, 0, st, b->d, W, a);
+    HIP_TRY(hipGetLastError());
+    return AZUL_SUCCESS;
+}
+
+int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int32_t *action_dev, const float *qvals_dev, int n_samples,
+                       float inv_n_total, const float *w1t_dev, const float *b1_dev, const float *w2c_dev, const float *b2c_dev,
+                       const float *w2a_t_dev, const float *b2a_dev, const float *w2a_dev, int num_inputs, int hidden_size, int num_actions,
+                       float *workspace_dev, int workspace_parts, float *grad_dev, void *stream)
+{
+    if (num_inputs != PF_IN || hidden_size != PF_HID || num_actions != PF_ACT)
+        return fail(AZUL_ERR_INVALID, "azul_a2c_gradients: only ActorCritic(136, 180, hidden 180) is compiled in");
+    if (!w1t_dev || !b1_dev || !w2c_dev || !b2c_dev || !w2a_t_dev || !b2a_dev || !w2a_dev || !workspace_dev || !grad_dev || n_samples < 0 ||
+        workspace_parts <= 0 || (n_samples > 0 && (!obs_dev || !mask_dev || !action_dev || !qvals_dev)))
+        return fail(AZUL_ERR_INVALID, "azul_a2c_gradients: bad arguments");
+    if (((uintptr_t)w2a_t_dev & 7u) != 0 || ((uintptr_t)w2a_dev & 7u) != 0 || ((uintptr_t)mask_dev & 3u) != 0)
+        return fail(AZUL_ERR_INVALID, "azul_a2c_gradients: weights must be 8-byte aligned, mask_dev 4-byte aligned");
+    const hipStream_t st = (hipStream_t)stream;
+    const u32 tiles = ((u32)n_samples + PF_GAMES - 1) / PF_GAMES;
+    const u32 parts = tiles < (u32)workspace_parts ? tiles : (u32)workspace_parts;
+    if (parts == 0) { HIP_TRY(hipMemsetAsync(grad_dev, 0, sizeof(float) * LG_P_TOTAL, st)); return AZUL_SUCCESS; }
+    PolicyWeights W = {w1t_dev, b1_dev, w2c_dev, b2c_dev, w2a_t_dev, b2a_dev};
+    LearnerArgs a = {obs_dev, mask_dev, action_dev, qvals_dev, (u32)n_samples, inv_n_total, w2a_dev, workspace_dev};
+    hipLaunchKernelGGL(azul_a2c_grad_kernel, dim3(parts), dim3(64 * LG_WAVES), 0, st, W, a);
+    hipLaunchKernelGGL(azul_a2c_reduce_kernel, dim3((LG_P_TOTAL + 255) / 256), dim3(256), 0, st, workspace_dev, parts, grad_dev);
     HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }

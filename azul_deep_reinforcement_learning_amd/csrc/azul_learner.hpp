@@ -1,0 +1,315 @@
+// azul_learner.hpp -- device code of row N2: the A2C update of agent.py:39-62 as hand-written gfx950 kernels; included by
+// azul_kernels.hip after azul_policy.hpp (shares its constants, PolicyWeights and the 16-lane row reductions).
+//
+//   azul_a2c_grad_kernel     forward + backward of the reference's loss for tiles of 16 samples, everything GEMM-shaped on the f32
+//                            matrix cores (v_mfma_f32_16x16x4_f32).  A workgroup of 8 waves walks over its share of the sample tiles
+//                            and keeps its partial weight gradients IN REGISTERS for the whole launch (dW1: 207 16x16 tiles, dW2: 144
+//                            tiles -> 176 accumulator registers per lane), then writes one partial gradient vector per workgroup.
+//   azul_a2c_reduce_kernel   sums the per-workgroup partials in a fixed order (deterministic) into one flat gradient + loss terms.
+//
+// Loss per sample i (agent.py:45-57; n = number of samples of the whole batch, all ranks):
+//     adv = q - v                                      (NOT detached in the actor term, like the reference)
+//     L_i = ( -logp[a] * adv  +  0.5 * adv^2  +  0.1 * ( -mean_{j legal} logp[j] ) ) / n
+// hence   dL/dv       = ( logp[a] - adv ) / n
+//         dL/dlogp_j  = ( -adv [j == a]  -  0.1 / |legal| [j legal] ) / n
+//         dL/dlogit_k = dL/dlogp_k - softmax_k * sum_j dL/dlogp_j            (masked log-softmax; 0 for illegal k)
+// Gradient vector layout (k-major like the forward weights): dw1t [136][360] | db1 [360] | dw2c [180] | db2c [1] | dw2a_t [180][180]
+// | db2a [180]  = 82081 floats, followed by the four loss sums (actor, critic, entropy, count of samples used).
+#pragma once
+
+constexpr int LG_P_W1 = 0, LG_P_B1 = LG_P_W1 + PF_IN * PF_H2, LG_P_W2C = LG_P_B1 + PF_H2, LG_P_B2C = LG_P_W2C + PF_HID,
+              LG_P_W2A = LG_P_B2C + 1, LG_P_B2A = LG_P_W2A + PF_HID * PF_ACT, LG_P_PARAMS = LG_P_B2A + PF_ACT,
+              LG_P_LOSS = LG_P_PARAMS, LG_P_TOTAL = LG_P_PARAMS + 4;
+static_assert(LG_P_PARAMS == 82081, "ActorCritic(136, 180, 180) has 82081 parameters");
+
+constexpr u32 LG_WAVES = 8, LG_AHEAD = 8;
+constexpr int LG_F_TILES = 9, LG_C_TILES = 23;                 // dW1: 136 -> 9 feature tiles, 360 -> 23 column tiles
+constexpr int LG_C_PER_WAVE = (LG_C_TILES + (int)LG_WAVES - 1) / (int)LG_WAVES;      // 3: wave w owns column tiles w, w + 8, w + 16
+
+struct LearnerArgs {
+    const float *obs;        // [n][136]
+    const uint8_t *mask;     // [n][180]
+    const i32 *action;       // [n]
+    const float *qvals;      // [n]
+    u32 n;                   // samples of this launch (this rank)
+    float inv_n;             // 1 / (samples of the whole batch)
+    const float *w2a;        // [180 actions][180 hidden]: actor_linear2.weight as PyTorch stores it (for dh = dlogits @ W)
+    float *partial;          // [gridDim.x][LG_P_TOTAL]
+};
+
+__global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeights W, LearnerArgs a)
+{
+    __shared__ float obsS[PF_GAMES * PF_OBS_STRIDE];     // x      [16][136 (+pad, zero)]
+    __shared__ float hidS[PF_GAMES * PF_HID_STRIDE];     // relu h [16][360 (+pad, zero)]
+    __shared__ float lgS[PF_GAMES * PF_LOG_STRIDE];      // logits, then dL/dlogits [16][180 (+pad, zero)]
+    __shared__ float dzS[PF_GAMES * PF_HID_STRIDE];      // dL/dz  [16][360 (+pad, zero)]
+    __shared__ float w2cS[PF_HID];
+    __shared__ float valS[PF_GAMES], dvS[PF_GAMES];
+    __shared__ float lossS[4];
+    const u32 tid = threadIdx.x, l = tid & 63u, c = l & 15u, q = l >> 4;
+    const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const u32 n = a.n, n_tiles = (n + PF_GAMES - 1) / PF_GAMES;
+
+    // one-time LDS state: zero everything (the pad columns must stay zero: they feed the padded gradient tiles)
+    for (u32 i = tid; i < (u32)(PF_GAMES * PF_OBS_STRIDE); i += 64u * LG_WAVES) obsS[i] = 0.f;
+    for (u32 i = tid; i < (u32)(PF_GAMES * PF_HID_STRIDE); i += 64u * LG_WAVES) { hidS[i] = 0.f; dzS[i] = 0.f; }
+    for (u32 i = tid; i < (u32)(PF_GAMES * PF_LOG_STRIDE); i += 64u * LG_WAVES) lgS[i] = 0.f;
+    if (tid < (u32)PF_HID) w2cS[tid] = W.w2c[tid];
+    if (tid < 4u) lossS[tid] = 0.f;
+
+    // buffer descriptors: per-lane byte offset + literal k-step offset (see azul_policy_rollout_kernel)
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)W.w1t, 0, PF_IN * PF_H2 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2t = __builtin_amdgcn_make_buffer_rsrc((void *)W.w2a_t, 0, PF_HID * PF_ACT * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2a, 0, PF_ACT * PF_HID * 4, 0x00020000);
+    // forward layer 1: wave w owns hidden columns 48w + 3c + j (j = 0..2)
+    const u32 f1col0 = 48u * w + 3u * c;
+    const bool f1live = f1col0 < (u32)PF_H2;
+    const u32 voff1 = ((f1live ? f1col0 : 0u) + q * (u32)PF_H2) * 4u;
+    float f1bias[3];
+    for (int j = 0; j < 3; j++) f1bias[j] = W.b1[(f1live ? f1col0 : 0u) + j];
+    // forward layer 2 and dh: waves 0..5 own columns 32w + 2c + j (j = 0, 1) of a 180-wide matrix
+    const bool mm2 = w < 6u;
+    const u32 f2col0 = 32u * w + 2u * c;
+    const bool f2live = mm2 && f2col0 < (u32)PF_ACT;
+    const u32 voff2 = ((f2live ? f2col0 : 0u) + q * (u32)PF_ACT) * 4u;
+    const float f2bias0 = W.b2a[f2live ? f2col0 : 0u], f2bias1 = W.b2a[f2live ? f2col0 + 1u : 0u];
+    const float b2c_v = W.b2c[0];
+#define LG_LOAD_W1(s, j) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, voff1 + 4u * (j), (4 * (s)) * PF_H2 * 4, 0))
+#define LG_LOAD_2(rs, s) __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff2, (4 * (s)) * PF_ACT * 4, 0))
+
+    // register-resident partial gradients of this workgroup
+    pf_f32x4 gW2[3][6];                                  // dW2a_t tiles: hidden tiles 3 (w & 3) + i, action tiles 6 (w >> 2) + j
+    pf_f32x4 gW1[LG_C_PER_WAVE][LG_F_TILES];             // dW1t tiles: column tiles w + 8 i (i = 0..2), all nine feature tiles
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 6; j++) gW2[i][j] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < LG_C_PER_WAVE; i++) for (int f = 0; f < LG_F_TILES; f++) gW1[i][f] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
+    float g_b1 = 0.f, g_b2a = 0.f, g_w2c = 0.f, g_b2c = 0.f;      // thread tid: db1[tid] (tid < 360), db2a / dw2c [tid] (tid < 180), db2c (tid 0)
+    float l_actor = 0.f, l_critic = 0.f, l_entropy = 0.f, l_count = 0.f;
+    const u32 wk = w & 3u, wj = w >> 2;
+    __syncthreads();
+
+#pragma unroll 1
+    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const u32 s0 = tile * PF_GAMES;
+        // ---- P0: observation tile -> LDS (rows past the batch are zero: they contribute nothing anywhere)
+        for (u32 i = tid; i < (u32)(PF_GAMES * PF_IN); i += 64u * LG_WAVES) {
+            u32 row = i / PF_IN, k = i - row * PF_IN;
+            obsS[row * PF_OBS_STRIDE + k] = s0 + row < n ? a.obs[(size_t)(s0 + row) * PF_IN + k] : 0.f;
+        }
+        __syncthreads();
+        // ---- P1: hidden = relu(x @ w1t + b1)
+        {
+            pf_f32x4 acc[3];
+            for (int j = 0; j < 3; j++) acc[j] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
+            const float *ap = obsS + c * PF_OBS_STRIDE + q;
+            float bw[PF_IN / 4][3];
+#pragma unroll
+            for (int s = 0; s < (int)LG_AHEAD; s++) for (int j = 0; j < 3; j++) bw[s][j] = LG_LOAD_W1(s, j);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < PF_IN / 4; s++) {
+                if (s + (int)LG_AHEAD < PF_IN / 4) for (int j = 0; j < 3; j++) bw[s + LG_AHEAD][j] = LG_LOAD_W1(s + LG_AHEAD, j);
+                const float av = ap[4 * s];
+                for (int j = 0; j < 3; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s][j], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (f1live)
+                for (int j = 0; j < 3; j++)
+                    for (int rr = 0; rr < 4; rr++) {
+                        float h = acc[j][rr] + f1bias[j];
+                        hidS[(4u * q + rr) * PF_HID_STRIDE + f1col0 + j] = h > 0.f ? h : 0.f;
+                    }
+        }
+        __syncthreads();
+        // ---- P2: logits = h_actor @ w2a_t + b2a (waves 0..5), value = h_critic . w2c + b2c (wave 6)
+        if (mm2) {
+            pf_f32x4 acc0 = (pf_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            const float *ap = hidS + c * PF_HID_STRIDE + PF_HID + q;
+            float2 bw[PF_HID / 4];
+#pragma unroll
+            for (int s = 0; s < (int)LG_AHEAD; s++) bw[s] = LG_LOAD_2(rs2t, s);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < PF_HID / 4; s++) {
+                if (s + (int)LG_AHEAD < PF_HID / 4) bw[s + LG_AHEAD] = LG_LOAD_2(rs2t, s + LG_AHEAD);
+                const float av = ap[4 * s];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].y, acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (f2live)
+                for (int rr = 0; rr < 4; rr++) {
+                    float *lp = lgS + (4u * q + rr) * PF_LOG_STRIDE + f2col0;
+                    lp[0] = acc0[rr] + f2bias0;
+                    lp[1] = acc1[rr] + f2bias1;
+                }
+        } else if (w == 6u) {
+            float sum = 0.f;
+            const float *hp = hidS + c * PF_HID_STRIDE;
+#pragma unroll
+            for (int s = 0; s < PF_HID / 4; s++) sum = fmaf(hp[4 * s + q], w2cS[4 * s + q], sum);
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            if (q == 0u) valS[c] = sum + b2c_v;
+        }
+        __syncthreads();
+        // ---- P3: per sample (16 lanes each, waves 0..3): masked log-softmax, loss terms, dL/dlogits (in place), dL/dv
+        if (w < 4u) {
+            const u32 row = 4u * w + q, s = s0 + row;
+            const bool valid = s < n;
+            const u32 sc = valid ? s : n - 1u;
+            float *lg = lgS + row * PF_LOG_STRIDE + 12u * c;       // lane c == 15 owns the pad columns 180..191
+            float x[HEAD_PER_LANE];
+            for (int j = 0; j < HEAD_PER_LANE; j++) x[j] = lg[j];
+            const u32 okbits = valid ? head_mask_bits(a.mask + (size_t)sc * AZUL_NUM_ACTIONS, c) : 0u;
+            const float NEG = -3.0e38f;
+            float m = NEG;
+            for (int j = 0; j < HEAD_PER_LANE; j++) m = fmaxf(m, ((okbits >> j) & 1u) ? x[j] : NEG);
+            m = row_max(m);
+            const u32 cnt = row_sum_u((u32)__popc(okbits));
+            float z[HEAD_PER_LANE], e[HEAD_PER_LANE], mine = 0.f, zs = 0.f;
+            for (int j = 0; j < HEAD_PER_LANE; j++) {
+                bool ok = (okbits >> j) & 1u;
+                z[j] = ok ? x[j] - m : 0.f;
+                e[j] = ok ? expf(z[j]) : 0.f;
+                mine += e[j];
+                zs += z[j];
+            }
+            const float S = row_sum(mine), logS = logf(S), zsum = row_sum(zs);
+            const bool use = valid && cnt != 0u;                   // rows without a legal action carry no sample
+            const i32 act = a.action[sc];
+            const i32 aj = act - (i32)(12u * c);                   // index of the chosen action inside this lane, if any
+            float mine_lpa = 0.f;
+            for (int j = 0; j < HEAD_PER_LANE; j++) if (j == aj && ((okbits >> j) & 1u)) mine_lpa = z[j] - logS;
+            const float logp_a = row_sum(mine_lpa);
+            const float adv = a.qvals[sc] - valS[row];
+            const float ent_w = 0.1f / (float)(cnt ? cnt : 1u);
+            const float G = -adv - 0.1f;                           // sum_j dL/dlogp_j (times n)
+            const float invS = 1.0f / S;
+            for (int j = 0; j < HEAD_PER_LANE; j++) {
+                bool ok = (okbits >> j) & 1u;
+                float gj = (j == aj ? -adv : 0.f) - ent_w;
+                float d = (gj - e[j] * invS * G) * a.inv_n;
+                lg[j] = (use && ok) ? d : 0.f;
+            }
+            if (c == 0u) {
+                dvS[row] = use ? (logp_a - adv) * a.inv_n : 0.f;
+                if (use) {
+                    l_actor += -logp_a * adv;
+                    l_critic += adv * adv;
+                    l_entropy += -(zsum / (float)cnt - logS);
+                    l_count += 1.f;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P4a: bias-like gradients of layer 2 (column sums over the 16 samples)
+        if (tid < (u32)PF_HID) {
+            float sb = 0.f, sw = 0.f;
+            for (int s = 0; s < PF_GAMES; s++) {
+                sb += lgS[s * PF_LOG_STRIDE + tid];
+                sw = fmaf(dvS[s], hidS[s * PF_HID_STRIDE + tid], sw);
+            }
+            g_b2a += sb;
+            g_w2c += sw;
+            if (tid == 0u) { float sv = 0.f; for (int s = 0; s < PF_GAMES; s++) sv += dvS[s]; g_b2c += sv; }
+        }
+        // ---- P4b: dW2a_t[k][j] += sum_s h_actor[s][k] * dlogits[s][j]   (samples are the MFMA's k: four chunks of four)
+        const float *ha = hidS + q * PF_HID_STRIDE + PF_HID + 48u * wk + c;
+        const float *la = lgS + q * PF_LOG_STRIDE + 96u * wj + c;
+#pragma unroll
+        for (int mch = 0; mch < 4; mch++) {
+            float af[3], bf[6];
+            for (int i = 0; i < 3; i++) af[i] = ha[4 * mch * PF_HID_STRIDE + 16 * i];
+            for (int j = 0; j < 6; j++) bf[j] = la[4 * mch * PF_LOG_STRIDE + 16 * j];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 6; j++) gW2[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], gW2[i][j], 0, 0, 0);
+        }
+        // ---- P4c: dz.  Actor half: dh = dlogits @ W2a (waves 0..5), times relu'; critic half: dv * w2c * relu' (waves 6, 7)
+        if (mm2) {
+            pf_f32x4 acc0 = (pf_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            const float *ap = lgS + c * PF_LOG_STRIDE + q;
+            float2 bw[PF_ACT / 4];
+#pragma unroll
+            for (int s = 0; s < (int)LG_AHEAD; s++) bw[s] = LG_LOAD_2(rs2, s);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < PF_ACT / 4; s++) {
+                if (s + (int)LG_AHEAD < PF_ACT / 4) bw[s + LG_AHEAD] = LG_LOAD_2(rs2, s + LG_AHEAD);
+                const float av = ap[4 * s];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].y, acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (f2live)
+                for (int rr = 0; rr < 4; rr++) {
+                    const u32 o = (4u * q + rr) * PF_HID_STRIDE + PF_HID + f2col0;
+                    dzS[o] = hidS[o] > 0.f ? acc0[rr] : 0.f;
+                    dzS[o + 1u] = hidS[o + 1u] > 0.f ? acc1[rr] : 0.f;
+                }
+        } else {
+            // 16 samples x 180 critic units over 128 threads
+            for (u32 i = tid - 384u; i < (u32)(PF_GAMES * PF_HID); i += 128u) {
+                u32 s = i / PF_HID, k = i - s * PF_HID;
+                dzS[s * PF_HID_STRIDE + k] = hidS[s * PF_HID_STRIDE + k] > 0.f ? dvS[s] * w2cS[k] : 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- P5: db1 and dW1t[f][col] += sum_s x[s][f] * dz[s][col]
+        if (tid < (u32)PF_H2) {
+            float sb = 0.f;
+            for (int s = 0; s < PF_GAMES; s++) sb += dzS[s * PF_HID_STRIDE + tid];
+            g_b1 += sb;
+        }
+        {
+            // per-lane bases + compile-time offsets: the wave's column tiles are a constant stride apart
+            const float *xa = obsS + q * PF_OBS_STRIDE + c;
+            const float *za = dzS + q * PF_HID_STRIDE + 16u * w + c;
+#pragma unroll
+            for (int mch = 0; mch < 4; mch++) {
+                float af[LG_F_TILES], bf[LG_C_PER_WAVE];
+                for (int f = 0; f < LG_F_TILES; f++) af[f] = xa[4 * mch * PF_OBS_STRIDE + 16 * f];
+                for (int i = 0; i < LG_C_PER_WAVE; i++) bf[i] = za[4 * mch * PF_HID_STRIDE + 16 * (int)LG_WAVES * i];
+                for (int i = 0; i < LG_C_PER_WAVE; i++)
+                    for (int f = 0; f < LG_F_TILES; f++) gW1[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[f], bf[i], gW1[i][f], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                 // the next tile overwrites obsS / hidS / lgS / dzS
+    }
+
+    // ---- this workgroup's partial gradient vector
+    float *out = a.partial + (size_t)blockIdx.x * LG_P_TOTAL;
+    for (int i = 0; i < LG_C_PER_WAVE; i++)
+        for (int f = 0; f < LG_F_TILES; f++) {
+            const u32 col = 16u * (w + LG_WAVES * (u32)i) + c;
+            for (int rr = 0; rr < 4; rr++) {
+                const u32 ff = 16u * (u32)f + 4u * q + rr;
+                if (ff < (u32)PF_IN && col < (u32)PF_H2) out[LG_P_W1 + ff * PF_H2 + col] = gW1[i][f][rr];
+            }
+        }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 6; j++) {
+            const u32 col = 16u * (6u * wj + j) + c;
+            for (int rr = 0; rr < 4; rr++) {
+                const u32 k = 16u * (3u * wk + i) + 4u * q + rr;
+                if (k < (u32)PF_HID && col < (u32)PF_ACT) out[LG_P_W2A + k * PF_ACT + col] = gW2[i][j][rr];
+            }
+        }
+    if (tid < (u32)PF_H2) out[LG_P_B1 + tid] = g_b1;
+    if (tid < (u32)PF_HID) { out[LG_P_B2A + tid] = g_b2a; out[LG_P_W2C + tid] = g_w2c; }
+    if (tid == 0u) out[LG_P_B2C] = g_b2c;
+    if (w < 4u && c == 0u) {
+        atomicAdd(&lossS[0], l_actor); atomicAdd(&lossS[1], l_critic); atomicAdd(&lossS[2], l_entropy); atomicAdd(&lossS[3], l_count);
+    }
+    __syncthreads();
+    if (tid < 4u) out[LG_P_LOSS + tid] = lossS[tid];
+}
+
+// sum of the per-workgroup partials in workgroup order (deterministic); optionally scaled loss sums stay raw (caller divides)
+__global__ void __launch_bounds__(256) azul_a2c_reduce_kernel(const float *partial, u32 n_parts, float *grad /* [LG_P_TOTAL] */)
+{
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= (u32)LG_P_TOTAL) return;
+    float s = 0.f;
+    for (u32 i = 0; i < n_parts; i++) s += partial[(size_t)i * LG_P_TOTAL + p];
+    grad[p] = s;
+}

@@ -29,9 +29,17 @@ def complete_episode_samples(done):
     return torch.flip(torch.cummax(torch.flip(d, dims=[0]).to(torch.uint8), dim=0).values, dims=[0]).bool()
 
 
+N_PARAMS = 82081            # ActorCritic(136, 180, 180)
+
+
 class A2CLearner:
-    def __init__(self, policy, learning_rate=3e-4, gamma=0.99, process_group=None, distributed=None):
+    def __init__(self, policy, learning_rate=3e-4, gamma=0.99, process_group=None, distributed=None, fused=None):
+        """fused=True: gradients from the hand-written kernel azul_a2c_gradients (forward + backward on the f32 matrix cores, one
+        launch + a deterministic reduction) instead of PyTorch autograd; needs CUDA tensors and the reference's network shape.
+        Default: fused whenever that is possible."""
         self.policy = policy
+        self.fused = fused
+        self._ws = None
         self.gamma = gamma
         self.optimizer = torch.optim.Adam(policy.parameters(), lr=learning_rate)        # agent.py:37
         self.group = process_group
@@ -67,6 +75,56 @@ class A2CLearner:
         ac_loss = ACTOR_COEFF * actor_loss + CRITIC_COEFF * critic_loss + ENTROPY_COEFF * entropy_loss
         return actor_loss, critic_loss, entropy_loss, ac_loss
 
+    # ---- hand-written gradient path -------------------------------------------------------------------------------------
+    def _can_fuse(self, obs):
+        pol = self.policy
+        return (obs.is_cuda and hasattr(pol, "critic_linear1") and pol.critic_linear1.in_features == 136 and
+                pol.critic_linear1.out_features == 180 and pol.actor_linear2.out_features == 180 and pol.actor_linear1.out_features == 180)
+
+    def _fused_gradients(self, obs, mask, action, qvals, n_total):
+        """Fills every parameter's .grad from azul_a2c_gradients; returns (actor, critic, entropy) loss sums / n_total."""
+        import ctypes as C
+        from . import _lib as L
+        pol, dev = self.policy, obs.device
+        if self._ws is None or self._ws["ws"].device != dev:
+            self._ws = {"ws": torch.empty(256, N_PARAMS + 4, device=dev), "grad": torch.empty(N_PARAMS + 4, device=dev)}
+        ws = self._ws
+        with torch.no_grad():
+            w1t = torch.cat([pol.critic_linear1.weight, pol.actor_linear1.weight], dim=0).t().contiguous()
+            b1 = torch.cat([pol.critic_linear1.bias, pol.actor_linear1.bias]).contiguous()
+            w2c = pol.critic_linear2.weight.reshape(-1).contiguous()
+            w2a = pol.actor_linear2.weight.contiguous()
+            w2a_t = w2a.t().contiguous()
+            obs = obs.contiguous().float()
+            mask = mask.contiguous().to(torch.uint8)
+            action = action.contiguous().to(torch.int32)
+            qvals = qvals.contiguous().float()
+            p = lambda t: C.c_void_p(t.data_ptr())
+            L.check(L.lib.azul_a2c_gradients(p(obs), p(mask), p(action), p(qvals), int(obs.shape[0]), C.c_float(1.0 / float(n_total)),
+                                             p(w1t), p(b1), p(w2c), p(pol.critic_linear2.bias), p(w2a_t), p(pol.actor_linear2.bias), p(w2a),
+                                             136, 180, 180, p(ws["ws"]), 256, p(ws["grad"]),
+                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            g = ws["grad"]
+            if self.distributed:
+                dist.all_reduce(g, group=self.group)                       # one flat bucket: 82 085 floats
+            o = 0
+            gw1 = g[o:o + 136 * 360].view(136, 360); o += 136 * 360
+            gb1 = g[o:o + 360]; o += 360
+            gw2c = g[o:o + 180]; o += 180
+            gb2c = g[o:o + 1]; o += 1
+            gw2a = g[o:o + 180 * 180].view(180, 180); o += 180 * 180
+            gb2a = g[o:o + 180]; o += 180
+            pairs = [(pol.critic_linear1.weight, gw1[:, :180].t()), (pol.actor_linear1.weight, gw1[:, 180:].t()),
+                     (pol.critic_linear1.bias, gb1[:180]), (pol.actor_linear1.bias, gb1[180:]),
+                     (pol.critic_linear2.weight, gw2c.view(1, 180)), (pol.critic_linear2.bias, gb2c),
+                     (pol.actor_linear2.weight, gw2a.t()), (pol.actor_linear2.bias, gb2a)]
+            for prm, grad in pairs:
+                if prm.grad is None:
+                    prm.grad = torch.empty_like(prm)
+                prm.grad.copy_(grad)
+            sums = g[o:o + 4] / float(n_total)
+        return sums[0], sums[1], sums[2]
+
     def update(self, obs, mask, action, qvals, weight=None):
         """One optimiser step on the given samples (this rank's share when distributed).  Returns the loss terms (global means).
         Rows with weight 0 are compacted away first (the network is not evaluated on them)."""
@@ -78,6 +136,15 @@ class A2CLearner:
         n_total = n_local.clone()
         if self.distributed:
             dist.all_reduce(n_total, group=self.group)
+        use_fused = self._can_fuse(obs) if self.fused is None else bool(self.fused)
+        if use_fused:
+            a, c, e = self._fused_gradients(obs, mask, action, qvals, float(n_total))
+            loss = ACTOR_COEFF * a + CRITIC_COEFF * c + ENTROPY_COEFF * e
+            self.optimizer.step()
+            out = {"actor_loss": a, "critic_loss": c, "entropy_loss": e, "ac_loss": loss, "samples": n_total.squeeze(0)}
+            for k2, v in out.items():
+                self.statistics[k2].append(v)
+            return out
         # rows without a legal action (stuck games) carry no sample
         legal_any = mask.bool().any(dim=1)
         w = legal_any.to(torch.float32) if weight is None else weight.to(torch.float32) * legal_any

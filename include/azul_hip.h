@@ -189,6 +189,18 @@ int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random,
                               int hidden_size, int num_actions, uint64_t seed, uint64_t counter, uint64_t *counter_dev, float *obs_dev,
                               uint8_t *mask_dev, uint8_t *player_dev, int32_t *action_dev, int32_t *reward_dev, uint8_t *done_dev,
                               float *value_dev, float *logp_dev, float *entropy_dev, uint8_t *status_dev, void *stream);
+/* The A2C update's gradients (Agent.update, agent.py:39-58) for n_samples recorded (observation, mask, action, q-value) samples:
+ * forward and backward of  L = mean_i( -logp_i[a_i] * adv_i + 0.5 * adv_i^2 + 0.1 * (-mean_{j legal} logp_i[j]) ),  adv = q - V
+ * (advantage not detached, like the reference), on the f32 matrix cores.  `inv_n_total` = 1 / (samples of the whole batch over
+ * all ranks): with data parallelism every rank calls this on its share and the flat gradients are summed.  Weight layouts as in
+ * azul_policy_forward plus w2a_dev = actor_linear2.weight as PyTorch stores it ([action][hidden]).  grad_dev receives 82085 floats:
+ * dw1t [136][360] | db1 [360] | dw2c [180] | db2c [1] | dw2a_t [180][180] | db2a [180] | sums over the samples used of the actor /
+ * critic / entropy terms and their count.  workspace_dev: workspace_parts x 82085 floats (one partial per workgroup; 256 parts use
+ * every CU).  Rows without a legal action carry no sample.  Only (136, 180, 180) is compiled in. */
+int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int32_t *action_dev, const float *qvals_dev, int n_samples,
+                       float inv_n_total, const float *w1t_dev, const float *b1_dev, const float *w2c_dev, const float *b2c_dev,
+                       const float *w2a_t_dev, const float *b2a_dev, const float *w2a_dev, int num_inputs, int hidden_size, int num_actions,
+                       float *workspace_dev, int workspace_parts, float *grad_dev, void *stream);
 /* discounted returns q[t] = r[t] + gamma * q[t+1] within episodes over a time-major window [n_steps][n_games]
  * (nn_runner.py:70-76); done[t][g] != 0 closes an episode at move t; carry_dev[n_games] (optional) chains windows. */
 int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, float *returns_dev, float *carry_dev,

@@ -783,7 +783,8 @@ int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random,
 int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int32_t *action_dev, const float *qvals_dev, int n_samples,
                        float inv_n_total, const float *w1t_dev, const float *b1_dev, const float *w2c_dev, const float *b2c_dev,
                        const float *w2a_t_dev, const float *b2a_dev, const float *w2a_dev, int num_inputs, int hidden_size, int num_actions,
-                       float *workspace_dev, int workspace_parts, float *grad_dev, void *stream)
+                       float *workspace_dev, int workspace_parts, float *grad_dev, const int32_t *index_dev, const int32_t *n_samples_dev,
+                       const float *inv_n_total_dev, void *stream)
 {
     if (num_inputs != PF_IN || hidden_size != PF_HID || num_actions != PF_ACT)
         return fail(AZUL_ERR_INVALID, "azul_a2c_gradients: only ActorCritic(136, 180, hidden 180) is compiled in");
@@ -797,9 +798,21 @@ int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int3
     const u32 parts = tiles < (u32)workspace_parts ? tiles : (u32)workspace_parts;
     if (parts == 0) { HIP_TRY(hipMemsetAsync(grad_dev, 0, sizeof(float) * LG_P_TOTAL, st)); return AZUL_SUCCESS; }
     PolicyWeights W = {w1t_dev, b1_dev, w2c_dev, b2c_dev, w2a_t_dev, b2a_dev};
-    LearnerArgs a = {obs_dev, mask_dev, action_dev, qvals_dev, (u32)n_samples, inv_n_total, w2a_dev, workspace_dev};
+    LearnerArgs a = {obs_dev, mask_dev, action_dev, qvals_dev, (u32)n_samples, inv_n_total, w2a_dev, workspace_dev, index_dev, n_samples_dev,
+                     inv_n_total_dev};
     hipLaunchKernelGGL(azul_a2c_grad_kernel, dim3(parts), dim3(64 * LG_WAVES), 0, st, W, a);
     hipLaunchKernelGGL(azul_a2c_reduce_kernel, dim3((LG_P_TOTAL + 255) / 256), dim3(256), 0, st, workspace_dev, parts, grad_dev);
+    HIP_TRY(hipGetLastError());
+    return AZUL_SUCCESS;
+}
+
+int azul_select_complete_samples(const uint8_t *done_dev, const int32_t *action_dev, int n_steps, int n_games, int32_t *index_dev,
+                                 int32_t *count_dev, void *stream)
+{
+    if (!done_dev || !action_dev || !index_dev || !count_dev || n_steps < 0 || n_games <= 0)
+        return fail(AZUL_ERR_INVALID, "azul_select_complete_samples: bad arguments");
+    hipLaunchKernelGGL(azul_select_complete_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, done_dev, action_dev, n_steps, (u32)n_games,
+                       index_dev, count_dev);
     HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }

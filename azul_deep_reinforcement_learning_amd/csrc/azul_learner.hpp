@@ -35,6 +35,9 @@ struct LearnerArgs {
     float inv_n;             // 1 / (samples of the whole batch)
     const float *w2a;        // [180 actions][180 hidden]: actor_linear2.weight as PyTorch stores it (for dh = dlogits @ W)
     float *partial;          // [gridDim.x][LG_P_TOTAL]
+    const i32 *index;        // optional [n]: sample s lives in row index[s] of obs / mask / action / qvals (a device-built selection)
+    const i32 *n_dev;        // optional: the sample count in device memory (overrides n; no host round trip to learn it)
+    const float *inv_n_dev;  // optional: 1 / (samples of the whole batch) in device memory (overrides inv_n)
 };
 
 __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeights W, LearnerArgs a)
@@ -48,7 +51,8 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
     __shared__ float lossS[4];
     const u32 tid = threadIdx.x, l = tid & 63u, c = l & 15u, q = l >> 4;
     const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const u32 n = a.n, n_tiles = (n + PF_GAMES - 1) / PF_GAMES;
+    const u32 n = a.n_dev ? (u32)*a.n_dev : a.n, n_tiles = (n + PF_GAMES - 1) / PF_GAMES;
+    const float inv_n = a.inv_n_dev ? *a.inv_n_dev : a.inv_n;
 
     // one-time LDS state: zero everything (the pad columns must stay zero: they feed the padded gradient tiles)
     for (u32 i = tid; i < (u32)(PF_GAMES * PF_OBS_STRIDE); i += 64u * LG_WAVES) obsS[i] = 0.f;
@@ -93,7 +97,9 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
         // ---- P0: observation tile -> LDS (rows past the batch are zero: they contribute nothing anywhere)
         for (u32 i = tid; i < (u32)(PF_GAMES * PF_IN); i += 64u * LG_WAVES) {
             u32 row = i / PF_IN, k = i - row * PF_IN;
-            obsS[row * PF_OBS_STRIDE + k] = s0 + row < n ? a.obs[(size_t)(s0 + row) * PF_IN + k] : 0.f;
+            float v = 0.f;
+            if (s0 + row < n) { const u32 src = a.index ? (u32)a.index[s0 + row] : s0 + row; v = a.obs[(size_t)src * PF_IN + k]; }
+            obsS[row * PF_OBS_STRIDE + k] = v;
         }
         __syncthreads();
         // ---- P1: hidden = relu(x @ w1t + b1)
@@ -156,7 +162,7 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
         if (w < 4u) {
             const u32 row = 4u * w + q, s = s0 + row;
             const bool valid = s < n;
-            const u32 sc = valid ? s : n - 1u;
+            const u32 sc_ = valid ? s : n - 1u, sc = a.index ? (u32)a.index[sc_] : sc_;
             float *lg = lgS + row * PF_LOG_STRIDE + 12u * c;       // lane c == 15 owns the pad columns 180..191
             float x[HEAD_PER_LANE];
             for (int j = 0; j < HEAD_PER_LANE; j++) x[j] = lg[j];
@@ -188,11 +194,11 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
             for (int j = 0; j < HEAD_PER_LANE; j++) {
                 bool ok = (okbits >> j) & 1u;
                 float gj = (j == aj ? -adv : 0.f) - ent_w;
-                float d = (gj - e[j] * invS * G) * a.inv_n;
+                float d = (gj - e[j] * invS * G) * inv_n;
                 lg[j] = (use && ok) ? d : 0.f;
             }
             if (c == 0u) {
-                dvS[row] = use ? (logp_a - adv) * a.inv_n : 0.f;
+                dvS[row] = use ? (logp_a - adv) * inv_n : 0.f;
                 if (use) {
                     l_actor += -logp_a * adv;
                     l_critic += adv * adv;
@@ -312,4 +318,43 @@ __global__ void __launch_bounds__(256) azul_a2c_reduce_kernel(const float *parti
     float s = 0.f;
     for (u32 i = 0; i < n_parts; i++) s += partial[(size_t)i * LG_P_TOTAL + p];
     grad[p] = s;
+}
+
+
+// Which steps of a window feed the update: those whose episode ends inside the window (exact Monte-Carlo returns, nn_runner.py:70-76)
+// and that carry an action.  done / action are time-major [T][N]; the selection is written game by game, steps ascending, as flat
+// indices t * N + g, and its length to count[0].  One workgroup; deterministic order.
+__global__ void __launch_bounds__(1024) azul_select_complete_kernel(const uint8_t *done, const i32 *action, int T, u32 N, i32 *index, i32 *count)
+{
+    __shared__ u32 scanS[1024];
+    __shared__ u32 baseS;
+    const u32 tid = threadIdx.x;
+    if (tid == 0u) baseS = 0u;
+    __syncthreads();
+    for (u32 g0 = 0; g0 < N; g0 += 1024u) {
+        const u32 g = g0 + tid;
+        int last = -1;
+        u32 kept = 0;
+        if (g < N) {
+            for (int t = T - 1; t >= 0; t--) if (done[(size_t)t * N + g] != 0) { last = t; break; }
+            for (int t = 0; t <= last; t++) kept += action[(size_t)t * N + g] >= 0 ? 1u : 0u;
+        }
+        // inclusive scan of `kept` over the 1024 threads (Hillis-Steele in LDS)
+        scanS[tid] = kept;
+        __syncthreads();
+        for (u32 o = 1; o < 1024u; o <<= 1) {
+            u32 v = tid >= o ? scanS[tid - o] : 0u;
+            __syncthreads();
+            scanS[tid] += v;
+            __syncthreads();
+        }
+        u32 pos = baseS + scanS[tid] - kept;
+        if (g < N)
+            for (int t = 0; t <= last; t++)
+                if (action[(size_t)t * N + g] >= 0) index[pos++] = (i32)((u32)t * N + g);
+        __syncthreads();
+        if (tid == 1023u) baseS += scanS[1023];
+        __syncthreads();
+    }
+    if (tid == 0u) count[0] = (i32)baseS;
 }

@@ -81,8 +81,10 @@ class A2CLearner:
         return (obs.is_cuda and hasattr(pol, "critic_linear1") and pol.critic_linear1.in_features == 136 and
                 pol.critic_linear1.out_features == 180 and pol.actor_linear2.out_features == 180 and pol.actor_linear1.out_features == 180)
 
-    def _fused_gradients(self, obs, mask, action, qvals, n_total):
-        """Fills every parameter's .grad from azul_a2c_gradients; returns (actor, critic, entropy) loss sums / n_total."""
+    def _fused_gradients(self, obs, mask, action, qvals, n_total=None, index=None, count=None, kweights=None):
+        """Fills every parameter's .grad from azul_a2c_gradients; returns (actor, critic, entropy, samples): loss sums / n_total.
+        Either `n_total` (host number; all rows are samples) or `index` + `count` (device selection of rows; the global count
+        is then formed on the device, no host round trip).  `kweights`: the k-major weight copies a PolicyRollout keeps."""
         import ctypes as C
         from . import _lib as L
         pol, dev = self.policy, obs.device
@@ -90,19 +92,32 @@ class A2CLearner:
             self._ws = {"ws": torch.empty(256, N_PARAMS + 4, device=dev), "grad": torch.empty(N_PARAMS + 4, device=dev)}
         ws = self._ws
         with torch.no_grad():
-            w1t = torch.cat([pol.critic_linear1.weight, pol.actor_linear1.weight], dim=0).t().contiguous()
-            b1 = torch.cat([pol.critic_linear1.bias, pol.actor_linear1.bias]).contiguous()
-            w2c = pol.critic_linear2.weight.reshape(-1).contiguous()
+            if kweights is None:
+                w1t = torch.cat([pol.critic_linear1.weight, pol.actor_linear1.weight], dim=0).t().contiguous()
+                b1 = torch.cat([pol.critic_linear1.bias, pol.actor_linear1.bias]).contiguous()
+                w2c = pol.critic_linear2.weight.reshape(-1).contiguous()
+                w2a_t = pol.actor_linear2.weight.t().contiguous()
+            else:
+                w1t, b1, w2c, w2a_t = kweights["w1t"], kweights["b1"], kweights["w2c"], kweights["w2a_t"]
             w2a = pol.actor_linear2.weight.contiguous()
-            w2a_t = w2a.t().contiguous()
             obs = obs.contiguous().float()
             mask = mask.contiguous().to(torch.uint8)
             action = action.contiguous().to(torch.int32)
             qvals = qvals.contiguous().float()
-            p = lambda t: C.c_void_p(t.data_ptr())
-            L.check(L.lib.azul_a2c_gradients(p(obs), p(mask), p(action), p(qvals), int(obs.shape[0]), C.c_float(1.0 / float(n_total)),
+            p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+            inv_dev = None
+            if index is not None:
+                n_dev = count.to(torch.float32)
+                if self.distributed:
+                    dist.all_reduce(n_dev, group=self.group)
+                inv_dev = (1.0 / n_dev.clamp(min=1.0)).contiguous()
+                inv_host = 1.0
+            else:
+                n_dev = None
+                inv_host = 1.0 / float(n_total)
+            L.check(L.lib.azul_a2c_gradients(p(obs), p(mask), p(action), p(qvals), int(obs.shape[0]), C.c_float(inv_host),
                                              p(w1t), p(b1), p(w2c), p(pol.critic_linear2.bias), p(w2a_t), p(pol.actor_linear2.bias), p(w2a),
-                                             136, 180, 180, p(ws["ws"]), 256, p(ws["grad"]),
+                                             136, 180, 180, p(ws["ws"]), 256, p(ws["grad"]), p(index), p(count), p(inv_dev),
                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
             g = ws["grad"]
             if self.distributed:
@@ -122,8 +137,21 @@ class A2CLearner:
                 if prm.grad is None:
                     prm.grad = torch.empty_like(prm)
                 prm.grad.copy_(grad)
-            sums = g[o:o + 4] / float(n_total)
-        return sums[0], sums[1], sums[2]
+            if index is not None:
+                sums = g[o:o + 3] * inv_dev
+                samples = n_dev.squeeze(0)
+            else:
+                sums = g[o:o + 3] / float(n_total)
+                samples = torch.as_tensor(float(n_total), device=dev)
+        return sums[0], sums[1], sums[2], samples
+
+    def _finish_fused(self, a, c, e, samples):
+        loss = ACTOR_COEFF * a + CRITIC_COEFF * c + ENTROPY_COEFF * e
+        self.optimizer.step()
+        out = {"actor_loss": a, "critic_loss": c, "entropy_loss": e, "ac_loss": loss, "samples": samples}
+        for k2, v in out.items():
+            self.statistics[k2].append(v)
+        return out
 
     def update(self, obs, mask, action, qvals, weight=None):
         """One optimiser step on the given samples (this rank's share when distributed).  Returns the loss terms (global means).
@@ -138,13 +166,7 @@ class A2CLearner:
             dist.all_reduce(n_total, group=self.group)
         use_fused = self._can_fuse(obs) if self.fused is None else bool(self.fused)
         if use_fused:
-            a, c, e = self._fused_gradients(obs, mask, action, qvals, float(n_total))
-            loss = ACTOR_COEFF * a + CRITIC_COEFF * c + ENTROPY_COEFF * e
-            self.optimizer.step()
-            out = {"actor_loss": a, "critic_loss": c, "entropy_loss": e, "ac_loss": loss, "samples": n_total.squeeze(0)}
-            for k2, v in out.items():
-                self.statistics[k2].append(v)
-            return out
+            return self._finish_fused(*self._fused_gradients(obs, mask, action, qvals, n_total=float(n_total)))
         # rows without a legal action (stuck games) carry no sample
         legal_any = mask.bool().any(dim=1)
         w = legal_any.to(torch.float32) if weight is None else weight.to(torch.float32) * legal_any
@@ -167,9 +189,26 @@ class A2CLearner:
             self.statistics[k2].append(v)
         return out
 
-    def update_from_windows(self, trajectories, complete_only=True):
+    def update_from_windows(self, trajectories, complete_only=True, kweights=None):
         """`trajectories`: the per-part dicts PolicyRollout.run_window returns (opponent="random": every record is one agent
-        step).  Uses the steps whose episode finished inside the window (exact Monte-Carlo returns, the reference's qvals)."""
+        step).  Uses the steps whose episode finished inside the window (exact Monte-Carlo returns, the reference's qvals).
+        With one part on the GPU the whole update stays on the device: azul_select_complete_samples picks the steps,
+        azul_a2c_gradients reads them through the index list -- no compaction copies, no host round trip."""
+        tr0 = trajectories[0]
+        if len(trajectories) == 1 and complete_only and (self._can_fuse(tr0["obs"]) if self.fused is None else bool(self.fused)):
+            import ctypes as C
+            from . import _lib as L
+            T, N = tr0["action"].shape
+            dev = tr0["obs"].device
+            if getattr(self, "_sel", None) is None or self._sel[0].numel() != T * N or self._sel[0].device != dev:
+                self._sel = (torch.empty(T * N, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+            index, count = self._sel
+            L.check(L.lib.azul_select_complete_samples(C.c_void_p(tr0["done"].data_ptr()), C.c_void_p(tr0["action"].data_ptr()), T, N,
+                                                       C.c_void_p(index.data_ptr()), C.c_void_p(count.data_ptr()),
+                                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            return self._finish_fused(*self._fused_gradients(
+                tr0["obs"][:T].reshape(T * N, -1), tr0["mask"][:T].reshape(T * N, -1), tr0["action"].reshape(-1), tr0["returns"].reshape(-1),
+                index=index, count=count, kweights=kweights))
         obs, mask, action, ret = [], [], [], []
         for tr in trajectories:
             T = tr["action"].shape[0]

@@ -107,6 +107,10 @@ class PolicyRollout:
                 else:
                     setattr(self, name, v.contiguous().clone())
 
+    def kweights(self):
+        """The k-major weight copies (refresh_weights keeps them current): the learner's gradient kernel reads the same layouts."""
+        return {"w1t": self.w1t, "b1": self.b1, "w2c": self.w2c, "w2a_t": self.w2a_t}
+
     # one move of one part, enqueued on the current stream
     def _move(self, p, t):
         env, tr, w = self.envs[p], self.traj[p], self.work[p]

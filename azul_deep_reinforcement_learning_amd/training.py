@@ -65,7 +65,7 @@ class BatchedTrainer:
     def run_batch(self):
         tr = self.rollout.run_window(self.gamma)
         self.rollout.synchronize()
-        out = self.learner.update_from_windows(tr)
+        out = self.learner.update_from_windows(tr, kweights=self.rollout.kweights())
         self.rollout.refresh_weights()
         self.batch += 1
         episodes, game = self._game_statistics()

@@ -97,7 +97,7 @@ def train(a):
     def one_window():
         tr = ro.run_window()
         ro.synchronize()
-        out = learner.update_from_windows(tr)
+        out = learner.update_from_windows(tr, kweights=ro.kweights())
         ro.refresh_weights()
         return out
 

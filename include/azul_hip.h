@@ -196,11 +196,19 @@ int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random,
  * azul_policy_forward plus w2a_dev = actor_linear2.weight as PyTorch stores it ([action][hidden]).  grad_dev receives 82085 floats:
  * dw1t [136][360] | db1 [360] | dw2c [180] | db2c [1] | dw2a_t [180][180] | db2a [180] | sums over the samples used of the actor /
  * critic / entropy terms and their count.  workspace_dev: workspace_parts x 82085 floats (one partial per workgroup; 256 parts use
- * every CU).  Rows without a legal action carry no sample.  Only (136, 180, 180) is compiled in. */
+ * every CU).  Rows without a legal action carry no sample.  Optional device-side inputs: index_dev [n] (sample s is row index_dev[s]
+ * of the arrays), n_samples_dev (the count; n_samples is then only an upper bound), inv_n_total_dev.  Only (136, 180, 180) is compiled in. */
 int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int32_t *action_dev, const float *qvals_dev, int n_samples,
                        float inv_n_total, const float *w1t_dev, const float *b1_dev, const float *w2c_dev, const float *b2c_dev,
                        const float *w2a_t_dev, const float *b2a_dev, const float *w2a_dev, int num_inputs, int hidden_size, int num_actions,
-                       float *workspace_dev, int workspace_parts, float *grad_dev, void *stream);
+                       float *workspace_dev, int workspace_parts, float *grad_dev, const int32_t *index_dev, const int32_t *n_samples_dev,
+                       const float *inv_n_total_dev, void *stream);
+/* Which steps of a window feed the update (NNRunner.train uses whole episodes, nn_runner.py:59-76): the steps whose episode ends
+ * inside the window and that carry an action (>= 0).  done / action are time-major [n_steps][n_games]; index_dev receives the flat
+ * indices t * n_games + g (game by game, steps ascending), count_dev[0] their number.  Feeds azul_a2c_gradients' index_dev /
+ * n_samples_dev without a host round trip. */
+int azul_select_complete_samples(const uint8_t *done_dev, const int32_t *action_dev, int n_steps, int n_games, int32_t *index_dev,
+                                 int32_t *count_dev, void *stream);
 /* discounted returns q[t] = r[t] + gamma * q[t+1] within episodes over a time-major window [n_steps][n_games]
  * (nn_runner.py:70-76); done[t][g] != 0 closes an episode at move t; carry_dev[n_games] (optional) chains windows. */
 int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, float *returns_dev, float *carry_dev,

@@ -270,3 +270,29 @@ def test_fused_update_lands_on_the_reference_parameters(golden_dir):
     for k in ("actor_loss", "critic_loss", "entropy_loss", "ac_loss"):
         assert np.isclose(float(out[k]), float(g[k][0]), rtol=2e-5, atol=1e-6), k
     _check_after(net, g, atol=3e-6)
+
+
+@pytest.mark.gpu
+def test_device_side_sample_selection_equals_host_compaction(golden_dir):
+    """update_from_windows on the GPU (azul_select_complete_samples + indexed azul_a2c_gradients, nothing leaves the device) must give
+    the update that explicit compaction of the same window gives (the sample order differs: game-major vs time-major)."""
+    from azul_deep_reinforcement_learning_amd import PolicyRollout
+    from azul_deep_reinforcement_learning_amd.learner import A2CLearner, complete_episode_samples
+    g0 = _golden(golden_dir)
+    nets = [_net_from(g0, "before_", "cuda") for _ in range(2)]
+    ro = PolicyRollout(nets[0], n_games=300, parts=1, seed_base=11, window=50, opponent="random", persistent=True)
+    tr = ro.run_window()
+    ro.synchronize()
+    t = tr[0]
+    T, N = t["action"].shape
+    keep = (complete_episode_samples(t["done"]) & (t["action"] >= 0)).reshape(-1)
+    out_a = A2CLearner(nets[0], distributed=False, fused=True).update_from_windows(tr, kweights=ro.kweights())
+    out_b = A2CLearner(nets[1], distributed=False, fused=True).update(t["obs"][:T].reshape(T * N, -1)[keep], t["mask"][:T].reshape(T * N, -1)[keep],
+                                                                      t["action"].reshape(-1)[keep], t["returns"].reshape(-1)[keep])
+    assert int(out_a["samples"]) == int(keep.sum()) == int(out_b["samples"]) and int(keep.sum()) > 1000
+    for k in ("actor_loss", "critic_loss", "entropy_loss", "ac_loss"):
+        assert np.isclose(float(out_a[k]), float(out_b[k]), rtol=1e-5, atol=1e-6), k
+    for (name, pa), (_, pb) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        assert torch.allclose(pa, pb, rtol=0, atol=2e-6), name
+        scale = float(pb.grad.abs().max()) + 1e-12
+        assert float((pa.grad - pb.grad).abs().max()) <= 2e-5 * scale + 1e-7, name

@@ -336,8 +336,13 @@ __global__ void __launch_bounds__(1024) azul_select_complete_kernel(const uint8_
         int last = -1;
         u32 kept = 0;
         if (g < N) {
-            for (int t = T - 1; t >= 0; t--) if (done[(size_t)t * N + g] != 0) { last = t; break; }
-            for (int t = 0; t <= last; t++) kept += action[(size_t)t * N + g] >= 0 ? 1u : 0u;
+            // one pass without a data-dependent exit (the loads pipeline): running count of usable steps, latched at every `done`
+            u32 run = 0;
+#pragma unroll 8
+            for (int t = 0; t < T; t++) {
+                run += action[(size_t)t * N + g] >= 0 ? 1u : 0u;
+                if (done[(size_t)t * N + g] != 0) { kept = run; last = t; }
+            }
         }
         // inclusive scan of `kept` over the 1024 threads (Hillis-Steele in LDS)
         scanS[tid] = kept;

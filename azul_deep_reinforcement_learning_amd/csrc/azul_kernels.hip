@@ -7,9 +7,12 @@
 // the mask/observation write-out and the fp64 weight division.
 //
 // Kernels
-//   azul_seed_kernel      one THREAD per game: CPython init_by_array is a strictly sequential 1247-step recurrence
-//   azul_op_kernel        one wave per game: every single-call rule / runner entry point of the ABI
-//   azul_selfplay_kernel  one wave per game, state register-resident across n_steps env moves (the hot path)
+//   azul_seed_kernel            one THREAD per game: CPython init_by_array is a strictly sequential 1247-step recurrence
+//   azul_op_kernel              one wave per game: every single-call rule / runner entry point of the ABI
+//   azul_selfplay_kernel        one wave per game, state register-resident across n_steps env moves (the hot path)
+//   azul_returns_kernel         discounted returns over a trajectory window
+//   azul_policy.hpp             policy head, fused ActorCritic forward, persistent policy rollout (rows N1 / N2)
+//   azul_learner.hpp            A2C gradients (forward + backward on the matrix cores), partial reduction, sample selection (row N2)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>

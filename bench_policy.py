@@ -32,24 +32,43 @@ def main():
     from azul_deep_reinforcement_learning_amd import BatchedActorCritic, PolicyRollout
     if a.train:
         return train(a)
+    import os
+    import torch.distributed as dist
+    # N > 1 (python -m torch.distributed.run --nproc-per-node N bench_policy.py): games shard by global id, every rank keeps its own
+    # trajectories (they feed that rank's share of the data-parallel update); the value is the aggregate over the ranks
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("AZUL_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        a.no_compare = True
 
     def measure(parts, fused_mlp, persistent=False):
         torch.manual_seed(0)
         net = BatchedActorCritic(136, 180, 180)
-        ro = PolicyRollout(net, n_games=a.games, parts=parts, window=a.window, use_graph=not a.no_graph,
-                           fused_head=not a.torch_head, fused_mlp=fused_mlp, persistent=persistent)
+        ro = PolicyRollout(net, n_games=a.games, parts=parts, window=a.window, use_graph=not a.no_graph, seed_base=rank * a.games,
+                           sample_seed=0x5EED + rank, fused_head=not a.torch_head, fused_mlp=fused_mlp, persistent=persistent)
         for _ in range(3):
             ro.run_window()
         ro.synchronize()
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         t0 = time.perf_counter()
         for _ in range(a.windows):
             ro.run_window()
         ro.synchronize()
         torch.cuda.synchronize()
-        return ro, time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return ro, dt
 
-    moves = a.games * a.window * a.windows
+    moves = a.games * world * a.window * a.windows
     extra = {}
     if not a.no_compare and not a.torch_mlp:
         # comparison runs go FIRST: measured after the one-launch-per-window kernel has run in the same process, the PyTorch-GEMM
@@ -66,12 +85,15 @@ def main():
     ro, dt = measure(a.parts, not a.torch_mlp, persistent=not a.per_move)
     c = ro.counters()
     out = {"metric": "Azul env steps/sec (ActorCritic policy self-play, trajectories recorded)", "value": moves / dt,
-           "unit": "env steps/s", "n_gpus": 1, "config": {"workload": "BASELINE configs[2]", "games": a.games,
+           "unit": "env steps/s", "n_gpus": world, "config": {"workload": "BASELINE configs[2]", "games_per_gpu": a.games,
            "stream_parts": a.parts, "moves_per_graph": a.window, "hip_graph": ro.use_graph, "fused_head": ro.fused_head, "fused_mlp": ro.fused_mlp,
            "one_launch_per_window": ro.persistent, "graph_error": ro.graph_error}, "ms_per_step": dt / (a.window * a.windows) * 1e3,
            "episodes_finished": c["episodes"], "stuck": c["stuck"], "dtype": "fp32 policy / u8 env", "data": "synthetic"}
     out.update(extra)
-    print(json.dumps(out))
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def train(a):

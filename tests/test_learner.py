@@ -296,3 +296,20 @@ def test_device_side_sample_selection_equals_host_compaction(golden_dir):
         assert torch.allclose(pa, pb, rtol=0, atol=2e-6), name
         scale = float(pb.grad.abs().max()) + 1e-12
         assert float((pa.grad - pb.grad).abs().max()) <= 2e-5 * scale + 1e-7, name
+
+
+@pytest.mark.gpu
+def test_window_without_a_finished_episode_is_a_no_op(golden_dir):
+    """No episode ends inside a 4-step window: zero samples, zero gradients, parameters untouched, no NaNs."""
+    from azul_deep_reinforcement_learning_amd import PolicyRollout
+    from azul_deep_reinforcement_learning_amd.learner import A2CLearner
+    net = _net_from(_golden(golden_dir), "before_", "cuda")
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    ro = PolicyRollout(net, n_games=64, parts=1, seed_base=3, window=4, opponent="random", persistent=True)
+    tr = ro.run_window()
+    ro.synchronize()
+    assert int(tr[0]["done"].sum()) == 0
+    out = A2CLearner(net, distributed=False).update_from_windows(tr, kweights=ro.kweights())
+    assert int(out["samples"]) == 0 and all(np.isfinite(float(out[k])) for k in ("actor_loss", "critic_loss", "entropy_loss", "ac_loss"))
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k]), k

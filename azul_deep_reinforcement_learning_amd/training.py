@@ -62,16 +62,28 @@ class BatchedTrainer:
         return n, {k: (float(sums[i] - sums0[i]) / n if n else float("nan")) for i, k in enumerate(STAT_KEYS)}
 
     # ---- one batch -----------------------------------------------------------------------------------
-    def run_batch(self):
+    def run_batch(self, collect_stats=True):
+        """One rollout window + one update.  collect_stats=False keeps everything on the device (no host round trip): the
+        episode statistics and the reward keep accumulating and are reported by the next collecting call, like the reference's
+        GameStatistics buffers between two get_stats() calls (game_runner.py:17-22)."""
         tr = self.rollout.run_window(self.gamma)
         self.rollout.synchronize()
         out = self.learner.update_from_windows(tr, kweights=self.rollout.kweights())
         self.rollout.refresh_weights()
         self.batch += 1
+        r = sum(part["reward"].sum() for part in tr)
+        self._reward_acc = r if getattr(self, "_reward_acc", None) is None else self._reward_acc + r
+        if not collect_stats:
+            return None
         episodes, game = self._game_statistics()
-        total_reward = sum(float(part["reward"].sum()) for part in tr)
-        row = {"batch": self.batch, "reward": total_reward / episodes if episodes else float("nan")}
-        row.update({k: float(out[k]) for k in AGENT_STAT_KEYS[1:]})
+        row = {"batch": self.batch, "reward": float(self._reward_acc) / episodes if episodes else float("nan")}
+        self._reward_acc = None
+        # the loss terms of every update since the last collecting call, averaged (AgentStatistics.get_stats, agent.py:19-24)
+        mark = getattr(self, "_loss_mark", 0)
+        for k in AGENT_STAT_KEYS[1:]:
+            vals = self.learner.statistics[k][mark:]
+            row[k] = float(torch.stack([torch.as_tensor(v, dtype=torch.float32, device=self.rollout.device) for v in vals]).mean())
+        self._loss_mark = len(self.learner.statistics["ac_loss"])
         row.update(game)
         for k, v in row.items():
             self.history[k].append(v)
@@ -89,8 +101,10 @@ class BatchedTrainer:
                     csv.writer(fh, delimiter=",", quotechar='"', quoting=csv.QUOTE_MINIMAL).writerow(
                         ["batch"] + list(AGENT_STAT_KEYS) + list(STAT_KEYS))
         last = None
-        for _ in range(batches):
-            last = self.run_batch()
+        for i in range(batches):
+            logging = (self.batch + 1) % log_every == 0 or i == batches - 1
+            row = self.run_batch(collect_stats=logging)
+            last = row if row is not None else last
             if path is not None and self.batch % log_every == 0:
                 with open(path, mode="a+", newline="") as fh:                               # nn_runner.py:80-82
                     csv.writer(fh, delimiter=",", quotechar='"', quoting=csv.QUOTE_MINIMAL).writerow(
@@ -132,3 +146,5 @@ class BatchedTrainer:
         torch.cuda.synchronize(ro.device)
         self.batch = int(ck["batch"])
         self._stat_base = self._stat_totals()
+        self._reward_acc = None
+        self._loss_mark = len(self.learner.statistics["ac_loss"])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B two builds of libazulhip.so with bench.py (development helper): tests/ab_bench.sh a.so b.so
+# A/B two builds of libazulhip.so with bench.py (development helper): tools/ab_bench.sh a.so b.so
 L=azul_deep_reinforcement_learning_amd/libazulhip.so
 cp $L /tmp/orig.so
 for rep in 1 2; do

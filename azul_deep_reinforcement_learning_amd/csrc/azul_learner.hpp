@@ -316,7 +316,15 @@ __global__ void __launch_bounds__(256) azul_a2c_reduce_kernel(const float *parti
     const u32 p = blockIdx.x * 256u + threadIdx.x;
     if (p >= (u32)LG_P_TOTAL) return;
     float s = 0.f;
-    for (u32 i = 0; i < n_parts; i++) s += partial[(size_t)i * LG_P_TOTAL + p];
+    u32 i = 0;
+    for (; i + 8u <= n_parts; i += 8u) {                 // eight loads in flight, added in workgroup order (the order is what is fixed)
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = partial[(size_t)(i + j) * LG_P_TOTAL + p];
+#pragma unroll
+        for (int j = 0; j < 8; j++) s += v[j];
+    }
+    for (; i < n_parts; i++) s += partial[(size_t)i * LG_P_TOTAL + p];
     grad[p] = s;
 }
 

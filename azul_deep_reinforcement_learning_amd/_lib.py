@@ -16,6 +16,7 @@ POOL_RANDOM, POOL_LID = 0, 1
 FIRST_RANDOM = 0
 PERSP_PLAYER0, PERSP_PLAYER1, PERSP_CURRENT = 0, 1, 2
 FLAG_END_OF_ROUND, FLAG_END_OF_GAME, FLAG_ENDED_FLAG = 1, 2, 4
+POLICY_ARGMAX = 0xFFFFFFFFFFFFFFFF        # `seed` value: np.argmax instead of sampling (agent.py action_selection="Max")
 
 _vp, _i, _u64, _u32 = C.c_void_p, C.c_int, C.c_uint64, C.c_uint32
 

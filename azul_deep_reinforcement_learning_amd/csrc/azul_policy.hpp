@@ -90,6 +90,7 @@ __device__ __forceinline__ void policy_head_rows(const float (&x)[HEAD_PER_LANE]
     // inverse CDF in ascending action order (agent.py:69): exclusive prefix of the lane sums inside the row, then the lane's 12 steps
     float incl = mine;
     incl += dpp_f<DPP_SHR1>(incl); incl += dpp_f<DPP_SHR2>(incl); incl += dpp_f<DPP_SHR4>(incl); incl += dpp_f<DPP_SHR8>(incl);
+    const bool argmax = seed == AZUL_POLICY_ARGMAX;      // action_selection == "Max" (agent.py:70-71): np.argmax, first maximum
     const float u = (float)(philox_u32(seed, counter, g) >> 8) * (1.0f / 16777216.0f);       // [0, 1), 24 bits
     const float target = u * S;
     float cum = incl - mine;
@@ -99,7 +100,7 @@ __device__ __forceinline__ void policy_head_rows(const float (&x)[HEAD_PER_LANE]
         bool ok = (okbits >> j) & 1u;
         cum += e[j];
         if (ok) { lastok = j; zlast = z[j]; }
-        if (ok && pick < 0 && target < cum) { pick = j; zpick = z[j]; }
+        if (ok && pick < 0 && (argmax ? z[j] == 0.f : target < cum)) { pick = j; zpick = z[j]; }
     }
     const u64 hit = __ballot(pick >= 0), any = __ballot(okbits != 0u);
     const u32 hit16 = (u32)(hit >> (16u * grp)) & 0xffffu, any16 = (u32)(any >> (16u * grp)) & 0xffffu;

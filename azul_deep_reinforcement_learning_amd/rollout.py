@@ -33,7 +33,8 @@ def _p(t):
 
 class PolicyRollout:
     def __init__(self, policy, n_games=4096, parts=1, rules={"first_player": "Random", "tile_pool": "Lid"}, seed_base=0,
-                 device=None, window=32, use_graph=True, fused_head=True, sample_seed=0x5EED, opponent=None, fused_mlp=True, persistent=False):
+                 device=None, window=32, use_graph=True, fused_head=True, sample_seed=0x5EED, opponent=None, fused_mlp=True, persistent=False,
+                 action_selection="Distribution"):
         """opponent=None: the policy moves for both players (flat self-play, one record per env move).
         opponent="random": the reference's training setup -- the policy is player 1 of GameRunner, the opponent a RandomAgent
         inside the env step (game_runner.py:43-47); one record per AGENT step, observations from the agent's perspective."""
@@ -49,7 +50,10 @@ class PolicyRollout:
                               policy.critic_linear1.out_features == 180 and policy.actor_linear2.out_features == L.NUM_ACTIONS)
         # persistent=True: the whole window runs in ONE launch per part (azul_batch_policy_rollout); same results
         self.persistent = bool(persistent and self.fused_mlp)
-        self.sample_seed = int(sample_seed)
+        # Agent.get_ac_output's two modes (agent.py:64-72): sample from the masked softmax, or take its first maximum
+        assert action_selection in ("Distribution", "Max") and (fused_head or action_selection == "Distribution")
+        self.action_selection = action_selection
+        self.sample_seed = L.POLICY_ARGMAX if action_selection == "Max" else int(sample_seed)
         self.envs, self.streams, self.work, self.traj, self.graphs = [], [], [], [], []
         self.refresh_weights()
         d, h, T = self.device, self.h, window

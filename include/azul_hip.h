@@ -156,6 +156,9 @@ int azul_batch_agent_step(azul_batch_t *b, const int32_t *actions_dev, const uin
                           uint8_t *mask_next_dev /*[N][180]*/, uint8_t *player_next_dev /*[N]*/, void *stream);
 /* observation + mask + player to move in one launch (the first decision of a rollout) */
 int azul_batch_observe_all(azul_batch_t *b, int perspective, float *obs_dev, uint8_t *mask_dev, uint8_t *player_dev, void *stream);
+/* `seed` value that switches the policy entries below from sampling ("Distribution") to np.argmax over the masked softmax
+ * ("Max": the first maximum in action order), the two action_selection modes of Agent.get_ac_output (agent.py:64-72) */
+#define AZUL_POLICY_ARGMAX 0xFFFFFFFFFFFFFFFFull
 /* policy head for a batch of action logits [N][180] + legal masks [N][180]: masked softmax, ONE categorical sample per game
  * (agent.py:64-72), the log-probability of that action and the entropy term -mean(log p over legal actions)
  * (nn_runner.py:32-40).  fp32; randomness = Philox4x32-10(seed, counter [+ *counter_dev], game): keep the step counter in

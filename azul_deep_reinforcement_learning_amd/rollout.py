@@ -195,13 +195,21 @@ class PolicyRollout:
         `obs`, `mask`, `player` have T+1 slots: slot t is what the policy saw at move t)."""
         if self.use_graph and gamma != getattr(self, "gamma", gamma):
             raise ValueError("gamma is baked into the captured graph")
+        cur = torch.cuda.current_stream(self.device)
         for p in range(self.parts):
+            self.streams[p].wait_stream(cur)             # e.g. the optimiser step / refresh_weights enqueued by the caller
             with torch.cuda.stream(self.streams[p]):
                 if self.use_graph:
                     self.graphs[p].replay()
                 else:
                     self._window(p, gamma)
         return self.traj
+
+    def join(self):
+        """Make the caller's current stream wait for the window(s) in flight -- on the device, the host does not block."""
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            cur.wait_stream(s)
 
     def synchronize(self):
         for s in self.streams:

@@ -67,7 +67,7 @@ class BatchedTrainer:
         episode statistics and the reward keep accumulating and are reported by the next collecting call, like the reference's
         GameStatistics buffers between two get_stats() calls (game_runner.py:17-22)."""
         tr = self.rollout.run_window(self.gamma)
-        self.rollout.synchronize()
+        self.rollout.join()                              # device-side dependency: the host keeps enqueueing
         out = self.learner.update_from_windows(tr, kweights=self.rollout.kweights())
         self.rollout.refresh_weights()
         self.batch += 1

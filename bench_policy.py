@@ -118,7 +118,7 @@ def train(a):
 
     def one_window():
         tr = ro.run_window()
-        ro.synchronize()
+        ro.join()                                           # device-side dependency between the streams; no host sync per window
         out = learner.update_from_windows(tr, kweights=ro.kweights())
         ro.refresh_weights()
         return out

@@ -16,6 +16,7 @@ POOL_RANDOM, POOL_LID = 0, 1
 FIRST_RANDOM = 0
 PERSP_PLAYER0, PERSP_PLAYER1, PERSP_CURRENT = 0, 1, 2
 FLAG_END_OF_ROUND, FLAG_END_OF_GAME, FLAG_ENDED_FLAG = 1, 2, 4
+A2C_FLAT_SIZE = 82082          # k-major flat layout of the parameters / gradient / Adam moments (82081 + 1 pad)
 POLICY_ARGMAX = 0xFFFFFFFFFFFFFFFF        # `seed` value: np.argmax instead of sampling (agent.py action_selection="Max")
 
 _vp, _i, _u64, _u32 = C.c_void_p, C.c_int, C.c_uint64, C.c_uint32
@@ -58,6 +59,7 @@ SIGNATURES = {
     "azul_policy_forward": (_i, [_vp] * 8 + [_i, _i, _i, _u64, _u64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "azul_batch_policy_rollout": (_i, [_vp, _i, _i] + [_vp] * 6 + [_i, _i, _i, _u64, _u64, _vp] + [_vp] * 10 + [_vp]),
     "azul_a2c_gradients": (_i, [_vp, _vp, _vp, _vp, _i, C.c_float] + [_vp] * 7 + [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "azul_a2c_apply_adam": (_i, [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _i] + [_vp] * 8 + [_vp]),
     "azul_select_complete_samples": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "azul_discounted_returns": (_i, [_vp, _vp, _vp, _vp, C.c_float, _i, _i, _vp]),
     "azul_batch_sample_mask": (_i, [_vp, _vp, _vp, _vp, _vp]),

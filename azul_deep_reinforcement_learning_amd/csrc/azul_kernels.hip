@@ -14,6 +14,7 @@
 //   azul_policy.hpp             policy head, fused ActorCritic forward, persistent policy rollout (rows N1 / N2)
 //   azul_learner.hpp            A2C gradients (forward + backward on the matrix cores), partial reduction, sample selection (row N2)
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -805,6 +806,21 @@ int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int3
                      inv_n_total_dev};
     hipLaunchKernelGGL(azul_a2c_grad_kernel, dim3(parts), dim3(64 * LG_WAVES), 0, st, W, a);
     hipLaunchKernelGGL(azul_a2c_reduce_kernel, dim3((LG_P_TOTAL + 255) / 256), dim3(256), 0, st, workspace_dev, parts, grad_dev);
+    HIP_TRY(hipGetLastError());
+    return AZUL_SUCCESS;
+}
+
+int azul_a2c_apply_adam(const float *grad_dev, float *flat_dev, float *exp_avg_dev, float *exp_avg_sq_dev, float lr, float beta1, float beta2,
+                        float eps, int step, float *critic1_w, float *critic1_b, float *critic2_w, float *critic2_b, float *actor1_w,
+                        float *actor1_b, float *actor2_w, float *actor2_b, void *stream)
+{
+    if (!grad_dev || !flat_dev || !exp_avg_dev || !exp_avg_sq_dev || step < 1 || !critic1_w || !critic1_b || !critic2_w || !critic2_b ||
+        !actor1_w || !actor1_b || !actor2_w || !actor2_b)
+        return fail(AZUL_ERR_INVALID, "azul_a2c_apply_adam: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    ModuleParams P = {critic1_w, critic1_b, critic2_w, critic2_b, actor1_w, actor1_b, actor2_w, actor2_b};
+    hipLaunchKernelGGL(azul_a2c_apply_kernel, dim3((LG_P_PARAMS + 255) / 256), dim3(256), 0, (hipStream_t)stream, grad_dev, flat_dev, exp_avg_dev,
+                       exp_avg_sq_dev, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), P);
     HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }

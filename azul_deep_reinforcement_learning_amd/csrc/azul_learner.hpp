@@ -13,14 +13,15 @@
 // hence   dL/dv       = ( logp[a] - adv ) / n
 //         dL/dlogp_j  = ( -adv [j == a]  -  0.1 / |legal| [j legal] ) / n
 //         dL/dlogit_k = dL/dlogp_k - softmax_k * sum_j dL/dlogp_j            (masked log-softmax; 0 for illegal k)
-// Gradient vector layout (k-major like the forward weights): dw1t [136][360] | db1 [360] | dw2c [180] | db2c [1] | dw2a_t [180][180]
-// | db2a [180]  = 82081 floats, followed by the four loss sums (actor, critic, entropy, count of samples used).
+// Gradient vector layout (k-major like the forward weights): dw1t [136][360] | db1 [360] | dw2c [180] | db2c [1]
+// | (1 pad) | dw2a_t [180][180] | db2a [180]  = 82082 floats, followed by the four loss sums (actor, critic, entropy, count of
+// samples used).  The same layout holds the k-major master copy of the parameters and Adam's moments (azul_a2c_apply_kernel).
 #pragma once
 
 constexpr int LG_P_W1 = 0, LG_P_B1 = LG_P_W1 + PF_IN * PF_H2, LG_P_W2C = LG_P_B1 + PF_H2, LG_P_B2C = LG_P_W2C + PF_HID,
-              LG_P_W2A = LG_P_B2C + 1, LG_P_B2A = LG_P_W2A + PF_HID * PF_ACT, LG_P_PARAMS = LG_P_B2A + PF_ACT,
-              LG_P_LOSS = LG_P_PARAMS, LG_P_TOTAL = LG_P_PARAMS + 4;
-static_assert(LG_P_PARAMS == 82081, "ActorCritic(136, 180, 180) has 82081 parameters");
+              LG_P_W2A = LG_P_B2C + 2 /* one pad float: the matrix starts 8-byte aligned */, LG_P_B2A = LG_P_W2A + PF_HID * PF_ACT,
+              LG_P_PARAMS = LG_P_B2A + PF_ACT, LG_P_LOSS = LG_P_PARAMS, LG_P_TOTAL = LG_P_PARAMS + 4;
+static_assert(LG_P_PARAMS == 82082 && LG_P_W2A % 2 == 0, "ActorCritic(136, 180, 180): 82081 parameters + 1 pad");
 
 constexpr u32 LG_WAVES = 8, LG_AHEAD = 8;
 constexpr int LG_F_TILES = 9, LG_C_TILES = 23;                 // dW1: 136 -> 9 feature tiles, 360 -> 23 column tiles
@@ -302,7 +303,7 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
         }
     if (tid < (u32)PF_H2) out[LG_P_B1 + tid] = g_b1;
     if (tid < (u32)PF_HID) { out[LG_P_B2A + tid] = g_b2a; out[LG_P_W2C + tid] = g_w2c; }
-    if (tid == 0u) out[LG_P_B2C] = g_b2c;
+    if (tid == 0u) { out[LG_P_B2C] = g_b2c; out[LG_P_B2C + 1] = 0.f; }
     if (w < 4u && c == 0u) {
         atomicAdd(&lossS[0], l_actor); atomicAdd(&lossS[1], l_critic); atomicAdd(&lossS[2], l_entropy); atomicAdd(&lossS[3], l_count);
     }
@@ -370,4 +371,44 @@ __global__ void __launch_bounds__(1024) azul_select_complete_kernel(const uint8_
         __syncthreads();
     }
     if (tid == 0u) count[0] = (i32)baseS;
+}
+
+
+// Adam (torch.optim.Adam's defaults and arithmetic: lerp for the first moment, bias corrections, eps added to the corrected root)
+// on the flat k-major master copy of the parameters, one thread per parameter; the step also lands in the eight PyTorch parameter
+// tensors (nn.Linear layouts, i.e. transposed), so the module, the rollout kernels (which read the master copy) and the optimiser
+// state never disagree and no re-layout kernels run after an update.
+struct ModuleParams {
+    float *c1w, *c1b, *c2w, *c2b, *a1w, *a1b, *a2w, *a2b;      // critic_linear1/2, actor_linear1/2: weight [out][in], bias [out]
+};
+
+__global__ void __launch_bounds__(256) azul_a2c_apply_kernel(const float *grad, float *flat, float *m, float *v, float lr, float beta1,
+                                                             float beta2, float eps, float bias_c1, float bias_c2_sqrt, ModuleParams P)
+{
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= (u32)LG_P_PARAMS || p == (u32)LG_P_B2C + 1u) return;
+    const float g = grad[p];
+    const float m1 = m[p] + (g - m[p]) * (1.0f - beta1);               // exp_avg.lerp_(grad, 1 - beta1)
+    const float v1 = v[p] * beta2 + (1.0f - beta2) * g * g;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    m[p] = m1;
+    v[p] = v1;
+    const float denom = sqrtf(v1) / bias_c2_sqrt + eps;
+    const float w = flat[p] - (lr / bias_c1) * (m1 / denom);           // param.addcdiv_(exp_avg, denom, value = -step_size)
+    flat[p] = w;
+    if (p < (u32)LG_P_B1) {
+        const u32 k = p / (u32)PF_H2, col = p - k * (u32)PF_H2;
+        if (col < (u32)PF_HID) P.c1w[col * PF_IN + k] = w; else P.a1w[(col - PF_HID) * PF_IN + k] = w;
+    } else if (p < (u32)LG_P_W2C) {
+        const u32 col = p - (u32)LG_P_B1;
+        if (col < (u32)PF_HID) P.c1b[col] = w; else P.a1b[col - PF_HID] = w;
+    } else if (p < (u32)LG_P_B2C) {
+        P.c2w[p - (u32)LG_P_W2C] = w;
+    } else if (p == (u32)LG_P_B2C) {
+        P.c2b[0] = w;
+    } else if (p < (u32)LG_P_B2A) {
+        const u32 i = p - (u32)LG_P_W2A, k = i / (u32)PF_ACT, j = i - k * (u32)PF_ACT;
+        P.a2w[j * PF_HID + k] = w;
+    } else {
+        P.a2b[p - (u32)LG_P_B2A] = w;
+    }
 }

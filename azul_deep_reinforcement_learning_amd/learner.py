@@ -41,7 +41,8 @@ class A2CLearner:
         self.fused = fused
         self._ws = None
         self.gamma = gamma
-        self.optimizer = torch.optim.Adam(policy.parameters(), lr=learning_rate)        # agent.py:37
+        self.optimizer = self._own_adam = torch.optim.Adam(policy.parameters(), lr=learning_rate)        # agent.py:37
+        self.fused_apply = True           # the fused path steps with azul_a2c_apply_adam while `optimizer` is the learner's own Adam
         self.group = process_group
         self.distributed = (dist.is_available() and dist.is_initialized()) if distributed is None else distributed
         self.statistics = {"actor_loss": [], "critic_loss": [], "entropy_loss": [], "ac_loss": [], "samples": []}
@@ -75,31 +76,75 @@ class A2CLearner:
         ac_loss = ACTOR_COEFF * actor_loss + CRITIC_COEFF * critic_loss + ENTROPY_COEFF * entropy_loss
         return actor_loss, critic_loss, entropy_loss, ac_loss
 
-    # ---- hand-written gradient path -------------------------------------------------------------------------------------
+    # ---- hand-written gradient / optimiser path -------------------------------------------------------------------------
+    # One flat k-major vector holds the master copy of the parameters (layout of azul_a2c_gradients' gradient):
+    #     w1t [136][360] | b1 [360] | w2c [180] | b2c [1] | pad | w2a_t [180][180] | b2a [180]
+    # the policy / rollout kernels read views of it (kweights()), Adam's two moments use the same layout, and
+    # azul_a2c_apply_adam writes every step into the flat copy AND into the eight nn.Linear tensors of the module.
+    _OFF = {"w1t": (0, 136 * 360), "b1": (48960, 360), "w2c": (49320, 180), "b2c": (49500, 1), "w2a_t": (49502, 180 * 180), "b2a": (81902, 180)}
+
     def _can_fuse(self, obs):
         pol = self.policy
         return (obs.is_cuda and hasattr(pol, "critic_linear1") and pol.critic_linear1.in_features == 136 and
                 pol.critic_linear1.out_features == 180 and pol.actor_linear2.out_features == 180 and pol.actor_linear1.out_features == 180)
 
+    def _ensure_flat(self, dev):
+        if self._ws is None or self._ws["flat"].device != dev:
+            from . import _lib as L
+            n = L.A2C_FLAT_SIZE
+            self._ws = {"ws": torch.empty(256, n + 4, device=dev), "grad": torch.empty(n + 4, device=dev), "flat": torch.zeros(n, device=dev),
+                        "m": torch.zeros(n, device=dev), "v": torch.zeros(n, device=dev), "step": 0}
+            self.sync_from_module()
+        return self._ws
+
+    def sync_from_module(self):
+        """(Re)build the flat k-major master copy from the module's parameters (after load_state_dict or any outside edit)."""
+        if self._ws is None:
+            return
+        pol, f = self.policy, self._ws["flat"]
+        with torch.no_grad():
+            f[0:48960].view(136, 360).copy_(torch.cat([pol.critic_linear1.weight, pol.actor_linear1.weight], dim=0).t())
+            f[48960:49320].copy_(torch.cat([pol.critic_linear1.bias, pol.actor_linear1.bias]))
+            f[49320:49500].copy_(pol.critic_linear2.weight.reshape(-1))
+            f[49500:49501].copy_(pol.critic_linear2.bias)
+            f[49502:81902].view(180, 180).copy_(pol.actor_linear2.weight.t())
+            f[81902:82082].copy_(pol.actor_linear2.bias)
+
+    def kweights(self, device=None):
+        """Views of the flat master copy in the layouts the policy kernels read (None when the fused path is unavailable)."""
+        dev = device if device is not None else next(self.policy.parameters()).device
+        if torch.device(dev).type != "cuda" or not self._can_fuse(next(self.policy.parameters())) or self.fused is False:
+            return None
+        f = self._ensure_flat(torch.device(dev))["flat"]
+        return {"w1t": f[0:48960].view(136, 360), "b1": f[48960:49320], "w2c": f[49320:49500], "b2c": f[49500:49501],
+                "w2a_t": f[49502:81902].view(180, 180), "b2a": f[81902:82082]}
+
+    def optimizer_state(self):
+        """What a checkpoint needs: torch's Adam state, plus the fused path's moments and step when it is in use."""
+        st = {"torch": self.optimizer.state_dict()}
+        if self._ws is not None:
+            st["fused"] = {"m": self._ws["m"].cpu(), "v": self._ws["v"].cpu(), "step": self._ws["step"]}
+        return st
+
+    def load_optimizer_state(self, st):
+        self.optimizer.load_state_dict(st["torch"])
+        if "fused" in st:
+            ws = self._ensure_flat(next(self.policy.parameters()).device)
+            ws["m"].copy_(st["fused"]["m"])
+            ws["v"].copy_(st["fused"]["v"])
+            ws["step"] = int(st["fused"]["step"])
+        self.sync_from_module()
+
     def _fused_gradients(self, obs, mask, action, qvals, n_total=None, index=None, count=None, kweights=None):
-        """Fills every parameter's .grad from azul_a2c_gradients; returns (actor, critic, entropy, samples): loss sums / n_total.
-        Either `n_total` (host number; all rows are samples) or `index` + `count` (device selection of rows; the global count
-        is then formed on the device, no host round trip).  `kweights`: the k-major weight copies a PolicyRollout keeps."""
+        """The flat gradient from azul_a2c_gradients (summed over the ranks); returns (actor, critic, entropy, samples): loss sums /
+        n_total.  Either `n_total` (host number; all rows are samples) or `index` + `count` (device selection of rows; the global
+        count is then formed on the device, no host round trip)."""
         import ctypes as C
         from . import _lib as L
         pol, dev = self.policy, obs.device
-        if self._ws is None or self._ws["ws"].device != dev:
-            self._ws = {"ws": torch.empty(256, N_PARAMS + 4, device=dev), "grad": torch.empty(N_PARAMS + 4, device=dev)}
-        ws = self._ws
+        ws = self._ensure_flat(dev)
+        kw = self.kweights(dev)
         with torch.no_grad():
-            if kweights is None:
-                w1t = torch.cat([pol.critic_linear1.weight, pol.actor_linear1.weight], dim=0).t().contiguous()
-                b1 = torch.cat([pol.critic_linear1.bias, pol.actor_linear1.bias]).contiguous()
-                w2c = pol.critic_linear2.weight.reshape(-1).contiguous()
-                w2a_t = pol.actor_linear2.weight.t().contiguous()
-            else:
-                w1t, b1, w2c, w2a_t = kweights["w1t"], kweights["b1"], kweights["w2c"], kweights["w2a_t"]
-            w2a = pol.actor_linear2.weight.contiguous()
             obs = obs.contiguous().float()
             mask = mask.contiguous().to(torch.uint8)
             action = action.contiguous().to(torch.int32)
@@ -116,27 +161,13 @@ class A2CLearner:
                 n_dev = None
                 inv_host = 1.0 / float(n_total)
             L.check(L.lib.azul_a2c_gradients(p(obs), p(mask), p(action), p(qvals), int(obs.shape[0]), C.c_float(inv_host),
-                                             p(w1t), p(b1), p(w2c), p(pol.critic_linear2.bias), p(w2a_t), p(pol.actor_linear2.bias), p(w2a),
-                                             136, 180, 180, p(ws["ws"]), 256, p(ws["grad"]), p(index), p(count), p(inv_dev),
-                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+                                             p(kw["w1t"]), p(kw["b1"]), p(kw["w2c"]), p(kw["b2c"]), p(kw["w2a_t"]), p(kw["b2a"]),
+                                             p(pol.actor_linear2.weight), 136, 180, 180, p(ws["ws"]), 256, p(ws["grad"]), p(index), p(count),
+                                             p(inv_dev), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
             g = ws["grad"]
             if self.distributed:
-                dist.all_reduce(g, group=self.group)                       # one flat bucket: 82 085 floats
-            o = 0
-            gw1 = g[o:o + 136 * 360].view(136, 360); o += 136 * 360
-            gb1 = g[o:o + 360]; o += 360
-            gw2c = g[o:o + 180]; o += 180
-            gb2c = g[o:o + 1]; o += 1
-            gw2a = g[o:o + 180 * 180].view(180, 180); o += 180 * 180
-            gb2a = g[o:o + 180]; o += 180
-            pairs = [(pol.critic_linear1.weight, gw1[:, :180].t()), (pol.actor_linear1.weight, gw1[:, 180:].t()),
-                     (pol.critic_linear1.bias, gb1[:180]), (pol.actor_linear1.bias, gb1[180:]),
-                     (pol.critic_linear2.weight, gw2c.view(1, 180)), (pol.critic_linear2.bias, gb2c),
-                     (pol.actor_linear2.weight, gw2a.t()), (pol.actor_linear2.bias, gb2a)]
-            for prm, grad in pairs:
-                if prm.grad is None:
-                    prm.grad = torch.empty_like(prm)
-                prm.grad.copy_(grad)
+                dist.all_reduce(g, group=self.group)                       # one flat bucket
+            o = L.A2C_FLAT_SIZE
             if index is not None:
                 sums = g[o:o + 3] * inv_dev
                 samples = n_dev.squeeze(0)
@@ -146,8 +177,38 @@ class A2CLearner:
         return sums[0], sums[1], sums[2], samples
 
     def _finish_fused(self, a, c, e, samples):
+        """Optimiser step: azul_a2c_apply_adam on the flat copy + module (the learner's own Adam), or -- when the caller installed
+        another optimiser -- the flat gradient scattered into the parameters' .grad and that optimiser's step."""
+        import ctypes as C
+        from . import _lib as L
+        pol, ws = self.policy, self._ws
+        g = ws["grad"]
+        dev = g.device
+        if self.optimizer is self._own_adam and self.fused_apply:
+            grp = self.optimizer.param_groups[0]
+            ws["step"] += 1
+            p = lambda t: C.c_void_p(t.data_ptr())
+            L.check(L.lib.azul_a2c_apply_adam(p(g), p(ws["flat"]), p(ws["m"]), p(ws["v"]), C.c_float(grp["lr"]), C.c_float(grp["betas"][0]),
+                                              C.c_float(grp["betas"][1]), C.c_float(grp["eps"]), int(ws["step"]),
+                                              p(pol.critic_linear1.weight), p(pol.critic_linear1.bias), p(pol.critic_linear2.weight),
+                                              p(pol.critic_linear2.bias), p(pol.actor_linear1.weight), p(pol.actor_linear1.bias),
+                                              p(pol.actor_linear2.weight), p(pol.actor_linear2.bias),
+                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        else:
+            with torch.no_grad():
+                gw1 = g[0:48960].view(136, 360)
+                gb1 = g[48960:49320]
+                pairs = [(pol.critic_linear1.weight, gw1[:, :180].t()), (pol.actor_linear1.weight, gw1[:, 180:].t()),
+                         (pol.critic_linear1.bias, gb1[:180]), (pol.actor_linear1.bias, gb1[180:]),
+                         (pol.critic_linear2.weight, g[49320:49500].view(1, 180)), (pol.critic_linear2.bias, g[49500:49501]),
+                         (pol.actor_linear2.weight, g[49502:81902].view(180, 180).t()), (pol.actor_linear2.bias, g[81902:82082])]
+                for prm, grad in pairs:
+                    if prm.grad is None:
+                        prm.grad = torch.empty_like(prm)
+                    prm.grad.copy_(grad)
+            self.optimizer.step()
+            self.sync_from_module()
         loss = ACTOR_COEFF * a + CRITIC_COEFF * c + ENTROPY_COEFF * e
-        self.optimizer.step()
         out = {"actor_loss": a, "critic_loss": c, "entropy_loss": e, "ac_loss": loss, "samples": samples}
         for k2, v in out.items():
             self.statistics[k2].append(v)

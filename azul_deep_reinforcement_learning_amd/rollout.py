@@ -34,7 +34,7 @@ def _p(t):
 class PolicyRollout:
     def __init__(self, policy, n_games=4096, parts=1, rules={"first_player": "Random", "tile_pool": "Lid"}, seed_base=0,
                  device=None, window=32, use_graph=True, fused_head=True, sample_seed=0x5EED, opponent=None, fused_mlp=True, persistent=False,
-                 action_selection="Distribution"):
+                 action_selection="Distribution", kweights=None):
         """opponent=None: the policy moves for both players (flat self-play, one record per env move).
         opponent="random": the reference's training setup -- the policy is player 1 of GameRunner, the opponent a RandomAgent
         inside the env step (game_runner.py:43-47); one record per AGENT step, observations from the agent's perspective."""
@@ -55,6 +55,13 @@ class PolicyRollout:
         self.action_selection = action_selection
         self.sample_seed = L.POLICY_ARGMAX if action_selection == "Max" else int(sample_seed)
         self.envs, self.streams, self.work, self.traj, self.graphs = [], [], [], [], []
+        # kweights: k-major weight tensors owned by someone else (A2CLearner.kweights(): views of its flat master copy, kept current
+        # by the optimiser kernel) -- then nothing is copied here and refresh_weights() has nothing to do
+        self._external_kweights = kweights is not None
+        if kweights is not None:
+            self.H = policy.critic_linear1.out_features
+            self.w1t, self.b1, self.w2c, self.w2a_t = kweights["w1t"], kweights["b1"], kweights["w2c"], kweights["w2a_t"]
+            self.w2c_t = self.w2c.view(-1, 1)
         self.refresh_weights()
         d, h, T = self.device, self.h, window
         for p in range(parts):
@@ -99,6 +106,8 @@ class PolicyRollout:
         """(Re)build the fused first-layer weights from the policy's parameters -- call after every optimiser step.  The
         staging tensors are updated IN PLACE: a captured HIP graph keeps reading the same addresses."""
         pol = self.policy
+        if self._external_kweights:
+            return
         with torch.no_grad():
             self.H = pol.critic_linear1.out_features
             fresh = {"w1t": torch.cat([pol.critic_linear1.weight, pol.actor_linear1.weight], dim=0).t(),

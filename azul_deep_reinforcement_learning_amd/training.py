@@ -35,9 +35,13 @@ AGENT_STAT_KEYS = ("reward", "actor_loss", "critic_loss", "entropy_loss", "ac_lo
 class BatchedTrainer:
     def __init__(self, policy, n_games=4096, window=32, parts=1, learning_rate=3e-4, gamma=0.99, seed_base=0, sample_seed=0x5EED,
                  rules={"first_player": "Random", "tile_pool": "Lid"}, device=None, use_graph=True, persistent=True, results_dir="results"):
-        self.rollout = PolicyRollout(policy, n_games=n_games, parts=parts, rules=rules, seed_base=seed_base, device=device, window=window,
-                                     use_graph=use_graph, sample_seed=sample_seed, opponent="random", persistent=persistent)
-        self.learner = A2CLearner(self.rollout.policy, learning_rate=learning_rate, gamma=gamma)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        policy = policy.to(dev)
+        self.learner = A2CLearner(policy, learning_rate=learning_rate, gamma=gamma)
+        # rollout kernels and learner share ONE k-major copy of the weights (the learner's flat master copy)
+        self.rollout = PolicyRollout(policy, n_games=n_games, parts=parts, rules=rules, seed_base=seed_base, device=dev, window=window,
+                                     use_graph=use_graph, sample_seed=sample_seed, opponent="random", persistent=persistent,
+                                     kweights=self.learner.kweights(dev))
         self.gamma = gamma
         self.results_dir = results_dir
         self.batch = 0
@@ -68,7 +72,7 @@ class BatchedTrainer:
         GameStatistics buffers between two get_stats() calls (game_runner.py:17-22)."""
         tr = self.rollout.run_window(self.gamma)
         self.rollout.join()                              # device-side dependency: the host keeps enqueueing
-        out = self.learner.update_from_windows(tr, kweights=self.rollout.kweights())
+        out = self.learner.update_from_windows(tr)
         self.rollout.refresh_weights()
         self.batch += 1
         r = sum(part["reward"].sum() for part in tr)
@@ -124,7 +128,7 @@ class BatchedTrainer:
                          "counter": ro.work[p]["counter"].cpu().numpy().copy(),
                          "next_obs": ro.traj[p]["obs"][ro.T].cpu(), "next_mask": ro.traj[p]["mask"][ro.T].cpu(),
                          "next_player": ro.traj[p]["player"][ro.T].cpu()})
-        torch.save({"policy": ro.policy.state_dict(), "optimizer": self.learner.optimizer.state_dict(), "envs": envs,
+        torch.save({"policy": ro.policy.state_dict(), "optimizer": self.learner.optimizer_state(), "envs": envs,
                     "batch": self.batch, "n_games": ro.n, "parts": ro.parts, "window": ro.T}, path)
 
     def load_checkpoint(self, path):
@@ -134,7 +138,7 @@ class BatchedTrainer:
             raise ValueError("checkpoint was written for n_games=%d parts=%d window=%d" % (ck["n_games"], ck["parts"], ck["window"]))
         ro.synchronize()
         ro.policy.load_state_dict(ck["policy"])
-        self.learner.optimizer.load_state_dict(ck["optimizer"])
+        self.learner.load_optimizer_state(ck["optimizer"])          # also rebuilds the flat master copy from the module
         ro.refresh_weights()
         for p, (env, e) in enumerate(zip(ro.envs, ck["envs"])):
             env.set_records(e["records"])

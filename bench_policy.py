@@ -110,16 +110,16 @@ def train(a):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("AZUL_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     torch.manual_seed(0)                                    # same initial weights on every rank
-    net = BatchedActorCritic(136, 180, 180)
+    net = BatchedActorCritic(136, 180, 180).cuda()
+    learner = A2CLearner(net)
     ro = PolicyRollout(net, n_games=a.games, parts=a.parts, window=a.window, use_graph=not a.no_graph, fused_head=not a.torch_head,
                        fused_mlp=not a.torch_mlp, persistent=not a.per_move, opponent="random", seed_base=rank * a.games,
-                       sample_seed=0x5EED + rank)
-    learner = A2CLearner(net)
+                       sample_seed=0x5EED + rank, kweights=learner.kweights())
 
     def one_window():
         tr = ro.run_window()
         ro.join()                                           # device-side dependency between the streams; no host sync per window
-        out = learner.update_from_windows(tr, kweights=ro.kweights())
+        out = learner.update_from_windows(tr)
         ro.refresh_weights()
         return out
 

@@ -196,9 +196,9 @@ int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random,
  * forward and backward of  L = mean_i( -logp_i[a_i] * adv_i + 0.5 * adv_i^2 + 0.1 * (-mean_{j legal} logp_i[j]) ),  adv = q - V
  * (advantage not detached, like the reference), on the f32 matrix cores.  `inv_n_total` = 1 / (samples of the whole batch over
  * all ranks): with data parallelism every rank calls this on its share and the flat gradients are summed.  Weight layouts as in
- * azul_policy_forward plus w2a_dev = actor_linear2.weight as PyTorch stores it ([action][hidden]).  grad_dev receives 82085 floats:
- * dw1t [136][360] | db1 [360] | dw2c [180] | db2c [1] | dw2a_t [180][180] | db2a [180] | sums over the samples used of the actor /
- * critic / entropy terms and their count.  workspace_dev: workspace_parts x 82085 floats (one partial per workgroup; 256 parts use
+ * azul_policy_forward plus w2a_dev = actor_linear2.weight as PyTorch stores it ([action][hidden]).  grad_dev receives
+ * AZUL_A2C_FLAT_SIZE + 4 floats: dw1t [136][360] | db1 [360] | dw2c [180] | db2c [1] | 1 pad | dw2a_t [180][180] | db2a [180] | sums
+ * over the samples used of the actor / critic / entropy terms and their count.  workspace_dev: workspace_parts x that many floats (one partial per workgroup; 256 parts use
  * every CU).  Rows without a legal action carry no sample.  Optional device-side inputs: index_dev [n] (sample s is row index_dev[s]
  * of the arrays), n_samples_dev (the count; n_samples is then only an upper bound), inv_n_total_dev.  Only (136, 180, 180) is compiled in. */
 int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int32_t *action_dev, const float *qvals_dev, int n_samples,
@@ -206,6 +206,14 @@ int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int3
                        const float *w2a_t_dev, const float *b2a_dev, const float *w2a_dev, int num_inputs, int hidden_size, int num_actions,
                        float *workspace_dev, int workspace_parts, float *grad_dev, const int32_t *index_dev, const int32_t *n_samples_dev,
                        const float *inv_n_total_dev, void *stream);
+#define AZUL_A2C_FLAT_SIZE 82082      /* 82081 parameters of ActorCritic(136, 180, 180) in the k-major layout above + 1 pad float */
+/* torch.optim.Adam's step (defaults: betas 0.9 / 0.999, eps 1e-8, no weight decay; same arithmetic) on the flat k-major master copy of
+ * the parameters (layout of azul_a2c_gradients' gradient; w1t / b1 / w2c / b2c / w2a_t / b2a of the policy entries are views of it),
+ * with the two moment vectors in the same layout; `step` counts from 1.  The updated values are also written into the eight PyTorch
+ * parameter tensors (nn.Linear layouts), so module, kernels and optimiser state stay in sync without re-layout launches. */
+int azul_a2c_apply_adam(const float *grad_dev, float *flat_dev, float *exp_avg_dev, float *exp_avg_sq_dev, float lr, float beta1, float beta2,
+                        float eps, int step, float *critic1_w, float *critic1_b, float *critic2_w, float *critic2_b, float *actor1_w,
+                        float *actor1_b, float *actor2_w, float *actor2_b, void *stream);
 /* Which steps of a window feed the update (NNRunner.train uses whole episodes, nn_runner.py:59-76): the steps whose episode ends
  * inside the window and that carry an action (>= 0).  done / action are time-major [n_steps][n_games]; index_dev receives the flat
  * indices t * n_games + g (game by game, steps ascending), count_dev[0] their number.  Feeds azul_a2c_gradients' index_dev /

@@ -344,13 +344,16 @@ __global__ void __launch_bounds__(1024) azul_select_complete_kernel(const uint8_
         const u32 g = g0 + tid;
         int last = -1;
         u32 kept = 0;
+        u64 okmask = 0, okmask_at_done = 0;              // bit t: step t carries an action (windows of up to 64 steps need no second read)
         if (g < N) {
             // one pass without a data-dependent exit (the loads pipeline): running count of usable steps, latched at every `done`
             u32 run = 0;
 #pragma unroll 8
             for (int t = 0; t < T; t++) {
-                run += action[(size_t)t * N + g] >= 0 ? 1u : 0u;
-                if (done[(size_t)t * N + g] != 0) { kept = run; last = t; }
+                const bool ok = action[(size_t)t * N + g] >= 0;
+                run += ok ? 1u : 0u;
+                if (t < 64) okmask |= (u64)(ok ? 1u : 0u) << t;
+                if (done[(size_t)t * N + g] != 0) { kept = run; last = t; okmask_at_done = okmask; }
             }
         }
         // inclusive scan of `kept` over the 1024 threads (Hillis-Steele in LDS)
@@ -363,9 +366,15 @@ __global__ void __launch_bounds__(1024) azul_select_complete_kernel(const uint8_
             __syncthreads();
         }
         u32 pos = baseS + scanS[tid] - kept;
-        if (g < N)
-            for (int t = 0; t <= last; t++)
-                if (action[(size_t)t * N + g] >= 0) index[pos++] = (i32)((u32)t * N + g);
+        if (g < N) {
+            if (last < 64) {
+                for (u64 mbits = okmask_at_done; mbits != 0; mbits &= mbits - 1)       // stores only: ascending steps of this game
+                    index[pos++] = (i32)((u32)__builtin_ctzll(mbits) * N + g);
+            } else {
+                for (int t = 0; t <= last; t++)
+                    if (action[(size_t)t * N + g] >= 0) index[pos++] = (i32)((u32)t * N + g);
+            }
+        }
         __syncthreads();
         if (tid == 1023u) baseS += scanS[1023];
         __syncthreads();

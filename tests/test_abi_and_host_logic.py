@@ -80,3 +80,27 @@ def test_rule_parsing():
 def test_global_id_sharding():
     from azul_deep_reinforcement_learning_amd.parallel import shard_seed_base
     assert [shard_seed_base(10, 4096, r) for r in range(3)] == [10, 4106, 8202]
+
+
+def test_argument_validation_needs_no_gpu():
+    """API misuse is rejected on the host, before anything is launched: a negative AZUL_ERR_* and a message."""
+    from azul_deep_reinforcement_learning_amd import _lib as L
+    lib = L.lib
+    one = ctypes.c_void_p(8)                                   # a non-NULL, 8-byte "aligned" placeholder; never dereferenced
+    # wrong network shape / NULL pointers
+    assert lib.azul_policy_forward(one, one, one, one, one, one, one, one, 136, 128, 180, 1, 0, None, 0, 16, one, one, one, one, None, None) == L.ERR_INVALID
+    assert b"136, 180" in lib.azul_last_error_string()
+    assert lib.azul_policy_forward(None, one, one, one, one, one, one, one, 136, 180, 180, 1, 0, None, 0, 16, one, one, one, one, None, None) == L.ERR_INVALID
+    assert lib.azul_policy_head(None, one, 1, 0, None, 4, one, one, one, None) == L.ERR_INVALID
+    assert lib.azul_a2c_gradients(one, one, one, one, 16, ctypes.c_float(1.0), one, one, one, one, one, one, one, 136, 180, 181,
+                                  one, 256, one, None, None, None, None) == L.ERR_INVALID
+    assert lib.azul_a2c_gradients(one, one, one, one, 16, ctypes.c_float(1.0), one, one, one, one, one, one, one, 136, 180, 180,
+                                  None, 256, one, None, None, None, None) == L.ERR_INVALID
+    assert lib.azul_a2c_apply_adam(one, one, one, one, ctypes.c_float(3e-4), ctypes.c_float(0.9), ctypes.c_float(0.999), ctypes.c_float(1e-8), 0,
+                                   one, one, one, one, one, one, one, one, None) == L.ERR_INVALID          # steps count from 1
+    assert lib.azul_select_complete_samples(one, one, 8, 0, one, one, None) == L.ERR_INVALID
+    assert lib.azul_discounted_returns(None, one, one, None, ctypes.c_float(0.99), 4, 4, None) == L.ERR_INVALID
+    assert lib.azul_batch_policy_rollout(None, 4, 0, one, one, one, one, one, one, 136, 180, 180, 1, 0, None, one, one, one, one, one, one, one, one,
+                                         one, None, None) == L.ERR_INVALID
+    with pytest.raises(L.AzulHipError):
+        L.check(lib.azul_batch_selfplay(None, 4, None, None, None, None, None, None, None, None))

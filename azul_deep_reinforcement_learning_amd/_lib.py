@@ -55,8 +55,8 @@ SIGNATURES = {
     "azul_batch_policy_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "azul_batch_agent_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "azul_batch_observe_all": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
-    "azul_policy_head": (_i, [_vp, _vp, _u64, _u64, _vp, _i, _vp, _vp, _vp, _vp]),
-    "azul_policy_forward": (_i, [_vp] * 8 + [_i, _i, _i, _u64, _u64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "azul_policy_head": (_i, [_vp, _vp, _u64, _u64, _vp, _i, _u32, _vp, _vp, _vp, _vp]),
+    "azul_policy_forward": (_i, [_vp] * 8 + [_i, _i, _i, _u64, _u64, _vp, _i, _i, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "azul_batch_policy_rollout": (_i, [_vp, _i, _i] + [_vp] * 6 + [_i, _i, _i, _u64, _u64, _vp] + [_vp] * 10 + [_vp]),
     "azul_a2c_gradients": (_i, [_vp, _vp, _vp, _vp, _i, C.c_float] + [_vp] * 7 + [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "azul_a2c_apply_adam": (_i, [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _i] + [_vp] * 8 + [_vp]),
@@ -66,11 +66,13 @@ SIGNATURES = {
     "azul_batch_score_preview": (_i, [_vp, _vp, _vp]),
     "azul_batch_selfplay": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "azul_batch_counters": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "azul_batch_counters_dev": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "azul_batch_reset_counters": (_i, [_vp, _vp]),
+    "azul_batch_set_id_base": (_i, [_vp, _u32]),
     "azul_batch_set_draw_margin": (_i, [_vp, _u64]),
     "azul_batch_segment_profile": (_i, [_vp, _vp, _i, _i]),
     "azul_timing_begin": (_i, [_vp, _vp]),
-    "azul_timing_end": (_i, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(_i)]),
+    "azul_timing_end": (_i, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(C.c_float), C.POINTER(_i)]),
 }
 
 

@@ -44,6 +44,17 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class _DevArray:
+    """A device array owned by the library, exposed through __cuda_array_interface__ so torch can view it without a copy."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def _dev_view(ptr, shape, typestr, device):
+    return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device)
+
+
 class BatchedAzul:
     def __init__(self, n_games, rules={"first_player": "Random", "tile_pool": "Lid"}, device=None, seed=None):
         if not torch.cuda.is_available():
@@ -279,8 +290,21 @@ class BatchedAzul:
                                           ss.ctypes.data_as(C.c_void_p), self._stream()))
         return {"episodes": ep, "stuck": stuck, "stat_sums": ss, "keys": list(STAT_KEYS)}
 
+    def counters_dev(self):
+        """Zero-copy torch views of the device-resident counters (no synchronisation): episodes int64 [N], stuck int32 [N],
+        stat_sums float64 [N][10].  The views alias the batch's arrays: keep the batch alive while they are in use."""
+        ep, stuck, ss = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        L.check(L.lib.azul_batch_counters_dev(self._h, C.byref(ep), C.byref(stuck), C.byref(ss)))
+        return {"episodes": _dev_view(ep.value, (self.n,), "<i8", self.device),
+                "stuck": _dev_view(stuck.value, (self.n,), "<i4", self.device),
+                "stat_sums": _dev_view(ss.value, (self.n, L.NUM_STATS), "<f8", self.device), "keys": list(STAT_KEYS)}
+
     def reset_counters(self):
         L.check(L.lib.azul_batch_reset_counters(self._h, self._stream()))
+
+    def set_id_base(self, first_global_id):
+        """Global id of this batch's game 0 (multi-GPU shards / stream parts): keys the policy sampler's Philox stream."""
+        L.check(L.lib.azul_batch_set_id_base(self._h, int(first_global_id) & 0xFFFFFFFF))
 
     def set_draw_margin(self, margin):
         """Test knob: widen the window in which the factory draw falls back to the literal fp64 computation."""
@@ -290,6 +314,7 @@ class BatchedAzul:
         L.check(L.lib.azul_timing_begin(self._h, self._stream()))
 
     def timing_end(self):
-        ms, n = C.c_float(0), C.c_int(0)
-        L.check(L.lib.azul_timing_end(self._h, self._stream(), C.byref(ms), C.byref(n)))
-        return float(ms.value), int(n.value)
+        """-> (bracket ms, launches inside it, summed per-launch kernel ms, launches that carried their own event pair)."""
+        ms, n, kms, kn = C.c_float(0), C.c_int(0), C.c_float(0), C.c_int(0)
+        L.check(L.lib.azul_timing_end(self._h, self._stream(), C.byref(ms), C.byref(n), C.byref(kms), C.byref(kn)))
+        return float(ms.value), int(n.value), float(kms.value), int(kn.value)

@@ -43,6 +43,7 @@ struct BatchDev {
     Rules rules;
     u64 draw_margin;     // AZ_DRAW_MARGIN; tests widen it to force the literal fp64 factory draw
     u64 *prof;           // [SEG_COUNT] segment cycle sums (only written by the -DAZ_PROFILE_SEGMENTS diagnostic build)
+    u32 id_base;         // global id of game 0 (azul_batch_set_id_base): keys the policy sampler's Philox stream
 };
 
 enum {
@@ -392,12 +393,15 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
 // host side: C ABI
 // ------------------------------------------------------------------------------------------------
 struct azul_batch {
-    BatchDev d;
-    int device;
-    hipEvent_t ev0, ev1;
-    int timed_launches;
+    BatchDev d;          // `T` is written once by azul_batch_create
+    int device;          // the device the batch's arrays live on: every entry runs there (DeviceGuard)
+    hipEvent_t ev0, ev1; // bracket of a timed region (azul_timing_begin / _end)
+    std::vector<hipEvent_t> lev;   // event pairs around the individual self-play launches of a timed region
+    int timed_launches;  // launches since azul_timing_begin
+    int timed_pairs;     // of which bracketed by their own event pair (the first AZ_TIMED_PAIRS)
     bool timing;
 };
+enum { AZ_TIMED_PAIRS = 256 };
 
 static thread_local std::string g_err;
 
@@ -410,31 +414,71 @@ static int fail(int code, const char *what, hipError_t e = hipSuccess)
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(AZUL_ERR_HIP, #expr, e_); } while (0)
 
+// Every entry runs on ONE device -- the batch's (recorded by azul_batch_create), or for the batch-less entries the
+// device `stream` belongs to (NULL stream: the caller's current device) -- whatever device is current in the calling
+// thread: the guard makes that device current for the duration of the call and restores the caller's on return.  A
+// stream that belongs to another device than the batch is a caller bug and is refused (AZUL_ERR_INVALID).
+struct DeviceGuard {
+    int prev, rc;
+    bool switched;
+    DeviceGuard() : prev(-1), rc(AZUL_SUCCESS), switched(false) {}
+    int enter(int want, void *stream, const char *who)
+    {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return rc = fail(AZUL_ERR_HIP, "hipGetDevice", e);
+        int sdev = -1;
+        if (stream) {
+            hipDevice_t d;
+            e = hipStreamGetDevice((hipStream_t)stream, &d);
+            if (e != hipSuccess) return rc = fail(AZUL_ERR_HIP, "hipStreamGetDevice", e);
+            sdev = (int)d;
+        }
+        if (want < 0) want = sdev >= 0 ? sdev : prev;
+        else if (sdev >= 0 && sdev != want) {
+            g_err = std::string(who) + ": the stream belongs to device " + std::to_string(sdev) + ", the batch lives on device " + std::to_string(want);
+            return rc = AZUL_ERR_INVALID;
+        }
+        if (want != prev) {
+            e = hipSetDevice(want);
+            if (e != hipSuccess) return rc = fail(AZUL_ERR_HIP, "hipSetDevice", e);
+            switched = true;
+        }
+        return AZUL_SUCCESS;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+// first statement of an entry that takes a batch (`b` may still be NULL: the entry's own checks report that)
+#define BATCH_GUARD(b, stream) DeviceGuard guard_; if ((b) && guard_.enter((b)->device, (void *)(stream), __func__)) return guard_.rc
+// first statement of an entry without a batch
+#define STREAM_GUARD(stream) DeviceGuard guard_; if (guard_.enter(-1, (void *)(stream), __func__)) return guard_.rc
+
 extern "C" {
 
 const char *azul_last_error_string(void) { return g_err.c_str(); }
 const char *azul_version(void) { return "azul-mi355x 0.1 (gfx950, wave-per-game)"; }
 
-int azul_batch_create(azul_batch_t **out, int n_games, int first_player, int tile_pool)
+static void batch_free(azul_batch *b)
 {
-    if (!out || n_games <= 0) return fail(AZUL_ERR_INVALID, "azul_batch_create: bad arguments");
-    if (first_player < 0 || first_player > 2) return fail(AZUL_ERR_RULE, "first_player must be 0 (Random), 1 or 2");
-    if (tile_pool != AZUL_POOL_RANDOM && tile_pool != AZUL_POOL_LID) return fail(AZUL_ERR_RULE, "tile_pool must be AZUL_POOL_RANDOM or AZUL_POOL_LID");
-    azul_batch *b = new azul_batch();
-    memset(&b->d, 0, sizeof(b->d));
-    b->timing = false;
-    b->timed_launches = 0;
+    void *bufs[] = {b->d.state, b->d.mt, b->d.mtpos, (void *)b->d.T, b->d.episodes, b->d.stuck, b->d.stat_sum, b->d.prof};
+    for (void *p : bufs) if (p) (void)hipFree(p);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    for (hipEvent_t e : b->lev) (void)hipEventDestroy(e);
+    delete b;
+}
+
+static int batch_alloc(azul_batch *b, int n_games, int first_player, int tile_pool)
+{
     HIP_TRY(hipGetDevice(&b->device));
     const size_t N = (size_t)n_games;
     b->d.n = (u32)n_games;
     b->d.rules.first_player = (u32)first_player;
     b->d.rules.tile_pool = (u32)tile_pool;
     b->d.draw_margin = AZ_DRAW_MARGIN;
-    double *T = nullptr;
     HIP_TRY(hipMalloc((void **)&b->d.state, N * AZUL_RECORD_BYTES));
     HIP_TRY(hipMalloc((void **)&b->d.mt, N * 624 * sizeof(u32)));
     HIP_TRY(hipMalloc((void **)&b->d.mtpos, N * sizeof(u32)));
-    HIP_TRY(hipMalloc((void **)&T, sizeof(double) * T_WORDS));
+    HIP_TRY(hipMalloc((void **)&b->d.T, sizeof(double) * T_WORDS));
     HIP_TRY(hipMalloc((void **)&b->d.episodes, N * sizeof(u64)));
     HIP_TRY(hipMalloc((void **)&b->d.stuck, N * sizeof(u32)));
     HIP_TRY(hipMalloc((void **)&b->d.stat_sum, N * 10 * sizeof(double)));
@@ -442,8 +486,7 @@ int azul_batch_create(azul_batch_t **out, int n_games, int first_player, int til
     HIP_TRY(hipMemset(b->d.prof, 0, SEG_COUNT * sizeof(u64)));
     std::vector<double> hT((size_t)T_WORDS);
     if (!build_sample_tab(hT.data())) return fail(AZUL_ERR_INVALID, "weight-table decomposition check failed on this host");
-    HIP_TRY(hipMemcpy(T, hT.data(), hT.size() * sizeof(double), hipMemcpyHostToDevice));
-    b->d.T = T;
+    HIP_TRY(hipMemcpy((void *)b->d.T, hT.data(), hT.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(b->d.state, 0, N * AZUL_RECORD_BYTES));
     HIP_TRY(hipMemset(b->d.mt, 0, N * 624 * sizeof(u32)));
     {   // a defined stream even before azul_batch_seed: index 624 over an all-zero state is never used un-seeded
@@ -455,6 +498,24 @@ int azul_batch_create(azul_batch_t **out, int n_games, int first_player, int til
     HIP_TRY(hipMemset(b->d.stat_sum, 0, N * 10 * sizeof(double)));
     HIP_TRY(hipEventCreate(&b->ev0));
     HIP_TRY(hipEventCreate(&b->ev1));
+    return AZUL_SUCCESS;
+}
+
+int azul_batch_create(azul_batch_t **out, int n_games, int first_player, int tile_pool)
+{
+    if (!out || n_games <= 0) return fail(AZUL_ERR_INVALID, "azul_batch_create: bad arguments");
+    if (first_player < 0 || first_player > 2) return fail(AZUL_ERR_RULE, "first_player must be 0 (Random), 1 or 2");
+    if (tile_pool != AZUL_POOL_RANDOM && tile_pool != AZUL_POOL_LID) return fail(AZUL_ERR_RULE, "tile_pool must be AZUL_POOL_RANDOM or AZUL_POOL_LID");
+    *out = nullptr;
+    azul_batch *b = new azul_batch();
+    memset(&b->d, 0, sizeof(b->d));
+    b->device = -1;
+    b->ev0 = b->ev1 = nullptr;
+    b->timing = false;
+    b->timed_launches = 0;
+    b->timed_pairs = 0;
+    int rc = batch_alloc(b, n_games, first_player, tile_pool);
+    if (rc != AZUL_SUCCESS) { batch_free(b); return rc; }      // nothing leaks when an allocation fails half way
     *out = b;
     return AZUL_SUCCESS;
 }
@@ -462,11 +523,8 @@ int azul_batch_create(azul_batch_t **out, int n_games, int first_player, int til
 int azul_batch_destroy(azul_batch_t *b)
 {
     if (!b) return AZUL_SUCCESS;
-    void *bufs[] = {b->d.state, b->d.mt, b->d.mtpos, (void *)b->d.T, b->d.episodes, b->d.stuck, b->d.stat_sum, b->d.prof};
-    for (void *p : bufs) (void)hipFree(p);
-    (void)hipEventDestroy(b->ev0);
-    (void)hipEventDestroy(b->ev1);
-    delete b;
+    BATCH_GUARD(b, nullptr);
+    batch_free(b);
     return AZUL_SUCCESS;
 }
 
@@ -483,6 +541,7 @@ static int check_range(const azul_batch_t *b, int first, int count)
 
 int azul_batch_get_state(azul_batch_t *b, int first, int count, void *records_host, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (int rc = check_range(b, first, count)) return rc;
     if (!records_host) return fail(AZUL_ERR_INVALID, "records_host is NULL");
     HIP_TRY(hipMemcpyAsync(records_host, b->d.state + (size_t)first * AZUL_RECORD_BYTES, (size_t)count * AZUL_RECORD_BYTES,
@@ -493,6 +552,7 @@ int azul_batch_get_state(azul_batch_t *b, int first, int count, void *records_ho
 
 int azul_batch_set_state(azul_batch_t *b, int first, int count, const void *records_host, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (int rc = check_range(b, first, count)) return rc;
     if (!records_host) return fail(AZUL_ERR_INVALID, "records_host is NULL");
     const uint8_t *p = (const uint8_t *)records_host;
@@ -516,6 +576,7 @@ int azul_batch_set_state(azul_batch_t *b, int first, int count, const void *reco
 
 int azul_batch_get_rng(azul_batch_t *b, int game, uint32_t *mt_host, uint32_t *pos_host, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (int rc = check_range(b, game, 1)) return rc;
     if (mt_host) HIP_TRY(hipMemcpyAsync(mt_host, b->d.mt + (size_t)game * 624, 624 * sizeof(u32), hipMemcpyDeviceToHost, (hipStream_t)stream));
     if (pos_host) HIP_TRY(hipMemcpyAsync(pos_host, b->d.mtpos + game, sizeof(u32), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -525,6 +586,7 @@ int azul_batch_get_rng(azul_batch_t *b, int game, uint32_t *mt_host, uint32_t *p
 
 int azul_batch_set_rng(azul_batch_t *b, int game, const uint32_t *mt_host, uint32_t pos, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (int rc = check_range(b, game, 1)) return rc;
     if (!mt_host || pos > 624u) return fail(AZUL_ERR_INVALID, "azul_batch_set_rng: need 624 words and an index in 0..624");
     HIP_TRY(hipMemcpyAsync(b->d.mt + (size_t)game * 624, mt_host, 624 * sizeof(u32), hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -535,6 +597,7 @@ int azul_batch_set_rng(azul_batch_t *b, int game, const uint32_t *mt_host, uint3
 
 int azul_batch_get_rng_range(azul_batch_t *b, int first, int count, uint32_t *mt_host, uint32_t *pos_host, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (int rc = check_range(b, first, count)) return rc;
     if (count == 0) return AZUL_SUCCESS;
     if (mt_host) HIP_TRY(hipMemcpyAsync(mt_host, b->d.mt + (size_t)first * 624, (size_t)count * 624 * sizeof(u32), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -545,6 +608,7 @@ int azul_batch_get_rng_range(azul_batch_t *b, int first, int count, uint32_t *mt
 
 int azul_batch_set_rng_range(azul_batch_t *b, int first, int count, const uint32_t *mt_host, const uint32_t *pos_host, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (int rc = check_range(b, first, count)) return rc;
     if (count == 0) return AZUL_SUCCESS;
     if (!mt_host || !pos_host) return fail(AZUL_ERR_INVALID, "azul_batch_set_rng_range: need 624 words and an index per game");
@@ -558,6 +622,7 @@ int azul_batch_set_rng_range(azul_batch_t *b, int first, int count, const uint32
 
 int azul_batch_seed(azul_batch_t *b, uint64_t seed_base, const uint64_t *seeds_host, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
     u64 *dseeds = nullptr;
     if (seeds_host) {
@@ -594,18 +659,21 @@ static OpArgs op_args(int op)
 
 int azul_batch_init(azul_batch_t *b, const uint8_t *active_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     OpArgs a = op_args(OP_INIT); a.active = active_dev;
     return launch_op(b, a, stream);
 }
 
 int azul_batch_new_round(azul_batch_t *b, const uint8_t *active_dev, uint8_t *status_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     OpArgs a = op_args(OP_NEW_ROUND); a.active = active_dev; a.status = status_dev;
     return launch_op(b, a, stream);
 }
 
 int azul_batch_move(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *active_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!actions_dev) return fail(AZUL_ERR_INVALID, "actions_dev is NULL");
     OpArgs a = op_args(OP_MOVE); a.actions = actions_dev; a.active = active_dev;
     return launch_op(b, a, stream);
@@ -613,6 +681,7 @@ int azul_batch_move(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *
 
 int azul_batch_legal_mask(azul_batch_t *b, uint8_t *mask_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!mask_dev) return fail(AZUL_ERR_INVALID, "mask_dev is NULL");
     OpArgs a = op_args(OP_QUERY); a.mask = mask_dev;
     return launch_op(b, a, stream);
@@ -620,12 +689,14 @@ int azul_batch_legal_mask(azul_batch_t *b, uint8_t *mask_dev, void *stream)
 
 int azul_batch_next_player(azul_batch_t *b, const uint8_t *active_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     OpArgs a = op_args(OP_NEXT_PLAYER); a.active = active_dev;
     return launch_op(b, a, stream);
 }
 
 int azul_batch_flags(azul_batch_t *b, uint8_t *flags_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!flags_dev) return fail(AZUL_ERR_INVALID, "flags_dev is NULL");
     OpArgs a = op_args(OP_QUERY); a.flags = flags_dev;
     return launch_op(b, a, stream);
@@ -633,12 +704,14 @@ int azul_batch_flags(azul_batch_t *b, uint8_t *flags_dev, void *stream)
 
 int azul_batch_count_score(azul_batch_t *b, const uint8_t *active_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     OpArgs a = op_args(OP_COUNT_SCORE); a.active = active_dev;
     return launch_op(b, a, stream);
 }
 
 int azul_batch_step(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *active_dev, uint8_t *status_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!actions_dev) return fail(AZUL_ERR_INVALID, "actions_dev is NULL");
     OpArgs a = op_args(OP_STEP); a.actions = actions_dev; a.active = active_dev; a.status = status_dev;
     return launch_op(b, a, stream);
@@ -646,6 +719,7 @@ int azul_batch_step(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *
 
 int azul_batch_statistics(azul_batch_t *b, double *stats_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!stats_dev) return fail(AZUL_ERR_INVALID, "stats_dev is NULL");
     OpArgs a = op_args(OP_QUERY); a.stats = stats_dev;
     return launch_op(b, a, stream);
@@ -653,12 +727,14 @@ int azul_batch_statistics(azul_batch_t *b, double *stats_dev, void *stream)
 
 int azul_batch_runner_init(azul_batch_t *b, const uint8_t *active_dev, uint8_t *status_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     OpArgs a = op_args(OP_RUNNER_INIT); a.active = active_dev; a.status = status_dev;
     return launch_op(b, a, stream);
 }
 
 int azul_batch_runner_reset(azul_batch_t *b, const uint8_t *active_dev, uint8_t *status_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     OpArgs a = op_args(OP_RUNNER_RESET); a.active = active_dev; a.status = status_dev;
     return launch_op(b, a, stream);
 }
@@ -666,6 +742,7 @@ int azul_batch_runner_reset(azul_batch_t *b, const uint8_t *active_dev, uint8_t 
 int azul_batch_runner_step(azul_batch_t *b, const int32_t *actions_dev, const uint8_t *active_dev, int32_t *reward_dev,
                            uint8_t *done_dev, uint8_t *status_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!actions_dev) return fail(AZUL_ERR_INVALID, "actions_dev is NULL");
     OpArgs a = op_args(OP_RUNNER_STEP);
     a.actions = actions_dev; a.active = active_dev; a.reward = reward_dev; a.done = done_dev; a.status = status_dev;
@@ -674,6 +751,7 @@ int azul_batch_runner_step(azul_batch_t *b, const int32_t *actions_dev, const ui
 
 int azul_batch_observe(azul_batch_t *b, int perspective, float *obs_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!obs_dev || perspective < 0 || perspective > 2) return fail(AZUL_ERR_INVALID, "azul_batch_observe: bad arguments");
     OpArgs a = op_args(OP_QUERY); a.obs = obs_dev; a.persp = perspective;
     return launch_op(b, a, stream);
@@ -681,6 +759,7 @@ int azul_batch_observe(azul_batch_t *b, int perspective, float *obs_dev, void *s
 
 int azul_batch_random_action(azul_batch_t *b, const uint8_t *active_dev, int32_t *actions_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!actions_dev) return fail(AZUL_ERR_INVALID, "actions_dev is NULL");
     OpArgs a = op_args(OP_RANDOM_ACTION); a.active = active_dev; a.actions_out = actions_dev;
     return launch_op(b, a, stream);
@@ -690,6 +769,7 @@ int azul_batch_policy_step(azul_batch_t *b, const int32_t *actions_dev, const ui
                            uint8_t *done_dev, uint8_t *status_dev, int perspective, float *obs_next_dev,
                            uint8_t *mask_next_dev, uint8_t *player_next_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!actions_dev || perspective < 0 || perspective > 2) return fail(AZUL_ERR_INVALID, "azul_batch_policy_step: bad arguments");
     OpArgs a = op_args(OP_POLICY_STEP);
     a.actions = actions_dev; a.active = active_dev; a.reward = reward_dev; a.done = done_dev; a.status = status_dev;
@@ -701,6 +781,7 @@ int azul_batch_agent_step(azul_batch_t *b, const int32_t *actions_dev, const uin
                           uint8_t *done_dev, uint8_t *status_dev, int perspective, float *obs_next_dev,
                           uint8_t *mask_next_dev, uint8_t *player_next_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!actions_dev || perspective < 0 || perspective > 2) return fail(AZUL_ERR_INVALID, "azul_batch_agent_step: bad arguments");
     OpArgs a = op_args(OP_AGENT_STEP);
     a.actions = actions_dev; a.active = active_dev; a.reward = reward_dev; a.done = done_dev; a.status = status_dev;
@@ -710,6 +791,7 @@ int azul_batch_agent_step(azul_batch_t *b, const int32_t *actions_dev, const uin
 
 int azul_batch_observe_all(azul_batch_t *b, int perspective, float *obs_dev, uint8_t *mask_dev, uint8_t *player_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (perspective < 0 || perspective > 2) return fail(AZUL_ERR_INVALID, "azul_batch_observe_all: bad perspective");
     OpArgs a = op_args(OP_QUERY); a.persp = perspective; a.obs = obs_dev; a.mask = mask_dev; a.player = player_dev;
     return launch_op(b, a, stream);
@@ -720,6 +802,7 @@ int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, 
 {
     if (!reward_dev || !done_dev || !returns_dev || n_steps < 0 || n_games <= 0) return fail(AZUL_ERR_INVALID, "azul_discounted_returns: bad arguments");
     if (n_steps == 0) return AZUL_SUCCESS;
+    STREAM_GUARD(stream);
     hipLaunchKernelGGL(azul_returns_kernel, dim3(((u32)n_games + 255u) / 256u), dim3(256), 0, (hipStream_t)stream,
                        reward_dev, done_dev, returns_dev, carry_dev, gamma, n_steps, (u32)n_games);
     HIP_TRY(hipGetLastError());
@@ -727,20 +810,21 @@ int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, 
 }
 
 int azul_policy_head(const float *logits_dev, const uint8_t *mask_dev, uint64_t seed, uint64_t counter, const uint64_t *counter_dev,
-                     int n_games, int32_t *action_dev, float *logp_dev, float *entropy_dev, void *stream)
+                     int n_games, uint32_t game_id_base, int32_t *action_dev, float *logp_dev, float *entropy_dev, void *stream)
 {
     if (!logits_dev || !mask_dev || !action_dev || !logp_dev || !entropy_dev || n_games <= 0) return fail(AZUL_ERR_INVALID, "azul_policy_head: bad arguments");
     if (((uintptr_t)mask_dev & 3u) != 0) return fail(AZUL_ERR_INVALID, "azul_policy_head: mask_dev must be 4-byte aligned");
+    STREAM_GUARD(stream);
     hipLaunchKernelGGL(azul_policy_head_kernel, dim3(((u32)n_games + 3u) / 4u), dim3(64), 0, (hipStream_t)stream, logits_dev, mask_dev,
-                       (u64)seed, (u64)counter, (const u64 *)counter_dev, (u32)n_games, action_dev, logp_dev, entropy_dev);
+                       (u64)seed, (u64)counter, (const u64 *)counter_dev, (u32)n_games, action_dev, logp_dev, entropy_dev, (u32)game_id_base);
     HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }
 
 int azul_policy_forward(const float *obs_dev, const uint8_t *mask_dev, const float *w1t_dev, const float *b1_dev, const float *w2c_dev,
                         const float *b2c_dev, const float *w2a_t_dev, const float *b2a_dev, int num_inputs, int hidden_size, int num_actions,
-                        uint64_t seed, uint64_t counter, uint64_t *counter_dev, int advance_counter, int n_games, float *value_dev,
-                        int32_t *action_dev, float *logp_dev, float *entropy_dev, float *logits_dev, void *stream)
+                        uint64_t seed, uint64_t counter, uint64_t *counter_dev, int advance_counter, int n_games, uint32_t game_id_base,
+                        float *value_dev, int32_t *action_dev, float *logp_dev, float *entropy_dev, float *logits_dev, void *stream)
 {
     if (num_inputs != PF_IN || hidden_size != PF_HID || num_actions != PF_ACT)
         return fail(AZUL_ERR_INVALID, "azul_policy_forward: only ActorCritic(136, 180, hidden 180) is compiled in");
@@ -749,10 +833,11 @@ int azul_policy_forward(const float *obs_dev, const uint8_t *mask_dev, const flo
         return fail(AZUL_ERR_INVALID, "azul_policy_forward: bad arguments");
     if (((uintptr_t)w1t_dev & 7u) != 0 || ((uintptr_t)mask_dev & 3u) != 0)
         return fail(AZUL_ERR_INVALID, "azul_policy_forward: w1t_dev must be 8-byte aligned, mask_dev 4-byte aligned");
+    STREAM_GUARD(stream);
     PolicyWeights W = {w1t_dev, b1_dev, w2c_dev, b2c_dev, w2a_t_dev, b2a_dev};
     hipLaunchKernelGGL(azul_policy_forward_kernel, dim3(((u32)n_games + PF_GAMES - 1) / PF_GAMES), dim3(256), 0, (hipStream_t)stream,
                        obs_dev, mask_dev, W, (u64)seed, (u64)counter, (u64 *)counter_dev, advance_counter, (u32)n_games, value_dev,
-                       action_dev, logp_dev, entropy_dev, logits_dev);
+                       action_dev, logp_dev, entropy_dev, logits_dev, (u32)game_id_base);
     HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }
@@ -763,6 +848,7 @@ int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random,
                               uint8_t *mask_dev, uint8_t *player_dev, int32_t *action_dev, int32_t *reward_dev, uint8_t *done_dev,
                               float *value_dev, float *logp_dev, float *entropy_dev, uint8_t *status_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!b || n_steps < 0) return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: bad arguments");
     if (num_inputs != PF_IN || hidden_size != PF_HID || num_actions != PF_ACT)
         return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: only ActorCritic(136, 180, hidden 180) is compiled in");
@@ -797,6 +883,7 @@ int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int3
         return fail(AZUL_ERR_INVALID, "azul_a2c_gradients: bad arguments");
     if (((uintptr_t)w2a_t_dev & 7u) != 0 || ((uintptr_t)w2a_dev & 7u) != 0 || ((uintptr_t)mask_dev & 3u) != 0)
         return fail(AZUL_ERR_INVALID, "azul_a2c_gradients: weights must be 8-byte aligned, mask_dev 4-byte aligned");
+    STREAM_GUARD(stream);
     const hipStream_t st = (hipStream_t)stream;
     const u32 tiles = ((u32)n_samples + PF_GAMES - 1) / PF_GAMES;
     const u32 parts = tiles < (u32)workspace_parts ? tiles : (u32)workspace_parts;
@@ -817,6 +904,7 @@ int azul_a2c_apply_adam(const float *grad_dev, float *flat_dev, float *exp_avg_d
     if (!grad_dev || !flat_dev || !exp_avg_dev || !exp_avg_sq_dev || step < 1 || !critic1_w || !critic1_b || !critic2_w || !critic2_b ||
         !actor1_w || !actor1_b || !actor2_w || !actor2_b)
         return fail(AZUL_ERR_INVALID, "azul_a2c_apply_adam: bad arguments");
+    STREAM_GUARD(stream);
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     ModuleParams P = {critic1_w, critic1_b, critic2_w, critic2_b, actor1_w, actor1_b, actor2_w, actor2_b};
     hipLaunchKernelGGL(azul_a2c_apply_kernel, dim3((LG_P_PARAMS + 255) / 256), dim3(256), 0, (hipStream_t)stream, grad_dev, flat_dev, exp_avg_dev,
@@ -830,6 +918,7 @@ int azul_select_complete_samples(const uint8_t *done_dev, const int32_t *action_
 {
     if (!done_dev || !action_dev || !index_dev || !count_dev || n_steps < 0 || n_games <= 0)
         return fail(AZUL_ERR_INVALID, "azul_select_complete_samples: bad arguments");
+    STREAM_GUARD(stream);
     hipLaunchKernelGGL(azul_select_complete_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, done_dev, action_dev, n_steps, (u32)n_games,
                        index_dev, count_dev);
     HIP_TRY(hipGetLastError());
@@ -838,6 +927,7 @@ int azul_select_complete_samples(const uint8_t *done_dev, const int32_t *action_
 
 int azul_batch_sample_mask(azul_batch_t *b, const uint8_t *mask_dev, const uint8_t *active_dev, int32_t *actions_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!mask_dev || !actions_dev) return fail(AZUL_ERR_INVALID, "azul_batch_sample_mask: NULL pointer");
     OpArgs a = op_args(OP_SAMPLE_MASK); a.mask_in = mask_dev; a.active = active_dev; a.actions_out = actions_dev;
     return launch_op(b, a, stream);
@@ -845,6 +935,7 @@ int azul_batch_sample_mask(azul_batch_t *b, const uint8_t *mask_dev, const uint8
 
 int azul_batch_score_preview(azul_batch_t *b, int32_t *potential_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!potential_dev) return fail(AZUL_ERR_INVALID, "potential_dev is NULL");
     OpArgs a = op_args(OP_QUERY); a.potential = potential_dev;
     return launch_op(b, a, stream);
@@ -853,6 +944,7 @@ int azul_batch_score_preview(azul_batch_t *b, int32_t *potential_dev, void *stre
 int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_t *maskbits_dev, int32_t *action_dev,
                         int32_t *reward_dev, uint8_t *done_dev, uint32_t *packed_dev, uint8_t *rec_dev, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!b || n_steps < 0) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: bad arguments");
     if (n_steps == 0) return AZUL_SUCCESS;
     TrajArgs t = {n_steps, mask_dev, (u64 *)maskbits_dev, action_dev, reward_dev, done_dev, rec_dev, packed_dev};
@@ -864,15 +956,24 @@ int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_
         if (none) hipLaunchKernelGGL((azul_selfplay_kernel<LID, 0>), grid, block, 0, st, b->d, t); \
         else if (full) hipLaunchKernelGGL((azul_selfplay_kernel<LID, 1>), grid, block, 0, st, b->d, t); \
         else hipLaunchKernelGGL((azul_selfplay_kernel<LID, 2>), grid, block, 0, st, b->d, t); } while (0)
+    // inside a timed region the first AZ_TIMED_PAIRS launches are bracketed by their own event pair (the kernel's duration,
+    // not the distance between launches)
+    const bool pair = b->timing && b->timed_pairs < AZ_TIMED_PAIRS;
+    if (pair) {
+        while ((int)b->lev.size() < 2 * (b->timed_pairs + 1)) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); b->lev.push_back(e); }
+        HIP_TRY(hipEventRecord(b->lev[2 * b->timed_pairs], st));
+    }
     if (b->d.rules.tile_pool == POOL_LID) AZ_LAUNCH(true); else AZ_LAUNCH(false);
 #undef AZ_LAUNCH
     HIP_TRY(hipGetLastError());
+    if (pair) { HIP_TRY(hipEventRecord(b->lev[2 * b->timed_pairs + 1], st)); b->timed_pairs++; }
     if (b->timing) b->timed_launches++;
     return AZUL_SUCCESS;
 }
 
 int azul_batch_counters(azul_batch_t *b, uint64_t *episodes_host, uint32_t *stuck_host, double *stat_sums_host, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
     const size_t N = b->d.n;
     if (episodes_host) HIP_TRY(hipMemcpyAsync(episodes_host, b->d.episodes, N * sizeof(u64), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -884,6 +985,7 @@ int azul_batch_counters(azul_batch_t *b, uint64_t *episodes_host, uint32_t *stuc
 
 int azul_batch_reset_counters(azul_batch_t *b, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
     const size_t N = b->d.n;
     HIP_TRY(hipMemsetAsync(b->d.episodes, 0, N * sizeof(u64), (hipStream_t)stream));
@@ -892,8 +994,25 @@ int azul_batch_reset_counters(azul_batch_t *b, void *stream)
     return AZUL_SUCCESS;
 }
 
+int azul_batch_counters_dev(azul_batch_t *b, uint64_t **episodes_dev, uint32_t **stuck_dev, double **stat_sums_dev)
+{
+    if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
+    if (episodes_dev) *episodes_dev = (uint64_t *)b->d.episodes;
+    if (stuck_dev) *stuck_dev = (uint32_t *)b->d.stuck;
+    if (stat_sums_dev) *stat_sums_dev = b->d.stat_sum;
+    return AZUL_SUCCESS;
+}
+
+int azul_batch_set_id_base(azul_batch_t *b, uint32_t first_global_id)
+{
+    if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
+    b->d.id_base = first_global_id;
+    return AZUL_SUCCESS;
+}
+
 int azul_batch_set_draw_margin(azul_batch_t *b, uint64_t margin)
 {
+    BATCH_GUARD(b, nullptr);
     if (!b || margin < AZ_DRAW_MARGIN || margin > 0x7fffffffull) return fail(AZUL_ERR_INVALID, "margin must be in [8192, 2^31)");
     b->d.draw_margin = margin;
     return AZUL_SUCCESS;
@@ -901,6 +1020,7 @@ int azul_batch_set_draw_margin(azul_batch_t *b, uint64_t margin)
 
 int azul_batch_segment_profile(azul_batch_t *b, uint64_t *cycles_host, int n, int reset)
 {
+    BATCH_GUARD(b, nullptr);
     if (!b || !cycles_host || n < 1) return fail(AZUL_ERR_INVALID, "azul_batch_segment_profile: bad arguments");
     if (n > SEG_COUNT) n = SEG_COUNT;
     HIP_TRY(hipDeviceSynchronize());
@@ -911,15 +1031,18 @@ int azul_batch_segment_profile(azul_batch_t *b, uint64_t *cycles_host, int n, in
 
 int azul_timing_begin(azul_batch_t *b, void *stream)
 {
+    BATCH_GUARD(b, stream);
     if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
     b->timing = true;
     b->timed_launches = 0;
+    b->timed_pairs = 0;
     HIP_TRY(hipEventRecord(b->ev0, (hipStream_t)stream));
     return AZUL_SUCCESS;
 }
 
-int azul_timing_end(azul_batch_t *b, void *stream, float *total_ms, int *launches)
+int azul_timing_end(azul_batch_t *b, void *stream, float *total_ms, int *launches, float *kernel_ms, int *kernel_launches)
 {
+    BATCH_GUARD(b, stream);
     if (!b || !b->timing) return fail(AZUL_ERR_INVALID, "azul_timing_end without azul_timing_begin");
     HIP_TRY(hipEventRecord(b->ev1, (hipStream_t)stream));
     HIP_TRY(hipEventSynchronize(b->ev1));
@@ -927,6 +1050,14 @@ int azul_timing_end(azul_batch_t *b, void *stream, float *total_ms, int *launche
     HIP_TRY(hipEventElapsedTime(&ms, b->ev0, b->ev1));
     if (total_ms) *total_ms = ms;
     if (launches) *launches = b->timed_launches;
+    float ksum = 0.f;
+    for (int i = 0; i < b->timed_pairs; i++) {
+        float k = 0.f;
+        HIP_TRY(hipEventElapsedTime(&k, b->lev[2 * i], b->lev[2 * i + 1]));
+        ksum += k;
+    }
+    if (kernel_ms) *kernel_ms = ksum;
+    if (kernel_launches) *kernel_launches = b->timed_pairs;
     b->timing = false;
     return AZUL_SUCCESS;
 }

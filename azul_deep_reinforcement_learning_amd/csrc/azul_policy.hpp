@@ -9,8 +9,9 @@
 //                               value  = hidden[:, :180] . critic_linear2 + b                         16
 //                               logits = hidden[:, 180:] @ actor_linear2^T + b                        16 x 180, K = 180
 //                           observation tile, hidden and logits live in LDS; weights stream from L2 (k-major, coalesced).
-// fp32 throughout (the reference computes in fp32 torch); randomness: Philox4x32-10 keyed by (seed, game) with the step
-// counter as the block index -- its own documented stream, not torch's or numpy's.
+// fp32 throughout (the reference computes in fp32 torch); randomness: Philox4x32-10 keyed by (seed, GLOBAL game id) with the
+// step counter as the block index -- its own documented stream, not torch's or numpy's.  The global id is
+// `id_base` + the game's index in the launch, so a game draws the same numbers however the games are sharded over GPUs.
 #pragma once
 
 __device__ __forceinline__ void philox_round(u32 &c0, u32 &c1, u32 &c2, u32 &c3, u32 k0, u32 k1)
@@ -66,7 +67,7 @@ constexpr int HEAD_PER_LANE = 12;
 // x[j]: the lane's 12 logits; okbits: bit j set when action 12c+j is legal; g: the lane's game (uniform inside a 16-lane row).
 // Lane c == 0 of every row whose `store` is true writes the three results of its game.
 __device__ __forceinline__ void policy_head_rows(const float (&x)[HEAD_PER_LANE], u32 okbits, u64 seed, u64 counter, u32 g, u32 l,
-                                                 bool store, i32 *action, float *logp, float *entropy, i32 *lds_action = nullptr)
+                                                 bool store, i32 *action, float *logp, float *entropy, u32 id_base, i32 *lds_action = nullptr)
 {
     const u32 c = l & 15u, grp = l >> 4;
     const float NEG = -3.0e38f;
@@ -91,7 +92,7 @@ __device__ __forceinline__ void policy_head_rows(const float (&x)[HEAD_PER_LANE]
     float incl = mine;
     incl += dpp_f<DPP_SHR1>(incl); incl += dpp_f<DPP_SHR2>(incl); incl += dpp_f<DPP_SHR4>(incl); incl += dpp_f<DPP_SHR8>(incl);
     const bool argmax = seed == AZUL_POLICY_ARGMAX;      // action_selection == "Max" (agent.py:70-71): np.argmax, first maximum
-    const float u = (float)(philox_u32(seed, counter, g) >> 8) * (1.0f / 16777216.0f);       // [0, 1), 24 bits
+    const float u = (float)(philox_u32(seed, counter, id_base + g) >> 8) * (1.0f / 16777216.0f);       // [0, 1), 24 bits
     const float target = u * S;
     float cum = incl - mine;
     int pick = -1, lastok = 0;
@@ -133,7 +134,7 @@ __device__ __forceinline__ u32 head_mask_bits(const uint8_t *mk_row, u32 c)
 }
 
 __global__ void __launch_bounds__(64) azul_policy_head_kernel(const float *logits, const uint8_t *mask, u64 seed, u64 counter,
-                                                              const u64 *counter_dev, u32 n, i32 *action, float *logp, float *entropy)
+                                                              const u64 *counter_dev, u32 n, i32 *action, float *logp, float *entropy, u32 id_base)
 {
     const u32 l = threadIdx.x, c = l & 15u;
     const u32 g = blockIdx.x * 4u + (l >> 4);
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(64) azul_policy_head_kernel(const float *logit
     const float *lg = logits + (size_t)gc * AZUL_NUM_ACTIONS + (c < 15u ? 12u * c : 0u);
     for (int j = 0; j < HEAD_PER_LANE; j++) x[j] = lg[j];
     u32 okbits = head_mask_bits(mask + (size_t)gc * AZUL_NUM_ACTIONS, c);
-    policy_head_rows(x, okbits, seed, counter, gc, l, g < n, action, logp, entropy);
+    policy_head_rows(x, okbits, seed, counter, gc, l, g < n, action, logp, entropy, id_base);
 }
 
 // ---- fused ActorCritic forward + head ------------------------------------------------------------------------------
@@ -166,7 +167,7 @@ typedef float pf_f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) azul_policy_forward_kernel(const float *obs, const uint8_t *mask, PolicyWeights W, u64 seed, u64 counter,
                                                                   u64 *counter_dev, int advance, u32 n, float *value, i32 *action,
-                                                                  float *logp, float *entropy, float *logits_out)
+                                                                  float *logp, float *entropy, float *logits_out, u32 id_base)
 {
     __shared__ float obsS[PF_GAMES * PF_OBS_STRIDE];
     __shared__ float hidS[PF_GAMES * PF_HID_STRIDE];
@@ -322,7 +323,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         float x[HEAD_PER_LANE];
         const float *lg = lgS + hrow * PF_LOG_STRIDE + (c < 15u ? 12u * c : 0u);
         for (int j = 0; j < HEAD_PER_LANE; j++) x[j] = lg[j];
-        policy_head_rows(x, okbits, seed, counter, hgc, l, hg < n, action, logp, entropy);
+        policy_head_rows(x, okbits, seed, counter, hgc, l, hg < n, action, logp, entropy, id_base);
     }
     PF_STAMP();
 #if defined(AZ_PF_PROFILE)
@@ -521,7 +522,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
             if (off > 52u) field |= hi << (64u - off);
             const u32 okbits = c < 15u ? (u32)field & 0xfffu : 0u;
             policy_head_rows(x, okbits, a.seed, counter + (u64)t, hg < n ? hg : n - 1u, l, hg < n, a.action + row_t, a.logp + row_t,
-                             a.entropy + row_t, actS + 4u * hw);
+                             a.entropy + row_t, b.id_base, actS + 4u * hw);
         }
         __syncthreads();
         PR_STAMP(4);                                     // head (incl. barrier)

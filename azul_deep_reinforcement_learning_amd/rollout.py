@@ -34,10 +34,13 @@ def _p(t):
 class PolicyRollout:
     def __init__(self, policy, n_games=4096, parts=1, rules={"first_player": "Random", "tile_pool": "Lid"}, seed_base=0,
                  device=None, window=32, use_graph=True, fused_head=True, sample_seed=0x5EED, opponent=None, fused_mlp=True, persistent=False,
-                 action_selection="Distribution", kweights=None):
+                 action_selection="Distribution", kweights=None, game_id_base=None):
         """opponent=None: the policy moves for both players (flat self-play, one record per env move).
         opponent="random": the reference's training setup -- the policy is player 1 of GameRunner, the opponent a RandomAgent
-        inside the env step (game_runner.py:43-47); one record per AGENT step, observations from the agent's perspective."""
+        inside the env step (game_runner.py:43-47); one record per AGENT step, observations from the agent's perspective.
+        `seed_base` / `game_id_base`: game i of this rollout is global game game_id_base + i (default: seed_base, so that a rank
+        passes the id of its first game once); its CPython stream is random.seed(seed_base + i) and its sampling stream is
+        Philox(sample_seed, step, global id) -- both independent of how the games are sharded over GPUs or split into parts."""
         assert n_games % parts == 0
         assert opponent in (None, "random")
         self.opponent = opponent
@@ -54,6 +57,7 @@ class PolicyRollout:
         assert action_selection in ("Distribution", "Max") and (fused_head or action_selection == "Distribution")
         self.action_selection = action_selection
         self.sample_seed = L.POLICY_ARGMAX if action_selection == "Max" else int(sample_seed)
+        self.game_id_base = int(seed_base if game_id_base is None else game_id_base) & 0xFFFFFFFF
         self.envs, self.streams, self.work, self.traj, self.graphs = [], [], [], [], []
         # kweights: k-major weight tensors owned by someone else (A2CLearner.kweights(): views of its flat master copy, kept current
         # by the optimiser kernel) -- then nothing is copied here and refresh_weights() has nothing to do
@@ -67,6 +71,7 @@ class PolicyRollout:
         for p in range(parts):
             env = BatchedAzul(h, rules=rules, device=d)
             env.seed(seed_base + p * h)                            # seeds follow the global game id
+            env.set_id_base(self.game_id_base + p * h)             # ... and so does the sampler's Philox key
             env.runner_init()                                      # GameRunner()
             if opponent == "random":
                 env.reset()                                        # GameRunner.reset(): the opponent opens when it starts
@@ -82,7 +87,7 @@ class PolicyRollout:
                  "returns": torch.zeros(T, h, device=d)}
             w = {"hidden": torch.zeros(h, 2 * self.H, device=d), "logits": torch.zeros(h, L.NUM_ACTIONS, device=d),
                  "status": torch.zeros(h, dtype=torch.uint8, device=d),
-                 "counter": torch.tensor([p << 40, 0], dtype=torch.int64, device=d)}     # [0] Philox step counter (disjoint blocks per part), [1] launch ticket
+                 "counter": torch.tensor([0, 0], dtype=torch.int64, device=d)}     # [0] Philox step counter, [1] launch ticket
             self.traj.append(t)
             self.work.append(w)
             with torch.cuda.stream(self.streams[p]):
@@ -132,7 +137,8 @@ class PolicyRollout:
         if self.fused_mlp:                                  # whole forward + head: one launch on the f32 matrix cores
             L.check(L.lib.azul_policy_forward(_p(obs), _p(mask), _p(self.w1t), _p(self.b1), _p(self.w2c), _p(pol.critic_linear2.bias),
                                               _p(self.w2a_t), _p(pol.actor_linear2.bias), L.OBS_SIZE, H, L.NUM_ACTIONS,
-                                              self.sample_seed, 0, _p(w["counter"]), 1, self.h, _p(tr["value"][t]), _p(tr["action"][t]),
+                                              self.sample_seed, 0, _p(w["counter"]), 1, self.h, self.game_id_base + p * self.h,
+                                              _p(tr["value"][t]), _p(tr["action"][t]),
                                               _p(tr["log_prob"][t]), _p(tr["entropy"][t]), None,
                                               C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
             self._env_step(p, t)
@@ -143,7 +149,7 @@ class PolicyRollout:
             torch.addmm(pol.critic_linear2.bias, w["hidden"][:, :H], self.w2c_t, out=tr["value"][t])          # agent.py:66
             torch.addmm(pol.actor_linear2.bias, w["hidden"][:, H:], self.w2a_t, out=w["logits"])               # agent.py:67
             if self.fused_head:
-                L.check(L.lib.azul_policy_head(_p(w["logits"]), _p(mask), self.sample_seed, 0, _p(w["counter"]), self.h,
+                L.check(L.lib.azul_policy_head(_p(w["logits"]), _p(mask), self.sample_seed, 0, _p(w["counter"]), self.h, self.game_id_base + p * self.h,
                                                _p(tr["action"][t]), _p(tr["log_prob"][t]), _p(tr["entropy"][t]),
                                                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
                 w["counter"][:1].add_(1)

@@ -129,7 +129,7 @@ class BatchedTrainer:
                          "next_obs": ro.traj[p]["obs"][ro.T].cpu(), "next_mask": ro.traj[p]["mask"][ro.T].cpu(),
                          "next_player": ro.traj[p]["player"][ro.T].cpu()})
         torch.save({"policy": ro.policy.state_dict(), "optimizer": self.learner.optimizer_state(), "envs": envs,
-                    "batch": self.batch, "n_games": ro.n, "parts": ro.parts, "window": ro.T}, path)
+                    "batch": self.batch, "n_games": ro.n, "parts": ro.parts, "window": ro.T, "game_id_base": ro.game_id_base}, path)
 
     def load_checkpoint(self, path):
         ro = self.rollout
@@ -140,7 +140,9 @@ class BatchedTrainer:
         ro.policy.load_state_dict(ck["policy"])
         self.learner.load_optimizer_state(ck["optimizer"])          # also rebuilds the flat master copy from the module
         ro.refresh_weights()
+        ro.game_id_base = int(ck.get("game_id_base", ro.game_id_base))     # the sampling streams are keyed by the global game id
         for p, (env, e) in enumerate(zip(ro.envs, ck["envs"])):
+            env.set_id_base(ro.game_id_base + p * ro.h)
             env.set_records(e["records"])
             env.set_rng_range(e["mt"], e["pos"])
             ro.work[p]["counter"].copy_(torch.from_numpy(e["counter"]))

@@ -47,7 +47,7 @@ def main():
         torch.manual_seed(0)
         net = BatchedActorCritic(136, 180, 180)
         ro = PolicyRollout(net, n_games=a.games, parts=parts, window=a.window, use_graph=not a.no_graph, seed_base=rank * a.games,
-                           sample_seed=0x5EED + rank, fused_head=not a.torch_head, fused_mlp=fused_mlp, persistent=persistent)
+                           sample_seed=0x5EED, fused_head=not a.torch_head, fused_mlp=fused_mlp, persistent=persistent)
         for _ in range(3):
             ro.run_window()
         ro.synchronize()
@@ -114,7 +114,7 @@ def train(a):
     learner = A2CLearner(net)
     ro = PolicyRollout(net, n_games=a.games, parts=a.parts, window=a.window, use_graph=not a.no_graph, fused_head=not a.torch_head,
                        fused_mlp=not a.torch_mlp, persistent=not a.per_move, opponent="random", seed_base=rank * a.games,
-                       sample_seed=0x5EED + rank, kweights=learner.kweights())
+                       sample_seed=0x5EED, kweights=learner.kweights())
 
     def one_window():
         tr = ro.run_window()

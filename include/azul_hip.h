@@ -15,6 +15,10 @@
  *   - return value: AZUL_SUCCESS or a negative AZUL_ERR_* (API misuse / HIP failure).  Per-game rule
  *     outcomes are reported in `status_dev` (uint8[N]) -- the single-game Python facade maps them to
  *     the reference's exceptions (IllegalMove / GameEnded, azul.py:8-15);
+ *   - devices: a batch lives on the HIP device that was current in azul_batch_create; every entry that takes the batch
+ *     runs there whatever device is current in the calling thread (the caller's current device is restored on return)
+ *     and refuses a `stream` that belongs to another device (AZUL_ERR_INVALID).  The batch-less entries (policy /
+ *     learner kernels) run on the device `stream` belongs to (NULL stream: the current device);
  *   - there is no CPU implementation behind this ABI.
  *
  * Game record: 128 bytes per game, little endian, array-of-records [N][128] (one cache line per game;
@@ -162,9 +166,10 @@ int azul_batch_observe_all(azul_batch_t *b, int perspective, float *obs_dev, uin
 /* policy head for a batch of action logits [N][180] + legal masks [N][180]: masked softmax, ONE categorical sample per game
  * (agent.py:64-72), the log-probability of that action and the entropy term -mean(log p over legal actions)
  * (nn_runner.py:32-40).  fp32; randomness = Philox4x32-10(seed, counter [+ *counter_dev], game): keep the step counter in
- * device memory (counter_dev) when the call is replayed from a HIP graph.  Rows without a legal action give -1. */
+ * device memory (counter_dev) when the call is replayed from a HIP graph.  `game` is the GLOBAL id game_id_base + row, so a game
+ * draws the same numbers however the batch is sharded over GPUs or split into parts.  Rows without a legal action give -1. */
 int azul_policy_head(const float *logits_dev, const uint8_t *mask_dev, uint64_t seed, uint64_t counter, const uint64_t *counter_dev,
-                     int n_games, int32_t *action_dev, float *logp_dev, float *entropy_dev, void *stream);
+                     int n_games, uint32_t game_id_base, int32_t *action_dev, float *logp_dev, float *entropy_dev, void *stream);
 /* The whole ActorCritic forward (model.py:12-41) + the head above in ONE launch, 16 games per workgroup on the f32 matrix cores
  * (exact f32):  hidden = relu(obs @ w1t + b1), value = hidden[:, :H] . w2c + b2c, logits = hidden[:, H:] @ w2a_t + b2a, then
  * azul_policy_head's sampling on the logits.  Weight layouts (k-major, i.e. nn.Linear.weight transposed):
@@ -176,8 +181,8 @@ int azul_policy_head(const float *logits_dev, const uint8_t *mask_dev, uint64_t 
 int azul_policy_forward(const float *obs_dev /*[N][136]*/, const uint8_t *mask_dev /*[N][180]*/, const float *w1t_dev, const float *b1_dev,
                         const float *w2c_dev, const float *b2c_dev, const float *w2a_t_dev, const float *b2a_dev, int num_inputs,
                         int hidden_size, int num_actions, uint64_t seed, uint64_t counter, uint64_t *counter_dev, int advance_counter,
-                        int n_games, float *value_dev /*[N]*/, int32_t *action_dev, float *logp_dev, float *entropy_dev,
-                        float *logits_dev, void *stream);
+                        int n_games, uint32_t game_id_base, float *value_dev /*[N]*/, int32_t *action_dev, float *logp_dev,
+                        float *entropy_dev, float *logits_dev, void *stream);
 /* A whole WINDOW of policy-driven moves in one launch (the batched NNRunner.run_episode loop, nn_runner.py:17-47, without a
  * kernel boundary per move): for t = 0 .. n_steps-1 every game's observation / mask / player are written to slot t, the network
  * of azul_policy_forward is evaluated, an action is sampled (Philox counter `counter` + *counter_dev + t), and the env advances
@@ -240,9 +245,19 @@ int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, 
  */
 int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_t *maskbits_dev, int32_t *action_dev,
                         int32_t *reward_dev, uint8_t *done_dev, uint32_t *packed_dev, uint8_t *rec_dev, void *stream);
-/* per-game counters accumulated by selfplay / runner_step: episodes[N] u64, stuck[N] u32, stat sums [N][10] f64 (host copies; NULL to skip) */
+/* per-game counters accumulated by selfplay / runner_step / the policy entries: episodes[N] u64, stuck[N] u32, sums of
+ * get_statistics() over finished games [N][10] f64 (azul.py:314-315, the data behind GameStatistics, game_runner.py:10-22).
+ * azul_batch_counters_dev hands out the DEVICE arrays themselves (zero-copy, no synchronisation: read them on a stream
+ * ordered after the launches, like every other *_dev pointer of this ABI); azul_batch_counters is the convenience form
+ * for hosts -- it copies into HOST buffers (NULL to skip) and synchronises `stream`. */
+int azul_batch_counters_dev(azul_batch_t *b, uint64_t **episodes_dev, uint32_t **stuck_dev, double **stat_sums_dev);
 int azul_batch_counters(azul_batch_t *b, uint64_t *episodes_host, uint32_t *stuck_host, double *stat_sums_host, void *stream);
 int azul_batch_reset_counters(azul_batch_t *b, void *stream);
+
+/* global id of the batch's game 0 (default 0).  Multi-GPU runs shard games by global id (rank r owns [G r, G (r+1)), seeds
+ * seed_base + global id); the policy sampler of azul_batch_policy_rollout keys its Philox stream with id_base + local index, so
+ * a game's sampled actions -- like its CPython stream -- do not depend on the GPU count. */
+int azul_batch_set_id_base(azul_batch_t *b, uint32_t first_global_id);
 
 /* TEST KNOB: the factory draw decides a colour in integer arithmetic unless K*T lies within `margin` of a multiple of
  * 2^32 (then by the literal fp64 computation).  Default 8192 (proved sufficient); a wider margin only sends
@@ -254,10 +269,12 @@ int azul_batch_set_draw_margin(azul_batch_t *b, uint64_t margin);
  * build returns zeros.  Synchronises the device. */
 int azul_batch_segment_profile(azul_batch_t *b, uint64_t *cycles_host, int n, int reset);
 
-/* average device time (ms) of the last azul_batch_selfplay launches, measured with hipEvents on the launch stream:
- * call azul_timing_begin, launch any number of selfplay calls, then azul_timing_end (synchronises the stream). */
+/* device time of azul_batch_selfplay launches, measured with hipEvents on the launch stream: call azul_timing_begin, launch
+ * any number of selfplay calls, then azul_timing_end (synchronises the stream).  total_ms / launches: the event bracket from
+ * begin to end and the launches inside it; kernel_ms / kernel_launches: the sum of the event pairs recorded immediately
+ * around each of the first 256 launches (the kernel's own duration, what `rocprofv3 --kernel-trace` reports) and their number. */
 int azul_timing_begin(azul_batch_t *b, void *stream);
-int azul_timing_end(azul_batch_t *b, void *stream, float *total_ms, int *launches);
+int azul_timing_end(azul_batch_t *b, void *stream, float *total_ms, int *launches, float *kernel_ms, int *kernel_launches);
 
 #ifdef __cplusplus
 }

@@ -1,9 +1,10 @@
 // hostcheck.cpp -- TEST-ONLY: compiles the device core (csrc/azul_core.hpp) with g++ against the
-// 64-lane host emulation of csrc/azul_wave.hpp, so the wave-level game logic can be diffed against the
+// 64-lane host emulation of csrc/azul_wave.hpp (azul_wave_host.hpp, next to this file), so the wave-level game logic can be diffed against the
 // oracle in the build container (no GPU).  Not part of the product; never shipped in libazulhip.so.
 #include <stdlib.h>
 #include <string.h>
 
+#include "azul_wave_host.hpp"      // defines AZ_WAVE_HPP: the device header csrc/azul_wave.hpp is skipped
 #include "azul_core.hpp"
 #include "azul_tables.hpp"
 

@@ -88,10 +88,10 @@ def test_argument_validation_needs_no_gpu():
     lib = L.lib
     one = ctypes.c_void_p(8)                                   # a non-NULL, 8-byte "aligned" placeholder; never dereferenced
     # wrong network shape / NULL pointers
-    assert lib.azul_policy_forward(one, one, one, one, one, one, one, one, 136, 128, 180, 1, 0, None, 0, 16, one, one, one, one, None, None) == L.ERR_INVALID
+    assert lib.azul_policy_forward(one, one, one, one, one, one, one, one, 136, 128, 180, 1, 0, None, 0, 16, 0, one, one, one, one, None, None) == L.ERR_INVALID
     assert b"136, 180" in lib.azul_last_error_string()
-    assert lib.azul_policy_forward(None, one, one, one, one, one, one, one, 136, 180, 180, 1, 0, None, 0, 16, one, one, one, one, None, None) == L.ERR_INVALID
-    assert lib.azul_policy_head(None, one, 1, 0, None, 4, one, one, one, None) == L.ERR_INVALID
+    assert lib.azul_policy_forward(None, one, one, one, one, one, one, one, 136, 180, 180, 1, 0, None, 0, 16, 0, one, one, one, one, None, None) == L.ERR_INVALID
+    assert lib.azul_policy_head(None, one, 1, 0, None, 4, 0, one, one, one, None) == L.ERR_INVALID
     assert lib.azul_a2c_gradients(one, one, one, one, 16, ctypes.c_float(1.0), one, one, one, one, one, one, one, 136, 180, 181,
                                   one, 256, one, None, None, None, None) == L.ERR_INVALID
     assert lib.azul_a2c_gradients(one, one, one, one, 16, ctypes.c_float(1.0), one, one, one, one, one, one, one, 136, 180, 180,

@@ -1,0 +1,149 @@
+"""The N > 1 path with the KERNEL's buffers (tests/test_distributed_gloo.py feeds the same gather from the oracle on CPU):
+  * two ranks sharing the one GPU of a test box, gloo as the transport: every rank runs its shard of the games through
+    azul_batch_selfplay, TrajectoryGather ships the compact records + mask bits double-buffered like bench.py, and every
+    rank must end up with exactly what ONE process computes for all the games (and the oracle for sampled games);
+  * world size 1 over "nccl" (= RCCL): process-group init on a device, all_gather_into_tensor and the learner's flat
+    all-reduce execute through RCCL at least once (a 1-GPU box cannot do more; the 8-GPU run is the driver's).
+Reference: the path has no collective of its own (games are independent, azulnet/game_runner.py); SURVEY.md 8e."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+G, T, CHUNKS, BASE = 192, 64, 3, 4242
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    from azul_deep_reinforcement_learning_amd.parallel import TrajectoryGather, shard_seed_base
+    dev = torch.device("cuda", 0)
+    env = BatchedAzul(G, device=dev)
+    env.seed(shard_seed_base(BASE, G, rank))
+    env.runner_init()
+    env.runner_init()
+    bufs = [env.alloc_trajectory(T, packed_mask=True) for _ in range(2)]
+    tg = TrajectoryGather(world, dev, with_masks=True)
+    got = []
+    for i in range(CHUNKS):
+        slot = i & 1
+        tg.wait_buffer_free(slot)
+        if i >= 2:                                      # the gather of chunk i-2 has completed: keep what it delivered
+            got.append({k: v.cpu().numpy().copy() for k, v in tg.gathered(slot, T, G).items()})
+        b = bufs[slot]
+        env.selfplay(T, b["mask"], b["action"], b["reward"], b["done"], maskbits=b["maskbits"], packed=b["packed"])
+        tg.launch(slot, b, T)
+    tg.finish()
+    for i in range(max(CHUNKS - 2, 0), CHUNKS):
+        got.append({k: v.cpu().numpy().copy() for k, v in tg.gathered(i & 1, T, G).items()})
+    q.put((rank, got, env.get_records()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_the_gpu_and_gather_what_one_rank_computes():
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    from azul_deep_reinforcement_learning_amd.parallel import unpack_moves
+    from oracle import oracle as oz
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, got, recs = q.get(timeout=300)
+        res[rank] = (got, recs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the single-process run over all 2 G games
+    one = BatchedAzul(world * G)
+    one.seed(BASE)
+    one.runner_init()
+    one.runner_init()
+    t1 = one.alloc_trajectory(T, packed_mask=True)
+    for i in range(CHUNKS):
+        one.selfplay(T, t1["mask"], t1["action"], t1["reward"], t1["done"], maskbits=t1["maskbits"], packed=t1["packed"])
+        pk = t1["packed"].cpu().numpy().reshape(T, world, G).transpose(1, 0, 2)
+        mb = t1["maskbits"].cpu().numpy().reshape(T, world, G, 3).transpose(1, 0, 2, 3)
+        for rank in range(world):
+            assert np.array_equal(res[rank][0][i]["packed"], pk), (rank, i)          # every rank holds every rank's chunk
+            assert np.array_equal(res[rank][0][i]["maskbits"], mb), (rank, i)
+    final = one.get_records()
+    for rank in range(world):
+        assert res[rank][1].tobytes() == final[rank * G:(rank + 1) * G].tobytes()
+    # and the gathered records of a game on the second rank are the oracle's for its GLOBAL id
+    gid = G + 17
+    s = oz.Stream(BASE + gid)
+    for i in range(CHUNKS):
+        o = s.advance(T, want_records=False)
+        a, d, r = unpack_moves(torch.from_numpy(res[0][0][i]["packed"][1][:, 17].copy()))
+        assert np.array_equal(a.numpy(), o["action"]) and np.array_equal(d.numpy(), o["done"]) and np.array_equal(r.numpy(), o["reward"])
+
+
+def _nccl_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from azul_deep_reinforcement_learning_amd import BatchedActorCritic, BatchedAzul, PolicyRollout
+    from azul_deep_reinforcement_learning_amd.learner import A2CLearner
+    from azul_deep_reinforcement_learning_amd.parallel import TrajectoryGather
+    env = BatchedAzul(G, device=dev)
+    env.seed(BASE)
+    env.runner_init()
+    env.runner_init()
+    b = env.alloc_trajectory(T, packed_mask=True)
+    tg = TrajectoryGather(1, dev, with_masks=True)
+    env.selfplay(T, b["mask"], b["action"], b["reward"], b["done"], maskbits=b["maskbits"], packed=b["packed"])
+    tg.launch(0, b, T)
+    tg.finish()
+    torch.cuda.synchronize()
+    got = tg.gathered(0, T, G)
+    ok_gather = bool(torch.equal(got["packed"][0], b["packed"]) and torch.equal(got["maskbits"][0], b["maskbits"]))
+    # the learner's data-parallel update through RCCL (count all-reduce + one flat gradient all-reduce)
+    torch.manual_seed(0)
+    net = BatchedActorCritic(136, 180, 180).cuda()
+    before = [p.detach().clone() for p in net.parameters()]
+    learner = A2CLearner(net, distributed=True)
+    ro = PolicyRollout(net, n_games=G, window=32, persistent=True, opponent="random", kweights=learner.kweights())
+    for _ in range(2):
+        tr = ro.run_window()
+        ro.join()
+        out = learner.update_from_rollout(ro) if hasattr(learner, "update_from_rollout") else learner.update_from_windows(tr)
+    torch.cuda.synchronize()
+    moved = any(not torch.equal(a, p.detach()) for a, p in zip(before, net.parameters()))
+    q.put((ok_gather, float(out["samples"]), bool(np.isfinite(float(out["ac_loss"]))), moved, dist.get_backend()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_one_nccl_executes_the_rccl_collectives():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    ok_gather, samples, finite, moved, backend = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert backend == "nccl" and ok_gather and finite and moved and samples > 0

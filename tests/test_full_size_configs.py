@@ -1,0 +1,238 @@
+"""BASELINE configs[3] and configs[4] at FULL size on the one GPU a test box has: 32,768 concurrent games, once as one batch
+and once as the eight 4,096-game shards the 8-GPU run uses (games shard by global id: seeds `base + id`, Philox keys
+`id`).  Property: a game's trajectory does not depend on how the games are sharded -- byte-identical per global id --
+plus sampled games replayed through the oracle.  Also: the persistent policy-rollout kernel (azul_batch_policy_rollout,
+the config-3 headline kernel) replayed DIRECTLY through the oracle at 4,096 games, in both opponent modes.
+
+Reference call paths: azulnet/game_runner.py:43-55 (GameRunner.step), azulnet/nn_runner.py:17-47 (run_episode)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as oz
+
+pytestmark = pytest.mark.gpu
+
+SHARDS, G = 8, 4096
+
+
+def _contract_net(golden_dir):
+    from azul_deep_reinforcement_learning_amd.policy import BatchedActorCritic
+    c = np.load(os.path.join(golden_dir, "policy_contract.npz"))
+    sd = {k[3:]: torch.from_numpy(c[k]) for k in c.files if k.startswith("sd_")}
+    return BatchedActorCritic.from_reference(sd).cuda()
+
+
+def test_selfplay_32768_games_is_shard_invariant_and_matches_the_oracle():
+    """configs[3]: one BatchedAzul(32768) vs eight BatchedAzul(4096) seeded shard_seed_base(base, 4096, k); 320 moves in two
+    launches of the benchmarked kernel variant (all trajectory streams): compact records, mask bits, final 128-byte
+    records and MT19937 positions agree per global id; 32 games spread over the shards replay through the oracle."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    from azul_deep_reinforcement_learning_amd.parallel import shard_seed_base, unpack_moves
+    base, T, launches = 77000, 160, 2
+    big = BatchedAzul(SHARDS * G)
+    big.seed(base)
+    big.runner_init()
+    big.runner_init()
+    tb = big.alloc_trajectory(T, packed_mask=True)
+    big_packed, big_bits = [], []
+    for _ in range(launches):
+        big.selfplay(T, tb["mask"], tb["action"], tb["reward"], tb["done"], maskbits=tb["maskbits"], packed=tb["packed"])
+        big_packed.append(tb["packed"].clone())
+        big_bits.append(tb["maskbits"].clone())
+        # the three encodings of a move agree with each other
+        a, d, r = unpack_moves(tb["packed"])
+        assert torch.equal(a, tb["action"]) and torch.equal(d, tb["done"]) and torch.equal(r, tb["reward"])
+    torch.cuda.synchronize()
+    big_rec = big.get_records()
+    _, big_pos = big.get_rng_range()
+    big_cnt = big.counters()
+    assert int(big_cnt["episodes"].sum()) > SHARDS * G * 3            # every game finished several episodes
+    del tb
+    for k in range(SHARDS):
+        env = BatchedAzul(G)
+        env.seed(shard_seed_base(base, G, k))
+        env.runner_init()
+        env.runner_init()
+        ts = env.alloc_trajectory(T, packed_mask=True)
+        for i in range(launches):
+            env.selfplay(T, ts["mask"], ts["action"], ts["reward"], ts["done"], maskbits=ts["maskbits"], packed=ts["packed"])
+            assert torch.equal(ts["packed"], big_packed[i][:, k * G:(k + 1) * G]), (k, i)
+            assert torch.equal(ts["maskbits"], big_bits[i][:, k * G:(k + 1) * G]), (k, i)
+        torch.cuda.synchronize()
+        assert env.get_records().tobytes() == big_rec[k * G:(k + 1) * G].tobytes(), k
+        assert np.array_equal(env.get_rng_range()[1], big_pos[k * G:(k + 1) * G]), k
+        c = env.counters()
+        assert np.array_equal(c["episodes"], big_cnt["episodes"][k * G:(k + 1) * G])
+        del env, ts
+    # sampled global ids vs the oracle: whole trajectory (actions, rewards, done), final record, RNG position
+    pk = torch.cat(big_packed).cpu()
+    for gid in list(range(0, SHARDS * G, 1057)) + [G - 1, G, SHARDS * G - 1]:
+        s = oz.Stream(base + gid)
+        o = s.advance(T * launches, want_records=False)
+        a, d, r = unpack_moves(pk[:, gid])
+        assert np.array_equal(a.numpy(), o["action"]) and np.array_equal(r.numpy(), o["reward"]) and np.array_equal(d.numpy(), o["done"]), gid
+        assert s.record().tobytes() == big_rec[gid].tobytes(), gid
+        assert s.rng_state()[1] == int(big_pos[gid]), gid
+
+
+@pytest.mark.parametrize("opponent", [None, "random"])
+def test_policy_rollout_32768_games_is_shard_invariant(golden_dir, opponent):
+    """configs[4]: PolicyRollout(32768) vs eight PolicyRollout(4096, seed_base = game_id_base = 4096 k) with the same weights,
+    two windows of the one-launch-per-window kernel: the full C1 record (observation, mask, player, action, reward, done,
+    value, log-prob, entropy, returns) and the final game records are byte-identical per global id."""
+    from azul_deep_reinforcement_learning_amd import PolicyRollout
+    net = _contract_net(golden_dir)
+    T, base = 32, 3000
+    keys = ("obs", "mask", "player", "action", "reward", "done", "value", "log_prob", "entropy", "returns")
+    big = PolicyRollout(net, n_games=SHARDS * G, seed_base=base, window=T, persistent=True, opponent=opponent)
+    assert big.persistent
+    bw = []
+    for _ in range(2):
+        tr = big.run_window()
+        big.synchronize()
+        bw.append({k: tr[0][k].clone() for k in keys})
+    big_rec = big.envs[0].get_records()
+    assert int((bw[1]["done"] != 0).sum()) > 0
+    for k in range(SHARDS):
+        ro = PolicyRollout(net, n_games=G, seed_base=base + k * G, window=T, persistent=True, opponent=opponent)
+        for w in range(2):
+            tr = ro.run_window()
+            ro.synchronize()
+            for key in keys:
+                assert torch.equal(tr[0][key], bw[w][key][:, k * G:(k + 1) * G]), (k, w, key)
+        assert ro.envs[0].get_records().tobytes() == big_rec[k * G:(k + 1) * G].tobytes(), k
+        del ro
+    # ... and splitting a batch into stream parts does not change it either
+    ro = PolicyRollout(net, n_games=G, parts=2, seed_base=base, window=T, persistent=True, opponent=opponent)
+    tr = ro.run_window()
+    ro.synchronize()
+    for key in keys:
+        assert torch.equal(torch.cat([tr[0][key], tr[1][key]], dim=1), bw[0][key][:, :G]), key
+
+
+def test_training_update_on_32768_games_equals_the_sum_over_eight_shards(golden_dir):
+    """configs[4], learner side: the flat A2C gradient of one window over 32,768 games equals the sum of the eight shards'
+    gradients (what the data-parallel all-reduce forms), and so does the sample count."""
+    from azul_deep_reinforcement_learning_amd import PolicyRollout
+    from azul_deep_reinforcement_learning_amd import _lib as L
+    from azul_deep_reinforcement_learning_amd.learner import A2CLearner, complete_episode_samples
+    net = _contract_net(golden_dir)
+    T, base = 32, 41000
+
+    def grads(n, seed_base, inv_total):
+        learner = A2CLearner(net, fused=True)
+        ro = PolicyRollout(net, n_games=n, seed_base=seed_base, window=T, persistent=True, opponent="random", kweights=learner.kweights())
+        for _ in range(2):                                    # second window: episodes end inside it
+            tr = ro.run_window()
+        ro.join()
+        t0 = tr[0]
+        k = (complete_episode_samples(t0["done"]) & (t0["action"] >= 0)).reshape(-1)
+        idx = torch.nonzero(k).squeeze(1)
+        obs = t0["obs"][:T].reshape(T * n, -1).index_select(0, idx)
+        mask = t0["mask"][:T].reshape(T * n, -1).index_select(0, idx)
+        act = t0["action"].reshape(-1).index_select(0, idx)
+        q = t0["returns"].reshape(-1).index_select(0, idx)
+        learner._fused_gradients(obs, mask, act, q, n_total=1.0 / inv_total)
+        torch.cuda.synchronize()
+        return learner._ws["grad"].clone(), int(idx.numel())
+
+    # the divisor is the GLOBAL sample count: take it from the big run
+    g_probe, n_big = grads(SHARDS * G, base, 1.0)
+    g_big, _ = grads(SHARDS * G, base, 1.0 / n_big)
+    acc, n_sum = torch.zeros_like(g_big), 0
+    for k in range(SHARDS):
+        g, cnt = grads(G, base + k * G, 1.0 / n_big)
+        acc += g
+        n_sum += cnt
+    assert n_sum == n_big and n_big > SHARDS * G * 10
+    o = L.A2C_FLAT_SIZE
+    scale = float(g_big[:o].abs().max())
+    assert scale > 0
+    assert float((acc[:o] - g_big[:o]).abs().max()) <= 2e-5 * scale
+    assert torch.allclose(acc[o:o + 3], g_big[o:o + 3], rtol=1e-4)
+
+
+def _replay_flat(rec, mt, pos, actions):
+    """Flat policy-driven self-play (both sides play the sampled actions) in the oracle, auto-reset at game end."""
+    L = oz.lib()
+    q = oz.unpack(rec, oz.POOL_LID, oz.FIRST_RANDOM)
+    r = oz.Rng()
+    L.oz_rng_set(C.byref(r), mt.ctypes.data_as(C.POINTER(C.c_uint32)), int(pos))
+    out = {"mask": [], "obs": [], "player": [], "reward": [], "done": []}
+    for a in actions:
+        out["mask"].append(oz.check_all_valid(q.game))
+        cur = q.game.current_player
+        out["player"].append(cur)
+        out["obs"].append(oz.get_state(q.game, cur - 1))
+        assert L.oz_step(C.byref(q.game), int(a) % 6, (int(a) // 6) % 5, int(a) // 30, C.byref(r)) == 0
+        q.move_counter += 1
+        phi = L.oz_potential(C.byref(q.game))
+        out["reward"].append(phi - q.player_score)
+        q.player_score = phi
+        dn = bool(L.oz_is_end_of_game(C.byref(q.game)))
+        out["done"].append(dn)
+        if dn:
+            assert L.oz_runner_init(C.byref(q), oz.FIRST_RANDOM, oz.POOL_LID, C.byref(r)) == 0
+    return out, oz.pack(q), r.idx
+
+
+def _replay_agent(rec, mt, pos, actions):
+    """GameRunner.step with the RandomAgent opponent + GameRunner.reset at episode end (NNRunner.run_episode's env side)."""
+    L = oz.lib()
+    q = oz.unpack(rec, oz.POOL_LID, oz.FIRST_RANDOM)
+    r = oz.Rng()
+    L.oz_rng_set(C.byref(r), mt.ctypes.data_as(C.POINTER(C.c_uint32)), int(pos))
+    out = {"mask": [], "obs": [], "player": [], "reward": [], "done": []}
+    for a in actions:
+        out["mask"].append(oz.check_all_valid(q.game))
+        out["player"].append(q.game.current_player)
+        out["obs"].append(oz.get_state(q.game, 0))
+        rew, dn = C.c_int64(0), C.c_int(0)
+        assert L.oz_runner_step(C.byref(q), int(a), C.byref(r), C.byref(rew), C.byref(dn)) == 0
+        out["reward"].append(rew.value)
+        out["done"].append(bool(dn.value))
+        if dn.value:
+            assert L.oz_runner_reset(C.byref(q), C.byref(r)) == 0
+    return out, oz.pack(q), r.idx
+
+
+@pytest.mark.parametrize("opponent", [None, "random"])
+def test_persistent_rollout_kernel_replays_through_the_oracle_at_4096_games(golden_dir, opponent):
+    """azul_batch_policy_rollout itself (persistent=True: one launch per window) against the oracle -- not against the
+    per-move path: for sampled games of a 4096-game batch, three windows (episodes end and restart inside them), every
+    env-side record (mask, observation, player, reward, done), the final record and the MT19937 position are what the
+    oracle computes when it is fed the actions the kernel sampled."""
+    from azul_deep_reinforcement_learning_amd import PolicyRollout
+    net = _contract_net(golden_dir)
+    T, n, windows = 32, G, 4
+    ro = PolicyRollout(net, n_games=n, seed_base=12345, window=T, persistent=True, opponent=opponent)
+    assert ro.persistent and not ro.use_graph
+    env = ro.envs[0]
+    sample = list(range(0, n, 97)) + [n - 1]
+    rec0 = env.get_records()
+    rng0 = {g: env.get_rng(g) for g in sample}
+    got = []
+    for _ in range(windows):
+        tr = ro.run_window()
+        ro.synchronize()
+        got.append({k: tr[0][k][:, sample].cpu().numpy().copy() for k in ("obs", "mask", "player", "action", "reward", "done")})
+    final = env.get_records()
+    episodes = 0
+    for j, g in enumerate(sample):
+        acts = np.concatenate([w["action"][:, j] for w in got])
+        assert (acts >= 0).all()
+        mt, pos = rng0[g]
+        exp, rec, idx = (_replay_agent if opponent == "random" else _replay_flat)(rec0[g], mt, pos, acts)
+        assert np.array_equal(np.concatenate([w["mask"][:T, j] for w in got]).astype(bool), np.array(exp["mask"])), g
+        assert np.array_equal(np.concatenate([w["obs"][:T, j] for w in got]).astype(np.int64), np.array(exp["obs"])), g
+        assert np.array_equal(np.concatenate([w["player"][:T, j] for w in got]), np.array(exp["player"])), g
+        assert np.array_equal(np.concatenate([w["reward"][:, j] for w in got]), np.array(exp["reward"])), g
+        assert np.array_equal(np.concatenate([w["done"][:, j] for w in got]).astype(bool), np.array(exp["done"])), g
+        assert rec.tobytes() == final[g].tobytes(), g
+        assert env.get_rng(g)[1] == idx, g
+        episodes += int(np.sum(exp["done"]))
+    assert episodes >= len(sample) // 2                 # the replay crossed episode ends (scoring, reset, opponent's opening)

@@ -314,3 +314,38 @@ def test_api_misuse_returns_errors(torch_cuda):
         env.set_draw_margin(10)
     assert L.lib.azul_batch_legal_mask(env._h, None, None) == L.ERR_INVALID
     assert b"NULL" in L.lib.azul_last_error_string() or b"null" in L.lib.azul_last_error_string().lower()
+
+
+@pytest.mark.gpu
+def test_counters_dev_views_and_device_guard():
+    """azul_batch_counters_dev hands out the device arrays themselves (no sync, no copy); every batch entry runs on the
+    batch's device whatever device is current, and refuses a stream of another device."""
+    import torch
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    from azul_deep_reinforcement_learning_amd import _lib as L
+    env = BatchedAzul(64, device="cuda:0")
+    env.seed(5)
+    env.runner_init()
+    env.runner_init()
+    views = env.counters_dev()
+    assert views["episodes"].is_cuda and views["episodes"].shape == (64,) and views["stat_sums"].shape == (64, 10)
+    env.selfplay(400)
+    torch.cuda.synchronize()
+    host = env.counters()
+    assert np.array_equal(views["episodes"].cpu().numpy().astype(np.uint64), host["episodes"]) and host["episodes"].sum() > 0
+    assert np.array_equal(views["stat_sums"].cpu().numpy(), host["stat_sums"])
+    assert np.array_equal(views["stuck"].cpu().numpy().astype(np.uint32), host["stuck"])
+    # a stream created on the batch's device is accepted
+    s = torch.cuda.Stream(device="cuda:0")
+    L.check(L.lib.azul_batch_selfplay(env._h, 4, None, None, None, None, None, None, None, C.c_void_p(s.cuda_stream)))
+    s.synchronize()
+    if torch.cuda.device_count() >= 2:
+        rec = env.get_records()
+        with torch.cuda.device(1):                       # another device is current: the entry still runs on device 0
+            env.selfplay(8)
+            other = torch.cuda.Stream(device="cuda:1")
+            rc = L.lib.azul_batch_selfplay(env._h, 4, None, None, None, None, None, None, None, C.c_void_p(other.cuda_stream))
+            assert rc == L.ERR_INVALID and b"belongs to device" in L.lib.azul_last_error_string()
+            assert torch.cuda.current_device() == 1      # the caller's device is restored
+        torch.cuda.synchronize()
+        assert env.get_records().tobytes() != rec.tobytes()

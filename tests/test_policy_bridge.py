@@ -172,7 +172,7 @@ def test_policy_head_matches_torch_and_samples_the_distribution(contract):
     counts = torch.zeros(180, device="cuda")
     draws = 4000
     for c in range(draws):
-        L.check(L.lib.azul_policy_head(C.c_void_p(logits.data_ptr()), C.c_void_p(mask.data_ptr()), 1234, c, None, n,
+        L.check(L.lib.azul_policy_head(C.c_void_p(logits.data_ptr()), C.c_void_p(mask.data_ptr()), 1234, c, None, n, 0,
                                        C.c_void_p(action.data_ptr()), C.c_void_p(logp.data_ptr()), C.c_void_p(ent.data_ptr()), None))
         if c < 3:
             a = action.long()
@@ -194,10 +194,10 @@ def test_policy_head_matches_torch_and_samples_the_distribution(contract):
     dof = int(legal.sum()) - 1
     assert chi2 < dof + 6 * np.sqrt(2 * dof) + 10, (chi2, dof)
     # a different counter or seed gives a different (but reproducible) stream
-    L.check(L.lib.azul_policy_head(C.c_void_p(logits.data_ptr()), C.c_void_p(mask.data_ptr()), 1234, 17, None, n,
+    L.check(L.lib.azul_policy_head(C.c_void_p(logits.data_ptr()), C.c_void_p(mask.data_ptr()), 1234, 17, None, n, 0,
                                    C.c_void_p(action.data_ptr()), C.c_void_p(logp.data_ptr()), C.c_void_p(ent.data_ptr()), None))
     a1 = action.clone()
-    L.check(L.lib.azul_policy_head(C.c_void_p(logits.data_ptr()), C.c_void_p(mask.data_ptr()), 1234, 17, None, n,
+    L.check(L.lib.azul_policy_head(C.c_void_p(logits.data_ptr()), C.c_void_p(mask.data_ptr()), 1234, 17, None, n, 0,
                                    C.c_void_p(action.data_ptr()), C.c_void_p(logp.data_ptr()), C.c_void_p(ent.data_ptr()), None))
     assert torch.equal(a1, action)
 
@@ -234,7 +234,7 @@ def test_fused_forward_matches_the_reference_network(contract, n):
     p = lambda t: C.c_void_p(t.data_ptr())
     for rep in range(2):                        # second launch: the device counter advanced by itself
         L.check(L.lib.azul_policy_forward(p(obs), p(mask), p(w1t), p(b1), p(w2c), p(net.critic_linear2.bias), p(w2a_t),
-                                          p(net.actor_linear2.bias), 136, 180, 180, 77, 1000, p(counter), 1, n, p(value), p(action),
+                                          p(net.actor_linear2.bias), 136, 180, 180, 77, 1000, p(counter), 1, n, 0, p(value), p(action),
                                           p(logp), p(ent), p(logits), None))
         torch.cuda.synchronize()
         assert counter.tolist() == [6 + rep, 0]
@@ -246,7 +246,7 @@ def test_fused_forward_matches_the_reference_network(contract, n):
         a2 = torch.zeros_like(action)
         lp2 = torch.zeros_like(logp)
         e2 = torch.zeros_like(ent)
-        L.check(L.lib.azul_policy_head(p(logits), p(mask), 77, 1000 + 5 + rep, None, n, p(a2), p(lp2), p(e2), None))
+        L.check(L.lib.azul_policy_head(p(logits), p(mask), 77, 1000 + 5 + rep, None, n, 0, p(a2), p(lp2), p(e2), None))
         torch.cuda.synchronize()
         assert torch.equal(action, a2) and torch.equal(logp, lp2) and torch.equal(ent, e2)
         a = action.cpu().numpy()
@@ -254,7 +254,7 @@ def test_fused_forward_matches_the_reference_network(contract, n):
         assert (a[~legal_rows] == -1).all() and mask_np[np.flatnonzero(legal_rows), a[legal_rows]].all()
     # other network shapes are refused, not silently mis-computed
     assert L.lib.azul_policy_forward(p(obs), p(mask), p(w1t), p(b1), p(w2c), p(net.critic_linear2.bias), p(w2a_t), p(net.actor_linear2.bias),
-                                     136, 128, 180, 77, 0, None, 0, n, p(value), p(action), p(logp), p(ent), None, None) != 0
+                                     136, 128, 180, 77, 0, None, 0, n, 0, p(value), p(action), p(logp), p(ent), None, None) != 0
 
 
 @pytest.mark.gpu
@@ -306,7 +306,7 @@ def test_argmax_action_selection(contract):
     logp = torch.zeros(n, device="cuda")
     ent = torch.zeros(n, device="cuda")
     p = lambda t: C.c_void_p(t.data_ptr())
-    L.check(L.lib.azul_policy_head(p(logits), p(mask), L.POLICY_ARGMAX, 123, None, n, p(action), p(logp), p(ent), None))
+    L.check(L.lib.azul_policy_head(p(logits), p(mask), L.POLICY_ARGMAX, 123, None, n, 0, p(action), p(logp), p(ent), None))
     torch.cuda.synchronize()
     masked = logits.masked_fill(~mask.bool(), float("-inf"))
     want = masked.argmax(dim=1)

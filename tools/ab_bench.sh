@@ -5,6 +5,6 @@ cp $L /tmp/orig.so
 for rep in 1 2; do
 for f in "$@"; do
   cp $f $L
-  echo -n "$f: "; python3 bench.py --steps 4096 --warmup 256 --no-cpu-baseline | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.1f M/s  launch %.4f ms  %s' % (d['value']/1e6, d['roofline']['avg_launch_ms'], d['parity_gate'][:2]))"
+  echo -n "$f: "; python3 bench.py --steps 8 --warmup 1 --no-cpu-baseline --no-extras | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.1f M/s  launch %.4f ms  %s' % (d['value']/1e6, d['roofline']['avg_launch_ms'], d['parity_gate'][:2]))"
 done; done
 cp /tmp/orig.so $L

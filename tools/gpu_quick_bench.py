@@ -21,7 +21,8 @@ for outputs in (True, False):
             env.selfplay(T, t["mask"], t["action"], t["reward"], t["done"], maskbits=t["maskbits"], packed=t["packed"])
         else:
             env.selfplay(T)
-    ms, launches = env.timing_end()
+    ms, launches, kms, kn = env.timing_end()
+    ms, launches = (kms, kn) if kn else (ms, launches)     # per-launch event pairs: the kernel's own duration
     dt = time.time() - t0
     print("N=%d T=%d outputs=%s: %.3f ms/launch, %.1f us/step, %.1f M env-steps/s (wall %.1f M/s)" % (
         n, T, outputs, ms / launches, ms / launches / T * 1e3, n * T * launches / ms / 1e3, n * T * reps / dt / 1e6))

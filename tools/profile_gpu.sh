@@ -6,8 +6,8 @@ TAG=${1:-prof}
 R=$PWD/gpurun_out/$TAG
 mkdir -p $R
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 2048 --warmup 512 --no-cpu-baseline"   # every launch = 512 moves x 4096 games
-timeout -k 10 300 python3 bench.py --steps 4096 --warmup 256 > $R/bench.json 2> $R/bench.err
+BENCH="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras"   # every step = one launch = 512 moves x 4096 games
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $R/bench.json 2> $R/bench.err
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats -- $BENCH > $R/stats.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/pmc_fetch -- $BENCH > $R/pmc_fetch.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/pmc_write -- $BENCH > $R/pmc_write.log 2>&1

@@ -4,7 +4,7 @@ Host-side mirror of the reference's ``azulnet`` API for the environment hot path
 game_runner.py); every rule evaluation runs in hand-written gfx950 kernels behind the C ABI of
 ``libazulhip.so`` (include/azul_hip.h).  There is no CPU execution path.
 """
-from .records import RECORD_DTYPE, STAT_KEYS  # noqa: F401
+from .records import RECORD_DTYPE, RECORD_NP_DTYPE, STAT_KEYS  # noqa: F401
 from .codec import nn_serialize, nn_deserialize  # noqa: F401
 from .batch import BatchedAzul, IllegalRule, parse_rules  # noqa: F401
 from .azul import Azul, IllegalMove, GameEnded  # noqa: F401

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libazulhip.so")
 
 RECORD_BYTES, NUM_ACTIONS, OBS_SIZE, MT_WORDS, NUM_STATS = 128, 180, 136, 624, 10
+RECORD_BYTES_WIDE = 256         # batches of 3 or 4 players
 SUCCESS, ERR_INVALID, ERR_HIP, ERR_RANGE, ERR_RULE = 0, -1, -2, -3, -4
 OK, ILLEGAL_MOVE, GAME_ENDED, STUCK, BAD_ACTION, BOX_EMPTY = 0, 1, 2, 3, 4, 5
 POOL_RANDOM, POOL_LID = 0, 1
@@ -26,6 +27,9 @@ SIGNATURES = {
     "azul_last_error_string": (C.c_char_p, []),
     "azul_version": (C.c_char_p, []),
     "azul_batch_create": (_i, [C.POINTER(_vp), _i, _i, _i]),
+    "azul_batch_create_players": (_i, [C.POINTER(_vp), _i, _i, _i, _i]),
+    "azul_batch_players": (_i, [_vp]),
+    "azul_batch_record_bytes": (_i, [_vp]),
     "azul_batch_destroy": (_i, [_vp]),
     "azul_batch_size": (_i, [_vp]),
     "azul_batch_state_dev": (_vp, [_vp]),

@@ -4,8 +4,8 @@ Same constructor, attributes (numpy arrays that callers read AND write), methods
 as the reference; every rule evaluation (new_round, move, is_legal_move, is_end_of_round, is_end_of_game,
 count_score, step, get_statistics) is one kernel launch through libazulhip.so on the current state of the
 attributes.  What stays on the host is bookkeeping only: rule parsing, attribute <-> record conversion, JSON
-I/O, ``__eq__``, and ``next_player`` / array shapes for the 3-4 player objects the reference can construct
-but never plays (SURVEY.md hazard H5; the kernels are two-player).
+I/O and ``__eq__``.  ``Azul(players=3)`` / ``Azul(players=4)`` behave like the reference's (five displays, turn order
+1..P; azul.py:18-33, 177-181; SURVEY.md hazard H5) on the 3 / 4 player kernels and the 256-byte wide record.
 """
 import json
 import random
@@ -15,7 +15,7 @@ import numpy as np
 from . import _lib as L
 from . import facade_backend as fb
 from .batch import IllegalRule, parse_rules
-from .records import RECORD_DTYPE, bits_to_walls, pack_flags, unpack_flags, walls_to_bits
+from .records import RECORD_DTYPE, RECORD_NP_DTYPE, bits_to_walls, pack_flags, unpack_flags, walls_to_bits
 
 
 class IllegalMove(Exception):
@@ -31,6 +31,8 @@ _STATUS_EXC = {L.ILLEGAL_MOVE: IllegalMove, L.GAME_ENDED: GameEnded, L.BAD_ACTIO
 
 class Azul:
     def __init__(self, players=2, state_file=None, rules={}):
+        if players not in (2, 3, 4):
+            raise ValueError("Azul is a game for 2, 3 or 4 players")
         self.game_board_displays = np.zeros((5, 5), dtype=int)
         self.game_board_center = np.zeros(6, dtype=int)
         self.pattern_lines = np.zeros((players, 5, 5), dtype=int)
@@ -111,13 +113,14 @@ class Azul:
     # attributes <-> 128-byte record
     # ------------------------------------------------------------------------------------------
     def _backend(self):
-        if self.players != 2:
-            raise NotImplementedError("the MI355X kernels play two-player Azul; %d-player objects only support "
-                                      "construction, next_player and new_round" % self.players)
-        return fb.backend(self._first_code, self._pool_code)
+        return fb.backend(self._first_code, self._pool_code, self.players)
 
     def _to_record(self, runner=None):
-        rec = np.zeros((), dtype=RECORD_DTYPE)
+        P = self.players
+        wide = P != 2
+        rec = np.zeros((), dtype=RECORD_NP_DTYPE if wide else RECORD_DTYPE)
+        if wide:
+            rec["players"] = P
 
         def fit(name, value, lo, hi):
             v = np.asarray(value)
@@ -127,41 +130,42 @@ class Azul:
 
         rec["displays"] = fit("game_board_displays", self.game_board_displays, 0, 255)
         rec["center"] = fit("game_board_center", self.game_board_center, 0, 255)
-        rec["flags"] = pack_flags(fit("current_player", self.current_player, 0, 2),
-                                  fit("next_first_player", self.next_first_player, 0, 2), self.end_of_game)
-        rec["pattern_lines"] = fit("pattern_lines", self.pattern_lines, 0, 255)
-        rec["floors"] = fit("floors", self.floors, 0, 7)
-        rec["walls"] = walls_to_bits(self.walls)
-        rec["score"] = fit("score", self.score, -32768, 32767)
+        rec["flags"] = pack_flags(fit("current_player", self.current_player, 0, P),
+                                  fit("next_first_player", self.next_first_player, 0, P), self.end_of_game)
+        rec["pattern_lines"][:P] = fit("pattern_lines", self.pattern_lines, 0, 255)
+        rec["floors"][:P] = fit("floors", self.floors, 0, 7)
+        rec["walls"][:P] = walls_to_bits(self.walls)
+        rec["score"][:P] = fit("score", self.score, -32768, 32767)
         if self.tile_pool == "Lid":
             rec["box"] = fit("box_tiles", self.box_tiles, 0, 255)
             rec["lid"] = fit("lid_tiles", self.lid_tiles, 0, 255)
         rec["turn_counter"] = fit("turn_counter", self.turn_counter, 0, 65535)
-        rec["first_player_stats"] = fit("first_player_stats", self.first_player_stats, 0, 65535)
-        rec["floor_penalty"] = fit("floor_penalty", self.floor_penalty, -32768, 32767)
-        rec["max_combo"] = fit("max_combo", self.max_combo, 0, 255)
-        rec["completed_lines"] = fit("completed_lines", self.completed_lines, 0, 255)
+        rec["first_player_stats"][:P] = fit("first_player_stats", self.first_player_stats, 0, 65535)
+        rec["floor_penalty"][:P] = fit("floor_penalty", self.floor_penalty, -32768, 32767)
+        rec["max_combo"][:P] = fit("max_combo", self.max_combo, 0, 255)
+        rec["completed_lines"][:P] = fit("completed_lines", self.completed_lines, 0, 255)
         if runner is not None:
             rec["player_score"] = fit("player_score", runner.player_score, -32768, 32767)
             rec["move_counter"] = fit("move_counter", runner.move_counter, 0, 65535)
         return rec
 
     def _from_record(self, rec, runner=None):
+        P = self.players
         self.game_board_displays = rec["displays"].astype(int)
         self.game_board_center = rec["center"].astype(int)
         self.current_player, self.next_first_player, self.end_of_game = unpack_flags(rec["flags"])
-        self.pattern_lines = rec["pattern_lines"].astype(int)
-        self.floors = rec["floors"].astype(int)
-        self.walls = bits_to_walls(rec["walls"])
-        self.score = rec["score"].astype(int)
+        self.pattern_lines = rec["pattern_lines"][:P].astype(int)
+        self.floors = rec["floors"][:P].astype(int)
+        self.walls = bits_to_walls(rec["walls"][:P])
+        self.score = rec["score"][:P].astype(int)
         if self.tile_pool == "Lid":
             self.box_tiles = rec["box"].astype(int)
             self.lid_tiles = rec["lid"].astype(int)
         self.turn_counter = int(rec["turn_counter"])
-        self.first_player_stats = rec["first_player_stats"].astype(float)
-        self.floor_penalty = rec["floor_penalty"].astype(float)
-        self.max_combo = rec["max_combo"].astype(float)
-        self.completed_lines = rec["completed_lines"].astype(float)
+        self.first_player_stats = rec["first_player_stats"][:P].astype(float)
+        self.floor_penalty = rec["floor_penalty"][:P].astype(float)
+        self.max_combo = rec["max_combo"][:P].astype(float)
+        self.completed_lines = rec["completed_lines"][:P].astype(float)
         if runner is not None:
             runner.player_score = int(rec["player_score"])
             runner.move_counter = int(rec["move_counter"])
@@ -182,27 +186,9 @@ class Azul:
     # rules (GPU)
     # ------------------------------------------------------------------------------------------
     def new_round(self):
-        if self.players != 2:
-            return self._new_round_many_players()
         st = self._run("op_new_round", draws=True)
         if st == L.BOX_EMPTY:
             raise ValueError("Total of weights must be finite")      # what random.choices raises in the reference
-
-    def _new_round_many_players(self):
-        # azul.py:64-89 for the 3-4 player objects: per-player bookkeeping on the host, the factory draw on the GPU
-        nfp = self.next_first_player
-        proxy = Azul(rules={k: v for k, v in self.rules.items() if k != "first_player"})
-        if self.tile_pool == "Lid":
-            proxy.box_tiles, proxy.lid_tiles = self.box_tiles, self.lid_tiles
-        proxy.next_first_player = 1
-        proxy.new_round()
-        self.game_board_displays, self.game_board_center = proxy.game_board_displays, proxy.game_board_center
-        if self.tile_pool == "Lid":
-            self.box_tiles, self.lid_tiles = proxy.box_tiles, proxy.lid_tiles
-        self.current_player = nfp
-        self.first_player_stats[nfp - 1] += 1
-        self.turn_counter += 1
-        self.next_first_player = 0
 
     def move(self, display, color, pattern):
         self._run("op_move", display + 6 * color + 30 * pattern)
@@ -216,9 +202,6 @@ class Azul:
         return self._run("op_mask", mutates=False)
 
     def next_player(self):
-        if self.players != 2:
-            self.current_player = self.current_player + 1 if self.current_player < self.players else 1   # azul.py:177-181
-            return
         self._run("op_next_player")
 
     def is_end_of_round(self):

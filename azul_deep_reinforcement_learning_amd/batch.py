@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .records import RECORD_DTYPE, STAT_KEYS
+from .records import RECORD_DTYPE, RECORD_NP_DTYPE, STAT_KEYS
 
 _RULE_POOL = {"Random": L.POOL_RANDOM, "Lid": L.POOL_LID}
 
@@ -56,16 +56,20 @@ def _dev_view(ptr, shape, typestr, device):
 
 
 class BatchedAzul:
-    def __init__(self, n_games, rules={"first_player": "Random", "tile_pool": "Lid"}, device=None, seed=None):
+    def __init__(self, n_games, rules={"first_player": "Random", "tile_pool": "Lid"}, device=None, seed=None, players=2):
+        """players = 3 or 4: the reference's Azul(players=...) (five displays, azul.py:19); such batches hold 256-byte records
+        (records.RECORD_NP_DTYPE) and support the Azul rule methods, not the two-player GameRunner ones."""
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedAzul needs an MI355X: there is no CPU path")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.n = int(n_games)
         self.rules = dict(rules)
-        first, pool = parse_rules(rules)
+        self.players = int(players)
+        self.record_dtype = RECORD_DTYPE if self.players == 2 else RECORD_NP_DTYPE
+        first, pool = parse_rules(rules, self.players)
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
-            L.check(L.lib.azul_batch_create(C.byref(self._h), self.n, first, pool))
+            L.check(L.lib.azul_batch_create_players(C.byref(self._h), self.n, self.players, first, pool))
         if seed is not None:
             self.seed(seed)
 
@@ -98,12 +102,12 @@ class BatchedAzul:
 
     def get_records(self, first=0, count=None):
         count = self.n - first if count is None else count
-        out = np.zeros(count, dtype=RECORD_DTYPE)
+        out = np.zeros(count, dtype=self.record_dtype)
         L.check(L.lib.azul_batch_get_state(self._h, first, count, out.ctypes.data_as(C.c_void_p), self._stream()))
         return out
 
     def set_records(self, records, first=0):
-        rec = np.ascontiguousarray(records, dtype=RECORD_DTYPE).reshape(-1)
+        rec = np.ascontiguousarray(records, dtype=self.record_dtype).reshape(-1)
         L.check(L.lib.azul_batch_set_state(self._h, first, len(rec), rec.ctypes.data_as(C.c_void_p), self._stream()))
 
     def get_rng(self, game):
@@ -148,7 +152,7 @@ class BatchedAzul:
             import json
             with open(src) as fh:
                 src = json.load(fh)
-        self.set_records(np.array([json_to_record(d) for d in src], dtype=RECORD_DTYPE), first)
+        self.set_records(np.array([json_to_record(d) for d in src], dtype=self.record_dtype), first)
 
     # -- Azul methods, batched --------------------------------------------------------------------
     def init(self, active=None):

@@ -311,13 +311,10 @@ struct Mask {
 
 AZ_FN u32 sources_board(const Game &g) { return (u32)ballot(g.cs != 0u) & 0x7fffffffu; }
 
-AZ_FN void legal_mask(const Game &g, const LaneConst &k, Mask &out)
+// shared tail of the mask: B = sources holding tiles (31 bits), pme = the mover's non-empty pattern cells (25 bits),
+// wl = the mover's wall
+AZ_FN void mask_from_boards(u32 B, u32 pme, u32 wl, const LaneConst &k, Mask &out)
 {
-    u32 B = sources_board(g);
-    u64 PL = ballot(g.cp != 0u);
-    u32 me = me_index(g);
-    u32 pme = (u32)(PL >> (25u * me)) & 0x1ffffffu;
-    u32 wl = me ? g.wall1 : g.wall0;
     // "row r accepts colour c": no OTHER colour lies on the row (azul.py:172) and the wall cell is free (:174);
     // one lane per (row, colour), ballot -> 25-bit board; bit 31: the floor "row" accepts everything
     vu32 l = lane();
@@ -332,6 +329,16 @@ AZ_FN void legal_mask(const Game &g, const LaneConst &k, Mask &out)
     out.m0 = ballot(out.b0 != 0u);
     out.m1 = ballot(out.b1 != 0u);
     out.m2 = ballot(out.b2 != 0u);
+}
+
+AZ_FN void legal_mask(const Game &g, const LaneConst &k, Mask &out)
+{
+    u32 B = sources_board(g);
+    u64 PL = ballot(g.cp != 0u);
+    u32 me = me_index(g);
+    u32 pme = (u32)(PL >> (25u * me)) & 0x1ffffffu;
+    u32 wl = me ? g.wall1 : g.wall0;
+    mask_from_boards(B, pme, wl, k, out);
 }
 
 AZ_FN u64 mask_word(const Mask &m, u32 w) { return w == 0u ? m.m0 : (w == 1u ? m.m1 : m.m2); }
@@ -504,11 +511,9 @@ AZ_FN vu32 run_length_v(vu32 bits, vu32 pos)
     return up + down;
 }
 
-AZ_FN void score_vec(const Game &g, const LaneConst &k, u64 F, ScoreVec &s)
+// w: per lane, the wall its placement is priced against (the player's wall + the full lines scored before it)
+AZ_FN void score_boards(vu32 w, const LaneConst &k, ScoreVec &s)
 {
-    vbool p1 = lane() >= 25u;
-    u32 f0 = (u32)F & 0x1ffffffu, f1 = (u32)(F >> 25) & 0x1ffffffu;
-    vu32 w = sel(p1, splat(g.wall1), splat(g.wall0)) | (sel(p1, splat(f1), splat(f0)) & k.pbelow);   // :219
     vu32 rowbits = (w >> (k.prow * 5u)) & 31u;
     vu32 h = ((rowbits << k.prow) | (rowbits >> (5u - k.prow))) & 31u;       // the row in board-column order
     vu32 hr = run_length_v(h, k.pbcol);                                      // :230-242
@@ -523,6 +528,14 @@ AZ_FN void score_vec(const Game &g, const LaneConst &k, u64 F, ScoreVec &s)
     vbool kd = v == 31u;                                                     // :282-288
     s.val = s.pos + sel(rd, splat(2u), splat(0u)) + sel(cd, splat(10u), splat(0u)) + sel(kd, splat(7u), splat(0u));
     s.rowdone = ballot(rd); s.colordone = ballot(cd); s.coldone = ballot(kd);
+}
+
+AZ_FN void score_vec(const Game &g, const LaneConst &k, u64 F, ScoreVec &s)
+{
+    vbool p1 = lane() >= 25u;
+    u32 f0 = (u32)F & 0x1ffffffu, f1 = (u32)(F >> 25) & 0x1ffffffu;
+    vu32 w = sel(p1, splat(g.wall1), splat(g.wall0)) | (sel(p1, splat(f1), splat(f0)) & k.pbelow);   // :219
+    score_boards(w, k, s);
 }
 
 AZ_FN i32 floor_penalty(u32 floor_tiles)
@@ -635,22 +648,21 @@ AZ_FN i32 potential(Game &g, const LaneConst &k)
 // ---- new_round: azul.py:64-89 ----
 AZ_FN u32 byte_sum5(u64 v) { return (u32)(((v & 0xffffffffffull) * 0x0101010101ull) >> 32) & 0xffu; }
 
+// The factory draw itself (azul.py:71-89): the centre receives the first-player token, five displays receive four tiles each.
+// Shared by the two-player core below and by the 3/4-player core (azul_core_np.hpp): the reference deals 5 displays whatever
+// the number of players (azul.py:19, TODO at tests/test_azul.py:14).
 template <bool LID>
-AZ_FN u32 new_round(Game &g, Rng &r)
+AZ_FN u32 deal_factories(vu32 &cs, u64 &box, u64 &lid, Rng &r)
 {
-    g.cur = g.nfp;
-    g.fps += (g.nfp == 1u) ? 1u : 0x10000u;              // :67 (numpy [-1] == player 2 when nfp == 0)
-    g.turn += 1u;
-    g.nfp = 0;
     vu32 l = lane();
-    g.cs = sel(l == 30u, splat(1u), splat(0u));          // :71,:73
+    cs = sel(l == 30u, splat(1u), splat(0u));            // :71,:73
     if (!LID) {
 #if AZ_DEVICE_BUILD
 #pragma unroll 1
 #endif
         for (u32 t = 0; t < 20u; t++) {
             u32 color = rng_below(r, 5u, 3u);            // :78 randrange(0,5,1)
-            g.cs = g.cs + sel(l == (t >> 2) * 5u + color, splat(1u), splat(0u));   // :88
+            cs = cs + sel(l == (t >> 2) * 5u + color, splat(1u), splat(0u));   // :88
         }
         return ST_OK;
     }
@@ -674,7 +686,7 @@ AZ_FN u32 new_round(Game &g, Rng &r)
         klo = (wa << 26) | wb;
         khi = wa >> 6;
     }
-    u64 P = ((g.box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;     // byte c = box_0 + .. + box_c
+    u64 P = ((box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;     // byte c = box_0 + .. + box_c
     // When the box holds at least 20 tiles no refill can happen: draw t sees total T0 - t, so K*T and the margin
     // test of all 20 draws are evaluated by the lanes before the sequential loop.
     const u32 T0 = (u32)(P >> 32) & 0xffu;
@@ -703,9 +715,9 @@ AZ_FN u32 new_round(Game &g, Rng &r)
             for (u32 j = 0; j < 4u; j++) {
                 vu32 pc = (plo >> sh) & 0xffu;
                 u32 color = popc64(ballot(((pc << 21) <= readlane(kthi, d * 4u + j)) & (l < 4u)));
-                g.box -= 1ull << (8u * color);               // :89
+                box -= 1ull << (8u * color);               // :89
                 plo -= (u32)(0x0101010101ull << (8u * color));   // colours >= `color` lose one tile from their prefix (colour 4: no-op)
-                g.cs = g.cs + sel(l == d * 5u + color, splat(1u), splat(0u));   // :88
+                cs = cs + sel(l == d * 5u + color, splat(1u), splat(0u));   // :88
             }
         }
         r.pos += 40u;
@@ -717,8 +729,8 @@ AZ_FN u32 new_round(Game &g, Rng &r)
     for (u32 t = 0; t < 20u; t++) {
         u32 total = (u32)(P >> 32) & 0xffu;
         if (AZ_UNLIKELY(total == 0u)) {                                              // :81-83, :85
-            g.box = g.lid; g.lid = 0;
-            P = ((g.box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;
+            box = lid; lid = 0;
+            P = ((box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;
             total = (u32)(P >> 32) & 0xffu;
             if (total == 0u) return ST_BOX_EMPTY;
         }
@@ -732,7 +744,7 @@ AZ_FN u32 new_round(Game &g, Rng &r)
             color = popc64(ballot(((pc << 21) <= (u32)(KT >> 32)) & (l < 4u)));
         } else {
             // weights = box_c / total (fp64), cumulative left-to-right, x = random() * cum[-1]   (:87, choices)
-            u32 blo = (u32)g.box, bhi = (u32)(g.box >> 32);
+            u32 blo = (u32)box, bhi = (u32)(box >> 32);
             vu32 mine = sel(l < 4u, (blo >> ((l & 3u) * 8u)) & 0xffu, splat(bhi & 0xffu));
             vf64 wq = divlanes(mine, (double)total);
             double c0 = readlane_d(wq, 0);
@@ -744,11 +756,21 @@ AZ_FN u32 new_round(Game &g, Rng &r)
             double x = u * (c4 + 0.0);
             color = (u32)!(x < c0) + (u32)!(x < c1) + (u32)!(x < c2) + (u32)!(x < c3);    // bisect_right(cum, x, 0, 4)
         }
-        g.box -= 1ull << (8u * color);                   // :89
+        box -= 1ull << (8u * color);                   // :89
         P -= (0x0101010101ull << (8u * color)) & 0xffffffffffull;
-        g.cs = g.cs + sel(l == (t >> 2) * 5u + color, splat(1u), splat(0u));   // :88
+        cs = cs + sel(l == (t >> 2) * 5u + color, splat(1u), splat(0u));   // :88
     }
     return ST_OK;
+}
+
+template <bool LID>
+AZ_FN u32 new_round(Game &g, Rng &r)
+{
+    g.cur = g.nfp;
+    g.fps += (g.nfp == 1u) ? 1u : 0x10000u;              // :67 (numpy [-1] == player 2 when nfp == 0)
+    g.turn += 1u;
+    g.nfp = 0;
+    return deal_factories<LID>(g.cs, g.box, g.lid, r);
 }
 
 // ---- Azul.__init__ + GameRunner reset bookkeeping: azul.py:18-61, game_runner.py:76-82 ----

@@ -9,6 +9,7 @@
 // Kernels
 //   azul_seed_kernel            one THREAD per game: CPython init_by_array is a strictly sequential 1247-step recurrence
 //   azul_op_kernel              one wave per game: every single-call rule / runner entry point of the ABI
+//   azul_np_op_kernel           the rule entries for batches of 3- and 4-player games (row N4; azul_core_np.hpp, 256-byte records)
 //   azul_selfplay_kernel        one wave per game, state register-resident across n_steps env moves (the hot path)
 //   azul_returns_kernel         discounted returns over a trajectory window
 //   azul_policy.hpp             policy head, fused ActorCritic forward, persistent policy rollout (rows N1 / N2)
@@ -24,6 +25,7 @@
 
 #include "../../include/azul_hip.h"
 #include "azul_core.hpp"
+#include "azul_core_np.hpp"
 #include "azul_tables.hpp"
 
 using namespace az;
@@ -293,6 +295,97 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
     if (a.player) AZ_LANE0(a.player[gi] = (uint8_t)g.cur);
 }
 
+// Rule entries for 3 and 4 players (row N4): Azul.__init__ / new_round / move / is_legal_move (mask) / next_player / is_end_of_round /
+// is_end_of_game / count_score / step / get_statistics, plus the RandomAgent sampler on the game's own or a caller's mask.
+// The env wrapper (GameRunner) is two-player in the reference (game_runner.py:50,57), so there is no runner / self-play entry here.
+template <u32 P, bool LID>
+__global__ void __launch_bounds__(64) azul_np_op_kernel(BatchDev b, OpArgs a)
+{
+    __shared__ u32 mt_lds[624];
+    __shared__ double fr_lds[T_ROWS * T_BINADES];
+    const u32 gi = blockIdx.x;
+    const bool act = a.active ? (a.active[gi] != 0) : true;
+    uint8_t *rec = b.state + (size_t)gi * NP_RECORD_BYTES;
+    LaneConst k;
+    lane_consts(k);
+    SampleTab tab;
+    sample_tab_load(tab, b.T, fr_lds);
+    GameN<P> g;
+    gamen_load(g, rec);
+    u32 st = ST_OK;
+    if (act && a.op != OP_QUERY) {
+        Rng r;
+        const bool use_rng = op_needs_rng(a.op);
+        rng_attach(r, b.mt + (size_t)gi * 624u, mt_lds, use_rng ? b.mtpos[gi] : 0u);
+        r.margin = b.draw_margin;
+        bool dirty_state = true;
+        switch (a.op) {
+        case OP_INIT:
+            game_ctor_np<LID>(g, b.rules.first_player, r);
+            break;
+        case OP_NEW_ROUND:
+            st = new_round_np<LID>(g, r);
+            break;
+        case OP_MOVE: {
+            i32 av = a.actions[gi];
+            if (av < 0 || av >= 180) { st = ST_BAD_ACTION; dirty_state = false; break; }
+            do_move_np<LID>(g, action_code((u32)av));
+        } break;
+        case OP_NEXT_PLAYER:
+            g.cur = (g.cur < P) ? g.cur + 1u : 1u;
+            break;
+        case OP_COUNT_SCORE:
+            count_score_np<LID>(g, k);
+            break;
+        case OP_STEP:
+            st = checked_step_np<LID>(g, k, r, a.actions[gi]);
+            dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION);
+            break;
+        case OP_RANDOM_ACTION: {
+            Mask m;
+            legal_mask_np(g, k, m);
+            u32 code;
+            i32 av = random_agent(m, r, tab, k, code);
+            AZ_LANE0(a.actions_out[gi] = av);
+            dirty_state = false;
+        } break;
+        case OP_SAMPLE_MASK: {
+            const uint8_t *mi = a.mask_in + (size_t)gi * AZUL_NUM_ACTIONS;
+            vu32 l = lane();
+            Mask m;
+            m.b0 = ld_u8(mi, l, l < 64u) != 0u ? 1u : 0u;
+            m.b1 = ld_u8(mi, l + 64u, l < 64u) != 0u ? 1u : 0u;
+            m.b2 = ld_u8(mi, l + 128u, l < 52u) != 0u ? 1u : 0u;
+            m.m0 = ballot(m.b0 != 0u); m.m1 = ballot(m.b1 != 0u); m.m2 = ballot(m.b2 != 0u);
+            u32 code;
+            i32 av = random_agent(m, r, tab, k, code);
+            AZ_LANE0(a.actions_out[gi] = av);
+            dirty_state = false;
+        } break;
+        default:
+            dirty_state = false;
+            break;
+        }
+        if (dirty_state) gamen_store(g, rec);
+        if (use_rng) rng_close(r, b.mtpos + gi);
+    }
+    if (a.status && act) AZ_LANE0(a.status[gi] = (uint8_t)st);
+    if (a.mask) {
+        Mask m;
+        legal_mask_np(g, k, m);
+        mask_write(m, a.mask + (size_t)gi * AZUL_NUM_ACTIONS);
+    }
+    if (a.flags) {
+        u32 f = (sources_board_np(g) == 0u ? AZUL_FLAG_END_OF_ROUND : 0) | (walls_end_game_np(g) ? AZUL_FLAG_END_OF_GAME : 0) |
+                (g.eog ? AZUL_FLAG_ENDED_FLAG : 0);
+        AZ_LANE0(a.flags[gi] = (uint8_t)f);
+    }
+    if (a.stats) {
+        for (u32 q = 0; q < 10u; q++) { double sv = game_stat_np(g, q); AZ_LANE0(a.stats[(size_t)gi * 10 + q] = sv); }
+    }
+    if (a.player) AZ_LANE0(a.player[gi] = (uint8_t)g.cur);
+}
+
 // Discounted returns over the time-major trajectory of one launch window (reference loop: nn_runner.py:70-76,
 // qval = reward + gamma * qval backwards within an episode).  One thread per game walks its column backwards;
 // `done[t][g] != 0` ends an episode at move t; `carry[g]` holds the return flowing in from the NEXT window
@@ -395,6 +488,8 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
 struct azul_batch {
     BatchDev d;          // `T` is written once by azul_batch_create
     int device;          // the device the batch's arrays live on: every entry runs there (DeviceGuard)
+    int players;         // 2 (128-byte records, every entry) or 3 / 4 (256-byte records, the rule entries: row N4)
+    int rec_bytes;
     hipEvent_t ev0, ev1; // bracket of a timed region (azul_timing_begin / _end)
     std::vector<hipEvent_t> lev;   // event pairs around the individual self-play launches of a timed region
     int timed_launches;  // launches since azul_timing_begin
@@ -471,11 +566,12 @@ static int batch_alloc(azul_batch *b, int n_games, int first_player, int tile_po
 {
     HIP_TRY(hipGetDevice(&b->device));
     const size_t N = (size_t)n_games;
+    const size_t RB = (size_t)b->rec_bytes;
     b->d.n = (u32)n_games;
     b->d.rules.first_player = (u32)first_player;
     b->d.rules.tile_pool = (u32)tile_pool;
     b->d.draw_margin = AZ_DRAW_MARGIN;
-    HIP_TRY(hipMalloc((void **)&b->d.state, N * AZUL_RECORD_BYTES));
+    HIP_TRY(hipMalloc((void **)&b->d.state, N * RB));
     HIP_TRY(hipMalloc((void **)&b->d.mt, N * 624 * sizeof(u32)));
     HIP_TRY(hipMalloc((void **)&b->d.mtpos, N * sizeof(u32)));
     HIP_TRY(hipMalloc((void **)&b->d.T, sizeof(double) * T_WORDS));
@@ -487,7 +583,7 @@ static int batch_alloc(azul_batch *b, int n_games, int first_player, int tile_po
     std::vector<double> hT((size_t)T_WORDS);
     if (!build_sample_tab(hT.data())) return fail(AZUL_ERR_INVALID, "weight-table decomposition check failed on this host");
     HIP_TRY(hipMemcpy((void *)b->d.T, hT.data(), hT.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(b->d.state, 0, N * AZUL_RECORD_BYTES));
+    HIP_TRY(hipMemset(b->d.state, 0, N * RB));
     HIP_TRY(hipMemset(b->d.mt, 0, N * 624 * sizeof(u32)));
     {   // a defined stream even before azul_batch_seed: index 624 over an all-zero state is never used un-seeded
         std::vector<u32> pos(N, 624u);
@@ -503,13 +599,21 @@ static int batch_alloc(azul_batch *b, int n_games, int first_player, int tile_po
 
 int azul_batch_create(azul_batch_t **out, int n_games, int first_player, int tile_pool)
 {
+    return azul_batch_create_players(out, n_games, 2, first_player, tile_pool);
+}
+
+int azul_batch_create_players(azul_batch_t **out, int n_games, int players, int first_player, int tile_pool)
+{
     if (!out || n_games <= 0) return fail(AZUL_ERR_INVALID, "azul_batch_create: bad arguments");
-    if (first_player < 0 || first_player > 2) return fail(AZUL_ERR_RULE, "first_player must be 0 (Random), 1 or 2");
+    if (players < 2 || players > 4) return fail(AZUL_ERR_INVALID, "players must be 2, 3 or 4");
+    if (first_player < 0 || first_player > players) return fail(AZUL_ERR_RULE, "first_player must be 0 (Random) or 1 .. players");
     if (tile_pool != AZUL_POOL_RANDOM && tile_pool != AZUL_POOL_LID) return fail(AZUL_ERR_RULE, "tile_pool must be AZUL_POOL_RANDOM or AZUL_POOL_LID");
     *out = nullptr;
     azul_batch *b = new azul_batch();
     memset(&b->d, 0, sizeof(b->d));
     b->device = -1;
+    b->players = players;
+    b->rec_bytes = players == 2 ? AZUL_RECORD_BYTES : AZUL_RECORD_BYTES_WIDE;
     b->ev0 = b->ev1 = nullptr;
     b->timing = false;
     b->timed_launches = 0;
@@ -529,6 +633,8 @@ int azul_batch_destroy(azul_batch_t *b)
 }
 
 int azul_batch_size(const azul_batch_t *b) { return b ? (int)b->d.n : 0; }
+int azul_batch_players(const azul_batch_t *b) { return b ? b->players : 0; }
+int azul_batch_record_bytes(const azul_batch_t *b) { return b ? b->rec_bytes : 0; }
 void *azul_batch_state_dev(azul_batch_t *b) { return b ? b->d.state : nullptr; }
 void *azul_batch_mt_dev(azul_batch_t *b) { return b ? b->d.mt : nullptr; }
 void *azul_batch_mtpos_dev(azul_batch_t *b) { return b ? b->d.mtpos : nullptr; }
@@ -544,8 +650,8 @@ int azul_batch_get_state(azul_batch_t *b, int first, int count, void *records_ho
     BATCH_GUARD(b, stream);
     if (int rc = check_range(b, first, count)) return rc;
     if (!records_host) return fail(AZUL_ERR_INVALID, "records_host is NULL");
-    HIP_TRY(hipMemcpyAsync(records_host, b->d.state + (size_t)first * AZUL_RECORD_BYTES, (size_t)count * AZUL_RECORD_BYTES,
-                           hipMemcpyDeviceToHost, (hipStream_t)stream));
+    const size_t RB = (size_t)b->rec_bytes;
+    HIP_TRY(hipMemcpyAsync(records_host, b->d.state + (size_t)first * RB, (size_t)count * RB, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return AZUL_SUCCESS;
 }
@@ -556,20 +662,25 @@ int azul_batch_set_state(azul_batch_t *b, int first, int count, const void *reco
     if (int rc = check_range(b, first, count)) return rc;
     if (!records_host) return fail(AZUL_ERR_INVALID, "records_host is NULL");
     const uint8_t *p = (const uint8_t *)records_host;
-    for (int i = 0; i < count; i++, p += AZUL_RECORD_BYTES) {
+    const size_t RB = (size_t)b->rec_bytes;
+    for (int i = 0; i < count; i++, p += RB) {
         // domain the kernels are exact on (documented in DESIGN.md)
+        const u32 P = (u32)b->players;
         u32 flags = p[31];
-        if ((flags & 7u) > 2u || ((flags >> 3) & 7u) > 2u || (flags & 0x80u)) return fail(AZUL_ERR_RANGE, "flags: players are 0..2");
-        if (p[82] > 7 || p[83] > 7) return fail(AZUL_ERR_RANGE, "floors are 0..7 (azul.py:120-123)");
-        u32 w0, w1;
-        memcpy(&w0, p + 84, 4); memcpy(&w1, p + 88, 4);
-        if ((w0 | w1) >> 25) return fail(AZUL_ERR_RANGE, "walls are 25-bit boards");
+        if ((flags & 7u) > P || ((flags >> 3) & 7u) > P || (flags & 0x80u)) return fail(AZUL_ERR_RANGE, "flags: players are 0..P");
+        const uint8_t *floors = p + (P == 2 ? 82 : 132), *walls = p + (P == 2 ? 84 : 136), *box = p + (P == 2 ? 96 : 160);
+        for (u32 q = 0; q < P; q++) {
+            if (floors[q] > 7) return fail(AZUL_ERR_RANGE, "floors are 0..7 (azul.py:120-123)");
+            u32 w;
+            memcpy(&w, walls + 4 * q, 4);
+            if (w >> 25) return fail(AZUL_ERR_RANGE, "walls are 25-bit boards");
+        }
         u32 sb = 0, sl = 0;
-        for (int c = 0; c < 5; c++) { sb += p[96 + c]; sl += p[101 + c]; }
+        for (int c = 0; c < 5; c++) { sb += box[c]; sl += box[5 + c]; }
         if (sb > 255 || sl > 255) return fail(AZUL_ERR_RANGE, "box / lid hold at most 255 tiles in total");
+        if (P != 2 && p[204] != P) return fail(AZUL_ERR_RANGE, "wide record: byte 204 must hold the batch's number of players");
     }
-    HIP_TRY(hipMemcpyAsync(b->d.state + (size_t)first * AZUL_RECORD_BYTES, records_host, (size_t)count * AZUL_RECORD_BYTES,
-                           hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(b->d.state + (size_t)first * RB, records_host, (size_t)count * RB, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return AZUL_SUCCESS;
 }
@@ -638,13 +749,37 @@ int azul_batch_seed(azul_batch_t *b, uint64_t seed_base, const uint64_t *seeds_h
     return AZUL_SUCCESS;
 }
 
+static bool np_supported(const OpArgs &a)
+{
+    switch (a.op) {
+    case OP_QUERY: return !a.obs && !a.potential;       // get_state / the what-if potential are GameRunner's: two players
+    case OP_INIT: case OP_NEW_ROUND: case OP_MOVE: case OP_NEXT_PLAYER: case OP_COUNT_SCORE: case OP_STEP:
+    case OP_RANDOM_ACTION: case OP_SAMPLE_MASK: return true;
+    default: return false;
+    }
+}
+
 static int launch_op(azul_batch_t *b, const OpArgs &a, void *stream)
 {
     if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
-    if (b->d.rules.tile_pool == POOL_LID)
-        hipLaunchKernelGGL(azul_op_kernel<true>, dim3(b->d.n), dim3(64), 0, (hipStream_t)stream, b->d, a);
-    else
-        hipLaunchKernelGGL(azul_op_kernel<false>, dim3(b->d.n), dim3(64), 0, (hipStream_t)stream, b->d, a);
+    const dim3 grid(b->d.n), block(64);
+    const hipStream_t st = (hipStream_t)stream;
+    const bool lid = b->d.rules.tile_pool == POOL_LID;
+    if (b->players == 2) {
+        if (lid) hipLaunchKernelGGL(azul_op_kernel<true>, grid, block, 0, st, b->d, a);
+        else hipLaunchKernelGGL(azul_op_kernel<false>, grid, block, 0, st, b->d, a);
+    } else {
+        if (!np_supported(a))
+            return fail(AZUL_ERR_INVALID, "this entry mirrors GameRunner, which the reference defines for two players only (game_runner.py:50,57); "
+                                          "3- and 4-player batches support the Azul rule entries");
+        if (b->players == 3) {
+            if (lid) hipLaunchKernelGGL((azul_np_op_kernel<3, true>), grid, block, 0, st, b->d, a);
+            else hipLaunchKernelGGL((azul_np_op_kernel<3, false>), grid, block, 0, st, b->d, a);
+        } else {
+            if (lid) hipLaunchKernelGGL((azul_np_op_kernel<4, true>), grid, block, 0, st, b->d, a);
+            else hipLaunchKernelGGL((azul_np_op_kernel<4, false>), grid, block, 0, st, b->d, a);
+        }
+    }
     HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }
@@ -850,6 +985,7 @@ int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random,
 {
     BATCH_GUARD(b, stream);
     if (!b || n_steps < 0) return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: bad arguments");
+    if (b->players != 2) return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: GameRunner self-play is two-player (game_runner.py:50)");
     if (num_inputs != PF_IN || hidden_size != PF_HID || num_actions != PF_ACT)
         return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: only ActorCritic(136, 180, hidden 180) is compiled in");
     if (!w1t_dev || !b1_dev || !w2c_dev || !b2c_dev || !w2a_t_dev || !b2a_dev || !obs_dev || !mask_dev || !player_dev || !action_dev ||
@@ -946,6 +1082,7 @@ int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_
 {
     BATCH_GUARD(b, stream);
     if (!b || n_steps < 0) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: bad arguments");
+    if (b->players != 2) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: GameRunner self-play is two-player (game_runner.py:50)");
     if (n_steps == 0) return AZUL_SUCCESS;
     TrajArgs t = {n_steps, mask_dev, (u64 *)maskbits_dev, action_dev, reward_dev, done_dev, rec_dev, packed_dev};
     const bool none = !mask_dev && !maskbits_dev && !action_dev && !reward_dev && !done_dev && !rec_dev && !packed_dev;

@@ -88,6 +88,7 @@ AZ_FN void stu_u8(uint8_t *p, u32 v) { *p = (uint8_t)v; }
 AZ_FN void stu_u64(u64 *p, u64 v) { *p = v; }
 #endif
 AZ_FN vf64 self64(bool c, vf64 a, vf64 b) { return c ? a : b; }
+AZ_FN vu32 selu(bool c, vu32 a, vu32 b) { return c ? a : b; }     // select between lane values on a UNIFORM condition
 AZ_FN vu32 vmin(vu32 a, u32 b) { return a < b ? a : b; }
 // per-lane pointers (a VGPR pair on the device): trajectory streams advance with ONE vector add per step and are
 // written by all lanes (lanes without a value of their own repeat a neighbour's address AND data)

@@ -1,7 +1,7 @@
 """Single-game bridge between the Python facade (azul.py / game_runner.py of this package) and the C ABI.
 
-A facade call = pack the object's numpy attributes into one 128-byte record, run ONE kernel on a 1-game
-batch, unpack.  Randomness stays the reference's: the process-global CPython ``random`` stream.  Before a
+A facade call = pack the object's numpy attributes into one record (128 bytes for two players, the 256-byte wide
+record for three and four), run ONE kernel on a 1-game batch, unpack.  Randomness stays the reference's: the process-global CPython ``random`` stream.  Before a
 call that draws, the generator's 624 words + index are pushed into the game's device stream
 (``azul_batch_set_rng``); afterwards the advanced state is pulled back and installed with
 ``random.setstate`` -- so ``random.seed(1); Azul().new_round()`` gives the reference's board exactly
@@ -17,7 +17,7 @@ from . import _lib as L
 class HipBackend:
     """1-game BatchedAzul per rule set, created lazily on the current CUDA device."""
 
-    def __init__(self, first_player, tile_pool):
+    def __init__(self, first_player, tile_pool, players=2):
         import torch
         from .batch import BatchedAzul
         if not torch.cuda.is_available():
@@ -26,7 +26,7 @@ class HipBackend:
         self.torch = torch
         rules = {"first_player": "Random" if first_player == L.FIRST_RANDOM else int(first_player),
                  "tile_pool": "Lid" if tile_pool == L.POOL_LID else "Random"}
-        self.env = BatchedAzul(1, rules=rules)
+        self.env = BatchedAzul(1, rules=rules, players=players)
 
     # --- RNG bridging -------------------------------------------------------------------------
     def push_rng(self):
@@ -101,8 +101,8 @@ _FACTORY = HipBackend      # tests/hostcheck swaps in its 64-lane host emulation
 _CACHE = {}
 
 
-def backend(first_player, tile_pool):
-    key = (_FACTORY, int(first_player), int(tile_pool))
+def backend(first_player, tile_pool, players=2):
+    key = (_FACTORY, int(first_player), int(tile_pool), int(players))
     if key not in _CACHE:
-        _CACHE[key] = _FACTORY(int(first_player), int(tile_pool))
+        _CACHE[key] = _FACTORY(int(first_player), int(tile_pool), int(players))
     return _CACHE[key]

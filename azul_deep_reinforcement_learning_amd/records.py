@@ -25,6 +25,27 @@ RECORD_DTYPE = np.dtype([
 ])
 assert RECORD_DTYPE.itemsize == 128
 
+# the 256-byte wide record of 3- and 4-player batches (include/azul_hip.h; row N4)
+RECORD_NP_DTYPE = np.dtype([
+    ("displays", "u1", (5, 5)),
+    ("center", "u1", (6,)),
+    ("flags", "u1"),
+    ("pattern_lines", "u1", (4, 5, 5)),
+    ("floors", "u1", (4,)),
+    ("walls", "<u4", (4,)),
+    ("score", "<i2", (4,)),
+    ("box", "u1", (5,)),
+    ("lid", "u1", (5,)),
+    ("turn_counter", "<u2"),
+    ("first_player_stats", "<u2", (4,)),
+    ("floor_penalty", "<i2", (4,)),
+    ("max_combo", "u1", (4,)),
+    ("completed_lines", "u1", (4, 3)),
+    ("players", "u1"),
+    ("reserved", "u1", (51,)),
+])
+assert RECORD_NP_DTYPE.itemsize == 256
+
 _WALL_SHIFTS = np.arange(25, dtype=np.uint32)
 
 
@@ -38,61 +59,80 @@ def unpack_flags(flags):
 
 
 def walls_to_bits(walls):
-    """bool[2][5][5] -> uint32[2] (bit 5*row+colour)."""
-    w = np.asarray(walls).astype(bool).reshape(2, 25).astype(np.uint32)
+    """bool[P][5][5] -> uint32[P] (bit 5*row+colour)."""
+    w = np.asarray(walls).astype(bool)
+    w = w.reshape(w.shape[0], 25).astype(np.uint32)
     return (w << _WALL_SHIFTS).sum(axis=1).astype(np.uint32)
 
 
 def bits_to_walls(bits):
-    b = np.asarray(bits, dtype=np.uint32).reshape(2, 1)
-    return (((b >> _WALL_SHIFTS) & 1) != 0).reshape(2, 5, 5)
+    b = np.asarray(bits, dtype=np.uint32).reshape(-1, 1)
+    return (((b >> _WALL_SHIFTS) & 1) != 0).reshape(b.shape[0], 5, 5)
+
+
+def record_players(rec):
+    """Number of players a record describes: 2 for the 128-byte record, the `players` byte of the 256-byte wide record."""
+    return int(rec["players"]) if "players" in rec.dtype.names else 2
 
 
 def record_to_json(rec):
-    """One 128-byte record -> the dict Azul.export_JSON writes (azul.py:106-117: ten keys) plus `x_*` keys for what the
-    reference's schema leaves out (tile pools, end_of_game flag, per-game statistics, GameRunner's score/move counters)."""
+    """One record (128 bytes, or the 256-byte wide record of 3 / 4 players) -> the dict Azul.export_JSON writes
+    (azul.py:106-117: ten keys) plus `x_*` keys for what the reference's schema leaves out (tile pools, end_of_game flag,
+    per-game statistics, GameRunner's score/move counters)."""
     cur, nfp, eog = unpack_flags(rec["flags"])
+    P = record_players(rec)
     d = {
         "game_board_displays": rec["displays"].astype(int).tolist(),
         "game_board_center": rec["center"].astype(int).tolist(),
-        "pattern_lines": rec["pattern_lines"].astype(int).tolist(),
-        "walls": bits_to_walls(rec["walls"]).astype(int).tolist(),
-        "floors": rec["floors"].astype(int).tolist(),
-        "score": rec["score"].astype(int).tolist(),
+        "pattern_lines": rec["pattern_lines"][:P].astype(int).tolist(),
+        "walls": bits_to_walls(rec["walls"][:P]).astype(int).tolist(),
+        "floors": rec["floors"][:P].astype(int).tolist(),
+        "score": rec["score"][:P].astype(int).tolist(),
         "current_player": int(cur),
         "next_first_player": int(nfp),
-        "players": 2,
+        "players": P,
         "turn_counter": int(rec["turn_counter"]),
         "x_end_of_game": bool(eog),
         "x_box_tiles": rec["box"].astype(int).tolist(),
         "x_lid_tiles": rec["lid"].astype(int).tolist(),
-        "x_first_player_stats": rec["first_player_stats"].astype(int).tolist(),
-        "x_floor_penalty": rec["floor_penalty"].astype(int).tolist(),
-        "x_max_combo": rec["max_combo"].astype(int).tolist(),
-        "x_completed_lines": rec["completed_lines"].astype(int).tolist(),
-        "x_player_score": int(rec["player_score"]),
-        "x_move_counter": int(rec["move_counter"]),
+        "x_first_player_stats": rec["first_player_stats"][:P].astype(int).tolist(),
+        "x_floor_penalty": rec["floor_penalty"][:P].astype(int).tolist(),
+        "x_max_combo": rec["max_combo"][:P].astype(int).tolist(),
+        "x_completed_lines": rec["completed_lines"][:P].astype(int).tolist(),
     }
+    if P == 2:
+        d["x_player_score"] = int(rec["player_score"])
+        d["x_move_counter"] = int(rec["move_counter"])
     return d
 
 
 def json_to_record(d):
     """Inverse of record_to_json; a plain reference file (no `x_*` keys) loads with empty pools / zero statistics, like
-    Azul.import_JSON (azul.py:90-104), which restores exactly those ten keys."""
-    if int(d.get("players", 2)) != 2:
-        raise ValueError("the MI355X kernels play two-player Azul")
-    rec = np.zeros((), dtype=RECORD_DTYPE)
+    Azul.import_JSON (azul.py:90-104), which restores exactly those ten keys.  Two players give a 128-byte record, three and
+    four the 256-byte wide record."""
+    P = int(d.get("players", 2))
+    if P not in (2, 3, 4):
+        raise ValueError("Azul is a game for 2, 3 or 4 players")
+    rec = np.zeros((), dtype=RECORD_DTYPE if P == 2 else RECORD_NP_DTYPE)
+    if P != 2:
+        rec["players"] = P
     rec["displays"] = np.asarray(d["game_board_displays"])
     rec["center"] = np.asarray(d["game_board_center"])
-    rec["pattern_lines"] = np.asarray(d["pattern_lines"])
-    rec["walls"] = walls_to_bits(np.asarray(d["walls"]))
-    rec["floors"] = np.asarray(d["floors"])
-    rec["score"] = np.asarray(d["score"])
+    rec["pattern_lines"][:P] = np.asarray(d["pattern_lines"])
+    rec["walls"][:P] = walls_to_bits(np.asarray(d["walls"]))
+    rec["floors"][:P] = np.asarray(d["floors"])
+    rec["score"][:P] = np.asarray(d["score"])
     rec["flags"] = pack_flags(d["current_player"], d["next_first_player"], d.get("x_end_of_game", False))
     rec["turn_counter"] = d["turn_counter"]
-    for key, field in (("x_box_tiles", "box"), ("x_lid_tiles", "lid"), ("x_first_player_stats", "first_player_stats"),
-                       ("x_floor_penalty", "floor_penalty"), ("x_max_combo", "max_combo"), ("x_completed_lines", "completed_lines"),
-                       ("x_player_score", "player_score"), ("x_move_counter", "move_counter")):
+    for key, field in (("x_box_tiles", "box"), ("x_lid_tiles", "lid")):
         if key in d:
             rec[field] = np.asarray(d[key])
+    for key, field in (("x_first_player_stats", "first_player_stats"), ("x_floor_penalty", "floor_penalty"), ("x_max_combo", "max_combo"),
+                       ("x_completed_lines", "completed_lines")):
+        if key in d:
+            rec[field][:P] = np.asarray(d[key])
+    if P == 2:
+        for key, field in (("x_player_score", "player_score"), ("x_move_counter", "move_counter")):
+            if key in d:
+                rec[field] = np.asarray(d[key])
     return rec

@@ -140,7 +140,12 @@ class BatchedTrainer:
         ro.policy.load_state_dict(ck["policy"])
         self.learner.load_optimizer_state(ck["optimizer"])          # also rebuilds the flat master copy from the module
         ro.refresh_weights()
-        ro.game_id_base = int(ck.get("game_id_base", ro.game_id_base))     # the sampling streams are keyed by the global game id
+        new_base = int(ck.get("game_id_base", ro.game_id_base))            # the sampling streams are keyed by the global game id
+        if new_base != ro.game_id_base:
+            ro.game_id_base = new_base
+            if ro.use_graph:                                                # the id base is a launch argument baked into the captured graphs
+                ro.graphs = []
+                ro._capture(getattr(ro, "gamma", self.gamma))               # (its warm-up window advances the games: they are restored below)
         for p, (env, e) in enumerate(zip(ro.envs, ck["envs"])):
             env.set_id_base(ro.game_id_base + p * ro.h)
             env.set_records(e["records"])

@@ -42,6 +42,27 @@
  *   124   2  i16 player_score              GameRunner.player_score        game_runner.py:35
  *   126   2  u16 move_counter              GameRunner.move_counter        game_runner.py:36
  *
+ * Wide record (batches of THREE or FOUR players, azul_batch_create_players; row N4 of SURVEY.md 8f): 256 bytes per game.
+ * The reference deals five displays whatever the number of players (azul.py:19), so only the per-player fields grow:
+ *
+ *   off size field                         reference (azul.py)
+ *     0  25  u8  displays[5][5]            azul.py:19
+ *    25   6  u8  center[6]                 azul.py:20,71
+ *    31   1  u8  flags                     bits0-2 current_player (0..4), bits3-5 next_first_player (0..4), bit6 end_of_game
+ *    32 100  u8  pattern_lines[4][5][5]    azul.py:21-22   (players beyond `players` stay zero)
+ *   132   4  u8  floors[4]                 azul.py:25
+ *   136  16  u32 walls[4]                  azul.py:23-24
+ *   152   8  i16 score[4]                  azul.py:26
+ *   160   5  u8  box[5]                    azul.py:51
+ *   165   5  u8  lid[5]                    azul.py:52
+ *   170   2  u16 turn_counter              azul.py:30
+ *   172   8  u16 first_player_stats[4]     azul.py:31
+ *   180   8  i16 floor_penalty[4]          azul.py:32
+ *   188   4  u8  max_combo[4]              azul.py:33
+ *   192  12  u8  completed_lines[4][3]     azul.py:58
+ *   204   1  u8  players                   azul.py:28
+ *   205  51      reserved (zero)
+ *
  * Random numbers: every game owns a CPython-exact MT19937 stream (624 words + index), i.e. what the
  * reference consumes through the process-global `random` module (azul.py:37,78,87; game_runner.py:97).
  */
@@ -55,6 +76,7 @@ extern "C" {
 #endif
 
 #define AZUL_RECORD_BYTES 128
+#define AZUL_RECORD_BYTES_WIDE 256   /* batches of 3 or 4 players */
 #define AZUL_NUM_ACTIONS  180
 #define AZUL_OBS_SIZE     136
 #define AZUL_MT_WORDS     624
@@ -98,6 +120,14 @@ const char *azul_version(void);
 /* ---- lifetime ------------------------------------------------------------------------------- */
 /* N two-player games on the current HIP device, rules as in Azul(rules=...) (azul.py:35-56). */
 int azul_batch_create(azul_batch_t **out, int n_games, int first_player, int tile_pool);
+/* N games of `players` = 2, 3 or 4 players: Azul(players=..., rules=...) (azul.py:18-33; first_player 0 = "Random" or 1..players).
+ * players = 2 is azul_batch_create.  For 3 and 4 players the records are the 256-byte wide records and the entries that
+ * mirror Azul's own methods work -- azul_batch_init / _new_round / _move / _legal_mask / _next_player / _flags / _count_score /
+ * _step / _statistics, the state and RNG I/O, azul_batch_random_action / _sample_mask -- while the entries that mirror
+ * GameRunner (two-player in the reference: game_runner.py:50,57) return AZUL_ERR_INVALID. */
+int azul_batch_create_players(azul_batch_t **out, int n_games, int players, int first_player, int tile_pool);
+int azul_batch_players(const azul_batch_t *b);
+int azul_batch_record_bytes(const azul_batch_t *b);       /* 128, or 256 for 3 / 4 players */
 int azul_batch_destroy(azul_batch_t *b);
 int azul_batch_size(const azul_batch_t *b);
 /* device pointers of the resident arrays (for zero-copy views): records [N][128] u8, MT words [N][624] u32, MT index [N] u32 */

@@ -663,6 +663,72 @@ void oz_unpack(oz_runner *q, const uint8_t rec[128], int tile_pool, int first_pl
 }
 
 /* ------------------------------------------------------------------------- */
+/* wide record: 256 bytes, 2..4 players (layout: include/azul_hip.h, row N4)  */
+/* ------------------------------------------------------------------------- */
+int oz_pack_np(const oz_game *g, uint8_t rec[256])
+{
+    int bad = 0;
+    const int P = g->players;
+    memset(rec, 0, 256);
+    if (P < 2 || P > OZ_MAXP) return -1;
+#define CHK(v, lo, hi) do { if ((v) < (lo) || (v) > (hi)) bad = 1; } while (0)
+    for (int d = 0; d < 5; d++) for (int c = 0; c < 5; c++) { CHK(g->displays[d][c], 0, 255); rec[d * 5 + c] = (uint8_t)g->displays[d][c]; }
+    for (int c = 0; c < 6; c++) { CHK(g->center[c], 0, 255); rec[25 + c] = (uint8_t)g->center[c]; }
+    CHK(g->current_player, 0, P); CHK(g->next_first_player, 0, P);
+    rec[31] = (uint8_t)((g->current_player & 7) | ((g->next_first_player & 7) << 3) | ((g->end_of_game ? 1 : 0) << 6));
+    for (int p = 0; p < P; p++) for (int r = 0; r < 5; r++) for (int c = 0; c < 5; c++) {
+        CHK(g->pattern_lines[p][r][c], 0, 255);
+        rec[32 + p * 25 + r * 5 + c] = (uint8_t)g->pattern_lines[p][r][c];
+    }
+    for (int p = 0; p < P; p++) { CHK(g->floors[p], 0, 7); rec[132 + p] = (uint8_t)g->floors[p]; }
+    for (int p = 0; p < P; p++) {
+        uint32_t w = 0;
+        for (int r = 0; r < 5; r++) for (int c = 0; c < 5; c++) if (g->walls[p][r][c]) w |= 1u << (r * 5 + c);
+        for (int k = 0; k < 4; k++) rec[136 + 4 * p + k] = (uint8_t)((w >> (8 * k)) & 0xff);
+    }
+    for (int p = 0; p < P; p++) { CHK(g->score[p], -32768, 32767); put16(rec + 152 + 2 * p, (int)g->score[p]); }
+    for (int c = 0; c < 5; c++) { CHK(g->box[c], 0, 255); rec[160 + c] = (uint8_t)g->box[c]; }
+    for (int c = 0; c < 5; c++) { CHK(g->lid[c], 0, 255); rec[165 + c] = (uint8_t)g->lid[c]; }
+    CHK(g->turn_counter, 0, 65535); put16(rec + 170, g->turn_counter);
+    for (int p = 0; p < P; p++) { CHK(g->first_player_stats[p], 0, 65535); put16(rec + 172 + 2 * p, (int)g->first_player_stats[p]); }
+    for (int p = 0; p < P; p++) { CHK(g->floor_penalty[p], -32768, 32767); put16(rec + 180 + 2 * p, (int)g->floor_penalty[p]); }
+    for (int p = 0; p < P; p++) { CHK(g->max_combo[p], 0, 255); rec[188 + p] = (uint8_t)g->max_combo[p]; }
+    for (int p = 0; p < P; p++) for (int k = 0; k < 3; k++) { CHK(g->completed_lines[p][k], 0, 255); rec[192 + p * 3 + k] = (uint8_t)g->completed_lines[p][k]; }
+    rec[204] = (uint8_t)P;
+#undef CHK
+    return bad ? -1 : 0;
+}
+
+void oz_unpack_np(oz_game *g, const uint8_t rec[256], int tile_pool)
+{
+    memset(g, 0, sizeof(*g));
+    const int P = rec[204];
+    g->players = P;
+    g->tile_pool = tile_pool;
+    for (int d = 0; d < 5; d++) for (int c = 0; c < 5; c++) g->displays[d][c] = rec[d * 5 + c];
+    for (int c = 0; c < 6; c++) g->center[c] = rec[25 + c];
+    g->current_player = rec[31] & 7;
+    g->next_first_player = (rec[31] >> 3) & 7;
+    g->end_of_game = (rec[31] >> 6) & 1;
+    for (int p = 0; p < P; p++) for (int r = 0; r < 5; r++) for (int c = 0; c < 5; c++)
+        g->pattern_lines[p][r][c] = rec[32 + p * 25 + r * 5 + c];
+    for (int p = 0; p < P; p++) g->floors[p] = rec[132 + p];
+    for (int p = 0; p < P; p++) {
+        uint32_t w = 0;
+        for (int k = 0; k < 4; k++) w |= (uint32_t)rec[136 + 4 * p + k] << (8 * k);
+        for (int r = 0; r < 5; r++) for (int c = 0; c < 5; c++) g->walls[p][r][c] = (uint8_t)((w >> (r * 5 + c)) & 1);
+    }
+    for (int p = 0; p < P; p++) g->score[p] = get16s(rec + 152 + 2 * p);
+    for (int c = 0; c < 5; c++) g->box[c] = rec[160 + c];
+    for (int c = 0; c < 5; c++) g->lid[c] = rec[165 + c];
+    g->turn_counter = get16u(rec + 170);
+    for (int p = 0; p < P; p++) g->first_player_stats[p] = get16u(rec + 172 + 2 * p);
+    for (int p = 0; p < P; p++) g->floor_penalty[p] = get16s(rec + 180 + 2 * p);
+    for (int p = 0; p < P; p++) g->max_combo[p] = rec[188 + p];
+    for (int p = 0; p < P; p++) for (int k = 0; k < 3; k++) g->completed_lines[p][k] = rec[192 + p * 3 + k];
+}
+
+/* ------------------------------------------------------------------------- */
 /* batched drivers                                                           */
 /* ------------------------------------------------------------------------- */
 int oz_stream_start(oz_runner *q, oz_rng *r, uint64_t seed, int first_player, int tile_pool)

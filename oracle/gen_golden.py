@@ -7,6 +7,7 @@ Imports /root/reference/azulnet (with the two removed numpy aliases restored), p
 through the reference's own GameRunner / Azul / RandomAgent code and stores inputs + expected
 outputs as arrays.  Only DATA is written: no reference source text leaves the container.
 """
+import collections
 import copy
 import os
 import random
@@ -293,6 +294,134 @@ def gen_a2c_update():
     print("wrote a2c_update.npz")
 
 
+PLAYER_RULESETS = {
+    # name: (rules handed to the reference with `players` substituted for "P", first_player code, tile_pool code)
+    "default": ({}, -1, 0),                                                     # Azul(players=P): random pool, player 1 starts
+    "lid_randomfirst": ({"first_player": "Random", "tile_pool": "Lid"}, 0, 1),
+    "lid_firstP": ({"first_player": "P", "tile_pool": "Lid"}, "P", 1),          # the LAST player starts
+}
+PLAYER_FIELDS = ["mask", "action", "displays", "center", "pattern_lines", "walls", "floors", "score", "cur", "nfp", "eog_flag",
+                 "turn_counter", "box", "lid", "first_player_stats", "floor_penalty", "max_combo", "completed_lines", "rng_words",
+                 "eor_before_step", "eog_walls"]
+
+
+def play_players_stream(seed, players, rules, max_moves=400):
+    """Azul(players=3|4) driven through Azul.step (azul.py:296-313) with uniformly random LEGAL actions; the action picker
+    is a private random.Random so that the process-global stream is consumed by the game alone (azul.py:37,78,87)."""
+    from azulnet.azul import GameEnded, IllegalMove
+    from azulnet import nn_deserialize
+    rows = {k: [] for k in PLAYER_FIELDS}
+    random.seed(seed)
+    pos0 = words_pos()
+    words = [0, pos0]
+
+    def sync():
+        pos = words_pos()
+        d = pos - words[1]
+        if d < 0:
+            d += 624
+        words[0] += d
+        words[1] = pos
+        return words[0]
+
+    picker = random.Random(seed * 7919 + players)
+    g = Azul(players=players, rules=dict(rules))
+    words_ctor = sync()
+    init = {"nfp": g.next_first_player, "cur": g.current_player}
+    g.new_round()
+    words_round = sync()
+    first = {"displays": np.array(g.game_board_displays, dtype=np.uint8), "center": np.array(g.game_board_center, dtype=np.uint8),
+             "cur": g.current_player, "fps": np.array(g.first_player_stats, dtype=np.uint16)}
+    end = "max_moves"
+    illegal_checked = 0
+    for t in range(max_moves):
+        mask = check_all_valid(g)
+        legal = np.flatnonzero(mask)
+        if len(legal) == 0:
+            end = "stuck"                            # hazard H3: nobody can move, the round is not over
+            break
+        if t % 9 == 4 and len(legal) < 180:           # an illegal move raises and leaves the game untouched (azul.py:301-302)
+            bad = int(np.flatnonzero(~mask)[picker.randrange(180 - len(legal))])
+            before = copy.deepcopy(g)
+            try:
+                g.step(*nn_deserialize(bad))
+                raise AssertionError("illegal move accepted")
+            except IllegalMove:
+                assert g == before
+                illegal_checked += 1
+        a = int(legal[picker.randrange(len(legal))])
+        eor_before = bool(g.is_end_of_round())
+        try:
+            g.step(*nn_deserialize(a))
+        except ValueError:                            # "Lid" pool: box and lid both empty inside new_round (azul.py:85-87)
+            end = "box_empty"
+            rows["mask"].append(np.packbits(mask, bitorder="little"))
+            rows["action"].append(a)
+            break
+        r = rows
+        r["mask"].append(np.packbits(mask, bitorder="little"))
+        r["action"].append(a)
+        r["displays"].append(np.array(g.game_board_displays, dtype=np.uint8))
+        r["center"].append(np.array(g.game_board_center, dtype=np.uint8))
+        r["pattern_lines"].append(np.array(g.pattern_lines, dtype=np.uint8))
+        r["walls"].append(np.array(g.walls, dtype=np.uint8))
+        r["floors"].append(np.array(g.floors, dtype=np.uint8))
+        r["score"].append(np.array(g.score, dtype=np.int16))
+        r["cur"].append(g.current_player)
+        r["nfp"].append(g.next_first_player)
+        r["eog_flag"].append(bool(g.end_of_game))
+        r["turn_counter"].append(g.turn_counter)
+        r["box"].append(np.array(g.box_tiles, dtype=np.uint8) if g.tile_pool == "Lid" else np.zeros(5, np.uint8))
+        r["lid"].append(np.array(g.lid_tiles, dtype=np.uint8) if g.tile_pool == "Lid" else np.zeros(5, np.uint8))
+        r["first_player_stats"].append(np.array(g.first_player_stats, dtype=np.uint16))
+        r["floor_penalty"].append(np.array(g.floor_penalty, dtype=np.int16))
+        r["max_combo"].append(np.array(g.max_combo, dtype=np.uint8))
+        r["completed_lines"].append(np.array(g.completed_lines, dtype=np.uint8))
+        r["rng_words"].append(sync())
+        r["eor_before_step"].append(eor_before)
+        r["eog_walls"].append(bool(g.is_end_of_game()))
+        if g.end_of_game:
+            end = "game_end"
+            try:
+                g.step(*nn_deserialize(a))
+                raise AssertionError("step on a finished game accepted")
+            except GameEnded:
+                pass
+            break
+    st = g.get_statistics()
+    stats = np.array([float(st[k]) for k in ["player_score", "opponent_score", "rounds", "percent_first_player", "floor_penalty",
+                                             "max_combo", "completed_rows", "completed_columns", "completed_colors", "win_percent"]])
+    out = {k: np.array(v) for k, v in rows.items()}
+    out.update({"end": np.array(end), "stats": stats, "words_ctor": np.array(words_ctor), "words_round": np.array(words_round),
+                "init_nfp": np.array(init["nfp"]), "first_displays": first["displays"], "first_center": first["center"],
+                "first_cur": np.array(first["cur"]), "first_fps": first["fps"], "illegal_checked": np.array(illegal_checked)})
+    return out
+
+
+def gen_players():
+    """Row N4, first slice: what the reference itself does for 3 and 4 players (5 displays, azul.py:18-33,162-191,291-295)."""
+    blob = {}
+    index = []
+    for players in (3, 4):
+        for name, (rules, fp, pool) in PLAYER_RULESETS.items():
+            rules = {k: (players if v == "P" else v) for k, v in rules.items()}
+            fp = players if fp == "P" else fp
+            for seed in range(8):
+                key = "p%d_%s_s%d" % (players, name, seed)
+                d = play_players_stream(seed, players, rules)
+                for k, v in d.items():
+                    blob[key + "_" + k] = v
+                index.append((players, fp, pool, seed, key))
+    blob["index_players"] = np.array([i[0] for i in index])
+    blob["index_first"] = np.array([i[1] for i in index])
+    blob["index_pool"] = np.array([i[2] for i in index])
+    blob["index_seed"] = np.array([i[3] for i in index])
+    blob["index_key"] = np.array([i[4] for i in index])
+    np.savez_compressed(os.path.join(OUT, "traj_players.npz"), **blob)
+    ends = collections.Counter(str(blob[i[4] + "_end"]) for i in index)
+    print("wrote traj_players.npz (%d streams; endings: %s)" % (len(index), dict(ends)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("reference:", os.path.dirname(azulnet.__file__))
@@ -302,11 +431,15 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "a2c":
         gen_a2c_update()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "players":
+        gen_players()
+        return
     gen_rng()
     gen_boards()
     gen_trajectories()
     gen_policy_contract()
     gen_a2c_update()
+    gen_players()
 
 
 if __name__ == "__main__":

@@ -108,6 +108,8 @@ def lib():
         "oz_potential": (C.c_int64, [P(Game)]),
         "oz_pack": (C.c_int, [P(Runner), u8p]),
         "oz_unpack": (None, [P(Runner), u8p, C.c_int, C.c_int]),
+        "oz_pack_np": (C.c_int, [P(Game), u8p]),
+        "oz_unpack_np": (None, [P(Game), u8p, C.c_int]),
         "oz_stream_start": (C.c_int, [P(Runner), P(Rng), C.c_uint64, C.c_int, C.c_int]),
         "oz_stream_advance": (C.c_int, [P(Runner), P(Rng), C.c_int, u8p, i32p, i32p, u8p, u8p, u64p, u64p, f64p]),
         "oz_bench_selfplay": (C.c_uint64, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u64p]),
@@ -156,6 +158,33 @@ def unpack(rec, tile_pool=POOL_RANDOM, first_player=FIRST_ABSENT):
     q = Runner()
     lib().oz_unpack(C.byref(q), _p(raw, C.c_uint8), tile_pool, first_player)
     return q
+
+
+# wide record for 2..4 players (row N4), mirrored (independently) from include/azul_hip.h
+RECORD_NP_DTYPE = np.dtype([
+    ("displays", "u1", (5, 5)), ("center", "u1", (6,)), ("flags", "u1"),
+    ("pattern_lines", "u1", (4, 5, 5)), ("floors", "u1", (4,)), ("walls", "<u4", (4,)),
+    ("score", "<i2", (4,)), ("box", "u1", (5,)), ("lid", "u1", (5,)), ("turn_counter", "<u2"),
+    ("first_player_stats", "<u2", (4,)), ("floor_penalty", "<i2", (4,)), ("max_combo", "u1", (4,)),
+    ("completed_lines", "u1", (4, 3)), ("players", "u1"), ("pad", "u1", (51,)),
+])
+assert RECORD_NP_DTYPE.itemsize == 256
+
+
+def pack_np(game):
+    rec = np.zeros(256, dtype=np.uint8)
+    if lib().oz_pack_np(C.byref(game), _p(rec, C.c_uint8)):
+        raise ValueError("state not representable in the 256-byte record")
+    return rec.view(RECORD_NP_DTYPE)[0]
+
+
+def unpack_np(rec, tile_pool=POOL_RANDOM):
+    a = np.asarray(rec)
+    raw = np.frombuffer(a.tobytes(), dtype=np.uint8).copy()
+    assert raw.size == 256
+    g = Game()
+    lib().oz_unpack_np(C.byref(g), _p(raw, C.c_uint8), tile_pool)
+    return g
 
 
 def check_all_valid(game):

@@ -88,6 +88,7 @@ AZ_FN void stu_i32(i32 *p, i32 v) { *p = v; }
 AZ_FN void stu_u8(uint8_t *p, u32 v) { *p = (uint8_t)v; }
 AZ_FN void stu_u64(u64 *p, u64 v) { *p = v; }
 AZ_FN vf64 self64(bool c, const vf64 &a, const vf64 &b) { return c ? a : b; }
+AZ_FN vu32 selu(bool c, const vu32 &a, const vu32 &b) { return c ? a : b; }   // select between lane values on a UNIFORM condition
 AZ_FN vu32 vmin(const vu32 &a, u32 b) { vu32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] < b ? a.v[i] : b; return r; }
 struct vptr { uintptr_t v[64]; };
 AZ_FN vptr vptr_splat(const void *p) { vptr r; for (int i = 0; i < 64; i++) r.v[i] = (uintptr_t)p; return r; }

@@ -37,6 +37,7 @@ def lib():
         L.hc_next_player.argtypes = [C.c_void_p]
         L.hc_statistics.argtypes = [C.c_void_p, C.c_void_p]
         L.hc_sample_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hc_np_op.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
         _lib = L
     return _lib
 
@@ -79,7 +80,10 @@ class EmuBackend:
     core, compiled for the host with the 64-lane emulation.  Lets the facade's logic (and, in the build
     container, the reference's own test files) run without a GPU.  Never selected by the product."""
 
-    def __init__(self, first_player, tile_pool):
+    def __new__(cls, first_player, tile_pool, players=2):
+        return super().__new__(EmuBackendNP if int(players) != 2 and cls is EmuBackend else cls)
+
+    def __init__(self, first_player, tile_pool, players=2):
         self.fp, self.pool = int(first_player), int(tile_pool)
         self.rec = np.zeros(128, np.uint8)
         self.mt = np.zeros(624, np.uint32)
@@ -157,3 +161,56 @@ class EmuBackend:
     def op_sample_mask(self, mask):
         m = np.ascontiguousarray(np.asarray(mask, dtype=np.uint8).reshape(-1)[:180])
         return lib().hc_sample_mask(ptr(m), ptr(self.mt), ptr(self.pos))
+
+
+class EmuBackendNP(EmuBackend):
+    """The 3 / 4 player core (csrc/azul_core_np.hpp) behind the same interface: 256-byte wide records, Azul's own methods."""
+
+    def __init__(self, first_player, tile_pool, players):
+        super().__init__(first_player, tile_pool)
+        self.players = int(players)
+        self.rec = np.zeros(256, np.uint8)
+
+    def get(self):
+        from azul_deep_reinforcement_learning_amd.records import RECORD_NP_DTYPE
+        return self.rec.copy().view(RECORD_NP_DTYPE)[0]
+
+    def _op(self, op, action=0, mask=False, flags=False, stats=False):
+        m = np.zeros(180, np.uint8) if mask else None
+        f = C.c_int(0)
+        s = np.zeros(10) if stats else None
+        st = lib().hc_np_op(ptr(self.rec), self.players, self.fp, self.pool, op, int(action), ptr(self.mt), ptr(self.pos), ptr(m),
+                            C.cast(C.byref(f), C.c_void_p) if flags else None, ptr(s))
+        return st, m, f.value, s
+
+    def op_init(self):
+        self._op(0)
+
+    def op_new_round(self):
+        return self._op(1)[0]
+
+    def op_move(self, action):
+        self._op(2, action)
+
+    def op_next_player(self):
+        self._op(3)
+
+    def op_count_score(self):
+        self._op(4)
+
+    def op_step(self, action):
+        return self._op(5, action)[0]
+
+    def op_flags(self):
+        return self._op(99, flags=True)[2]
+
+    def op_mask(self):
+        return self._op(99, mask=True)[1].astype(bool)
+
+    def op_statistics(self):
+        return self._op(99, stats=True)[3]
+
+    def _two_players_only(self, *a, **k):
+        raise RuntimeError("GameRunner entries are two-player (game_runner.py:50,57)")
+
+    op_observe = op_potential = op_runner_init = op_runner_reset = op_runner_step = _two_players_only

@@ -69,6 +69,7 @@ SIGNATURES = {
     "azul_batch_sample_mask": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "azul_batch_score_preview": (_i, [_vp, _vp, _vp]),
     "azul_batch_selfplay": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "azul_batch_selfplay_strided": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "azul_batch_counters": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "azul_batch_counters_dev": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "azul_batch_reset_counters": (_i, [_vp, _vp]),

@@ -266,16 +266,27 @@ class BatchedAzul:
 
     # -- flat self-play rollout -------------------------------------------------------------------
     def selfplay(self, n_steps, mask=None, action=None, reward=None, done=None, records=None, maskbits=None, packed=None):
-        """`n_steps` env moves for every game in one launch; outputs are preallocated tensors or None."""
-        L.check(L.lib.azul_batch_selfplay(self._h, int(n_steps), _ptr(mask), _ptr(maskbits), _ptr(action), _ptr(reward),
-                                          _ptr(done), _ptr(packed), _ptr(records), self._stream()))
+        """`n_steps` env moves for every game in one launch; outputs are preallocated tensors or None.  `mask` may be a
+        [T][N][180] view of a wider [T][N][pitch] buffer (alloc_trajectory(mask_pitch=192)): the row pitch is taken from its
+        strides."""
+        pitch = L.NUM_ACTIONS
+        if mask is not None:
+            pitch = mask.stride(-2)
+            if mask.stride(-1) != 1 or mask.shape[-1] != L.NUM_ACTIONS or (mask.dim() == 3 and mask.shape[0] > 1 and mask.stride(0) != self.n * pitch):
+                raise ValueError("mask must be [T][N][180] uint8 with contiguous rows and a uniform row pitch")
+        L.check(L.lib.azul_batch_selfplay_strided(self._h, int(n_steps), _ptr(mask), int(pitch), _ptr(maskbits), _ptr(action), _ptr(reward),
+                                                  _ptr(done), _ptr(packed), _ptr(records), self._stream()))
 
-    def alloc_trajectory(self, n_steps, with_records=False, packed_mask=False):
+    def alloc_trajectory(self, n_steps, with_records=False, packed_mask=False, mask_pitch=None):
         """Trajectory buffers [n_steps][N]....  With `packed_mask` also the bit-packed mask `maskbits` (int64 [T][N][3])
         and the compact per-move record `packed` (int32 [T][N]: action | done << 8 | reward << 16) -- the two
-        contiguous arrays the multi-GPU all-gather ships."""
+        contiguous arrays the multi-GPU all-gather ships.  `mask_pitch` (e.g. 192): the byte mask is a [T][N][180] view of a
+        [T][N][mask_pitch] buffer, so that every game's row starts 64-byte aligned (whole-sector stores)."""
         n = self.n
-        t = {"mask": self._new((n_steps, n, L.NUM_ACTIONS), torch.uint8),
+        pitch = L.NUM_ACTIONS if mask_pitch is None else int(mask_pitch)
+        store = torch.zeros((n_steps, n, pitch), dtype=torch.uint8, device=self.device) if pitch != L.NUM_ACTIONS else \
+            self._new((n_steps, n, L.NUM_ACTIONS), torch.uint8)
+        t = {"mask": store[:, :, :L.NUM_ACTIONS],
              "action": self._new((n_steps, n), torch.int32),
              "reward": self._new((n_steps, n), torch.int32),
              "done": self._new((n_steps, n), torch.uint8)}

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -478,6 +479,70 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
     rng_close(r, b.mtpos + gi);
 }
 
+
+#include "azul_selfplay2.hpp"
+
+// Flat self-play, TWO GAMES PER WAVEFRONT (azul_selfplay2.hpp): grid = ceil(N / 2) one-wave workgroups; lanes 0..31 own game
+// 2 b, lanes 32..63 game 2 b + 1.  Same semantics and outputs as azul_selfplay_kernel; `mask_stride` is the byte distance between
+// the mask rows of consecutive games (180, or 192 to keep every row 64-byte aligned).
+template <bool LID, int OUT>
+__global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs t, u32 mask_stride)
+{
+    __shared__ u32 mt_lds[2][624];
+    __shared__ double tab_lds[T_WORDS];
+    const u32 lane = wv::lane(), l = lane & 31u, half = lane >> 5;
+    for (u32 i = lane; i < (u32)T_WORDS; i += 64u) tab_lds[i] = b.T[i];
+    az2::lds_sync();
+    const u32 gi = blockIdx.x * 2u + half;
+    if (gi >= b.n) return;                               // odd batch: the last wave plays one game
+    const size_t N = b.n;
+    uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
+    az2::K2 k;
+    az2::k2_init(k);
+    az2::Tab2 tab = {tab_lds, tab_lds + T_ROWS * T_BINADES};
+    az2::G2 g;
+    az2::g2_load(g, rec, l);
+    az2::prime2(g, k);
+    az2::Rng2 r;
+    u32 *gmt = b.mt + (size_t)gi * 624u;
+    az2::rng2_open(r, gmt, mt_lds[half], b.mtpos[gi], l);
+    const u64 margin = b.draw_margin;
+    az2::Counters2 cnt = {b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10};
+    az2::Out2 o;
+    o.mask = t.mask ? t.mask + (size_t)gi * mask_stride : nullptr;
+    o.maskbits = t.maskbits ? t.maskbits + (size_t)gi * 3 : nullptr;
+    o.action = t.action ? t.action + gi : nullptr;
+    o.reward = t.reward ? t.reward + gi : nullptr;
+    o.done = t.done ? t.done + gi : nullptr;
+    o.packed = t.packed ? t.packed + gi : nullptr;
+    o.rec = t.rec ? t.rec + (size_t)gi * AZUL_RECORD_BYTES : nullptr;
+    o.s_mask = t.mask ? N * mask_stride : 0; o.s_bits = t.maskbits ? N * 3 : 0; o.s_rec = t.rec ? N * AZUL_RECORD_BYTES : 0;   // a NULL stream stays NULL
+#if defined(AZ_PROFILE_SEGMENTS)
+    SegProf prof;
+    for (int q = 0; q < SEG_COUNT; q++) prof.acc[q] = 0;
+    prof.last = __builtin_amdgcn_s_memtime();
+    SegProf *pp = &prof;
+#else
+    SegProf *pp = nullptr;
+#endif
+#pragma unroll 1
+    for (int s = 0; s < t.n_steps; s++) {
+        u32 f = az2::selfplay_step2<LID, OUT>(g, b.rules.first_player, k, r, tab, margin, cnt, o, pp);
+        if (f & 0x100u) break;      // rule error (box empty): leave the game as it is
+        if (OUT != 0) {
+            o.mask += o.s_mask; o.maskbits += o.s_bits; o.rec += o.s_rec;
+            if (OUT == 1 || o.action) o.action += N;
+            if (OUT == 1 || o.reward) o.reward += N;
+            if (OUT == 1 || o.done) o.done += N;
+            if (OUT == 1 || o.packed) o.packed += N;
+        }
+    }
+#if defined(AZ_PROFILE_SEGMENTS)
+    if (lane == 0u) for (int q = 0; q < SEG_COUNT; q++) atomicAdd((unsigned long long *)(b.prof + q), (unsigned long long)prof.acc[q]);
+#endif
+    az2::g2_store(g, rec, l);
+    az2::rng2_close(r, gmt, b.mtpos + gi, l);
+}
 
 #include "azul_policy.hpp"
 #include "azul_learner.hpp"
@@ -1077,22 +1142,40 @@ int azul_batch_score_preview(azul_batch_t *b, int32_t *potential_dev, void *stre
     return launch_op(b, a, stream);
 }
 
-int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_t *maskbits_dev, int32_t *action_dev,
-                        int32_t *reward_dev, uint8_t *done_dev, uint32_t *packed_dev, uint8_t *rec_dev, void *stream)
+// AZUL_SELFPLAY_KERNEL=1 selects the one-game-per-wave kernel (azul_core.hpp) for A/B measurements; default: two games per wave
+static int selfplay_kernel_version()
+{
+    static int v = [] { const char *e = getenv("AZUL_SELFPLAY_KERNEL"); return (e && e[0] == '1') ? 1 : 2; }();
+    return v;
+}
+
+int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev, int mask_row_bytes, uint64_t *maskbits_dev, int32_t *action_dev,
+                                int32_t *reward_dev, uint8_t *done_dev, uint32_t *packed_dev, uint8_t *rec_dev, void *stream)
 {
     BATCH_GUARD(b, stream);
     if (!b || n_steps < 0) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: bad arguments");
     if (b->players != 2) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: GameRunner self-play is two-player (game_runner.py:50)");
+    if (mask_row_bytes < AZUL_NUM_ACTIONS) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: mask rows hold 180 bytes, mask_row_bytes >= 180");
     if (n_steps == 0) return AZUL_SUCCESS;
+    const int version = selfplay_kernel_version();
+    if (version == 1 && mask_row_bytes != AZUL_NUM_ACTIONS)
+        return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: the one-game-per-wave kernel writes dense 180-byte mask rows");
     TrajArgs t = {n_steps, mask_dev, (u64 *)maskbits_dev, action_dev, reward_dev, done_dev, rec_dev, packed_dev};
     const bool none = !mask_dev && !maskbits_dev && !action_dev && !reward_dev && !done_dev && !rec_dev && !packed_dev;
     const bool full = mask_dev && maskbits_dev && action_dev && reward_dev && done_dev && packed_dev && !rec_dev;
-    const dim3 grid(b->d.n), block(64);
+    const dim3 grid(version == 1 ? b->d.n : (b->d.n + 1u) / 2u), block(64);
     const hipStream_t st = (hipStream_t)stream;
+    const u32 ms = (u32)mask_row_bytes;
 #define AZ_LAUNCH(LID) do { \
-        if (none) hipLaunchKernelGGL((azul_selfplay_kernel<LID, 0>), grid, block, 0, st, b->d, t); \
-        else if (full) hipLaunchKernelGGL((azul_selfplay_kernel<LID, 1>), grid, block, 0, st, b->d, t); \
-        else hipLaunchKernelGGL((azul_selfplay_kernel<LID, 2>), grid, block, 0, st, b->d, t); } while (0)
+        if (version == 1) { \
+            if (none) hipLaunchKernelGGL((azul_selfplay_kernel<LID, 0>), grid, block, 0, st, b->d, t); \
+            else if (full) hipLaunchKernelGGL((azul_selfplay_kernel<LID, 1>), grid, block, 0, st, b->d, t); \
+            else hipLaunchKernelGGL((azul_selfplay_kernel<LID, 2>), grid, block, 0, st, b->d, t); \
+        } else { \
+            if (none) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 0>), grid, block, 0, st, b->d, t, ms); \
+            else if (full) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1>), grid, block, 0, st, b->d, t, ms); \
+            else hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 2>), grid, block, 0, st, b->d, t, ms); \
+        } } while (0)
     // inside a timed region the first AZ_TIMED_PAIRS launches are bracketed by their own event pair (the kernel's duration,
     // not the distance between launches)
     const bool pair = b->timing && b->timed_pairs < AZ_TIMED_PAIRS;
@@ -1106,6 +1189,13 @@ int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_
     if (pair) { HIP_TRY(hipEventRecord(b->lev[2 * b->timed_pairs + 1], st)); b->timed_pairs++; }
     if (b->timing) b->timed_launches++;
     return AZUL_SUCCESS;
+}
+
+int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_t *maskbits_dev, int32_t *action_dev,
+                        int32_t *reward_dev, uint8_t *done_dev, uint32_t *packed_dev, uint8_t *rec_dev, void *stream)
+{
+    return azul_batch_selfplay_strided(b, n_steps, mask_dev, AZUL_NUM_ACTIONS, maskbits_dev, action_dev, reward_dev, done_dev, packed_dev, rec_dev,
+                                       stream);
 }
 
 int azul_batch_counters(azul_batch_t *b, uint64_t *episodes_host, uint32_t *stuck_host, double *stat_sums_host, void *stream)

@@ -1,0 +1,803 @@
+// azul_selfplay2.hpp -- the flat random-agent self-play step (BASELINE configs[1], the benchmarked hot path) for TWO GAMES
+// PER 64-LANE WAVEFRONT: lanes 0..31 play one game, lanes 32..63 another.  Included by azul_kernels.hip.
+//
+// Why: with one game per wave (azul_core.hpp) every per-game quantity is wave-uniform, the compiler keeps it in SGPRs and the
+// move is bound by the SCALAR pipe: one scalar ALU per CU issues ~1 instruction every 4.3 cycles per SIMD, the vector ALUs one
+// every ~2.4 (tools/issue_model.hip, profiles/round2_issue_model.txt), and a move is 253 scalar + 205 vector instructions.
+// Here every per-game quantity lives in a VGPR, replicated across the game's 32 lanes ("half-uniform"), so the rules run
+// on the vector pipe, one instruction serves two games, and the scalar pipe only carries the loop and the exec masks of
+// the rare paths (factory draw, scoring, episode reset), which are ordinary divergent branches between the two halves.
+//
+// Layout inside a half (l = lane & 31):
+//   cs        lane 5d+c = displays[d][c] (0..24), lane 25+c = center[c], lane 30 = token          (31 cells)
+//   cp0, cp1  lane 5r+c = pattern_lines[p][r][c]                                                   (25 cells each)
+//   everything else: half-uniform values (walls as 25-bit boards, floors, scores, turn data, box / lid byte vectors ...)
+// Cross-lane traffic stays inside a half: hb() = my half of a wave ballot (the half's cell array as a bitboard), hread() =
+// ds_bpermute with the half's base lane (cell gather / broadcast), hsum() / hmax() = DPP reductions over 32 lanes.
+// Legal-move mask: action a = 32 w + l for w = 0..5 (six 32-bit words per game instead of three 64-bit ones).
+// MT19937: each game's 624 words in LDS (two regions per wave); the regeneration runs 32 lanes wide.
+//
+// The arithmetic is azul_core.hpp's, statement for statement (same exactness arguments): the trajectories are
+// byte-identical to the one-game-per-wave kernel and to the oracle (tests/test_gpu_selfplay.py, tests/test_full_size_configs.py).
+// Reference lines as in azul_core.hpp: azulnet/azul.py:64-89, 118-161, 162-176, 177-191, 192-313; azulnet/game_runner.py:43-55,
+// 76-97; CPython random.py / _randommodule.c.
+#pragma once
+
+namespace az2 {
+using namespace az;
+
+AZ_FN u32 wlane() { return wv::lane(); }
+AZ_FN bool upper() { return (wlane() & 32u) != 0u; }
+AZ_FN u32 hsel(u64 b) { return upper() ? (u32)(b >> 32) : (u32)b; }
+// the half's 32 lanes as a bitboard
+AZ_FN u32 hb(bool p) { return hsel(__builtin_amdgcn_ballot_w64(p)); }
+// value of lane `idx` of MY half, idx per lane (a gather through the LDS crossbar; idx in 0..31)
+AZ_FN u32 hread(u32 v, u32 idx) { return (u32)__builtin_amdgcn_ds_bpermute((int)((idx << 2) | ((wlane() & 32u) << 2)), (int)v); }
+// the same for a HALF-UNIFORM idx (every lane of a half asks for the same lane): two scalar lane reads and a select instead of
+// an LDS round trip -- the move is latency bound (two waves per SIMD), and this is ~25 cycles instead of ~120
+AZ_FN u32 hbcast(u32 v, u32 idx)
+{
+    u32 ia = (u32)__builtin_amdgcn_readlane((int)idx, 0), ib = (u32)__builtin_amdgcn_readlane((int)idx, 32);
+    u32 a = (u32)__builtin_amdgcn_readlane((int)v, (int)(ia & 31u)), b = (u32)__builtin_amdgcn_readlane((int)v, (int)((ib & 31u) | 32u));
+    return upper() ? b : a;
+}
+template <u32 IDX>
+AZ_FN u32 hbcast_c(u32 v)
+{
+    u32 a = (u32)__builtin_amdgcn_readlane((int)v, (int)IDX), b = (u32)__builtin_amdgcn_readlane((int)v, (int)(IDX + 32u));
+    return upper() ? b : a;
+}
+// is the predicate true in ANY lane of the wave?  (a scalar branch: no exec-mask bookkeeping for the rare paths)
+AZ_FN bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+AZ_FN double hread_d(double v, u32 idx)
+{
+    u64 b = (u64)__double_as_longlong(v);
+    u32 lo = hread((u32)b, idx), hi = hread((u32)(b >> 32), idx);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+
+template <int CTRL, int ROWMASK>
+AZ_FN u32 dpp0(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, true); }   // lanes without a source read 0
+// sum / maximum over the 32 lanes of my half (every lane receives it)
+AZ_FN u32 hsum(u32 v)
+{
+    v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);   // row_shr 1, 2, 4, 8
+    v += dpp0<0x142, 0xa>(v);                                                                             // row_bcast:15 into rows 1 and 3
+    return hbcast_c<31>(v);
+}
+AZ_FN u32 umax(u32 a, u32 b) { return a > b ? a : b; }
+AZ_FN u32 hmax(u32 v)
+{
+    v = umax(v, dpp0<0x111, 0xf>(v)); v = umax(v, dpp0<0x112, 0xf>(v)); v = umax(v, dpp0<0x114, 0xf>(v)); v = umax(v, dpp0<0x118, 0xf>(v));
+    v = umax(v, dpp0<0x142, 0xa>(v));
+    return hbcast_c<31>(v);
+}
+
+// ---- per-lane constants -------------------------------------------------------------------------------------------------
+struct K2 {
+    u32 l;               // lane & 31
+    u32 spos[6];         // action a = 32 w + l: cs lane of its source cell (31 = none: bit 31 of the source board is always 0)
+    u32 okpos[6];        // action a: bit of the "row accepts colour" board (31 = floor move, always ok)
+    u32 acode[6];        // action a decoded once (LaneConst::acode's packing)
+    u32 rowp1;           // l < 25: row + 1, else 0xff
+    u32 prow, pcol, pbcol, pbelow, pcolboard;      // pattern cell l < 25: row, colour, board column, bits 0..l, cells of that board column
+};
+
+AZ_FN void k2_init(K2 &k)
+{
+    const u32 l = wlane() & 31u;
+    k.l = l;
+    for (u32 w = 0; w < 6u; w++) {
+        u32 a = l + w * 32u;
+        u32 d = a % 6u, c = (a / 6u) % 5u, r = a / 30u;
+        u32 sp = d == 0u ? c + 25u : (d - 1u) * 5u + c;
+        u32 db = d == 0u ? 0u : (d - 1u) * 5u;
+        k.spos[w] = a < 180u ? sp : 31u;
+        k.okpos[w] = (a < 180u && r != 0u) ? (r - 1u) * 5u + c : 31u;
+        k.acode[w] = sp | (db << 5) | (c << 10) | (r << 13) | ((d == 0u ? 0u : 1u) << 16) | (a << 17);
+    }
+    k.rowp1 = l < 25u ? l / 5u + 1u : 0xffu;
+    u32 i = l < 25u ? l : 0u;
+    k.prow = i / 5u;
+    k.pcol = i % 5u;
+    u32 bc = k.prow + k.pcol;
+    k.pbcol = bc >= 5u ? bc - 5u : bc;
+    k.pbelow = (2u << i) - 1u;
+    k.pcolboard = k.pbcol == 0u ? column_board_c(0) : k.pbcol == 1u ? column_board_c(1) : k.pbcol == 2u ? column_board_c(2)
+                : k.pbcol == 3u ? column_board_c(3) : column_board_c(4);
+}
+
+// ---- game state: every field is a per-lane value; all but cs / cp0 / cp1 are half-uniform -------------------------------
+struct G2 {
+    u32 cs, cp0, cp1;
+    u32 wall0, wall1, floor0, floor1;
+    i32 score0, score1;
+    u32 cur, nfp, eog, turn, fps, fpen, maxc;
+    u64 box, lid, compl_;
+    i32 pscore;
+    u32 moves;
+    i32 wc0, wc1, wi0, wi1;     // what-if cache (game_runner.py:48-50), see azul_core.hpp
+    u32 over;
+};
+
+AZ_FN u32 me2(const G2 &g) { return g.cur == 0u ? 1u : g.cur - 1u; }
+
+AZ_FN void g2_load(G2 &g, const uint8_t *rec, u32 l)
+{
+    u32 a = rec[l];
+    u32 b0 = l < 25u ? (u32)rec[32u + l] : 0u;
+    u32 b1 = l < 27u ? (u32)rec[57u + l] : 0u;                     // pattern_lines[1] (25 cells), floors[2]
+    u32 t = l < 11u ? ((const u32 *)(rec + 84))[l] : 0u;
+    u32 flags = hread(a, 31);
+    g.cur = flags & 7u; g.nfp = (flags >> 3) & 7u; g.eog = (flags >> 6) & 1u;
+    g.cs = l < 31u ? a : 0u;
+    g.cp0 = b0;
+    g.cp1 = l < 25u ? b1 : 0u;
+    g.floor0 = hread(b1, 25); g.floor1 = hread(b1, 26);
+    g.wall0 = hread(t, 0); g.wall1 = hread(t, 1);
+    u32 sc = hread(t, 2);
+    g.score0 = (i32)(int16_t)(sc & 0xffffu); g.score1 = (i32)(int16_t)(sc >> 16);
+    u32 w3 = hread(t, 3), w4 = hread(t, 4), w5 = hread(t, 5);
+    g.box = (u64)w3 | ((u64)(w4 & 0xffu) << 32);
+    g.lid = (u64)(w4 >> 8) | ((u64)(w5 & 0xffffu) << 24);
+    g.turn = w5 >> 16;
+    g.fps = hread(t, 6);
+    g.fpen = hread(t, 7);
+    u32 w8 = hread(t, 8), w9 = hread(t, 9), w10 = hread(t, 10);
+    g.maxc = w8 & 0xffffu;
+    g.compl_ = (u64)(w8 >> 16) | ((u64)w9 << 16);
+    g.pscore = (i32)(int16_t)(w10 & 0xffffu);
+    g.moves = w10 >> 16;
+    g.wc0 = g.wc1 = 0; g.wi0 = g.wi1 = 0; g.over = 0;
+}
+
+AZ_FN void g2_store(const G2 &g, uint8_t *rec, u32 l)
+{
+    u32 flags = (g.cur & 7u) | ((g.nfp & 7u) << 3) | ((g.eog & 1u) << 6);
+    rec[l] = (uint8_t)(l == 31u ? flags : g.cs);
+    if (l < 25u) rec[32u + l] = (uint8_t)g.cp0;
+    // (three separate stores: a nested select between struct fields would be folded into a select of ADDRESSES and keep the
+    // whole game state in scratch memory)
+    if (l < 25u) rec[57u + l] = (uint8_t)g.cp1;
+    if (l == 25u) rec[82] = (uint8_t)g.floor0;
+    if (l == 26u) rec[83] = (uint8_t)g.floor1;
+    u32 t = 0;
+    t = l == 0u ? g.wall0 : t;
+    t = l == 1u ? g.wall1 : t;
+    t = l == 2u ? (((u32)g.score0 & 0xffffu) | ((u32)g.score1 << 16)) : t;
+    t = l == 3u ? (u32)g.box : t;
+    t = l == 4u ? ((u32)((g.box >> 32) & 0xffu) | ((u32)g.lid << 8)) : t;
+    t = l == 5u ? ((u32)((g.lid >> 24) & 0xffffu) | (g.turn << 16)) : t;
+    t = l == 6u ? g.fps : t;
+    t = l == 7u ? g.fpen : t;
+    t = l == 8u ? ((g.maxc & 0xffffu) | ((u32)(g.compl_ & 0xffffu) << 16)) : t;
+    t = l == 9u ? (u32)(g.compl_ >> 16) : t;
+    t = l == 10u ? (((u32)g.pscore & 0xffffu) | (g.moves << 16)) : t;
+    if (l < 11u) ((u32 *)(rec + 84))[l] = t;
+}
+
+// ---- CPython MT19937 stream of one game (azul_core.hpp's Rng, 32 lanes wide) ---------------------------------------------
+struct Rng2 {
+    u32 *lds;        // my game's 624 words in LDS
+    u32 pos;         // CPython's `index`
+    u32 dirty;       // a regeneration happened: LDS differs from global memory
+    u32 wbase, wend; // the window `win` serves words wbase .. wend-1 (wend == 0: none loaded)
+    u32 win;         // lane l: TEMPERED word wbase + l
+};
+
+AZ_FN u32 temper2(u32 y)
+{
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+AZ_FN void lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+AZ_FN void rng2_open(Rng2 &r, const u32 *gmt, u32 *lds, u32 pos, u32 l)
+{
+    r.lds = lds; r.pos = pos; r.dirty = 0; r.wbase = 0; r.wend = 0; r.win = 0;
+    u32 w[20];
+#pragma unroll
+    for (u32 q = 0; q < 20u; q++) { u32 i = l + 32u * q; w[q] = i < 624u ? gmt[i] : 0u; }     // all loads in flight, then the LDS writes
+#pragma unroll
+    for (u32 q = 0; q < 20u; q++) { u32 i = l + 32u * q; if (i < 624u) lds[i] = w[q]; }
+    lds_sync();
+}
+
+AZ_FN void rng2_twist(Rng2 &r, u32 l)
+{
+    // genrand_uint32's regeneration; ascending 32-wide chunks are legal for the same reason as 64-wide ones:
+    // element i needs OLD mt[i], mt[i+1] and (i < 227: OLD mt[i+397] | i >= 227: NEW mt[i-227], at least 7 chunks back)
+#pragma unroll 1
+    for (u32 q = 0; q < 20u; q++) {
+        u32 i = l + q * 32u;
+        bool act = i < 624u;
+        u32 i1 = i == 623u ? 0u : i + 1u;
+        u32 i2 = i < 227u ? i + 397u : i - 227u;
+        u32 a = 0, b = 0, c = 0;
+        if (act) { a = r.lds[i]; b = r.lds[i1]; c = r.lds[i2]; }
+        u32 y = (a & 0x80000000u) | (b & 0x7fffffffu);
+        u32 v = c ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+        lds_sync();
+        if (act) r.lds[i] = v;
+        lds_sync();
+    }
+    r.dirty = 1;
+    r.pos = 0;
+    r.wend = 0;
+}
+
+AZ_FN void rng2_refill(Rng2 &r, u32 l)
+{
+    if (r.pos >= 624u) rng2_twist(r, l);
+    r.wbase = r.pos;
+    r.wend = r.pos + 32u < 624u ? r.pos + 32u : 624u;
+    u32 i = l + r.pos;
+    r.win = temper2(i < 624u ? r.lds[i] : 0u);
+}
+
+AZ_FN u32 rng2_u32(Rng2 &r, u32 l)
+{
+    if (r.pos >= r.wend) rng2_refill(r, l);
+    u32 y = hbcast(r.win, r.pos - r.wbase);
+    r.pos += 1u;
+    return y;
+}
+
+// random_random(): (a >> 5, b >> 6) -> (a * 2^26 + b) / 2^53, exact
+AZ_FN double rng2_random(Rng2 &r, u32 l)
+{
+    u32 a, b;
+    if (r.pos + 2u <= r.wend) {
+        u32 off = r.pos - r.wbase;
+        a = hbcast(r.win, off);
+        b = hbcast(r.win, off + 1u);
+        r.pos += 2u;
+    } else {
+        a = rng2_u32(r, l);
+        b = rng2_u32(r, l);
+    }
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+AZ_FN u32 rng2_below(Rng2 &r, u32 n, u32 bits, u32 l)
+{
+    u32 v = rng2_u32(r, l) >> (32u - bits);
+    while (v >= n) v = rng2_u32(r, l) >> (32u - bits);
+    return v;
+}
+
+AZ_FN void rng2_close(Rng2 &r, u32 *gmt, u32 *pos_out, u32 l)
+{
+    if (r.dirty) {
+#pragma unroll 1
+        for (u32 q = 0; q < 20u; q++) { u32 i = l + 32u * q; if (i < 624u) gmt[i] = r.lds[i]; }
+    }
+    if (l == 0u) *pos_out = r.pos;
+}
+
+// ---- legal-move mask: six 32-bit words per game ---------------------------------------------------------------------------
+struct Mask2 {
+    u32 m[6];        // half-uniform: bit l of word w = action 32 w + l is legal
+    u32 bit[6];      // the same bit for MY action of each word (what the byte mask stores)
+    u32 B;           // sources holding tiles (31 bits; bit 30 = the token)
+};
+
+AZ_FN void legal_mask2(const G2 &g, const K2 &k, Mask2 &out)
+{
+    const u32 l = k.l;
+    u32 B = hb(g.cs != 0u) & 0x7fffffffu;
+    u32 me = me2(g);
+    u32 mine = me ? g.cp1 : g.cp0;
+    u32 pme = hb(mine != 0u) & 0x1ffffffu;
+    u32 wl = me ? g.wall1 : g.wall0;
+    // "row r accepts colour c": no OTHER colour lies on the row (azul.py:172) and the wall cell is free (:174)
+    u32 rb = (pme >> (k.prow * 5u)) & 31u;
+    u32 own = (rb >> k.pcol) & 1u;
+    bool alone = (rb == 0u) | (((rb & (rb - 1u)) == 0u) & (own != 0u));
+    bool free_ = ((wl >> l) & 1u) == 0u;
+    u32 ok = (hb(alone & free_ & (l < 25u)) & 0x1ffffffu) | 0x80000000u;
+    out.B = B;
+#pragma unroll
+    for (u32 w = 0; w < 6u; w++) {
+        out.bit[w] = ((B >> k.spos[w]) & (ok >> k.okpos[w])) & 1u;
+        out.m[w] = hb(out.bit[w] != 0u);
+    }
+}
+
+// ---- RandomAgent: game_runner.py:87-97 + random.choices; azul_core.hpp's decomposition of the cumulative weights -------------
+struct Tab2 { const double *fr; const double *s; };      // LDS: Fr[31][8], S[31]
+
+AZ_FN double tpat2(const Tab2 &t, u32 J, u32 m) { return (double)m + t.fr[8u * J + 31u - (u32)__builtin_clz(m)]; }
+AZ_FN double tseq2(const Tab2 &t, u32 J, u32 kk) { return kk <= J ? t.s[kk] : tpat2(t, J, kk - J); }
+
+// bisect_right over the cumulative weights == smallest ordinal kk with cum(kk) > x: the generic search (x inside the 0.01-weight
+// floor moves, or a guess too close to an integer boundary: rare, see azul_core.hpp)
+AZ_FN u32 sample_slow2(const Tab2 &T, double x, double sJ, u32 J, u32 M, u32 L)
+{
+    u32 kg;
+    if (x < sJ) {
+        kg = (u32)(x * 100.0) + 1u;
+        kg = kg > J ? J : kg;
+        for (u32 it = 0; it < 64u; it++) {
+            bool below = x < tseq2(T, J, kg - 1u), inside = x < tseq2(T, J, kg);
+            if (below && kg > 1u) kg -= 1u;
+            else if (!inside && kg < L) kg += 1u;
+            else break;
+        }
+    } else {
+        double d = x - sJ;
+        u32 mg = (u32)d + 1u;
+        mg = mg > M ? M : mg;
+        for (u32 it = 0; it < 256u; it++) {
+            u32 ml = mg - 1u;
+            double lo = ml ? tpat2(T, J, ml) : sJ;
+            double hi = tpat2(T, J, mg);
+            if (x < lo && mg > 1u) mg -= 1u;
+            else if (!(x < hi) && mg < M) mg += 1u;
+            else break;
+        }
+        kg = J + mg;
+    }
+    return kg;
+}
+
+// ---- move: azul.py:118-161.  Returns whether the targeted pattern line is full afterwards ------------------------------------
+template <bool LID>
+AZ_FN bool do_move2(G2 &g, u32 code, u32 B /* sources before the move */, u32 l)
+{
+    const u32 me = me2(g);
+    const u32 src = code & 31u, db = (code >> 5) & 31u, c = (code >> 10) & 7u, row = (code >> 13) & 7u;
+    const bool from_display = ((code >> 16) & 1u) != 0u;
+    u32 n = hbcast(g.cs, src);                                         // :127 / :136
+    bool token = (!from_display) & (((B >> 30) & 1u) != 0u);           // :140
+    u32 moved = hread(g.cs, l - 25u + db);                             // :131
+    bool centre = (l >= 25u) & (l < 30u) & (l != 25u + c) & from_display;
+    bool gone = ((l >= db) & (l < db + 5u) & from_display) | (l == src) | ((l == 30u) & token);   // :129,:133,:138,:141
+    g.cs = gone ? 0u : (centre ? g.cs + moved : g.cs);
+    g.nfp = token ? g.cur : g.nfp;                                     // :142
+    u32 fl = (me ? g.floor1 : g.floor0) + (token ? 1u : 0u);           // :143
+    fl = fl < 7u ? fl : 7u;
+    u32 cell = 5u * ((row ? row : 1u) - 1u) + c;
+    u32 mine = me ? g.cp1 : g.cp0;
+    u32 old = hbcast(mine, cell);
+    i32 overflow = row ? (i32)row - (i32)old - (i32)n : -(i32)n;       // :147
+    u32 spill = overflow < 0 ? (u32)(-overflow) : 0u;
+    u32 newv = overflow < 0 ? row : old + n;                           // :150 / :152
+    mine = ((l == cell) & (row != 0u)) ? newv : mine;
+    g.cp0 = me ? g.cp0 : mine;
+    g.cp1 = me ? mine : g.cp1;
+    fl += spill;                                                       // :154 / :159
+    fl = fl < 7u ? fl : 7u;
+    g.floor0 = me ? g.floor0 : fl;
+    g.floor1 = me ? fl : g.floor1;
+    if (LID) g.lid += (u64)spill << (8u * c);                          // :156-157 / :160-161
+    return (row != 0u) & (overflow <= 0);
+}
+
+// ---- wall pricing: azul_core.hpp's score_boards for one player in lanes 0..24 --------------------------------------------
+struct Score2 { u32 val, pos; u32 rowdone, colordone, coldone; };
+
+AZ_FN u32 run_length2(u32 bits, u32 pos)
+{
+    u32 up = (u32)__builtin_ctz(~(bits >> pos));
+    u32 below = ~bits & ((1u << pos) - 1u);
+    u32 down = below != 0u ? pos + (u32)__builtin_clz(below | 1u) - 32u : pos;
+    return up + down;
+}
+
+AZ_FN void score2(u32 w /* per lane: the wall the placement is priced against */, const K2 &k, Score2 &s)
+{
+    u32 rowbits = (w >> (k.prow * 5u)) & 31u;
+    u32 h = ((rowbits << k.prow) | (rowbits >> (5u - k.prow))) & 31u;
+    u32 hr = run_length2(h, k.pbcol);                                  // azul.py:230-242
+    u32 wc = w & k.pcolboard;
+    u32 t = wc | (wc >> 1) | (wc >> 2) | (wc >> 3) | (wc >> 4);
+    u32 v = (((t & 0x108421u) * 0x111110u) >> 20) & 31u;
+    u32 vr = run_length2(v, k.prow);                                   // :244-257
+    u32 both = hr + vr;
+    s.pos = (hr == 1u && vr == 1u) ? 1u : ((hr > 1u && vr > 1u) ? both : both - 1u);     // :258-263
+    bool rd = rowbits == 31u, cd = ((w >> k.pcol) & 0x108421u) == 0x108421u, kd = v == 31u;
+    s.val = s.pos + (rd ? 2u : 0u) + (cd ? 10u : 0u) + (kd ? 7u : 0u);                    // :266-288
+    s.rowdone = hb(rd); s.colordone = hb(cd); s.coldone = hb(kd);
+}
+
+// sum of the placement values of one player's full lines F (25 bits); no commits (the what-if of game_runner.py:48-50)
+AZ_FN i32 wall_points2(u32 wall, u32 F, const K2 &k)
+{
+    Score2 s;
+    score2(wall | (F & k.pbelow), k, s);
+    return (i32)hsum(((F >> k.l) & 1u) ? s.val : 0u);
+}
+
+AZ_FN u32 full_lines2(u32 cp, const K2 &k) { return hb(cp == k.rowp1) & 0x1ffffffu; }    // azul.py:216
+
+AZ_FN void whatif_scores2(G2 &g)
+{
+    g.wi0 = clamp0(g.score0 + floor_penalty(g.floor0) + g.wc0);
+    g.wi1 = clamp0(g.score1 + floor_penalty(g.floor1) + g.wc1);
+}
+
+AZ_FN void prime2(G2 &g, const K2 &k)
+{
+    g.over = (any_row_full(g.wall0) | any_row_full(g.wall1)) ? 1u : 0u;
+    g.wc0 = wall_points2(g.wall0, full_lines2(g.cp0, k), k);
+    g.wc1 = wall_points2(g.wall1, full_lines2(g.cp1, k), k);
+    whatif_scores2(g);
+}
+
+// Σ_r r * [line (r, c) is full] for the five colours, as the byte vector the lid receives (azul.py:220-222)
+AZ_FN u64 lid_return2(u32 F)
+{
+    u64 add = 0;
+#pragma unroll
+    for (u32 c = 0; c < 5u; c++) {
+        u32 t = F >> c;
+        u32 s = ((t >> 5) & 1u) + 2u * ((t >> 10) & 1u) + 3u * ((t >> 15) & 1u) + 4u * ((t >> 20) & 1u);
+        add |= (u64)s << (8u * c);
+    }
+    return add;
+}
+
+// count_wall + count_floor for one player (azul.py:200-290), committed
+template <bool LID>
+AZ_FN void count_player2(u32 &wall, u32 &cp, u32 &floor_, i32 &score, u32 &maxc8, u32 &compl24, i32 &fpen16, u64 &lid, const K2 &k)
+{
+    u32 F = full_lines2(cp, k);
+    i32 cnt = 0;
+    if (F != 0u) {
+        Score2 s;
+        score2(wall | (F & k.pbelow), k, s);
+        bool on = ((F >> k.l) & 1u) != 0u;
+        cnt = (i32)hsum(on ? s.val : 0u);                                              // :289
+        maxc8 = umax(maxc8, hmax(on ? s.pos : 0u));                                    // :264
+        compl24 += (u32)__popc(s.rowdone & F) + ((u32)__popc(s.colordone & F) << 8) + ((u32)__popc(s.coldone & F) << 16);   // :270,:278,:286
+        if (LID) lid += lid_return2(F);                                                // :220-222
+        wall |= F;                                                                     // :219
+        cp = (cp == k.rowp1) ? 0u : cp;                                                // :218
+    }
+    i32 pen = floor_penalty(floor_);
+    fpen16 += pen;                                                                     // :208
+    floor_ = 0;                                                                        // :209
+    score = clamp0(score + pen + cnt);                                                 // :292-295
+}
+
+template <bool LID>
+AZ_FN void count_score2(G2 &g, const K2 &k)
+{
+    u32 mc0 = g.maxc & 0xffu, mc1 = (g.maxc >> 8) & 0xffu;
+    u32 cl0 = (u32)g.compl_ & 0xffffffu, cl1 = (u32)(g.compl_ >> 24) & 0xffffffu;
+    i32 fp0 = (i32)(int16_t)(g.fpen & 0xffffu), fp1 = (i32)(int16_t)(g.fpen >> 16);
+    count_player2<LID>(g.wall0, g.cp0, g.floor0, g.score0, mc0, cl0, fp0, g.lid, k);
+    count_player2<LID>(g.wall1, g.cp1, g.floor1, g.score1, mc1, cl1, fp1, g.lid, k);
+    g.maxc = (mc0 & 0xffu) | ((mc1 & 0xffu) << 8);
+    // byte-wise counters (no carries between them in the reference's floats either: each stays below 256 for real games)
+    g.compl_ = (u64)(cl0 & 0xffffffu) | ((u64)(cl1 & 0xffffffu) << 24);
+    g.fpen = ((u32)fp0 & 0xffffu) | (((u32)fp1 & 0xffffu) << 16);
+    g.wc0 = g.wc1 = 0; g.wi0 = g.score0; g.wi1 = g.score1;
+    g.over = (any_row_full(g.wall0) | any_row_full(g.wall1)) ? 1u : 0u;
+}
+
+// ---- new_round: azul.py:64-89 (deal_factories of azul_core.hpp, 32 lanes) ------------------------------------------------
+template <bool LID>
+AZ_FN u32 new_round2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
+{
+    const u32 l = k.l;
+    g.cur = g.nfp;
+    g.fps += (g.nfp == 1u) ? 1u : 0x10000u;              // :67 (numpy [-1] == player 2 when nfp == 0)
+    g.turn += 1u;
+    g.nfp = 0;
+    g.cs = l == 30u ? 1u : 0u;                           // :71,:73
+    if (!LID) {
+#pragma unroll 1
+        for (u32 t = 0; t < 20u; t++) {
+            u32 color = rng2_below(r, 5u, 3u, l);        // :78 randrange(0,5,1)
+            g.cs += (l == (t >> 2) * 5u + color) ? 1u : 0u;   // :88
+        }
+        return ST_OK;
+    }
+    // "Lid" pool: every draw is one random.choices = one random() = two MT words; see azul_core.hpp for the exactness argument
+    // (integer decision P_c * 2^53 <= K * T unless K*T lies within `margin` of a multiple of 2^32, then the literal fp64 code).
+    const bool batched = r.pos + 40u <= 624u;
+    u32 klo = 0, khi = 0;
+    if (batched) {
+        u32 wa = 0, wb = 0;
+        if (l < 20u) { wa = temper2(r.lds[r.pos + 2u * l]) >> 5; wb = temper2(r.lds[r.pos + 2u * l + 1u]) >> 6; }
+        klo = (wa << 26) | wb;
+        khi = wa >> 6;
+    }
+    u64 P = ((g.box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;     // byte c = box_0 + .. + box_c
+    if (((u32)(P >> 32) & 0xffu) == 0u) {
+        // the box is empty when the round starts: the first draw refills it from the lid (:81-83) -- done here, so that the
+        // whole round can take the parallel path below
+        g.box = g.lid; g.lid = 0;
+        P = ((g.box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;
+        if (((u32)(P >> 32) & 0xffu) == 0u) return ST_BOX_EMPTY;
+    }
+    const u32 T0 = (u32)(P >> 32) & 0xffu;
+    const bool pre = batched && T0 >= 20u;               // no refill can happen: draw t sees total T0 - t
+    u32 kthi = 0, risky = 0;
+    if (pre) {
+        u32 tt = T0 - l;
+        u32 lo = klo * tt, hi = khi * tt + __umulhi(klo, tt);
+        u32 mg = (u32)margin;
+        risky = hb(((lo < mg) | (lo >= 0u - mg)) & (l < 20u));
+        kthi = hi;
+    }
+    if (pre && risky == 0u) {
+        // The common round: twenty integer draws WITHOUT a 20-step serial loop.  Lane t owns draw t:
+        //     colour_t = #{c < 4 : (P_c - n_c(t)) * 2^53 <= K_t * T_t},   n_c(t) = #{s < t : colour_s <= c}
+        // (P_c = prefix sums of the box when the round starts).  Iterate  colours <- f(colours)  from n = 0: after i passes
+        // the first i draws are final (draw t only depends on draws s < t), so a pass that changes nothing has reached the
+        // unique fixed point, which is the sequential result.  Boundaries move by one tile in ~100 per draw: two or three
+        // passes in practice, at most 21.
+        const u32 p0 = (u32)P & 0xffu, p1 = ((u32)P >> 8) & 0xffu, p2 = ((u32)P >> 16) & 0xffu, p3 = (u32)P >> 24;
+        const u32 below = (1u << l) - 1u;
+        const bool draw = l < 20u;
+        u32 col = (u32)((p0 << 21) <= kthi) + (u32)((p1 << 21) <= kthi) + (u32)((p2 << 21) <= kthi) + (u32)((p3 << 21) <= kthi);
+#pragma unroll 1
+        for (u32 it = 0; it < 21u; it++) {
+            u32 n0 = (u32)__popc(hb(draw & (col == 0u)) & below), n1 = (u32)__popc(hb(draw & (col <= 1u)) & below),
+                n2 = (u32)__popc(hb(draw & (col <= 2u)) & below), n3 = (u32)__popc(hb(draw & (col <= 3u)) & below);
+            u32 nc = (u32)(((p0 - n0) << 21) <= kthi) + (u32)(((p1 - n1) << 21) <= kthi) + (u32)(((p2 - n2) << 21) <= kthi) +
+                     (u32)(((p3 - n3) << 21) <= kthi);
+            bool changed = draw & (nc != col);
+            col = nc;
+            if (hb(changed) == 0u) break;
+        }
+        const u32 e0 = hb(draw & (col == 0u)), e1 = hb(draw & (col == 1u)), e2 = hb(draw & (col == 2u)), e3 = hb(draw & (col == 3u)),
+                  e4 = hb(draw & (col == 4u));
+        // display d receives draws 4d .. 4d+3: lane 5d + c counts those of colour c (:88)
+        const u32 ec = k.pcol == 0u ? e0 : k.pcol == 1u ? e1 : k.pcol == 2u ? e2 : k.pcol == 3u ? e3 : e4;
+        g.cs = l < 25u ? (u32)__popc((ec >> (4u * k.prow)) & 0xfu) : g.cs;
+        const u32 take_lo = (u32)__popc(e0) | ((u32)__popc(e1) << 8) | ((u32)__popc(e2) << 16) | ((u32)__popc(e3) << 24);
+        g.box -= (u64)take_lo | ((u64)(u32)__popc(e4) << 32);      // :89 (no borrows: a colour is only drawn while the box holds it)
+        r.pos += 40u;
+        return ST_OK;
+    }
+#pragma unroll 1
+    for (u32 t = 0; t < 20u; t++) {
+        u32 total = (u32)(P >> 32) & 0xffu;
+        if (total == 0u) {                                                           // :81-83, :85
+            g.box = g.lid; g.lid = 0;
+            P = ((g.box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;
+            total = (u32)(P >> 32) & 0xffu;
+            if (total == 0u) return ST_BOX_EMPTY;
+        }
+        u32 Klo, Khi;
+        if (batched) { Klo = hread(klo, t); Khi = hread(khi, t); r.pos += 2u; }
+        else { u32 a27 = rng2_u32(r, l) >> 5, b26 = rng2_u32(r, l) >> 6; Klo = (a27 << 26) | b26; Khi = a27 >> 6; }
+        u64 KT = (u64)Klo * total + (((u64)Khi * total) << 32);
+        u32 color;
+        if (((KT - margin) >> 32) == ((KT + margin) >> 32)) {
+            u32 pc = ((u32)P >> ((l & 3u) * 8u)) & 0xffu;
+            color = (u32)__popc(hb(((pc << 21) <= (u32)(KT >> 32)) & (l < 4u)));
+        } else {
+            // weights = box_c / total (fp64, correctly rounded division), cumulative left to right, x = random() * cum[-1]
+            double tot = (double)total;
+            double q0 = (double)((u32)g.box & 0xffu) / tot, q1 = (double)((u32)(g.box >> 8) & 0xffu) / tot,
+                   q2 = (double)((u32)(g.box >> 16) & 0xffu) / tot, q3 = (double)((u32)(g.box >> 24) & 0xffu) / tot,
+                   q4 = (double)((u32)(g.box >> 32) & 0xffu) / tot;
+            double c0 = q0, c1 = c0 + q1, c2 = c1 + q2, c3 = c2 + q3, c4 = c3 + q4;
+            double u = ((double)Khi * 4294967296.0 + (double)Klo) * (1.0 / 9007199254740992.0);
+            double x = u * (c4 + 0.0);
+            color = (u32)!(x < c0) + (u32)!(x < c1) + (u32)!(x < c2) + (u32)!(x < c3);    // bisect_right(cum, x, 0, 4)
+        }
+        g.box -= 1ull << (8u * color);                   // :89
+        P -= (0x0101010101ull << (8u * color)) & 0xffffffffffull;
+        g.cs += (l == (t >> 2) * 5u + color) ? 1u : 0u;  // :88
+    }
+    return ST_OK;
+}
+
+// Azul.__init__ + GameRunner's reset bookkeeping (azul.py:18-61, game_runner.py:76-82), then the first round
+template <bool LID>
+AZ_FN u32 episode_reset2(G2 &g, u32 first_player, Rng2 &r, u64 margin, const K2 &k)
+{
+    g.cs = 0; g.cp0 = 0; g.cp1 = 0;
+    g.wall0 = g.wall1 = 0; g.score0 = g.score1 = 0; g.floor0 = g.floor1 = 0;
+    g.cur = 0; g.eog = 0; g.turn = 0;
+    g.fps = 0; g.fpen = 0; g.maxc = 0; g.compl_ = 0;
+    g.wc0 = g.wc1 = 0; g.wi0 = g.wi1 = 0; g.over = 0;
+    if (first_player == 0u) g.nfp = 1u + rng2_below(r, 2u, 2u, k.l);     // random.choice([1, 2]) (:37)
+    else g.nfp = first_player;
+    if (LID) { g.box = 0x1414141414ull; g.lid = 0; }
+    else { g.box = 0; g.lid = 0; }
+    g.pscore = 0;
+    g.moves = 0;
+    return new_round2<LID>(g, r, margin, k);
+}
+
+AZ_FN double game_stat2(const G2 &g, u32 q)
+{
+    double f0 = (double)(g.fps & 0xffffu), f1 = (double)(g.fps >> 16);
+    switch (q) {
+    case 0: return (double)g.score0;
+    case 1: return (double)g.score1;
+    case 2: return (double)g.turn;
+    case 3: return f0 / (f0 + f1) * 100;
+    case 4: return -(double)(i32)(int16_t)(g.fpen & 0xffffu);
+    case 5: return (double)(g.maxc & 0xffu);
+    case 6: return (double)(g.compl_ & 0xffu);
+    case 7: return (double)((g.compl_ >> 16) & 0xffu);
+    case 8: return (double)((g.compl_ >> 8) & 0xffu);
+    default: return g.score0 > g.score1 ? 1.0 : 0.0;
+    }
+}
+
+// ---- trajectory streams ------------------------------------------------------------------------------------------------------
+struct Out2 {
+    uint8_t *mask;       // my game's row of slot t: lane l writes bytes l, 32 + l, ... (row stride `mask_stride`)
+    u64 *maskbits;       // [3]
+    i32 *action, *reward;
+    uint8_t *done;
+    u32 *packed;
+    uint8_t *rec;        // test stream: the record after the move
+    size_t s_mask, s_bits, s_i32, s_u8, s_rec;     // strides between consecutive moves (elements of each stream)
+};
+
+template <int OUT>
+AZ_FN void outputs2(const G2 &g, const Out2 &o, i32 a, i32 reward, u32 dn, u32 l)
+{
+    if (OUT == 0) return;
+    const i32 av = a >= 0 ? a : -1;
+    if (OUT == 1) {
+        // every lane of the half stores the same value to the same address: one request, no exec masking
+        *o.action = av; *o.reward = reward; *o.packed = pack_move(a, dn, reward); *o.done = (uint8_t)dn;
+    } else {
+        if (l == 0u) {
+            if (o.action) *o.action = av;
+            if (o.reward) *o.reward = reward;
+            if (o.packed) *o.packed = pack_move(a, dn, reward);
+            if (o.done) *o.done = (uint8_t)dn;
+        }
+        if (o.rec) g2_store(g, o.rec, l);
+    }
+}
+
+struct Counters2 { u64 *episodes; u32 *stuck; double *stat_sum; };
+
+// One env move of flat random-agent self-play for the two games of a wave (selfplay_step of azul_core.hpp).
+// Returns 0 = move played, 1 = game ended with this move, 2 = stuck, 0x100 | status on a rule error.
+//
+// Control flow: two waves per SIMD cannot hide a taken branch's instruction refetch, so the common move is ONE fall-through path;
+// every rare event (window refill across a regeneration, stuck slot, sampler boundary case, end of round, end of game) is tested
+// for the whole wave with one scalar branch (wave_any, hinted unlikely -> placed out of line) and handled per half inside.
+template <bool LID, int OUT>
+AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Tab2 &T, u64 margin, const Counters2 &cnt, const Out2 &o,
+                        SegProf *prof_ = nullptr)
+{
+    (void)prof_;
+    AZ_STAMP(SEG_LOOP);
+    const u32 l = k.l;
+    // -- the two MT19937 words of this move's random(), fetched speculatively (independent of the mask: overlaps with it).
+    //    Refilling the window is state-neutral; a fetch that would cross a regeneration is left to the rare path below.
+    if (wave_any(r.pos + 2u > r.wend)) {
+        bool easy = (r.pos + 2u > r.wend) & (r.pos + 2u <= 624u);
+        u32 i = r.pos + l;
+        u32 raw = r.lds[i < 624u ? i : 623u];
+        r.win = easy ? temper2(raw) : r.win;
+        r.wbase = easy ? r.pos : r.wbase;
+        r.wend = easy ? (r.pos + 32u < 624u ? r.pos + 32u : 624u) : r.wend;
+    }
+    const u32 off = r.pos - r.wbase;
+    u32 wa = hbcast(r.win, off), wb = hbcast(r.win, off + 1u);
+    const bool hard = r.pos + 2u > r.wend;               // still not served: the two words straddle / follow a regeneration
+
+    Mask2 m;
+    legal_mask2(g, k, m);
+    if (OUT == 1 || (OUT == 2 && o.mask)) {
+#pragma unroll
+        for (u32 w = 0; w < 5u; w++) o.mask[32u * w + l] = (uint8_t)m.bit[w];
+        if (l < 20u) o.mask[160u + l] = (uint8_t)m.bit[5];
+    }
+    if (OUT == 1 || (OUT == 2 && o.maskbits)) {
+        u32 lo = l == 0u ? m.m[0] : (l == 1u ? m.m[2] : m.m[4]), hi = l == 0u ? m.m[1] : (l == 1u ? m.m[3] : m.m[5]);
+        if (l < 3u) o.maskbits[l] = (u64)lo | ((u64)hi << 32);
+    }
+    AZ_STAMP(SEG_MASK);
+
+    // -- RandomAgent (game_runner.py:87-97): ordinal of the chosen legal action
+    const u32 c0 = __popc(m.m[0]), c1 = __popc(m.m[1]), c2 = __popc(m.m[2]), c3 = __popc(m.m[3]), c4 = __popc(m.m[4]), c5 = __popc(m.m[5]);
+    const u32 J = __popc(m.m[0] & 0x3fffffffu);          // legal floor moves (a < 30, weight 0.01)
+    const u32 p1 = c0, p2 = p1 + c1, p3 = p2 + c2, p4 = p3 + c3, p5 = p4 + c4, L = p5 + c5;
+    const bool nomove = (L == 0u) | (g.eog != 0u);        // ValueError in the reference (raised before random()) / a finished game handed in
+    const u32 M = L - J, Mc = M ? M : 1u;
+    const double sJ = T.s[J < 31u ? J : 30u];
+    const double frv = T.fr[8u * (J < 31u ? J : 30u) + 31u - (u32)__builtin_clz(Mc)];
+    const double total = (M ? (double)M + frv : sJ) + 0.0;
+    if (AZ_UNLIKELY(wave_any(hard & !nomove))) {
+        if (hard & !nomove) { wa = rng2_u32(r, l); wb = rng2_u32(r, l); }
+    }
+    r.pos += (hard | nomove) ? 0u : 2u;
+    const double x = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0) * total;
+    // pattern moves: cum(J + mm) = mm + Fr[J][ilog2 mm]; away from integer boundaries floor(x - S[J]) + 1 IS the ordinal
+    const double d = x - sJ;
+    const u32 fl = (u32)d;
+    const double fr = d - (double)fl;
+    u32 kg = J + fl + 1u;
+    const bool edge = (x < sJ) | !(fr > 1e-9 && fr < 1.0 - 1e-9) | (fl + 1u > M);
+    if (AZ_UNLIKELY(wave_any(edge & !nomove))) {
+        if (edge & !nomove) kg = sample_slow2(T, x, sJ, J, M, L);
+    }
+    // kg-th legal action: every lane ranks its own six actions, the one with rank kg answers
+    const u32 want = kg - 1u, below = (1u << l) - 1u;
+    const bool h0 = (m.bit[0] != 0u) & (__popc(m.m[0] & below) == want);
+    const bool h1 = (m.bit[1] != 0u) & (__popc(m.m[1] & below) + p1 == want);
+    const bool h2 = (m.bit[2] != 0u) & (__popc(m.m[2] & below) + p2 == want);
+    const bool h3 = (m.bit[3] != 0u) & (__popc(m.m[3] & below) + p3 == want);
+    const bool h4 = (m.bit[4] != 0u) & (__popc(m.m[4] & below) + p4 == want);
+    const bool h5 = (m.bit[5] != 0u) & (__popc(m.m[5] & below) + p5 == want);
+    // (at most one word hits in a lane; OR of masked values rather than a select chain, which the compiler would turn into a
+    // select of ADDRESSES and with it push the whole constant table into scratch memory)
+    const u32 mine = (h0 ? k.acode[0] : 0u) | (h1 ? k.acode[1] : 0u) | (h2 ? k.acode[2] : 0u) | (h3 ? k.acode[3] : 0u) | (h4 ? k.acode[4] : 0u) |
+                     (h5 ? k.acode[5] : 0u);
+    const u32 who = hb(h0 | h1 | h2 | h3 | h4 | h5);
+    const u32 code = hbcast(mine, (u32)__builtin_ctz(who | 0x80000000u));
+    const i32 a = (i32)(code >> 17);
+    AZ_STAMP(SEG_SAMPLE);
+
+    u32 ret = 0;
+    if (AZ_UNLIKELY(wave_any(nomove))) {
+        if (nomove) {
+            // stuck (hazard H3), or handed an already finished game: report, restart the slot
+            if (l == 0u) *cnt.stuck += 1u;
+            outputs2<OUT>(g, o, -1, 0, 2u, l);
+            u32 st0 = episode_reset2<LID>(g, first_player, r, margin, k);
+            ret = st0 ? (0x100u | st0) : 2u;
+        }
+        AZ_STAMP(SEG_RESET);
+    }
+    if (!nomove) {
+        const u32 me = me2(g);
+        const bool filled = do_move2<LID>(g, code, m.B, l);    // azul.py:304
+        g.moves += 1u;
+        AZ_STAMP(SEG_MOVE);
+        // a move only changes the MOVER's lines and floor; the pricing of his full lines only when one more of them filled
+        i32 wc = me ? g.wc1 : g.wc0;
+        if (wave_any(filled)) {
+            i32 fresh = wall_points2(me ? g.wall1 : g.wall0, full_lines2(me ? g.cp1 : g.cp0, k), k);
+            wc = filled ? fresh : wc;
+        }
+        const i32 wi = clamp0((me ? g.score1 : g.score0) + floor_penalty(me ? g.floor1 : g.floor0) + wc);
+        g.wc0 = me ? g.wc0 : wc; g.wc1 = me ? wc : g.wc1;
+        g.wi0 = me ? g.wi0 : wi; g.wi1 = me ? wi : g.wi1;
+        const bool eor = (hb(g.cs != 0u) & 0x7fffffffu) == 0u;   // :306 is_end_of_round (the token counts)
+        g.cur = eor ? g.cur : (g.cur < 2u ? g.cur + 1u : 1u);    // :313 next_player
+        u32 st = ST_OK;
+        AZ_STAMP(SEG_AFTERMOVE);
+        if (AZ_UNLIKELY(wave_any(eor))) {
+            if (eor) {
+                count_score2<LID>(g, k);                         // :307 (also resets the what-if cache)
+                if (g.over) g.eog = 1;                           // :308-309
+            }
+            AZ_STAMP(SEG_SCORE);
+            if (eor & !g.over) st = new_round2<LID>(g, r, margin, k);      // :311
+            AZ_STAMP(SEG_NEWROUND);
+        }
+        const i32 phi = g.wi0 - g.wi1;
+        const i32 reward = phi - g.pscore;
+        g.pscore = phi;
+        const u32 dn = g.over ? 1u : 0u;
+        outputs2<OUT>(g, o, a, reward, dn, l);
+        AZ_STAMP(SEG_TAIL);
+        ret = st != ST_OK ? (0x100u | st) : dn;
+        if (AZ_UNLIKELY(wave_any((dn != 0u) & (st == ST_OK)))) {
+            if ((dn != 0u) & (st == ST_OK)) {
+                if (l == 0u) {
+                    for (u32 q = 0; q < 10u; q++) cnt.stat_sum[q] += game_stat2(g, q);
+                    *cnt.episodes += 1ull;
+                }
+                u32 st2 = episode_reset2<LID>(g, first_player, r, margin, k);     // GameRunner.reset(): Azul(rules) ... new_round()
+                if (st2) ret = 0x100u | st2;
+            }
+            AZ_STAMP(SEG_RESET);
+        }
+    }
+    return ret;
+}
+
+} // namespace az2

@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL trajectory all-gather")
     ap.add_argument("--gather-masks", action="store_true", help="N>1: also ship the bit-packed legal masks (24 B/move)")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[2] / training-loop lines under `extra`")
+    ap.add_argument("--mask-pitch", type=int, default=192, help="byte pitch of a game's legal-mask row (180 = dense, 192 = 64-byte aligned rows)")
     return ap.parse_args()
 
 
@@ -207,7 +208,7 @@ def main():
     env.seed(base)
     env.runner_init()                                    # GameRunner()
     env.runner_init()                                    # reset()   (DESIGN.md "stream semantics")
-    bufs = [env.alloc_trajectory(T, packed_mask=True) for _ in range(2)]
+    bufs = [env.alloc_trajectory(T, packed_mask=True, mask_pitch=args.mask_pitch) for _ in range(2)]
     gather = TrajectoryGather(world, dev, with_masks=args.gather_masks) if (world > 1 and not args.no_gather) else None
 
     def run(n_launches):
@@ -277,6 +278,7 @@ def main():
                        "step_definition": "one step = one launch of the persistent self-play kernel = %d env moves for each of the %d "
                                           "games of a GPU (%d env moves per step and GPU)" % (T, G, T * G),
                        "games_per_gpu": G, "global_games": G * world, "moves_per_launch": T, "env_moves_timed": int(total_moves),
+                       "mask_row_pitch_bytes": args.mask_pitch, "selfplay_kernel": os.environ.get("AZUL_SELFPLAY_KERNEL", "2") + " game(s) per wavefront",
                        "parallelism": "games sharded by global id; %s" %
                                       (("%s all-gather of the compact trajectory records%s, issued async behind each launch" %
                                         ("RCCL" if backend == "nccl" else backend, " + mask bits" if args.gather_masks else "")) if gather else "no collective")},

@@ -275,6 +275,12 @@ int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, 
  */
 int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_t *maskbits_dev, int32_t *action_dev,
                         int32_t *reward_dev, uint8_t *done_dev, uint32_t *packed_dev, uint8_t *rec_dev, void *stream);
+/* the same with a row pitch for the byte mask: mask_dev is [n_steps][N][mask_row_bytes] (>= 180; bytes 180.. of a row are not
+ * written).  192 keeps every game's row 64-byte aligned, so a wave's mask stores cover whole 32-byte sectors (no partial
+ * writes: DESIGN.md 3, write amplification). */
+int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev, int mask_row_bytes, uint64_t *maskbits_dev,
+                                int32_t *action_dev, int32_t *reward_dev, uint8_t *done_dev, uint32_t *packed_dev, uint8_t *rec_dev,
+                                void *stream);
 /* per-game counters accumulated by selfplay / runner_step / the policy entries: episodes[N] u64, stuck[N] u32, sums of
  * get_statistics() over finished games [N][10] f64 (azul.py:314-315, the data behind GameStatistics, game_runner.py:10-22).
  * azul_batch_counters_dev hands out the DEVICE arrays themselves (zero-copy, no synchronisation: read them on a stream

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Static ISA statistics of the self-play kernels (development helper): instruction counts by pipe, registers, LDS, scratch.
+Usage: tools/isa_stats.py [kernel-name-substring ...]   (compiles csrc/azul_kernels.hip with -S for gfx950 into gpurun_out/)."""
+import collections
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+asm = os.path.join(ROOT, "gpurun_out", "azul_kernels.s")
+os.makedirs(os.path.dirname(asm), exist_ok=True)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                       "-Wno-unused-value", "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", asm,
+                       os.path.join(ROOT, "azul_deep_reinforcement_learning_amd", "csrc", "azul_kernels.hip")], stderr=subprocess.DEVNULL)
+s = open(asm).read()
+want = sys.argv[1:] or ["azul_selfplay2_kernelILb1ELi1E", "azul_selfplay_kernelILb1ELi1E"]
+meta = s[s.index("amdhsa.kernels"):]
+for name in re.findall(r"^(_Z\w+):\s*; @", s, flags=re.M):
+    if not any(w in name for w in want):
+        continue
+    body = re.search(r"^" + re.escape(name) + r":(.*?)^\.Lfunc_end", s, re.S | re.M).group(1)
+    ins = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith((".", ";")) and not ln.strip().endswith(":")]
+    c = collections.Counter(ln.split()[0] for ln in ins)
+    pipe = lambda p: sum(v for k, v in c.items() if k.startswith(p))
+    print("%s\n   instructions %d: s_ %d  v_ %d  ds_ %d  global_/flat_ %d  scratch_ %d  branches %d" % (
+        name, len(ins), pipe("s_"), pipe("v_"), pipe("ds_"), pipe("global_") + pipe("flat_"), pipe("scratch_"),
+        sum(v for k, v in c.items() if k.startswith("s_cbranch") or k == "s_branch")))
+    j = meta.index(name)
+    blk = meta[max(0, j - 2500):j + 1500]
+    vals = {}
+    for key in (".sgpr_count", ".vgpr_count", ".agpr_count", ".private_segment_fixed_size", ".group_segment_fixed_size", ".vgpr_spill_count",
+                ".sgpr_spill_count"):
+        mm = re.findall(re.escape(key) + r":\s+(\d+)", blk)
+        vals[key] = mm[-1] if mm else "?"
+    print("   " + "  ".join("%s %s" % (k[1:], v) for k, v in vals.items()))
+    if "-v" in sys.argv:
+        for k, v in c.most_common(40):
+            print("      %5d %s" % (v, k))

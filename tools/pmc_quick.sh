@@ -11,5 +11,5 @@ for sub in ("pmc_sq","pmc_sq2"):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "selfplay" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k,v in sorted(agg.items()): print("%-22s per wave-step %10.2f"%(k, sum(v)/len(v)/(4096*64)))
+    for k,v in sorted(agg.items()): print("%-22s per game-move %10.2f"%(k, sum(v)/len(v)/(4096*64)))
 PY

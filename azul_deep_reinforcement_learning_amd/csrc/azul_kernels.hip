@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
 // Flat self-play, TWO GAMES PER WAVEFRONT (azul_selfplay2.hpp): grid = ceil(N / 2) one-wave workgroups; lanes 0..31 own game
 // 2 b, lanes 32..63 game 2 b + 1.  Same semantics and outputs as azul_selfplay_kernel; `mask_stride` is the byte distance between
 // the mask rows of consecutive games (180, or 192 to keep every row 64-byte aligned).
-template <bool LID, int OUT>
+template <bool LID, int OUT, bool PAD>
 __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs t, u32 mask_stride)
 {
     __shared__ u32 mt_lds[2][624];
@@ -495,7 +495,6 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
     az2::lds_sync();
     const u32 gi = blockIdx.x * 2u + half;
     if (gi >= b.n) return;                               // odd batch: the last wave plays one game
-    const size_t N = b.n;
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
     az2::K2 k;
     az2::k2_init(k);
@@ -508,15 +507,7 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
     az2::rng2_open(r, gmt, mt_lds[half], b.mtpos[gi], l);
     const u64 margin = b.draw_margin;
     az2::Counters2 cnt = {b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10};
-    az2::Out2 o;
-    o.mask = t.mask ? t.mask + (size_t)gi * mask_stride : nullptr;
-    o.maskbits = t.maskbits ? t.maskbits + (size_t)gi * 3 : nullptr;
-    o.action = t.action ? t.action + gi : nullptr;
-    o.reward = t.reward ? t.reward + gi : nullptr;
-    o.done = t.done ? t.done + gi : nullptr;
-    o.packed = t.packed ? t.packed + gi : nullptr;
-    o.rec = t.rec ? t.rec + (size_t)gi * AZUL_RECORD_BYTES : nullptr;
-    o.s_mask = t.mask ? N * mask_stride : 0; o.s_bits = t.maskbits ? N * 3 : 0; o.s_rec = t.rec ? N * AZUL_RECORD_BYTES : 0;   // a NULL stream stays NULL
+    az2::Out2 o = {t.mask, t.maskbits, t.action, t.reward, t.done, t.packed, t.rec, mask_stride, gi};
 #if defined(AZ_PROFILE_SEGMENTS)
     SegProf prof;
     for (int q = 0; q < SEG_COUNT; q++) prof.acc[q] = 0;
@@ -527,15 +518,9 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
 #endif
 #pragma unroll 1
     for (int s = 0; s < t.n_steps; s++) {
-        u32 f = az2::selfplay_step2<LID, OUT>(g, b.rules.first_player, k, r, tab, margin, cnt, o, pp);
+        u32 f = az2::selfplay_step2<LID, OUT, PAD>(g, b.rules.first_player, k, r, tab, margin, cnt, o, pp);
         if (f & 0x100u) break;      // rule error (box empty): leave the game as it is
-        if (OUT != 0) {
-            o.mask += o.s_mask; o.maskbits += o.s_bits; o.rec += o.s_rec;
-            if (OUT == 1 || o.action) o.action += N;
-            if (OUT == 1 || o.reward) o.reward += N;
-            if (OUT == 1 || o.done) o.done += N;
-            if (OUT == 1 || o.packed) o.packed += N;
-        }
+        o.e += b.n;
     }
 #if defined(AZ_PROFILE_SEGMENTS)
     if (lane == 0u) for (int q = 0; q < SEG_COUNT; q++) atomicAdd((unsigned long long *)(b.prof + q), (unsigned long long)prof.acc[q]);
@@ -1158,6 +1143,8 @@ int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev,
     if (mask_row_bytes < AZUL_NUM_ACTIONS) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: mask rows hold 180 bytes, mask_row_bytes >= 180");
     if (n_steps == 0) return AZUL_SUCCESS;
     const int version = selfplay_kernel_version();
+    if (version == 2 && (u64)n_steps * b->d.n * (u64)(rec_dev && mask_row_bytes < AZUL_RECORD_BYTES ? AZUL_RECORD_BYTES : mask_row_bytes) >= (1ull << 32))
+        return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: a trajectory stream of one launch must stay below 4 GiB (use fewer moves per launch)");
     if (version == 1 && mask_row_bytes != AZUL_NUM_ACTIONS)
         return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: the one-game-per-wave kernel writes dense 180-byte mask rows");
     TrajArgs t = {n_steps, mask_dev, (u64 *)maskbits_dev, action_dev, reward_dev, done_dev, rec_dev, packed_dev};
@@ -1172,9 +1159,10 @@ int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev,
             else if (full) hipLaunchKernelGGL((azul_selfplay_kernel<LID, 1>), grid, block, 0, st, b->d, t); \
             else hipLaunchKernelGGL((azul_selfplay_kernel<LID, 2>), grid, block, 0, st, b->d, t); \
         } else { \
-            if (none) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 0>), grid, block, 0, st, b->d, t, ms); \
-            else if (full) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1>), grid, block, 0, st, b->d, t, ms); \
-            else hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 2>), grid, block, 0, st, b->d, t, ms); \
+            if (none) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 0, false>), grid, block, 0, st, b->d, t, ms); \
+            else if (full && ms >= 192u) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true>), grid, block, 0, st, b->d, t, ms); \
+            else if (full) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, false>), grid, block, 0, st, b->d, t, ms); \
+            else hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 2, false>), grid, block, 0, st, b->d, t, ms); \
         } } while (0)
     // inside a timed region the first AZ_TIMED_PAIRS launches are bracketed by their own event pair (the kernel's duration,
     // not the distance between launches)

@@ -33,17 +33,15 @@ AZ_FN u32 hsel(u64 b) { return upper() ? (u32)(b >> 32) : (u32)b; }
 AZ_FN u32 hb(bool p) { return hsel(__builtin_amdgcn_ballot_w64(p)); }
 // value of lane `idx` of MY half, idx per lane (a gather through the LDS crossbar; idx in 0..31)
 AZ_FN u32 hread(u32 v, u32 idx) { return (u32)__builtin_amdgcn_ds_bpermute((int)((idx << 2) | ((wlane() & 32u) << 2)), (int)v); }
-// the same for a HALF-UNIFORM idx (every lane of a half asks for the same lane): two scalar lane reads and a select instead of
-// an LDS round trip -- the move is latency bound (two waves per SIMD), and this is ~25 cycles instead of ~120
-AZ_FN u32 hbcast(u32 v, u32 idx)
-{
-    u32 ia = (u32)__builtin_amdgcn_readlane((int)idx, 0), ib = (u32)__builtin_amdgcn_readlane((int)idx, 32);
-    u32 a = (u32)__builtin_amdgcn_readlane((int)v, (int)(ia & 31u)), b = (u32)__builtin_amdgcn_readlane((int)v, (int)((ib & 31u) | 32u));
-    return upper() ? b : a;
-}
+// the same for a HALF-UNIFORM idx.  (Measured: the LDS crossbar beats a v_readlane pair per half + select -- two instructions and one
+// wait against seven instructions with SGPR hazards: 1.125 vs 1.195 ms per 512-move launch.)
+AZ_FN u32 hbcast(u32 v, u32 idx) { return hread(v, idx); }
 template <u32 IDX>
 AZ_FN u32 hbcast_c(u32 v)
 {
+#if defined(AZ2_CONST_BCAST_LDS)
+    return hread(v, IDX);
+#endif
     u32 a = (u32)__builtin_amdgcn_readlane((int)v, (int)IDX), b = (u32)__builtin_amdgcn_readlane((int)v, (int)(IDX + 32u));
     return upper() ? b : a;
 }
@@ -629,14 +627,17 @@ AZ_FN double game_stat2(const G2 &g, u32 q)
 }
 
 // ---- trajectory streams ------------------------------------------------------------------------------------------------------
+// Base pointers of the time-major streams (wave-uniform: they stay in SGPRs) and ONE per-lane element index e = t * N + game,
+// advanced by N per move: every address is base + e * element size (32-bit offsets: the host refuses streams of 4 GiB or more).
 struct Out2 {
-    uint8_t *mask;       // my game's row of slot t: lane l writes bytes l, 32 + l, ... (row stride `mask_stride`)
-    u64 *maskbits;       // [3]
+    uint8_t *mask;       // [T][N][pitch]: lane l writes bytes l, 32 + l, ... of its game's row
+    u64 *maskbits;       // [T][N][3]
     i32 *action, *reward;
     uint8_t *done;
     u32 *packed;
     uint8_t *rec;        // test stream: the record after the move
-    size_t s_mask, s_bits, s_i32, s_u8, s_rec;     // strides between consecutive moves (elements of each stream)
+    u32 pitch;           // bytes between the mask rows of consecutive games
+    u32 e;
 };
 
 template <int OUT>
@@ -646,15 +647,15 @@ AZ_FN void outputs2(const G2 &g, const Out2 &o, i32 a, i32 reward, u32 dn, u32 l
     const i32 av = a >= 0 ? a : -1;
     if (OUT == 1) {
         // every lane of the half stores the same value to the same address: one request, no exec masking
-        *o.action = av; *o.reward = reward; *o.packed = pack_move(a, dn, reward); *o.done = (uint8_t)dn;
+        o.action[o.e] = av; o.reward[o.e] = reward; o.packed[o.e] = pack_move(a, dn, reward); o.done[o.e] = (uint8_t)dn;
     } else {
         if (l == 0u) {
-            if (o.action) *o.action = av;
-            if (o.reward) *o.reward = reward;
-            if (o.packed) *o.packed = pack_move(a, dn, reward);
-            if (o.done) *o.done = (uint8_t)dn;
+            if (o.action) o.action[o.e] = av;
+            if (o.reward) o.reward[o.e] = reward;
+            if (o.packed) o.packed[o.e] = pack_move(a, dn, reward);
+            if (o.done) o.done[o.e] = (uint8_t)dn;
         }
-        if (o.rec) g2_store(g, o.rec, l);
+        if (o.rec) g2_store(g, o.rec + o.e * (u32)AZUL_RECORD_BYTES, l);
     }
 }
 
@@ -666,7 +667,7 @@ struct Counters2 { u64 *episodes; u32 *stuck; double *stat_sum; };
 // Control flow: two waves per SIMD cannot hide a taken branch's instruction refetch, so the common move is ONE fall-through path;
 // every rare event (window refill across a regeneration, stuck slot, sampler boundary case, end of round, end of game) is tested
 // for the whole wave with one scalar branch (wave_any, hinted unlikely -> placed out of line) and handled per half inside.
-template <bool LID, int OUT>
+template <bool LID, int OUT, bool PAD>
 AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Tab2 &T, u64 margin, const Counters2 &cnt, const Out2 &o,
                         SegProf *prof_ = nullptr)
 {
@@ -690,13 +691,18 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     Mask2 m;
     legal_mask2(g, k, m);
     if (OUT == 1 || (OUT == 2 && o.mask)) {
+        uint8_t *row = o.mask + (o.e * o.pitch + l);
 #pragma unroll
-        for (u32 w = 0; w < 5u; w++) o.mask[32u * w + l] = (uint8_t)m.bit[w];
-        if (l < 20u) o.mask[160u + l] = (uint8_t)m.bit[5];
+        for (u32 w = 0; w < 5u; w++) row[32u * w] = (uint8_t)m.bit[w];
+        // bytes 160..179: with padded rows (pitch >= 192) lanes 20..31 may write their zeros into the pad, no exec masking
+        if (PAD) row[160] = (uint8_t)m.bit[5];
+        else if (l < 20u) row[160] = (uint8_t)m.bit[5];
     }
     if (OUT == 1 || (OUT == 2 && o.maskbits)) {
-        u32 lo = l == 0u ? m.m[0] : (l == 1u ? m.m[2] : m.m[4]), hi = l == 0u ? m.m[1] : (l == 1u ? m.m[3] : m.m[5]);
-        if (l < 3u) o.maskbits[l] = (u64)lo | ((u64)hi << 32);
+        // every lane stores (lanes 3.. repeat lane 2's address and data): no exec masking
+        const u32 q = l < 2u ? l : 2u;
+        u32 lo = q == 0u ? m.m[0] : (q == 1u ? m.m[2] : m.m[4]), hi = q == 0u ? m.m[1] : (q == 1u ? m.m[3] : m.m[5]);
+        o.maskbits[o.e * 3u + q] = (u64)lo | ((u64)hi << 32);
     }
     AZ_STAMP(SEG_MASK);
 
@@ -758,7 +764,11 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
         AZ_STAMP(SEG_MOVE);
         // a move only changes the MOVER's lines and floor; the pricing of his full lines only when one more of them filled
         i32 wc = me ? g.wc1 : g.wc0;
+#if defined(AZ2_ALWAYS_WALLPTS)
+        {
+#else
         if (wave_any(filled)) {
+#endif
             i32 fresh = wall_points2(me ? g.wall1 : g.wall0, full_lines2(me ? g.cp1 : g.cp0, k), k);
             wc = filled ? fresh : wc;
         }

@@ -1085,16 +1085,36 @@ int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int3
 
 int azul_a2c_apply_adam(const float *grad_dev, float *flat_dev, float *exp_avg_dev, float *exp_avg_sq_dev, float lr, float beta1, float beta2,
                         float eps, int step, float *critic1_w, float *critic1_b, float *critic2_w, float *critic2_b, float *actor1_w,
-                        float *actor1_b, float *actor2_w, float *actor2_b, void *stream)
+                        float *actor1_b, float *actor2_w, float *actor2_b, int32_t *step_dev, const float *n_total_dev, void *stream)
 {
-    if (!grad_dev || !flat_dev || !exp_avg_dev || !exp_avg_sq_dev || step < 1 || !critic1_w || !critic1_b || !critic2_w || !critic2_b ||
-        !actor1_w || !actor1_b || !actor2_w || !actor2_b)
+    if (!grad_dev || !flat_dev || !exp_avg_dev || !exp_avg_sq_dev || (!step_dev && step < 1) || !critic1_w || !critic1_b || !critic2_w ||
+        !critic2_b || !actor1_w || !actor1_b || !actor2_w || !actor2_b)
         return fail(AZUL_ERR_INVALID, "azul_a2c_apply_adam: bad arguments");
     STREAM_GUARD(stream);
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double st = step_dev ? 1.0 : (double)step;
+    const double bc1 = 1.0 - pow((double)beta1, st), bc2 = 1.0 - pow((double)beta2, st);
     ModuleParams P = {critic1_w, critic1_b, critic2_w, critic2_b, actor1_w, actor1_b, actor2_w, actor2_b};
+    if (step_dev) hipLaunchKernelGGL(azul_a2c_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, n_total_dev);
     hipLaunchKernelGGL(azul_a2c_apply_kernel, dim3((LG_P_PARAMS + 255) / 256), dim3(256), 0, (hipStream_t)stream, grad_dev, flat_dev, exp_avg_dev,
-                       exp_avg_sq_dev, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), P);
+                       exp_avg_sq_dev, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), P, (const i32 *)step_dev, n_total_dev);
+    HIP_TRY(hipGetLastError());
+    return AZUL_SUCCESS;
+}
+
+int azul_select_episode_samples(const uint8_t *done_ring_dev, const int32_t *action_ring_dev, int window_steps, int ring_windows, int n_games,
+                                int64_t steps_played, int32_t *pending_dev, int32_t *index_dev, int32_t *count_dev, int32_t *scratch_dev,
+                                void *stream)
+{
+    if (!done_ring_dev || !action_ring_dev || !pending_dev || !index_dev || !count_dev || !scratch_dev || window_steps <= 0 || ring_windows <= 0 ||
+        n_games <= 0 || steps_played < window_steps || steps_played % window_steps != 0 || steps_played > 0x7fff0000ll)
+        return fail(AZUL_ERR_INVALID, "azul_select_episode_samples: bad arguments");
+    STREAM_GUARD(stream);
+    const u32 N = (u32)n_games, blocks = (N + 255u) / 256u;
+    const int R = window_steps * ring_windows;
+    hipLaunchKernelGGL(azul_select_ring_count_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, done_ring_dev, action_ring_dev, window_steps, R, N,
+                       (i32)steps_played, (const i32 *)pending_dev, scratch_dev, count_dev);
+    hipLaunchKernelGGL(azul_select_ring_write_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, action_ring_dev, R, N, pending_dev,
+                       (const i32 *)scratch_dev, index_dev, count_dev);
     HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }

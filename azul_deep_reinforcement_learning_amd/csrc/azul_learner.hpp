@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
     __shared__ float dzS[PF_GAMES * PF_HID_STRIDE];      // dL/dz  [16][360 (+pad, zero)]
     __shared__ float w2cS[PF_HID];
     __shared__ float valS[PF_GAMES], dvS[PF_GAMES];
-    __shared__ float lossS[4];
+    __shared__ float lossS[4][16];                       // loss-term partials of the 16 head rows-groups, summed in a fixed order
     const u32 tid = threadIdx.x, l = tid & 63u, c = l & 15u, q = l >> 4;
     const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const u32 n = a.n_dev ? (u32)*a.n_dev : a.n, n_tiles = (n + PF_GAMES - 1) / PF_GAMES;
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
     for (u32 i = tid; i < (u32)(PF_GAMES * PF_HID_STRIDE); i += 64u * LG_WAVES) { hidS[i] = 0.f; dzS[i] = 0.f; }
     for (u32 i = tid; i < (u32)(PF_GAMES * PF_LOG_STRIDE); i += 64u * LG_WAVES) lgS[i] = 0.f;
     if (tid < (u32)PF_HID) w2cS[tid] = W.w2c[tid];
-    if (tid < 4u) lossS[tid] = 0.f;
+    if (tid < 64u) lossS[tid >> 4][tid & 15u] = 0.f;
 
     // buffer descriptors: per-lane byte offset + literal k-step offset (see azul_policy_rollout_kernel)
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)W.w1t, 0, PF_IN * PF_H2 * 4, 0x00020000);
@@ -304,11 +304,16 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
     if (tid < (u32)PF_H2) out[LG_P_B1 + tid] = g_b1;
     if (tid < (u32)PF_HID) { out[LG_P_B2A + tid] = g_b2a; out[LG_P_W2C + tid] = g_w2c; }
     if (tid == 0u) { out[LG_P_B2C] = g_b2c; out[LG_P_B2C + 1] = 0.f; }
-    if (w < 4u && c == 0u) {
-        atomicAdd(&lossS[0], l_actor); atomicAdd(&lossS[1], l_critic); atomicAdd(&lossS[2], l_entropy); atomicAdd(&lossS[3], l_count);
+    if (w < 4u && c == 0u) {                             // one slot per contributing lane: no atomics, so the logged losses are bit-reproducible
+        const u32 slot = 4u * w + q;
+        lossS[0][slot] = l_actor; lossS[1][slot] = l_critic; lossS[2][slot] = l_entropy; lossS[3][slot] = l_count;
     }
     __syncthreads();
-    if (tid < 4u) out[LG_P_LOSS + tid] = lossS[tid];
+    if (tid < 4u) {
+        float sum = 0.f;
+        for (int i = 0; i < 16; i++) sum += lossS[tid][i];
+        out[LG_P_LOSS + tid] = sum;
+    }
 }
 
 // sum of the per-workgroup partials in workgroup order (deterministic); optionally scaled loss sums stay raw (caller divides)
@@ -383,6 +388,83 @@ __global__ void __launch_bounds__(1024) azul_select_complete_kernel(const uint8_
 }
 
 
+// ---- selection over a RING of windows: every step of every episode is trained exactly once ---------------------------------
+// The trajectory arrays are rings of R = D * T time slots (D windows of T agent steps); absolute step s lives in slot s mod R.
+// After window k (absolute steps kT .. (k+1)T - 1) has been played, game g contributes the steps from `pend[g]` -- the first
+// step of its oldest episode that has not been trained yet -- up to its LAST episode end inside window k: episodes that ended
+// in this window, including their opening steps recorded in earlier windows (whose returns the caller has chained backwards
+// through the ring with azul_discounted_returns' carry).  Steps that have already fallen out of the ring are counted in
+// count[1] ("dropped").  Two launches, deterministic order (game by game, steps ascending): counts + block sums, then offsets +
+// index writes.  scratch: int32 [3 N + blocks].
+__global__ void __launch_bounds__(256) azul_select_ring_count_kernel(const uint8_t *done, const i32 *action, int T, int R, u32 N, i32 s_end,
+                                                                   const i32 *pend, i32 *scratch, i32 *count)
+{
+    __shared__ i32 redS[256];
+    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    const u32 nb = gridDim.x;
+    i32 *cntA = scratch, *startA = scratch + N, *lastA = scratch + 2 * (size_t)N, *blockA = scratch + 3 * (size_t)N;
+    i32 cnt = 0, start = 0, last = -1, dropped = 0;
+    if (g < N) {
+        const i32 s_win = s_end - T;
+        for (int t = 0; t < T; t++)                       // (loads pipeline: no data-dependent exit)
+            if (done[(size_t)((s_win + t) % R) * N + g] != 0) last = s_win + t;
+        if (last >= 0) {
+            const i32 lo = s_end - R > 0 ? s_end - R : 0;
+            const i32 p0 = pend[g];
+            start = p0 > lo ? p0 : lo;
+            dropped = start - p0;
+            for (i32 s = start; s <= last; s++) cnt += action[(size_t)(s % R) * N + g] >= 0 ? 1 : 0;
+        }
+        cntA[g] = cnt; startA[g] = start; lastA[g] = last;
+    }
+    redS[threadIdx.x] = cnt;
+    __syncthreads();
+    for (u32 o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) redS[threadIdx.x] += redS[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) blockA[blockIdx.x] = redS[0];
+    if (g == 0) { count[0] = 0; }
+    if (dropped) atomicAdd(&count[1], dropped);           // integer: order does not matter
+    (void)nb;
+}
+
+__global__ void __launch_bounds__(256) azul_select_ring_write_kernel(const i32 *action, int R, u32 N, i32 *pend, const i32 *scratch, i32 *index,
+                                                                   i32 *count)
+{
+    __shared__ i32 scanS[256];
+    __shared__ i32 baseS;
+    const u32 tid = threadIdx.x, g = blockIdx.x * 256u + tid;
+    const i32 *cntA = scratch, *startA = scratch + N, *lastA = scratch + 2 * (size_t)N, *blockA = scratch + 3 * (size_t)N;
+    // this block's base: the sum of the earlier blocks' totals (fixed order)
+    i32 part = 0;
+    for (u32 b = tid; b < blockIdx.x; b += 256u) part += blockA[b];
+    scanS[tid] = part;
+    __syncthreads();
+    for (u32 o = 128; o > 0; o >>= 1) { if (tid < o) scanS[tid] += scanS[tid + o]; __syncthreads(); }
+    if (tid == 0) baseS = scanS[0];
+    __syncthreads();
+    const i32 cnt = g < N ? cntA[g] : 0;
+    scanS[tid] = cnt;
+    __syncthreads();
+    for (u32 o = 1; o < 256u; o <<= 1) {                 // inclusive scan (Hillis-Steele)
+        i32 v = tid >= o ? scanS[tid - o] : 0;
+        __syncthreads();
+        scanS[tid] += v;
+        __syncthreads();
+    }
+    if (g < N) {
+        i32 pos = baseS + scanS[tid] - cnt;
+        const i32 last = lastA[g];
+        if (last >= 0) {
+            for (i32 s = startA[g]; s <= last; s++) {
+                const i32 slot = s % R;
+                if (action[(size_t)slot * N + g] >= 0) index[pos++] = (i32)((u32)slot * N + g);
+            }
+            pend[g] = last + 1;
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 255u) count[0] = baseS + scanS[255];
+}
+
+
 // Adam (torch.optim.Adam's defaults and arithmetic: lerp for the first moment, bias corrections, eps added to the corrected root)
 // on the flat k-major master copy of the parameters, one thread per parameter; the step also lands in the eight PyTorch parameter
 // tensors (nn.Linear layouts, i.e. transposed), so the module, the rollout kernels (which read the master copy) and the optimiser
@@ -391,9 +473,29 @@ struct ModuleParams {
     float *c1w, *c1b, *c2w, *c2b, *a1w, *a1b, *a2w, *a2b;      // critic_linear1/2, actor_linear1/2: weight [out][in], bias [out]
 };
 
-__global__ void __launch_bounds__(256) azul_a2c_apply_kernel(const float *grad, float *flat, float *m, float *v, float lr, float beta1,
-                                                             float beta2, float eps, float bias_c1, float bias_c2_sqrt, ModuleParams P)
+// step counter of the optimiser in device memory: advanced only by an update that has samples (an empty window must not
+// move the parameters along the stale moments, nor change the bias corrections of later updates)
+__global__ void azul_a2c_step_kernel(i32 *step_dev, const float *n_total_dev)
 {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && (!n_total_dev || *n_total_dev > 0.f)) step_dev[0] += 1;
+}
+
+__global__ void __launch_bounds__(256) azul_a2c_apply_kernel(const float *grad, float *flat, float *m, float *v, float lr, float beta1,
+                                                             float beta2, float eps, float bias_c1, float bias_c2_sqrt, ModuleParams P,
+                                                             const i32 *step_dev, const float *n_total_dev)
+{
+    if (n_total_dev && !(*n_total_dev > 0.f)) return;    // a window without a finished episode: no samples, no step
+    if (step_dev) {                                      // bias corrections from the device-resident step (torch.optim.Adam: 1 - beta^step)
+        __shared__ float bcS[2];
+        if (threadIdx.x == 0) {
+            const double st = (double)step_dev[0];
+            bcS[0] = (float)(1.0 - pow((double)beta1, st));
+            bcS[1] = (float)sqrt(1.0 - pow((double)beta2, st));
+        }
+        __syncthreads();
+        bias_c1 = bcS[0];
+        bias_c2_sqrt = bcS[1];
+    }
     const u32 p = blockIdx.x * 256u + threadIdx.x;
     if (p >= (u32)LG_P_PARAMS || p == (u32)LG_P_B2C + 1u) return;
     const float g = grad[p];

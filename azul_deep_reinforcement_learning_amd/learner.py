@@ -15,6 +15,8 @@ Data parallel (one process per GPU): every rank holds the samples of its own gam
 samples divided by the GLOBAL sample count, and gradients are summed over ranks (one flat all-reduce over RCCL), so the
 update equals the single-process update on the union of all ranks' samples whatever the per-rank counts are.
 """
+import collections
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -24,7 +26,9 @@ ACTOR_COEFF, CRITIC_COEFF, ENTROPY_COEFF = 1.0, 0.5, 0.1        # agent.py:47-49
 
 def complete_episode_samples(done):
     """[T, N] done flags of a window -> bool [T, N]: the steps whose episode ENDS inside the window, i.e. whose discounted
-    return (nn_runner.py:70-76) is exact without bootstrapping.  Steps after a game's last `done` are left for a later window."""
+    return (nn_runner.py:70-76) is exact without bootstrapping.  Steps after a game's last `done` belong to an episode that
+    ends in a LATER window: with a single-window rollout they are never trained (the next window overwrites the buffers) --
+    A2CLearner.update_from_rollout on a PolicyRollout(ring >= 2) keeps them and trains them when their episode ends."""
     d = done != 0
     return torch.flip(torch.cummax(torch.flip(d, dims=[0]).to(torch.uint8), dim=0).values, dims=[0]).bool()
 
@@ -33,7 +37,7 @@ N_PARAMS = 82081            # ActorCritic(136, 180, 180)
 
 
 class A2CLearner:
-    def __init__(self, policy, learning_rate=3e-4, gamma=0.99, process_group=None, distributed=None, fused=None):
+    def __init__(self, policy, learning_rate=3e-4, gamma=0.99, process_group=None, distributed=None, fused=None, stat_history=4096):
         """fused=True: gradients from the hand-written kernel azul_a2c_gradients (forward + backward on the f32 matrix cores, one
         launch + a deterministic reduction) instead of PyTorch autograd; needs CUDA tensors and the reference's network shape.
         Default: fused whenever that is possible."""
@@ -45,7 +49,10 @@ class A2CLearner:
         self.fused_apply = True           # the fused path steps with azul_a2c_apply_adam while `optimizer` is the learner's own Adam
         self.group = process_group
         self.distributed = (dist.is_available() and dist.is_initialized()) if distributed is None else distributed
-        self.statistics = {"actor_loss": [], "critic_loss": [], "entropy_loss": [], "ac_loss": [], "samples": []}
+        # the last updates' loss terms (device scalars; bounded: the reference keeps one float per logged batch, agent.py:19-24)
+        self.statistics = {k: collections.deque(maxlen=stat_history) for k in ("actor_loss", "critic_loss", "entropy_loss", "ac_loss", "samples")}
+        self.updates = 0                  # optimiser steps requested so far (statistics entries ever appended)
+        self.dropped_steps = None         # device int32[2] of update_from_rollout: [samples of the last update, steps lost from the ring]
 
     def loss_terms(self, obs, mask, action, qvals, weight=None, n_total=None):
         """obs [n,136] f32, mask [n,180] bool/u8, action [n] int, qvals [n] -> the four loss terms of agent.py:51-57.
@@ -93,7 +100,8 @@ class A2CLearner:
             from . import _lib as L
             n = L.A2C_FLAT_SIZE
             self._ws = {"ws": torch.empty(256, n + 4, device=dev), "grad": torch.empty(n + 4, device=dev), "flat": torch.zeros(n, device=dev),
-                        "m": torch.zeros(n, device=dev), "v": torch.zeros(n, device=dev), "step": 0}
+                        "m": torch.zeros(n, device=dev), "v": torch.zeros(n, device=dev),
+                        "step": torch.zeros(1, dtype=torch.int32, device=dev)}        # Adam's step counter lives on the device
             self.sync_from_module()
         return self._ws
 
@@ -123,7 +131,7 @@ class A2CLearner:
         """What a checkpoint needs: torch's Adam state, plus the fused path's moments and step when it is in use."""
         st = {"torch": self.optimizer.state_dict()}
         if self._ws is not None:
-            st["fused"] = {"m": self._ws["m"].cpu(), "v": self._ws["v"].cpu(), "step": self._ws["step"]}
+            st["fused"] = {"m": self._ws["m"].cpu(), "v": self._ws["v"].cpu(), "step": int(self._ws["step"].item())}
         return st
 
     def load_optimizer_state(self, st):
@@ -132,7 +140,7 @@ class A2CLearner:
             ws = self._ensure_flat(next(self.policy.parameters()).device)
             ws["m"].copy_(st["fused"]["m"])
             ws["v"].copy_(st["fused"]["v"])
-            ws["step"] = int(st["fused"]["step"])
+            ws["step"].fill_(int(st["fused"]["step"]))
         self.sync_from_module()
 
     def _fused_gradients(self, obs, mask, action, qvals, n_total=None, index=None, count=None, kweights=None):
@@ -176,6 +184,12 @@ class A2CLearner:
                 samples = torch.as_tensor(float(n_total), device=dev)
         return sums[0], sums[1], sums[2], samples
 
+    def _record(self, out):
+        for k2, v in out.items():
+            self.statistics[k2].append(v)
+        self.updates += 1
+        return out
+
     def _finish_fused(self, a, c, e, samples):
         """Optimiser step: azul_a2c_apply_adam on the flat copy + module (the learner's own Adam), or -- when the caller installed
         another optimiser -- the flat gradient scattered into the parameters' .grad and that optimiser's step."""
@@ -186,13 +200,15 @@ class A2CLearner:
         dev = g.device
         if self.optimizer is self._own_adam and self.fused_apply:
             grp = self.optimizer.param_groups[0]
-            ws["step"] += 1
             p = lambda t: C.c_void_p(t.data_ptr())
+            # the step counter and the "any samples at all?" test stay on the device: an update without samples (a window in which
+            # no episode ended) leaves parameters, moments and step untouched
+            n_dev = samples.reshape(1).to(torch.float32).contiguous()
             L.check(L.lib.azul_a2c_apply_adam(p(g), p(ws["flat"]), p(ws["m"]), p(ws["v"]), C.c_float(grp["lr"]), C.c_float(grp["betas"][0]),
-                                              C.c_float(grp["betas"][1]), C.c_float(grp["eps"]), int(ws["step"]),
+                                              C.c_float(grp["betas"][1]), C.c_float(grp["eps"]), 0,
                                               p(pol.critic_linear1.weight), p(pol.critic_linear1.bias), p(pol.critic_linear2.weight),
                                               p(pol.critic_linear2.bias), p(pol.actor_linear1.weight), p(pol.actor_linear1.bias),
-                                              p(pol.actor_linear2.weight), p(pol.actor_linear2.bias),
+                                              p(pol.actor_linear2.weight), p(pol.actor_linear2.bias), p(ws["step"]), p(n_dev),
                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         else:
             with torch.no_grad():
@@ -209,10 +225,7 @@ class A2CLearner:
             self.optimizer.step()
             self.sync_from_module()
         loss = ACTOR_COEFF * a + CRITIC_COEFF * c + ENTROPY_COEFF * e
-        out = {"actor_loss": a, "critic_loss": c, "entropy_loss": e, "ac_loss": loss, "samples": samples}
-        for k2, v in out.items():
-            self.statistics[k2].append(v)
-        return out
+        return self._record({"actor_loss": a, "critic_loss": c, "entropy_loss": e, "ac_loss": loss, "samples": samples})
 
     def update(self, obs, mask, action, qvals, weight=None):
         """One optimiser step on the given samples (this rank's share when distributed).  Returns the loss terms (global means).
@@ -245,10 +258,47 @@ class A2CLearner:
                 o += p.numel()
             stats = flat[o:]
         self.optimizer.step()
-        out = {"actor_loss": stats[0], "critic_loss": stats[1], "entropy_loss": stats[2], "ac_loss": stats[3], "samples": n_total.squeeze(0)}
-        for k2, v in out.items():
-            self.statistics[k2].append(v)
-        return out
+        return self._record({"actor_loss": stats[0], "critic_loss": stats[1], "entropy_loss": stats[2], "ac_loss": stats[3],
+                             "samples": n_total.squeeze(0)})
+
+    def update_from_rollout(self, rollout):
+        """One update from a PolicyRollout after run_window().  With a ring of >= 2 windows (one part, fused path) EVERY step of
+        EVERY episode is trained exactly once, like NNRunner.train (nn_runner.py:59-76): azul_select_episode_samples picks, per game,
+        the steps from the first one not trained yet up to its last episode end inside the newest window -- including the opening
+        steps recorded in earlier windows, whose returns run_window has chained backwards through the ring -- and
+        azul_a2c_gradients reads them through the index list straight from the ring.  Steps whose episode outlives the ring
+        (longer than (ring - 1) * window + 1 agent steps) are dropped and counted in `dropped_steps[1]`.
+        Otherwise (ring == 1, several parts, PyTorch path): update_from_windows on the newest window."""
+        ro = rollout
+        tr0 = ro.traj[0]
+        if ro.ring < 2 or ro.parts != 1 or not (self._can_fuse(tr0["obs"]) if self.fused is None else bool(self.fused)):
+            return self.update_from_windows(ro.traj)
+        import ctypes as C
+        from . import _lib as L
+        rg, T, N, D = ro.rings[0], ro.T, ro.h, ro.ring
+        dev = tr0["obs"].device
+        R = D * T
+        st = getattr(self, "_ring", None)
+        if st is None or st["key"] != (id(ro), R, N):
+            st = self._ring = {"key": (id(ro), R, N), "index": torch.empty(R * N, dtype=torch.int32, device=dev),
+                               "count": torch.zeros(2, dtype=torch.int32, device=dev), "pending": torch.zeros(N, dtype=torch.int32, device=dev),
+                               "scratch": torch.empty(3 * N + (N + 255) // 256, dtype=torch.int32, device=dev), "offset": 0}
+            # this learner's books start with the window that was just played (earlier windows -- warm-up -- are nobody's samples);
+            # the clock is the rollout's own (absolute step s lives in ring slot s % R), shifted down by whole rings when it grows
+            st["pending"].fill_((ro.windows_played - 1) * T)
+            self.dropped_steps = st["count"]
+        played = ro.windows_played * T - st["offset"]
+        if played > (1 << 30):                            # keep the absolute step counters inside int32: rebase by whole rings
+            shift = (played - R) // R * R
+            st["pending"].sub_(shift)
+            st["offset"] += shift
+            played -= shift
+        p = lambda t: C.c_void_p(t.data_ptr())
+        L.check(L.lib.azul_select_episode_samples(p(rg["done"]), p(rg["action"]), T, D, N, int(played), p(st["pending"]), p(st["index"]),
+                                                  p(st["count"]), p(st["scratch"]), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return self._finish_fused(*self._fused_gradients(
+            rg["obs"][:R].reshape(R * N, -1), rg["mask"][:R].reshape(R * N, -1), rg["action"].reshape(-1), rg["returns"].reshape(-1),
+            index=st["index"], count=st["count"][:1]))
 
     def update_from_windows(self, trajectories, complete_only=True, kweights=None):
         """`trajectories`: the per-part dicts PolicyRollout.run_window returns (opponent="random": every record is one agent

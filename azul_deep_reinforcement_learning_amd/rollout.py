@@ -34,13 +34,17 @@ def _p(t):
 class PolicyRollout:
     def __init__(self, policy, n_games=4096, parts=1, rules={"first_player": "Random", "tile_pool": "Lid"}, seed_base=0,
                  device=None, window=32, use_graph=True, fused_head=True, sample_seed=0x5EED, opponent=None, fused_mlp=True, persistent=False,
-                 action_selection="Distribution", kweights=None, game_id_base=None):
+                 action_selection="Distribution", kweights=None, game_id_base=None, ring=1):
         """opponent=None: the policy moves for both players (flat self-play, one record per env move).
         opponent="random": the reference's training setup -- the policy is player 1 of GameRunner, the opponent a RandomAgent
         inside the env step (game_runner.py:43-47); one record per AGENT step, observations from the agent's perspective.
         `seed_base` / `game_id_base`: game i of this rollout is global game game_id_base + i (default: seed_base, so that a rank
         passes the id of its first game once); its CPython stream is random.seed(seed_base + i) and its sampling stream is
-        Philox(sample_seed, step, global id) -- both independent of how the games are sharded over GPUs or split into parts."""
+        Philox(sample_seed, step, global id) -- both independent of how the games are sharded over GPUs or split into parts.
+        `ring` (persistent=True only): the trajectory buffers hold the last `ring` windows (a ring of ring * window time slots);
+        run_window fills the next window of the ring and re-chains the discounted returns backwards through the older windows, so
+        that the opening steps of an episode that ends in a LATER window get their exact Monte-Carlo return too
+        (A2CLearner.update_from_rollout trains every step of every episode exactly once, like NNRunner.train)."""
         assert n_games % parts == 0
         assert opponent in (None, "random")
         self.opponent = opponent
@@ -53,6 +57,9 @@ class PolicyRollout:
                               policy.critic_linear1.out_features == 180 and policy.actor_linear2.out_features == L.NUM_ACTIONS)
         # persistent=True: the whole window runs in ONE launch per part (azul_batch_policy_rollout); same results
         self.persistent = bool(persistent and self.fused_mlp)
+        self.ring = int(ring) if self.persistent else 1
+        assert self.ring >= 1
+        self.windows_played = 0
         # Agent.get_ac_output's two modes (agent.py:64-72): sample from the masked softmax, or take its first maximum
         assert action_selection in ("Distribution", "Max") and (fused_head or action_selection == "Distribution")
         self.action_selection = action_selection
@@ -79,12 +86,16 @@ class PolicyRollout:
                 env.runner_init()                                  # reset() without pre-moves (flat self-play)
             self.envs.append(env)
             self.streams.append(torch.cuda.Stream(device=d))
-            t = {"obs": torch.zeros(T + 1, h, L.OBS_SIZE, device=d), "mask": torch.zeros(T + 1, h, L.NUM_ACTIONS, dtype=torch.uint8, device=d),
-                 "player": torch.zeros(T + 1, h, dtype=torch.uint8, device=d),
-                 "action": torch.zeros(T, h, dtype=torch.int32, device=d), "reward": torch.zeros(T, h, dtype=torch.int32, device=d),
-                 "done": torch.zeros(T, h, dtype=torch.uint8, device=d),
-                 "value": torch.zeros(T, h, 1, device=d), "log_prob": torch.zeros(T, h, device=d), "entropy": torch.zeros(T, h, device=d),
-                 "returns": torch.zeros(T, h, device=d)}
+            R = self.ring * T
+            rg = {"obs": torch.zeros(R + 1, h, L.OBS_SIZE, device=d), "mask": torch.zeros(R + 1, h, L.NUM_ACTIONS, dtype=torch.uint8, device=d),
+                  "player": torch.zeros(R + 1, h, dtype=torch.uint8, device=d),
+                  "action": torch.zeros(R, h, dtype=torch.int32, device=d), "reward": torch.zeros(R, h, dtype=torch.int32, device=d),
+                  "done": torch.zeros(R, h, dtype=torch.uint8, device=d),
+                  "value": torch.zeros(R, h, 1, device=d), "log_prob": torch.zeros(R, h, device=d), "entropy": torch.zeros(R, h, device=d),
+                  "returns": torch.zeros(R, h, device=d), "carry": torch.zeros(h, device=d)}
+            self.rings = getattr(self, "rings", [])
+            self.rings.append(rg)
+            t = self._window_views(rg, self.ring - 1)             # the "previous" window: its slot T seeds the first window
             w = {"hidden": torch.zeros(h, 2 * self.H, device=d), "logits": torch.zeros(h, L.NUM_ACTIONS, device=d),
                  "status": torch.zeros(h, dtype=torch.uint8, device=d),
                  "counter": torch.tensor([0, 0], dtype=torch.int64, device=d)}     # [0] Philox step counter, [1] launch ticket
@@ -103,6 +114,14 @@ class PolicyRollout:
                 self.graphs = []
                 self.use_graph = False
                 torch.cuda.synchronize(d)
+
+    def _window_views(self, rg, w):
+        """Views of window `w` of a ring: T + 1 slots of obs / mask / player (slot T = the state after the window), T of the rest."""
+        T = self.T
+        lo = w * T
+        out = {k: rg[k][lo:lo + T + 1] for k in ("obs", "mask", "player")}
+        out.update({k: rg[k][lo:lo + T] for k in ("action", "reward", "done", "value", "log_prob", "entropy", "returns")})
+        return out
 
     def _persp(self):
         return 0 if self.opponent == "random" else L.PERSP_CURRENT     # NNRunner observes with perspective 0 (game_runner.py:56)
@@ -173,7 +192,11 @@ class PolicyRollout:
             env.policy_step(tr["action"][t], tr["reward"][t], tr["done"][t], w["status"], tr["obs"][t + 1], tr["mask"][t + 1], tr["player"][t + 1])
 
     def _window(self, p, gamma):
-        tr, T = self.traj[p], self.T
+        T = self.T
+        if self.persistent and self.ring > 1:
+            wi = self.windows_played % self.ring                   # (run_window advances windows_played after all parts)
+            self.traj[p] = self._window_views(self.rings[p], wi)
+        tr = self.traj[p]
         if self.persistent:
             env, w, pol = self.envs[p], self.work[p], self.policy
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -182,7 +205,16 @@ class PolicyRollout:
                 _p(self.w2a_t), _p(pol.actor_linear2.bias), L.OBS_SIZE, self.H, L.NUM_ACTIONS, self.sample_seed, 0, _p(w["counter"]),
                 _p(tr["obs"]), _p(tr["mask"]), _p(tr["player"]), _p(tr["action"]), _p(tr["reward"]), _p(tr["done"]), _p(tr["value"]),
                 _p(tr["log_prob"]), _p(tr["entropy"]), _p(w["status"]), st))
-            L.check(L.lib.azul_discounted_returns(_p(tr["reward"]), _p(tr["done"]), _p(tr["returns"]), None, C.c_float(gamma), T, self.h, st))
+            if self.ring == 1:
+                L.check(L.lib.azul_discounted_returns(_p(tr["reward"]), _p(tr["done"]), _p(tr["returns"]), None, C.c_float(gamma), T, self.h, st))
+                return
+            # returns of the new window, then chained backwards through the older windows of the ring: the value flowing out of a
+            # window's first step is the carry of the window before it (nn_runner.py:70-76 across window boundaries)
+            rg = self.rings[p]
+            rg["carry"].zero_()
+            for back in range(min(self.ring, self.windows_played + 1)):
+                v = self._window_views(rg, (wi - back) % self.ring)
+                L.check(L.lib.azul_discounted_returns(_p(v["reward"]), _p(v["done"]), _p(v["returns"]), _p(rg["carry"]), C.c_float(gamma), T, self.h, st))
             return
         tr["obs"][0].copy_(tr["obs"][T])
         tr["mask"][0].copy_(tr["mask"][T])
@@ -218,6 +250,7 @@ class PolicyRollout:
                     self.graphs[p].replay()
                 else:
                     self._window(p, gamma)
+        self.windows_played += 1
         return self.traj
 
     def join(self):

@@ -3,7 +3,8 @@ the CSV training log the reference intends to write, checkpoints, and resumable 
 
 One "batch" of the reference is `batch_size` sequential episodes followed by one `Agent.update`; here it is one rollout
 window of `window` agent steps for all `n_games` concurrent games (policy vs the RandomAgent opponent inside the env
-step) followed by one `A2CLearner.update` on the steps whose episode finished inside the window.
+step) followed by one `A2CLearner.update`: with the default ring of three windows every step of every episode is trained exactly
+once, when its episode ends (A2CLearner.update_from_rollout; the reference trains on whole episodes, nn_runner.py:59-76).
 
 CSV (nn_runner.py:51-54, 79-82): header ``batch`` + the five agent statistics keys (agent.py:13) + the ten game statistics
 keys (game_runner.py:12); one row per logged batch with the batch's means.  The reference's own writer dereferences
@@ -34,14 +35,17 @@ AGENT_STAT_KEYS = ("reward", "actor_loss", "critic_loss", "entropy_loss", "ac_lo
 
 class BatchedTrainer:
     def __init__(self, policy, n_games=4096, window=32, parts=1, learning_rate=3e-4, gamma=0.99, seed_base=0, sample_seed=0x5EED,
-                 rules={"first_player": "Random", "tile_pool": "Lid"}, device=None, use_graph=True, persistent=True, results_dir="results"):
+                 rules={"first_player": "Random", "tile_pool": "Lid"}, device=None, use_graph=True, persistent=True, results_dir="results",
+                 ring=3):
+        """ring: trajectory windows kept (persistent rollout with one part): with ring >= 2 every step of every episode is trained
+        exactly once (episodes straddle windows; an episode may span ring - 1 window boundaries), like NNRunner.train."""
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         policy = policy.to(dev)
         self.learner = A2CLearner(policy, learning_rate=learning_rate, gamma=gamma)
         # rollout kernels and learner share ONE k-major copy of the weights (the learner's flat master copy)
         self.rollout = PolicyRollout(policy, n_games=n_games, parts=parts, rules=rules, seed_base=seed_base, device=dev, window=window,
                                      use_graph=use_graph, sample_seed=sample_seed, opponent="random", persistent=persistent,
-                                     kweights=self.learner.kweights(dev))
+                                     kweights=self.learner.kweights(dev), ring=ring if (persistent and parts == 1) else 1)
         self.gamma = gamma
         self.results_dir = results_dir
         self.batch = 0
@@ -72,7 +76,7 @@ class BatchedTrainer:
         GameStatistics buffers between two get_stats() calls (game_runner.py:17-22)."""
         tr = self.rollout.run_window(self.gamma)
         self.rollout.join()                              # device-side dependency: the host keeps enqueueing
-        out = self.learner.update_from_windows(tr)
+        out = self.learner.update_from_rollout(self.rollout)
         self.rollout.refresh_weights()
         self.batch += 1
         r = sum(part["reward"].sum() for part in tr)
@@ -83,11 +87,11 @@ class BatchedTrainer:
         row = {"batch": self.batch, "reward": float(self._reward_acc) / episodes if episodes else float("nan")}
         self._reward_acc = None
         # the loss terms of every update since the last collecting call, averaged (AgentStatistics.get_stats, agent.py:19-24)
-        mark = getattr(self, "_loss_mark", 0)
+        fresh = min(self.learner.updates - getattr(self, "_loss_mark", 0), len(self.learner.statistics["ac_loss"]))
         for k in AGENT_STAT_KEYS[1:]:
-            vals = self.learner.statistics[k][mark:]
+            vals = list(self.learner.statistics[k])[len(self.learner.statistics[k]) - fresh:]
             row[k] = float(torch.stack([torch.as_tensor(v, dtype=torch.float32, device=self.rollout.device) for v in vals]).mean())
-        self._loss_mark = len(self.learner.statistics["ac_loss"])
+        self._loss_mark = self.learner.updates
         row.update(game)
         for k, v in row.items():
             self.history[k].append(v)
@@ -158,4 +162,4 @@ class BatchedTrainer:
         self.batch = int(ck["batch"])
         self._stat_base = self._stat_totals()
         self._reward_acc = None
-        self._loss_mark = len(self.learner.statistics["ac_loss"])
+        self._loss_mark = self.learner.updates

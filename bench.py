@@ -140,12 +140,12 @@ def extras(games):
     torch.manual_seed(0)
     net = BatchedActorCritic(136, 180, 180).cuda()
     learner = A2CLearner(net)
-    ro = PolicyRollout(net, n_games=games, parts=1, window=window, persistent=True, opponent="random", kweights=learner.kweights())
+    ro = PolicyRollout(net, n_games=games, parts=1, window=window, persistent=True, opponent="random", kweights=learner.kweights(), ring=3)
 
     def one_window():
         tr = ro.run_window()
         ro.join()
-        out = learner.update_from_windows(tr) if not hasattr(learner, "update_from_rollout") else learner.update_from_rollout(ro)
+        out = learner.update_from_rollout(ro)
         ro.refresh_weights()
         return out
 
@@ -159,12 +159,13 @@ def extras(games):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     samples = float(out["samples"])
+    dropped = int(learner.dropped_steps[1]) if learner.dropped_steps is not None else None
     res["training"] = {
         "metric": "A2C training throughput (policy vs RandomAgent opponent, one update per window)", "value": games * window * windows / dt,
-        "unit": "agent steps/s", "updates_per_s": windows / dt, "samples_last_update": samples,
+        "unit": "agent steps/s", "updates_per_s": windows / dt, "samples_last_update": samples, "steps_dropped_from_ring": dropped,
         "episodes_per_s": (ro.counters()["episodes"] - ep0) / dt,
-        "config": {"workload": "NNRunner.train batched: %d games, window %d agent steps, rollout + selection + gradients + Adam per window"
-                               % (games, window), "windows_timed": windows},
+        "config": {"workload": "NNRunner.train batched: %d games, window %d agent steps (ring of 3 windows: every step of every episode is "
+                               "trained once), rollout + selection + gradients + Adam per window" % (games, window), "windows_timed": windows},
         "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TFLOPS,
                      "achieved": (GRAD_FLOP_PER_SAMPLE * samples + FWD_FLOP_PER_GAME * games * window) * windows / dt / 1e12,
                      "frac": (GRAD_FLOP_PER_SAMPLE * samples + FWD_FLOP_PER_GAME * games * window) * windows / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,

@@ -114,12 +114,12 @@ def train(a):
     learner = A2CLearner(net)
     ro = PolicyRollout(net, n_games=a.games, parts=a.parts, window=a.window, use_graph=not a.no_graph, fused_head=not a.torch_head,
                        fused_mlp=not a.torch_mlp, persistent=not a.per_move, opponent="random", seed_base=rank * a.games,
-                       sample_seed=0x5EED, kweights=learner.kweights())
+                       sample_seed=0x5EED, kweights=learner.kweights(), ring=3 if (a.parts == 1 and not a.per_move) else 1)
 
     def one_window():
         tr = ro.run_window()
         ro.join()                                           # device-side dependency between the streams; no host sync per window
-        out = learner.update_from_windows(tr)
+        out = learner.update_from_rollout(ro)
         ro.refresh_weights()
         return out
 
@@ -137,7 +137,7 @@ def train(a):
         dist.barrier()
     dt = time.perf_counter() - t0
     c = ro.counters()
-    stats = learner.statistics
+    stats = {k: list(v) for k, v in learner.statistics.items()}
     if rank == 0:
         print(json.dumps({"metric": "A2C training throughput (policy vs RandomAgent opponent, one update per window)",
                           "value": a.games * world * a.window * a.windows / dt, "unit": "agent steps/s", "n_gpus": world,

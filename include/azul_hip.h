@@ -245,16 +245,31 @@ int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int3
 /* torch.optim.Adam's step (defaults: betas 0.9 / 0.999, eps 1e-8, no weight decay; same arithmetic) on the flat k-major master copy of
  * the parameters (layout of azul_a2c_gradients' gradient; w1t / b1 / w2c / b2c / w2a_t / b2a of the policy entries are views of it),
  * with the two moment vectors in the same layout; `step` counts from 1.  The updated values are also written into the eight PyTorch
- * parameter tensors (nn.Linear layouts), so module, kernels and optimiser state stay in sync without re-layout launches. */
+ * parameter tensors (nn.Linear layouts), so module, kernels and optimiser state stay in sync without re-layout launches.
+ * step_dev (optional, int32[1] in device memory): the step counter lives on the device -- it is advanced, and the step applied, only when
+ * *n_total_dev > 0 (n_total_dev optional: the update's global sample count as a float in device memory); an update without samples
+ * then leaves parameters, moments and step untouched.  With step_dev == NULL the host passes `step` (>= 1). */
 int azul_a2c_apply_adam(const float *grad_dev, float *flat_dev, float *exp_avg_dev, float *exp_avg_sq_dev, float lr, float beta1, float beta2,
                         float eps, int step, float *critic1_w, float *critic1_b, float *critic2_w, float *critic2_b, float *actor1_w,
-                        float *actor1_b, float *actor2_w, float *actor2_b, void *stream);
+                        float *actor1_b, float *actor2_w, float *actor2_b, int32_t *step_dev, const float *n_total_dev, void *stream);
 /* Which steps of a window feed the update (NNRunner.train uses whole episodes, nn_runner.py:59-76): the steps whose episode ends
  * inside the window and that carry an action (>= 0).  done / action are time-major [n_steps][n_games]; index_dev receives the flat
  * indices t * n_games + g (game by game, steps ascending), count_dev[0] their number.  Feeds azul_a2c_gradients' index_dev /
  * n_samples_dev without a host round trip. */
 int azul_select_complete_samples(const uint8_t *done_dev, const int32_t *action_dev, int n_steps, int n_games, int32_t *index_dev,
                                  int32_t *count_dev, void *stream);
+/* The same selection over a RING of `ring_windows` windows of `window_steps` agent steps each, so that EVERY step of EVERY episode is
+ * trained exactly once, like NNRunner.train (nn_runner.py:59-76), although episodes straddle windows: the time-major arrays hold
+ * ring_windows * window_steps slots, absolute step s lives in slot s % (ring_windows * window_steps); `steps_played` = absolute steps
+ * recorded so far (a multiple of window_steps: the newest window is steps_played - window_steps .. steps_played - 1); pending_dev
+ * [n_games] (int32, start at 0) holds per game the first step not trained yet and is advanced by the call.  A game contributes its
+ * steps from pending up to its last episode end inside the newest window (the caller chains azul_discounted_returns backwards
+ * through the ring with the carry, so those steps' returns are exact).  index_dev receives flat indices slot * n_games + game (game by
+ * game, steps ascending), count_dev[0] their number, count_dev[1] ACCUMULATES the steps that had left the ring before their episode
+ * ended (zero it once); scratch_dev: int32 [3 n_games + ceil(n_games / 256)]. */
+int azul_select_episode_samples(const uint8_t *done_ring_dev, const int32_t *action_ring_dev, int window_steps, int ring_windows, int n_games,
+                                int64_t steps_played, int32_t *pending_dev, int32_t *index_dev, int32_t *count_dev, int32_t *scratch_dev,
+                                void *stream);
 /* discounted returns q[t] = r[t] + gamma * q[t+1] within episodes over a time-major window [n_steps][n_games]
  * (nn_runner.py:70-76); done[t][g] != 0 closes an episode at move t; carry_dev[n_games] (optional) chains windows. */
 int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, float *returns_dev, float *carry_dev,

@@ -126,11 +126,11 @@ def _nccl_worker(port, q):
     net = BatchedActorCritic(136, 180, 180).cuda()
     before = [p.detach().clone() for p in net.parameters()]
     learner = A2CLearner(net, distributed=True)
-    ro = PolicyRollout(net, n_games=G, window=32, persistent=True, opponent="random", kweights=learner.kweights())
+    ro = PolicyRollout(net, n_games=G, window=32, persistent=True, opponent="random", kweights=learner.kweights(), ring=3)
     for _ in range(2):
         tr = ro.run_window()
         ro.join()
-        out = learner.update_from_rollout(ro) if hasattr(learner, "update_from_rollout") else learner.update_from_windows(tr)
+        out = learner.update_from_rollout(ro)
     torch.cuda.synchronize()
     moved = any(not torch.equal(a, p.detach()) for a, p in zip(before, net.parameters()))
     q.put((ok_gather, float(out["samples"]), bool(np.isfinite(float(out["ac_loss"]))), moved, dist.get_backend()))

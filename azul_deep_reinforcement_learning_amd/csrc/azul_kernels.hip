@@ -490,15 +490,17 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
 {
     __shared__ u32 mt_lds[2][624];
     __shared__ double tab_lds[T_WORDS];
+    __shared__ double2 tabfs_lds[T_ROWS * T_BINADES];      // {Fr[J][b], S[J]}: both table values of a decision in one 16-byte read
     const u32 lane = wv::lane(), l = lane & 31u, half = lane >> 5;
     for (u32 i = lane; i < (u32)T_WORDS; i += 64u) tab_lds[i] = b.T[i];
+    for (u32 i = lane; i < (u32)(T_ROWS * T_BINADES); i += 64u) tabfs_lds[i] = make_double2(b.T[i], b.T[T_ROWS * T_BINADES + i / T_BINADES]);
     az2::lds_sync();
     const u32 gi = blockIdx.x * 2u + half;
     if (gi >= b.n) return;                               // odd batch: the last wave plays one game
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
     az2::K2 k;
     az2::k2_init(k);
-    az2::Tab2 tab = {tab_lds, tab_lds + T_ROWS * T_BINADES};
+    az2::Tab2 tab = {tab_lds, tab_lds + T_ROWS * T_BINADES, tabfs_lds};
     az2::G2 g;
     az2::g2_load(g, rec, l);
     az2::prime2(g, k);

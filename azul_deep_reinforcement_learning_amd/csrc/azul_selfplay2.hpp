@@ -116,6 +116,7 @@ struct G2 {
     u32 moves;
     i32 wc0, wc1, wi0, wi1;     // what-if cache (game_runner.py:48-50), see azul_core.hpp
     u32 over;
+    u32 B;                      // derived: sources holding tiles, hb(cs != 0) & 0x7fffffff (refreshed whenever cs changes)
 };
 
 AZ_FN u32 me2(const G2 &g) { return g.cur == 0u ? 1u : g.cur - 1u; }
@@ -147,6 +148,7 @@ AZ_FN void g2_load(G2 &g, const uint8_t *rec, u32 l)
     g.pscore = (i32)(int16_t)(w10 & 0xffffu);
     g.moves = w10 >> 16;
     g.wc0 = g.wc1 = 0; g.wi0 = g.wi1 = 0; g.over = 0;
+    g.B = hb(g.cs != 0u) & 0x7fffffffu;
 }
 
 AZ_FN void g2_store(const G2 &g, uint8_t *rec, u32 l)
@@ -287,7 +289,7 @@ struct Mask2 {
 AZ_FN void legal_mask2(const G2 &g, const K2 &k, Mask2 &out)
 {
     const u32 l = k.l;
-    u32 B = hb(g.cs != 0u) & 0x7fffffffu;
+    const u32 B = g.B;
     u32 me = me2(g);
     u32 mine = me ? g.cp1 : g.cp0;
     u32 pme = hb(mine != 0u) & 0x1ffffffu;
@@ -307,7 +309,7 @@ AZ_FN void legal_mask2(const G2 &g, const K2 &k, Mask2 &out)
 }
 
 // ---- RandomAgent: game_runner.py:87-97 + random.choices; azul_core.hpp's decomposition of the cumulative weights -------------
-struct Tab2 { const double *fr; const double *s; };      // LDS: Fr[31][8], S[31]
+struct Tab2 { const double *fr; const double *s; const double2 *fs; };      // LDS: Fr[31][8], S[31], and {Fr[J][b], S[J]} pairs (one 16-byte read)
 
 AZ_FN double tpat2(const Tab2 &t, u32 J, u32 m) { return (double)m + t.fr[8u * J + 31u - (u32)__builtin_clz(m)]; }
 AZ_FN double tseq2(const Tab2 &t, u32 J, u32 kk) { return kk <= J ? t.s[kk] : tpat2(t, J, kk - J); }
@@ -481,7 +483,18 @@ AZ_FN void count_score2(G2 &g, const K2 &k)
 
 // ---- new_round: azul.py:64-89 (deal_factories of azul_core.hpp, 32 lanes) ------------------------------------------------
 template <bool LID>
+AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k);
+
+template <bool LID>
 AZ_FN u32 new_round2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
+{
+    u32 st = deal2<LID>(g, r, margin, k);
+    g.B = hb(g.cs != 0u) & 0x7fffffffu;
+    return st;
+}
+
+template <bool LID>
+AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
 {
     const u32 l = k.l;
     g.cur = g.nfp;
@@ -712,21 +725,27 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     const u32 p1 = c0, p2 = p1 + c1, p3 = p2 + c2, p4 = p3 + c3, p5 = p4 + c4, L = p5 + c5;
     const bool nomove = (L == 0u) | (g.eog != 0u);        // ValueError in the reference (raised before random()) / a finished game handed in
     const u32 M = L - J, Mc = M ? M : 1u;
-    const double sJ = T.s[J < 31u ? J : 30u];
-    const double frv = T.fr[8u * (J < 31u ? J : 30u) + 31u - (u32)__builtin_clz(Mc)];
-    const double total = (M ? (double)M + frv : sJ) + 0.0;
-    if (AZ_UNLIKELY(wave_any(hard & !nomove))) {
-        if (hard & !nomove) { wa = rng2_u32(r, l); wb = rng2_u32(r, l); }
-    }
-    r.pos += (hard | nomove) ? 0u : 2u;
-    const double x = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0) * total;
+    const double2 fs = T.fs[8u * (J < 31u ? J : 30u) + 31u - (u32)__builtin_clz(Mc)];      // {Fr[J][ilog2 M], S[J]}
+    const double sJ = fs.y;
+    const double total = (M ? (double)M + fs.x : sJ) + 0.0;
     // pattern moves: cum(J + mm) = mm + Fr[J][ilog2 mm]; away from integer boundaries floor(x - S[J]) + 1 IS the ordinal
-    const double d = x - sJ;
-    const u32 fl = (u32)d;
-    const double fr = d - (double)fl;
+    double x = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0) * total;
+    double d = x - sJ;
+    u32 fl = (u32)d;
+    double fr = d - (double)fl;
     u32 kg = J + fl + 1u;
-    const bool edge = (x < sJ) | !(fr > 1e-9 && fr < 1.0 - 1e-9) | (fl + 1u > M);
-    if (AZ_UNLIKELY(wave_any(edge & !nomove))) {
+    bool edge = (x < sJ) | !(fr > 1e-9 && fr < 1.0 - 1e-9) | (fl + 1u > M);
+    r.pos += (hard | nomove) ? 0u : 2u;
+    // ONE test for everything unusual about this decision (a random() that crosses a regeneration, a draw at a boundary of the
+    // cumulative weights, nothing legal); the stuck slot itself is restarted further down
+    if (AZ_UNLIKELY(wave_any((hard | edge) & !nomove))) {
+        if (hard & !nomove) {
+            wa = rng2_u32(r, l); wb = rng2_u32(r, l);
+            x = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0) * total;
+            d = x - sJ; fl = (u32)d; fr = d - (double)fl;
+            kg = J + fl + 1u;
+            edge = (x < sJ) | !(fr > 1e-9 && fr < 1.0 - 1e-9) | (fl + 1u > M);
+        }
         if (edge & !nomove) kg = sample_slow2(T, x, sJ, J, M, L);
     }
     // kg-th legal action: every lane ranks its own six actions, the one with rank kg answers
@@ -775,7 +794,8 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
         const i32 wi = clamp0((me ? g.score1 : g.score0) + floor_penalty(me ? g.floor1 : g.floor0) + wc);
         g.wc0 = me ? g.wc0 : wc; g.wc1 = me ? wc : g.wc1;
         g.wi0 = me ? g.wi0 : wi; g.wi1 = me ? wi : g.wi1;
-        const bool eor = (hb(g.cs != 0u) & 0x7fffffffu) == 0u;   // :306 is_end_of_round (the token counts)
+        g.B = hb(g.cs != 0u) & 0x7fffffffu;                      // the sources after the move (next move's mask reads it)
+        const bool eor = g.B == 0u;                              // :306 is_end_of_round (the token counts)
         g.cur = eor ? g.cur : (g.cur < 2u ? g.cur + 1u : 1u);    // :313 next_player
         u32 st = ST_OK;
         AZ_STAMP(SEG_AFTERMOVE);

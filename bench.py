@@ -48,10 +48,25 @@ def parse():
 
 
 def _host_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a 1-GPU box exposes every core of
+    the host in the mask but grants a share of them)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(-(-float(quota) // period))))
+            break
+        except Exception:
+            continue
+    return n
 
 
 def cpu_baseline(games, seed_base):
@@ -59,7 +74,8 @@ def cpu_baseline(games, seed_base):
     (i) all host cores this process may use, one game stream per thread at a time, (ii) one core."""
     from oracle import oracle as oz
     cores = int(os.environ.get("AZUL_CPU_THREADS", _host_cores()))
-    streams, steps = games, 4000                         # every game of the workload, ~16 M moves on all cores
+    streams = games                                      # every game of the workload
+    steps = max(1000, min(16000, 250 * cores))           # ~1 M moves per core, at least ~4 M in total
     oz.bench_selfplay(seed_base, min(streams, 64), 200, cores)           # warm the pages
     t0 = time.perf_counter()
     moves, _ = oz.bench_selfplay(seed_base, streams, steps, cores)

@@ -26,6 +26,18 @@ __global__ void calib_write_u8_rows(unsigned char *dst, size_t n_rows)
     }
 }
 
+__global__ void calib_write_u8_rows192(unsigned char *dst, size_t n_rows)
+{
+    // the two-games-per-wave kernel's mask write-out: rows at a 192-byte pitch, a wave writes TWO adjacent rows with six
+    // byte-per-lane stores (lanes 0..31 -> bytes 32 w .. 32 w + 31 of the first row, lanes 32..63 -> of the second)
+    size_t pair = (size_t)blockIdx.x;
+    unsigned l = threadIdx.x & 31u, half = threadIdx.x >> 5;
+    for (; 2 * pair + 1 < n_rows; pair += gridDim.x) {
+        unsigned char *p = dst + (2 * pair + half) * 192 + l;
+        for (int w = 0; w < 6; w++) p[32 * w] = (unsigned char)l;
+    }
+}
+
 __global__ void calib_write_u32(unsigned *dst, size_t n_words)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
@@ -44,9 +56,11 @@ int main()
     for (int rep = 0; rep < 3; rep++) {
         calib_read_u32<<<4096, 256>>>(a, sink, bytes / 4);
         calib_write_u8_rows<<<8192, 64>>>(b, rows);
+        calib_write_u8_rows192<<<8192, 64>>>(b, bytes / 192);
         calib_write_u32<<<4096, 256>>>((unsigned *)b, bytes / 4);
     }
     hipDeviceSynchronize();
-    printf("calib: read_u32 bytes=%zu write_u8_rows bytes=%zu write_u32 bytes=%zu\n", bytes, rows * 180, bytes);
+    printf("calib: read_u32 bytes=%zu write_u8_rows bytes=%zu write_u8_rows192 bytes=%zu write_u32 bytes=%zu\n", bytes, rows * 180,
+           (bytes / 192 / 2) * 2 * 192, bytes);
     return 0;
 }

@@ -495,7 +495,12 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
     for (u32 i = lane; i < (u32)T_WORDS; i += 64u) tab_lds[i] = b.T[i];
     for (u32 i = lane; i < (u32)(T_ROWS * T_BINADES); i += 64u) tabfs_lds[i] = make_double2(b.T[i], b.T[T_ROWS * T_BINADES + i / T_BINADES]);
     az2::lds_sync();
-    const u32 gi = blockIdx.x * 2u + half;
+    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b runs on XCD b % 8.
+    // Give every XCD a CONTIGUOUS range of games: the waves that share a cache line of a time-major stream (32 games of an int32
+    // stream, 2 / 3 of a mask row pair) then write it through ONE L2, which merges them into whole-line HBM writes.
+    const u32 nb = gridDim.x, xcd = blockIdx.x & 7u, q8 = nb >> 3, rem = nb & 7u;
+    const u32 wave_id = xcd * q8 + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+    const u32 gi = wave_id * 2u + half;
     if (gi >= b.n) return;                               // odd batch: the last wave plays one game
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
     az2::K2 k;

@@ -6,7 +6,7 @@ TAG=${1:-prof}
 R=$PWD/gpurun_out/$TAG
 mkdir -p $R
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras"   # every step = one launch = 512 moves x 4096 games
+BENCH="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras"   # the driver's command (every step = one launch = 512 moves x 4096 games)
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $R/bench.json 2> $R/bench.err
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats -- $BENCH > $R/stats.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/pmc_fetch -- $BENCH > $R/pmc_fetch.log 2>&1

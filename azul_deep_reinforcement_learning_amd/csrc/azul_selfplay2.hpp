@@ -727,7 +727,9 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     const u32 M = L - J, Mc = M ? M : 1u;
     const double2 fs = T.fs[8u * (J < 31u ? J : 30u) + 31u - (u32)__builtin_clz(Mc)];      // {Fr[J][ilog2 M], S[J]}
     const double sJ = fs.y;
-    const double total = (M ? (double)M + fs.x : sJ) + 0.0;
+    // cum(J + M) = M + Fr[J][ilog2 M] (M >= 1), S[J] (M == 0); written as ONE sum so that both table values are used
+    // unconditionally (a conditional use makes the compiler split the 16-byte read and branch around half of it)
+    const double total = ((double)M + (M ? fs.x : sJ)) + 0.0;
     // pattern moves: cum(J + mm) = mm + Fr[J][ilog2 mm]; away from integer boundaries floor(x - S[J]) + 1 IS the ordinal
     double x = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0) * total;
     double d = x - sJ;
@@ -748,20 +750,17 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
         }
         if (edge & !nomove) kg = sample_slow2(T, x, sJ, J, M, L);
     }
-    // kg-th legal action: every lane ranks its own six actions, the one with rank kg answers
-    const u32 want = kg - 1u, below = (1u << l) - 1u;
-    const bool h0 = (m.bit[0] != 0u) & (__popc(m.m[0] & below) == want);
-    const bool h1 = (m.bit[1] != 0u) & (__popc(m.m[1] & below) + p1 == want);
-    const bool h2 = (m.bit[2] != 0u) & (__popc(m.m[2] & below) + p2 == want);
-    const bool h3 = (m.bit[3] != 0u) & (__popc(m.m[3] & below) + p3 == want);
-    const bool h4 = (m.bit[4] != 0u) & (__popc(m.m[4] & below) + p4 == want);
-    const bool h5 = (m.bit[5] != 0u) & (__popc(m.m[5] & below) + p5 == want);
-    // (at most one word hits in a lane; OR of masked values rather than a select chain, which the compiler would turn into a
-    // select of ADDRESSES and with it push the whole constant table into scratch memory)
-    const u32 mine = (h0 ? k.acode[0] : 0u) | (h1 ? k.acode[1] : 0u) | (h2 ? k.acode[2] : 0u) | (h3 ? k.acode[3] : 0u) | (h4 ? k.acode[4] : 0u) |
-                     (h5 ? k.acode[5] : 0u);
-    const u32 who = hb(h0 | h1 | h2 | h3 | h4 | h5);
-    const u32 code = hbcast(mine, (u32)__builtin_ctz(who | 0x80000000u));
+    // kg-th legal action: its mask word from the prefix counts (half-uniform compares), then ONE rank test per lane
+    const u32 want = kg - 1u;
+    const bool g1 = want >= p1, g2 = want >= p2, g3 = want >= p3, g4 = want >= p4, g5 = want >= p5;
+    const u32 mword = g5 ? m.m[5] : g4 ? m.m[4] : g3 ? m.m[3] : g2 ? m.m[2] : g1 ? m.m[1] : m.m[0];
+    const u32 base = g5 ? p5 : g4 ? p4 : g3 ? p3 : g2 ? p2 : g1 ? p1 : 0u;
+    // (masked sums, not a select chain over the constant table: see the note at the address-select pitfall above)
+    const u32 mycode = (g5 ? k.acode[5] : 0u) | ((g4 & !g5) ? k.acode[4] : 0u) | ((g3 & !g4) ? k.acode[3] : 0u) | ((g2 & !g3) ? k.acode[2] : 0u) |
+                       ((g1 & !g2) ? k.acode[1] : 0u) | (!g1 ? k.acode[0] : 0u);
+    const bool hit = (((mword >> l) & 1u) != 0u) & ((u32)__popc(mword & ((1u << l) - 1u)) == want - base);
+    const u32 who = hb(hit);
+    const u32 code = hbcast(mycode, (u32)__builtin_ctz(who | 0x80000000u));
     const i32 a = (i32)(code >> 17);
     AZ_STAMP(SEG_SAMPLE);
 

@@ -117,6 +117,7 @@ struct G2 {
     i32 wc0, wc1, wi0, wi1;     // what-if cache (game_runner.py:48-50), see azul_core.hpp
     u32 over;
     u32 B;                      // derived: sources holding tiles, hb(cs != 0) & 0x7fffffff (refreshed whenever cs changes)
+    u32 ok0, ok1;               // derived: the players' "row r accepts colour c" boards (bit 5r + c), see ok_board2
 };
 
 AZ_FN u32 me2(const G2 &g) { return g.cur == 0u ? 1u : g.cur - 1u; }
@@ -286,20 +287,24 @@ struct Mask2 {
     u32 B;           // sources holding tiles (31 bits; bit 30 = the token)
 };
 
-AZ_FN void legal_mask2(const G2 &g, const K2 &k, Mask2 &out)
+// "row r accepts colour c" (azul.py:171-175) for one player as a 25-bit board: no OTHER colour lies on the row and the wall cell is
+// free.  Walls only change at scoring and a move changes ONE row of the mover (afterwards that row holds the moved colour only), so
+// the boards are kept in the game state: rebuilt here after loading / scoring / a reset, patched arithmetically by do_move2.
+AZ_FN u32 ok_board2(u32 cp, u32 wall, const K2 &k)
 {
     const u32 l = k.l;
-    const u32 B = g.B;
-    u32 me = me2(g);
-    u32 mine = me ? g.cp1 : g.cp0;
-    u32 pme = hb(mine != 0u) & 0x1ffffffu;
-    u32 wl = me ? g.wall1 : g.wall0;
-    // "row r accepts colour c": no OTHER colour lies on the row (azul.py:172) and the wall cell is free (:174)
+    u32 pme = hb(cp != 0u) & 0x1ffffffu;
     u32 rb = (pme >> (k.prow * 5u)) & 31u;
     u32 own = (rb >> k.pcol) & 1u;
     bool alone = (rb == 0u) | (((rb & (rb - 1u)) == 0u) & (own != 0u));
-    bool free_ = ((wl >> l) & 1u) == 0u;
-    u32 ok = (hb(alone & free_ & (l < 25u)) & 0x1ffffffu) | 0x80000000u;
+    bool free_ = ((wall >> l) & 1u) == 0u;
+    return hb(alone & free_ & (l < 25u)) & 0x1ffffffu;
+}
+
+AZ_FN void legal_mask2(const G2 &g, const K2 &k, Mask2 &out)
+{
+    const u32 B = g.B;
+    const u32 ok = (me2(g) ? g.ok1 : g.ok0) | 0x80000000u;      // bit 31: the floor "row" accepts everything
     out.B = B;
 #pragma unroll
     for (u32 w = 0; w < 6u; w++) {
@@ -370,6 +375,13 @@ AZ_FN bool do_move2(G2 &g, u32 code, u32 B /* sources before the move */, u32 l)
     mine = ((l == cell) & (row != 0u)) ? newv : mine;
     g.cp0 = me ? g.cp0 : mine;
     g.cp1 = me ? mine : g.cp1;
+    {   // the row now holds colour c only (the move was legal: the row was empty or held c, the wall cell is free)
+        const u32 sh = 5u * ((row ? row : 1u) - 1u);
+        u32 okm = me ? g.ok1 : g.ok0;
+        okm = row ? ((okm & ~(31u << sh)) | (1u << (sh + c))) : okm;
+        g.ok0 = me ? g.ok0 : okm;
+        g.ok1 = me ? okm : g.ok1;
+    }
     fl += spill;                                                       // :154 / :159
     fl = fl < 7u ? fl : 7u;
     g.floor0 = me ? g.floor0 : fl;
@@ -427,6 +439,8 @@ AZ_FN void prime2(G2 &g, const K2 &k)
     g.wc0 = wall_points2(g.wall0, full_lines2(g.cp0, k), k);
     g.wc1 = wall_points2(g.wall1, full_lines2(g.cp1, k), k);
     whatif_scores2(g);
+    g.ok0 = ok_board2(g.cp0, g.wall0, k);
+    g.ok1 = ok_board2(g.cp1, g.wall1, k);
 }
 
 // Σ_r r * [line (r, c) is full] for the five colours, as the byte vector the lid receives (azul.py:220-222)
@@ -479,6 +493,8 @@ AZ_FN void count_score2(G2 &g, const K2 &k)
     g.fpen = ((u32)fp0 & 0xffffu) | (((u32)fp1 & 0xffffu) << 16);
     g.wc0 = g.wc1 = 0; g.wi0 = g.score0; g.wi1 = g.score1;
     g.over = (any_row_full(g.wall0) | any_row_full(g.wall1)) ? 1u : 0u;
+    g.ok0 = ok_board2(g.cp0, g.wall0, k);                // walls and lines changed
+    g.ok1 = ok_board2(g.cp1, g.wall1, k);
 }
 
 // ---- new_round: azul.py:64-89 (deal_factories of azul_core.hpp, 32 lanes) ------------------------------------------------
@@ -613,6 +629,7 @@ AZ_FN u32 episode_reset2(G2 &g, u32 first_player, Rng2 &r, u64 margin, const K2 
     g.cur = 0; g.eog = 0; g.turn = 0;
     g.fps = 0; g.fpen = 0; g.maxc = 0; g.compl_ = 0;
     g.wc0 = g.wc1 = 0; g.wi0 = g.wi1 = 0; g.over = 0;
+    g.ok0 = g.ok1 = 0x1ffffffu;                          // empty lines, empty walls: every row accepts every colour
     if (first_player == 0u) g.nfp = 1u + rng2_below(r, 2u, 2u, k.l);     // random.choice([1, 2]) (:37)
     else g.nfp = first_player;
     if (LID) { g.box = 0x1414141414ull; g.lid = 0; }

@@ -277,7 +277,7 @@ class BatchedAzul:
         L.check(L.lib.azul_batch_selfplay_strided(self._h, int(n_steps), _ptr(mask), int(pitch), _ptr(maskbits), _ptr(action), _ptr(reward),
                                                   _ptr(done), _ptr(packed), _ptr(records), self._stream()))
 
-    def alloc_trajectory(self, n_steps, with_records=False, packed_mask=False, mask_pitch=None):
+    def alloc_trajectory(self, n_steps, with_records=False, packed_mask=False, mask_pitch=None, mask_bits=None):
         """Trajectory buffers [n_steps][N]....  With `packed_mask` also the bit-packed mask `maskbits` (int64 [T][N][3])
         and the compact per-move record `packed` (int32 [T][N]: action | done << 8 | reward << 16) -- the two
         contiguous arrays the multi-GPU all-gather ships.  `mask_pitch` (e.g. 192): the byte mask is a [T][N][180] view of a
@@ -291,7 +291,8 @@ class BatchedAzul:
              "reward": self._new((n_steps, n), torch.int32),
              "done": self._new((n_steps, n), torch.uint8)}
         if packed_mask:
-            t["maskbits"] = torch.zeros((n_steps, n, 3), dtype=torch.int64, device=self.device)
+            if mask_bits is None or mask_bits:          # mask_bits=False: only the compact record (what the all-gather ships by default)
+                t["maskbits"] = torch.zeros((n_steps, n, 3), dtype=torch.int64, device=self.device)
             t["packed"] = torch.zeros((n_steps, n), dtype=torch.int32, device=self.device)
         if with_records:
             t["records"] = self._new((n_steps, n, L.RECORD_BYTES), torch.uint8)

@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
 // Flat self-play, TWO GAMES PER WAVEFRONT (azul_selfplay2.hpp): grid = ceil(N / 2) one-wave workgroups; lanes 0..31 own game
 // 2 b, lanes 32..63 game 2 b + 1.  Same semantics and outputs as azul_selfplay_kernel; `mask_stride` is the byte distance between
 // the mask rows of consecutive games (180, or 192 to keep every row 64-byte aligned).
-template <bool LID, int OUT, bool PAD>
+template <bool LID, int OUT, bool PAD, bool BITS>
 __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs t, u32 mask_stride)
 {
     __shared__ u32 mt_lds[2][624];
@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
 #endif
 #pragma unroll 1
     for (int s = 0; s < t.n_steps; s++) {
-        u32 f = az2::selfplay_step2<LID, OUT, PAD>(g, b.rules.first_player, k, r, tab, margin, cnt, o, pp);
+        u32 f = az2::selfplay_step2<LID, OUT, PAD, BITS>(g, b.rules.first_player, k, r, tab, margin, cnt, o, pp);
         if (f & 0x100u) break;      // rule error (box empty): leave the game as it is
         o.e += b.n;
     }
@@ -1176,7 +1176,8 @@ int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev,
         return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: the one-game-per-wave kernel writes dense 180-byte mask rows");
     TrajArgs t = {n_steps, mask_dev, (u64 *)maskbits_dev, action_dev, reward_dev, done_dev, rec_dev, packed_dev};
     const bool none = !mask_dev && !maskbits_dev && !action_dev && !reward_dev && !done_dev && !rec_dev && !packed_dev;
-    const bool full = mask_dev && maskbits_dev && action_dev && reward_dev && done_dev && packed_dev && !rec_dev;
+    const bool core = mask_dev && action_dev && reward_dev && done_dev && packed_dev && !rec_dev;     // + maskbits_dev or not
+    const bool full = core && maskbits_dev;
     const dim3 grid(version == 1 ? b->d.n : (b->d.n + 1u) / 2u), block(64);
     const hipStream_t st = (hipStream_t)stream;
     const u32 ms = (u32)mask_row_bytes;
@@ -1186,10 +1187,11 @@ int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev,
             else if (full) hipLaunchKernelGGL((azul_selfplay_kernel<LID, 1>), grid, block, 0, st, b->d, t); \
             else hipLaunchKernelGGL((azul_selfplay_kernel<LID, 2>), grid, block, 0, st, b->d, t); \
         } else { \
-            if (none) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 0, false>), grid, block, 0, st, b->d, t, ms); \
-            else if (full && ms >= 192u) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true>), grid, block, 0, st, b->d, t, ms); \
-            else if (full) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, false>), grid, block, 0, st, b->d, t, ms); \
-            else hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 2, false>), grid, block, 0, st, b->d, t, ms); \
+            if (none) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 0, false, false>), grid, block, 0, st, b->d, t, ms); \
+            else if (full && ms >= 192u) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true, true>), grid, block, 0, st, b->d, t, ms); \
+            else if (core && ms >= 192u) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true, false>), grid, block, 0, st, b->d, t, ms); \
+            else if (full) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, false, true>), grid, block, 0, st, b->d, t, ms); \
+            else hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 2, false, false>), grid, block, 0, st, b->d, t, ms); \
         } } while (0)
     // inside a timed region the first AZ_TIMED_PAIRS launches are bracketed by their own event pair (the kernel's duration,
     // not the distance between launches)

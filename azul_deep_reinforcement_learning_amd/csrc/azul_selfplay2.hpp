@@ -697,7 +697,7 @@ struct Counters2 { u64 *episodes; u32 *stuck; double *stat_sum; };
 // Control flow: two waves per SIMD cannot hide a taken branch's instruction refetch, so the common move is ONE fall-through path;
 // every rare event (window refill across a regeneration, stuck slot, sampler boundary case, end of round, end of game) is tested
 // for the whole wave with one scalar branch (wave_any, hinted unlikely -> placed out of line) and handled per half inside.
-template <bool LID, int OUT, bool PAD>
+template <bool LID, int OUT, bool PAD, bool BITS>
 AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Tab2 &T, u64 margin, const Counters2 &cnt, const Out2 &o,
                         SegProf *prof_ = nullptr)
 {
@@ -728,7 +728,7 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
         if (PAD) row[160] = (uint8_t)m.bit[5];
         else if (l < 20u) row[160] = (uint8_t)m.bit[5];
     }
-    if (OUT == 1 || (OUT == 2 && o.maskbits)) {
+    if ((OUT == 1 && BITS) || (OUT == 2 && o.maskbits)) {
         // every lane stores (lanes 3.. repeat lane 2's address and data): no exec masking
         const u32 q = l < 2u ? l : 2u;
         u32 lo = q == 0u ? m.m[0] : (q == 1u ? m.m[2] : m.m[4]), hi = q == 0u ? m.m[1] : (q == 1u ? m.m[3] : m.m[5]);

@@ -225,7 +225,10 @@ def main():
     env.seed(base)
     env.runner_init()                                    # GameRunner()
     env.runner_init()                                    # reset()   (DESIGN.md "stream semantics")
-    bufs = [env.alloc_trajectory(T, packed_mask=True, mask_pitch=args.mask_pitch) for _ in range(2)]
+    # per move: the legal mask (bytes), action, reward, done and the compact record the multi-GPU gather ships; the bit-packed mask
+    # is only produced when it is shipped (--gather-masks) or by the one-game-per-wave kernel, whose full variant always writes it
+    want_bits = args.gather_masks or os.environ.get("AZUL_SELFPLAY_KERNEL", "2") == "1"
+    bufs = [env.alloc_trajectory(T, packed_mask=True, mask_pitch=args.mask_pitch, mask_bits=want_bits) for _ in range(2)]
     gather = TrajectoryGather(world, dev, with_masks=args.gather_masks) if (world > 1 and not args.no_gather) else None
 
     def run(n_launches):
@@ -233,7 +236,7 @@ def main():
             b = bufs[i & 1]
             if gather is not None:
                 gather.wait_buffer_free(i & 1)           # the all-gather that last read this buffer has finished
-            env.selfplay(T, b["mask"], b["action"], b["reward"], b["done"], maskbits=b["maskbits"], packed=b["packed"])
+            env.selfplay(T, b["mask"], b["action"], b["reward"], b["done"], maskbits=b.get("maskbits"), packed=b["packed"])
             if gather is not None:
                 gather.launch(i & 1, b, T)               # side stream, overlaps the next launch
         if gather is not None:

@@ -32,7 +32,11 @@ AZ_FN u32 hsel(u64 b) { return upper() ? (u32)(b >> 32) : (u32)b; }
 // the half's 32 lanes as a bitboard
 AZ_FN u32 hb(bool p) { return hsel(__builtin_amdgcn_ballot_w64(p)); }
 // value of lane `idx` of MY half, idx per lane (a gather through the LDS crossbar; idx in 0..31)
+#if defined(AZ2_EXPERIMENT_NO_LDS)
+AZ_FN u32 hread(u32 v, u32 idx) { return v + (idx & 0u); }     // TIMING EXPERIMENT ONLY (wrong results): no LDS round trips
+#else
 AZ_FN u32 hread(u32 v, u32 idx) { return (u32)__builtin_amdgcn_ds_bpermute((int)((idx << 2) | ((wlane() & 32u) << 2)), (int)v); }
+#endif
 // the same for a HALF-UNIFORM idx.  (Measured: the LDS crossbar beats a v_readlane pair per half + select -- two instructions and one
 // wait against seven instructions with SGPR hazards: 1.125 vs 1.195 ms per 512-move launch.)
 AZ_FN u32 hbcast(u32 v, u32 idx) { return hread(v, idx); }
@@ -358,14 +362,19 @@ AZ_FN bool do_move2(G2 &g, u32 code, u32 B /* sources before the move */, u32 l)
     const u32 src = code & 31u, db = (code >> 5) & 31u, c = (code >> 10) & 7u, row = (code >> 13) & 7u;
     const bool from_display = ((code >> 16) & 1u) != 0u;
     u32 n = hbcast(g.cs, src);                                         // :127 / :136
+#if defined(AZ2_EXPERIMENT_EXTRA_LDS)
+    n = hread(n, l);                                                   // TIMING EXPERIMENT: one more dependent LDS round trip (identity)
+#endif
+#if defined(AZ2_EXPERIMENT_EXTRA_BRANCH)
+    asm volatile("s_branch 1f\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n 1:\n s_branch 2f\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n 2:\n s_branch 3f\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n 3:\n s_branch 4f\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n 4:" ::: "memory");   // TIMING EXPERIMENT: four taken branches
+#endif
     bool token = (!from_display) & (((B >> 30) & 1u) != 0u);           // :140
     u32 moved = hread(g.cs, l - 25u + db);                             // :131
     bool centre = (l >= 25u) & (l < 30u) & (l != 25u + c) & from_display;
     bool gone = ((l >= db) & (l < db + 5u) & from_display) | (l == src) | ((l == 30u) & token);   // :129,:133,:138,:141
     g.cs = gone ? 0u : (centre ? g.cs + moved : g.cs);
     g.nfp = token ? g.cur : g.nfp;                                     // :142
-    u32 fl = (me ? g.floor1 : g.floor0) + (token ? 1u : 0u);           // :143
-    fl = fl < 7u ? fl : 7u;
+    u32 fl = (me ? g.floor1 : g.floor0) + (token ? 1u : 0u);           // :143 (the cap of :120-123 is applied once, below: it is monotone)
     u32 cell = 5u * ((row ? row : 1u) - 1u) + c;
     u32 mine = me ? g.cp1 : g.cp0;
     u32 old = hbcast(mine, cell);

@@ -16,62 +16,75 @@ from .codec import nn_deserialize, nn_serialize
 from .records import STAT_KEYS
 
 
+class GameStatistics:
+    """What GameRunner.game_statistics collects (game_runner.py:10-22): the ten get_statistics() values of every finished game
+    are buffered per key; get_stats() folds the buffered games into ONE mean per key, appends it to `statistics` and empties
+    the buffer.  (The batched trainer gets the same means from sums the kernels accumulate on the device.)"""
+
+    def __init__(self):
+        self._pending = {key: [] for key in STAT_KEYS}
+        self.statistics = {key: np.empty(0) for key in STAT_KEYS}
+
+    @property
+    def statisticsBuffer(self):
+        return {key: np.asarray(vals, dtype=float) for key, vals in self._pending.items()}
+
+    def update(self, statistics):
+        for key, value in statistics.items():
+            self._pending[key].append(value)
+
+    def get_stats(self):
+        for key, vals in self._pending.items():
+            if vals:
+                self.statistics[key] = np.append(self.statistics[key], float(np.mean(vals)))
+                vals.clear()
+        return self.statistics
+
+
 class GameRunner:
-    class GameStatistics:
-        # game_runner.py:10-22
-        def __init__(self):
-            self.statisticsBuffer = {key: np.empty(0) for key in STAT_KEYS}
-            self.statistics = {key: np.empty(0) for key in STAT_KEYS}
-
-        def update(self, statistics):
-            for stat in statistics:
-                self.statisticsBuffer[stat] = np.append(self.statisticsBuffer[stat], statistics[stat])
-
-        def get_stats(self):
-            for stat in self.statistics:
-                if len(self.statisticsBuffer[stat]) > 0:
-                    self.statistics[stat] = np.append(self.statistics[stat], self.statisticsBuffer[stat].mean())
-                    self.statisticsBuffer[stat] = np.empty(0)
-            return self.statistics
+    GameStatistics = GameStatistics          # the reference nests the class (game_runner.py:10)
 
     def __init__(self, opponent=None, rules={"first_player": "Random", "tile_pool": "Lid"}):
-        self.game = Azul(rules=rules)
         self.rules = rules
-        self.game_statistics = GameRunner.GameStatistics()
-        self.opponent = opponent if opponent is not None else RandomAgent()
-        self.game.new_round()
+        self.game_statistics = GameStatistics()
+        self.opponent = RandomAgent() if opponent is None else opponent
         self.player_score = 0
         self.move_counter = 0
+        self.game = Azul(rules=rules)
+        self.game.new_round()
 
     def _device_opponent(self):
         return type(self.opponent) is RandomAgent
 
     def opponent_move(self):
-        # game_runner.py:37-42
-        state = self.get_state(perspective=self.game.current_player - 1)
-        valid_moves = torch.from_numpy(self.get_valid_moves().reshape(1, 180))
-        action = self.opponent.get_a_output(state, valid_moves)
-        self.game.step(*nn_deserialize(action))
+        """One move of `self.opponent` for the player to move (game_runner.py:37-42), policy evaluated on the host."""
+        seat = self.game.current_player - 1
+        legal = torch.from_numpy(self.get_valid_moves()[None, :])
+        choice = self.opponent.get_a_output(self.get_state(perspective=seat), legal)
+        self.game.step(*nn_deserialize(choice))
         self.move_counter += 1
+
+    def _raise_for(self, status):
+        if status in (L.ILLEGAL_MOVE, L.BAD_ACTION):
+            raise IllegalMove
+        if status == L.GAME_ENDED:
+            raise GameEnded
+        if status == L.STUCK:
+            raise ValueError("Total of weights must be greater than zero")   # RandomAgent with no legal move
 
     def step(self, i):
         if self._device_opponent():
-            reward, done, st = self.game._run("op_runner_step", int(i), draws=True, runner=self)
-            if st == L.ILLEGAL_MOVE or st == L.BAD_ACTION:
-                raise IllegalMove
-            if st == L.GAME_ENDED:
-                raise GameEnded
-            if st == L.STUCK:
-                raise ValueError("Total of weights must be greater than zero")   # RandomAgent with no legal move
+            # the agent's move, the RandomAgent's replies, the shaped reward and `done` in ONE launch (game_runner.py:43-55)
+            reward, done, status = self.game._run("op_runner_step", int(i), draws=True, runner=self)
+            self._raise_for(status)
         else:
-            # game_runner.py:43-52 with the opponent policy evaluated on the host
             self.game.step(*nn_deserialize(i))
             self.move_counter += 1
-            while (self.game.current_player != 1 or np.count_nonzero(self.get_valid_moves()) < 2) and not self.game.is_end_of_game():
+            # the opponent plays until it is player 1's turn with a real choice, or the game is over (game_runner.py:46-47)
+            while not self.game.is_end_of_game() and (self.game.current_player != 1 or np.count_nonzero(self.get_valid_moves()) < 2):
                 self.opponent_move()
-            new_player_score = self.game._run("op_potential", mutates=False)
-            reward = new_player_score - self.player_score
-            self.player_score = new_player_score
+            potential = self.game._run("op_potential", mutates=False)         # deepcopy + count_score, score[0] - score[1] (:48-50)
+            reward, self.player_score = potential - self.player_score, potential
             done = self.game.is_end_of_game()
         if done:
             self.game_statistics.update(self.game.get_statistics())      # game_runner.py:53-54
@@ -84,11 +97,11 @@ class GameRunner:
         return check_all_valid(self.game)
 
     def reset(self):
-        # game_runner.py:76-85
-        self.game = Azul(rules=self.rules)
-        self.game.new_round()
+        """A fresh game, first round dealt, the opponent opening if it starts (game_runner.py:76-85)."""
         self.player_score = 0
         self.move_counter = 0
+        self.game = Azul(rules=self.rules)
+        self.game.new_round()
         while self.game.current_player != 1:
             self.opponent_move()
 

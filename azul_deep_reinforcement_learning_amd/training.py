@@ -119,7 +119,33 @@ class BatchedTrainer:
                         [last["batch"]] + [last[k] for k in AGENT_STAT_KEYS] + [last[k] for k in STAT_KEYS])
             if net_name is not None and self.batch % checkpoint_every == 0:                # nn_runner.py:83-84
                 self.save_checkpoint(os.path.join(self.results_dir, net_name + ".pt"))
+                self.export_mx(os.path.join(self.results_dir, net_name + ".mx"))            # the reference's file name and content
         return last
+
+    # ---- the reference's own network file ---------------------------------------------------------------
+    def export_mx(self, path, module_factory=None):
+        """The file the reference writes and reads: NNRunner.train does torch.save(agent.ac_net, "/results/<name>.mx") (nn_runner.py:83-84)
+        and Agent(base_net_file=...) torch.load()s that MODULE (agent.py:36).  `module_factory` builds the module to pickle -- pass the
+        reference's azulnet.model.ActorCritic to get a file the unchanged reference loads; default: this package's BatchedActorCritic
+        (same parameter names, so its state_dict loads into either class).  The weights are copied to the CPU first."""
+        from .policy import BatchedActorCritic
+        pol = self.rollout.policy
+        self.rollout.synchronize()
+        mod = (module_factory or (lambda: BatchedActorCritic(pol.critic_linear1.in_features, pol.actor_linear2.out_features,
+                                                             pol.critic_linear1.out_features)))()
+        mod.load_state_dict({k: v.detach().cpu() for k, v in pol.state_dict().items()})
+        torch.save(mod, path)
+        return path
+
+    def import_mx(self, path):
+        """Continue from a reference network file: a pickled module (anything with state_dict(): the reference's ActorCritic, loadable
+        where its class is importable) or a plain state_dict, with the reference's parameter names."""
+        obj = torch.load(path, map_location="cpu", weights_only=False)
+        sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
+        self.rollout.synchronize()
+        self.rollout.policy.load_state_dict({k: v.to(self.rollout.device) for k, v in sd.items()})
+        self.learner.sync_from_module()                  # the flat k-major master copy the kernels read
+        self.rollout.refresh_weights()
 
     # ---- checkpoints ---------------------------------------------------------------------------------
     def save_checkpoint(self, path):

@@ -101,6 +101,11 @@ def test_trainer_csv_log_and_resume(tmp_path, golden_dir, use_graph, parts, pers
     sd = torch.load(ck, map_location="cpu", weights_only=False)["policy"]
     assert sorted(sd) == sorted(["critic_linear1.weight", "critic_linear1.bias", "critic_linear2.weight", "critic_linear2.bias",
                                  "actor_linear1.weight", "actor_linear1.bias", "actor_linear2.weight", "actor_linear2.bias"])
+    # the reference's own network file: a pickled module under <name>.mx (nn_runner.py:83-84) that Agent(base_net_file=...) torch.load()s
+    mx = os.path.join(str(tmp_path), "blue.mx")
+    assert os.path.exists(mx)
+    mod = torch.load(mx, map_location="cpu", weights_only=False)
+    assert sorted(mod.state_dict()) == sorted(sd) and all(torch.equal(mod.state_dict()[k2], sd[k2].cpu()) for k2 in sd)
     # resume: a fresh trainer (other seeds, other weights) restored from the file replays the NEXT window bit for bit
     nxt = tr.rollout.run_window()
     tr.rollout.synchronize()
@@ -114,6 +119,14 @@ def test_trainer_csv_log_and_resume(tmp_path, golden_dir, use_graph, parts, pers
     for p in range(parts):
         for k in ("obs", "mask", "player", "action", "reward", "done", "value", "log_prob", "entropy", "returns"):
             assert torch.equal(want[p][k], got[p][k]), (p, k)
+    # ... and a trainer can continue from the reference's file alone (weights only)
+    torch.manual_seed(7)
+    tr3 = BatchedTrainer(BatchedActorCritic(136, 180, 180), seed_base=77, **kw)
+    tr3.import_mx(mx)
+    for (n3, p3), (_, p1) in zip(tr3.rollout.policy.named_parameters(), tr.rollout.policy.named_parameters()):
+        assert torch.equal(p3, p1), n3
+    assert torch.equal(tr3.learner.kweights()["b1"], tr.learner.kweights()["b1"])
+    del tr3
     # and training continues from there, appending to the same log
     tr2.train(net_name="blue", batches=1, log_every=1, checkpoint_every=1000)
     rows = list(csv.reader(open(os.path.join(str(tmp_path), "blue.csv"))))

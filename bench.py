@@ -298,7 +298,7 @@ def main():
                        "step_definition": "one step = one launch of the persistent self-play kernel = %d env moves for each of the %d "
                                           "games of a GPU (%d env moves per step and GPU)" % (T, G, T * G),
                        "games_per_gpu": G, "global_games": G * world, "moves_per_launch": T, "env_moves_timed": int(total_moves),
-                       "mask_row_pitch_bytes": args.mask_pitch, "selfplay_kernel": os.environ.get("AZUL_SELFPLAY_KERNEL", "2") + " game(s) per wavefront",
+                       "mask_row_pitch_bytes": args.mask_pitch, "mask_bits_stream": bool(want_bits), "selfplay_kernel": os.environ.get("AZUL_SELFPLAY_KERNEL", "2") + " game(s) per wavefront",
                        "parallelism": "games sharded by global id; %s" %
                                       (("%s all-gather of the compact trajectory records%s, issued async behind each launch" %
                                         ("RCCL" if backend == "nccl" else backend, " + mask bits" if args.gather_masks else "")) if gather else "no collective")},

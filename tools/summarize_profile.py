@@ -63,16 +63,17 @@ summary["calibration_factors"] = fac
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     f = pmc["FETCH_SIZE"]["mean"] * fac.get("fetch_bytes_per_counted_KB_u32_reads", 1024.0)
     pitch = bench["config"].get("mask_row_pitch_bytes", 180)
+    payload = pitch + 4 + 4 + 1 + 4 + (24 if bench["config"].get("mask_bits_stream", True) else 0)     # mask row, action, reward, done, compact record (+ mask bits)
     wkey = "write_bytes_per_counted_KB_u8_rows192" if pitch >= 192 and "write_bytes_per_counted_KB_u8_rows192" in fac else "write_bytes_per_counted_KB_u8_rows"
     w = pmc["WRITE_SIZE"]["mean"] * fac.get(wkey, 1024.0)
     summary["hbm_bytes_per_launch"] = {"fetch": f, "write": w, "total": f + w,
                                         "write_calibration": wkey if "WRITE_SIZE" in pmc else None,
-                                        "payload_bytes_written_per_move": pitch + 24 + 4 + 4 + 1 + 4,
+                                        "payload_bytes_written_per_move": payload,
                                         "note": "counter KB x calibration factor measured in this path's access widths"}
     json.dump({"bytes_per_launch": f + w, "fetch": f, "write": w, "source": "profiles/%s_summary.json" % name,
                "games": bench["config"]["games_per_gpu"], "moves_per_launch": bench["config"]["moves_per_launch"],
                "bytes_per_move": (f + w) / waves_steps_for_traffic, "write_bytes_per_move": w / waves_steps_for_traffic,
-               "payload_bytes_written_per_move": pitch + 24 + 4 + 4 + 1 + 4,
+               "payload_bytes_written_per_move": payload,
                "launch": "azul_selfplay_kernel, %d games x %d moves" % (bench["config"]["games_per_gpu"], bench["config"]["moves_per_launch"])}, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 waves_steps = bench["config"]["games_per_gpu"] * bench["config"]["moves_per_launch"]
 if "SQ_INSTS_VALU" in pmc:

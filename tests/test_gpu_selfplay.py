@@ -174,3 +174,45 @@ def test_policy_step_handles_stuck_and_finished_slots(torch_cuda):
     assert after[2]["move_counter"] == rec[2]["move_counter"] + 1
     assert mask.cpu().numpy()[0].any()             # the returned mask already belongs to the new episode
     assert env.counters()["stuck"][0] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 7, 130])
+def test_every_kernel_variant_writes_the_same_trajectory(n):
+    """The self-play entry picks a kernel variant from the streams it is handed (all / core / any subset, dense or 192-byte pitched
+    mask rows, with or without the bit-packed mask): every variant -- and odd batch sizes, where the last wave plays ONE game --
+    must produce the same bytes, equal to the oracle's."""
+    import torch
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    T, seed = 150, 4711
+
+    def play(pitch, bits, subset):
+        env = BatchedAzul(n)
+        env.seed(seed)
+        env.runner_init()
+        env.runner_init()
+        t = env.alloc_trajectory(T, packed_mask=True, mask_pitch=pitch, mask_bits=bits)
+        if subset:
+            env.selfplay(T, t["mask"], t["action"], None, t["done"])            # run-time checked subset (no reward / packed)
+            t["reward"].zero_()
+            t["packed"].zero_()
+        else:
+            env.selfplay(T, t["mask"], t["action"], t["reward"], t["done"], maskbits=t.get("maskbits"), packed=t["packed"])
+        torch.cuda.synchronize()
+        return {k: v.cpu().numpy().copy() for k, v in t.items()}, env.get_records(), env.get_rng_range()[1], env.counters()
+
+    base, rec0, pos0, cnt0 = play(None, True, False)                              # all streams, dense rows
+    for pitch, bits, subset in [(192, True, False), (192, False, False), (None, False, False), (192, True, True), (256, False, False)]:
+        got, rec, pos, cnt = play(pitch, bits, subset)
+        for k in ("mask", "action", "done") + (() if subset else ("reward", "packed")) + (("maskbits",) if bits and not subset else ()):
+            assert np.array_equal(got[k], base[k]), (pitch, bits, subset, k)
+        assert rec.tobytes() == rec0.tobytes() and np.array_equal(pos, pos0)
+        assert np.array_equal(cnt["episodes"], cnt0["episodes"]) and np.array_equal(cnt["stat_sums"], cnt0["stat_sums"])
+    for g in range(n):
+        s = oz.Stream(seed + g)
+        o = s.advance(T, want_records=False)
+        assert np.array_equal(o["action"], base["action"][:, g]) and np.array_equal(o["reward"], base["reward"][:, g])
+        assert np.array_equal(o["mask"], base["mask"][:, g]) and np.array_equal(o["done"], base["done"][:, g])
+        bits = np.packbits(np.pad(o["mask"], ((0, 0), (0, 12))), axis=1, bitorder="little").view(np.int64)
+        assert np.array_equal(bits, base["maskbits"][:, g])
+        assert s.record().tobytes() == rec0[g].tobytes()

@@ -469,19 +469,18 @@ AZ_FN u64 lid_return2(u32 F)
 template <bool LID>
 AZ_FN void count_player2(u32 &wall, u32 &cp, u32 &floor_, i32 &score, u32 &maxc8, u32 &compl24, i32 &fpen16, u64 &lid, const K2 &k)
 {
-    u32 F = full_lines2(cp, k);
-    i32 cnt = 0;
-    if (F != 0u) {
-        Score2 s;
-        score2(wall | (F & k.pbelow), k, s);
-        bool on = ((F >> k.l) & 1u) != 0u;
-        cnt = (i32)hsum(on ? s.val : 0u);                                              // :289
-        maxc8 = umax(maxc8, hmax(on ? s.pos : 0u));                                    // :264
-        compl24 += (u32)__popc(s.rowdone & F) + ((u32)__popc(s.colordone & F) << 8) + ((u32)__popc(s.coldone & F) << 16);   // :270,:278,:286
-        if (LID) lid += lid_return2(F);                                                // :220-222
-        wall |= F;                                                                     // :219
-        cp = (cp == k.rowp1) ? 0u : cp;                                                // :218
-    }
+    // (no "any full line?" branch: with F == 0 every term below is zero, and without the branch the two players' chains sit in ONE
+    // basic block, where the scheduler interleaves them -- the kernel is bound by dependent-issue latency)
+    const u32 F = full_lines2(cp, k);
+    Score2 s;
+    score2(wall | (F & k.pbelow), k, s);
+    const bool on = ((F >> k.l) & 1u) != 0u;
+    const i32 cnt = (i32)hsum(on ? s.val : 0u);                                        // :289
+    maxc8 = umax(maxc8, hmax(on ? s.pos : 0u));                                        // :264
+    compl24 += (u32)__popc(s.rowdone & F) + ((u32)__popc(s.colordone & F) << 8) + ((u32)__popc(s.coldone & F) << 16);   // :270,:278,:286
+    if (LID) lid += lid_return2(F);                                                    // :220-222
+    wall |= F;                                                                         // :219
+    cp = (cp == k.rowp1) ? 0u : cp;                                                    // :218
     i32 pen = floor_penalty(floor_);
     fpen16 += pen;                                                                     // :208
     floor_ = 0;                                                                        // :209

@@ -607,7 +607,7 @@ struct DeviceGuard {
 extern "C" {
 
 const char *azul_last_error_string(void) { return g_err.c_str(); }
-const char *azul_version(void) { return "azul-mi355x 0.1 (gfx950, wave-per-game)"; }
+const char *azul_version(void) { return "azul-mi355x 0.2 (gfx950; rule entries: one game per wavefront, self-play: two games per wavefront)"; }
 
 static void batch_free(azul_batch *b)
 {

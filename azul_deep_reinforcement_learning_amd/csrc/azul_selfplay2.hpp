@@ -452,17 +452,16 @@ AZ_FN void prime2(G2 &g, const K2 &k)
     g.ok1 = ok_board2(g.cp1, g.wall1, k);
 }
 
-// Σ_r r * [line (r, c) is full] for the five colours, as the byte vector the lid receives (azul.py:220-222)
-AZ_FN u64 lid_return2(u32 F)
+// Σ_r r * [line (r, c) is full] for the five colours, as the byte vector the lid receives (azul.py:220-222): lane c sums its colour
+// (rows 1, 3 weigh one bit, rows 2, 3 two, row 4 four), lanes 0..3 are packed into the low word with two DPP steps
+AZ_FN u64 lid_return2(u32 F, u32 l)
 {
-    u64 add = 0;
-#pragma unroll
-    for (u32 c = 0; c < 5u; c++) {
-        u32 t = F >> c;
-        u32 s = ((t >> 5) & 1u) + 2u * ((t >> 10) & 1u) + 3u * ((t >> 15) & 1u) + 4u * ((t >> 20) & 1u);
-        add |= (u64)s << (8u * c);
-    }
-    return add;
+    const u32 t = (F >> (l < 5u ? l : 0u)) & 0x108421u;                      // bits 5 r of colour l
+    u32 s = (u32)__popc(t & 0x8020u) + 2u * (u32)__popc(t & 0x8400u) + 4u * (u32)__popc(t & 0x100000u);
+    u32 v = l < 4u ? s << (8u * l) : 0u;
+    v |= dpp0<0x111, 0xf>(v);                                               // row_shr:1
+    v |= dpp0<0x112, 0xf>(v);                                               // row_shr:2  -> lane 3 holds bytes 0..3
+    return (u64)hbcast_c<3>(v) | ((u64)hbcast_c<4>(s) << 32);
 }
 
 // count_wall + count_floor for one player (azul.py:200-290), committed
@@ -478,7 +477,7 @@ AZ_FN void count_player2(u32 &wall, u32 &cp, u32 &floor_, i32 &score, u32 &maxc8
     const i32 cnt = (i32)hsum(on ? s.val : 0u);                                        // :289
     maxc8 = umax(maxc8, hmax(on ? s.pos : 0u));                                        // :264
     compl24 += (u32)__popc(s.rowdone & F) + ((u32)__popc(s.colordone & F) << 8) + ((u32)__popc(s.coldone & F) << 16);   // :270,:278,:286
-    if (LID) lid += lid_return2(F);                                                    // :220-222
+    if (LID) lid += lid_return2(F, k.l);                                                    // :220-222
     wall |= F;                                                                         // :219
     cp = (cp == k.rowp1) ? 0u : cp;                                                    // :218
     i32 pen = floor_penalty(floor_);
@@ -544,15 +543,16 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
         klo = (wa << 26) | wb;
         khi = wa >> 6;
     }
-    u64 P = ((g.box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;     // byte c = box_0 + .. + box_c
-    if (((u32)(P >> 32) & 0xffu) == 0u) {
+    if ((g.box & 0xffffffffffull) == 0ull) {
         // the box is empty when the round starts: the first draw refills it from the lid (:81-83) -- done here, so that the
         // whole round can take the parallel path below
         g.box = g.lid; g.lid = 0;
-        P = ((g.box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;
-        if (((u32)(P >> 32) & 0xffu) == 0u) return ST_BOX_EMPTY;
+        if ((g.box & 0xffffffffffull) == 0ull) return ST_BOX_EMPTY;
     }
-    const u32 T0 = (u32)(P >> 32) & 0xffu;
+    // prefix sums of the box: p_c = box_0 + .. + box_c (c < 4), T0 = all five
+    const u32 blo = (u32)g.box;
+    const u32 p0 = blo & 0xffu, p1 = p0 + ((blo >> 8) & 0xffu), p2 = p1 + ((blo >> 16) & 0xffu), p3 = p2 + (blo >> 24);
+    const u32 T0 = p3 + ((u32)(g.box >> 32) & 0xffu);
     const bool pre = batched && T0 >= 20u;               // no refill can happen: draw t sees total T0 - t
     u32 kthi = 0, risky = 0;
     if (pre) {
@@ -569,22 +569,21 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
         // the first i draws are final (draw t only depends on draws s < t), so a pass that changes nothing has reached the
         // unique fixed point, which is the sequential result.  Boundaries move by one tile in ~100 per draw: two or three
         // passes in practice, at most 21.
-        const u32 p0 = (u32)P & 0xffu, p1 = ((u32)P >> 8) & 0xffu, p2 = ((u32)P >> 16) & 0xffu, p3 = (u32)P >> 24;
         const u32 below = (1u << l) - 1u;
         const bool draw = l < 20u;
         u32 col = (u32)((p0 << 21) <= kthi) + (u32)((p1 << 21) <= kthi) + (u32)((p2 << 21) <= kthi) + (u32)((p3 << 21) <= kthi);
+        u32 b0 = 0, b1 = 0, b2 = 0, b3 = 0;               // draws with colour <= c, as of the pass that confirmed the colours
 #pragma unroll 1
         for (u32 it = 0; it < 21u; it++) {
-            u32 n0 = (u32)__popc(hb(draw & (col == 0u)) & below), n1 = (u32)__popc(hb(draw & (col <= 1u)) & below),
-                n2 = (u32)__popc(hb(draw & (col <= 2u)) & below), n3 = (u32)__popc(hb(draw & (col <= 3u)) & below);
+            b0 = hb(draw & (col == 0u)); b1 = hb(draw & (col <= 1u)); b2 = hb(draw & (col <= 2u)); b3 = hb(draw & (col <= 3u));
+            u32 n0 = (u32)__popc(b0 & below), n1 = (u32)__popc(b1 & below), n2 = (u32)__popc(b2 & below), n3 = (u32)__popc(b3 & below);
             u32 nc = (u32)(((p0 - n0) << 21) <= kthi) + (u32)(((p1 - n1) << 21) <= kthi) + (u32)(((p2 - n2) << 21) <= kthi) +
                      (u32)(((p3 - n3) << 21) <= kthi);
             bool changed = draw & (nc != col);
             col = nc;
-            if (hb(changed) == 0u) break;
+            if (hb(changed) == 0u) break;                // the boards b0..b3 were taken from the colours that have just been confirmed
         }
-        const u32 e0 = hb(draw & (col == 0u)), e1 = hb(draw & (col == 1u)), e2 = hb(draw & (col == 2u)), e3 = hb(draw & (col == 3u)),
-                  e4 = hb(draw & (col == 4u));
+        const u32 e0 = b0, e1 = b1 & ~b0, e2 = b2 & ~b1, e3 = b3 & ~b2, e4 = 0xfffffu & ~b3;
         // display d receives draws 4d .. 4d+3: lane 5d + c counts those of colour c (:88)
         const u32 ec = k.pcol == 0u ? e0 : k.pcol == 1u ? e1 : k.pcol == 2u ? e2 : k.pcol == 3u ? e3 : e4;
         g.cs = l < 25u ? (u32)__popc((ec >> (4u * k.prow)) & 0xfu) : g.cs;
@@ -593,6 +592,7 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
         r.pos += 40u;
         return ST_OK;
     }
+    u64 P = ((g.box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;     // byte c = box_0 + .. + box_c
 #pragma unroll 1
     for (u32 t = 0; t < 20u; t++) {
         u32 total = (u32)(P >> 32) & 0xffu;

@@ -14,7 +14,9 @@
 //   everything else: half-uniform values (walls as 25-bit boards, floors, scores, turn data, box / lid byte vectors ...)
 // Cross-lane traffic stays inside a half: hb() = my half of a wave ballot (the half's cell array as a bitboard), hread() =
 // ds_bpermute with the half's base lane (cell gather / broadcast), hsum() / hmax() = DPP reductions over 32 lanes.
-// Legal-move mask: action a = 32 w + l for w = 0..5 (six 32-bit words per game instead of three 64-bit ones).
+// Legal-move mask: ONE WORD PER PATTERN ROW -- action a = d + 6 c + 30 r is bit l = d + 6 c (< 30) of word r, i.e. lane l of a half
+// owns (display d, colour c) for all six rows: its source cell is the same in every word and a chosen action decodes into (row =
+// word, lane's constants) without a table.
 // MT19937: each game's 624 words in LDS (two regions per wave); the regeneration runs 32 lanes wide.
 //
 // The arithmetic is azul_core.hpp's, statement for statement (same exactness arguments): the trajectories are
@@ -78,9 +80,10 @@ AZ_FN u32 hmax(u32 v)
 // ---- per-lane constants -------------------------------------------------------------------------------------------------
 struct K2 {
     u32 l;               // lane & 31
-    u32 spos[6];         // action a = 32 w + l: cs lane of its source cell (31 = none: bit 31 of the source board is always 0)
-    u32 okpos[6];        // action a: bit of the "row accepts colour" board (31 = floor move, always ok)
-    u32 acode[6];        // action a decoded once (LaneConst::acode's packing)
+    u32 spos;            // lane l < 30 owns (display d = l % 6, colour c = l / 6): cs lane of that source cell (31 = none: bit 31 of the
+                         // source board is always 0)
+    u32 col6;            // c = l / 6 (0 for l >= 30)
+    u32 lcode;           // (d, c) decoded once, LaneConst::acode's packing without row and action number
     u32 rowp1;           // l < 25: row + 1, else 0xff
     u32 prow, pcol, pbcol, pbelow, pcolboard;      // pattern cell l < 25: row, colour, board column, bits 0..l, cells of that board column
 };
@@ -89,14 +92,13 @@ AZ_FN void k2_init(K2 &k)
 {
     const u32 l = wlane() & 31u;
     k.l = l;
-    for (u32 w = 0; w < 6u; w++) {
-        u32 a = l + w * 32u;
-        u32 d = a % 6u, c = (a / 6u) % 5u, r = a / 30u;
-        u32 sp = d == 0u ? c + 25u : (d - 1u) * 5u + c;
-        u32 db = d == 0u ? 0u : (d - 1u) * 5u;
-        k.spos[w] = a < 180u ? sp : 31u;
-        k.okpos[w] = (a < 180u && r != 0u) ? (r - 1u) * 5u + c : 31u;
-        k.acode[w] = sp | (db << 5) | (c << 10) | (r << 13) | ((d == 0u ? 0u : 1u) << 16) | (a << 17);
+    {
+        const u32 d = l % 6u, c = l / 6u;
+        const u32 sp = d == 0u ? c + 25u : (d - 1u) * 5u + c;
+        const u32 db = d == 0u ? 0u : (d - 1u) * 5u;
+        k.spos = l < 30u ? sp : 31u;
+        k.col6 = l < 30u ? c : 0u;
+        k.lcode = sp | (db << 5) | (c << 10) | ((d == 0u ? 0u : 1u) << 16);
     }
     k.rowp1 = l < 25u ? l / 5u + 1u : 0xffu;
     u32 i = l < 25u ? l : 0u;
@@ -286,7 +288,7 @@ AZ_FN void rng2_close(Rng2 &r, u32 *gmt, u32 *pos_out, u32 l)
 
 // ---- legal-move mask: six 32-bit words per game ---------------------------------------------------------------------------
 struct Mask2 {
-    u32 m[6];        // half-uniform: bit l of word w = action 32 w + l is legal
+    u32 m[6];        // half-uniform: bit l (< 30) of word r = action 30 r + l is legal
     u32 bit[6];      // the same bit for MY action of each word (what the byte mask stores)
     u32 B;           // sources holding tiles (31 bits; bit 30 = the token)
 };
@@ -308,12 +310,15 @@ AZ_FN u32 ok_board2(u32 cp, u32 wall, const K2 &k)
 AZ_FN void legal_mask2(const G2 &g, const K2 &k, Mask2 &out)
 {
     const u32 B = g.B;
-    const u32 ok = (me2(g) ? g.ok1 : g.ok0) | 0x80000000u;      // bit 31: the floor "row" accepts everything
+    const u32 has = (B >> k.spos) & 1u;                          // my source holds tiles of my colour (azul.py:164-169)
+    const u32 okc = (me2(g) ? g.ok1 : g.ok0) >> k.col6;          // bit 5 (r - 1): pattern row r accepts my colour (:171-175)
     out.B = B;
+    out.bit[0] = has;                                            // the floor "row" accepts everything
+    out.m[0] = hb(has != 0u);
 #pragma unroll
-    for (u32 w = 0; w < 6u; w++) {
-        out.bit[w] = ((B >> k.spos[w]) & (ok >> k.okpos[w])) & 1u;
-        out.m[w] = hb(out.bit[w] != 0u);
+    for (u32 w = 1; w < 6u; w++) {
+        out.bit[w] = has & (okc >> (5u * (w - 1u)));
+        out.m[w] = hb((out.bit[w] & 1u) != 0u);
     }
 }
 
@@ -729,24 +734,27 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     Mask2 m;
     legal_mask2(g, k, m);
     if (OUT == 1 || (OUT == 2 && o.mask)) {
+        // byte a = 30 r + l of the game's row: six stores of 30 bytes (lanes 30, 31 own no action)
         uint8_t *row = o.mask + (o.e * o.pitch + l);
+        if (l < 30u) {
 #pragma unroll
-        for (u32 w = 0; w < 5u; w++) row[32u * w] = (uint8_t)m.bit[w];
-        // bytes 160..179: with padded rows (pitch >= 192) lanes 20..31 may write their zeros into the pad, no exec masking
-        if (PAD) row[160] = (uint8_t)m.bit[5];
-        else if (l < 20u) row[160] = (uint8_t)m.bit[5];
+            for (u32 w = 0; w < 6u; w++) row[30u * w] = (uint8_t)m.bit[w];
+        }
     }
     if ((OUT == 1 && BITS) || (OUT == 2 && o.maskbits)) {
+        // the same 180 bits packed (bit a & 63 of word a >> 6): the six 30-bit row words concatenated
+        const u64 q0 = (u64)m.m[0] | ((u64)m.m[1] << 30) | ((u64)m.m[2] << 60);
+        const u64 q1 = ((u64)m.m[2] >> 4) | ((u64)m.m[3] << 26) | ((u64)m.m[4] << 56);
+        const u64 q2 = ((u64)m.m[4] >> 8) | ((u64)m.m[5] << 22);
         // every lane stores (lanes 3.. repeat lane 2's address and data): no exec masking
         const u32 q = l < 2u ? l : 2u;
-        u32 lo = q == 0u ? m.m[0] : (q == 1u ? m.m[2] : m.m[4]), hi = q == 0u ? m.m[1] : (q == 1u ? m.m[3] : m.m[5]);
-        o.maskbits[o.e * 3u + q] = (u64)lo | ((u64)hi << 32);
+        o.maskbits[o.e * 3u + q] = q == 0u ? q0 : (q == 1u ? q1 : q2);
     }
     AZ_STAMP(SEG_MASK);
 
     // -- RandomAgent (game_runner.py:87-97): ordinal of the chosen legal action
     const u32 c0 = __popc(m.m[0]), c1 = __popc(m.m[1]), c2 = __popc(m.m[2]), c3 = __popc(m.m[3]), c4 = __popc(m.m[4]), c5 = __popc(m.m[5]);
-    const u32 J = __popc(m.m[0] & 0x3fffffffu);          // legal floor moves (a < 30, weight 0.01)
+    const u32 J = c0;                                    // legal floor moves (row 0: a < 30, weight 0.01)
     const u32 p1 = c0, p2 = p1 + c1, p3 = p2 + c2, p4 = p3 + c3, p5 = p4 + c4, L = p5 + c5;
     const bool nomove = (L == 0u) | (g.eog != 0u);        // ValueError in the reference (raised before random()) / a finished game handed in
     const u32 M = L - J, Mc = M ? M : 1u;
@@ -775,17 +783,17 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
         }
         if (edge & !nomove) kg = sample_slow2(T, x, sJ, J, M, L);
     }
-    // kg-th legal action: its mask word from the prefix counts (half-uniform compares), then ONE rank test per lane
+    // kg-th legal action: its pattern row (= mask word) from the prefix counts (half-uniform compares), then ONE rank test per lane;
+    // the lane that answers holds (display, colour) as a constant, the row is the word index
     const u32 want = kg - 1u;
     const bool g1 = want >= p1, g2 = want >= p2, g3 = want >= p3, g4 = want >= p4, g5 = want >= p5;
     const u32 mword = g5 ? m.m[5] : g4 ? m.m[4] : g3 ? m.m[3] : g2 ? m.m[2] : g1 ? m.m[1] : m.m[0];
     const u32 base = g5 ? p5 : g4 ? p4 : g3 ? p3 : g2 ? p2 : g1 ? p1 : 0u;
-    // (masked sums, not a select chain over the constant table: see the note at the address-select pitfall above)
-    const u32 mycode = (g5 ? k.acode[5] : 0u) | ((g4 & !g5) ? k.acode[4] : 0u) | ((g3 & !g4) ? k.acode[3] : 0u) | ((g2 & !g3) ? k.acode[2] : 0u) |
-                       ((g1 & !g2) ? k.acode[1] : 0u) | (!g1 ? k.acode[0] : 0u);
+    const u32 prow_ = (u32)g1 + (u32)g2 + (u32)g3 + (u32)g4 + (u32)g5;
     const bool hit = (((mword >> l) & 1u) != 0u) & ((u32)__popc(mword & ((1u << l) - 1u)) == want - base);
     const u32 who = hb(hit);
-    const u32 code = hbcast(mycode, (u32)__builtin_ctz(who | 0x80000000u));
+    const u32 ln = (u32)__builtin_ctz(who | 0x80000000u);
+    const u32 code = hbcast(k.lcode, ln) | (prow_ << 13) | ((30u * prow_ + ln) << 17);
     const i32 a = (i32)(code >> 17);
     AZ_STAMP(SEG_SAMPLE);
 

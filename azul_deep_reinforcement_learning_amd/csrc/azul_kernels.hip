@@ -1116,7 +1116,7 @@ int azul_select_episode_samples(const uint8_t *done_ring_dev, const int32_t *act
         n_games <= 0 || steps_played < window_steps || steps_played % window_steps != 0 || steps_played > 0x7fff0000ll)
         return fail(AZUL_ERR_INVALID, "azul_select_episode_samples: bad arguments");
     STREAM_GUARD(stream);
-    const u32 N = (u32)n_games, blocks = (N + 255u) / 256u;
+    const u32 N = (u32)n_games, blocks = (N + 3u) / 4u;      // one wave per game, four games per workgroup
     const int R = window_steps * ring_windows;
     hipLaunchKernelGGL(azul_select_ring_count_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, done_ring_dev, action_ring_dev, window_steps, R, N,
                        (i32)steps_played, (const i32 *)pending_dev, scratch_dev, count_dev);

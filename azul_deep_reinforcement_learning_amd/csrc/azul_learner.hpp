@@ -396,72 +396,81 @@ __global__ void __launch_bounds__(1024) azul_select_complete_kernel(const uint8_
 // through the ring with azul_discounted_returns' carry).  Steps that have already fallen out of the ring are counted in
 // count[1] ("dropped").  Two launches, deterministic order (game by game, steps ascending): counts + block sums, then offsets +
 // index writes.  scratch: int32 [3 N + blocks].
+// (one WAVE per game: the lanes read 64 time slots at once and ballots replace the per-thread loops over steps)
 __global__ void __launch_bounds__(256) azul_select_ring_count_kernel(const uint8_t *done, const i32 *action, int T, int R, u32 N, i32 s_end,
                                                                    const i32 *pend, i32 *scratch, i32 *count)
 {
-    __shared__ i32 redS[256];
-    const u32 g = blockIdx.x * 256u + threadIdx.x;
-    const u32 nb = gridDim.x;
+    __shared__ i32 cntS[4];
+    const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const u32 g = blockIdx.x * 4u + w;
     i32 *cntA = scratch, *startA = scratch + N, *lastA = scratch + 2 * (size_t)N, *blockA = scratch + 3 * (size_t)N;
     i32 cnt = 0, start = 0, last = -1, dropped = 0;
     if (g < N) {
         const i32 s_win = s_end - T;
-        for (int t = 0; t < T; t++)                       // (loads pipeline: no data-dependent exit)
-            if (done[(size_t)((s_win + t) % R) * N + g] != 0) last = s_win + t;
+        for (i32 t0 = 0; t0 < T; t0 += 64) {              // the newest window: the LAST episode end of this game inside it
+            const i32 t = t0 + (i32)lane;
+            const bool d = t < T && done[(size_t)((s_win + t) % R) * N + g] != 0;
+            const u64 m = __ballot(d);
+            if (m) last = s_win + t0 + 63 - (i32)__builtin_clzll(m);
+        }
         if (last >= 0) {
             const i32 lo = s_end - R > 0 ? s_end - R : 0;
             const i32 p0 = pend[g];
             start = p0 > lo ? p0 : lo;
             dropped = start - p0;
-            for (i32 s = start; s <= last; s++) cnt += action[(size_t)(s % R) * N + g] >= 0 ? 1 : 0;
+            for (i32 s0 = start; s0 <= last; s0 += 64) {
+                const i32 sx = s0 + (i32)lane;
+                const bool ok = sx <= last && action[(size_t)(sx % R) * N + g] >= 0;
+                cnt += (i32)__builtin_popcountll(__ballot(ok));
+            }
         }
-        cntA[g] = cnt; startA[g] = start; lastA[g] = last;
+        if (lane == 0u) { cntA[g] = cnt; startA[g] = start; lastA[g] = last; }
     }
-    redS[threadIdx.x] = cnt;
+    if (lane == 0u) cntS[w] = cnt;
     __syncthreads();
-    for (u32 o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) redS[threadIdx.x] += redS[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) blockA[blockIdx.x] = redS[0];
-    if (g == 0) { count[0] = 0; }
-    if (dropped) atomicAdd(&count[1], dropped);           // integer: order does not matter
-    (void)nb;
+    if (threadIdx.x == 0) blockA[blockIdx.x] = cntS[0] + cntS[1] + cntS[2] + cntS[3];
+    if (g == 0 && lane == 0u) count[0] = 0;
+    if (dropped && lane == 0u) atomicAdd(&count[1], dropped);           // integer: order does not matter
 }
 
 __global__ void __launch_bounds__(256) azul_select_ring_write_kernel(const i32 *action, int R, u32 N, i32 *pend, const i32 *scratch, i32 *index,
                                                                    i32 *count)
 {
-    __shared__ i32 scanS[256];
+    __shared__ i32 redS[256];
     __shared__ i32 baseS;
-    const u32 tid = threadIdx.x, g = blockIdx.x * 256u + tid;
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const u32 g = blockIdx.x * 4u + w;
     const i32 *cntA = scratch, *startA = scratch + N, *lastA = scratch + 2 * (size_t)N, *blockA = scratch + 3 * (size_t)N;
-    // this block's base: the sum of the earlier blocks' totals (fixed order)
+    // this block's base: the sum of the earlier blocks' totals (integers: any order)
     i32 part = 0;
     for (u32 b = tid; b < blockIdx.x; b += 256u) part += blockA[b];
-    scanS[tid] = part;
+    redS[tid] = part;
     __syncthreads();
-    for (u32 o = 128; o > 0; o >>= 1) { if (tid < o) scanS[tid] += scanS[tid + o]; __syncthreads(); }
-    if (tid == 0) baseS = scanS[0];
+    for (u32 o = 128; o > 0; o >>= 1) { if (tid < o) redS[tid] += redS[tid + o]; __syncthreads(); }
+    if (tid == 0) baseS = redS[0];
     __syncthreads();
-    const i32 cnt = g < N ? cntA[g] : 0;
-    scanS[tid] = cnt;
-    __syncthreads();
-    for (u32 o = 1; o < 256u; o <<= 1) {                 // inclusive scan (Hillis-Steele)
-        i32 v = tid >= o ? scanS[tid - o] : 0;
-        __syncthreads();
-        scanS[tid] += v;
-        __syncthreads();
-    }
+    const u32 g0 = blockIdx.x * 4u;
+    i32 pos = baseS;
+    for (u32 v = 0; v < w; v++) pos += (g0 + v < N) ? cntA[g0 + v] : 0;      // the games of this block before mine
     if (g < N) {
-        i32 pos = baseS + scanS[tid] - cnt;
         const i32 last = lastA[g];
         if (last >= 0) {
-            for (i32 s = startA[g]; s <= last; s++) {
-                const i32 slot = s % R;
-                if (action[(size_t)slot * N + g] >= 0) index[pos++] = (i32)((u32)slot * N + g);
+            for (i32 s0 = startA[g]; s0 <= last; s0 += 64) {
+                const i32 sx = s0 + (i32)lane;
+                const i32 slot = sx % R;
+                const bool ok = sx <= last && action[(size_t)slot * N + g] >= 0;
+                const u64 m = __ballot(ok);
+                if (ok) index[pos + (i32)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (i32)((u32)slot * N + g);
+                pos += (i32)__builtin_popcountll(m);
             }
-            pend[g] = last + 1;
+            if (lane == 0u) pend[g] = last + 1;
         }
     }
-    if (blockIdx.x == gridDim.x - 1 && tid == 255u) count[0] = baseS + scanS[255];
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        i32 total = baseS;
+        for (u32 v = 0; v < 4u; v++) total += (g0 + v < N) ? cntA[g0 + v] : 0;
+        count[0] = total;
+    }
 }
 
 

@@ -282,7 +282,7 @@ class A2CLearner:
         if st is None or st["key"] != (id(ro), R, N):
             st = self._ring = {"key": (id(ro), R, N), "index": torch.empty(R * N, dtype=torch.int32, device=dev),
                                "count": torch.zeros(2, dtype=torch.int32, device=dev), "pending": torch.zeros(N, dtype=torch.int32, device=dev),
-                               "scratch": torch.empty(3 * N + (N + 255) // 256, dtype=torch.int32, device=dev), "offset": 0}
+                               "scratch": torch.empty(3 * N + (N + 3) // 4, dtype=torch.int32, device=dev), "offset": 0}
             # this learner's books start with the window that was just played (earlier windows -- warm-up -- are nobody's samples);
             # the clock is the rollout's own (absolute step s lives in ring slot s % R), shifted down by whole rings when it grows
             st["pending"].fill_((ro.windows_played - 1) * T)

@@ -266,7 +266,7 @@ int azul_select_complete_samples(const uint8_t *done_dev, const int32_t *action_
  * steps from pending up to its last episode end inside the newest window (the caller chains azul_discounted_returns backwards
  * through the ring with the carry, so those steps' returns are exact).  index_dev receives flat indices slot * n_games + game (game by
  * game, steps ascending), count_dev[0] their number, count_dev[1] ACCUMULATES the steps that had left the ring before their episode
- * ended (zero it once); scratch_dev: int32 [3 n_games + ceil(n_games / 256)]. */
+ * ended (zero it once); scratch_dev: int32 [3 n_games + ceil(n_games / 4)]. */
 int azul_select_episode_samples(const uint8_t *done_ring_dev, const int32_t *action_ring_dev, int window_steps, int ring_windows, int n_games,
                                 int64_t steps_played, int32_t *pending_dev, int32_t *index_dev, int32_t *count_dev, int32_t *scratch_dev,
                                 void *stream);

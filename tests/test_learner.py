@@ -372,7 +372,7 @@ def test_every_step_of_every_episode_is_trained_exactly_once_across_windows(gold
     index = torch.empty(R * n, dtype=torch.int32, device=dev)
     count = torch.zeros(2, dtype=torch.int32, device=dev)
     pending = torch.zeros(n, dtype=torch.int32, device=dev)
-    scratch = torch.empty(3 * n + (n + 255) // 256, dtype=torch.int32, device=dev)
+    scratch = torch.empty(3 * n + (n + 3) // 4, dtype=torch.int32, device=dev)
     p = lambda t: C.c_void_p(t.data_ptr())
     hist = {k: [] for k in ("action", "reward", "done")}
     seen = {}                                                # (game, absolute step) -> return handed to the learner

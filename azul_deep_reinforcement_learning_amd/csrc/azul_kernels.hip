@@ -407,6 +407,25 @@ __global__ void __launch_bounds__(256) azul_returns_kernel(const i32 *reward, co
 }
 
 
+// The same scan over a RING of time slots (absolute step s lives in slot s % ring_steps): one launch walks from the newest step
+// s_end - 1 back over `span` steps, so the return flowing out of a window's first step chains into the window before it.
+__global__ void __launch_bounds__(64) azul_returns_ring_kernel(const i32 *reward, const uint8_t *done, float *out, float gamma, int ring_steps,
+                                                               int s_end, int span, u32 n)
+{
+    u32 g = blockIdx.x * 64u + threadIdx.x;
+    if (g >= n) return;
+    float q = 0.f;
+    int slot = (s_end - 1) % ring_steps;
+#pragma unroll 8
+    for (int j = 0; j < span; j++) {
+        size_t i = (size_t)slot * n + g;
+        if (done[i]) q = 0.f;
+        q = (float)reward[i] + gamma * q;
+        out[i] = q;
+        slot = slot == 0 ? ring_steps - 1 : slot - 1;
+    }
+}
+
 struct TrajArgs {
     int n_steps;
     uint8_t *mask;     // [T][N][180]
@@ -1001,6 +1020,21 @@ int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, 
     return AZUL_SUCCESS;
 }
 
+int azul_discounted_returns_ring(const int32_t *reward_ring_dev, const uint8_t *done_ring_dev, float *returns_ring_dev, float gamma,
+                                 int ring_steps, int64_t steps_played, int span_steps, int n_games, void *stream)
+{
+    if (!reward_ring_dev || !done_ring_dev || !returns_ring_dev || ring_steps <= 0 || steps_played <= 0 || span_steps < 0 ||
+        span_steps > ring_steps || span_steps > steps_played || n_games <= 0)
+        return fail(AZUL_ERR_INVALID, "azul_discounted_returns_ring: bad arguments");
+    if (span_steps == 0) return AZUL_SUCCESS;
+    STREAM_GUARD(stream);
+    hipLaunchKernelGGL(azul_returns_ring_kernel, dim3(((u32)n_games + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, reward_ring_dev, done_ring_dev,
+                       returns_ring_dev, gamma, ring_steps, (int)(steps_played % ring_steps == 0 ? ring_steps : steps_played % ring_steps), span_steps,
+                       (u32)n_games);
+    HIP_TRY(hipGetLastError());
+    return AZUL_SUCCESS;
+}
+
 int azul_policy_head(const float *logits_dev, const uint8_t *mask_dev, uint64_t seed, uint64_t counter, const uint64_t *counter_dev,
                      int n_games, uint32_t game_id_base, int32_t *action_dev, float *logp_dev, float *entropy_dev, void *stream)
 {
@@ -1092,7 +1126,8 @@ int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int3
 
 int azul_a2c_apply_adam(const float *grad_dev, float *flat_dev, float *exp_avg_dev, float *exp_avg_sq_dev, float lr, float beta1, float beta2,
                         float eps, int step, float *critic1_w, float *critic1_b, float *critic2_w, float *critic2_b, float *actor1_w,
-                        float *actor1_b, float *actor2_w, float *actor2_b, int32_t *step_dev, const float *n_total_dev, void *stream)
+                        float *actor1_b, float *actor2_w, float *actor2_b, int32_t *step_dev, const float *n_total_dev, float n_total_host,
+                        float *stats_out_dev, void *stream)
 {
     if (!grad_dev || !flat_dev || !exp_avg_dev || !exp_avg_sq_dev || (!step_dev && step < 1) || !critic1_w || !critic1_b || !critic2_w ||
         !critic2_b || !actor1_w || !actor1_b || !actor2_w || !actor2_b)
@@ -1103,14 +1138,14 @@ int azul_a2c_apply_adam(const float *grad_dev, float *flat_dev, float *exp_avg_d
     ModuleParams P = {critic1_w, critic1_b, critic2_w, critic2_b, actor1_w, actor1_b, actor2_w, actor2_b};
     if (step_dev) hipLaunchKernelGGL(azul_a2c_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, n_total_dev);
     hipLaunchKernelGGL(azul_a2c_apply_kernel, dim3((LG_P_PARAMS + 255) / 256), dim3(256), 0, (hipStream_t)stream, grad_dev, flat_dev, exp_avg_dev,
-                       exp_avg_sq_dev, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), P, (const i32 *)step_dev, n_total_dev);
+                       exp_avg_sq_dev, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), P, (const i32 *)step_dev, n_total_dev, n_total_host, stats_out_dev);
     HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }
 
 int azul_select_episode_samples(const uint8_t *done_ring_dev, const int32_t *action_ring_dev, int window_steps, int ring_windows, int n_games,
-                                int64_t steps_played, int32_t *pending_dev, int32_t *index_dev, int32_t *count_dev, int32_t *scratch_dev,
-                                void *stream)
+                                int64_t steps_played, int32_t *pending_dev, int32_t *index_dev, int32_t *count_dev, float *countf_dev,
+                                int32_t *scratch_dev, void *stream)
 {
     if (!done_ring_dev || !action_ring_dev || !pending_dev || !index_dev || !count_dev || !scratch_dev || window_steps <= 0 || ring_windows <= 0 ||
         n_games <= 0 || steps_played < window_steps || steps_played % window_steps != 0 || steps_played > 0x7fff0000ll)
@@ -1121,7 +1156,7 @@ int azul_select_episode_samples(const uint8_t *done_ring_dev, const int32_t *act
     hipLaunchKernelGGL(azul_select_ring_count_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, done_ring_dev, action_ring_dev, window_steps, R, N,
                        (i32)steps_played, (const i32 *)pending_dev, scratch_dev, count_dev);
     hipLaunchKernelGGL(azul_select_ring_write_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, action_ring_dev, R, N, pending_dev,
-                       (const i32 *)scratch_dev, index_dev, count_dev);
+                       (const i32 *)scratch_dev, index_dev, count_dev, countf_dev);
     HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }

@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(256) azul_select_ring_count_kernel(const uint8
 }
 
 __global__ void __launch_bounds__(256) azul_select_ring_write_kernel(const i32 *action, int R, u32 N, i32 *pend, const i32 *scratch, i32 *index,
-                                                                   i32 *count)
+                                                                   i32 *count, float *countf)
 {
     __shared__ i32 redS[256];
     __shared__ i32 baseS;
@@ -470,6 +470,7 @@ __global__ void __launch_bounds__(256) azul_select_ring_write_kernel(const i32 *
         i32 total = baseS;
         for (u32 v = 0; v < 4u; v++) total += (g0 + v < N) ? cntA[g0 + v] : 0;
         count[0] = total;
+        if (countf) { countf[0] = (float)total; countf[1] = 1.0f / (float)(total > 0 ? total : 1); }     // for the learner: n and 1 / max(n, 1)
     }
 }
 
@@ -491,8 +492,14 @@ __global__ void azul_a2c_step_kernel(i32 *step_dev, const float *n_total_dev)
 
 __global__ void __launch_bounds__(256) azul_a2c_apply_kernel(const float *grad, float *flat, float *m, float *v, float lr, float beta1,
                                                              float beta2, float eps, float bias_c1, float bias_c2_sqrt, ModuleParams P,
-                                                             const i32 *step_dev, const float *n_total_dev)
+                                                             const i32 *step_dev, const float *n_total_dev, float n_total_host, float *stats_out)
 {
+    if (stats_out && blockIdx.x == 0 && threadIdx.x == 0) {
+        // the update's loss terms as the reference logs them (agent.py:51-58): means over the batch, ac_loss = 1 a + 0.5 c + 0.1 e
+        const float nn = n_total_dev ? *n_total_dev : n_total_host, inv = 1.0f / (nn > 0.f ? nn : 1.0f);
+        const float la = grad[LG_P_LOSS] * inv, lc = grad[LG_P_LOSS + 1] * inv, le = grad[LG_P_LOSS + 2] * inv;
+        stats_out[0] = la; stats_out[1] = lc; stats_out[2] = le; stats_out[3] = 1.0f * la + 0.5f * lc + 0.1f * le; stats_out[4] = nn;
+    }
     if (n_total_dev && !(*n_total_dev > 0.f)) return;    // a window without a finished episode: no samples, no step
     if (step_dev) {                                      // bias corrections from the device-resident step (torch.optim.Adam: 1 - beta^step)
         __shared__ float bcS[2];

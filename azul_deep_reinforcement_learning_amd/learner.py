@@ -143,10 +143,11 @@ class A2CLearner:
             ws["step"].fill_(int(st["fused"]["step"]))
         self.sync_from_module()
 
-    def _fused_gradients(self, obs, mask, action, qvals, n_total=None, index=None, count=None, kweights=None):
-        """The flat gradient from azul_a2c_gradients (summed over the ranks); returns (actor, critic, entropy, samples): loss sums /
-        n_total.  Either `n_total` (host number; all rows are samples) or `index` + `count` (device selection of rows; the global
-        count is then formed on the device, no host round trip)."""
+    def _fused_gradients(self, obs, mask, action, qvals, n_total=None, index=None, count=None, kweights=None, countf=None):
+        """The flat gradient from azul_a2c_gradients (summed over the ranks); returns what _finish_fused needs: (n_dev, n_host) -- the
+        global sample count as a device float[1] or as a host number.  Either `n_total` (host number; all rows are samples) or
+        `index` + `count` (device selection of rows; `countf` = [count, 1 / max(count, 1)] as floats when the selection kernel
+        already wrote them: single-process runs then need no arithmetic outside the kernels, no host round trip either way)."""
         import ctypes as C
         from . import _lib as L
         pol, dev = self.policy, obs.device
@@ -159,7 +160,9 @@ class A2CLearner:
             qvals = qvals.contiguous().float()
             p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
             inv_dev = None
-            if index is not None:
+            if index is not None and countf is not None and not self.distributed:
+                n_dev, inv_dev, inv_host = countf[0:1], countf[1:2], 1.0
+            elif index is not None:
                 n_dev = count.to(torch.float32)
                 if self.distributed:
                     dist.all_reduce(n_dev, group=self.group)
@@ -175,14 +178,7 @@ class A2CLearner:
             g = ws["grad"]
             if self.distributed:
                 dist.all_reduce(g, group=self.group)                       # one flat bucket
-            o = L.A2C_FLAT_SIZE
-            if index is not None:
-                sums = g[o:o + 3] * inv_dev
-                samples = n_dev.squeeze(0)
-            else:
-                sums = g[o:o + 3] / float(n_total)
-                samples = torch.as_tensor(float(n_total), device=dev)
-        return sums[0], sums[1], sums[2], samples
+        return (n_dev, None) if index is not None else (None, float(n_total))
 
     def _record(self, out):
         for k2, v in out.items():
@@ -190,26 +186,34 @@ class A2CLearner:
         self.updates += 1
         return out
 
-    def _finish_fused(self, a, c, e, samples):
+    def _stat_slot(self):
+        """Row of the statistics ring that the next update's loss terms go to (written by the optimiser kernel itself)."""
+        ws = self._ws
+        if "stats" not in ws:
+            ws["stats"] = torch.zeros(self.statistics["ac_loss"].maxlen, 5, device=ws["grad"].device)
+        return ws["stats"][self.updates % ws["stats"].shape[0]]
+
+    def _finish_fused(self, n_dev, n_host):
         """Optimiser step: azul_a2c_apply_adam on the flat copy + module (the learner's own Adam), or -- when the caller installed
-        another optimiser -- the flat gradient scattered into the parameters' .grad and that optimiser's step."""
+        another optimiser -- the flat gradient scattered into the parameters' .grad and that optimiser's step.  The update's loss
+        terms (agent.py:51-58) are written by the same kernel into a row of a device-resident ring: no small launches follow."""
         import ctypes as C
         from . import _lib as L
         pol, ws = self.policy, self._ws
         g = ws["grad"]
         dev = g.device
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        row = self._stat_slot()
         if self.optimizer is self._own_adam and self.fused_apply:
             grp = self.optimizer.param_groups[0]
-            p = lambda t: C.c_void_p(t.data_ptr())
             # the step counter and the "any samples at all?" test stay on the device: an update without samples (a window in which
             # no episode ended) leaves parameters, moments and step untouched
-            n_dev = samples.reshape(1).to(torch.float32).contiguous()
             L.check(L.lib.azul_a2c_apply_adam(p(g), p(ws["flat"]), p(ws["m"]), p(ws["v"]), C.c_float(grp["lr"]), C.c_float(grp["betas"][0]),
                                               C.c_float(grp["betas"][1]), C.c_float(grp["eps"]), 0,
                                               p(pol.critic_linear1.weight), p(pol.critic_linear1.bias), p(pol.critic_linear2.weight),
                                               p(pol.critic_linear2.bias), p(pol.actor_linear1.weight), p(pol.actor_linear1.bias),
                                               p(pol.actor_linear2.weight), p(pol.actor_linear2.bias), p(ws["step"]), p(n_dev),
-                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+                                              C.c_float(n_host or 0.0), p(row), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         else:
             with torch.no_grad():
                 gw1 = g[0:48960].view(136, 360)
@@ -222,10 +226,15 @@ class A2CLearner:
                     if prm.grad is None:
                         prm.grad = torch.empty_like(prm)
                     prm.grad.copy_(grad)
+                # the loss terms the optimiser kernel would have written (this branch is the uncommon one: a few small launches)
+                o = L.A2C_FLAT_SIZE
+                nn = n_dev.reshape(1).to(torch.float32) if n_dev is not None else torch.full((1,), float(n_host), device=dev)
+                row[0:3] = g[o:o + 3] / nn.clamp(min=1.0)
+                row[3] = ACTOR_COEFF * row[0] + CRITIC_COEFF * row[1] + ENTROPY_COEFF * row[2]
+                row[4] = nn[0]
             self.optimizer.step()
             self.sync_from_module()
-        loss = ACTOR_COEFF * a + CRITIC_COEFF * c + ENTROPY_COEFF * e
-        return self._record({"actor_loss": a, "critic_loss": c, "entropy_loss": e, "ac_loss": loss, "samples": samples})
+        return self._record({"actor_loss": row[0], "critic_loss": row[1], "entropy_loss": row[2], "ac_loss": row[3], "samples": row[4]})
 
     def update(self, obs, mask, action, qvals, weight=None):
         """One optimiser step on the given samples (this rank's share when distributed).  Returns the loss terms (global means).
@@ -281,7 +290,8 @@ class A2CLearner:
         st = getattr(self, "_ring", None)
         if st is None or st["key"] != (id(ro), R, N):
             st = self._ring = {"key": (id(ro), R, N), "index": torch.empty(R * N, dtype=torch.int32, device=dev),
-                               "count": torch.zeros(2, dtype=torch.int32, device=dev), "pending": torch.zeros(N, dtype=torch.int32, device=dev),
+                               "count": torch.zeros(2, dtype=torch.int32, device=dev), "countf": torch.zeros(2, device=dev),
+                               "pending": torch.zeros(N, dtype=torch.int32, device=dev),
                                "scratch": torch.empty(3 * N + (N + 3) // 4, dtype=torch.int32, device=dev), "offset": 0}
             # this learner's books start with the window that was just played (earlier windows -- warm-up -- are nobody's samples);
             # the clock is the rollout's own (absolute step s lives in ring slot s % R), shifted down by whole rings when it grows
@@ -295,10 +305,11 @@ class A2CLearner:
             played -= shift
         p = lambda t: C.c_void_p(t.data_ptr())
         L.check(L.lib.azul_select_episode_samples(p(rg["done"]), p(rg["action"]), T, D, N, int(played), p(st["pending"]), p(st["index"]),
-                                                  p(st["count"]), p(st["scratch"]), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+                                                  p(st["count"]), p(st["countf"]), p(st["scratch"]),
+                                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return self._finish_fused(*self._fused_gradients(
             rg["obs"][:R].reshape(R * N, -1), rg["mask"][:R].reshape(R * N, -1), rg["action"].reshape(-1), rg["returns"].reshape(-1),
-            index=st["index"], count=st["count"][:1]))
+            index=st["index"], count=st["count"][:1], countf=st["countf"]))
 
     def update_from_windows(self, trajectories, complete_only=True, kweights=None):
         """`trajectories`: the per-part dicts PolicyRollout.run_window returns (opponent="random": every record is one agent

@@ -208,13 +208,13 @@ class PolicyRollout:
             if self.ring == 1:
                 L.check(L.lib.azul_discounted_returns(_p(tr["reward"]), _p(tr["done"]), _p(tr["returns"]), None, C.c_float(gamma), T, self.h, st))
                 return
-            # returns of the new window, then chained backwards through the older windows of the ring: the value flowing out of a
-            # window's first step is the carry of the window before it (nn_runner.py:70-76 across window boundaries)
+            # returns of the new window and, chained backwards through the ring, of the older windows: the value flowing out of a
+            # window's first step flows into the window before it (nn_runner.py:70-76 across window boundaries) -- one launch
             rg = self.rings[p]
-            rg["carry"].zero_()
-            for back in range(min(self.ring, self.windows_played + 1)):
-                v = self._window_views(rg, (wi - back) % self.ring)
-                L.check(L.lib.azul_discounted_returns(_p(v["reward"]), _p(v["done"]), _p(v["returns"]), _p(rg["carry"]), C.c_float(gamma), T, self.h, st))
+            R = self.ring * T
+            played = (self.windows_played + 1) * T
+            L.check(L.lib.azul_discounted_returns_ring(_p(rg["reward"]), _p(rg["done"]), _p(rg["returns"]), C.c_float(gamma), R,
+                                                       played % (1 << 40), min(R, played), self.h, st))
             return
         tr["obs"][0].copy_(tr["obs"][T])
         tr["mask"][0].copy_(tr["mask"][T])

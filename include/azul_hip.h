@@ -248,10 +248,13 @@ int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int3
  * parameter tensors (nn.Linear layouts), so module, kernels and optimiser state stay in sync without re-layout launches.
  * step_dev (optional, int32[1] in device memory): the step counter lives on the device -- it is advanced, and the step applied, only when
  * *n_total_dev > 0 (n_total_dev optional: the update's global sample count as a float in device memory); an update without samples
- * then leaves parameters, moments and step untouched.  With step_dev == NULL the host passes `step` (>= 1). */
+ * then leaves parameters, moments and step untouched.  With step_dev == NULL the host passes `step` (>= 1).
+ * stats_out_dev (optional, float[5]): the update's loss terms as the reference logs them (agent.py:51-58) -- actor, critic, entropy
+ * loss (the gradient buffer's loss sums / n), ac_loss = 1 a + 0.5 c + 0.1 e, and the sample count n (*n_total_dev, else n_total_host). */
 int azul_a2c_apply_adam(const float *grad_dev, float *flat_dev, float *exp_avg_dev, float *exp_avg_sq_dev, float lr, float beta1, float beta2,
                         float eps, int step, float *critic1_w, float *critic1_b, float *critic2_w, float *critic2_b, float *actor1_w,
-                        float *actor1_b, float *actor2_w, float *actor2_b, int32_t *step_dev, const float *n_total_dev, void *stream);
+                        float *actor1_b, float *actor2_w, float *actor2_b, int32_t *step_dev, const float *n_total_dev, float n_total_host,
+                        float *stats_out_dev, void *stream);
 /* Which steps of a window feed the update (NNRunner.train uses whole episodes, nn_runner.py:59-76): the steps whose episode ends
  * inside the window and that carry an action (>= 0).  done / action are time-major [n_steps][n_games]; index_dev receives the flat
  * indices t * n_games + g (game by game, steps ascending), count_dev[0] their number.  Feeds azul_a2c_gradients' index_dev /
@@ -266,14 +269,20 @@ int azul_select_complete_samples(const uint8_t *done_dev, const int32_t *action_
  * steps from pending up to its last episode end inside the newest window (the caller chains azul_discounted_returns backwards
  * through the ring with the carry, so those steps' returns are exact).  index_dev receives flat indices slot * n_games + game (game by
  * game, steps ascending), count_dev[0] their number, count_dev[1] ACCUMULATES the steps that had left the ring before their episode
- * ended (zero it once); scratch_dev: int32 [3 n_games + ceil(n_games / 4)]. */
+ * ended (zero it once); countf_dev (optional, float[2]) receives the count and 1 / max(count, 1) as floats (what azul_a2c_gradients'
+ * inv_n_total_dev and azul_a2c_apply_adam's n_total_dev read); scratch_dev: int32 [3 n_games + ceil(n_games / 4)]. */
 int azul_select_episode_samples(const uint8_t *done_ring_dev, const int32_t *action_ring_dev, int window_steps, int ring_windows, int n_games,
-                                int64_t steps_played, int32_t *pending_dev, int32_t *index_dev, int32_t *count_dev, int32_t *scratch_dev,
-                                void *stream);
+                                int64_t steps_played, int32_t *pending_dev, int32_t *index_dev, int32_t *count_dev, float *countf_dev,
+                                int32_t *scratch_dev, void *stream);
 /* discounted returns q[t] = r[t] + gamma * q[t+1] within episodes over a time-major window [n_steps][n_games]
  * (nn_runner.py:70-76); done[t][g] != 0 closes an episode at move t; carry_dev[n_games] (optional) chains windows. */
 int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, float *returns_dev, float *carry_dev,
                             float gamma, int n_steps, int n_games, void *stream);
+/* the same over a ring of `ring_steps` time slots (absolute step s in slot s % ring_steps) in ONE launch: from the newest recorded
+ * step (steps_played - 1) back over span_steps (<= ring_steps) steps, e.g. all the windows a trajectory ring holds; equals the
+ * window-by-window calls chained through the carry. */
+int azul_discounted_returns_ring(const int32_t *reward_ring_dev, const uint8_t *done_ring_dev, float *returns_ring_dev, float gamma,
+                                 int ring_steps, int64_t steps_played, int span_steps, int n_games, void *stream);
 
 /* ---- flat random-agent self-play (the benchmarked hot path) ----------------------------------- */
 /*

@@ -104,8 +104,8 @@ def test_argument_validation_needs_no_gpu():
     assert lib.azul_a2c_gradients(one, one, one, one, 16, ctypes.c_float(1.0), one, one, one, one, one, one, one, 136, 180, 180,
                                   None, 256, one, None, None, None, None) == L.ERR_INVALID
     assert lib.azul_a2c_apply_adam(one, one, one, one, ctypes.c_float(3e-4), ctypes.c_float(0.9), ctypes.c_float(0.999), ctypes.c_float(1e-8), 0,
-                                   one, one, one, one, one, one, one, one, None, None, None) == L.ERR_INVALID   # steps count from 1
-    assert lib.azul_select_episode_samples(one, one, 32, 3, 64, 48, one, one, one, one, None) == L.ERR_INVALID    # not a whole number of windows
+                                   one, one, one, one, one, one, one, one, None, None, ctypes.c_float(0), None, None) == L.ERR_INVALID   # steps count from 1
+    assert lib.azul_select_episode_samples(one, one, 32, 3, 64, 48, one, one, one, None, one, None) == L.ERR_INVALID    # not a whole number of windows
     assert lib.azul_select_complete_samples(one, one, 8, 0, one, one, None) == L.ERR_INVALID
     assert lib.azul_discounted_returns(None, one, one, None, ctypes.c_float(0.99), 4, 4, None) == L.ERR_INVALID
     assert lib.azul_batch_policy_rollout(None, 4, 0, one, one, one, one, one, one, 136, 180, 180, 1, 0, None, one, one, one, one, one, one, one, one,

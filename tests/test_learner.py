@@ -382,7 +382,7 @@ def test_every_step_of_every_episode_is_trained_exactly_once_across_windows(gold
         for k in hist:
             hist[k].append(tr[0][k].cpu().numpy().copy())
         L.check(L.lib.azul_select_episode_samples(p(ro.rings[0]["done"]), p(ro.rings[0]["action"]), T, D, n, (w + 1) * T, p(pending), p(index),
-                                                  p(count), p(scratch), None))
+                                                  p(count), None, p(scratch), None))
         torch.cuda.synchronize()
         cnt = int(count[0])
         idx = index[:cnt].cpu().numpy().astype(np.int64)

@@ -1112,7 +1112,7 @@ int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int3
         return fail(AZUL_ERR_INVALID, "azul_a2c_gradients: weights must be 8-byte aligned, mask_dev 4-byte aligned");
     STREAM_GUARD(stream);
     const hipStream_t st = (hipStream_t)stream;
-    const u32 tiles = ((u32)n_samples + PF_GAMES - 1) / PF_GAMES;
+    const u32 tiles = ((u32)n_samples + LG_M - 1) / LG_M;
     const u32 parts = tiles < (u32)workspace_parts ? tiles : (u32)workspace_parts;
     if (parts == 0) { HIP_TRY(hipMemsetAsync(grad_dev, 0, sizeof(float) * LG_P_TOTAL, st)); return AZUL_SUCCESS; }
     PolicyWeights W = {w1t_dev, b1_dev, w2c_dev, b2c_dev, w2a_t_dev, b2a_dev};
@@ -1123,6 +1123,15 @@ int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int3
     HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }
+
+#if defined(AZ_LG_PROFILE)
+extern "C" int azul_debug_lg_profile(uint64_t *host, int n, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(host, HIP_SYMBOL(lg_prof_dev), sizeof(uint64_t) * (size_t)n) != hipSuccess) return AZUL_ERR_HIP;
+    if (reset) { static const unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(lg_prof_dev), z, sizeof(z)) != hipSuccess) return AZUL_ERR_HIP; }
+    return AZUL_SUCCESS;
+}
+#endif
 
 int azul_a2c_apply_adam(const float *grad_dev, float *flat_dev, float *exp_avg_dev, float *exp_avg_sq_dev, float lr, float beta1, float beta2,
                         float eps, int step, float *critic1_w, float *critic1_b, float *critic2_w, float *critic2_b, float *actor1_w,

@@ -23,7 +23,8 @@ constexpr int LG_P_W1 = 0, LG_P_B1 = LG_P_W1 + PF_IN * PF_H2, LG_P_W2C = LG_P_B1
               LG_P_PARAMS = LG_P_B2A + PF_ACT, LG_P_LOSS = LG_P_PARAMS, LG_P_TOTAL = LG_P_PARAMS + 4;
 static_assert(LG_P_PARAMS == 82082 && LG_P_W2A % 2 == 0, "ActorCritic(136, 180, 180): 82081 parameters + 1 pad");
 
-constexpr u32 LG_WAVES = 8, LG_AHEAD = 8;
+constexpr u32 LG_WAVES = 8, LG_AHEAD = 4;
+constexpr int LG_SUB = 2, LG_M = PF_GAMES * LG_SUB;           // samples per pass: two 16-row MFMA tiles share every streamed weight fragment
 constexpr int LG_F_TILES = 9, LG_C_TILES = 23;                 // dW1: 136 -> 9 feature tiles, 360 -> 23 column tiles
 constexpr int LG_C_PER_WAVE = (LG_C_TILES + (int)LG_WAVES - 1) / (int)LG_WAVES;      // 3: wave w owns column tiles w, w + 8, w + 16
 
@@ -41,26 +42,65 @@ struct LearnerArgs {
     const float *inv_n_dev;  // optional: 1 / (samples of the whole batch) in device memory (overrides inv_n)
 };
 
+// One 180-deep GEMM pass of the gradient kernel: NT column tiles of this wave (NT == 2: columns col0, col0 + 1 of a lane, one 8-byte
+// load per k-step; NT == 1: column col0, one 4-byte load) times the two 16-row tiles of the pass.  B fragments stream from L2
+// through the buffer descriptor `rs` (k-major rows of PF_ACT floats), A fragments come from LDS (ap, rows 16 u + c).
+template <int NT>
+__device__ __forceinline__ void lg_gemm180(const __amdgpu_buffer_rsrc_t rs, u32 voff, const float *ap, int sub_stride, pf_f32x4 (&acc)[LG_SUB][2])
+{
+    for (int u = 0; u < LG_SUB; u++) acc[u][0] = acc[u][1] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
+    float2 bw[PF_HID / 4];
+#define LG_LOAD_B(s) (NT == 2 ? __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (4 * (s)) * PF_ACT * 4, 0)) \
+                              : make_float2(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (4 * (s)) * PF_ACT * 4, 0)), 0.f))
+#pragma unroll
+    for (int s = 0; s < (int)LG_AHEAD; s++) bw[s] = LG_LOAD_B(s);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < PF_HID / 4; s++) {
+        if (s + (int)LG_AHEAD < PF_HID / 4) bw[s + LG_AHEAD] = LG_LOAD_B(s + LG_AHEAD);
+        float av[LG_SUB];
+        for (int u = 0; u < LG_SUB; u++) av[u] = ap[u * sub_stride + 4 * s];
+        for (int u = 0; u < LG_SUB; u++) {
+            acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bw[s].x, acc[u][0], 0, 0, 0);
+            if (NT == 2) acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bw[s].y, acc[u][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef LG_LOAD_B
+}
+
+#if defined(AZ_LG_PROFILE)
+// diagnostic build only (tools/grad_profile.py): s_memtime ticks of wave 0 per phase, summed over passes and workgroups
+__device__ unsigned long long lg_prof_dev[16];
+#define LG_STAMP(i) do { if (w == 0u) { __builtin_amdgcn_s_waitcnt(0); u64 t_ = __builtin_amdgcn_s_memtime(); lg_acc[i] += t_ - lg_t; lg_t = t_; } } while (0)
+#else
+#define LG_STAMP(i) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeights W, LearnerArgs a)
 {
-    __shared__ float obsS[PF_GAMES * PF_OBS_STRIDE];     // x      [16][136 (+pad, zero)]
-    __shared__ float hidS[PF_GAMES * PF_HID_STRIDE];     // relu h [16][360 (+pad, zero)]
-    __shared__ float lgS[PF_GAMES * PF_LOG_STRIDE];      // logits, then dL/dlogits [16][180 (+pad, zero)]
-    __shared__ float dzS[PF_GAMES * PF_HID_STRIDE];      // dL/dz  [16][360 (+pad, zero)]
+    __shared__ float obsS[LG_M * PF_OBS_STRIDE];         // x      [32][136 (+pad, zero)]
+    __shared__ float hidS[LG_M * PF_HID_STRIDE];         // relu h [32][360 (+pad, zero)]
+    __shared__ float lgS[LG_M * PF_LOG_STRIDE];          // logits, then dL/dlogits [32][180 (+pad, zero)]
+    __shared__ float dzS[LG_M * PF_HID_STRIDE];          // dL/dz  [32][360 (+pad, zero)]
     __shared__ float w2cS[PF_HID];
-    __shared__ float valS[PF_GAMES], dvS[PF_GAMES];
-    __shared__ float lossS[4][16];                       // loss-term partials of the 16 head rows-groups, summed in a fixed order
+    __shared__ float valS[LG_M], dvS[LG_M];
+    __shared__ float lossS[5][LG_M];                     // loss-term (+ dL/dv) partials of the 32 head row-groups, summed in a fixed order
     const u32 tid = threadIdx.x, l = tid & 63u, c = l & 15u, q = l >> 4;
     const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const u32 n = a.n_dev ? (u32)*a.n_dev : a.n, n_tiles = (n + PF_GAMES - 1) / PF_GAMES;
+    const u32 n = a.n_dev ? (u32)*a.n_dev : a.n, n_tiles = (n + LG_M - 1) / LG_M;
     const float inv_n = a.inv_n_dev ? *a.inv_n_dev : a.inv_n;
 
     // one-time LDS state: zero everything (the pad columns must stay zero: they feed the padded gradient tiles)
-    for (u32 i = tid; i < (u32)(PF_GAMES * PF_OBS_STRIDE); i += 64u * LG_WAVES) obsS[i] = 0.f;
-    for (u32 i = tid; i < (u32)(PF_GAMES * PF_HID_STRIDE); i += 64u * LG_WAVES) { hidS[i] = 0.f; dzS[i] = 0.f; }
-    for (u32 i = tid; i < (u32)(PF_GAMES * PF_LOG_STRIDE); i += 64u * LG_WAVES) lgS[i] = 0.f;
+    for (u32 i = tid; i < (u32)(LG_M * PF_OBS_STRIDE); i += 64u * LG_WAVES) obsS[i] = 0.f;
+    for (u32 i = tid; i < (u32)(LG_M * PF_HID_STRIDE); i += 64u * LG_WAVES) { hidS[i] = 0.f; dzS[i] = 0.f; }
+    for (u32 i = tid; i < (u32)(LG_M * PF_LOG_STRIDE); i += 64u * LG_WAVES) lgS[i] = 0.f;
     if (tid < (u32)PF_HID) w2cS[tid] = W.w2c[tid];
-    if (tid < 64u) lossS[tid >> 4][tid & 15u] = 0.f;
+    if (tid < 5u * LG_M) lossS[tid / LG_M][tid % LG_M] = 0.f;
+    __syncthreads();
+    // a column of ones next to the observations / the actor's hidden units: the weight-gradient MFMAs then produce the bias gradients
+    // as one more row (db1 = row 136 of dW1t, db2a = row 180 of dW2a_t) -- no separate column sums
+    if (tid < (u32)LG_M) { obsS[tid * PF_OBS_STRIDE + PF_IN] = 1.0f; hidS[tid * PF_HID_STRIDE + PF_H2] = 1.0f; }
 
     // buffer descriptors: per-lane byte offset + literal k-step offset (see azul_policy_rollout_kernel)
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)W.w1t, 0, PF_IN * PF_H2 * 4, 0x00020000);
@@ -72,41 +112,45 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
     const u32 voff1 = ((f1live ? f1col0 : 0u) + q * (u32)PF_H2) * 4u;
     float f1bias[3];
     for (int j = 0; j < 3; j++) f1bias[j] = W.b1[(f1live ? f1col0 : 0u) + j];
-    // forward layer 2 and dh: waves 0..5 own columns 32w + 2c + j (j = 0, 1) of a 180-wide matrix
-    const bool mm2 = w < 6u;
-    const u32 f2col0 = 32u * w + 2u * c;
-    const bool f2live = mm2 && f2col0 < (u32)PF_ACT;
+    // forward layer 2 and dh, 180 columns = 12 tiles over 8 waves, three per SIMD (waves w and w + 4 share one): waves 0..3 own two
+    // tiles (columns 32w + 2c + j, j = 0, 1), waves 4..7 one (columns 128 + 16 (w - 4) + c)
+    const bool two = w < 4u;
+    const u32 f2col0 = two ? 32u * w + 2u * c : 128u + 16u * (w - 4u) + c;
+    const bool f2live = f2col0 < (u32)PF_ACT;
     const u32 voff2 = ((f2live ? f2col0 : 0u) + q * (u32)PF_ACT) * 4u;
-    const float f2bias0 = W.b2a[f2live ? f2col0 : 0u], f2bias1 = W.b2a[f2live ? f2col0 + 1u : 0u];
+    const float f2bias0 = W.b2a[f2live ? f2col0 : 0u], f2bias1 = W.b2a[(f2live && two) ? f2col0 + 1u : 0u];
     const float b2c_v = W.b2c[0];
 #define LG_LOAD_W1(s, j) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, voff1 + 4u * (j), (4 * (s)) * PF_H2 * 4, 0))
-#define LG_LOAD_2(rs, s) __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff2, (4 * (s)) * PF_ACT * 4, 0))
 
     // register-resident partial gradients of this workgroup
     pf_f32x4 gW2[3][6];                                  // dW2a_t tiles: hidden tiles 3 (w & 3) + i, action tiles 6 (w >> 2) + j
     pf_f32x4 gW1[LG_C_PER_WAVE][LG_F_TILES];             // dW1t tiles: column tiles w + 8 i (i = 0..2), all nine feature tiles
     for (int i = 0; i < 3; i++) for (int j = 0; j < 6; j++) gW2[i][j] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < LG_C_PER_WAVE; i++) for (int f = 0; f < LG_F_TILES; f++) gW1[i][f] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
-    float g_b1 = 0.f, g_b2a = 0.f, g_w2c = 0.f, g_b2c = 0.f;      // thread tid: db1[tid] (tid < 360), db2a / dw2c [tid] (tid < 180), db2c (tid 0)
-    float l_actor = 0.f, l_critic = 0.f, l_entropy = 0.f, l_count = 0.f;
+    float g_w2c = 0.f;                                   // thread tid: dw2c[tid & 255] over the samples 16 (tid >> 8) .. + 15 of every pass
+    float l_actor = 0.f, l_critic = 0.f, l_entropy = 0.f, l_count = 0.f, l_dv = 0.f;
     const u32 wk = w & 3u, wj = w >> 2;
     __syncthreads();
+#if defined(AZ_LG_PROFILE)
+    u64 lg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lg_t = __builtin_amdgcn_s_memtime();
+#endif
 
 #pragma unroll 1
     for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const u32 s0 = tile * PF_GAMES;
-        // ---- P0: observation tile -> LDS (rows past the batch are zero: they contribute nothing anywhere)
-        for (u32 i = tid; i < (u32)(PF_GAMES * PF_IN); i += 64u * LG_WAVES) {
+        const u32 s0 = tile * LG_M;
+        // ---- P0: observation rows -> LDS (rows past the batch are zero: they contribute nothing anywhere)
+        for (u32 i = tid; i < (u32)(LG_M * PF_IN); i += 64u * LG_WAVES) {
             u32 row = i / PF_IN, k = i - row * PF_IN;
             float v = 0.f;
             if (s0 + row < n) { const u32 src = a.index ? (u32)a.index[s0 + row] : s0 + row; v = a.obs[(size_t)src * PF_IN + k]; }
             obsS[row * PF_OBS_STRIDE + k] = v;
         }
         __syncthreads();
-        // ---- P1: hidden = relu(x @ w1t + b1)
+        LG_STAMP(0);
+        // ---- P1: hidden = relu(x @ w1t + b1): every weight fragment feeds both 16-row tiles
         {
-            pf_f32x4 acc[3];
-            for (int j = 0; j < 3; j++) acc[j] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
+            pf_f32x4 acc[LG_SUB][3];
+            for (int u = 0; u < LG_SUB; u++) for (int j = 0; j < 3; j++) acc[u][j] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
             const float *ap = obsS + c * PF_OBS_STRIDE + q;
             float bw[PF_IN / 4][3];
 #pragma unroll
@@ -115,52 +159,47 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
 #pragma unroll
             for (int s = 0; s < PF_IN / 4; s++) {
                 if (s + (int)LG_AHEAD < PF_IN / 4) for (int j = 0; j < 3; j++) bw[s + LG_AHEAD][j] = LG_LOAD_W1(s + LG_AHEAD, j);
-                const float av = ap[4 * s];
-                for (int j = 0; j < 3; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s][j], acc[j], 0, 0, 0);
+                float av[LG_SUB];
+                for (int u = 0; u < LG_SUB; u++) av[u] = ap[u * PF_GAMES * PF_OBS_STRIDE + 4 * s];
+                for (int j = 0; j < 3; j++)
+                    for (int u = 0; u < LG_SUB; u++) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bw[s][j], acc[u][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (f1live)
-                for (int j = 0; j < 3; j++)
+                for (int u = 0; u < LG_SUB; u++)
+                    for (int j = 0; j < 3; j++)
+                        for (int rr = 0; rr < 4; rr++) {
+                            float h = acc[u][j][rr] + f1bias[j];
+                            hidS[(16u * u + 4u * q + rr) * PF_HID_STRIDE + f1col0 + j] = h > 0.f ? h : 0.f;
+                        }
+        }
+        __syncthreads();
+        LG_STAMP(1);
+        // ---- P2: value = h_critic . w2c + b2c (four rows per wave, 16 lanes each), logits = h_actor @ w2a_t + b2a
+        {
+            const u32 row = 4u * w + q;
+            const float *hp = hidS + row * PF_HID_STRIDE + c;
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 12; i++) { const u32 k = c + 16u * (u32)i; sum = fmaf(k < (u32)PF_HID ? hp[16 * i] : 0.f, w2cS[k < (u32)PF_HID ? k : 0u], sum); }
+            sum = row_sum(sum);
+            if (c == 0u) valS[row] = sum + b2c_v;
+            pf_f32x4 acc[LG_SUB][2];
+            const float *ap = hidS + c * PF_HID_STRIDE + PF_HID + q;
+            if (two) lg_gemm180<2>(rs2t, voff2, ap, PF_GAMES * PF_HID_STRIDE, acc);
+            else lg_gemm180<1>(rs2t, voff2, ap, PF_GAMES * PF_HID_STRIDE, acc);
+            if (f2live)
+                for (int u = 0; u < LG_SUB; u++)
                     for (int rr = 0; rr < 4; rr++) {
-                        float h = acc[j][rr] + f1bias[j];
-                        hidS[(4u * q + rr) * PF_HID_STRIDE + f1col0 + j] = h > 0.f ? h : 0.f;
+                        float *lp = lgS + (16u * u + 4u * q + rr) * PF_LOG_STRIDE + f2col0;
+                        lp[0] = acc[u][0][rr] + f2bias0;
+                        if (two) lp[1] = acc[u][1][rr] + f2bias1;
                     }
         }
         __syncthreads();
-        // ---- P2: logits = h_actor @ w2a_t + b2a (waves 0..5), value = h_critic . w2c + b2c (wave 6)
-        if (mm2) {
-            pf_f32x4 acc0 = (pf_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-            const float *ap = hidS + c * PF_HID_STRIDE + PF_HID + q;
-            float2 bw[PF_HID / 4];
-#pragma unroll
-            for (int s = 0; s < (int)LG_AHEAD; s++) bw[s] = LG_LOAD_2(rs2t, s);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < PF_HID / 4; s++) {
-                if (s + (int)LG_AHEAD < PF_HID / 4) bw[s + LG_AHEAD] = LG_LOAD_2(rs2t, s + LG_AHEAD);
-                const float av = ap[4 * s];
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].y, acc1, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (f2live)
-                for (int rr = 0; rr < 4; rr++) {
-                    float *lp = lgS + (4u * q + rr) * PF_LOG_STRIDE + f2col0;
-                    lp[0] = acc0[rr] + f2bias0;
-                    lp[1] = acc1[rr] + f2bias1;
-                }
-        } else if (w == 6u) {
-            float sum = 0.f;
-            const float *hp = hidS + c * PF_HID_STRIDE;
-#pragma unroll
-            for (int s = 0; s < PF_HID / 4; s++) sum = fmaf(hp[4 * s + q], w2cS[4 * s + q], sum);
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            if (q == 0u) valS[c] = sum + b2c_v;
-        }
-        __syncthreads();
-        // ---- P3: per sample (16 lanes each, waves 0..3): masked log-softmax, loss terms, dL/dlogits (in place), dL/dv
-        if (w < 4u) {
+        LG_STAMP(2);
+        // ---- P3: per sample (16 lanes each, four per wave): masked log-softmax, loss terms, dL/dlogits (in place), dL/dv
+        {
             const u32 row = 4u * w + q, s = s0 + row;
             const bool valid = s < n;
             const u32 sc_ = valid ? s : n - 1u, sc = a.index ? (u32)a.index[sc_] : sc_;
@@ -199,7 +238,9 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
                 lg[j] = (use && ok) ? d : 0.f;
             }
             if (c == 0u) {
-                dvS[row] = use ? (logp_a - adv) * inv_n : 0.f;
+                const float dv = use ? (logp_a - adv) * inv_n : 0.f;
+                dvS[row] = dv;
+                l_dv += dv;
                 if (use) {
                     l_actor += -logp_a * adv;
                     l_critic += adv * adv;
@@ -209,70 +250,64 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
             }
         }
         __syncthreads();
-        // ---- P4a: bias-like gradients of layer 2 (column sums over the 16 samples)
-        if (tid < (u32)PF_HID) {
-            float sb = 0.f, sw = 0.f;
-            for (int s = 0; s < PF_GAMES; s++) {
-                sb += lgS[s * PF_LOG_STRIDE + tid];
-                sw = fmaf(dvS[s], hidS[s * PF_HID_STRIDE + tid], sw);
+        LG_STAMP(3);
+        // ---- P4a: dw2c[k] += sum_s dv[s] * h_critic[s][k]: thread (k = tid & 255, half = tid >> 8) over its 16 samples
+        {
+            const u32 k = tid & 255u, half = tid >> 8;
+            if (k < (u32)PF_HID) {
+                const float *hp = hidS + 16u * half * PF_HID_STRIDE + k;
+                const float *dp = dvS + 16u * half;
+                float sw = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; s++) sw = fmaf(dp[s], hp[s * PF_HID_STRIDE], sw);
+                g_w2c += sw;
             }
-            g_b2a += sb;
-            g_w2c += sw;
-            if (tid == 0u) { float sv = 0.f; for (int s = 0; s < PF_GAMES; s++) sv += dvS[s]; g_b2c += sv; }
         }
-        // ---- P4b: dW2a_t[k][j] += sum_s h_actor[s][k] * dlogits[s][j]   (samples are the MFMA's k: four chunks of four)
+        // ---- P4b: dW2a_t[k][j] += sum_s h_actor[s][k] * dlogits[s][j]   (samples are the MFMA's k: chunks of four; hidden "unit" 180
+        //      is the column of ones: that row is db2a)
         const float *ha = hidS + q * PF_HID_STRIDE + PF_HID + 48u * wk + c;
         const float *la = lgS + q * PF_LOG_STRIDE + 96u * wj + c;
 #pragma unroll
-        for (int mch = 0; mch < 4; mch++) {
+        for (int mch = 0; mch < LG_M / 4; mch++) {
             float af[3], bf[6];
             for (int i = 0; i < 3; i++) af[i] = ha[4 * mch * PF_HID_STRIDE + 16 * i];
             for (int j = 0; j < 6; j++) bf[j] = la[4 * mch * PF_LOG_STRIDE + 16 * j];
             for (int i = 0; i < 3; i++)
                 for (int j = 0; j < 6; j++) gW2[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], gW2[i][j], 0, 0, 0);
         }
-        // ---- P4c: dz.  Actor half: dh = dlogits @ W2a (waves 0..5), times relu'; critic half: dv * w2c * relu' (waves 6, 7)
-        if (mm2) {
-            pf_f32x4 acc0 = (pf_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        LG_STAMP(4);
+        // ---- P4c: dz.  Critic half: dv * w2c * relu' (row tid / 16, units tid % 16 + 16 i); actor half: dh = dlogits @ W2a, times relu'
+        {
+            const u32 row = tid >> 4;
+            const float dvr = dvS[row];
+            const float *hp = hidS + row * PF_HID_STRIDE + c;
+            float *zp = dzS + row * PF_HID_STRIDE + c;
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const u32 k = c + 16u * (u32)i;
+                if (k < (u32)PF_HID) zp[16 * i] = hp[16 * i] > 0.f ? dvr * w2cS[k] : 0.f;
+            }
+            pf_f32x4 acc[LG_SUB][2];
             const float *ap = lgS + c * PF_LOG_STRIDE + q;
-            float2 bw[PF_ACT / 4];
-#pragma unroll
-            for (int s = 0; s < (int)LG_AHEAD; s++) bw[s] = LG_LOAD_2(rs2, s);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < PF_ACT / 4; s++) {
-                if (s + (int)LG_AHEAD < PF_ACT / 4) bw[s + LG_AHEAD] = LG_LOAD_2(rs2, s + LG_AHEAD);
-                const float av = ap[4 * s];
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].y, acc1, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            if (two) lg_gemm180<2>(rs2, voff2, ap, PF_GAMES * PF_LOG_STRIDE, acc);
+            else lg_gemm180<1>(rs2, voff2, ap, PF_GAMES * PF_LOG_STRIDE, acc);
             if (f2live)
-                for (int rr = 0; rr < 4; rr++) {
-                    const u32 o = (4u * q + rr) * PF_HID_STRIDE + PF_HID + f2col0;
-                    dzS[o] = hidS[o] > 0.f ? acc0[rr] : 0.f;
-                    dzS[o + 1u] = hidS[o + 1u] > 0.f ? acc1[rr] : 0.f;
-                }
-        } else {
-            // 16 samples x 180 critic units over 128 threads
-            for (u32 i = tid - 384u; i < (u32)(PF_GAMES * PF_HID); i += 128u) {
-                u32 s = i / PF_HID, k = i - s * PF_HID;
-                dzS[s * PF_HID_STRIDE + k] = hidS[s * PF_HID_STRIDE + k] > 0.f ? dvS[s] * w2cS[k] : 0.f;
-            }
+                for (int u = 0; u < LG_SUB; u++)
+                    for (int rr = 0; rr < 4; rr++) {
+                        const u32 o = (16u * u + 4u * q + rr) * PF_HID_STRIDE + PF_HID + f2col0;
+                        dzS[o] = hidS[o] > 0.f ? acc[u][0][rr] : 0.f;
+                        if (two) dzS[o + 1u] = hidS[o + 1u] > 0.f ? acc[u][1][rr] : 0.f;
+                    }
         }
         __syncthreads();
-        // ---- P5: db1 and dW1t[f][col] += sum_s x[s][f] * dz[s][col]
-        if (tid < (u32)PF_H2) {
-            float sb = 0.f;
-            for (int s = 0; s < PF_GAMES; s++) sb += dzS[s * PF_HID_STRIDE + tid];
-            g_b1 += sb;
-        }
+        LG_STAMP(5);
+        // ---- P5: dW1t[f][col] += sum_s x[s][f] * dz[s][col]   ("feature" 136 is the column of ones: that row is db1)
         {
             // per-lane bases + compile-time offsets: the wave's column tiles are a constant stride apart
             const float *xa = obsS + q * PF_OBS_STRIDE + c;
             const float *za = dzS + q * PF_HID_STRIDE + 16u * w + c;
 #pragma unroll
-            for (int mch = 0; mch < 4; mch++) {
+            for (int mch = 0; mch < LG_M / 4; mch++) {
                 float af[LG_F_TILES], bf[LG_C_PER_WAVE];
                 for (int f = 0; f < LG_F_TILES; f++) af[f] = xa[4 * mch * PF_OBS_STRIDE + 16 * f];
                 for (int i = 0; i < LG_C_PER_WAVE; i++) bf[i] = za[4 * mch * PF_HID_STRIDE + 16 * (int)LG_WAVES * i];
@@ -280,8 +315,12 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
                     for (int f = 0; f < LG_F_TILES; f++) gW1[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[f], bf[i], gW1[i][f], 0, 0, 0);
             }
         }
-        __syncthreads();                                 // the next tile overwrites obsS / hidS / lgS / dzS
+        __syncthreads();                                 // the next pass overwrites obsS / hidS / lgS / dzS
+        LG_STAMP(6);
     }
+#if defined(AZ_LG_PROFILE)
+    if (tid == 0u) for (int i = 0; i < 7; i++) atomicAdd(&lg_prof_dev[i], (unsigned long long)lg_acc[i]);
+#endif
 
     // ---- this workgroup's partial gradient vector
     float *out = a.partial + (size_t)blockIdx.x * LG_P_TOTAL;
@@ -301,18 +340,29 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
                 if (k < (u32)PF_HID && col < (u32)PF_ACT) out[LG_P_W2A + k * PF_ACT + col] = gW2[i][j][rr];
             }
         }
-    if (tid < (u32)PF_H2) out[LG_P_B1 + tid] = g_b1;
-    if (tid < (u32)PF_HID) { out[LG_P_B2A + tid] = g_b2a; out[LG_P_W2C + tid] = g_w2c; }
-    if (tid == 0u) { out[LG_P_B2C] = g_b2c; out[LG_P_B2C + 1] = 0.f; }
-    if (w < 4u && c == 0u) {                             // one slot per contributing lane: no atomics, so the logged losses are bit-reproducible
+    // the bias rows of the weight-gradient tiles: feature 136 = tile 8, row 4 * 2 + 0; hidden unit 180 = tile 11 (wk == 3, i == 2), row 4 * 1 + 0
+    if (q == 2u)
+        for (int i = 0; i < LG_C_PER_WAVE; i++) {
+            const u32 col = 16u * (w + LG_WAVES * (u32)i) + c;
+            if (col < (u32)PF_H2) out[LG_P_B1 + col] = gW1[i][8][0];
+        }
+    if (q == 1u && wk == 3u)
+        for (int j = 0; j < 6; j++) {
+            const u32 col = 16u * (6u * wj + j) + c;
+            if (col < (u32)PF_ACT) out[LG_P_B2A + col] = gW2[2][j][0];
+        }
+    if (c == 0u) {                                       // one slot per contributing lane: no atomics, so the logged losses are bit-reproducible
         const u32 slot = 4u * w + q;
-        lossS[0][slot] = l_actor; lossS[1][slot] = l_critic; lossS[2][slot] = l_entropy; lossS[3][slot] = l_count;
+        lossS[0][slot] = l_actor; lossS[1][slot] = l_critic; lossS[2][slot] = l_entropy; lossS[3][slot] = l_count; lossS[4][slot] = l_dv;
     }
+    if (tid >= 256u && (tid & 255u) < (u32)PF_HID) hidS[tid & 255u] = g_w2c;      // (the pass loop ended with a barrier: hidS is free)
     __syncthreads();
-    if (tid < 4u) {
+    if (tid < (u32)PF_HID) out[LG_P_W2C + tid] = g_w2c + hidS[tid];
+    if (tid < 5u) {
         float sum = 0.f;
-        for (int i = 0; i < 16; i++) sum += lossS[tid][i];
-        out[LG_P_LOSS + tid] = sum;
+        for (int i = 0; i < LG_M; i++) sum += lossS[tid][i];
+        if (tid < 4u) out[LG_P_LOSS + tid] = sum;
+        else { out[LG_P_B2C] = sum; out[LG_P_B2C + 1] = 0.f; }
     }
 }
 

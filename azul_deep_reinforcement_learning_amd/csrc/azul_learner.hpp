@@ -23,7 +23,7 @@ constexpr int LG_P_W1 = 0, LG_P_B1 = LG_P_W1 + PF_IN * PF_H2, LG_P_W2C = LG_P_B1
               LG_P_PARAMS = LG_P_B2A + PF_ACT, LG_P_LOSS = LG_P_PARAMS, LG_P_TOTAL = LG_P_PARAMS + 4;
 static_assert(LG_P_PARAMS == 82082 && LG_P_W2A % 2 == 0, "ActorCritic(136, 180, 180): 82081 parameters + 1 pad");
 
-constexpr u32 LG_WAVES = 8, LG_AHEAD = 4;
+constexpr u32 LG_WAVES = 8, LG_AHEAD = 8;
 constexpr int LG_SUB = 2, LG_M = PF_GAMES * LG_SUB;           // samples per pass: two 16-row MFMA tiles share every streamed weight fragment
 constexpr int LG_F_TILES = 9, LG_C_TILES = 23;                 // dW1: 136 -> 9 feature tiles, 360 -> 23 column tiles
 constexpr int LG_C_PER_WAVE = (LG_C_TILES + (int)LG_WAVES - 1) / (int)LG_WAVES;      // 3: wave w owns column tiles w, w + 8, w + 16
@@ -42,31 +42,54 @@ struct LearnerArgs {
     const float *inv_n_dev;  // optional: 1 / (samples of the whole batch) in device memory (overrides inv_n)
 };
 
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, NOT for its global loads, so weight
+// fragments and samples requested ahead stay in flight across it.
+__device__ __forceinline__ void lg_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // One 180-deep GEMM pass of the gradient kernel: NT column tiles of this wave (NT == 2: columns col0, col0 + 1 of a lane, one 8-byte
 // load per k-step; NT == 1: column col0, one 4-byte load) times the two 16-row tiles of the pass.  B fragments stream from L2
-// through the buffer descriptor `rs` (k-major rows of PF_ACT floats), A fragments come from LDS (ap, rows 16 u + c).
+// through the buffer descriptor `rs` (k-major rows of PF_ACT floats), A fragments come from LDS (ap, rows 16 u + c).  The first
+// LG_AHEAD k-steps' fragments are requested by the caller a phase earlier (lg_request180), which hides the L2 latency of the ramp.
+#define LG_LOAD_B(NT_, s) ((NT_) == 2 ? __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (4 * (s)) * PF_ACT * 4, 0)) \
+                                      : make_float2(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (4 * (s)) * PF_ACT * 4, 0)), 0.f))
+__device__ __forceinline__ void lg_request180(bool two, const __amdgpu_buffer_rsrc_t rs, u32 voff, float2 (&pre)[LG_AHEAD])
+{
+    if (two) {
+#pragma unroll
+        for (int s = 0; s < (int)LG_AHEAD; s++) pre[s] = LG_LOAD_B(2, s);
+    } else {
+#pragma unroll
+        for (int s = 0; s < (int)LG_AHEAD; s++) pre[s] = LG_LOAD_B(1, s);
+    }
+}
+
 template <int NT>
-__device__ __forceinline__ void lg_gemm180(const __amdgpu_buffer_rsrc_t rs, u32 voff, const float *ap, int sub_stride, pf_f32x4 (&acc)[LG_SUB][2])
+__device__ __forceinline__ void lg_gemm180(const __amdgpu_buffer_rsrc_t rs, u32 voff, const float *ap, int sub_stride, const float2 (&pre)[LG_AHEAD],
+                                           pf_f32x4 (&acc)[LG_SUB][2])
 {
     for (int u = 0; u < LG_SUB; u++) acc[u][0] = acc[u][1] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
     float2 bw[PF_HID / 4];
-#define LG_LOAD_B(s) (NT == 2 ? __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (4 * (s)) * PF_ACT * 4, 0)) \
-                              : make_float2(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (4 * (s)) * PF_ACT * 4, 0)), 0.f))
 #pragma unroll
-    for (int s = 0; s < (int)LG_AHEAD; s++) bw[s] = LG_LOAD_B(s);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < (int)LG_AHEAD; s++) bw[s] = pre[s];
+    float an[LG_SUB];
+    for (int u = 0; u < LG_SUB; u++) an[u] = ap[u * sub_stride];
 #pragma unroll
     for (int s = 0; s < PF_HID / 4; s++) {
-        if (s + (int)LG_AHEAD < PF_HID / 4) bw[s + LG_AHEAD] = LG_LOAD_B(s + LG_AHEAD);
+        if (s + (int)LG_AHEAD < PF_HID / 4) bw[s + LG_AHEAD] = LG_LOAD_B(NT, s + LG_AHEAD);
         float av[LG_SUB];
-        for (int u = 0; u < LG_SUB; u++) av[u] = ap[u * sub_stride + 4 * s];
+        for (int u = 0; u < LG_SUB; u++) av[u] = an[u];
+        if (s + 1 < PF_HID / 4) for (int u = 0; u < LG_SUB; u++) an[u] = ap[u * sub_stride + 4 * (s + 1)];     // A fragments one k-step ahead
         for (int u = 0; u < LG_SUB; u++) {
             acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bw[s].x, acc[u][0], 0, 0, 0);
             if (NT == 2) acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bw[s].y, acc[u][1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-#undef LG_LOAD_B
 }
 
 #if defined(AZ_LG_PROFILE)
@@ -85,8 +108,16 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
     __shared__ float dzS[LG_M * PF_HID_STRIDE];          // dL/dz  [32][360 (+pad, zero)]
     __shared__ float w2cS[PF_HID];
     __shared__ float valS[LG_M], dvS[LG_M];
+    __shared__ float b1S[PF_H2 + 24], b2aS[PF_ACT + 12]; // biases (+ zero pads: the dead columns of the last waves)
+    __shared__ float gw2cS[2][PF_HID];                   // dw2c partial sums of the two 16-sample halves (accumulated in LDS: the
+                                                         // register file belongs to the weight-gradient tiles)
+    __shared__ u32 idxS[2][LG_M];                        // source rows of this pass / the next one (0xffffffff: past the batch)
     __shared__ float lossS[5][LG_M];                     // loss-term (+ dL/dv) partials of the 32 head row-groups, summed in a fixed order
-    const u32 tid = threadIdx.x, l = tid & 63u, c = l & 15u, q = l >> 4;
+    // lane constants are RE-DERIVED at the start of every phase from an opaque copy of threadIdx.x (LG_LANE): otherwise the compiler
+    // hoists every per-lane address out of the pass loop, and those ~30 loop-invariant registers push the weight-gradient
+    // accumulators (180 of the 256 registers) into scratch memory
+    u32 tid = threadIdx.x, c = tid & 15u, q = (tid >> 4) & 3u;
+#define LG_LANE() do { u32 t_ = threadIdx.x; asm volatile("" : "+v"(t_)); tid = t_; c = t_ & 15u; q = (t_ >> 4) & 3u; } while (0)
     const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const u32 n = a.n_dev ? (u32)*a.n_dev : a.n, n_tiles = (n + LG_M - 1) / LG_M;
     const float inv_n = a.inv_n_dev ? *a.inv_n_dev : a.inv_n;
@@ -95,9 +126,11 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
     for (u32 i = tid; i < (u32)(LG_M * PF_OBS_STRIDE); i += 64u * LG_WAVES) obsS[i] = 0.f;
     for (u32 i = tid; i < (u32)(LG_M * PF_HID_STRIDE); i += 64u * LG_WAVES) { hidS[i] = 0.f; dzS[i] = 0.f; }
     for (u32 i = tid; i < (u32)(LG_M * PF_LOG_STRIDE); i += 64u * LG_WAVES) lgS[i] = 0.f;
-    if (tid < (u32)PF_HID) w2cS[tid] = W.w2c[tid];
+    if (tid < (u32)PF_HID) { w2cS[tid] = W.w2c[tid]; gw2cS[0][tid] = 0.f; gw2cS[1][tid] = 0.f; }
+    if (tid < (u32)(PF_H2 + 24)) b1S[tid] = tid < (u32)PF_H2 ? W.b1[tid] : 0.f;
+    if (tid < (u32)(PF_ACT + 12)) b2aS[tid] = tid < (u32)PF_ACT ? W.b2a[tid] : 0.f;
     if (tid < 5u * LG_M) lossS[tid / LG_M][tid % LG_M] = 0.f;
-    __syncthreads();
+    lg_barrier();
     // a column of ones next to the observations / the actor's hidden units: the weight-gradient MFMAs then produce the bias gradients
     // as one more row (db1 = row 136 of dW1t, db2a = row 180 of dW2a_t) -- no separate column sums
     if (tid < (u32)LG_M) { obsS[tid * PF_OBS_STRIDE + PF_IN] = 1.0f; hidS[tid * PF_HID_STRIDE + PF_H2] = 1.0f; }
@@ -107,19 +140,16 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
     const __amdgpu_buffer_rsrc_t rs2t = __builtin_amdgcn_make_buffer_rsrc((void *)W.w2a_t, 0, PF_HID * PF_ACT * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w2a, 0, PF_ACT * PF_HID * 4, 0x00020000);
     // forward layer 1: wave w owns hidden columns 48w + 3c + j (j = 0..2)
-    const u32 f1col0 = 48u * w + 3u * c;
-    const bool f1live = f1col0 < (u32)PF_H2;
-    const u32 voff1 = ((f1live ? f1col0 : 0u) + q * (u32)PF_H2) * 4u;
-    float f1bias[3];
-    for (int j = 0; j < 3; j++) f1bias[j] = W.b1[(f1live ? f1col0 : 0u) + j];
+#define f1col0 (48u * w + 3u * c)
+#define f1live (f1col0 < (u32)PF_H2)
+#define voff1 (((f1live ? f1col0 : 0u) + q * (u32)PF_H2) * 4u)
     // forward layer 2 and dh, 180 columns = 12 tiles over 8 waves, three per SIMD (waves w and w + 4 share one): waves 0..3 own two
     // tiles (columns 32w + 2c + j, j = 0, 1), waves 4..7 one (columns 128 + 16 (w - 4) + c)
     const bool two = w < 4u;
-    const u32 f2col0 = two ? 32u * w + 2u * c : 128u + 16u * (w - 4u) + c;
-    const bool f2live = f2col0 < (u32)PF_ACT;
-    const u32 voff2 = ((f2live ? f2col0 : 0u) + q * (u32)PF_ACT) * 4u;
-    const float f2bias0 = W.b2a[f2live ? f2col0 : 0u], f2bias1 = W.b2a[(f2live && two) ? f2col0 + 1u : 0u];
-    const float b2c_v = W.b2c[0];
+#define f2col0 (two ? 32u * w + 2u * c : 128u + 16u * (w - 4u) + c)
+#define f2live (f2col0 < (u32)PF_ACT)
+#define voff2 (((f2live ? f2col0 : 0u) + q * (u32)PF_ACT) * 4u)
+    const float b2c_v = W.b2c[0];                        // (wave-uniform: a scalar register)
 #define LG_LOAD_W1(s, j) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, voff1 + 4u * (j), (4 * (s)) * PF_H2 * 4, 0))
 
     // register-resident partial gradients of this workgroup
@@ -127,25 +157,46 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
     pf_f32x4 gW1[LG_C_PER_WAVE][LG_F_TILES];             // dW1t tiles: column tiles w + 8 i (i = 0..2), all nine feature tiles
     for (int i = 0; i < 3; i++) for (int j = 0; j < 6; j++) gW2[i][j] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < LG_C_PER_WAVE; i++) for (int f = 0; f < LG_F_TILES; f++) gW1[i][f] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
-    float g_w2c = 0.f;                                   // thread tid: dw2c[tid & 255] over the samples 16 (tid >> 8) .. + 15 of every pass
-    float l_actor = 0.f, l_critic = 0.f, l_entropy = 0.f, l_count = 0.f, l_dv = 0.f;
     const u32 wk = w & 3u, wj = w >> 2;
-    __syncthreads();
+    lg_barrier();
 #if defined(AZ_LG_PROFILE)
     u64 lg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lg_t = __builtin_amdgcn_s_memtime();
 #endif
 
+    // Global-memory latency stays off the critical path: the source rows of a pass (the selection's indirection) are staged in LDS
+    // one pass ahead, its observations are requested before the previous pass's last MFMA phase and land in LDS after it, and the
+    // per-sample inputs of the loss (mask bits, action, return) are requested before layer 2 and used after it.
+    // (observation row tid / 16, features tid % 16 + 16 j: one source row and one address per thread, literal offsets for the nine loads)
+    constexpr int LG_OBS_PER_THREAD = (PF_IN + 15) / 16;           // 9; the last one covers features 128..135 (lanes 0..7 of the group)
+#define LG_FETCH_IDX(tile_) ([&]() -> u32 { const u32 s_ = (tile_) * LG_M + tid; return s_ < n ? (a.index ? (u32)a.index[s_] : s_) : 0xffffffffu; }())
+#define LG_FETCH_OBS(buf) do {                                                                                                  \
+        const u32 src_ = idxS[buf][tid >> 4];                                                                                   \
+        const float *op_ = a.obs + (size_t)(src_ != 0xffffffffu ? src_ : 0u) * PF_IN + c;                                       \
+        _Pragma("unroll") for (int j = 0; j < LG_OBS_PER_THREAD - 1; j++) ob[j] = op_[16 * j];                                  \
+        ob[LG_OBS_PER_THREAD - 1] = op_[c < 8u ? 128 : 0]; } while (0)
+#define LG_STORE_OBS(buf) do {                                                                                                  \
+        const bool ok_ = idxS[buf][tid >> 4] != 0xffffffffu;                                                                    \
+        float *xp_ = obsS + (tid >> 4) * PF_OBS_STRIDE + c;                                                                     \
+        _Pragma("unroll") for (int j = 0; j < LG_OBS_PER_THREAD - 1; j++) xp_[16 * j] = ok_ ? ob[j] : 0.f;                      \
+        if (c < 8u) xp_[128] = ok_ ? ob[LG_OBS_PER_THREAD - 1] : 0.f; } while (0)
+    float ob[LG_OBS_PER_THREAD];
+    float pre1[LG_AHEAD][3];                             // layer 1's first weight fragments, requested at the end of the previous pass
+    float2 pre2[LG_AHEAD];                               // the same for the two 180-wide GEMMs (layer 2, dh)
+#define LG_REQUEST_W1() do { _Pragma("unroll") for (int s = 0; s < (int)LG_AHEAD; s++) for (int j = 0; j < 3; j++) pre1[s][j] = LG_LOAD_W1(s, j); } while (0)
+    LG_REQUEST_W1();
+    if (tid < (u32)LG_M) idxS[0][tid] = LG_FETCH_IDX(blockIdx.x);
+    lg_barrier();
+    LG_FETCH_OBS(0);
+    LG_STORE_OBS(0);
+    lg_barrier();
+    u32 par = 0;
+
 #pragma unroll 1
-    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const u32 s0 = tile * LG_M;
-        // ---- P0: observation rows -> LDS (rows past the batch are zero: they contribute nothing anywhere)
-        for (u32 i = tid; i < (u32)(LG_M * PF_IN); i += 64u * LG_WAVES) {
-            u32 row = i / PF_IN, k = i - row * PF_IN;
-            float v = 0.f;
-            if (s0 + row < n) { const u32 src = a.index ? (u32)a.index[s0 + row] : s0 + row; v = a.obs[(size_t)src * PF_IN + k]; }
-            obsS[row * PF_OBS_STRIDE + k] = v;
-        }
-        __syncthreads();
+    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1u) {
+        // (this pass's observations are in LDS: rows past the batch are zero and contribute nothing anywhere)
+        LG_LANE();
+        u32 nidx = 0xffffffffu;
+        if (tid < (u32)LG_M) nidx = LG_FETCH_IDX(tile + gridDim.x);       // a tile past the end: every row invalid
         LG_STAMP(0);
         // ---- P1: hidden = relu(x @ w1t + b1): every weight fragment feeds both 16-row tiles
         {
@@ -154,28 +205,42 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
             const float *ap = obsS + c * PF_OBS_STRIDE + q;
             float bw[PF_IN / 4][3];
 #pragma unroll
-            for (int s = 0; s < (int)LG_AHEAD; s++) for (int j = 0; j < 3; j++) bw[s][j] = LG_LOAD_W1(s, j);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int s = 0; s < (int)LG_AHEAD; s++) for (int j = 0; j < 3; j++) bw[s][j] = pre1[s][j];
+            float an[LG_SUB];
+            for (int u = 0; u < LG_SUB; u++) an[u] = ap[u * PF_GAMES * PF_OBS_STRIDE];
 #pragma unroll
             for (int s = 0; s < PF_IN / 4; s++) {
                 if (s + (int)LG_AHEAD < PF_IN / 4) for (int j = 0; j < 3; j++) bw[s + LG_AHEAD][j] = LG_LOAD_W1(s + LG_AHEAD, j);
                 float av[LG_SUB];
-                for (int u = 0; u < LG_SUB; u++) av[u] = ap[u * PF_GAMES * PF_OBS_STRIDE + 4 * s];
+                for (int u = 0; u < LG_SUB; u++) av[u] = an[u];
+                if (s + 1 < PF_IN / 4) for (int u = 0; u < LG_SUB; u++) an[u] = ap[u * PF_GAMES * PF_OBS_STRIDE + 4 * (s + 1)];
                 for (int j = 0; j < 3; j++)
                     for (int u = 0; u < LG_SUB; u++) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bw[s][j], acc[u][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            lg_request180(two, rs2t, voff2, pre2);             // layer 2's first weight fragments: in flight across the barrier
             if (f1live)
                 for (int u = 0; u < LG_SUB; u++)
                     for (int j = 0; j < 3; j++)
                         for (int rr = 0; rr < 4; rr++) {
-                            float h = acc[u][j][rr] + f1bias[j];
+                            float h = acc[u][j][rr] + b1S[f1col0 + j];
                             hidS[(16u * u + 4u * q + rr) * PF_HID_STRIDE + f1col0 + j] = h > 0.f ? h : 0.f;
                         }
         }
-        __syncthreads();
+        lg_barrier();
         LG_STAMP(1);
+        LG_LANE();
         // ---- P2: value = h_critic . w2c + b2c (four rows per wave, 16 lanes each), logits = h_actor @ w2a_t + b2a
+        const u32 hsrc = idxS[par][4u * w + q];                   // P3's sample of this 16-lane group; its inputs are requested now
+        const bool hvalid = hsrc != 0xffffffffu;
+        const u32 hsc = hvalid ? hsrc : 0u;
+        u32 mraw[3];
+        {
+            const u32 *mp = (const u32 *)(a.mask + (size_t)hsc * AZUL_NUM_ACTIONS + (c < 15u ? 12u * c : 0u));
+            for (int d = 0; d < 3; d++) mraw[d] = mp[d];
+        }
+        const i32 hact = a.action[hsc];
+        const float hq = a.qvals[hsc];
         {
             const u32 row = 4u * w + q;
             const float *hp = hidS + row * PF_HID_STRIDE + c;
@@ -186,27 +251,33 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
             if (c == 0u) valS[row] = sum + b2c_v;
             pf_f32x4 acc[LG_SUB][2];
             const float *ap = hidS + c * PF_HID_STRIDE + PF_HID + q;
-            if (two) lg_gemm180<2>(rs2t, voff2, ap, PF_GAMES * PF_HID_STRIDE, acc);
-            else lg_gemm180<1>(rs2t, voff2, ap, PF_GAMES * PF_HID_STRIDE, acc);
+            if (two) lg_gemm180<2>(rs2t, voff2, ap, PF_GAMES * PF_HID_STRIDE, pre2, acc);
+            else lg_gemm180<1>(rs2t, voff2, ap, PF_GAMES * PF_HID_STRIDE, pre2, acc);
             if (f2live)
                 for (int u = 0; u < LG_SUB; u++)
                     for (int rr = 0; rr < 4; rr++) {
                         float *lp = lgS + (16u * u + 4u * q + rr) * PF_LOG_STRIDE + f2col0;
-                        lp[0] = acc[u][0][rr] + f2bias0;
-                        if (two) lp[1] = acc[u][1][rr] + f2bias1;
+                        lp[0] = acc[u][0][rr] + b2aS[f2col0];
+                        if (two) lp[1] = acc[u][1][rr] + b2aS[f2col0 + 1u];
                     }
         }
-        __syncthreads();
+        lg_barrier();
         LG_STAMP(2);
+        LG_LANE();
         // ---- P3: per sample (16 lanes each, four per wave): masked log-softmax, loss terms, dL/dlogits (in place), dL/dv
         {
-            const u32 row = 4u * w + q, s = s0 + row;
-            const bool valid = s < n;
-            const u32 sc_ = valid ? s : n - 1u, sc = a.index ? (u32)a.index[sc_] : sc_;
+            const u32 row = 4u * w + q;
+            const bool valid = hvalid;
             float *lg = lgS + row * PF_LOG_STRIDE + 12u * c;       // lane c == 15 owns the pad columns 180..191
             float x[HEAD_PER_LANE];
             for (int j = 0; j < HEAD_PER_LANE; j++) x[j] = lg[j];
-            const u32 okbits = valid ? head_mask_bits(a.mask + (size_t)sc * AZUL_NUM_ACTIONS, c) : 0u;
+            u32 okbits = 0;
+            for (int d = 0; d < 3; d++) {                          // byte b != 0 -> bit b: fold every byte onto its bit 0, gather with one multiply
+                u32 t = mraw[d] | (mraw[d] >> 4);
+                t |= t >> 2; t |= t >> 1;
+                okbits |= ((((t & 0x01010101u) * 0x01020408u) >> 24) & 15u) << (4 * d);
+            }
+            okbits = (valid && c < 15u) ? okbits : 0u;
             const float NEG = -3.0e38f;
             float m = NEG;
             for (int j = 0; j < HEAD_PER_LANE; j++) m = fmaxf(m, ((okbits >> j) & 1u) ? x[j] : NEG);
@@ -216,18 +287,18 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
             for (int j = 0; j < HEAD_PER_LANE; j++) {
                 bool ok = (okbits >> j) & 1u;
                 z[j] = ok ? x[j] - m : 0.f;
-                e[j] = ok ? expf(z[j]) : 0.f;
+                e[j] = ok ? __expf(z[j]) : 0.f;
                 mine += e[j];
                 zs += z[j];
             }
-            const float S = row_sum(mine), logS = logf(S), zsum = row_sum(zs);
+            const float S = row_sum(mine), logS = __logf(S), zsum = row_sum(zs);
             const bool use = valid && cnt != 0u;                   // rows without a legal action carry no sample
-            const i32 act = a.action[sc];
+            const i32 act = hact;
             const i32 aj = act - (i32)(12u * c);                   // index of the chosen action inside this lane, if any
             float mine_lpa = 0.f;
             for (int j = 0; j < HEAD_PER_LANE; j++) if (j == aj && ((okbits >> j) & 1u)) mine_lpa = z[j] - logS;
             const float logp_a = row_sum(mine_lpa);
-            const float adv = a.qvals[sc] - valS[row];
+            const float adv = hq - valS[row];
             const float ent_w = 0.1f / (float)(cnt ? cnt : 1u);
             const float G = -adv - 0.1f;                           // sum_j dL/dlogp_j (times n)
             const float invS = 1.0f / S;
@@ -240,17 +311,20 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
             if (c == 0u) {
                 const float dv = use ? (logp_a - adv) * inv_n : 0.f;
                 dvS[row] = dv;
-                l_dv += dv;
+                lossS[4][row] += dv;                     // (slot `row` belongs to this lane alone: fixed summation order)
                 if (use) {
-                    l_actor += -logp_a * adv;
-                    l_critic += adv * adv;
-                    l_entropy += -(zsum / (float)cnt - logS);
-                    l_count += 1.f;
+                    lossS[0][row] += -logp_a * adv;
+                    lossS[1][row] += adv * adv;
+                    lossS[2][row] += -(zsum / (float)cnt - logS);
+                    lossS[3][row] += 1.f;
                 }
             }
+            if (tid < (u32)LG_M) idxS[par ^ 1u][tid] = nidx;
         }
-        __syncthreads();
+        lg_barrier();
         LG_STAMP(3);
+        LG_LANE();
+        lg_request180(two, rs2, voff2, pre2);                // P4c's first weight fragments
         // ---- P4a: dw2c[k] += sum_s dv[s] * h_critic[s][k]: thread (k = tid & 255, half = tid >> 8) over its 16 samples
         {
             const u32 k = tid & 255u, half = tid >> 8;
@@ -260,7 +334,7 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
                 float sw = 0.f;
 #pragma unroll
                 for (int s = 0; s < 16; s++) sw = fmaf(dp[s], hp[s * PF_HID_STRIDE], sw);
-                g_w2c += sw;
+                gw2cS[half][k] += sw;
             }
         }
         // ---- P4b: dW2a_t[k][j] += sum_s h_actor[s][k] * dlogits[s][j]   (samples are the MFMA's k: chunks of four; hidden "unit" 180
@@ -276,6 +350,7 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
                 for (int j = 0; j < 6; j++) gW2[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], gW2[i][j], 0, 0, 0);
         }
         LG_STAMP(4);
+        LG_LANE();
         // ---- P4c: dz.  Critic half: dv * w2c * relu' (row tid / 16, units tid % 16 + 16 i); actor half: dh = dlogits @ W2a, times relu'
         {
             const u32 row = tid >> 4;
@@ -289,8 +364,8 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
             }
             pf_f32x4 acc[LG_SUB][2];
             const float *ap = lgS + c * PF_LOG_STRIDE + q;
-            if (two) lg_gemm180<2>(rs2, voff2, ap, PF_GAMES * PF_LOG_STRIDE, acc);
-            else lg_gemm180<1>(rs2, voff2, ap, PF_GAMES * PF_LOG_STRIDE, acc);
+            if (two) lg_gemm180<2>(rs2, voff2, ap, PF_GAMES * PF_LOG_STRIDE, pre2, acc);
+            else lg_gemm180<1>(rs2, voff2, ap, PF_GAMES * PF_LOG_STRIDE, pre2, acc);
             if (f2live)
                 for (int u = 0; u < LG_SUB; u++)
                     for (int rr = 0; rr < 4; rr++) {
@@ -299,9 +374,11 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
                         if (two) dzS[o + 1u] = hidS[o + 1u] > 0.f ? acc[u][1][rr] : 0.f;
                     }
         }
-        __syncthreads();
+        lg_barrier();
         LG_STAMP(5);
+        LG_LANE();
         // ---- P5: dW1t[f][col] += sum_s x[s][f] * dz[s][col]   ("feature" 136 is the column of ones: that row is db1)
+        LG_FETCH_OBS(par ^ 1u);                          // the next pass's observations: in flight during the MFMAs below
         {
             // per-lane bases + compile-time offsets: the wave's column tiles are a constant stride apart
             const float *xa = obsS + q * PF_OBS_STRIDE + c;
@@ -315,13 +392,18 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
                     for (int f = 0; f < LG_F_TILES; f++) gW1[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[f], bf[i], gW1[i][f], 0, 0, 0);
             }
         }
-        __syncthreads();                                 // the next pass overwrites obsS / hidS / lgS / dzS
+        lg_barrier();                                 // the next pass overwrites obsS / hidS / lgS / dzS
         LG_STAMP(6);
+        LG_LANE();
+        LG_REQUEST_W1();
+        LG_STORE_OBS(par ^ 1u);
+        lg_barrier();
     }
 #if defined(AZ_LG_PROFILE)
     if (tid == 0u) for (int i = 0; i < 7; i++) atomicAdd(&lg_prof_dev[i], (unsigned long long)lg_acc[i]);
 #endif
 
+    LG_LANE();
     // ---- this workgroup's partial gradient vector
     float *out = a.partial + (size_t)blockIdx.x * LG_P_TOTAL;
     for (int i = 0; i < LG_C_PER_WAVE; i++)
@@ -351,13 +433,8 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
             const u32 col = 16u * (6u * wj + j) + c;
             if (col < (u32)PF_ACT) out[LG_P_B2A + col] = gW2[2][j][0];
         }
-    if (c == 0u) {                                       // one slot per contributing lane: no atomics, so the logged losses are bit-reproducible
-        const u32 slot = 4u * w + q;
-        lossS[0][slot] = l_actor; lossS[1][slot] = l_critic; lossS[2][slot] = l_entropy; lossS[3][slot] = l_count; lossS[4][slot] = l_dv;
-    }
-    if (tid >= 256u && (tid & 255u) < (u32)PF_HID) hidS[tid & 255u] = g_w2c;      // (the pass loop ended with a barrier: hidS is free)
-    __syncthreads();
-    if (tid < (u32)PF_HID) out[LG_P_W2C + tid] = g_w2c + hidS[tid];
+    // (the loss terms were accumulated one slot per contributing lane, no atomics: the logged losses are bit-reproducible)
+    if (tid < (u32)PF_HID) out[LG_P_W2C + tid] = gw2cS[0][tid] + gw2cS[1][tid];
     if (tid < 5u) {
         float sum = 0.f;
         for (int i = 0; i < LG_M; i++) sum += lossS[tid][i];
@@ -365,6 +442,13 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
         else { out[LG_P_B2C] = sum; out[LG_P_B2C + 1] = 0.f; }
     }
 }
+#undef f1col0
+#undef f1live
+#undef voff1
+#undef f2col0
+#undef f2live
+#undef voff2
+#undef LG_LANE
 
 // sum of the per-workgroup partials in workgroup order (deterministic); optionally scaled loss sums stay raw (caller divides)
 __global__ void __launch_bounds__(256) azul_a2c_reduce_kernel(const float *partial, u32 n_parts, float *grad /* [LG_P_TOTAL] */)

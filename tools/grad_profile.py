@@ -16,7 +16,10 @@ import azul_deep_reinforcement_learning_amd._lib as L  # noqa: E402
 from azul_deep_reinforcement_learning_amd import BatchedActorCritic  # noqa: E402
 from azul_deep_reinforcement_learning_amd.learner import A2CLearner  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 131072
+if "--lib" in sys.argv:                                   # A/B runs of experimental builds: timing only
+    L.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+    L.lib = L._load()
 torch.manual_seed(0)
 rs = np.random.RandomState(0)
 obs = torch.from_numpy(rs.randint(0, 6, size=(n, 136)).astype(np.float32)).cuda()
@@ -48,6 +51,8 @@ flop = 391e3 * n
 print("shipped kernel: %.1f us per launch of %d samples (gradients + reduction) = %.1f TFLOP/s = %.1f %% of 157.3" % (
     ms * 1e3, n, flop / ms / 1e9, flop / ms / 1e9 / 157.3 * 100))
 
+if "--lib" in sys.argv:
+    sys.exit(0)
 lib = os.path.join(ROOT, "gpurun_out", "libazulhip_lgprof.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + ge.HIPCC_FLAGS + ["-DAZ_LG_PROFILE", "-I", os.path.join(ROOT, "include"),

@@ -42,15 +42,6 @@ struct LearnerArgs {
     const float *inv_n_dev;  // optional: 1 / (samples of the whole batch) in device memory (overrides inv_n)
 };
 
-// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, NOT for its global loads, so weight
-// fragments and samples requested ahead stay in flight across it.
-__device__ __forceinline__ void lg_barrier()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 // One 180-deep GEMM pass of the gradient kernel: NT column tiles of this wave (NT == 2: columns col0, col0 + 1 of a lane, one 8-byte
 // load per k-step; NT == 1: column col0, one 4-byte load) times the two 16-row tiles of the pass.  B fragments stream from L2
 // through the buffer descriptor `rs` (k-major rows of PF_ACT floats), A fragments come from LDS (ap, rows 16 u + c).  The first
@@ -130,7 +121,7 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
     if (tid < (u32)(PF_H2 + 24)) b1S[tid] = tid < (u32)PF_H2 ? W.b1[tid] : 0.f;
     if (tid < (u32)(PF_ACT + 12)) b2aS[tid] = tid < (u32)PF_ACT ? W.b2a[tid] : 0.f;
     if (tid < 5u * LG_M) lossS[tid / LG_M][tid % LG_M] = 0.f;
-    lg_barrier();
+    lds_barrier();
     // a column of ones next to the observations / the actor's hidden units: the weight-gradient MFMAs then produce the bias gradients
     // as one more row (db1 = row 136 of dW1t, db2a = row 180 of dW2a_t) -- no separate column sums
     if (tid < (u32)LG_M) { obsS[tid * PF_OBS_STRIDE + PF_IN] = 1.0f; hidS[tid * PF_HID_STRIDE + PF_H2] = 1.0f; }
@@ -158,7 +149,7 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
     for (int i = 0; i < 3; i++) for (int j = 0; j < 6; j++) gW2[i][j] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < LG_C_PER_WAVE; i++) for (int f = 0; f < LG_F_TILES; f++) gW1[i][f] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
     const u32 wk = w & 3u, wj = w >> 2;
-    lg_barrier();
+    lds_barrier();
 #if defined(AZ_LG_PROFILE)
     u64 lg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lg_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -185,10 +176,10 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
 #define LG_REQUEST_W1() do { _Pragma("unroll") for (int s = 0; s < (int)LG_AHEAD; s++) for (int j = 0; j < 3; j++) pre1[s][j] = LG_LOAD_W1(s, j); } while (0)
     LG_REQUEST_W1();
     if (tid < (u32)LG_M) idxS[0][tid] = LG_FETCH_IDX(blockIdx.x);
-    lg_barrier();
+    lds_barrier();
     LG_FETCH_OBS(0);
     LG_STORE_OBS(0);
-    lg_barrier();
+    lds_barrier();
     u32 par = 0;
 
 #pragma unroll 1
@@ -227,7 +218,7 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
                             hidS[(16u * u + 4u * q + rr) * PF_HID_STRIDE + f1col0 + j] = h > 0.f ? h : 0.f;
                         }
         }
-        lg_barrier();
+        lds_barrier();
         LG_STAMP(1);
         LG_LANE();
         // ---- P2: value = h_critic . w2c + b2c (four rows per wave, 16 lanes each), logits = h_actor @ w2a_t + b2a
@@ -261,7 +252,7 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
                         if (two) lp[1] = acc[u][1][rr] + b2aS[f2col0 + 1u];
                     }
         }
-        lg_barrier();
+        lds_barrier();
         LG_STAMP(2);
         LG_LANE();
         // ---- P3: per sample (16 lanes each, four per wave): masked log-softmax, loss terms, dL/dlogits (in place), dL/dv
@@ -321,7 +312,7 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
             }
             if (tid < (u32)LG_M) idxS[par ^ 1u][tid] = nidx;
         }
-        lg_barrier();
+        lds_barrier();
         LG_STAMP(3);
         LG_LANE();
         lg_request180(two, rs2, voff2, pre2);                // P4c's first weight fragments
@@ -374,7 +365,7 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
                         if (two) dzS[o + 1u] = hidS[o + 1u] > 0.f ? acc[u][1][rr] : 0.f;
                     }
         }
-        lg_barrier();
+        lds_barrier();
         LG_STAMP(5);
         LG_LANE();
         // ---- P5: dW1t[f][col] += sum_s x[s][f] * dz[s][col]   ("feature" 136 is the column of ones: that row is db1)
@@ -392,12 +383,12 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
                     for (int f = 0; f < LG_F_TILES; f++) gW1[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[f], bf[i], gW1[i][f], 0, 0, 0);
             }
         }
-        lg_barrier();                                 // the next pass overwrites obsS / hidS / lgS / dzS
+        lds_barrier();                                 // the next pass overwrites obsS / hidS / lgS / dzS
         LG_STAMP(6);
         LG_LANE();
         LG_REQUEST_W1();
         LG_STORE_OBS(par ^ 1u);
-        lg_barrier();
+        lds_barrier();
     }
 #if defined(AZ_LG_PROFILE)
     if (tid == 0u) for (int i = 0; i < 7; i++) atomicAdd(&lg_prof_dev[i], (unsigned long long)lg_acc[i]);

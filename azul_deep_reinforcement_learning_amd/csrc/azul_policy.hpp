@@ -30,6 +30,20 @@ __device__ __forceinline__ u32 philox_u32(u64 seed, u64 counter, u32 game)
     return c0;
 }
 
+__device__ __forceinline__ float policy_uniform(u64 seed, u64 counter, u32 game)      // [0, 1), 24 bits
+{
+    return (float)(philox_u32(seed, counter, game) >> 8) * (1.0f / 16777216.0f);
+}
+
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, NOT for its global loads and stores, so
+// weight fragments requested ahead and trajectory stores stay in flight across it.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // ---- the head: FOUR games per wave, 16 lanes per game, lane c of a group owns actions 12c .. 12c+11 (c < 15) -----------------
 // All reductions stay inside a 16-lane DPP row (quad_perm / row_half_mirror / row_mirror / row_shr): no LDS round trips.
 template <int CTRL>
@@ -67,7 +81,8 @@ constexpr int HEAD_PER_LANE = 12;
 // x[j]: the lane's 12 logits; okbits: bit j set when action 12c+j is legal; g: the lane's game (uniform inside a 16-lane row).
 // Lane c == 0 of every row whose `store` is true writes the three results of its game.
 __device__ __forceinline__ void policy_head_rows(const float (&x)[HEAD_PER_LANE], u32 okbits, u64 seed, u64 counter, u32 g, u32 l,
-                                                 bool store, i32 *action, float *logp, float *entropy, u32 id_base, i32 *lds_action = nullptr)
+                                                 bool store, i32 *action, float *logp, float *entropy, u32 id_base, i32 *lds_action = nullptr,
+                                                 const float *u_ready = nullptr /* the game's uniform, when the caller drew it ahead of time */)
 {
     const u32 c = l & 15u, grp = l >> 4;
     const float NEG = -3.0e38f;
@@ -92,7 +107,7 @@ __device__ __forceinline__ void policy_head_rows(const float (&x)[HEAD_PER_LANE]
     float incl = mine;
     incl += dpp_f<DPP_SHR1>(incl); incl += dpp_f<DPP_SHR2>(incl); incl += dpp_f<DPP_SHR4>(incl); incl += dpp_f<DPP_SHR8>(incl);
     const bool argmax = seed == AZUL_POLICY_ARGMAX;      // action_selection == "Max" (agent.py:70-71): np.argmax, first maximum
-    const float u = (float)(philox_u32(seed, counter, id_base + g) >> 8) * (1.0f / 16777216.0f);       // [0, 1), 24 bits
+    const float u = u_ready ? *u_ready : policy_uniform(seed, counter, id_base + g);
     const float target = u * S;
     float cum = incl - mine;
     int pick = -1, lastok = 0;
@@ -451,8 +466,10 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
 #pragma unroll 1
     for (int t = 0; t < a.n_steps; t++) {
         const size_t row_t = (size_t)t * n;
+        float bw2[PR_AHEAD];
+        float u_head = 0.f;
         PR_STAMP(0);                                     // own env step + publish
-        __syncthreads();                                 // observations and mask bits of all 16 games are in LDS
+        lds_barrier();                                 // observations and mask bits of all 16 games are in LDS
         PR_STAMP(1);                                     // waiting for the slowest env wave
         if (mm) {
             // layer 1: this wave owns hidden columns 32w + 2c + j (j = 0, 1): two 16x16 tiles with column stride 2
@@ -478,8 +495,14 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
                     hp[1] = h1 > 0.f ? h1 : 0.f;
                 }
             }
+#pragma unroll
+            for (int s = 0; s < (int)PR_AHEAD; s++) bw2[s] = PR_LOAD2(s);      // layer 2's first weight fragments: in flight across the barrier
+        } else if (w >= PR_HEAD_WAVE0) {
+            // the head waves idle during the matrix phases: they draw this move's uniforms now (Philox does not depend on the logits)
+            const u32 hg = g0 + 4u * (w - PR_HEAD_WAVE0) + q;
+            u_head = policy_uniform(a.seed, counter + (u64)t, b.id_base + (hg < n ? hg : n - 1u));
         }
-        __syncthreads();
+        lds_barrier();
         PR_STAMP(2);                                     // layer 1 (incl. barrier)
         if (mm) {
             // layer 2 (actor): logit column 16w + c
@@ -487,8 +510,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
             const float *ap = hidS + c * PF_HID_STRIDE + PF_HID + q;
             float bw[PF_HID / 4];
 #pragma unroll
-            for (int s = 0; s < (int)PR_AHEAD; s++) bw[s] = PR_LOAD2(s);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int s = 0; s < (int)PR_AHEAD; s++) bw[s] = bw2[s];
 #pragma unroll
             for (int s = 0; s < PF_HID / 4; s++) {
                 if (s + (int)PR_AHEAD < PF_HID / 4) bw[s + PR_AHEAD] = PR_LOAD2(s + PR_AHEAD);
@@ -507,7 +529,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
             sum += __shfl_xor(sum, 32, 64);
             if (q == 0u && g0 + c < n) a.value[row_t + g0 + c] = sum + b2c_v;
         }
-        __syncthreads();
+        lds_barrier();
         PR_STAMP(3);                                     // layer 2 + critic (incl. barrier)
         if (w >= PR_HEAD_WAVE0) {
             // head: waves 12..15 (idle during the matrix phases) sample four games each, 16 lanes per game
@@ -522,9 +544,9 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
             if (off > 52u) field |= hi << (64u - off);
             const u32 okbits = c < 15u ? (u32)field & 0xfffu : 0u;
             policy_head_rows(x, okbits, a.seed, counter + (u64)t, hg < n ? hg : n - 1u, l, hg < n, a.action + row_t, a.logp + row_t,
-                             a.entropy + row_t, b.id_base, actS + 4u * hw);
+                             a.entropy + row_t, b.id_base, actS + 4u * hw, &u_head);
         }
-        __syncthreads();
+        lds_barrier();
         PR_STAMP(4);                                     // head (incl. barrier)
         if (live) {
             const i32 av = actS[w];

@@ -556,6 +556,7 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
 }
 
 #include "azul_policy.hpp"
+#include "azul_rollout2.hpp"
 #include "azul_learner.hpp"
 
 // ------------------------------------------------------------------------------------------------
@@ -1086,9 +1087,21 @@ int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random,
     PolicyWeights W = {w1t_dev, b1_dev, w2c_dev, b2c_dev, w2a_t_dev, b2a_dev};
     RolloutArgs a = {n_steps, obs_dev, mask_dev, player_dev, action_dev, reward_dev, done_dev, value_dev, logp_dev, entropy_dev, status_dev,
                      (u64)seed, (u64)counter, (u64 *)counter_dev};
-    const dim3 grid((b->d.n + PF_GAMES - 1) / PF_GAMES), block(64 * PR_WAVES);
     const hipStream_t st = (hipStream_t)stream;
     const bool lid = b->d.rules.tile_pool == POOL_LID;
+    // AZUL_ROLLOUT_KERNEL=1 selects the one-game-per-wave kernel (azul_policy.hpp) for A/B measurements; default: the env side on
+    // the vector pipe, two games per wave (azul_rollout2.hpp)
+    static const int version = [] { const char *e = getenv("AZUL_ROLLOUT_KERNEL"); return (e && e[0] == '1') ? 1 : 2; }();
+    if (version == 2) {
+        const dim3 grid2((b->d.n + PF_GAMES - 1) / PF_GAMES), block2(64 * PR2_WAVES);
+        if (lid && opponent_random) hipLaunchKernelGGL((azul_policy_rollout2_kernel<true, true>), grid2, block2, 0, st, b->d, W, a);
+        else if (lid) hipLaunchKernelGGL((azul_policy_rollout2_kernel<true, false>), grid2, block2, 0, st, b->d, W, a);
+        else if (opponent_random) hipLaunchKernelGGL((azul_policy_rollout2_kernel<false, true>), grid2, block2, 0, st, b->d, W, a);
+        else hipLaunchKernelGGL((azul_policy_rollout2_kernel<false, false>), grid2, block2, 0, st, b->d, W, a);
+        HIP_TRY(hipGetLastError());
+        return AZUL_SUCCESS;
+    }
+    const dim3 grid((b->d.n + PF_GAMES - 1) / PF_GAMES), block(64 * PR_WAVES);
     if (lid && opponent_random) hipLaunchKernelGGL((azul_policy_rollout_kernel<true, true>), grid, block, 0, st, b->d, W, a);
     else if (lid) hipLaunchKernelGGL((azul_policy_rollout_kernel<true, false>), grid, block, 0, st, b->d, W, a);
     else if (opponent_random) hipLaunchKernelGGL((azul_policy_rollout_kernel<false, true>), grid, block, 0, st, b->d, W, a);

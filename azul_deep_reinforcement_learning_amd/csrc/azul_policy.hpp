@@ -459,6 +459,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
 
 #if defined(AZ_PROFILE_SEGMENTS)
     u64 pr_acc[6] = {0, 0, 0, 0, 0, 0}, pr_last = __builtin_amdgcn_s_memtime();
+    const u64 pr_t0 = pr_last, pr_r0 = __builtin_amdgcn_s_memrealtime();      // in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz
 #define PR_STAMP(i) do { u64 now_ = __builtin_amdgcn_s_memtime(); pr_acc[i] += now_ - pr_last; pr_last = now_; } while (0)
 #else
 #define PR_STAMP(i) do { } while (0)
@@ -560,7 +561,14 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
         }
     }
 #if defined(AZ_PROFILE_SEGMENTS)
-    if (l == 0u && w == 5u) for (int i = 0; i < 5; i++) atomicAdd((unsigned long long *)(b.prof + i), (unsigned long long)pr_acc[i]);
+    if (l == 0u && w == 5u) {
+        for (int i = 0; i < 5; i++) atomicAdd((unsigned long long *)(b.prof + i), (unsigned long long)pr_acc[i]);
+        atomicAdd((unsigned long long *)(b.prof + 6), (unsigned long long)(__builtin_amdgcn_s_memtime() - pr_t0));
+        const u64 pr_r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd((unsigned long long *)(b.prof + 7), (unsigned long long)(pr_r1 - pr_r0));
+        atomicMax((unsigned long long *)(b.prof + 5), (unsigned long long)((1ull << 62) - pr_r0));     // earliest loop start of any workgroup
+        atomicMax((unsigned long long *)(b.prof + 8), (unsigned long long)pr_r1);                      // latest loop end
+    }
 #endif
     if (live) {
         game_store(g, rec);

@@ -1,0 +1,505 @@
+// azul_rollout2.hpp -- the persistent policy rollout (row N1 / N2: the batched NNRunner.run_episode loop, nn_runner.py:17-47) with the
+// ENV SIDE ON THE VECTOR PIPE: a workgroup of 8 waves owns 16 games for a whole window, wave w plays games 2w and 2w + 1 in its two
+// 32-lane halves with azul_selfplay2.hpp's rules (state in VGPRs, half-uniform), and the same 8 waves run the network on the f32
+// matrix cores between the env phases.  Included by azul_kernels.hip after azul_policy.hpp.
+//
+// Why: in azul_policy_rollout_kernel (16 waves, one game per wave, azul_core.hpp) the env phase was 40 % (policy on both sides) to
+// 50 % (RandomAgent opponent) of a move: sixteen waves run scalar-heavy rule code on the CU's ONE scalar ALU, and every move waits
+// for the slowest of the sixteen games (a round end somewhere in 78 % of the moves).  tools/rollout_profile.py: env step 6.2 k +
+// waiting for the slowest 7.2 k of 33.2 k cycles per move.  Here a move's env work is ~500 vector instructions per PAIR of games.
+//
+// Arithmetic per output element is unchanged (the same k-ordered v_mfma_f32_16x16x4_f32 chain per hidden unit / logit, the same
+// critic summation, the same head), and the rules are azul_selfplay2.hpp's (byte-identical to azul_core.hpp's, tests/test_gpu_selfplay.py):
+// the trajectories are bit-identical to the per-move path and to the one-game-per-wave rollout kernel (tests/test_policy_bridge.py,
+// tests/test_full_size_configs.py).
+// Reference lines: azulnet/azul.py:296-313 (step), azulnet/game_runner.py:43-55 (GameRunner.step), :56-72 (get_state), :76-85 (reset),
+// :87-97 (RandomAgent); azulnet/nn_runner.py:17-47.
+#pragma once
+
+namespace az2 {
+
+// ---- observation: game_runner.py:56-72, 136 values; value j of my game for j = lane + 32 i ------------------------------------------
+// (layout as azul_core.hpp's observe: cells 0..30 | pattern_lines[order[0]] | pattern_lines[order[1]] | walls[order[0]] | walls[order[1]] |
+// floors | scores | next first player, seen from player `persp`)
+template <int I>
+AZ_FN u32 observe_val2(const G2 &g, u32 o0 /* half-uniform: 0 / 1 */, u32 l)
+{
+    const u32 cpa = o0 ? g.cp1 : g.cp0, cpb = o0 ? g.cp0 : g.cp1;
+    const u32 wall_a = o0 ? g.wall1 : g.wall0, wall_b = o0 ? g.wall0 : g.wall1;
+    if (I == 0) {
+        const u32 pa0 = hread(cpa, 0u);
+        return l < 31u ? g.cs : pa0;                                   // j = 31: order[0]'s cell 0
+    }
+    if (I == 1) {                                                       // j = 32 + l: order[0] cells 1..24 (l < 24), order[1] cells 0..7
+        const u32 va = hread(cpa, l + 1u), vb = hread(cpb, l - 24u);
+        return l < 24u ? va : vb;
+    }
+    if (I == 2) {                                                       // j = 64 + l: order[1] cells 8..24 (l < 17), walls[order[0]] bits 0..14
+        const u32 vb = hread(cpb, l + 8u);
+        return l < 17u ? vb : (wall_a >> ((l - 17u) & 31u)) & 1u;
+    }
+    if (I == 3)                                                         // j = 96 + l: walls[order[0]] bits 15..24 (l < 10), walls[order[1]] bits 0..21
+        return l < 10u ? (wall_a >> (l + 15u)) & 1u : (wall_b >> ((l - 10u) & 31u)) & 1u;
+    // j = 128 + l (l < 8): walls[order[1]] bits 22..24, floors, scores, next first player
+    const u32 floor_a = o0 ? g.floor1 : g.floor0, floor_b = o0 ? g.floor0 : g.floor1;
+    const i32 score_a = o0 ? g.score1 : g.score0, score_b = o0 ? g.score0 : g.score1;
+    const u32 pnfp = g.nfp > 0u ? (((g.nfp - 1u - o0) & 1u) + 1u) : 0u;     // game_runner.py:58-61
+    u32 v = (wall_b >> ((l + 22u) & 31u)) & 1u;
+    v = l == 3u ? floor_a : v;
+    v = l == 4u ? floor_b : v;
+    v = l == 5u ? (u32)score_a : v;
+    v = l == 6u ? (u32)score_b : v;
+    v = l == 7u ? pnfp : v;
+    return v;
+}
+
+// writes the 136 floats of my game to `lds_row` (the network's A operand) and to `glob` (trajectory slot)
+AZ_FN void observe2(const G2 &g, u32 persp, float *lds_row, float *glob, u32 l)
+{
+    const u32 o0 = persp & 1u;
+    float v0 = (float)(i32)observe_val2<0>(g, o0, l), v1 = (float)(i32)observe_val2<1>(g, o0, l), v2 = (float)(i32)observe_val2<2>(g, o0, l),
+          v3 = (float)(i32)observe_val2<3>(g, o0, l), v4 = (float)(i32)observe_val2<4>(g, o0, l);
+    lds_row[l] = v0; lds_row[l + 32u] = v1; lds_row[l + 64u] = v2; lds_row[l + 96u] = v3;
+    glob[l] = v0; glob[l + 32u] = v1; glob[l + 64u] = v2; glob[l + 96u] = v3;
+    if (l < 8u) { lds_row[l + 128u] = v4; glob[l + 128u] = v4; }
+}
+
+// ---- RandomAgent.get_a_output (game_runner.py:87-97): selfplay_step2's decision as a function --------------------------------------
+// Returns false when nothing is legal (ValueError in the reference, raised BEFORE random() is called: no words consumed).
+AZ_FN bool random_agent2(const Mask2 &m, Rng2 &r, const Tab2 &T, const K2 &k, u32 &code)
+{
+    const u32 l = k.l;
+    const u32 c0 = __popc(m.m[0]), c1 = __popc(m.m[1]), c2 = __popc(m.m[2]), c3 = __popc(m.m[3]), c4 = __popc(m.m[4]), c5 = __popc(m.m[5]);
+    const u32 J = c0;
+    const u32 p1 = c0, p2 = p1 + c1, p3 = p2 + c2, p4 = p3 + c3, p5 = p4 + c4, L = p5 + c5;
+    code = 0;
+    if (L == 0u) return false;
+    const u32 M = L - J, Mc = M ? M : 1u;
+    const double2 fs = T.fs[8u * (J < 31u ? J : 30u) + 31u - (u32)__builtin_clz(Mc)];
+    const double sJ = fs.y;
+    const double total = ((double)M + (M ? fs.x : sJ)) + 0.0;
+    const double x = rng2_random(r, l) * total;
+    const double d = x - sJ;
+    const u32 fl = (u32)d;
+    const double fr = d - (double)fl;
+    u32 kg = J + fl + 1u;
+    const bool edge = (x < sJ) | !(fr > 1e-9 && fr < 1.0 - 1e-9) | (fl + 1u > M);
+    if (AZ_UNLIKELY(edge)) kg = sample_slow2(T, x, sJ, J, M, L);
+    const u32 want = kg - 1u;
+    const bool g1 = want >= p1, g2 = want >= p2, g3 = want >= p3, g4 = want >= p4, g5 = want >= p5;
+    const u32 mword = g5 ? m.m[5] : g4 ? m.m[4] : g3 ? m.m[3] : g2 ? m.m[2] : g1 ? m.m[1] : m.m[0];
+    const u32 base = g5 ? p5 : g4 ? p4 : g3 ? p3 : g2 ? p2 : g1 ? p1 : 0u;
+    const u32 prow_ = (u32)g1 + (u32)g2 + (u32)g3 + (u32)g4 + (u32)g5;
+    const bool hit = (((mword >> l) & 1u) != 0u) & ((u32)__popc(mword & ((1u << l) - 1u)) == want - base);
+    const u32 ln = (u32)__builtin_ctz(hb(hit) | 0x80000000u);
+    code = hbcast(k.lcode, ln) | (prow_ << 13) | ((30u * prow_ + ln) << 17);
+    return true;
+}
+
+// the same packing for an action given by number (azul_core.hpp's action_code)
+AZ_FN u32 action_code2(u32 a, const K2 &k)
+{
+    const u32 prow_ = a / 30u, ln = a - 30u * prow_;
+    return hbcast(k.lcode, ln) | (prow_ << 13) | (a << 17);
+}
+
+// ---- Azul.step's body for a legal move (azul_core.hpp's apply_step: move_and_score + new_round), what-if caches kept ----------------
+template <bool LID>
+AZ_FN u32 apply_step2(G2 &g, u32 code, Rng2 &r, u64 margin, const K2 &k)
+{
+    const u32 me = me2(g);
+    const bool filled = do_move2<LID>(g, code, g.B, k.l);               // azul.py:304
+    i32 wc = me ? g.wc1 : g.wc0;
+    if (wave_any(filled)) {
+        const i32 fresh = wall_points2(me ? g.wall1 : g.wall0, full_lines2(me ? g.cp1 : g.cp0, k), k);
+        wc = filled ? fresh : wc;
+    }
+    const i32 wi = clamp0((me ? g.score1 : g.score0) + floor_penalty(me ? g.floor1 : g.floor0) + wc);
+    g.wc0 = me ? g.wc0 : wc; g.wc1 = me ? wc : g.wc1;
+    g.wi0 = me ? g.wi0 : wi; g.wi1 = me ? wi : g.wi1;
+    g.B = hb(g.cs != 0u) & 0x7fffffffu;
+    const bool eor = g.B == 0u;                                        // :306
+    g.cur = eor ? g.cur : (g.cur < 2u ? g.cur + 1u : 1u);              // :313
+    u32 st = ST_OK;
+    // (rare events are tested per wave and kept out of line: two waves per SIMD cannot hide a taken branch's instruction refetch)
+    if (AZ_UNLIKELY(wave_any(eor))) {
+        if (eor) {
+            count_score2<LID>(g, k);                                   // :307
+            if (g.over) g.eog = 1;                                     // :308-309
+            else st = new_round2<LID>(g, r, margin, k);                // :311
+        }
+    }
+    return st;
+}
+
+// Azul.step with the legality test of azul.py:298-302 (azul_core.hpp's checked_step); `m` is the mask of the current state
+template <bool LID>
+AZ_FN u32 checked_step2(G2 &g, i32 a, const Mask2 &m, Rng2 &r, u64 margin, const K2 &k)
+{
+    if (g.eog) return ST_GAME_ENDED;
+    if (a < 0 || a >= 180) return ST_BAD_ACTION;
+    const u32 row = (u32)a / 30u, bit = (u32)a - 30u * row;
+    const u32 word = row == 0u ? m.m[0] : row == 1u ? m.m[1] : row == 2u ? m.m[2] : row == 3u ? m.m[3] : row == 4u ? m.m[4] : m.m[5];
+    if (((word >> bit) & 1u) == 0u) return ST_ILLEGAL_MOVE;             // state untouched
+    return apply_step2<LID>(g, action_code2((u32)a, k), r, margin, k);
+}
+
+AZ_FN u32 mask_count2(const Mask2 &m) { return __popc(m.m[0]) + __popc(m.m[1]) + __popc(m.m[2]) + __popc(m.m[3]) + __popc(m.m[4]) + __popc(m.m[5]); }
+
+AZ_FN void episode_stats2(const G2 &g, const Counters2 &cnt, u32 l)
+{
+    if (l == 0u) {
+        for (u32 q = 0; q < 10u; q++) cnt.stat_sum[q] += game_stat2(g, q);
+        *cnt.episodes += 1ull;
+    }
+}
+
+template <bool LID>
+AZ_FN u32 reset2(G2 &g, u32 first_player, Rng2 &r, u64 margin, const K2 &k)
+{
+    u32 st = episode_reset2<LID>(g, first_player, r, margin, k);
+    prime2(g, k);
+    return st;
+}
+
+// One env move of policy-driven self-play (azul_kernels.hip's env_policy_step: the same decisions in the same order, with ONE reset site)
+template <bool LID>
+AZ_FN u32 policy_step2(G2 &g, i32 av, u32 first_player, Rng2 &r, u64 margin, const Counters2 &cnt, const K2 &k, i32 &rew, u32 &dn)
+{
+    rew = 0; dn = 0;
+    Mask2 m;
+    legal_mask2(g, k, m);
+    // "no action" is legitimate only when nothing is legal (hazard H3)
+    const bool stuck = (av < 0) & (g.eog == 0u) & (mask_count2(m) == 0u);
+    u32 st = ST_OK;
+    bool restart = false;
+    if (!stuck) {
+        st = checked_step2<LID>(g, av, m, r, margin, k);
+        const bool dirty = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION);
+        if (dirty) {
+            g.moves += 1u;
+            const i32 phi = g.wi0 - g.wi1;                             // game_runner.py:48-50 (the what-if caches are current)
+            rew = phi - g.pscore;
+            g.pscore = phi;
+            dn = g.over ? 1u : 0u;                                     // is_end_of_game(): the walls, not the record's flag
+            restart = dn && st == ST_OK;
+        } else if (st == ST_GAME_ENDED) {                               // a finished game handed in: restart the slot, report done
+            dn = 1u;
+            restart = true;
+        }
+    }
+    if (AZ_UNLIKELY(wave_any(stuck | restart))) {
+        if (stuck | restart) {
+            if (stuck) { if (k.l == 0u) *cnt.stuck += 1u; dn = 2u; }
+            else if (st == ST_OK) episode_stats2(g, cnt, k.l);         // (a game handed in finished is not counted: st == ST_GAME_ENDED)
+            u32 st0 = reset2<LID>(g, first_player, r, margin, k);
+            st = stuck ? (st0 ? st0 : (u32)ST_STUCK) : st0;
+        }
+    }
+    return st;
+}
+
+// GameRunner's opponent loop (game_runner.py:46-47 / :84): azul_core.hpp's runner_opponent_loop
+template <bool LID>
+AZ_FN u32 opponent_loop2(G2 &g, Rng2 &r, const Tab2 &T, u64 margin, const K2 &k, bool until_player1_only)
+{
+#pragma unroll 1
+    for (u32 guard = 0; guard < 4096u; guard++) {
+        Mask2 m;
+        legal_mask2(g, k, m);
+        const bool keep = until_player1_only ? (g.cur != 1u) : ((g.cur != 1u || mask_count2(m) < 2u) && !g.over);
+        if (!keep) break;
+        u32 code;
+        if (!random_agent2(m, r, T, k, code)) return ST_STUCK;
+        if (g.eog) return ST_GAME_ENDED;
+        u32 st = apply_step2<LID>(g, code, r, margin, k);
+        if (st) return st;
+        g.moves += 1u;
+    }
+    return ST_OK;
+}
+
+// One AGENT step of NNRunner.run_episode (azul_kernels.hip's env_agent_step over azul_core.hpp's runner_step, statement for statement)
+template <bool LID>
+AZ_FN u32 agent_step2(G2 &g, i32 av, u32 first_player, Rng2 &r, const Tab2 &T, u64 margin, const Counters2 &cnt, const K2 &k, i32 &rew, u32 &dn)
+{
+    rew = 0;
+    dn = g.over ? 1u : 0u;
+    Mask2 m;
+    legal_mask2(g, k, m);
+    u32 st = checked_step2<LID>(g, av, m, r, margin, k);                // game_runner.py:44
+    if (!st) {
+        g.moves += 1u;                                                  // :45
+        st = opponent_loop2<LID>(g, r, T, margin, k, false);            // :46-47
+        if (!st) {
+            const i32 phi = g.wi0 - g.wi1;                             // :48-50
+            rew = phi - g.pscore;                                      // :51
+            g.pscore = phi;                                            // :52
+            dn = g.over ? 1u : 0u;                                     // :55
+        }
+    }
+    const bool dirty = !(st == ST_ILLEGAL_MOVE || st == ST_BAD_ACTION);
+    if (st == ST_STUCK) { if (k.l == 0u) *cnt.stuck += 1u; dn = 2u; rew = 0; }   // hazard H3: nobody can move
+    else if (st == ST_GAME_ENDED) dn = 1u;
+    else if (st == ST_OK && dn) episode_stats2(g, cnt, k.l);
+    if (dirty && dn) {
+        u32 st2 = reset2<LID>(g, first_player, r, margin, k);
+        if (!st2) st2 = opponent_loop2<LID>(g, r, T, margin, k, true);
+        if (st == ST_OK) st = st2;
+    }
+    return st;
+}
+
+} // namespace az2
+
+constexpr u32 PR2_WAVES = 8, PR2_AHEAD = 8;
+
+// layer 1 of one wave: NP pairs of adjacent hidden columns per lane (8-byte loads), 136-deep, one 16-row tile
+template <int NP>
+__device__ __forceinline__ void pr2_layer1(const __amdgpu_buffer_rsrc_t rs1, u32 voffA, u32 voffB, const float *ap, pf_f32x4 (&acc)[4])
+{
+    float2 bwA[PF_IN / 4], bwB[PF_IN / 4];
+#define PR2_LOAD1(vo, s) __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs1, vo, (4 * (s)) * PF_H2 * 4, 0))
+#pragma unroll
+    for (int s = 0; s < (int)PR2_AHEAD; s++) { bwA[s] = PR2_LOAD1(voffA, s); if (NP == 2) bwB[s] = PR2_LOAD1(voffB, s); }
+    float an = ap[0];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < PF_IN / 4; s++) {
+        if (s + (int)PR2_AHEAD < PF_IN / 4) { bwA[s + PR2_AHEAD] = PR2_LOAD1(voffA, s + PR2_AHEAD); if (NP == 2) bwB[s + PR2_AHEAD] = PR2_LOAD1(voffB, s + PR2_AHEAD); }
+        const float av = an;
+        if (s + 1 < PF_IN / 4) an = ap[4 * (s + 1)];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bwA[s].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bwA[s].y, acc[1], 0, 0, 0);
+        if (NP == 2) {
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bwB[s].x, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bwB[s].y, acc[3], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef PR2_LOAD1
+}
+
+// layer 2 of one wave: NT logit columns per lane (NT == 2: one 8-byte load, NT == 1: one 4-byte load per k-step), 180-deep
+template <int NT>
+__device__ __forceinline__ void pr2_layer2(const __amdgpu_buffer_rsrc_t rs2, u32 voff, const float *ap, pf_f32x4 &acc0, pf_f32x4 &acc1)
+{
+    float2 bw[PF_HID / 4];
+#define PR2_LOAD2(s) (NT == 2 ? __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs2, voff, (4 * (s)) * PF_ACT * 4, 0)) \
+                              : make_float2(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, voff, (4 * (s)) * PF_ACT * 4, 0)), 0.f))
+#pragma unroll
+    for (int s = 0; s < (int)PR2_AHEAD; s++) bw[s] = PR2_LOAD2(s);
+    float an = ap[0];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < PF_HID / 4; s++) {
+        if (s + (int)PR2_AHEAD < PF_HID / 4) bw[s + PR2_AHEAD] = PR2_LOAD2(s + PR2_AHEAD);
+        const float av = an;
+        if (s + 1 < PF_HID / 4) an = ap[4 * (s + 1)];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].x, acc0, 0, 0, 0);
+        if (NT == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].y, acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef PR2_LOAD2
+}
+
+template <bool LID, bool OPP>
+__global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(BatchDev b, PolicyWeights W, RolloutArgs a)
+{
+    __shared__ float obsS[PF_GAMES * PF_OBS_STRIDE];
+    __shared__ float hidS[PF_GAMES * PF_HID_STRIDE];
+    __shared__ float lgS[PF_GAMES * PF_LOG_STRIDE];
+    __shared__ float w2cS[PF_HID];
+    __shared__ float b1S[PF_H2 + 24], b2aS[PF_ACT + 12];
+    __shared__ u32 mtS[PF_GAMES][624];
+    __shared__ double tab_lds[T_WORDS];
+    __shared__ double2 tabfs_lds[T_ROWS * T_BINADES];
+    __shared__ u64 maskS[PF_GAMES][4];
+    __shared__ i32 actS[PF_GAMES];
+    const u32 tid = threadIdx.x, lane = tid & 63u, l = lane & 31u, half = lane >> 5, c = lane & 15u, q = (lane >> 4) & 3u;
+    const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const u32 n = b.n, g0 = blockIdx.x * PF_GAMES, gl = 2u * w + half, gi = g0 + gl;
+    const bool live = gi < n;
+    const u32 gic = live ? gi : n - 1u;
+    u64 counter = a.counter;
+    if (a.counter_dev) counter += a.counter_dev[0];
+    if (tid < (u32)PF_HID) w2cS[tid] = W.w2c[tid];
+    if (tid < (u32)(PF_H2 + 24)) b1S[tid] = tid < (u32)PF_H2 ? W.b1[tid] : 0.f;
+    if (tid < (u32)(PF_ACT + 12)) b2aS[tid] = tid < (u32)PF_ACT ? W.b2a[tid] : 0.f;
+    if (OPP) {
+        for (u32 i = tid; i < (u32)T_WORDS; i += 64u * PR2_WAVES) tab_lds[i] = b.T[i];
+        for (u32 i = tid; i < (u32)(T_ROWS * T_BINADES); i += 64u * PR2_WAVES) tabfs_lds[i] = make_double2(b.T[i], b.T[T_ROWS * T_BINADES + i / T_BINADES]);
+    }
+    const float b2c_v = W.b2c[0];
+
+    // matrix-phase constants of this wave: layer 2 columns 32w + 2c + j (waves 0..3) or 128 + 16 (w - 4) + c (waves 4..7) -- three
+    // 16x16 tiles per SIMD (waves w and w + 4 share one); layer 1 likewise with twice the tiles (see there)
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)W.w1t, 0, PF_IN * PF_H2 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)W.w2a_t, 0, PF_HID * PF_ACT * 4, 0x00020000);
+    const bool two = w < 4u;
+#define PR2_L2COL0 (two ? 32u * w + 2u * c : 128u + 16u * (w - 4u) + c)
+
+    // env state of this half's game
+    az2::K2 k;
+    az2::k2_init(k);
+    az2::Tab2 tab = {tab_lds, tab_lds + T_ROWS * T_BINADES, tabfs_lds};
+    az2::G2 g;
+    uint8_t *rec = b.state + (size_t)gic * AZUL_RECORD_BYTES;
+    az2::g2_load(g, rec, l);
+    az2::prime2(g, k);
+    az2::Rng2 r;
+    u32 *gmt = b.mt + (size_t)gic * 624u;
+    az2::rng2_open(r, gmt, mtS[gl], b.mtpos[gic], l);
+    const u64 margin = b.draw_margin;
+    az2::Counters2 cnt = {b.episodes + gic, b.stuck + gic, b.stat_sum + (size_t)gic * 10};
+    u32 st_last = ST_OK;
+    float *orow = obsS + gl * PF_OBS_STRIDE;
+    __syncthreads();                                     // tables / biases staged
+
+    // observation + legal mask of the current state -> LDS (network / head) and trajectory slot `slot`
+    auto publish = [&](u32 slot) {
+        az2::Mask2 m;
+        az2::legal_mask2(g, k, m);
+        const size_t cell = (size_t)slot * n + gi;
+        uint8_t *row = a.mask + cell * AZUL_NUM_ACTIONS + l;
+        if (l < 30u) {
+#pragma unroll
+            for (u32 ww = 0; ww < 6u; ww++) row[30u * ww] = (uint8_t)m.bit[ww];
+        }
+        if (l == 0u) {                                   // the 180 bits packed: the six 30-bit row words concatenated
+            maskS[gl][0] = (u64)m.m[0] | ((u64)m.m[1] << 30) | ((u64)m.m[2] << 60);
+            maskS[gl][1] = ((u64)m.m[2] >> 4) | ((u64)m.m[3] << 26) | ((u64)m.m[4] << 56);
+            maskS[gl][2] = ((u64)m.m[4] >> 8) | ((u64)m.m[5] << 22);
+            a.player[cell] = (uint8_t)g.cur;
+        }
+        az2::observe2(g, OPP ? 0u : az2::me2(g), orow, a.obs + cell * PF_IN, l);
+    };
+    if (live) publish(0u);
+    else {
+        orow[l] = 0.f; orow[l + 32u] = 0.f; orow[l + 64u] = 0.f; orow[l + 96u] = 0.f;
+        if (l < 8u) orow[l + 128u] = 0.f;
+        if (l == 0u) { maskS[gl][0] = 0; maskS[gl][1] = 0; maskS[gl][2] = 0; }
+    }
+
+#if defined(AZ_PROFILE_SEGMENTS)
+    u64 pr_acc[6] = {0, 0, 0, 0, 0, 0}, pr_last = __builtin_amdgcn_s_memtime();
+    const u64 pr_t0 = pr_last, pr_r0 = __builtin_amdgcn_s_memrealtime();
+#define PR2_STAMP(i) do { u64 now_ = __builtin_amdgcn_s_memtime(); pr_acc[i] += now_ - pr_last; pr_last = now_; } while (0)
+#else
+#define PR2_STAMP(i) do { } while (0)
+#endif
+#pragma unroll 1
+    for (int t = 0; t < a.n_steps; t++) {
+        const size_t row_t = (size_t)t * n;
+        PR2_STAMP(0);                                    // own env step + publish
+        lds_barrier();                                   // observations and mask bits of all 16 games are in LDS
+        PR2_STAMP(1);                                    // waiting for the slowest env wave
+        {
+            // layer 1: pairs of adjacent hidden columns per lane (one 8-byte load per k-step and pair: a 16-lane group reads 128 contiguous
+            // bytes of a k-row).  Waves 0..3 own two pairs (columns 64w + 2c + j and 64w + 32 + 2c + j), waves 4..7 one (256 + 32 (w - 4) +
+            // 2c + j): 24 tiles over 8 waves, six per SIMD.
+            const u32 colA = two ? 64u * w + 2u * c : 256u + 32u * (w - 4u) + 2u * c, colB = colA + 32u;
+            const bool liveA = colA < (u32)PF_H2, liveB = two && colB < (u32)PF_H2;
+            const u32 voffA = ((liveA ? colA : 0u) + q * (u32)PF_H2) * 4u, voffB = ((liveB ? colB : 0u) + q * (u32)PF_H2) * 4u;
+            pf_f32x4 acc[4];
+            for (int j = 0; j < 4; j++) acc[j] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
+            const float *ap = obsS + c * PF_OBS_STRIDE + q;
+            if (two) pr2_layer1<2>(rs1, voffA, voffB, ap, acc);
+            else pr2_layer1<1>(rs1, voffA, voffB, ap, acc);
+            for (int rr = 0; rr < 4; rr++) {             // C layout: column = lane & 15, row = 4 (lane >> 4) + rr
+                float *hp = hidS + (4u * q + rr) * PF_HID_STRIDE;
+                if (liveA) {
+                    const float h0 = acc[0][rr] + b1S[colA], h1 = acc[1][rr] + b1S[colA + 1u];
+                    hp[colA] = h0 > 0.f ? h0 : 0.f;      // F.relu, model.py:24/30
+                    hp[colA + 1u] = h1 > 0.f ? h1 : 0.f;
+                }
+                if (liveB) {
+                    const float h0 = acc[2][rr] + b1S[colB], h1 = acc[3][rr] + b1S[colB + 1u];
+                    hp[colB] = h0 > 0.f ? h0 : 0.f;
+                    hp[colB + 1u] = h1 > 0.f ? h1 : 0.f;
+                }
+            }
+        }
+        lds_barrier();
+        PR2_STAMP(2);                                    // layer 1 (incl. barrier)
+        {
+            // layer 2 (actor)
+            const u32 col0 = PR2_L2COL0;
+            const bool live2 = col0 < (u32)PF_ACT;
+            const u32 voff = ((live2 ? col0 : 0u) + q * (u32)PF_ACT) * 4u;
+            pf_f32x4 acc0 = (pf_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            const float *ap = hidS + c * PF_HID_STRIDE + PF_HID + q;
+            if (two) pr2_layer2<2>(rs2, voff, ap, acc0, acc1);
+            else pr2_layer2<1>(rs2, voff, ap, acc0, acc1);
+            if (live2)
+                for (int rr = 0; rr < 4; rr++) {
+                    float *lp = lgS + (4u * q + rr) * PF_LOG_STRIDE + col0;
+                    lp[0] = acc0[rr] + b2aS[col0];
+                    if (two) lp[1] = acc1[rr] + b2aS[col0 + 1u];
+                }
+        }
+        lds_barrier();
+        PR2_STAMP(3);                                    // layer 2 + critic (incl. barrier)
+        if (w < 4u) {
+            // head: waves 0..3 (one per SIMD) sample four games each, 16 lanes per game
+            const u32 hrow = 4u * w + q, hg = g0 + hrow;
+            float x[HEAD_PER_LANE];
+            const float *lg = lgS + hrow * PF_LOG_STRIDE + (c < 15u ? 12u * c : 0u);
+            for (int j = 0; j < HEAD_PER_LANE; j++) x[j] = lg[j];
+            const u64 M0 = maskS[hrow][0], M1 = maskS[hrow][1], M2 = maskS[hrow][2];
+            const u32 bitpos = 12u * c, word = bitpos >> 6, off = bitpos & 63u;
+            const u64 lo = word == 0u ? M0 : (word == 1u ? M1 : M2), hi = word == 0u ? M1 : M2;
+            u64 field = lo >> off;
+            if (off > 52u) field |= hi << (64u - off);
+            const u32 okbits = c < 15u ? (u32)field & 0xfffu : 0u;
+            policy_head_rows(x, okbits, a.seed, counter + (u64)t, hg < n ? hg : n - 1u, lane, hg < n, a.action + row_t, a.logp + row_t,
+                             a.entropy + row_t, b.id_base, actS + 4u * w);
+        } else if (w == 7u) {
+            // the critic, on a wave that idles during the head, summed exactly like azul_policy_forward_kernel: lane (row c, quarter q)
+            // sums k = q (mod 4), then the quarters are added (model.py:22-26)
+            float sum = 0.f;
+            const float *hp = hidS + c * PF_HID_STRIDE;
+#pragma unroll
+            for (int s = 0; s < PF_HID / 4; s++) sum = fmaf(hp[4 * s + q], w2cS[4 * s + q], sum);
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            if (q == 0u && g0 + c < n) a.value[row_t + g0 + c] = sum + b2c_v;
+        }
+        lds_barrier();
+        PR2_STAMP(4);                                    // head (incl. barrier)
+        if (live) {
+            const i32 av = actS[gl];
+            i32 rew = 0;
+            u32 dn = 0;
+            st_last = OPP ? az2::agent_step2<LID>(g, av, b.rules.first_player, r, tab, margin, cnt, k, rew, dn)
+                          : az2::policy_step2<LID>(g, av, b.rules.first_player, r, margin, cnt, k, rew, dn);
+            if (l == 0u) { a.reward[row_t + gi] = rew; a.done[row_t + gi] = (uint8_t)dn; }
+            publish((u32)t + 1u);
+        }
+    }
+#if defined(AZ_PROFILE_SEGMENTS)
+    if (lane == 0u && w == 5u) {
+        for (int i = 0; i < 5; i++) atomicAdd((unsigned long long *)(b.prof + i), (unsigned long long)pr_acc[i]);
+        const u64 pr_r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd((unsigned long long *)(b.prof + 6), (unsigned long long)(__builtin_amdgcn_s_memtime() - pr_t0));
+        atomicAdd((unsigned long long *)(b.prof + 7), (unsigned long long)(pr_r1 - pr_r0));
+        atomicMax((unsigned long long *)(b.prof + 5), (unsigned long long)((1ull << 62) - pr_r0));
+        atomicMax((unsigned long long *)(b.prof + 8), (unsigned long long)pr_r1);
+    }
+#endif
+    if (live) {
+        az2::g2_store(g, rec, l);
+        az2::rng2_close(r, gmt, b.mtpos + gi, l);
+        if (a.status && l == 0u) a.status[gi] = (uint8_t)st_last;
+    }
+    if (a.counter_dev && tid == 0u) {
+        __threadfence();
+        u64 done_blocks = atomicAdd((unsigned long long *)(a.counter_dev + 1), 1ull);
+        if (done_blocks == (u64)gridDim.x - 1ull) {
+            a.counter_dev[1] = 0ull;
+            a.counter_dev[0] += (u64)a.n_steps;
+            __threadfence();
+        }
+    }
+#undef PR2_L2COL0
+}

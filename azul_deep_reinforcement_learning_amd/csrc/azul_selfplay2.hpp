@@ -559,13 +559,14 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
     const u32 p0 = blo & 0xffu, p1 = p0 + ((blo >> 8) & 0xffu), p2 = p1 + ((blo >> 16) & 0xffu), p3 = p2 + (blo >> 24);
     const u32 T0 = p3 + ((u32)(g.box >> 32) & 0xffu);
     const bool pre = batched && T0 >= 20u;               // no refill can happen: draw t sees total T0 - t
-    u32 kthi = 0, risky = 0;
+    u32 kthi = 0, risky = 0, kt0hi = 0;
     if (pre) {
         u32 tt = T0 - l;
         u32 lo = klo * tt, hi = khi * tt + __umulhi(klo, tt);
         u32 mg = (u32)margin;
         risky = hb(((lo < mg) | (lo >= 0u - mg)) & (l < 20u));
         kthi = hi;
+        kt0hi = khi * T0 + __umulhi(klo, T0);            // K_t * T0: for the first guess only
     }
     if (pre && risky == 0u) {
         // The common round: twenty integer draws WITHOUT a 20-step serial loop.  Lane t owns draw t:
@@ -576,7 +577,9 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
         // passes in practice, at most 21.
         const u32 below = (1u << l) - 1u;
         const bool draw = l < 20u;
-        u32 col = (u32)((p0 << 21) <= kthi) + (u32)((p1 << 21) <= kthi) + (u32)((p2 << 21) <= kthi) + (u32)((p3 << 21) <= kthi);
+        // first guess: the colour drawn from the UNDEPLETED box, P_c * 2^53 <= K_t * T0 -- the expected boundaries of draw t,
+        // (P_c - n_c(t)) / (T0 - t) ~ P_c / T0 (any start reaches the same fixed point; this one needs fewer passes)
+        u32 col = (u32)((p0 << 21) <= kt0hi) + (u32)((p1 << 21) <= kt0hi) + (u32)((p2 << 21) <= kt0hi) + (u32)((p3 << 21) <= kt0hi);
         u32 b0 = 0, b1 = 0, b2 = 0, b3 = 0;               // draws with colour <= c, as of the pass that confirmed the colours
 #pragma unroll 1
         for (u32 it = 0; it < 21u; it++) {

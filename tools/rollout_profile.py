@@ -22,22 +22,37 @@ import torch  # noqa: E402
 from azul_deep_reinforcement_learning_amd import BatchedActorCritic, PolicyRollout  # noqa: E402
 
 opp = "random" if "--opponent" in sys.argv else None
+WIN = int(sys.argv[sys.argv.index("--window") + 1]) if "--window" in sys.argv else 32
 torch.manual_seed(0)
-ro = PolicyRollout(BatchedActorCritic(136, 180, 180), n_games=4096, parts=1, window=32, opponent=opp, persistent=True)
+ro = PolicyRollout(BatchedActorCritic(136, 180, 180), n_games=4096, parts=1, window=WIN, opponent=opp, persistent=True)
 for _ in range(3):
     ro.run_window()
 ro.synchronize()
 cyc = np.zeros(9, dtype=np.uint64)
 L.check(L.lib.azul_batch_segment_profile(ro.envs[0]._h, cyc.ctypes.data_as(C.c_void_p), 9, 1))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+with torch.cuda.stream(ro.streams[0]):
+    e0.record()
+ro.run_window()                                            # one launch on its own: first workgroup start .. last workgroup end
+with torch.cuda.stream(ro.streams[0]):
+    e1.record()
+ro.synchronize()
+print("event bracket around that launch (+ the returns scan): %.1f us" % (e0.elapsed_time(e1) * 1e3))
+L.check(L.lib.azul_batch_segment_profile(ro.envs[0]._h, cyc.ctypes.data_as(C.c_void_p), 9, 1))
+span = (float(cyc[8]) - ((1 << 62) - float(cyc[5]))) / 100.0
+print("one launch: loops of the 256 workgroups span %.1f us (earliest start .. latest end); mean loop %.1f us" % (span, float(cyc[7]) / 256 / 100.0))
 windows = 10
 for _ in range(windows):
     ro.run_window()
 ro.synchronize()
 L.check(L.lib.azul_batch_segment_profile(ro.envs[0]._h, cyc.ctypes.data_as(C.c_void_p), 9, 1))
 names = ["env step + publish (own game)", "wait for the slowest env wave", "layer 1 (+ barrier)", "layer 2 / critic (+ barrier)", "head (+ barrier)"]
-moves = 256 * 32 * windows
+moves = 256 * WIN * windows
 tot = 0.0
 for nm, cv in zip(names, cyc):
     print("%-34s %8.0f cycles per move" % (nm, float(cv) / moves))
     tot += float(cv) / moves
-print("sum %.0f cycles = %.2f us per move at 2.35 GHz (wave 5 of each workgroup, opponent=%s)" % (tot, tot / 2350.0, opp))
+print("wave 5's loop per launch: %.0f shader cycles, %.1f us of s_memrealtime (100 MHz)" % (float(cyc[6]) / (256 * windows), float(cyc[7]) / (256 * windows) / 100.0))
+ghz = float(cyc[6]) / max(float(cyc[7]), 1.0) * 0.1
+print("sum %.0f cycles per move (wave 5 of each workgroup, opponent=%s); in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz = %.2f GHz"
+      " -> %.2f us per move" % (tot, opp, ghz, tot / ghz / 1e3))

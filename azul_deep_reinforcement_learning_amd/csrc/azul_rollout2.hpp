@@ -164,13 +164,13 @@ AZ_FN u32 reset2(G2 &g, u32 first_player, Rng2 &r, u64 margin, const K2 &k)
 
 // One env move of policy-driven self-play (azul_kernels.hip's env_policy_step: the same decisions in the same order, with ONE reset site)
 template <bool LID>
-AZ_FN u32 policy_step2(G2 &g, i32 av, u32 first_player, Rng2 &r, u64 margin, const Counters2 &cnt, const K2 &k, i32 &rew, u32 &dn)
+AZ_FN u32 policy_step2(G2 &g, i32 av, const Mask2 &m /* of the current state: the one that was published */, u32 first_player, Rng2 &r, u64 margin,
+                        const Counters2 &cnt, const K2 &k, i32 &rew, u32 &dn)
 {
     rew = 0; dn = 0;
-    Mask2 m;
-    legal_mask2(g, k, m);
     // "no action" is legitimate only when nothing is legal (hazard H3)
-    const bool stuck = (av < 0) & (g.eog == 0u) & (mask_count2(m) == 0u);
+    bool stuck = false;
+    if (AZ_UNLIKELY(wave_any(av < 0))) stuck = (av < 0) & (g.eog == 0u) & (mask_count2(m) == 0u);
     u32 st = ST_OK;
     bool restart = false;
     if (!stuck) {
@@ -221,12 +221,11 @@ AZ_FN u32 opponent_loop2(G2 &g, Rng2 &r, const Tab2 &T, u64 margin, const K2 &k,
 
 // One AGENT step of NNRunner.run_episode (azul_kernels.hip's env_agent_step over azul_core.hpp's runner_step, statement for statement)
 template <bool LID>
-AZ_FN u32 agent_step2(G2 &g, i32 av, u32 first_player, Rng2 &r, const Tab2 &T, u64 margin, const Counters2 &cnt, const K2 &k, i32 &rew, u32 &dn)
+AZ_FN u32 agent_step2(G2 &g, i32 av, const Mask2 &m /* of the current state */, u32 first_player, Rng2 &r, const Tab2 &T, u64 margin,
+                       const Counters2 &cnt, const K2 &k, i32 &rew, u32 &dn)
 {
     rew = 0;
     dn = g.over ? 1u : 0u;
-    Mask2 m;
-    legal_mask2(g, k, m);
     u32 st = checked_step2<LID>(g, av, m, r, margin, k);                // game_runner.py:44
     if (!st) {
         g.moves += 1u;                                                  // :45
@@ -281,8 +280,11 @@ __device__ __forceinline__ void pr2_layer1(const __amdgpu_buffer_rsrc_t rs1, u32
 }
 
 // layer 2 of one wave: NT logit columns per lane (NT == 2: one 8-byte load, NT == 1: one 4-byte load per k-step), 180-deep
+// (`draw`: the wave also draws its head rows' uniforms -- Philox does not depend on the logits -- while the first weight fragments are
+// on their way from L2: the matrix pipe would idle there)
 template <int NT>
-__device__ __forceinline__ void pr2_layer2(const __amdgpu_buffer_rsrc_t rs2, u32 voff, const float *ap, pf_f32x4 &acc0, pf_f32x4 &acc1)
+__device__ __forceinline__ void pr2_layer2(const __amdgpu_buffer_rsrc_t rs2, u32 voff, const float *ap, pf_f32x4 &acc0, pf_f32x4 &acc1, bool draw,
+                                           u64 seed, u64 ctr, u32 game, float &u_out)
 {
     float2 bw[PF_HID / 4];
 #define PR2_LOAD2(s) (NT == 2 ? __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs2, voff, (4 * (s)) * PF_ACT * 4, 0)) \
@@ -290,6 +292,8 @@ __device__ __forceinline__ void pr2_layer2(const __amdgpu_buffer_rsrc_t rs2, u32
 #pragma unroll
     for (int s = 0; s < (int)PR2_AHEAD; s++) bw[s] = PR2_LOAD2(s);
     float an = ap[0];
+    __builtin_amdgcn_sched_barrier(0);
+    if (draw) u_out = policy_uniform(seed, ctr, game);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < PF_HID / 4; s++) {
@@ -357,8 +361,8 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     __syncthreads();                                     // tables / biases staged
 
     // observation + legal mask of the current state -> LDS (network / head) and trajectory slot `slot`
+    az2::Mask2 m;                                        // legal mask of the published state: the next env step tests the action against it
     auto publish = [&](u32 slot) {
-        az2::Mask2 m;
         az2::legal_mask2(g, k, m);
         const size_t cell = (size_t)slot * n + gi;
         uint8_t *row = a.mask + cell * AZUL_NUM_ACTIONS + l;
@@ -391,6 +395,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
 #pragma unroll 1
     for (int t = 0; t < a.n_steps; t++) {
         const size_t row_t = (size_t)t * n;
+        float u_head = 0.f;
         PR2_STAMP(0);                                    // own env step + publish
         lds_barrier();                                   // observations and mask bits of all 16 games are in LDS
         PR2_STAMP(1);                                    // waiting for the slowest env wave
@@ -429,8 +434,9 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
             const u32 voff = ((live2 ? col0 : 0u) + q * (u32)PF_ACT) * 4u;
             pf_f32x4 acc0 = (pf_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
             const float *ap = hidS + c * PF_HID_STRIDE + PF_HID + q;
-            if (two) pr2_layer2<2>(rs2, voff, ap, acc0, acc1);
-            else pr2_layer2<1>(rs2, voff, ap, acc0, acc1);
+            const u32 hg_ = g0 + 4u * w + q;             // waves 0..3: the head row of this 16-lane group
+            if (two) pr2_layer2<2>(rs2, voff, ap, acc0, acc1, true, a.seed, counter + (u64)t, b.id_base + (hg_ < n ? hg_ : n - 1u), u_head);
+            else pr2_layer2<1>(rs2, voff, ap, acc0, acc1, false, 0, 0, 0, u_head);
             if (live2)
                 for (int rr = 0; rr < 4; rr++) {
                     float *lp = lgS + (4u * q + rr) * PF_LOG_STRIDE + col0;
@@ -453,7 +459,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
             if (off > 52u) field |= hi << (64u - off);
             const u32 okbits = c < 15u ? (u32)field & 0xfffu : 0u;
             policy_head_rows(x, okbits, a.seed, counter + (u64)t, hg < n ? hg : n - 1u, lane, hg < n, a.action + row_t, a.logp + row_t,
-                             a.entropy + row_t, b.id_base, actS + 4u * w);
+                             a.entropy + row_t, b.id_base, actS + 4u * w, &u_head);
         } else if (w == 7u) {
             // the critic, on a wave that idles during the head, summed exactly like azul_policy_forward_kernel: lane (row c, quarter q)
             // sums k = q (mod 4), then the quarters are added (model.py:22-26)
@@ -471,8 +477,8 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
             const i32 av = actS[gl];
             i32 rew = 0;
             u32 dn = 0;
-            st_last = OPP ? az2::agent_step2<LID>(g, av, b.rules.first_player, r, tab, margin, cnt, k, rew, dn)
-                          : az2::policy_step2<LID>(g, av, b.rules.first_player, r, margin, cnt, k, rew, dn);
+            st_last = OPP ? az2::agent_step2<LID>(g, av, m, b.rules.first_player, r, tab, margin, cnt, k, rew, dn)
+                          : az2::policy_step2<LID>(g, av, m, b.rules.first_player, r, margin, cnt, k, rew, dn);
             if (l == 0u) { a.reward[row_t + gi] = rew; a.done[row_t + gi] = (uint8_t)dn; }
             publish((u32)t + 1u);
         }

@@ -148,7 +148,7 @@ def extras(games):
         "config": {"workload": "BASELINE configs[2]: %d games, ActorCritic(136,180,180) f32 inside azul_batch_policy_rollout, "
                                "one launch per %d-move window" % (games, window), "windows_timed": windows},
         "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "kernel": "azul_policy_rollout_kernel (+ azul_returns_kernel)", "avg_window_ms": kms / windows,
+                     "traffic": None, "kernel": "azul_policy_rollout2_kernel (+ azul_returns_kernel)", "avg_window_ms": kms / windows,
                      "flop_per_env_move": FWD_FLOP_PER_GAME, "event_bracket_ms": kms, "host_elapsed_ms": dt * 1e3}}
     del ro
     torch.cuda.empty_cache()

@@ -289,6 +289,52 @@ def test_persistent_rollout_is_bit_identical_to_the_per_move_path(contract, oppo
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("opponent", [None, "random"])
+def test_rollout_kernel_follows_the_per_move_path_from_unusual_states(contract, opponent):
+    """The paths ordinary self-play rarely reaches, taken on purpose: games handed in without any tile on the table (nothing legal: the
+    policy head answers -1, hazard H3 -> stuck counter, slot restarted), games whose record says "ended" (GameEnded -> done, restarted),
+    and games whose wall already holds a complete row while the record's flag is still clear (is_end_of_game() reads the walls,
+    azul.py:184-191; Azul.step's GameEnded reads the flag, :298-299).  The one-launch-per-window kernel must do what the per-move path
+    does: every trajectory array, the final records, RNG positions, episode and stuck counters."""
+    from azul_deep_reinforcement_learning_amd import PolicyRollout
+    T, n = 12, 64
+    runs = []
+    for persistent in (False, True):
+        torch.manual_seed(3)
+        ro = PolicyRollout(_net(contract, "cuda"), n_games=n, parts=1, seed_base=4242, window=T, use_graph=False, opponent=opponent, persistent=persistent)
+        env = ro.envs[0]
+        recs = env.get_records()
+        raw = recs.view(np.uint8).reshape(n, -1).copy()
+        for g in (3, 20, 41):
+            raw[g, 0:31] = 0                                   # displays, centre and token empty
+        for g in (5, 33):
+            raw[g, 31] |= 0x40                                 # the record's "ended" flag
+        for g in (7, 40, 63):
+            raw[g, 84] |= 0x1f                                 # player 1's wall: row 0 complete
+        env.set_records(raw.view(recs.dtype).reshape(-1))
+        t = ro.traj[0]
+        with torch.cuda.stream(ro.streams[0]):
+            env.observe_all(ro._persp(), t["obs"][T], t["mask"][T], t["player"][T])      # slot 0 of the first window
+        ro.synchronize()
+        wins = []
+        for _ in range(2):
+            tr = ro.run_window()
+            ro.synchronize()
+            wins.append({k: v.clone() for k, v in tr[0].items()})
+        runs.append((wins, env.get_records(), env.get_rng_range()[1], ro.counters()))
+    (wa, ra, pa, ca), (wb, rb, pb, cb) = runs
+    for wi in range(2):
+        for key in ("obs", "mask", "player", "action", "reward", "done", "value", "log_prob", "entropy", "returns"):
+            assert torch.equal(wa[wi][key], wb[wi][key]), (wi, key)
+    assert ra.tobytes() == rb.tobytes() and np.array_equal(pa, pb) and ca == cb
+    d0 = wa[0]["done"][0].cpu().numpy()
+    assert (d0[[5, 33]] == 1).all()                            # GameEnded: reported done, slot restarted
+    if opponent is None:
+        assert ca["stuck"] >= 3 and (d0[[3, 20, 41]] == 2).all()
+    # (GameRunner.step with "no action" is a BAD_ACTION for the agent, game_runner.py:44: such a slot is left as it is)
+
+
+@pytest.mark.gpu
 def test_argmax_action_selection(contract):
     """seed = AZUL_POLICY_ARGMAX: Agent.get_ac_output(action_selection="Max") = np.argmax of the masked softmax (first maximum),
     with the same log-prob / entropy outputs; and a greedy rollout is the same whichever launch structure plays it."""

@@ -253,14 +253,45 @@ AZ_FN u32 agent_step2(G2 &g, i32 av, const Mask2 &m /* of the current state */, 
 
 constexpr u32 PR2_WAVES = 8, PR2_AHEAD = 8;
 
+// The first weight fragments of a matrix phase are REQUESTED A PHASE EARLIER (layer 1's before the env step, layer 2's before layer 1's
+// epilogue) and stay in flight across the LDS-only barriers: the matrix pipe does not wait for L2 after each barrier.
+constexpr int PR2_HOIST1 = 4, PR2_HOIST2 = 8;
+#define PR2_LOAD1(vo, s) __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs1, vo, (4 * (s)) * PF_H2 * 4, 0))
+#define PR2_LOAD2(NT_, s) ((NT_) == 2 ? __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs2, voff, (4 * (s)) * PF_ACT * 4, 0)) \
+                                      : make_float2(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, voff, (4 * (s)) * PF_ACT * 4, 0)), 0.f))
+
+__device__ __forceinline__ void pr2_request1(bool two, const __amdgpu_buffer_rsrc_t rs1, u32 voffA, u32 voffB, float2 (&preA)[PR2_HOIST1],
+                                             float2 (&preB)[PR2_HOIST1])
+{
+#pragma unroll
+    for (int s = 0; s < PR2_HOIST1; s++) preA[s] = PR2_LOAD1(voffA, s);
+    if (two) {
+#pragma unroll
+        for (int s = 0; s < PR2_HOIST1; s++) preB[s] = PR2_LOAD1(voffB, s);
+    }
+}
+
+__device__ __forceinline__ void pr2_request2(bool two, const __amdgpu_buffer_rsrc_t rs2, u32 voff, float2 (&pre)[PR2_HOIST2])
+{
+    if (two) {
+#pragma unroll
+        for (int s = 0; s < PR2_HOIST2; s++) pre[s] = PR2_LOAD2(2, s);
+    } else {
+#pragma unroll
+        for (int s = 0; s < PR2_HOIST2; s++) pre[s] = PR2_LOAD2(1, s);
+    }
+}
+
 // layer 1 of one wave: NP pairs of adjacent hidden columns per lane (8-byte loads), 136-deep, one 16-row tile
 template <int NP>
-__device__ __forceinline__ void pr2_layer1(const __amdgpu_buffer_rsrc_t rs1, u32 voffA, u32 voffB, const float *ap, pf_f32x4 (&acc)[4])
+__device__ __forceinline__ void pr2_layer1(const __amdgpu_buffer_rsrc_t rs1, u32 voffA, u32 voffB, const float *ap, const float2 (&preA)[PR2_HOIST1],
+                                           const float2 (&preB)[PR2_HOIST1], pf_f32x4 (&acc)[4])
 {
     float2 bwA[PF_IN / 4], bwB[PF_IN / 4];
-#define PR2_LOAD1(vo, s) __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs1, vo, (4 * (s)) * PF_H2 * 4, 0))
 #pragma unroll
-    for (int s = 0; s < (int)PR2_AHEAD; s++) { bwA[s] = PR2_LOAD1(voffA, s); if (NP == 2) bwB[s] = PR2_LOAD1(voffB, s); }
+    for (int s = 0; s < PR2_HOIST1; s++) { bwA[s] = preA[s]; if (NP == 2) bwB[s] = preB[s]; }
+#pragma unroll
+    for (int s = PR2_HOIST1; s < (int)PR2_AHEAD; s++) { bwA[s] = PR2_LOAD1(voffA, s); if (NP == 2) bwB[s] = PR2_LOAD1(voffB, s); }
     float an = ap[0];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -276,35 +307,30 @@ __device__ __forceinline__ void pr2_layer1(const __amdgpu_buffer_rsrc_t rs1, u32
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-#undef PR2_LOAD1
 }
 
 // layer 2 of one wave: NT logit columns per lane (NT == 2: one 8-byte load, NT == 1: one 4-byte load per k-step), 180-deep
-// (`draw`: the wave also draws its head rows' uniforms -- Philox does not depend on the logits -- while the first weight fragments are
-// on their way from L2: the matrix pipe would idle there)
+// (`draw`: the wave also draws its head rows' uniforms -- Philox does not depend on the logits -- before the loop)
 template <int NT>
-__device__ __forceinline__ void pr2_layer2(const __amdgpu_buffer_rsrc_t rs2, u32 voff, const float *ap, pf_f32x4 &acc0, pf_f32x4 &acc1, bool draw,
-                                           u64 seed, u64 ctr, u32 game, float &u_out)
+__device__ __forceinline__ void pr2_layer2(const __amdgpu_buffer_rsrc_t rs2, u32 voff, const float *ap, const float2 (&pre)[PR2_HOIST2], pf_f32x4 &acc0,
+                                           pf_f32x4 &acc1, bool draw, u64 seed, u64 ctr, u32 game, float &u_out)
 {
     float2 bw[PF_HID / 4];
-#define PR2_LOAD2(s) (NT == 2 ? __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs2, voff, (4 * (s)) * PF_ACT * 4, 0)) \
-                              : make_float2(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, voff, (4 * (s)) * PF_ACT * 4, 0)), 0.f))
 #pragma unroll
-    for (int s = 0; s < (int)PR2_AHEAD; s++) bw[s] = PR2_LOAD2(s);
+    for (int s = 0; s < PR2_HOIST2; s++) bw[s] = pre[s];
     float an = ap[0];
     __builtin_amdgcn_sched_barrier(0);
     if (draw) u_out = policy_uniform(seed, ctr, game);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < PF_HID / 4; s++) {
-        if (s + (int)PR2_AHEAD < PF_HID / 4) bw[s + PR2_AHEAD] = PR2_LOAD2(s + PR2_AHEAD);
+        if (s + PR2_HOIST2 < PF_HID / 4) bw[s + PR2_HOIST2] = PR2_LOAD2(NT, s + PR2_HOIST2);
         const float av = an;
         if (s + 1 < PF_HID / 4) an = ap[4 * (s + 1)];
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].x, acc0, 0, 0, 0);
         if (NT == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].y, acc1, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
-#undef PR2_LOAD2
 }
 
 template <bool LID, bool OPP>
@@ -385,6 +411,12 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
         if (l == 0u) { maskS[gl][0] = 0; maskS[gl][1] = 0; maskS[gl][2] = 0; }
     }
 
+    const u32 colA = two ? 64u * w + 2u * c : 256u + 32u * (w - 4u) + 2u * c, colB = colA + 32u;
+    const bool liveA = colA < (u32)PF_H2, liveB = two && colB < (u32)PF_H2;
+    const u32 voffA = ((liveA ? colA : 0u) + q * (u32)PF_H2) * 4u, voffB = ((liveB ? colB : 0u) + q * (u32)PF_H2) * 4u;
+    const u32 voff2 = ((PR2_L2COL0 < (u32)PF_ACT ? PR2_L2COL0 : 0u) + q * (u32)PF_ACT) * 4u;
+    float2 preA[PR2_HOIST1], preB[PR2_HOIST1], pre2[PR2_HOIST2];
+    pr2_request1(two, rs1, voffA, voffB, preA, preB);
 #if defined(AZ_PROFILE_SEGMENTS)
     u64 pr_acc[6] = {0, 0, 0, 0, 0, 0}, pr_last = __builtin_amdgcn_s_memtime();
     const u64 pr_t0 = pr_last, pr_r0 = __builtin_amdgcn_s_memrealtime();
@@ -403,14 +435,12 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
             // layer 1: pairs of adjacent hidden columns per lane (one 8-byte load per k-step and pair: a 16-lane group reads 128 contiguous
             // bytes of a k-row).  Waves 0..3 own two pairs (columns 64w + 2c + j and 64w + 32 + 2c + j), waves 4..7 one (256 + 32 (w - 4) +
             // 2c + j): 24 tiles over 8 waves, six per SIMD.
-            const u32 colA = two ? 64u * w + 2u * c : 256u + 32u * (w - 4u) + 2u * c, colB = colA + 32u;
-            const bool liveA = colA < (u32)PF_H2, liveB = two && colB < (u32)PF_H2;
-            const u32 voffA = ((liveA ? colA : 0u) + q * (u32)PF_H2) * 4u, voffB = ((liveB ? colB : 0u) + q * (u32)PF_H2) * 4u;
             pf_f32x4 acc[4];
             for (int j = 0; j < 4; j++) acc[j] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
             const float *ap = obsS + c * PF_OBS_STRIDE + q;
-            if (two) pr2_layer1<2>(rs1, voffA, voffB, ap, acc);
-            else pr2_layer1<1>(rs1, voffA, voffB, ap, acc);
+            if (two) pr2_layer1<2>(rs1, voffA, voffB, ap, preA, preB, acc);
+            else pr2_layer1<1>(rs1, voffA, voffB, ap, preA, preB, acc);
+            pr2_request2(two, rs2, voff2, pre2);         // layer 2's first fragments: in flight across the epilogue and the barrier
             for (int rr = 0; rr < 4; rr++) {             // C layout: column = lane & 15, row = 4 (lane >> 4) + rr
                 float *hp = hidS + (4u * q + rr) * PF_HID_STRIDE;
                 if (liveA) {
@@ -431,12 +461,11 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
             // layer 2 (actor)
             const u32 col0 = PR2_L2COL0;
             const bool live2 = col0 < (u32)PF_ACT;
-            const u32 voff = ((live2 ? col0 : 0u) + q * (u32)PF_ACT) * 4u;
             pf_f32x4 acc0 = (pf_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
             const float *ap = hidS + c * PF_HID_STRIDE + PF_HID + q;
             const u32 hg_ = g0 + 4u * w + q;             // waves 0..3: the head row of this 16-lane group
-            if (two) pr2_layer2<2>(rs2, voff, ap, acc0, acc1, true, a.seed, counter + (u64)t, b.id_base + (hg_ < n ? hg_ : n - 1u), u_head);
-            else pr2_layer2<1>(rs2, voff, ap, acc0, acc1, false, 0, 0, 0, u_head);
+            if (two) pr2_layer2<2>(rs2, voff2, ap, pre2, acc0, acc1, true, a.seed, counter + (u64)t, b.id_base + (hg_ < n ? hg_ : n - 1u), u_head);
+            else pr2_layer2<1>(rs2, voff2, ap, pre2, acc0, acc1, false, 0, 0, 0, u_head);
             if (live2)
                 for (int rr = 0; rr < 4; rr++) {
                     float *lp = lgS + (4u * q + rr) * PF_LOG_STRIDE + col0;
@@ -473,6 +502,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
         }
         lds_barrier();
         PR2_STAMP(4);                                    // head (incl. barrier)
+        pr2_request1(two, rs1, voffA, voffB, preA, preB);        // the next move's layer 1: in flight during the env step
         if (live) {
             const i32 av = actS[gl];
             i32 rew = 0;
@@ -508,4 +538,6 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
         }
     }
 #undef PR2_L2COL0
+#undef PR2_LOAD1
+#undef PR2_LOAD2
 }

@@ -409,20 +409,34 @@ __global__ void __launch_bounds__(256) azul_returns_kernel(const i32 *reward, co
 
 // The same scan over a RING of time slots (absolute step s lives in slot s % ring_steps): one launch walks from the newest step
 // s_end - 1 back over `span` steps, so the return flowing out of a window's first step chains into the window before it.
-__global__ void __launch_bounds__(64) azul_returns_ring_kernel(const i32 *reward, const uint8_t *done, float *out, float gamma, int ring_steps,
-                                                               int s_end, int span, u32 n)
+__global__ void __launch_bounds__(64) azul_returns_ring_kernel(const i32 *__restrict__ reward, const uint8_t *__restrict__ done, float *__restrict__ out,
+                                                               float gamma, int ring_steps, int s_end, int span, u32 n)
 {
     u32 g = blockIdx.x * 64u + threadIdx.x;
     if (g >= n) return;
     float q = 0.f;
     int slot = (s_end - 1) % ring_steps;
-#pragma unroll 8
-    for (int j = 0; j < span; j++) {
-        size_t i = (size_t)slot * n + g;
-        if (done[i]) q = 0.f;
-        q = (float)reward[i] + gamma * q;
-        out[i] = q;
-        slot = slot == 0 ? ring_steps - 1 : slot - 1;
+    // the scan itself is a short dependent chain; what costs is memory latency: sixteen steps' rewards and flags are requested
+    // together (unconditionally: past the span the last slot is read again), then folded in
+    constexpr int RB = 16;
+#pragma unroll 1
+    for (int j = 0; j < span; j += RB) {
+        i32 r[RB];
+        u32 d[RB], at[RB];
+#pragma unroll
+        for (int b = 0; b < RB; b++) {
+            at[b] = (u32)slot * n + g;
+            r[b] = reward[at[b]];
+            d[b] = done[at[b]];
+            if (j + b + 1 < span) slot = slot == 0 ? ring_steps - 1 : slot - 1;
+        }
+#pragma unroll
+        for (int b = 0; b < RB; b++) {
+            if (j + b < span) {
+                q = (float)r[b] + gamma * (d[b] ? 0.f : q);
+                out[at[b]] = q;
+            }
+        }
     }
 }
 
@@ -1025,7 +1039,7 @@ int azul_discounted_returns_ring(const int32_t *reward_ring_dev, const uint8_t *
                                  int ring_steps, int64_t steps_played, int span_steps, int n_games, void *stream)
 {
     if (!reward_ring_dev || !done_ring_dev || !returns_ring_dev || ring_steps <= 0 || steps_played <= 0 || span_steps < 0 ||
-        span_steps > ring_steps || span_steps > steps_played || n_games <= 0)
+        span_steps > ring_steps || span_steps > steps_played || n_games <= 0 || (uint64_t)ring_steps * (uint64_t)n_games >= (1ull << 32))
         return fail(AZUL_ERR_INVALID, "azul_discounted_returns_ring: bad arguments");
     if (span_steps == 0) return AZUL_SUCCESS;
     STREAM_GUARD(stream);

@@ -10,9 +10,11 @@
 #define REP16(x) REP4(x) REP4(x) REP4(x) REP4(x)
 
 // body: S16 groups of 16 scalar adds (4 independent chains) and V16 groups of 16 vector adds, interleaved group by group
-template <int S16, int V16, bool DEP>
+// HALF: only lanes 0..31 stay active (EXEC's upper half is zero): does a wave64 instruction on the 32-wide SIMD then skip its second pass?
+template <int S16, int V16, bool DEP, bool HALF = false>
 __global__ void __launch_bounds__(64) mix_kernel(unsigned *out, int iters)
 {
+    if (HALF && threadIdx.x >= 32) return;
     unsigned s0 = blockIdx.x, s1 = 1, s2 = 2, s3 = 3;
     unsigned v0 = threadIdx.x, v1 = 1, v2 = 2, v3 = 3;
     for (int i = 0; i < iters; i++) {
@@ -86,16 +88,18 @@ int main()
     hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0);
     const int iters = 2000;
     printf("clock %d kHz (nominal); cycles below assume it; one-wave workgroups, waves/SIMD = grid / 1024\n", clk_khz);
-    printf("%-34s %6s %12s %14s\n", "kernel", "w/SIMD", "ms", "cyc/instr/SIMD");
+    printf("%-38s %6s %12s %14s\n", "kernel", "w/SIMD", "ms", "cyc/instr/SIMD");
     const int waves[] = {1, 2, 4, 8};
 #define RUN(name, K, ninstr) for (int w : waves) { \
         double ms = time_ms([&] { hipLaunchKernelGGL(K, dim3(1024 * w), dim3(64), 0, 0, out, iters); }); \
         double cyc = ms * 1e-3 * clk_khz * 1e3; \
-        printf("%-34s %6d %12.3f %14.3f\n", name, w, ms, cyc / ((double)iters * (ninstr) * w)); }
+        printf("%-38s %6d %12.3f %14.3f\n", name, w, ms, cyc / ((double)iters * (ninstr) * w)); }
     RUN("salu x64 independent", (mix_kernel<4, 0, false>), 64)
     RUN("salu x64 dependent", (mix_kernel<4, 0, true>), 64)
     RUN("valu x64 independent", (mix_kernel<0, 4, false>), 64)
     RUN("valu x64 dependent", (mix_kernel<0, 4, true>), 64)
+    RUN("valu x64 independent, EXEC = low half", (mix_kernel<0, 4, false, true>), 64)
+    RUN("valu x64 dependent, EXEC = low half", (mix_kernel<0, 4, true, true>), 64)
     RUN("salu 64 + valu 64 (groups of 16)", (mix_kernel<4, 4, false>), 128)
     RUN("salu 32 + valu 96", (mix_kernel<2, 6, false>), 128)
     RUN("salu 96 + valu 32", (mix_kernel<6, 2, false>), 128)

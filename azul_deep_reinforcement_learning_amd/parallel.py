@@ -4,12 +4,12 @@ per-rank trajectory buffers.  One process per GPU, torch.distribu
 "gloo" in the CPU tests).
 
 What is shipped is the compact per-move record the kernel writes (`packed`: action | done << 8 | reward << 16,
-4 bytes per move) and, optionally, the bit-packed legal mask (24 bytes per move).  Sizing: at ~1.6 G moves/s per GPU
-the compact record is ~6.5 GB/s per GPU -- two orders of magnitude under an xGMI link (7 x ~153 GB/s per GPU, point to
-point) -- while masks would add ~39 GB/s per GPU, i.e. ~270 GB/s of all-gather traffic INTO each of 8 GPUs.  The
-self-play kernel keeps 4 of the 5 wave slots its register budget allows busy on every SIMD for the whole launch, so a
-collective kernel gets little room beside it; the gather is therefore kept small enough to cost little even when it
-serialises with the launches, and the masks (a deterministic function of seed + actions) are only shipped on request.
+4 bytes per move) and, optionally, the bit-packed legal mask (24 bytes per move).  Sizing: at ~2.1 G moves/s per GPU
+the compact record is ~8.5 GB/s per GPU -- two orders of magnitude under an xGMI link (7 x ~153 GB/s per GPU, point to
+point): 59 MB into each GPU per 512-move chunk with 8 ranks, ~0.2 ms against 1.0 ms of compute -- while masks would add
+~50 GB/s per GPU, i.e. ~350 GB/s of all-gather traffic INTO each of 8 GPUs.  The gather is therefore kept small enough to
+cost little even when it serialises with the launches, and the masks (a deterministic function of seed + actions) are
+only shipped on request.
 
 The all-gather is issued asynchronously right after the self-play launch that filled a buffer pair; the next launch
 writes the other pair (double buffering), and a buffer is reused only after its gather has completed.

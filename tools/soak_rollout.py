@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""One-off soak (not a test): the one-launch-per-window rollout kernel against the two-launches-per-move path over many windows
+(dozens of MT19937 regenerations and hundreds of episodes per game): final records, RNG positions, counters and the last window's
+trajectory must be identical.   python tools/soak_rollout.py [windows] [games]"""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from azul_deep_reinforcement_learning_amd import BatchedActorCritic, PolicyRollout  # noqa: E402
+
+windows = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+for opponent in (None, "random"):
+    runs = []
+    for persistent in (False, True):
+        torch.manual_seed(11)
+        ro = PolicyRollout(BatchedActorCritic(136, 180, 180), n_games=n, parts=1, seed_base=90210, window=32, use_graph=False,
+                           opponent=opponent, persistent=persistent)
+        for _ in range(windows):
+            tr = ro.run_window()
+        ro.synchronize()
+        last = {k: v.clone() for k, v in tr[0].items()}
+        mt, pos = ro.envs[0].get_rng_range()
+        runs.append((last, ro.envs[0].get_records(), mt, pos, ro.counters()))
+    (la, ra, ma, pa, ca), (lb, rb, mb, pb, cb) = runs
+    bad = [k for k in la if not torch.equal(la[k], lb[k])]
+    ok = not bad and ra.tobytes() == rb.tobytes() and np.array_equal(ma, mb) and np.array_equal(pa, pb) and ca == cb
+    print("opponent=%s: %d games x %d windows x 32 steps, %d episodes, %d stuck: %s %s" % (
+        opponent, n, windows, ca["episodes"], ca["stuck"], "IDENTICAL" if ok else "MISMATCH", bad))
+    assert ok

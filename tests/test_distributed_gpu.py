@@ -147,3 +147,58 @@ def test_world_size_one_nccl_executes_the_rccl_collectives():
     p.join(timeout=60)
     assert p.exitcode == 0
     assert backend == "nccl" and ok_gather and finite and moved and samples > 0
+
+
+# ---- data-parallel TRAINING with the kernels' own buffers: two ranks (sharing the GPU, gloo), each rolling out ITS shard of the games
+# and contributing its share of the fused gradient, must land where ONE process lands with all the games (BASELINE configs[4]) --------
+TG, TW, TWIN = 128, 16, 6          # games per rank, window, windows
+
+
+def _train_run(rank, world, n_games, id_base, distributed):
+    from azul_deep_reinforcement_learning_amd import BatchedActorCritic, PolicyRollout
+    from azul_deep_reinforcement_learning_amd.learner import A2CLearner
+    torch.manual_seed(0)
+    net = BatchedActorCritic(136, 180, 180).cuda()
+    learner = A2CLearner(net, distributed=distributed)
+    ro = PolicyRollout(net, n_games=n_games, window=TW, persistent=True, opponent="random", kweights=learner.kweights(), ring=3,
+                       seed_base=BASE + id_base, game_id_base=id_base)
+    samples = []
+    for _ in range(TWIN):
+        ro.run_window()
+        ro.join()
+        out = learner.update_from_rollout(ro)
+        samples.append(float(out["samples"]))
+    torch.cuda.synchronize()
+    return [p.detach().cpu().numpy().copy() for p in net.parameters()], samples, float(out["ac_loss"])
+
+
+def _train_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params, samples, loss = _train_run(rank, world, TG, TG * rank, True)
+    q.put((rank, params, samples, loss))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_equals_one_process_with_all_the_games():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref_params, ref_samples, ref_loss = _train_run(0, 1, 2 * TG, 0, False)
+    (_, pa, sa, la), (_, pb, sb, lb) = res
+    assert sa == sb == ref_samples and sum(ref_samples) > 0            # the global sample count of every update (all-reduced) = the single run's
+    for a, b_, r in zip(pa, pb, ref_params):
+        assert np.array_equal(a, b_)                                     # both ranks hold the same parameters, bit for bit
+        # the two shards' partial sums are added in another order than one process adds them: equal up to f32 rounding
+        assert np.allclose(a, r, rtol=0, atol=2e-6), float(np.abs(a - r).max())
+    assert np.isclose(la, ref_loss, rtol=1e-4) and la == lb

@@ -24,6 +24,7 @@ constexpr int LG_P_W1 = 0, LG_P_B1 = LG_P_W1 + PF_IN * PF_H2, LG_P_W2C = LG_P_B1
 static_assert(LG_P_PARAMS == 82082 && LG_P_W2A % 2 == 0, "ActorCritic(136, 180, 180): 82081 parameters + 1 pad");
 
 constexpr u32 LG_WAVES = 8, LG_AHEAD = 8;
+constexpr int LG_ADEPTH = 3;
 constexpr int LG_SUB = 2, LG_M = PF_GAMES * LG_SUB;           // samples per pass: two 16-row MFMA tiles share every streamed weight fragment
 constexpr int LG_F_TILES = 9, LG_C_TILES = 23;                 // dW1: 136 -> 9 feature tiles, 360 -> 23 column tiles
 constexpr int LG_C_PER_WAVE = (LG_C_TILES + (int)LG_WAVES - 1) / (int)LG_WAVES;      // 3: wave w owns column tiles w, w + 8, w + 16
@@ -67,14 +68,16 @@ __device__ __forceinline__ void lg_gemm180(const __amdgpu_buffer_rsrc_t rs, u32 
     float2 bw[PF_HID / 4];
 #pragma unroll
     for (int s = 0; s < (int)LG_AHEAD; s++) bw[s] = pre[s];
-    float an[LG_SUB];
-    for (int u = 0; u < LG_SUB; u++) an[u] = ap[u * sub_stride];
+    // A fragments LG_ADEPTH k-steps ahead: a step is 64..128 cycles of matrix pipe per wave, an LDS round trip is longer
+    float af[PF_HID / 4][LG_SUB];
+#pragma unroll
+    for (int s = 0; s < LG_ADEPTH; s++) for (int u = 0; u < LG_SUB; u++) af[s][u] = ap[u * sub_stride + 4 * s];
 #pragma unroll
     for (int s = 0; s < PF_HID / 4; s++) {
         if (s + (int)LG_AHEAD < PF_HID / 4) bw[s + LG_AHEAD] = LG_LOAD_B(NT, s + LG_AHEAD);
+        if (s + LG_ADEPTH < PF_HID / 4) for (int u = 0; u < LG_SUB; u++) af[s + LG_ADEPTH][u] = ap[u * sub_stride + 4 * (s + LG_ADEPTH)];
         float av[LG_SUB];
-        for (int u = 0; u < LG_SUB; u++) av[u] = an[u];
-        if (s + 1 < PF_HID / 4) for (int u = 0; u < LG_SUB; u++) an[u] = ap[u * sub_stride + 4 * (s + 1)];     // A fragments one k-step ahead
+        for (int u = 0; u < LG_SUB; u++) av[u] = af[s][u];
         for (int u = 0; u < LG_SUB; u++) {
             acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bw[s].x, acc[u][0], 0, 0, 0);
             if (NT == 2) acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bw[s].y, acc[u][1], 0, 0, 0);
@@ -197,14 +200,15 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
             float bw[PF_IN / 4][3];
 #pragma unroll
             for (int s = 0; s < (int)LG_AHEAD; s++) for (int j = 0; j < 3; j++) bw[s][j] = pre1[s][j];
-            float an[LG_SUB];
-            for (int u = 0; u < LG_SUB; u++) an[u] = ap[u * PF_GAMES * PF_OBS_STRIDE];
+            float af[PF_IN / 4][LG_SUB];
+#pragma unroll
+            for (int s = 0; s < LG_ADEPTH; s++) for (int u = 0; u < LG_SUB; u++) af[s][u] = ap[u * PF_GAMES * PF_OBS_STRIDE + 4 * s];
 #pragma unroll
             for (int s = 0; s < PF_IN / 4; s++) {
                 if (s + (int)LG_AHEAD < PF_IN / 4) for (int j = 0; j < 3; j++) bw[s + LG_AHEAD][j] = LG_LOAD_W1(s + LG_AHEAD, j);
+                if (s + LG_ADEPTH < PF_IN / 4) for (int u = 0; u < LG_SUB; u++) af[s + LG_ADEPTH][u] = ap[u * PF_GAMES * PF_OBS_STRIDE + 4 * (s + LG_ADEPTH)];
                 float av[LG_SUB];
-                for (int u = 0; u < LG_SUB; u++) av[u] = an[u];
-                if (s + 1 < PF_IN / 4) for (int u = 0; u < LG_SUB; u++) an[u] = ap[u * PF_GAMES * PF_OBS_STRIDE + 4 * (s + 1)];
+                for (int u = 0; u < LG_SUB; u++) av[u] = af[s][u];
                 for (int j = 0; j < 3; j++)
                     for (int u = 0; u < LG_SUB; u++) acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bw[s][j], acc[u][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);

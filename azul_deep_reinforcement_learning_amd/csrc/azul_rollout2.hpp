@@ -255,10 +255,16 @@ constexpr u32 PR2_WAVES = 8, PR2_AHEAD = 8;
 
 // The first weight fragments of a matrix phase are REQUESTED A PHASE EARLIER (layer 1's before the env step, layer 2's before layer 1's
 // epilogue) and stay in flight across the LDS-only barriers: the matrix pipe does not wait for L2 after each barrier.
-constexpr int PR2_HOIST1 = 4, PR2_HOIST2 = 8;
+constexpr int PR2_HOIST1 = 4, PR2_HOIST2 = 8, PR2_ADEPTH = 4;
+#if defined(PR2_EXPERIMENT_NO_WEIGHT_LOADS)
+// TIMING EXPERIMENT ONLY (wrong results): the matrix phases without their weight stream
+#define PR2_LOAD1(vo, s) make_float2((float)(vo) + (float)(s), 1.0f)
+#define PR2_LOAD2(NT_, s) make_float2((float)voff + (float)(s), 1.0f)
+#else
 #define PR2_LOAD1(vo, s) __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs1, vo, (4 * (s)) * PF_H2 * 4, 0))
 #define PR2_LOAD2(NT_, s) ((NT_) == 2 ? __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs2, voff, (4 * (s)) * PF_ACT * 4, 0)) \
                                       : make_float2(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, voff, (4 * (s)) * PF_ACT * 4, 0)), 0.f))
+#endif
 
 __device__ __forceinline__ void pr2_request1(bool two, const __amdgpu_buffer_rsrc_t rs1, u32 voffA, u32 voffB, float2 (&preA)[PR2_HOIST1],
                                              float2 (&preB)[PR2_HOIST1])
@@ -292,13 +298,16 @@ __device__ __forceinline__ void pr2_layer1(const __amdgpu_buffer_rsrc_t rs1, u32
     for (int s = 0; s < PR2_HOIST1; s++) { bwA[s] = preA[s]; if (NP == 2) bwB[s] = preB[s]; }
 #pragma unroll
     for (int s = PR2_HOIST1; s < (int)PR2_AHEAD; s++) { bwA[s] = PR2_LOAD1(voffA, s); if (NP == 2) bwB[s] = PR2_LOAD1(voffB, s); }
-    float an = ap[0];
+    // A fragments PR2_ADEPTH k-steps ahead: a step is only 64..128 cycles of matrix pipe per wave, an LDS round trip is longer
+    float af[PF_IN / 4];
+#pragma unroll
+    for (int s = 0; s < PR2_ADEPTH; s++) af[s] = ap[4 * s];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < PF_IN / 4; s++) {
         if (s + (int)PR2_AHEAD < PF_IN / 4) { bwA[s + PR2_AHEAD] = PR2_LOAD1(voffA, s + PR2_AHEAD); if (NP == 2) bwB[s + PR2_AHEAD] = PR2_LOAD1(voffB, s + PR2_AHEAD); }
-        const float av = an;
-        if (s + 1 < PF_IN / 4) an = ap[4 * (s + 1)];
+        if (s + PR2_ADEPTH < PF_IN / 4) af[s + PR2_ADEPTH] = ap[4 * (s + PR2_ADEPTH)];
+        const float av = af[s];
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bwA[s].x, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bwA[s].y, acc[1], 0, 0, 0);
         if (NP == 2) {
@@ -310,7 +319,9 @@ __device__ __forceinline__ void pr2_layer1(const __amdgpu_buffer_rsrc_t rs1, u32
 }
 
 // layer 2 of one wave: NT logit columns per lane (NT == 2: one 8-byte load, NT == 1: one 4-byte load per k-step), 180-deep
-// (`draw`: the wave also draws its head rows' uniforms -- Philox does not depend on the logits -- before the loop)
+// (`draw`: the wave also draws its head rows' uniforms -- Philox4x32-10 does not depend on the logits.  Its ten rounds are spread over
+// the first twenty k-steps, half a round each: the quarter-rate 32-bit multiplies issue in the shadow of the MFMAs instead of holding
+// up the head phase; philox_u32's arithmetic, statement for statement)
 template <int NT>
 __device__ __forceinline__ void pr2_layer2(const __amdgpu_buffer_rsrc_t rs2, u32 voff, const float *ap, const float2 (&pre)[PR2_HOIST2], pf_f32x4 &acc0,
                                            pf_f32x4 &acc1, bool draw, u64 seed, u64 ctr, u32 game, float &u_out)
@@ -318,19 +329,32 @@ __device__ __forceinline__ void pr2_layer2(const __amdgpu_buffer_rsrc_t rs2, u32
     float2 bw[PF_HID / 4];
 #pragma unroll
     for (int s = 0; s < PR2_HOIST2; s++) bw[s] = pre[s];
-    float an = ap[0];
-    __builtin_amdgcn_sched_barrier(0);
-    if (draw) u_out = policy_uniform(seed, ctr, game);
+    float af[PF_HID / 4];
+#pragma unroll
+    for (int s = 0; s < PR2_ADEPTH; s++) af[s] = ap[4 * s];
+    u32 c0 = (u32)ctr, c1 = (u32)(ctr >> 32), c2 = game, c3 = 0x415A554Cu, k0 = (u32)seed, k1 = (u32)(seed >> 32), hi0 = 0, lo0 = 0;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < PF_HID / 4; s++) {
         if (s + PR2_HOIST2 < PF_HID / 4) bw[s + PR2_HOIST2] = PR2_LOAD2(NT, s + PR2_HOIST2);
-        const float av = an;
-        if (s + 1 < PF_HID / 4) an = ap[4 * (s + 1)];
+        if (s + PR2_ADEPTH < PF_HID / 4) af[s + PR2_ADEPTH] = ap[4 * (s + PR2_ADEPTH)];
+        const float av = af[s];
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].x, acc0, 0, 0, 0);
+        if (NT == 2 && s < 20) {
+            if (draw) {
+                if ((s & 1) == 0) { hi0 = __umulhi(0xD2511F53u, c0); lo0 = 0xD2511F53u * c0; }
+                else {
+                    const u32 hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+                    const u32 n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+                    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+                    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+                }
+            }
+        }
         if (NT == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].y, acc1, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (NT == 2 && draw) u_out = (float)(c0 >> 8) * (1.0f / 16777216.0f);
 }
 
 template <bool LID, bool OPP>

@@ -12,7 +12,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 lib = os.path.join(ROOT, "gpurun_out", "libazulhip_prof.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
-subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + ge.HIPCC_FLAGS + ["-DAZ_PROFILE_SEGMENTS", "-I", os.path.join(ROOT, "include"),
+subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + ge.HIPCC_FLAGS + ["-DAZ_PROFILE_SEGMENTS"] + [a for a in sys.argv[1:] if a.startswith("-D")] + ["-I", os.path.join(ROOT, "include"),
                       "-o", lib, os.path.join(ge.CSRC, "azul_kernels.hip")], cwd=ge.CSRC)
 import azul_deep_reinforcement_learning_amd._lib as L  # noqa: E402
 L.LIB_PATH = lib

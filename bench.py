@@ -304,7 +304,7 @@ def main():
                                         ("RCCL" if backend == "nccl" else backend, " + mask bits" if args.gather_masks else "")) if gather else "no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "azul_selfplay_kernel", "avg_launch_ms": avg_launch_s * 1e3, "launches_timed": kern_launches,
+                         "kernel": "azul_selfplay2_kernel" if os.environ.get("AZUL_SELFPLAY_KERNEL", "2")[:1] != "1" else "azul_selfplay_kernel", "avg_launch_ms": avg_launch_s * 1e3, "launches_timed": kern_launches,
                          "event_bracket_ms": bracket_ms, "host_elapsed_ms": elapsed * 1e3,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * G * T,
                          "note": "working set is cache resident; the path is issue/latency bound, see DESIGN.md"},

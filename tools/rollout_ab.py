@@ -16,7 +16,10 @@ opp = "random" if "--opponent" in sys.argv else None
 WIN = int(sys.argv[sys.argv.index("--window") + 1]) if "--window" in sys.argv else 32
 sets = sys.argv[sys.argv.index("--") + 1:] if "--" in sys.argv else ["ship"]
 for fs in sets:
-    if fs != "ship":
+    if fs.endswith(".so"):                                # a prebuilt library (e.g. the previous commit's)
+        L.LIB_PATH = os.path.abspath(fs)
+        L.lib = L._load()
+    elif fs != "ship":
         lib = os.path.join(ROOT, "gpurun_out", "libazulhip_ab_%s.so" % fs.replace(",", "_"))
         if not os.path.exists(lib):
             os.makedirs(os.path.dirname(lib), exist_ok=True)

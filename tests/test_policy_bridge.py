@@ -335,6 +335,30 @@ def test_rollout_kernel_follows_the_per_move_path_from_unusual_states(contract, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("opponent", [None, "random"])
+def test_rollout_kernel_long_run_equals_the_per_move_path(contract, opponent):
+    """40 windows of 32 steps on 512 games (about a hundred episodes and several MT19937 regenerations per game): the one-launch-per-
+    window kernel and the two-launches-per-move path must end with the same records, the same 624-word generator states, counters and
+    last window (tools/soak_rollout.py is the 300-window, 4096-game form of this)."""
+    from azul_deep_reinforcement_learning_amd import PolicyRollout
+    runs = []
+    for persistent in (False, True):
+        torch.manual_seed(11)
+        ro = PolicyRollout(_net(contract, "cuda"), n_games=512, parts=1, seed_base=90210, window=32, use_graph=False, opponent=opponent,
+                           persistent=persistent)
+        for _ in range(40):
+            tr = ro.run_window()
+        ro.synchronize()
+        mt, pos = ro.envs[0].get_rng_range()
+        runs.append(({k: v.clone() for k, v in tr[0].items()}, ro.envs[0].get_records(), mt, pos, ro.counters()))
+    (la, ra, ma, pa, ca), (lb, rb, mb, pb, cb) = runs
+    for key in la:
+        assert torch.equal(la[key], lb[key]), key
+    assert ra.tobytes() == rb.tobytes() and np.array_equal(ma, mb) and np.array_equal(pa, pb) and ca == cb
+    assert ca["episodes"] > 5000
+
+
+@pytest.mark.gpu
 def test_argmax_action_selection(contract):
     """seed = AZUL_POLICY_ARGMAX: Agent.get_ac_output(action_selection="Max") = np.argmax of the masked softmax (first maximum),
     with the same log-prob / entropy outputs; and a greedy rollout is the same whichever launch structure plays it."""

@@ -54,12 +54,17 @@ class BatchedTrainer:
 
     # ---- statistics ----------------------------------------------------------------------------------
     def _stat_totals(self):
-        ep, sums = 0, np.zeros(len(STAT_KEYS))
-        for env in self.rollout.envs:
-            c = env.counters()
-            ep += int(c["episodes"].sum())
-            sums += np.asarray(c["stat_sums"]).reshape(-1, len(STAT_KEYS)).sum(axis=0)
-        return ep, sums
+        """Finished episodes and the ten get_statistics() sums over all games: reduced ON THE DEVICE (the per-game counters stay
+        there; 11 numbers cross PCIe instead of 88 bytes per game), on the stream that ran the games."""
+        tot = None
+        for p, env in enumerate(self.rollout.envs):
+            with torch.cuda.stream(self.rollout.streams[p]):
+                c = env.counters_dev()
+                t = torch.cat([c["episodes"].sum().to(torch.float64).reshape(1), c["stat_sums"].sum(dim=0)])
+            self.rollout.streams[p].synchronize()
+            tot = t if tot is None else tot + t
+        tot = tot.cpu().numpy()
+        return int(tot[0]), tot[1:]
 
     def _game_statistics(self):
         """Means over the episodes finished since the last call (GameStatistics.get_stats, game_runner.py:17-22)."""

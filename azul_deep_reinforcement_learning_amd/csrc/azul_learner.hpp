@@ -543,7 +543,12 @@ __global__ void __launch_bounds__(256) azul_select_ring_count_kernel(const uint8
             if (m) last = s_win + t0 + 63 - (i32)__builtin_clzll(m);
         }
         if (last >= 0) {
-            const i32 lo = s_end - R > 0 ? s_end - R : 0;
+            // oldest step that is still intact in the ring.  The rollout kernel also writes the state AFTER the window into time slot
+            // T of the window's view (the next window's slot 0: obs / mask / player only).  For the ring's last window that is the spare
+            // slot R; for every other window it is the physical slot of absolute step s_end - R, whose observation and mask are
+            // therefore gone (its action / reward / return are not): that step counts as fallen out of the ring.
+            const i32 lo_ = s_end - R + ((s_end % R) != 0 ? 1 : 0);
+            const i32 lo = lo_ > 0 ? lo_ : 0;
             const i32 p0 = pend[g];
             start = p0 > lo ? p0 : lo;
             dropped = start - p0;

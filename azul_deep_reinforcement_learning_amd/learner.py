@@ -311,6 +311,31 @@ class A2CLearner:
             rg["obs"][:R].reshape(R * N, -1), rg["mask"][:R].reshape(R * N, -1), rg["action"].reshape(-1), rg["returns"].reshape(-1),
             index=st["index"], count=st["count"][:1], countf=st["countf"]))
 
+    def ring_state(self):
+        """The books of update_from_rollout's ring selection (for a checkpoint): per game the first absolute step not trained yet, the
+        clock offset and the dropped-step counter; None before the first ring update."""
+        st = getattr(self, "_ring", None)
+        if st is None:
+            return None
+        return {"pending": st["pending"].cpu(), "offset": int(st["offset"]), "count": st["count"].cpu(), "R": st["key"][1], "N": st["key"][2]}
+
+    def load_ring_state(self, rollout, state):
+        """Restore ring_state() for `rollout` (whose ring buffers and windows_played the caller has restored), or -- state None --
+        forget the books: the next update_from_rollout starts them with the window played just before it."""
+        self._ring = None
+        self.dropped_steps = None
+        if state is None or rollout.ring < 2 or rollout.parts != 1:
+            return
+        R, N = rollout.ring * rollout.T, rollout.h
+        if (state["R"], state["N"]) != (R, N):
+            raise ValueError("ring state was written for %d slots x %d games" % (state["R"], state["N"]))
+        dev = rollout.device
+        self._ring = {"key": (id(rollout), R, N), "index": torch.empty(R * N, dtype=torch.int32, device=dev),
+                      "count": state["count"].to(dev).clone(), "countf": torch.zeros(2, device=dev),
+                      "pending": state["pending"].to(dev).clone(),
+                      "scratch": torch.empty(3 * N + (N + 3) // 4, dtype=torch.int32, device=dev), "offset": int(state["offset"])}
+        self.dropped_steps = self._ring["count"]
+
     def update_from_windows(self, trajectories, complete_only=True, kweights=None):
         """`trajectories`: the per-part dicts PolicyRollout.run_window returns (opponent="random": every record is one agent
         step).  Uses the steps whose episode finished inside the window (exact Monte-Carlo returns, the reference's qvals).

@@ -18,7 +18,8 @@ net name is given; the columns and their order here are the ones that code spell
 
 Checkpoints (`save_checkpoint` / `load_checkpoint`): the policy's state_dict (the reference's parameter names: loads into
 `azulnet.model.ActorCritic` as is), the Adam state, every game's 128-byte record and CPython RNG state, the Philox step
-counters and the batch index -- a restored run replays the next window bit for bit.
+counters, the batch index and (by default) the trajectory ring with the learner's selection books -- a restored run replays the
+next window bit for bit and performs the same updates as the uninterrupted run.
 """
 import csv
 import os
@@ -153,9 +154,15 @@ class BatchedTrainer:
         self.rollout.refresh_weights()
 
     # ---- checkpoints ---------------------------------------------------------------------------------
-    def save_checkpoint(self, path):
+    def save_checkpoint(self, path, save_ring=True):
+        """save_ring=True (default): the trajectory ring (the last `ring` windows: episodes in flight), the rollout's window clock and
+        the learner's per-game "first step not trained yet" go into the file, so that a restored run EQUALS the uninterrupted one
+        (~75 KB per game with the default ring of 3 x 32 steps).  save_ring=False: a small file; a run restored from it starts its
+        books with the first window it plays -- the steps of the episodes in flight at the checkpoint that were recorded before it are
+        not trained, and their tails are trained as if they were whole episodes (returns of those tails are still exact)."""
         ro = self.rollout
         ro.synchronize()
+        torch.cuda.synchronize(ro.device)
         envs = []
         for p, env in enumerate(ro.envs):
             mt, pos = env.get_rng_range()
@@ -163,8 +170,13 @@ class BatchedTrainer:
                          "counter": ro.work[p]["counter"].cpu().numpy().copy(),
                          "next_obs": ro.traj[p]["obs"][ro.T].cpu(), "next_mask": ro.traj[p]["mask"][ro.T].cpu(),
                          "next_player": ro.traj[p]["player"][ro.T].cpu()})
-        torch.save({"policy": ro.policy.state_dict(), "optimizer": self.learner.optimizer_state(), "envs": envs,
-                    "batch": self.batch, "n_games": ro.n, "parts": ro.parts, "window": ro.T, "game_id_base": ro.game_id_base}, path)
+        ck = {"policy": ro.policy.state_dict(), "optimizer": self.learner.optimizer_state(), "envs": envs,
+              "batch": self.batch, "n_games": ro.n, "parts": ro.parts, "window": ro.T, "game_id_base": ro.game_id_base,
+              "windows_played": ro.windows_played, "ring": ro.ring}
+        if save_ring and ro.ring > 1:
+            ck["ring_buffers"] = [{k: v.cpu() for k, v in rg.items()} for rg in ro.rings]
+            ck["learner_ring"] = self.learner.ring_state()
+        torch.save(ck, path)
 
     def load_checkpoint(self, path):
         ro = self.rollout
@@ -189,6 +201,20 @@ class BatchedTrainer:
             ro.traj[p]["obs"][ro.T].copy_(e["next_obs"])
             ro.traj[p]["mask"][ro.T].copy_(e["next_mask"])
             ro.traj[p]["player"][ro.T].copy_(e["next_player"])
+        # the trajectory ring and the books of the ring selection: restored when the file has them (the run then equals the
+        # uninterrupted one), otherwise the learner's books restart with the next window (nothing recorded before this call -- by the
+        # checkpointed run or by this trainer -- is ever selected: `pending` starts at the next window, whose selection only reads
+        # done flags of windows played from now on)
+        if "ring_buffers" in ck and ck.get("ring") == ro.ring and ro.ring > 1:
+            for rg, saved in zip(ro.rings, ck["ring_buffers"]):
+                for k, v in saved.items():
+                    rg[k].copy_(v)
+            ro.windows_played = int(ck["windows_played"])
+            for p in range(ro.parts):
+                ro.traj[p] = ro._window_views(ro.rings[p], (ro.windows_played - 1) % ro.ring)
+            self.learner.load_ring_state(ro, ck.get("learner_ring"))
+        else:
+            self.learner.load_ring_state(ro, None)
         torch.cuda.synchronize(ro.device)
         self.batch = int(ck["batch"])
         self._stat_base = self._stat_totals()

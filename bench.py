@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--games G] [--chunk T]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+Started as a plain command with --gpus N > 1 (no WORLD_SIZE in the environment) it launches the N ranks ITSELF: fresh child
+processes through torch.distributed.run, started before this process has made any GPU call; rank 0's JSON line appears on this
+process's stdout and the exit code is the launcher's (non-zero if any rank failed).
+
 One "step" = one pass of the hot path over one batch of synthetic input = ONE LAUNCH of the persistent self-play
 kernel: every one of the G games per GPU plays T = 512 env moves (per move: legal mask -> RandomAgent -> Azul.step
 -> reward -> done, auto-reset at game end; the state stays in registers for the whole launch) and the launch writes its
@@ -43,6 +47,7 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL trajectory all-gather")
     ap.add_argument("--gather-masks", action="store_true", help="N>1: also ship the bit-packed legal masks (24 B/move)")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[2] / training-loop lines under `extra`")
+    ap.add_argument("--extras-timeout", type=int, default=240, help="seconds after which the secondary measurements are abandoned")
     ap.add_argument("--mask-pitch", type=int, default=192, help="byte pitch of a game's legal-mask row (180 = dense, 192 = 64-byte aligned rows)")
     return ap.parse_args()
 
@@ -114,52 +119,81 @@ FWD_FLOP_PER_GAME = 2 * (136 * 360 + 180 * 180 + 180)            # ActorCritic(1
 GRAD_FLOP_PER_SAMPLE = 391000                                     # forward + backward of the A2C loss
 
 
-def extras(games):
-    """Driver-observed secondary lines (N = 1 only, after the headline measurement): BASELINE configs[2] -- the policy in
-    the loop, one launch per 32-move window -- and the training loop (NNRunner.train batched), each with its own roofline
-    against the f32 matrix peak.  Kernel time = torch events on the stream the kernels run on."""
+def _timed(world, dev, fn):
+    """barrier + synchronize on both sides of fn(); the MAX over ranks of the host-clock time."""
     import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    return float(el.item()), res
+
+
+def extras(games, world=1, rank=0, dev=None, seed_base=0, backend="nccl"):
+    """Driver-observed secondary lines (after the headline measurement; EVERY rank runs them): BASELINE configs[2] (N = 1) /
+    configs[4] (N > 1) -- the policy in the loop, one launch per 32-move window, games sharded by global id -- and the training loop
+    (NNRunner.train batched; N > 1: data parallel, the step is rollout -> selection -> gradients -> ALL-REDUCE of the global sample
+    count and of the flat 82,085-float gradient -> Adam, timed across the ranks), each with its own roofline against the f32 matrix
+    peak.  Kernel time = torch events on the stream the kernels run on (rank 0's)."""
+    import torch
+    import torch.distributed as dist
     from azul_deep_reinforcement_learning_amd import BatchedActorCritic, PolicyRollout
     from azul_deep_reinforcement_learning_amd.learner import A2CLearner
     res = {}
     window, windows = 32, 40
+    base = seed_base + rank * games                     # CPython seeds and Philox keys follow the GLOBAL game id
+    coll = "RCCL" if backend == "nccl" else backend
     torch.manual_seed(0)
     net = BatchedActorCritic(136, 180, 180)
-    ro = PolicyRollout(net, n_games=games, parts=1, window=window, persistent=True)
+    ro = PolicyRollout(net, n_games=games, parts=1, window=window, persistent=True, seed_base=base)
     for _ in range(3):
         ro.run_window()
     ro.synchronize()
     torch.cuda.synchronize()
     s = ro.streams[0]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record(s)
-    for _ in range(windows):
-        ro.run_window()
-    e1.record(s)
-    ro.synchronize()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+
+    def policy_windows():
+        e0.record(s)
+        for _ in range(windows):
+            ro.run_window()
+        e1.record(s)
+        ro.synchronize()
+
+    dt, _ = _timed(world, dev, policy_windows)
     kms = e0.elapsed_time(e1)
     moves = games * window * windows
     tf = FWD_FLOP_PER_GAME * moves / (kms / 1e3) / 1e12
     res["policy_config"] = {
-        "metric": "Azul env steps/sec (ActorCritic policy self-play, full C1 trajectory recorded)", "value": moves / dt, "unit": "env steps/s",
-        "config": {"workload": "BASELINE configs[2]: %d games, ActorCritic(136,180,180) f32 inside azul_batch_policy_rollout, "
-                               "one launch per %d-move window" % (games, window), "windows_timed": windows},
+        "metric": "Azul env steps/sec (ActorCritic policy self-play, full C1 trajectory recorded)", "value": world * moves / dt, "unit": "env steps/s",
+        "n_gpus": world,
+        "config": {"workload": "BASELINE configs[%d]: %d games per GPU (%d in all), ActorCritic(136,180,180) f32 inside azul_batch_policy_rollout, "
+                               "one launch per %d-move window" % (2 if world == 1 else 4, games, games * world, window), "windows_timed": windows,
+                   "parallelism": "games sharded by global id; no collective: the C1 trajectory records stay in the HBM of the rank that "
+                                  "produced them (DESIGN.md 7)"},
         "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS,
                      "traffic": None, "kernel": "azul_policy_rollout2_kernel (+ azul_returns_kernel)", "avg_window_ms": kms / windows,
-                     "flop_per_env_move": FWD_FLOP_PER_GAME, "event_bracket_ms": kms, "host_elapsed_ms": dt * 1e3}}
+                     "flop_per_env_move": FWD_FLOP_PER_GAME, "event_bracket_ms": kms, "host_elapsed_ms": dt * 1e3, "scope": "rank 0's GPU"}}
     del ro
     torch.cuda.empty_cache()
 
-    torch.manual_seed(0)
+    torch.manual_seed(0)                                # every rank starts from the same parameters (and keeps them: same updates)
     net = BatchedActorCritic(136, 180, 180).cuda()
-    learner = A2CLearner(net)
-    ro = PolicyRollout(net, n_games=games, parts=1, window=window, persistent=True, opponent="random", kweights=learner.kweights(), ring=3)
+    learner = A2CLearner(net)                           # distributed iff a process group exists: count + flat gradient all-reduced
+    ro = PolicyRollout(net, n_games=games, parts=1, window=window, persistent=True, opponent="random", kweights=learner.kweights(), ring=3,
+                       seed_base=base)
 
     def one_window():
-        tr = ro.run_window()
+        ro.run_window()
         ro.join()
         out = learner.update_from_rollout(ro)
         ro.refresh_weights()
@@ -169,39 +203,118 @@ def extras(games):
         one_window()
     torch.cuda.synchronize()
     ep0 = ro.counters()["episodes"]
-    t0 = time.perf_counter()
-    for _ in range(windows):
-        out = one_window()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    samples = float(out["samples"])
-    dropped = int(learner.dropped_steps[1]) if learner.dropped_steps is not None else None
+
+    def train_windows():
+        out = None
+        for _ in range(windows):
+            out = one_window()
+        return out
+
+    dt, out = _timed(world, dev, train_windows)
+    samples = float(out["samples"])                     # GLOBAL sample count of the last update
+    cnt = torch.tensor([float(ro.counters()["episodes"] - ep0), float(int(learner.dropped_steps[1]) if learner.dropped_steps is not None else 0)],
+                       dtype=torch.float64, device=dev)
+    chk = torch.stack([p.detach().double().sum() for p in net.parameters()]).sum().reshape(1)
+    lo, hi = chk.clone(), chk.clone()
+    if world > 1:
+        dist.all_reduce(cnt)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    flop = (GRAD_FLOP_PER_SAMPLE * samples + FWD_FLOP_PER_GAME * games * world * window) * windows / dt / 1e12
     res["training"] = {
-        "metric": "A2C training throughput (policy vs RandomAgent opponent, one update per window)", "value": games * window * windows / dt,
-        "unit": "agent steps/s", "updates_per_s": windows / dt, "samples_last_update": samples, "steps_dropped_from_ring": dropped,
-        "episodes_per_s": (ro.counters()["episodes"] - ep0) / dt,
-        "config": {"workload": "NNRunner.train batched: %d games, window %d agent steps (ring of 3 windows: every step of every episode is "
-                               "trained once), rollout + selection + gradients + Adam per window" % (games, window), "windows_timed": windows},
-        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TFLOPS,
-                     "achieved": (GRAD_FLOP_PER_SAMPLE * samples + FWD_FLOP_PER_GAME * games * window) * windows / dt / 1e12,
-                     "frac": (GRAD_FLOP_PER_SAMPLE * samples + FWD_FLOP_PER_GAME * games * window) * windows / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "kernel": "whole training step (rollout + gradients), wall clock",
-                     "note": "agent-step forwards only: the opponent's env moves inside the rollout carry no network evaluation"}}
+        "metric": "A2C training throughput (policy vs RandomAgent opponent, one update per window)", "value": world * games * window * windows / dt,
+        "unit": "agent steps/s", "n_gpus": world, "updates_per_s": windows / dt, "samples_last_update": samples,
+        "steps_dropped_from_ring": int(cnt[1].item()), "episodes_per_s": float(cnt[0].item()) / dt,
+        "ranks_hold_identical_parameters": bool(lo.item() == hi.item()),
+        "config": {"workload": "NNRunner.train batched%s: %d games per GPU (%d in all), window %d agent steps (ring of 3 windows: every step of "
+                               "every episode is trained once), rollout + selection + gradients + Adam per window"
+                               % ("" if world == 1 else " (BASELINE configs[4], data parallel)", games, games * world, window),
+                   "windows_timed": windows,
+                   "parallelism": "single process" if world == 1 else
+                                  "dp%d: games sharded by global id; per update ONE %s all-reduce of the global sample count (4 B) and ONE of the "
+                                  "flat gradient + loss sums (82,085 floats, 328 KB); no trajectory leaves its rank" % (world, coll)},
+        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TFLOPS * world, "achieved": flop,
+                     "frac": flop / (F32_MFMA_PEAK_TFLOPS * world),
+                     "traffic": None, "kernel": "whole training step (rollout + gradients%s), wall clock" % ("" if world == 1 else " + all-reduce"),
+                     "note": "agent-step forwards only: the opponent's env moves inside the rollout carry no network evaluation; "
+                             "peak = %d x the f32 matrix peak of one GPU" % world}}
     return res
+
+
+def facade_config1(budget_s=8.0, max_games=150):
+    """BASELINE configs[0] through the drop-in shims (integration/azulnet, i.e. the reference's own single-game Python API on the GPU
+    backend): SURVEY 8d config 1 -- random.seed(s); GameRunner(); reset(); loop get_valid_moves -> RandomAgent.get_a_output ->
+    GameRunner.step until done, s = 0, 1, ... -- in env steps/s (1 step = 1 accepted Azul.step = GameRunner.move_counter), beside the
+    2,690 steps/s/core the reference's CPython measured in the build container.  Every rule evaluation is a kernel launch on a 1-game
+    batch; this measures the per-call overhead of the compatibility layer, not the kernels."""
+    import random
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "integration"))
+    from azulnet.game_runner import GameRunner, RandomAgent
+    from azul_deep_reinforcement_learning_amd import facade_backend as fb
+    agent = RandomAgent()
+
+    def episode(seed):
+        random.seed(seed)
+        r = GameRunner()
+        r.reset()
+        done, calls = False, 0
+        while not done:
+            mask = r.get_valid_moves()
+            a = agent.get_a_output(None, torch.from_numpy(mask[None, :]))
+            _, done = r.step(a)
+            calls += 1
+        return r.move_counter, calls
+
+    episode(10 ** 6)                                     # warm-up: lazy backends, allocator
+    fb.reset_traffic()
+    t0 = time.perf_counter()
+    steps = agent_steps = games = 0
+    while games < max_games and time.perf_counter() - t0 < budget_s:
+        m, c = episode(games)
+        steps += m
+        agent_steps += c
+        games += 1
+    dt = time.perf_counter() - t0
+    tr = fb.traffic()
+    return {"metric": "Azul env steps/sec through the single-game drop-in API (GameRunner loop of SURVEY 8d config 1)", "value": steps / dt,
+            "unit": "env steps/s", "games": games, "env_steps": steps, "agent_steps_per_s": agent_steps / dt, "games_per_s": games / dt,
+            "reference_python_steps_per_s_per_core": 2690.0,
+            "pcie_bytes_per_episode": {"host_to_device": tr["h2d"] / max(games, 1), "device_to_host": tr["d2h"] / max(games, 1)},
+            "launches_per_episode": tr["launches"] / max(games, 1), "syncs_per_episode": tr["syncs"] / max(games, 1),
+            "config": {"workload": "BASELINE configs[0]: single 2-player game at a time, RandomAgent vs RandomAgent through "
+                                   "integration/azulnet (GameRunner / RandomAgent / check_all_valid on libazulhip.so), seeds 0..%d" % (games - 1)}}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` as a plain command: start the N ranks as FRESH child processes (torch.distributed.run) before this
+    process has imported torch or touched a GPU, pass every argument through, relay the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))                      # nothing below has run: no torch import, no GPU call in this process
+    import datetime
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     # AZUL_BENCH_BACKEND=gloo is a REHEARSAL mode for boxes with fewer GPUs than ranks (ranks share devices, the
     # all-gather goes through gloo); the driver's multi-GPU runs use the default: nccl (= RCCL over xGMI), one GPU per rank.
     backend = os.environ.get("AZUL_BENCH_BACKEND", "nccl")
@@ -212,9 +325,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
 
     from azul_deep_reinforcement_learning_amd import BatchedAzul
     from azul_deep_reinforcement_learning_amd.parallel import TrajectoryGather
@@ -275,51 +388,90 @@ def main():
     elapsed = float(el.item())
     total_moves = float(moves.item())
 
+    out = None
     if rank == 0:
         value = total_moves / elapsed
         avg_launch_s = kern_ms / 1e3 / max(kern_launches, 1)          # event pair around each launch: the kernel's own duration
         achieved = ALGO_BYTES_PER_STEP * G * T / avg_launch_s / 1e9
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_gbs = None, None, None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))     # PMC-measured HBM bytes per env move (an EARLIER rocprofv3 --pmc run, see `source`), scaled to one launch
                 traffic = tj["bytes_per_move"] * G * T
-                traffic_src = "not measured in this run: %s B/move from %s" % (tj["bytes_per_move"], tj.get("source", "profiles/hbm_traffic.json"))
+                traffic_gbs = traffic / avg_launch_s / 1e9
+                traffic_src = "not measured in this run: %s B/move (kernel %s) from %s" % (tj["bytes_per_move"], tj.get("kernel", "?"),
+                                                                                          tj.get("source", "profiles/hbm_traffic.json"))
             except Exception:
                 traffic = None
+        kernel_name = "azul_selfplay2_kernel" if os.environ.get("AZUL_SELFPLAY_KERNEL", "2")[:1] != "1" else "azul_selfplay_kernel"
+        coll = "RCCL" if backend == "nccl" else backend
+        if gather:
+            par = ("games sharded by global id (rank r owns games [%d r, %d (r + 1))), no data-path collective; the one exchange step is the %s "
+                   "all-gather of the compact trajectory records (4 B per move: action | done | reward%s), issued async behind each launch and "
+                   "inside the timed region; the byte masks (180 B per move) are a function of seed + actions and are not shipped"
+                   % (G, G, coll, "; + the bit-packed masks, 24 B per move" if args.gather_masks else ""))
+        elif world > 1:
+            par = "games sharded by global id; no collective (--no-gather)"
+        else:
+            par = "one GPU: nothing is exchanged (N > 1: games shard by global id, all-gather of the compact trajectory records over RCCL)"
         out = {
             "metric": "Azul env steps/sec (random-agent self-play), bit-exact vs CPU",
             "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/u32 (+f64 sampling)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d concurrent 2-player games per GPU, RandomAgent vs RandomAgent, "
-                                   "rules Lid + random first player, seeds base+global_id, auto-reset" % G,
+            "config": {"workload": "BASELINE configs[%d]: %d concurrent 2-player games per GPU, RandomAgent vs RandomAgent, "
+                                   "rules Lid + random first player, seeds base+global_id, auto-reset" % (1 if world == 1 else 3, G),
                        "step_definition": "one step = one launch of the persistent self-play kernel = %d env moves for each of the %d "
                                           "games of a GPU (%d env moves per step and GPU)" % (T, G, T * G),
                        "games_per_gpu": G, "global_games": G * world, "moves_per_launch": T, "env_moves_timed": int(total_moves),
-                       "mask_row_pitch_bytes": args.mask_pitch, "mask_bits_stream": bool(want_bits), "selfplay_kernel": os.environ.get("AZUL_SELFPLAY_KERNEL", "2") + " game(s) per wavefront",
-                       "parallelism": "games sharded by global id; %s" %
-                                      (("%s all-gather of the compact trajectory records%s, issued async behind each launch" %
-                                        ("RCCL" if backend == "nccl" else backend, " + mask bits" if args.gather_masks else "")) if gather else "no collective")},
+                       "mask_row_pitch_bytes": args.mask_pitch, "mask_bits_stream": bool(want_bits),
+                       "selfplay_kernel": os.environ.get("AZUL_SELFPLAY_KERNEL", "2") + " game(s) per wavefront",
+                       "parallelism": par},
+            # `achieved` / `frac` follow the contract: ALGORITHMIC bytes (445 B per env move) over the kernel's own duration.
+            # What really reaches HBM is less (the state never leaves the registers): `traffic` (PMC) and `traffic_gbs` / `traffic_frac`.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "azul_selfplay2_kernel" if os.environ.get("AZUL_SELFPLAY_KERNEL", "2")[:1] != "1" else "azul_selfplay_kernel", "avg_launch_ms": avg_launch_s * 1e3, "launches_timed": kern_launches,
+                         "traffic_gbs": traffic_gbs, "traffic_frac": (traffic_gbs / HBM_PEAK_GBS) if traffic_gbs else None,
+                         "kernel": kernel_name, "avg_launch_ms": avg_launch_s * 1e3, "launches_timed": kern_launches,
                          "event_bracket_ms": bracket_ms, "host_elapsed_ms": elapsed * 1e3,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * G * T,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * G * T, "scope": "rank 0's GPU",
+                         "limiter": "instruction issue / dependent-issue latency at two waves per SIMD, not HBM (DESIGN.md 3)",
                          "note": "working set is cache resident; the path is issue/latency bound, see DESIGN.md"},
             "parity_gate": gate, "parity_gate_after_timed_region": gate_end,
             "episodes_finished": int(cnt["episodes"].sum()), "stuck_resets": stuck,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(G, args.seed_base)
-        if world == 1 and not args.no_extras:
-            del bufs, env
-            torch.cuda.empty_cache()
+    if not args.no_extras:
+        # secondary lines, run by EVERY rank (N > 1: the data-parallel training step has collectives).  The headline must survive them: an
+        # exception is reported under `extra`; if a rank hangs, every rank's watchdog fires, rank 0 prints the headline and all exit.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["extra"] = {"error": "secondary measurements exceeded %d s" % args.extras_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        wd = threading.Timer(args.extras_timeout, give_up)
+        wd.daemon = True
+        wd.start()
+        del bufs, env, gather
+        torch.cuda.empty_cache()
+        try:
+            ex = extras(G, world, rank, dev, args.seed_base, backend)
+        except Exception as e:
+            ex = {"error": repr(e)}
+        if world == 1:
             try:
-                out["extra"] = extras(G)
-            except Exception as e:           # the headline line must survive a failure of the secondary measurements
-                out["extra"] = {"error": repr(e)}
+                ex["facade_config1"] = facade_config1()
+            except Exception as e:
+                ex["facade_config1"] = {"error": repr(e)}
+        wd.cancel()
+        if rank == 0:
+            out["extra"] = ex
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

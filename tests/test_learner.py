@@ -420,6 +420,68 @@ def test_every_step_of_every_episode_is_trained_exactly_once_across_windows(gold
 
 
 @pytest.mark.gpu
+def test_ring_selection_gathers_the_observation_and_mask_of_the_step_it_trains(golden_dir):
+    """A ring SHORTER than the episodes (24 slots, episodes of ~27 agent steps): selections reach back to the oldest slot of the
+    ring.  The rollout kernel also writes the post-window state into slot T of a window's view -- for every window but the ring's
+    last that is the physical slot of the oldest in-ring step, whose observation / mask are then another state's.  What the
+    learner gathers through `index` must be the observation and mask RECORDED WHEN THE STEP WAS PLAYED, the trained action must be
+    legal under the gathered mask, and every step of a finished episode is either selected once or counted as dropped."""
+    import ctypes as C
+    from azul_deep_reinforcement_learning_amd import PolicyRollout
+    from azul_deep_reinforcement_learning_amd import _lib as L
+    g = _golden(golden_dir)
+    net = _net_from(g, "before_", "cuda")
+    n, T, D, windows = 128, 8, 3, 45
+    ro = PolicyRollout(net, n_games=n, seed_base=777, window=T, persistent=True, opponent="random", ring=D)
+    R = D * T
+    dev = ro.device
+    index = torch.empty(R * n, dtype=torch.int32, device=dev)
+    count = torch.zeros(2, dtype=torch.int32, device=dev)
+    pending = torch.zeros(n, dtype=torch.int32, device=dev)
+    scratch = torch.empty(3 * n + (n + 3) // 4, dtype=torch.int32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    hist = {k: [] for k in ("obs", "mask", "action", "done")}
+    seen = set()
+    reached_oldest = 0
+    for w in range(windows):
+        tr = ro.run_window()
+        ro.synchronize()
+        for k in hist:
+            hist[k].append(tr[0][k][:T].cpu().numpy().copy())      # slot t = what the policy saw / did at step t of this window
+        L.check(L.lib.azul_select_episode_samples(p(ro.rings[0]["done"]), p(ro.rings[0]["action"]), T, D, n, (w + 1) * T, p(pending), p(index),
+                                                  p(count), None, p(scratch), None))
+        torch.cuda.synchronize()
+        cnt = int(count[0])
+        ix = index[:cnt].long()
+        obs_g = ro.rings[0]["obs"][:R].reshape(R * n, -1)[ix].cpu().numpy()
+        mask_g = ro.rings[0]["mask"][:R].reshape(R * n, -1)[ix].cpu().numpy()
+        act_g = ro.rings[0]["action"].reshape(-1)[ix].cpu().numpy()
+        idx = ix.cpu().numpy()
+        slot, game = idx // n, idx % n
+        end = (w + 1) * T - 1
+        absstep = end - ((end % R - slot) % R)
+        reached_oldest += int((absstep == end - R + 1).sum())
+        obs_h, mask_h, act_h = np.concatenate(hist["obs"]), np.concatenate(hist["mask"]), np.concatenate(hist["action"])
+        assert np.array_equal(obs_g, obs_h[absstep, game]), "window %d: gathered observation is not the step's own" % w
+        assert np.array_equal(mask_g, mask_h[absstep, game]), "window %d: gathered mask is not the step's own" % w
+        assert np.array_equal(act_g, act_h[absstep, game])
+        assert (mask_g[np.arange(cnt), act_g] != 0).all(), "trained action is illegal under the gathered mask"
+        for gm, st in zip(game, absstep):
+            assert (int(gm), int(st)) not in seen
+            seen.add((int(gm), int(st)))
+    assert reached_oldest > 0                                 # selections did reach the oldest intact slot
+    dropped = int(count[1])
+    assert dropped > 0                                        # ... and beyond: those steps are counted, not trained
+    action, done = np.concatenate(hist["action"]), np.concatenate(hist["done"])
+    finished = 0
+    for gm in range(n):
+        ends = np.flatnonzero(done[:, gm] != 0)
+        if len(ends):
+            finished += int((action[:ends[-1] + 1, gm] >= 0).sum())
+    assert finished == len(seen) + dropped
+
+
+@pytest.mark.gpu
 def test_update_without_samples_is_a_no_op_and_losses_are_bit_reproducible(golden_dir):
     """After a NORMAL update (moments are non-zero), an update whose selection is empty must leave parameters, Adam moments and the
     step counter untouched (the reference has no update without an episode); and the logged loss sums are reduced in a fixed

@@ -131,3 +131,55 @@ def test_trainer_csv_log_and_resume(tmp_path, golden_dir, use_graph, parts, pers
     tr2.train(net_name="blue", batches=1, log_every=1, checkpoint_every=1000)
     rows = list(csv.reader(open(os.path.join(str(tmp_path), "blue.csv"))))
     assert len(rows) == 5 and int(float(rows[-1][0])) == 4
+
+
+@pytest.mark.gpu
+def test_resumed_run_equals_the_uninterrupted_run(tmp_path):
+    """Checkpoint in the middle of training (episodes in flight in the trajectory ring), restore into a FRESH trainer and into a
+    trainer that HAS ALREADY TRAINED on other games: both must perform the same updates as the run that was never interrupted
+    (parameters bit-identical after three more batches: same samples, same returns, same deterministic kernels).  A checkpoint
+    without the ring restarts the selection books cleanly: nothing recorded before the restore is ever trained."""
+    import torch
+    from azul_deep_reinforcement_learning_amd import BatchedActorCritic
+    from azul_deep_reinforcement_learning_amd.training import BatchedTrainer
+    kw = dict(n_games=192, window=16, results_dir=str(tmp_path))
+    torch.manual_seed(0)
+    a = BatchedTrainer(BatchedActorCritic(136, 180, 180), seed_base=40, **kw)
+    for _ in range(5):
+        a.run_batch(collect_stats=False)
+    ck, ck_small = os.path.join(str(tmp_path), "mid.pt"), os.path.join(str(tmp_path), "mid_small.pt")
+    a.save_checkpoint(ck)
+    a.save_checkpoint(ck_small, save_ring=False)
+    assert os.path.getsize(ck_small) < os.path.getsize(ck) / 4
+    rows_a = [a.run_batch(collect_stats=True) for _ in range(3)]
+    want = {k: v.detach().clone() for k, v in a.rollout.policy.state_dict().items()}
+
+    torch.manual_seed(99)
+    b = BatchedTrainer(BatchedActorCritic(136, 180, 180), seed_base=9000, **kw)            # fresh: other weights, other games
+    b.load_checkpoint(ck)
+    torch.manual_seed(5)
+    c = BatchedTrainer(BatchedActorCritic(136, 180, 180), seed_base=333, **kw)             # has trained: its ring holds other episodes
+    for _ in range(4):
+        c.run_batch(collect_stats=False)
+    c.load_checkpoint(ck)
+    for t in (b, c):
+        rows = [t.run_batch(collect_stats=True) for _ in range(3)]
+        for k, v in t.rollout.policy.state_dict().items():
+            assert torch.equal(v, want[k]), k
+        for ra, rb in zip(rows_a, rows):
+            assert ra["batch"] == rb["batch"] and ra["ac_loss"] == rb["ac_loss"] and ra["player_score"] == rb["player_score"]
+        assert int(t.learner.dropped_steps[1]) == int(a.learner.dropped_steps[1])
+
+    # without the ring in the file: the books start with the first window played after the restore
+    c.load_checkpoint(ck_small)
+    assert c.learner._ring is None
+    w0 = c.rollout.windows_played
+    c.run_batch(collect_stats=False)
+    torch.cuda.synchronize()
+    pend = c.learner._ring["pending"].cpu().numpy()
+    assert (pend >= w0 * 16).all()                        # no step recorded before the restore was selected or is pending
+    n_sel = int(c.learner._ring["count"][0])
+    done = c.rollout.traj[0]["done"].cpu().numpy()
+    act = c.rollout.traj[0]["action"].cpu().numpy()
+    expect = sum(int((act[:np.flatnonzero(done[:, g])[-1] + 1, g] >= 0).sum()) for g in range(192) if done[:, g].any())
+    assert n_sel == expect                                # exactly the newest window's steps up to each game's last episode end

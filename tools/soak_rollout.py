@@ -10,13 +10,24 @@ import torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from azul_deep_reinforcement_learning_amd import BatchedActorCritic, PolicyRollout  # noqa: E402
 
+import hashlib  # noqa: E402
+import os  # noqa: E402
+
+from azul_deep_reinforcement_learning_amd import _lib as L  # noqa: E402
+
 windows = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+# provenance of a raw log: which library, which harness, which network (a claim of bit-identity is only as good as the log it cites)
+print("libazulhip.so sha256 %s | %s | soak_rollout.py sha256 %s | source rev %s" % (
+    hashlib.sha256(open(L.LIB_PATH, "rb").read()).hexdigest()[:16], L.lib.azul_version().decode(),
+    hashlib.sha256(open(__file__, "rb").read()).hexdigest()[:16], os.environ.get("AZUL_SOURCE_REV", "?")))
 for opponent in (None, "random"):
     runs = []
     for persistent in (False, True):
-        torch.manual_seed(11)
-        ro = PolicyRollout(BatchedActorCritic(136, 180, 180), n_games=n, parts=1, seed_base=90210, window=32, use_graph=False,
+        torch.manual_seed(11)               # INSIDE the arm loop: both arms must start from the same network
+        net = BatchedActorCritic(136, 180, 180)
+        print("  arm persistent=%s: net checksum %.9f" % (persistent, float(sum(p.double().sum() for p in net.parameters()))))
+        ro = PolicyRollout(net, n_games=n, parts=1, seed_base=90210, window=32, use_graph=False,
                            opponent=opponent, persistent=persistent)
         for _ in range(windows):
             tr = ro.run_window()
@@ -27,6 +38,6 @@ for opponent in (None, "random"):
     (la, ra, ma, pa, ca), (lb, rb, mb, pb, cb) = runs
     bad = [k for k in la if not torch.equal(la[k], lb[k])]
     ok = not bad and ra.tobytes() == rb.tobytes() and np.array_equal(ma, mb) and np.array_equal(pa, pb) and ca == cb
-    print("opponent=%s: %d games x %d windows x 32 steps, %d episodes, %d stuck: %s %s" % (
-        opponent, n, windows, ca["episodes"], ca["stuck"], "IDENTICAL" if ok else "MISMATCH", bad))
+    print("opponent=%s: %d games x %d windows x 32 steps, episodes per-move arm %d / one-launch arm %d, %d stuck: %s %s" % (
+        opponent, n, windows, ca["episodes"], cb["episodes"], ca["stuck"], "IDENTICAL" if ok else "MISMATCH", bad), flush=True)
     assert ok

@@ -22,6 +22,21 @@ POLICY_ARGMAX = 0xFFFFFFFFFFFFFFFF        # `seed` value: np.argmax instead of s
 
 _vp, _i, _u64, _u32 = C.c_void_p, C.c_int, C.c_uint64, C.c_uint32
 
+# azul_game_call (include/azul_hip.h): ops, result bits and the call block
+(CALL_QUERY, CALL_INIT, CALL_NEW_ROUND, CALL_MOVE, CALL_NEXT_PLAYER, CALL_COUNT_SCORE, CALL_STEP, CALL_RUNNER_INIT, CALL_RUNNER_RESET,
+ CALL_RUNNER_STEP, CALL_SAMPLE_MASK) = range(11)
+WANT_RECORD, WANT_MASK, WANT_OBS, WANT_FLAGS, WANT_POTENTIAL, WANT_STATS = 1, 2, 4, 8, 16, 32
+
+
+class AzulCall(C.Structure):
+    _fields_ = [("op", C.c_int32), ("game", C.c_int32), ("arg", C.c_int32), ("want", C.c_uint32),
+                ("record_in", C.c_void_p), ("mt_in", C.c_void_p), ("pos_in", C.c_uint32), ("mask_in", C.c_void_p),
+                ("record_out", C.c_void_p), ("mt_out", C.c_void_p),
+                ("pos_out", C.c_uint32), ("rng_regenerated", C.c_int32), ("status", C.c_int32), ("reward", C.c_int32), ("done", C.c_int32),
+                ("action", C.c_int32), ("flags", C.c_int32), ("potential", C.c_int32),
+                ("mask", C.c_uint8 * 180), ("obs", C.c_float * 136), ("stats", C.c_double * 10)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/azul_hip.h
 SIGNATURES = {
     "azul_last_error_string": (C.c_char_p, []),
@@ -70,6 +85,7 @@ SIGNATURES = {
     "azul_discounted_returns_ring": (_i, [_vp, _vp, _vp, C.c_float, _i, C.c_int64, _i, _i, _vp]),
     "azul_batch_sample_mask": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "azul_batch_score_preview": (_i, [_vp, _vp, _vp]),
+    "azul_game_call": (_i, [_vp, C.POINTER(AzulCall), _vp]),
     "azul_batch_selfplay": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "azul_batch_selfplay_strided": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "azul_batch_counters": (_i, [_vp, _vp, _vp, _vp, _vp]),

@@ -2,8 +2,8 @@
 
 Same constructor, attributes (numpy arrays that callers read AND write), methods, exceptions and JSON schema
 as the reference; every rule evaluation (new_round, move, is_legal_move, is_end_of_round, is_end_of_game,
-count_score, step, get_statistics) is one kernel launch through libazulhip.so on the current state of the
-attributes.  What stays on the host is bookkeeping only: rule parsing, attribute <-> record conversion, JSON
+count_score, step, get_statistics) is one kernel launch through libazulhip.so (azul_game_call: one submission, one host
+synchronisation) on the current state of the attributes.  What stays on the host is bookkeeping only: rule parsing, attribute <-> record conversion, JSON
 I/O and ``__eq__``.  ``Azul(players=3)`` / ``Azul(players=4)`` behave like the reference's (five displays, turn order
 1..P; azul.py:18-33, 177-181; SURVEY.md hazard H5) on the 3 / 4 player kernels and the 256-byte wide record.
 """
@@ -171,15 +171,9 @@ class Azul:
             runner.move_counter = int(rec["move_counter"])
 
     def _run(self, op, *args, draws=False, mutates=True, runner=None):
-        be = self._backend()
-        be.put(self._to_record(runner))
-        if draws:
-            be.push_rng()
-        out = getattr(be, op)(*args)
-        if draws:
-            be.pull_rng()
+        out, rec = self._backend().call(op, args, self._to_record(runner), draws, mutates)
         if mutates:
-            self._from_record(be.get(), runner)
+            self._from_record(rec, runner)
         return out
 
     # ------------------------------------------------------------------------------------------

@@ -70,6 +70,7 @@ struct OpArgs {
     i32 *potential;          // [N]   out
     double *stats;           // [N][10] out
     uint8_t *player;         // [N]   out: current_player after the op
+    u32 first;               // the launch covers games first .. first + grid - 1; row i of the arrays above belongs to game first + i
 };
 
 __global__ void __launch_bounds__(64) azul_seed_kernel(BatchDev b, u64 seed_base, const u64 *seeds)
@@ -168,8 +169,8 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
 {
     __shared__ u32 mt_lds[624];
     __shared__ double fr_lds[T_ROWS * T_BINADES];
-    const u32 gi = blockIdx.x;
-    const bool act = a.active ? (a.active[gi] != 0) : true;
+    const u32 oi = blockIdx.x, gi = oi + a.first;      // game of the batch / row of the caller's arrays
+    const bool act = a.active ? (a.active[oi] != 0) : true;
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
     LaneConst k;
     lane_consts(k);
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
             st = new_round<LID>(g, r);
             break;
         case OP_MOVE: {
-            i32 av = a.actions[gi];
+            i32 av = a.actions[oi];
             if (av < 0 || av >= 180) { st = ST_BAD_ACTION; dirty_state = false; break; }
             do_move<LID>(g, action_code((u32)av));
         } break;
@@ -205,7 +206,7 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
             count_score<LID>(g, k);
             break;
         case OP_STEP:
-            st = checked_step<LID>(g, k, r, a.actions[gi]);
+            st = checked_step<LID>(g, k, r, a.actions[oi]);
             dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION);
             break;
         case OP_RUNNER_INIT:
@@ -218,10 +219,10 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
         case OP_RUNNER_STEP: {
             i32 rew = 0;
             u32 dn = 0;
-            st = runner_step<LID>(g, k, r, tab, a.actions[gi], rew, dn);
+            st = runner_step<LID>(g, k, r, tab, a.actions[oi], rew, dn);
             dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION);
-            if (a.reward) AZ_LANE0(a.reward[gi] = rew);
-            if (a.done) AZ_LANE0(a.done[gi] = (uint8_t)dn);
+            if (a.reward) AZ_LANE0(a.reward[oi] = rew);
+            if (a.done) AZ_LANE0(a.done[oi] = (uint8_t)dn);
             if (!st && dn) {
                 for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(b.stat_sum[(size_t)gi * 10 + q] += sv); }
                 AZ_LANE0(b.episodes[gi] += 1ull);
@@ -233,25 +234,25 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
             legal_mask(g, k, m);
             u32 code;
             i32 av = random_agent(m, r, tab, k, code);
-            AZ_LANE0(a.actions_out[gi] = av);
+            AZ_LANE0(a.actions_out[oi] = av);
             dirty_state = false;
         } break;
         case OP_POLICY_STEP: {
             i32 rew = 0;
             u32 dn = 0;
-            st = env_policy_step<LID>(g, k, r, b, gi, a.actions[gi], rew, dn, dirty_state);
-            if (a.reward) AZ_LANE0(a.reward[gi] = rew);
-            if (a.done) AZ_LANE0(a.done[gi] = (uint8_t)dn);
+            st = env_policy_step<LID>(g, k, r, b, gi, a.actions[oi], rew, dn, dirty_state);
+            if (a.reward) AZ_LANE0(a.reward[oi] = rew);
+            if (a.done) AZ_LANE0(a.done[oi] = (uint8_t)dn);
         } break;
         case OP_AGENT_STEP: {
             i32 rew = 0;
             u32 dn = 0;
-            st = env_agent_step<LID>(g, k, r, tab, b, gi, a.actions[gi], rew, dn, dirty_state);
-            if (a.reward) AZ_LANE0(a.reward[gi] = rew);
-            if (a.done) AZ_LANE0(a.done[gi] = (uint8_t)dn);
+            st = env_agent_step<LID>(g, k, r, tab, b, gi, a.actions[oi], rew, dn, dirty_state);
+            if (a.reward) AZ_LANE0(a.reward[oi] = rew);
+            if (a.done) AZ_LANE0(a.done[oi] = (uint8_t)dn);
         } break;
         case OP_SAMPLE_MASK: {
-            const uint8_t *mi = a.mask_in + (size_t)gi * AZUL_NUM_ACTIONS;
+            const uint8_t *mi = a.mask_in + (size_t)oi * AZUL_NUM_ACTIONS;
             vu32 l = lane();
             Mask m;
             m.b0 = ld_u8(mi, l, l < 64u) != 0u ? 1u : 0u;
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
             m.m0 = ballot(m.b0 != 0u); m.m1 = ballot(m.b1 != 0u); m.m2 = ballot(m.b2 != 0u);
             u32 code;
             i32 av = random_agent(m, r, tab, k, code);
-            AZ_LANE0(a.actions_out[gi] = av);
+            AZ_LANE0(a.actions_out[oi] = av);
             dirty_state = false;
         } break;
         default:
@@ -270,30 +271,30 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
         if (dirty_state) game_store(g, rec);
         if (use_rng) rng_close(r, b.mtpos + gi);
     }
-    if (a.status && act) AZ_LANE0(a.status[gi] = (uint8_t)st);
+    if (a.status && act) AZ_LANE0(a.status[oi] = (uint8_t)st);
     // queries on the post-op state
     if (a.mask) {
         Mask m;
         legal_mask(g, k, m);
-        mask_write(m, a.mask + (size_t)gi * AZUL_NUM_ACTIONS);
+        mask_write(m, a.mask + (size_t)oi * AZUL_NUM_ACTIONS);
     }
     if (a.obs) {
         u32 p = (a.persp == AZUL_PERSP_CURRENT) ? me_index(g) : (u32)a.persp;
-        observe(g, p, a.obs + (size_t)gi * AZUL_OBS_SIZE);
+        observe(g, p, a.obs + (size_t)oi * AZUL_OBS_SIZE);
     }
     if (a.flags) {
         u32 f = (sources_board(g) == 0u ? AZUL_FLAG_END_OF_ROUND : 0) | (is_end_of_game(g) ? AZUL_FLAG_END_OF_GAME : 0) |
                 (g.eog ? AZUL_FLAG_ENDED_FLAG : 0);
-        AZ_LANE0(a.flags[gi] = (uint8_t)f);
+        AZ_LANE0(a.flags[oi] = (uint8_t)f);
     }
     if (a.potential) {
         i32 phi = potential<LID>(g, k);
-        AZ_LANE0(a.potential[gi] = phi);
+        AZ_LANE0(a.potential[oi] = phi);
     }
     if (a.stats) {
-        for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(a.stats[(size_t)gi * 10 + q] = sv); }
+        for (u32 q = 0; q < 10u; q++) { double sv = game_stat(g, q); AZ_LANE0(a.stats[(size_t)oi * 10 + q] = sv); }
     }
-    if (a.player) AZ_LANE0(a.player[gi] = (uint8_t)g.cur);
+    if (a.player) AZ_LANE0(a.player[oi] = (uint8_t)g.cur);
 }
 
 // Rule entries for 3 and 4 players (row N4): Azul.__init__ / new_round / move / is_legal_move (mask) / next_player / is_end_of_round /
@@ -304,8 +305,8 @@ __global__ void __launch_bounds__(64) azul_np_op_kernel(BatchDev b, OpArgs a)
 {
     __shared__ u32 mt_lds[624];
     __shared__ double fr_lds[T_ROWS * T_BINADES];
-    const u32 gi = blockIdx.x;
-    const bool act = a.active ? (a.active[gi] != 0) : true;
+    const u32 oi = blockIdx.x, gi = oi + a.first;      // game of the batch / row of the caller's arrays
+    const bool act = a.active ? (a.active[oi] != 0) : true;
     uint8_t *rec = b.state + (size_t)gi * NP_RECORD_BYTES;
     LaneConst k;
     lane_consts(k);
@@ -328,7 +329,7 @@ __global__ void __launch_bounds__(64) azul_np_op_kernel(BatchDev b, OpArgs a)
             st = new_round_np<LID>(g, r);
             break;
         case OP_MOVE: {
-            i32 av = a.actions[gi];
+            i32 av = a.actions[oi];
             if (av < 0 || av >= 180) { st = ST_BAD_ACTION; dirty_state = false; break; }
             do_move_np<LID>(g, action_code((u32)av));
         } break;
@@ -339,7 +340,7 @@ __global__ void __launch_bounds__(64) azul_np_op_kernel(BatchDev b, OpArgs a)
             count_score_np<LID>(g, k);
             break;
         case OP_STEP:
-            st = checked_step_np<LID>(g, k, r, a.actions[gi]);
+            st = checked_step_np<LID>(g, k, r, a.actions[oi]);
             dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION);
             break;
         case OP_RANDOM_ACTION: {
@@ -347,11 +348,11 @@ __global__ void __launch_bounds__(64) azul_np_op_kernel(BatchDev b, OpArgs a)
             legal_mask_np(g, k, m);
             u32 code;
             i32 av = random_agent(m, r, tab, k, code);
-            AZ_LANE0(a.actions_out[gi] = av);
+            AZ_LANE0(a.actions_out[oi] = av);
             dirty_state = false;
         } break;
         case OP_SAMPLE_MASK: {
-            const uint8_t *mi = a.mask_in + (size_t)gi * AZUL_NUM_ACTIONS;
+            const uint8_t *mi = a.mask_in + (size_t)oi * AZUL_NUM_ACTIONS;
             vu32 l = lane();
             Mask m;
             m.b0 = ld_u8(mi, l, l < 64u) != 0u ? 1u : 0u;
@@ -360,7 +361,7 @@ __global__ void __launch_bounds__(64) azul_np_op_kernel(BatchDev b, OpArgs a)
             m.m0 = ballot(m.b0 != 0u); m.m1 = ballot(m.b1 != 0u); m.m2 = ballot(m.b2 != 0u);
             u32 code;
             i32 av = random_agent(m, r, tab, k, code);
-            AZ_LANE0(a.actions_out[gi] = av);
+            AZ_LANE0(a.actions_out[oi] = av);
             dirty_state = false;
         } break;
         default:
@@ -370,21 +371,21 @@ __global__ void __launch_bounds__(64) azul_np_op_kernel(BatchDev b, OpArgs a)
         if (dirty_state) gamen_store(g, rec);
         if (use_rng) rng_close(r, b.mtpos + gi);
     }
-    if (a.status && act) AZ_LANE0(a.status[gi] = (uint8_t)st);
+    if (a.status && act) AZ_LANE0(a.status[oi] = (uint8_t)st);
     if (a.mask) {
         Mask m;
         legal_mask_np(g, k, m);
-        mask_write(m, a.mask + (size_t)gi * AZUL_NUM_ACTIONS);
+        mask_write(m, a.mask + (size_t)oi * AZUL_NUM_ACTIONS);
     }
     if (a.flags) {
         u32 f = (sources_board_np(g) == 0u ? AZUL_FLAG_END_OF_ROUND : 0) | (walls_end_game_np(g) ? AZUL_FLAG_END_OF_GAME : 0) |
                 (g.eog ? AZUL_FLAG_ENDED_FLAG : 0);
-        AZ_LANE0(a.flags[gi] = (uint8_t)f);
+        AZ_LANE0(a.flags[oi] = (uint8_t)f);
     }
     if (a.stats) {
-        for (u32 q = 0; q < 10u; q++) { double sv = game_stat_np(g, q); AZ_LANE0(a.stats[(size_t)gi * 10 + q] = sv); }
+        for (u32 q = 0; q < 10u; q++) { double sv = game_stat_np(g, q); AZ_LANE0(a.stats[(size_t)oi * 10 + q] = sv); }
     }
-    if (a.player) AZ_LANE0(a.player[gi] = (uint8_t)g.cur);
+    if (a.player) AZ_LANE0(a.player[oi] = (uint8_t)g.cur);
 }
 
 // Discounted returns over the time-major trajectory of one launch window (reference loop: nn_runner.py:70-76,
@@ -586,6 +587,8 @@ struct azul_batch {
     int timed_launches;  // launches since azul_timing_begin
     int timed_pairs;     // of which bracketed by their own event pair (the first AZ_TIMED_PAIRS)
     bool timing;
+    uint8_t *call_dev;   // azul_game_call: device scratch of one call (CallScratch), allocated by the first call
+    uint8_t *call_pin;   // ... and its pinned host mirror (+ staging for record / MT words)
 };
 enum { AZ_TIMED_PAIRS = 256 };
 
@@ -650,6 +653,8 @@ static void batch_free(azul_batch *b)
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     for (hipEvent_t e : b->lev) (void)hipEventDestroy(e);
+    if (b->call_dev) (void)hipFree(b->call_dev);
+    if (b->call_pin) (void)hipHostFree(b->call_pin);
     delete b;
 }
 
@@ -709,6 +714,7 @@ int azul_batch_create_players(azul_batch_t **out, int n_games, int players, int 
     b->timing = false;
     b->timed_launches = 0;
     b->timed_pairs = 0;
+    b->call_dev = b->call_pin = nullptr;
     int rc = batch_alloc(b, n_games, first_player, tile_pool);
     if (rc != AZUL_SUCCESS) { batch_free(b); return rc; }      // nothing leaks when an allocation fails half way
     *out = b;
@@ -736,6 +742,26 @@ static int check_range(const azul_batch_t *b, int first, int count)
     return AZUL_SUCCESS;
 }
 
+// domain the kernels are exact on (documented in DESIGN.md)
+static int record_in_domain(const azul_batch_t *b, const uint8_t *p)
+{
+    const u32 P = (u32)b->players;
+    u32 flags = p[31];
+    if ((flags & 7u) > P || ((flags >> 3) & 7u) > P || (flags & 0x80u)) return fail(AZUL_ERR_RANGE, "flags: players are 0..P");
+    const uint8_t *floors = p + (P == 2 ? 82 : 132), *walls = p + (P == 2 ? 84 : 136), *box = p + (P == 2 ? 96 : 160);
+    for (u32 q = 0; q < P; q++) {
+        if (floors[q] > 7) return fail(AZUL_ERR_RANGE, "floors are 0..7 (azul.py:120-123)");
+        u32 w;
+        memcpy(&w, walls + 4 * q, 4);
+        if (w >> 25) return fail(AZUL_ERR_RANGE, "walls are 25-bit boards");
+    }
+    u32 sb = 0, sl = 0;
+    for (int c = 0; c < 5; c++) { sb += box[c]; sl += box[5 + c]; }
+    if (sb > 255 || sl > 255) return fail(AZUL_ERR_RANGE, "box / lid hold at most 255 tiles in total");
+    if (P != 2 && p[204] != P) return fail(AZUL_ERR_RANGE, "wide record: byte 204 must hold the batch's number of players");
+    return AZUL_SUCCESS;
+}
+
 int azul_batch_get_state(azul_batch_t *b, int first, int count, void *records_host, void *stream)
 {
     BATCH_GUARD(b, stream);
@@ -754,23 +780,8 @@ int azul_batch_set_state(azul_batch_t *b, int first, int count, const void *reco
     if (!records_host) return fail(AZUL_ERR_INVALID, "records_host is NULL");
     const uint8_t *p = (const uint8_t *)records_host;
     const size_t RB = (size_t)b->rec_bytes;
-    for (int i = 0; i < count; i++, p += RB) {
-        // domain the kernels are exact on (documented in DESIGN.md)
-        const u32 P = (u32)b->players;
-        u32 flags = p[31];
-        if ((flags & 7u) > P || ((flags >> 3) & 7u) > P || (flags & 0x80u)) return fail(AZUL_ERR_RANGE, "flags: players are 0..P");
-        const uint8_t *floors = p + (P == 2 ? 82 : 132), *walls = p + (P == 2 ? 84 : 136), *box = p + (P == 2 ? 96 : 160);
-        for (u32 q = 0; q < P; q++) {
-            if (floors[q] > 7) return fail(AZUL_ERR_RANGE, "floors are 0..7 (azul.py:120-123)");
-            u32 w;
-            memcpy(&w, walls + 4 * q, 4);
-            if (w >> 25) return fail(AZUL_ERR_RANGE, "walls are 25-bit boards");
-        }
-        u32 sb = 0, sl = 0;
-        for (int c = 0; c < 5; c++) { sb += box[c]; sl += box[5 + c]; }
-        if (sb > 255 || sl > 255) return fail(AZUL_ERR_RANGE, "box / lid hold at most 255 tiles in total");
-        if (P != 2 && p[204] != P) return fail(AZUL_ERR_RANGE, "wide record: byte 204 must hold the batch's number of players");
-    }
+    for (int i = 0; i < count; i++, p += RB)
+        if (int rc = record_in_domain(b, p)) return rc;
     HIP_TRY(hipMemcpyAsync(b->d.state + (size_t)first * RB, records_host, (size_t)count * RB, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return AZUL_SUCCESS;
@@ -850,10 +861,10 @@ static bool np_supported(const OpArgs &a)
     }
 }
 
-static int launch_op(azul_batch_t *b, const OpArgs &a, void *stream)
+static int launch_op(azul_batch_t *b, const OpArgs &a, void *stream, int count = -1)
 {
     if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
-    const dim3 grid(b->d.n), block(64);
+    const dim3 grid(count < 0 ? b->d.n : (u32)count), block(64);      // games a.first .. a.first + grid - 1
     const hipStream_t st = (hipStream_t)stream;
     const bool lid = b->d.rules.tile_pool == POOL_LID;
     if (b->players == 2) {
@@ -1223,6 +1234,101 @@ int azul_batch_score_preview(azul_batch_t *b, int32_t *potential_dev, void *stre
     if (!potential_dev) return fail(AZUL_ERR_INVALID, "potential_dev is NULL");
     OpArgs a = op_args(OP_QUERY); a.potential = potential_dev;
     return launch_op(b, a, stream);
+}
+
+// ---- azul_game_call: one method call of the single-game API in one submission + one synchronisation ---------------------------
+struct CallScratch {             // device scratch of one call; the pinned mirror has the same layout
+    i32 action_in;
+    u32 pos;                     // (pinned mirror only: the stream index, in and out)
+    i32 reward, action_out, potential;
+    uint8_t status, done, flags, player;
+    uint8_t mask_in[AZUL_NUM_ACTIONS];
+    uint8_t mask[AZUL_NUM_ACTIONS];
+    float obs[AZUL_OBS_SIZE];
+    double stats[AZUL_NUM_STATS];
+    uint8_t record[AZUL_RECORD_BYTES_WIDE];
+    u32 mt[AZUL_MT_WORDS];
+};
+
+int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
+{
+    BATCH_GUARD(b, stream);
+    if (!b || !c) return fail(AZUL_ERR_INVALID, "azul_game_call: batch / call is NULL");
+    if (int rc = check_range(b, c->game, 1)) return rc;
+    static const int op_of[] = {OP_QUERY, OP_INIT, OP_NEW_ROUND, OP_MOVE, OP_NEXT_PLAYER, OP_COUNT_SCORE, OP_STEP, OP_RUNNER_INIT, OP_RUNNER_RESET,
+                                OP_RUNNER_STEP, OP_SAMPLE_MASK};
+    if (c->op < 0 || c->op > AZUL_CALL_SAMPLE_MASK) return fail(AZUL_ERR_INVALID, "azul_game_call: unknown op");
+    if (c->op == AZUL_CALL_SAMPLE_MASK && !c->mask_in) return fail(AZUL_ERR_INVALID, "azul_game_call: AZUL_CALL_SAMPLE_MASK needs mask_in");
+    if ((c->want & AZUL_WANT_RECORD) && !c->record_out) return fail(AZUL_ERR_INVALID, "azul_game_call: AZUL_WANT_RECORD needs record_out");
+    if (c->mt_in && c->pos_in > 624u) return fail(AZUL_ERR_INVALID, "azul_game_call: index outside 0..624");
+    if (c->record_in) if (int rc = record_in_domain(b, (const uint8_t *)c->record_in)) return rc;
+    const hipStream_t st = (hipStream_t)stream;
+    if (!b->call_dev) {
+        HIP_TRY(hipMalloc((void **)&b->call_dev, sizeof(CallScratch)));
+        HIP_TRY(hipHostMalloc((void **)&b->call_pin, sizeof(CallScratch), hipHostMallocDefault));
+    }
+    CallScratch *D = (CallScratch *)b->call_dev, *H = (CallScratch *)b->call_pin;
+    const size_t RB = (size_t)b->rec_bytes;
+    const size_t g = (size_t)c->game;
+    // ---- inputs: staged in the pinned mirror, copied asynchronously
+    if (c->record_in) {
+        memcpy(H->record, c->record_in, RB);
+        HIP_TRY(hipMemcpyAsync(b->d.state + g * RB, H->record, RB, hipMemcpyHostToDevice, st));
+    }
+    if (c->mt_in) {
+        memcpy(H->mt, c->mt_in, sizeof(H->mt));
+        H->pos = c->pos_in;
+        HIP_TRY(hipMemcpyAsync(b->d.mt + g * 624, H->mt, sizeof(H->mt), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->d.mtpos + g, &H->pos, sizeof(u32), hipMemcpyHostToDevice, st));
+    }
+    const bool takes_action = c->op == AZUL_CALL_MOVE || c->op == AZUL_CALL_STEP || c->op == AZUL_CALL_RUNNER_STEP;
+    if (takes_action || c->op == AZUL_CALL_SAMPLE_MASK) {
+        H->action_in = c->arg;
+        size_t nb = sizeof(i32);
+        if (c->op == AZUL_CALL_SAMPLE_MASK) {                     // action_in .. mask_in is one contiguous piece of the scratch
+            memcpy(H->mask_in, c->mask_in, AZUL_NUM_ACTIONS);
+            nb = offsetof(CallScratch, mask_in) + AZUL_NUM_ACTIONS;
+        }
+        HIP_TRY(hipMemcpyAsync(D, H, nb, hipMemcpyHostToDevice, st));
+    }
+    // ---- the rule kernel on this one game
+    OpArgs a = op_args(op_of[c->op]);
+    a.first = (u32)c->game;
+    a.actions = &D->action_in;
+    a.status = &D->status;
+    if (c->op == AZUL_CALL_RUNNER_STEP) { a.reward = &D->reward; a.done = &D->done; }
+    if (c->op == AZUL_CALL_SAMPLE_MASK) { a.mask_in = D->mask_in; a.actions_out = &D->action_out; }
+    if (c->want & AZUL_WANT_MASK) a.mask = D->mask;
+    if (c->want & AZUL_WANT_OBS) { a.obs = D->obs; a.persp = c->arg; }
+    if (c->want & AZUL_WANT_FLAGS) a.flags = &D->flags;
+    if (c->want & AZUL_WANT_POTENTIAL) a.potential = &D->potential;
+    if (c->want & AZUL_WANT_STATS) a.stats = D->stats;
+    H->status = AZUL_OK; H->done = 0; H->reward = 0;
+    if (int rc = launch_op(b, a, stream, 1)) return rc;
+    // ---- results: the scalar head of the scratch always (24 bytes), the rest on request
+    HIP_TRY(hipMemcpyAsync(&H->reward, &D->reward, offsetof(CallScratch, mask_in) - offsetof(CallScratch, reward), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&H->pos, b->d.mtpos + g, sizeof(u32), hipMemcpyDeviceToHost, st));
+    if (c->want & AZUL_WANT_MASK) HIP_TRY(hipMemcpyAsync(H->mask, D->mask, AZUL_NUM_ACTIONS, hipMemcpyDeviceToHost, st));
+    if (c->want & AZUL_WANT_OBS) HIP_TRY(hipMemcpyAsync(H->obs, D->obs, sizeof(H->obs), hipMemcpyDeviceToHost, st));
+    if (c->want & AZUL_WANT_STATS) HIP_TRY(hipMemcpyAsync(H->stats, D->stats, sizeof(H->stats), hipMemcpyDeviceToHost, st));
+    if (c->want & AZUL_WANT_RECORD) HIP_TRY(hipMemcpyAsync(H->record, b->d.state + g * RB, RB, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    c->status = H->status; c->reward = H->reward; c->done = H->done; c->action = H->action_out; c->flags = H->flags; c->potential = H->potential;
+    c->pos_out = H->pos;
+    if (c->want & AZUL_WANT_MASK) memcpy(c->mask, H->mask, AZUL_NUM_ACTIONS);
+    if (c->want & AZUL_WANT_OBS) memcpy(c->obs, H->obs, sizeof(H->obs));
+    if (c->want & AZUL_WANT_STATS) memcpy(c->stats, H->stats, sizeof(H->stats));
+    if (c->want & AZUL_WANT_RECORD) memcpy(c->record_out, H->record, RB);
+    // a call draws far fewer than 624 words, so the words were regenerated iff the index moved backwards (an index of 624 -- a
+    // freshly seeded stream -- regenerates at the first draw).  `pos_in` is the caller's statement of the index before the call;
+    // without mt_in the caller passes the index it last received.
+    c->rng_regenerated = (c->pos_out < c->pos_in) ? 1 : 0;
+    if (c->rng_regenerated && c->mt_out) {
+        HIP_TRY(hipMemcpyAsync(H->mt, b->d.mt + g * 624, sizeof(H->mt), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        memcpy(c->mt_out, H->mt, sizeof(H->mt));
+    }
+    return AZUL_SUCCESS;
 }
 
 // AZUL_SELFPLAY_KERNEL=1 selects the one-game-per-wave kernel (azul_core.hpp) for A/B measurements; default: two games per wave

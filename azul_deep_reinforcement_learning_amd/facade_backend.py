@@ -1,12 +1,18 @@
 """Single-game bridge between the Python facade (azul.py / game_runner.py of this package) and the C ABI.
 
-A facade call = pack the object's numpy attributes into one record (128 bytes for two players, the 256-byte wide
-record for three and four), run ONE kernel on a 1-game batch, unpack.  Randomness stays the reference's: the process-global CPython ``random`` stream.  Before a
-call that draws, the generator's 624 words + index are pushed into the game's device stream
-(``azul_batch_set_rng``); afterwards the advanced state is pulled back and installed with
-``random.setstate`` -- so ``random.seed(1); Azul().new_round()`` gives the reference's board exactly
-(reference tests/test_azul.py:36-39) while every draw is computed on the GPU.
+A facade call = ONE ``azul_game_call``: the object's numpy attributes packed into one record (128 bytes for two players, the
+256-byte wide record for three and four), ONE kernel on a 1-game batch, the results back -- one submission, one host
+synchronisation.  The record is only sent when it differs from what the device already holds (the facade's attributes are
+caller-writable numpy arrays, so the packed bytes are compared, not a dirty flag).
+
+Randomness stays the reference's: the process-global CPython ``random`` stream.  A call that draws runs on the game's device
+stream; afterwards the advanced state is installed with ``random.setstate`` -- so ``random.seed(1); Azul().new_round()`` gives
+the reference's board exactly (reference tests/test_azul.py:36-39) while every draw is computed on the GPU.  The 624 words
+cross PCIe only when they have to: host -> device when ``random.getstate()`` is not the state this backend installed last
+(somebody seeded or drew on the host in between), device -> host when the call regenerated them (every 624 draws); otherwise
+only the index moves.  `RandomAgent` samples on whichever backend holds the stream, so a GameRunner loop keeps it resident.
 """
+import ctypes as C
 import random
 
 import numpy as np
@@ -33,8 +39,44 @@ def _count(h2d=0, d2h=0, launches=0, syncs=0):
     _TRAFFIC["syncs"] += syncs
 
 
+# who holds the global `random` stream on a device: the backend that ran the last drawing call and the state it installed
+_RNG = {"be": None, "state": None, "pos": 0}
+
+
+class StepwiseBackend:
+    """A backend that exposes the steps of a facade call separately -- put / push_rng / op_* / pull_rng / get -- e.g. the host
+    emulation of the device core in tests/hostcheck.  `call` strings them together in the order the fused entry performs them."""
+
+    def call(self, op, args=(), rec=None, draws=False, mutates=True):
+        self.put(rec)
+        if draws:
+            self.push_rng()
+        out = getattr(self, op)(*args)
+        if draws:
+            self.pull_rng()
+        return out, (self.get() if mutates else None)
+
+    def sample(self, mask):
+        self.push_rng()
+        a = self.op_sample_mask(mask)
+        if a >= 0:
+            self.pull_rng()
+        return a
+
+
+# facade op -> (AZUL_CALL_*, results wanted, takes an argument)
+_OPS = {
+    "op_init": (L.CALL_INIT, 0), "op_new_round": (L.CALL_NEW_ROUND, 0), "op_move": (L.CALL_MOVE, 0),
+    "op_next_player": (L.CALL_NEXT_PLAYER, 0), "op_count_score": (L.CALL_COUNT_SCORE, 0), "op_step": (L.CALL_STEP, 0),
+    "op_flags": (L.CALL_QUERY, L.WANT_FLAGS), "op_mask": (L.CALL_QUERY, L.WANT_MASK), "op_observe": (L.CALL_QUERY, L.WANT_OBS),
+    "op_statistics": (L.CALL_QUERY, L.WANT_STATS), "op_potential": (L.CALL_QUERY, L.WANT_POTENTIAL),
+    "op_runner_init": (L.CALL_RUNNER_INIT, 0), "op_runner_reset": (L.CALL_RUNNER_RESET, 0), "op_runner_step": (L.CALL_RUNNER_STEP, 0),
+}
+_WANT_BYTES = ((L.WANT_MASK, 180), (L.WANT_OBS, 544), (L.WANT_STATS, 80))
+
+
 class HipBackend:
-    """1-game BatchedAzul per rule set, created lazily on the current CUDA device."""
+    """1-game BatchedAzul per rule set, created lazily on the current CUDA device; every facade call is one azul_game_call."""
 
     def __init__(self, first_player, tile_pool, players=2):
         import torch
@@ -46,84 +88,91 @@ class HipBackend:
         rules = {"first_player": "Random" if first_player == L.FIRST_RANDOM else int(first_player),
                  "tile_pool": "Lid" if tile_pool == L.POOL_LID else "Random"}
         self.env = BatchedAzul(1, rules=rules, players=players)
+        self.c = L.AzulCall()
+        self.c.game = 0
+        self._rec_in = np.zeros(1, dtype=self.env.record_dtype)
+        self._rec_out = np.zeros(1, dtype=self.env.record_dtype)
+        self._mt_in = np.zeros(624, dtype=np.uint32)
+        self._mt_out = np.zeros(624, dtype=np.uint32)
+        self._mask_in = np.zeros(180, dtype=np.uint8)
+        self.c.record_out = self._rec_out.ctypes.data
+        self.c.mt_out = self._mt_out.ctypes.data
+        self._resident = None                # bytes of the record the device holds
 
-    # --- RNG bridging -------------------------------------------------------------------------
-    def push_rng(self):
-        st = random.getstate()
-        words = np.array(st[1][:624], dtype=np.uint32)
-        self.env.set_rng(0, words, st[1][624])
-        _count(h2d=2500, syncs=1)
-        self._gauss = st[2]
+    def _submit(self, draws):
+        """Run self.c; for a drawing call: hand the global stream over (only if the device copy is stale) and install the advanced
+        state afterwards."""
+        c = self.c
+        h2d = 0
+        if draws:
+            st = random.getstate()
+            if _RNG["be"] is self and _RNG["state"] == st:
+                c.mt_in, c.pos_in = None, _RNG["pos"]              # the device stream IS the global stream
+            else:
+                self._mt_in[:] = st[1][:624]
+                c.mt_in, c.pos_in = self._mt_in.ctypes.data, st[1][624]
+                h2d += 2500
+        else:
+            c.mt_in, c.pos_in = None, 0
+        L.check(L.lib.azul_game_call(self.env._h, C.byref(c), self.env._stream()))
+        if draws:
+            words = tuple(self._mt_out.tolist()) if c.rng_regenerated else st[1][:624]
+            new = (3, words + (int(c.pos_out),), st[2])
+            random.setstate(new)
+            _RNG["be"], _RNG["state"], _RNG["pos"] = self, new, int(c.pos_out)
+        return h2d
 
-    def pull_rng(self):
-        mt, pos = self.env.get_rng(0)
-        _count(d2h=2500, syncs=1)
-        random.setstate((3, tuple(int(x) for x in mt) + (int(pos),), self._gauss))
+    def call(self, op, args=(), rec=None, draws=False, mutates=True):
+        """One facade method: `rec` = the caller's packed attributes; returns (result, record after the call or None)."""
+        c = self.c
+        c.op, want = _OPS[op]
+        c.arg = int(args[0]) if args else 0
+        c.mask_in = None
+        rb = rec.tobytes()
+        h2d = 4 if args else 0
+        if rb != self._resident:
+            self._rec_in[0] = rec
+            c.record_in = self._rec_in.ctypes.data
+            h2d += len(rb)
+        else:
+            c.record_in = None
+        c.want = want | (L.WANT_RECORD if mutates else 0)
+        try:
+            h2d += self._submit(draws)
+        except Exception:
+            self._resident = None            # the library refused the call (e.g. a record outside the kernels' domain)
+            raise
+        d2h = 24 + sum(n for bit, n in _WANT_BYTES if want & bit) + (len(rb) if mutates else 0) + (2496 if (draws and c.rng_regenerated) else 0)
+        _count(h2d=h2d, d2h=d2h, launches=1, syncs=1 + (1 if (draws and c.rng_regenerated) else 0))
+        new = None
+        if mutates:
+            new = self._rec_out[0].copy()
+            self._resident = new.tobytes()
+        else:
+            self._resident = rb
+        if op == "op_runner_step":
+            return (int(c.reward), bool(c.done), int(c.status)), new
+        if op == "op_mask":
+            return np.frombuffer(bytes(c.mask), dtype=np.uint8).astype(bool), new
+        if op == "op_observe":
+            return np.array(c.obs[:], dtype=np.float32).astype(np.int64), new
+        if op == "op_statistics":
+            return np.array(c.stats[:], dtype=np.float64), new
+        if op == "op_flags":
+            return int(c.flags), new
+        if op == "op_potential":
+            return int(c.potential), new
+        return int(c.status), new
 
-    # --- record in / out ------------------------------------------------------------------------
-    def put(self, rec):
-        self.env.set_records(rec)
-        _count(h2d=rec.nbytes, syncs=1)
-
-    def get(self):
-        _count(d2h=self.env.record_dtype.itemsize, syncs=1)
-        return self.env.get_records()[0]
-
-    # --- operations (each one launch) -------------------------------------------------------------
-    def _one(self, t, h2d=0):
-        _count(h2d=h2d, d2h=t.numel() * t.element_size(), launches=1, syncs=1 + (1 if h2d else 0))
-        return t.cpu().numpy()[0]
-
-    def op_init(self):
-        self.env.init()
-        _count(launches=1)
-
-    def op_new_round(self):
-        return int(self._one(self.env.new_round()))
-
-    def op_move(self, action):
-        self.env.move([action])
-        _count(h2d=4, launches=1, syncs=1)
-
-    def op_next_player(self):
-        self.env.next_player()
-        _count(launches=1)
-
-    def op_count_score(self):
-        self.env.count_score()
-        _count(launches=1)
-
-    def op_step(self, action):
-        return int(self._one(self.env.azul_step([action]), h2d=4))
-
-    def op_flags(self):
-        return int(self._one(self.env.flags()))
-
-    def op_mask(self):
-        return self._one(self.env.get_valid_moves()).astype(bool)
-
-    def op_observe(self, perspective):
-        return self._one(self.env.get_state(perspective)).astype(np.int64)
-
-    def op_statistics(self):
-        return self._one(self.env.statistics())
-
-    def op_potential(self):
-        return int(self._one(self.env.score_preview()))
-
-    def op_runner_init(self):
-        return int(self._one(self.env.runner_init()))
-
-    def op_runner_reset(self):
-        return int(self._one(self.env.reset()))
-
-    def op_runner_step(self, action):
-        reward, done, st = self.env.step([action])
-        _count(launches=-2)                             # one launch, three results
-        return int(self._one(reward, h2d=4)), bool(self._one(done)), int(self._one(st))
-
-    def op_sample_mask(self, mask):
-        return int(self._one(self.env.sample_mask(np.asarray(mask, dtype=np.uint8).reshape(1, 180)), h2d=180))
+    def sample(self, mask):
+        """RandomAgent.get_a_output on a caller's mask (game_runner.py:87-97): one random.choices draw on this backend's stream."""
+        c = self.c
+        c.op, c.arg, c.want, c.record_in = L.CALL_SAMPLE_MASK, 0, 0, None
+        self._mask_in[:] = np.asarray(mask, dtype=np.uint8).reshape(-1)[:180]
+        c.mask_in = self._mask_in.ctypes.data
+        h2d = 184 + self._submit(True)
+        _count(h2d=h2d, d2h=24 + (2496 if c.rng_regenerated else 0), launches=1, syncs=1 + (1 if c.rng_regenerated else 0))
+        return int(c.action)
 
 
 _FACTORY = HipBackend      # tests/hostcheck swaps in its 64-lane host emulation of the SAME core for CPU-only logic checks
@@ -135,3 +184,12 @@ def backend(first_player, tile_pool, players=2):
     if key not in _CACHE:
         _CACHE[key] = _FACTORY(int(first_player), int(tile_pool), int(players))
     return _CACHE[key]
+
+
+def sampling_backend():
+    """The backend RandomAgent draws on: the one that holds the global stream if there is one (any rule set can run the sampler),
+    so that a GameRunner loop never moves the 624 words."""
+    be = _RNG["be"]
+    if be is not None and type(be) is _FACTORY:
+        return be
+    return backend(1, L.POOL_RANDOM)

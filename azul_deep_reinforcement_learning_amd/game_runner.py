@@ -117,12 +117,9 @@ class RandomAgent:
     def get_a_output(self, state, valid_moves):
         from . import facade_backend as fb
         mask = np.asarray(valid_moves.numpy() if hasattr(valid_moves, "numpy") else valid_moves).reshape(-1)[:180]
-        be = fb.backend(1, L.POOL_RANDOM)
-        be.push_rng()
-        a = be.op_sample_mask(mask.astype(np.uint8))
+        a = fb.sampling_backend().sample(mask.astype(np.uint8))
         if a < 0:
             raise ValueError("Total of weights must be greater than zero")
-        be.pull_rng()
         return a
 
 

@@ -172,6 +172,58 @@ int azul_batch_sample_mask(azul_batch_t *b, const uint8_t *mask_dev /*[N][180]*/
                            int32_t *actions_dev, void *stream);
 int azul_batch_score_preview(azul_batch_t *b, int32_t *potential_dev /*[N]*/, void *stream);   /* deepcopy+count_score, score[0]-score[1]  game_runner.py:48-50 */
 
+/* ---- one method call of the reference's SINGLE-GAME API on one game of a batch -------------------
+ * What the Python facade (Azul / GameRunner / RandomAgent of this package, i.e. BASELINE configs[0]: tests/test_azul.py,
+ * tests/test_game_runner.py, nn_runner.py:22-30 on the unchanged agent.py) needs per method call, in ONE submission and ONE
+ * host synchronisation: [record_in -> device] [mt_in -> device] [the rule kernel on game `game`] [results -> host].
+ * `record_in` / `mt_in` NULL: the device copies are current (the caller compared them with what it last received);
+ * results are only transferred when asked for in `want`; the 624 MT19937 words only come back when the call regenerated them
+ * (`rng_regenerated`; otherwise only the index moved: `pos_out`).  All pointers are HOST pointers.
+ *   op                       reference method                                   arg
+ *   AZUL_CALL_QUERY          is_legal_move / check_all_valid (azul.py:162-176, game_runner.py:113-117), is_end_of_round /
+ *                            is_end_of_game (azul.py:182-191), get_state (game_runner.py:56-72), get_statistics (azul.py:314-315),
+ *                            the what-if potential (game_runner.py:48-50): selected by `want`   perspective (WANT_OBS)
+ *   AZUL_CALL_INIT           Azul.__init__ first-player draw (azul.py:37)                       -
+ *   AZUL_CALL_NEW_ROUND      new_round (azul.py:64-89)                                          -
+ *   AZUL_CALL_MOVE           move (azul.py:118-161)                                             action d + 6 c + 30 r
+ *   AZUL_CALL_NEXT_PLAYER    next_player (azul.py:177-181)                                      -
+ *   AZUL_CALL_COUNT_SCORE    count_score (azul.py:192-295)                                      -
+ *   AZUL_CALL_STEP           step (azul.py:296-313)                                             action
+ *   AZUL_CALL_RUNNER_INIT    GameRunner.__init__ (game_runner.py:23-36)                         -
+ *   AZUL_CALL_RUNNER_RESET   GameRunner.reset (game_runner.py:76-85)                            -
+ *   AZUL_CALL_RUNNER_STEP    GameRunner.step with the RandomAgent opponent (game_runner.py:43-55)   action
+ *   AZUL_CALL_SAMPLE_MASK    RandomAgent.get_a_output on `mask_in` (game_runner.py:87-97)       -                            */
+enum { AZUL_CALL_QUERY = 0, AZUL_CALL_INIT, AZUL_CALL_NEW_ROUND, AZUL_CALL_MOVE, AZUL_CALL_NEXT_PLAYER, AZUL_CALL_COUNT_SCORE,
+       AZUL_CALL_STEP, AZUL_CALL_RUNNER_INIT, AZUL_CALL_RUNNER_RESET, AZUL_CALL_RUNNER_STEP, AZUL_CALL_SAMPLE_MASK };
+#define AZUL_WANT_RECORD     1u    /* the game's record after the call -> record_out */
+#define AZUL_WANT_MASK       2u    /* legal mask of the state after the call -> mask[180] */
+#define AZUL_WANT_OBS        4u    /* get_state(perspective = arg) -> obs[136] (two players) */
+#define AZUL_WANT_FLAGS      8u    /* AZUL_FLAG_* -> flags */
+#define AZUL_WANT_POTENTIAL 16u    /* game_runner.py:48-50 -> potential (two players) */
+#define AZUL_WANT_STATS     32u    /* get_statistics -> stats[10] */
+typedef struct azul_call {
+    /* in */
+    int32_t op, game, arg;
+    uint32_t want;
+    const void *record_in;          /* NULL or the game's record (azul_batch_record_bytes bytes; validated like azul_batch_set_state) */
+    const uint32_t *mt_in;          /* NULL or 624 words: the stream to draw from (random.getstate()[1][:624]) */
+    uint32_t pos_in;                /* the stream's index BEFORE the call: random.getstate()[1][624] with mt_in, else the pos_out last received */
+    const uint8_t *mask_in;         /* AZUL_CALL_SAMPLE_MASK: uint8[180] */
+    void *record_out;               /* AZUL_WANT_RECORD */
+    uint32_t *mt_out;               /* NULL or room for 624 words, written only when rng_regenerated */
+    /* out */
+    uint32_t pos_out;               /* index of the game's stream after the call */
+    int32_t rng_regenerated;        /* the call regenerated the 624 words (they are in mt_out if given) */
+    int32_t status;                 /* AZUL_OK / AZUL_ILLEGAL_MOVE / ... */
+    int32_t reward, done;           /* AZUL_CALL_RUNNER_STEP */
+    int32_t action;                 /* AZUL_CALL_SAMPLE_MASK (-1: nothing legal) */
+    int32_t flags, potential;
+    uint8_t mask[AZUL_NUM_ACTIONS];
+    float obs[AZUL_OBS_SIZE];
+    double stats[AZUL_NUM_STATS];
+} azul_call_t;
+int azul_game_call(azul_batch_t *b, azul_call_t *call, void *stream);
+
 /* ---- policy-driven self-play (BASELINE configs[2]; callers: agent.py:64-81, nn_runner.py:17-47) ---------------- */
 /* One env move for every game with caller-chosen actions, fused: Azul.step for the current player (azul.py:296-313) ->
  * per-move shaped reward (delta of the what-if potential, game_runner.py:48-52) -> done -> statistics + auto-reset of

@@ -75,7 +75,10 @@ class HostStream:
         return {"rec": rec, "mt": mt, "pos": int(pos[0]), "episodes": int(ep[0]), "stuck": int(stuck[0]), "stat_sum": ss}
 
 
-class EmuBackend:
+from azul_deep_reinforcement_learning_amd.facade_backend import StepwiseBackend  # noqa: E402  (the facade's stepwise call order)
+
+
+class EmuBackend(StepwiseBackend):
     """TEST-ONLY stand-in for azul_deep_reinforcement_learning_amd.facade_backend.HipBackend: the same device
     core, compiled for the host with the 64-lane emulation.  Lets the facade's logic (and, in the build
     container, the reference's own test files) run without a GPU.  Never selected by the product."""

@@ -1,0 +1,110 @@
+"""azul_game_call -- one method of the reference's single-game API per submission (BASELINE configs[0], the drop-in path of
+tests/test_azul.py / tests/test_game_runner.py / nn_runner.py:22-30) -- against the oracle, with the bookkeeping that keeps
+PCIe quiet: the record is sent only when it differs from the device's copy, the 624 MT19937 words only when the global
+`random` stream is not the one the device holds, and they come back only when a call regenerated them."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _episode(pkg, agent, seed):
+    random.seed(seed)
+    r = pkg.GameRunner()
+    r.reset()
+    done, trace = False, []
+    while not done:
+        mask = r.get_valid_moves()
+        a = agent.get_a_output(None, torch.from_numpy(mask[None, :]))
+        reward, done = r.step(a)
+        trace.append((a, reward, done))
+    return r, trace
+
+
+def test_game_runner_loop_matches_the_oracle_and_keeps_the_stream_resident():
+    """SURVEY 8d config 1 through the facade vs the oracle's GameRunner, episode by episode: same actions, rewards, final records,
+    and the GLOBAL random stream ends where CPython's would (the oracle's stream state).  Across episodes the stream regenerates
+    several times; the words must only travel then."""
+    import azul_deep_reinforcement_learning_amd as pkg
+    import azul_deep_reinforcement_learning_amd.facade_backend as fb
+    from oracle import oracle as oz
+    fb._FACTORY = fb.HipBackend
+    agent = pkg.RandomAgent()
+    _episode(pkg, agent, 12345)                         # warm-up (lazy backends)
+    fb.reset_traffic()
+    games = 12
+    for seed in range(games):
+        r, trace = _episode(pkg, agent, seed)
+        # the oracle's version of the same program: random.seed(seed); GameRunner(); reset(); RandomAgent for player 1
+        lib, rng, q = oz.lib(), oz.seeded_rng(seed), oz.Runner()
+        assert lib.oz_runner_init(C.byref(q), oz.FIRST_RANDOM, oz.POOL_LID, C.byref(rng)) == 0
+        assert lib.oz_runner_reset(C.byref(q), C.byref(rng)) == 0
+        for (a, reward, done) in trace:
+            mask = np.ascontiguousarray(oz.check_all_valid(q.game).astype(np.uint8))
+            oa = lib.oz_random_agent(mask.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(rng))
+            orew, odone = C.c_int64(0), C.c_int(0)
+            assert lib.oz_runner_step(C.byref(q), oa, C.byref(rng), C.byref(orew), C.byref(odone)) == 0
+            assert (oa, orew.value, bool(odone.value)) == (a, reward, done)
+        assert oz.pack(q).tobytes() == r.game._to_record(r).tobytes()
+        st = random.getstate()
+        assert st[1][624] == int(rng.idx) and np.array_equal(np.array(st[1][:624], dtype=np.uint32), np.ctypeslib.as_array(rng.mt))
+    tr = fb.traffic()
+    # round 2's facade moved 156 KB per episode in each direction and synchronised 400 times (bench.py extra.facade_config1)
+    assert tr["h2d"] / games < 156019 / 5 and tr["d2h"] / games < 152777 / 5
+    assert tr["syncs"] / games < 120
+    random.seed()
+
+
+def test_call_block_semantics():
+    """The C entry itself: record / stream handed in or left resident, results on request, regeneration reported."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    from azul_deep_reinforcement_learning_amd import _lib as L
+    from oracle import oracle as oz
+    env = BatchedAzul(3, device="cuda:0")
+    env.seed(50)
+    env.runner_init()
+    env.reset()
+    recs = env.get_records()
+    c = L.AzulCall()
+    rec_out = np.zeros(1, dtype=env.record_dtype)
+    mt_out = np.zeros(624, dtype=np.uint32)
+    c.record_out, c.mt_out = rec_out.ctypes.data, mt_out.ctypes.data
+    # a query on game 1 leaves everything alone and answers what the batch entries answer
+    c.op, c.game, c.arg, c.want = L.CALL_QUERY, 1, 0, L.WANT_MASK | L.WANT_OBS | L.WANT_FLAGS | L.WANT_POTENTIAL | L.WANT_STATS
+    L.check(L.lib.azul_game_call(env._h, C.byref(c), None))
+    assert np.array_equal(np.frombuffer(bytes(c.mask), np.uint8), env.get_valid_moves().cpu().numpy()[1].astype(np.uint8))
+    assert np.array_equal(np.array(c.obs[:], np.float32), env.get_state(0).cpu().numpy()[1])
+    assert c.flags == int(env.flags()[1]) and c.potential == int(env.score_preview()[1])
+    assert np.array_equal(np.array(c.stats[:]), env.statistics().cpu().numpy()[1])
+    assert env.get_records().tobytes() == recs.tobytes()
+    # a stream handed in with the index at 623: the first random() straddles the regeneration -> reported, words returned
+    random.seed(7)
+    st = random.getstate()
+    words = np.array(st[1][:624], dtype=np.uint32)
+    mask = env.get_valid_moves().cpu().numpy()[2].astype(np.uint8)
+    c.op, c.game, c.want, c.record_in = L.CALL_SAMPLE_MASK, 2, 0, None
+    c.mt_in, c.pos_in, c.mask_in = words.ctypes.data, 623, mask.ctypes.data
+    L.check(L.lib.azul_game_call(env._h, C.byref(c), None))
+    random.setstate((3, st[1][:624] + (623,), None))
+    w = [0.01 if i < 30 else 1.0 for i in range(180)]
+    want = random.choices(range(180), weights=[w[i] * mask[i] for i in range(180)])[0]       # game_runner.py:94-97
+    assert c.action == want and c.rng_regenerated == 1 and c.pos_out == 1
+    after = random.getstate()
+    assert np.array_equal(mt_out, np.array(after[1][:624], dtype=np.uint32)) and after[1][624] == c.pos_out
+    # the next draw uses the resident stream (mt_in NULL): index moves, no regeneration
+    c.mt_in, c.pos_in = None, c.pos_out
+    L.check(L.lib.azul_game_call(env._h, C.byref(c), None))
+    want = random.choices(range(180), weights=[w[i] * mask[i] for i in range(180)])[0]
+    assert c.action == want and c.rng_regenerated == 0 and c.pos_out == 3
+    # a record handed in is validated like azul_batch_set_state
+    bad = recs[:1].copy()
+    bad["floors"][0, 0] = 9
+    c.op, c.game, c.record_in, c.mask_in = L.CALL_QUERY, 0, bad.ctypes.data, None
+    assert L.lib.azul_game_call(env._h, C.byref(c), None) == L.ERR_RANGE
+    c.game = 3
+    assert L.lib.azul_game_call(env._h, C.byref(c), None) == L.ERR_INVALID
+    random.seed()

@@ -523,6 +523,7 @@ template <bool LID, int OUT, bool PAD, bool BITS>
 __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs t, u32 mask_stride)
 {
     __shared__ u32 mt_lds[2][624];
+    __shared__ u32 mtt_lds[2][624];                        // the same words tempered (az2::Rng2::tlds)
     __shared__ double tab_lds[T_WORDS];
     __shared__ double2 tabfs_lds[T_ROWS * T_BINADES];      // {Fr[J][b], S[J]}: both table values of a decision in one 16-byte read
     const u32 lane = wv::lane(), l = lane & 31u, half = lane >> 5;
@@ -546,9 +547,11 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
     az2::Rng2 r;
     u32 *gmt = b.mt + (size_t)gi * 624u;
     az2::rng2_open(r, gmt, mt_lds[half], b.mtpos[gi], l);
+    az2::rng2_attach_tempered(r, mtt_lds[half], l);
     const u64 margin = b.draw_margin;
     az2::Counters2 cnt = {b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10};
-    az2::Out2 o = {t.mask, t.maskbits, t.action, t.reward, t.done, t.packed, t.rec, mask_stride, gi};
+    az2::Out2 o = {t.mask, t.maskbits, t.action, t.reward, t.done, t.packed, t.rec, mask_stride, gi,
+                   l == 0u ? (u32 *)t.action : (l == 1u ? (u32 *)t.reward : t.packed)};
 #if defined(AZ_PROFILE_SEGMENTS)
     SegProf prof;
     for (int q = 0; q < SEG_COUNT; q++) prof.acc[q] = 0;
@@ -557,12 +560,23 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
 #else
     SegProf *pp = nullptr;
 #endif
+#if !defined(AZ2_ROTATED_LOOP)    // default: one selfplay_step2 per move; -DAZ2_ROTATED_LOOP: the rotated loop (measured 2 % slower)
 #pragma unroll 1
     for (int s = 0; s < t.n_steps; s++) {
         u32 f = az2::selfplay_step2<LID, OUT, PAD, BITS>(g, b.rules.first_player, k, r, tab, margin, cnt, o, pp);
         if (f & 0x100u) break;      // rule error (box empty): leave the game as it is
         o.e += b.n;
     }
+#else
+    az2::Prep2 P;
+    az2::prepare2(g, k, r, tab, P);
+#pragma unroll 1
+    for (int s = 0; s < t.n_steps; s++) {
+        u32 f = az2::selfplay_rotated2<LID, OUT, PAD, BITS>(g, P, b.rules.first_player, k, r, tab, margin, cnt, o, pp);
+        if (f & 0x100u) break;      // rule error (box empty): leave the game as it is
+        o.e += b.n;
+    }
+#endif
 #if defined(AZ_PROFILE_SEGMENTS)
     if (lane == 0u) for (int q = 0; q < SEG_COUNT; q++) atomicAdd((unsigned long long *)(b.prof + q), (unsigned long long)prof.acc[q]);
 #endif
@@ -1358,6 +1372,8 @@ int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev,
     const dim3 grid(version == 1 ? b->d.n : (b->d.n + 1u) / 2u), block(64);
     const hipStream_t st = (hipStream_t)stream;
     const u32 ms = (u32)mask_row_bytes;
+    // padded rows (>= 192 bytes, 8-byte aligned: alloc_trajectory(mask_pitch = 192)) take the one-store-per-row path
+    const bool pad = ms >= 192u && ms % 8u == 0u && ((uintptr_t)mask_dev & 7u) == 0u;
 #define AZ_LAUNCH(LID) do { \
         if (version == 1) { \
             if (none) hipLaunchKernelGGL((azul_selfplay_kernel<LID, 0>), grid, block, 0, st, b->d, t); \
@@ -1365,8 +1381,8 @@ int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev,
             else hipLaunchKernelGGL((azul_selfplay_kernel<LID, 2>), grid, block, 0, st, b->d, t); \
         } else { \
             if (none) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 0, false, false>), grid, block, 0, st, b->d, t, ms); \
-            else if (full && ms >= 192u) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true, true>), grid, block, 0, st, b->d, t, ms); \
-            else if (core && ms >= 192u) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true, false>), grid, block, 0, st, b->d, t, ms); \
+            else if (full && pad) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true, true>), grid, block, 0, st, b->d, t, ms); \
+            else if (core && pad) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true, false>), grid, block, 0, st, b->d, t, ms); \
             else if (full) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, false, true>), grid, block, 0, st, b->d, t, ms); \
             else hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 2, false, false>), grid, block, 0, st, b->d, t, ms); \
         } } while (0)

@@ -62,19 +62,34 @@ AZ_FN double hread_d(double v, u32 idx)
 
 template <int CTRL, int ROWMASK>
 AZ_FN u32 dpp0(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, true); }   // lanes without a source read 0
-// sum / maximum over the 32 lanes of my half (every lane receives it)
+// sum / maximum over the 32 lanes of my half (every lane receives it): an all-reduce inside each 16-lane row with four DPP steps
+// (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), then gfx950's v_permlane16_swap exchanges the two rows of each half
+// (odd rows of the first operand with even rows of the second): six instructions, no trip through the scalar registers
+// (the round-2 form -- row_shr chain, row_bcast:15, two v_readlane, two moves, a select -- needed ten)
 AZ_FN u32 hsum(u32 v)
 {
+#if defined(AZ2_HSUM_READLANE)
     v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);   // row_shr 1, 2, 4, 8
     v += dpp0<0x142, 0xa>(v);                                                                             // row_bcast:15 into rows 1 and 3
     return hbcast_c<31>(v);
+#else
+    v += dpp0<0xB1, 0xf>(v); v += dpp0<0x4E, 0xf>(v); v += dpp0<0x141, 0xf>(v); v += dpp0<0x140, 0xf>(v);
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (u32)r[0] + (u32)r[1];
+#endif
 }
 AZ_FN u32 umax(u32 a, u32 b) { return a > b ? a : b; }
 AZ_FN u32 hmax(u32 v)
 {
+#if defined(AZ2_HSUM_READLANE)
     v = umax(v, dpp0<0x111, 0xf>(v)); v = umax(v, dpp0<0x112, 0xf>(v)); v = umax(v, dpp0<0x114, 0xf>(v)); v = umax(v, dpp0<0x118, 0xf>(v));
     v = umax(v, dpp0<0x142, 0xa>(v));
     return hbcast_c<31>(v);
+#else
+    v = umax(v, dpp0<0xB1, 0xf>(v)); v = umax(v, dpp0<0x4E, 0xf>(v)); v = umax(v, dpp0<0x141, 0xf>(v)); v = umax(v, dpp0<0x140, 0xf>(v));
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return umax((u32)r[0], (u32)r[1]);
+#endif
 }
 
 // ---- per-lane constants -------------------------------------------------------------------------------------------------
@@ -186,6 +201,8 @@ AZ_FN void g2_store(const G2 &g, uint8_t *rec, u32 l)
 // ---- CPython MT19937 stream of one game (azul_core.hpp's Rng, 32 lanes wide) ---------------------------------------------
 struct Rng2 {
     u32 *lds;        // my game's 624 words in LDS
+    u32 *tlds;       // optional: the same 624 words TEMPERED (kept current by the regeneration), what genrand_uint32 returns for index i;
+                     // the rotated self-play loop reads a move's two words from here with one LDS read and no arithmetic
     u32 pos;         // CPython's `index`
     u32 dirty;       // a regeneration happened: LDS differs from global memory
     u32 wbase, wend; // the window `win` serves words wbase .. wend-1 (wend == 0: none loaded)
@@ -205,12 +222,21 @@ AZ_FN void lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); _
 
 AZ_FN void rng2_open(Rng2 &r, const u32 *gmt, u32 *lds, u32 pos, u32 l)
 {
-    r.lds = lds; r.pos = pos; r.dirty = 0; r.wbase = 0; r.wend = 0; r.win = 0;
+    r.lds = lds; r.tlds = nullptr; r.pos = pos; r.dirty = 0; r.wbase = 0; r.wend = 0; r.win = 0;
     u32 w[20];
 #pragma unroll
     for (u32 q = 0; q < 20u; q++) { u32 i = l + 32u * q; w[q] = i < 624u ? gmt[i] : 0u; }     // all loads in flight, then the LDS writes
 #pragma unroll
     for (u32 q = 0; q < 20u; q++) { u32 i = l + 32u * q; if (i < 624u) lds[i] = w[q]; }
+    lds_sync();
+}
+
+// attach the tempered copy (624 more words of LDS per game) and fill it from the words rng2_open staged
+AZ_FN void rng2_attach_tempered(Rng2 &r, u32 *tlds, u32 l)
+{
+    r.tlds = tlds;
+#pragma unroll 1
+    for (u32 q = 0; q < 20u; q++) { u32 i = l + 32u * q; if (i < 624u) tlds[i] = temper2(r.lds[i]); }
     lds_sync();
 }
 
@@ -229,7 +255,7 @@ AZ_FN void rng2_twist(Rng2 &r, u32 l)
         u32 y = (a & 0x80000000u) | (b & 0x7fffffffu);
         u32 v = c ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
         lds_sync();
-        if (act) r.lds[i] = v;
+        if (act) { r.lds[i] = v; if (r.tlds) r.tlds[i] = temper2(v); }
         lds_sync();
     }
     r.dirty = 1;
@@ -361,12 +387,15 @@ AZ_FN u32 sample_slow2(const Tab2 &T, double x, double sJ, u32 J, u32 M, u32 L)
 
 // ---- move: azul.py:118-161.  Returns whether the targeted pattern line is full afterwards ------------------------------------
 template <bool LID>
-AZ_FN bool do_move2(G2 &g, u32 code, u32 B /* sources before the move */, u32 l)
+AZ_FN bool do_move2f(G2 &g, u32 src, u32 db, u32 c, u32 row, bool from_display, u32 B /* sources before the move */, u32 l)
 {
     const u32 me = me2(g);
-    const u32 src = code & 31u, db = (code >> 5) & 31u, c = (code >> 10) & 7u, row = (code >> 13) & 7u;
-    const bool from_display = ((code >> 16) & 1u) != 0u;
+    // the three cell gathers of a move depend on the chosen action only: requested together (ONE LDS round trip on the move's chain)
+    const u32 cell = 5u * ((row ? row : 1u) - 1u) + c;
+    u32 mine = me ? g.cp1 : g.cp0;
     u32 n = hbcast(g.cs, src);                                         // :127 / :136
+    const u32 moved = hread(g.cs, l - 25u + db);                       // :131
+    const u32 old = hbcast(mine, cell);
 #if defined(AZ2_EXPERIMENT_EXTRA_LDS)
     n = hread(n, l);                                                   // TIMING EXPERIMENT: one more dependent LDS round trip (identity)
 #endif
@@ -374,15 +403,12 @@ AZ_FN bool do_move2(G2 &g, u32 code, u32 B /* sources before the move */, u32 l)
     asm volatile("s_branch 1f\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n 1:\n s_branch 2f\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n 2:\n s_branch 3f\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n 3:\n s_branch 4f\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n 4:" ::: "memory");   // TIMING EXPERIMENT: four taken branches
 #endif
     bool token = (!from_display) & (((B >> 30) & 1u) != 0u);           // :140
-    u32 moved = hread(g.cs, l - 25u + db);                             // :131
     bool centre = (l >= 25u) & (l < 30u) & (l != 25u + c) & from_display;
     bool gone = ((l >= db) & (l < db + 5u) & from_display) | (l == src) | ((l == 30u) & token);   // :129,:133,:138,:141
-    g.cs = gone ? 0u : (centre ? g.cs + moved : g.cs);
+    const u32 grown = g.cs + (centre ? moved : 0u);                    // (a plain sum: no branch around the gathered value)
+    g.cs = gone ? 0u : grown;
     g.nfp = token ? g.cur : g.nfp;                                     // :142
     u32 fl = (me ? g.floor1 : g.floor0) + (token ? 1u : 0u);           // :143 (the cap of :120-123 is applied once, below: it is monotone)
-    u32 cell = 5u * ((row ? row : 1u) - 1u) + c;
-    u32 mine = me ? g.cp1 : g.cp0;
-    u32 old = hbcast(mine, cell);
     i32 overflow = row ? (i32)row - (i32)old - (i32)n : -(i32)n;       // :147
     u32 spill = overflow < 0 ? (u32)(-overflow) : 0u;
     u32 newv = overflow < 0 ? row : old + n;                           // :150 / :152
@@ -402,6 +428,12 @@ AZ_FN bool do_move2(G2 &g, u32 code, u32 B /* sources before the move */, u32 l)
     g.floor1 = me ? fl : g.floor1;
     if (LID) g.lid += (u64)spill << (8u * c);                          // :156-157 / :160-161
     return (row != 0u) & (overflow <= 0);
+}
+
+template <bool LID>
+AZ_FN bool do_move2(G2 &g, u32 code, u32 B /* sources before the move */, u32 l)
+{
+    return do_move2f<LID>(g, code & 31u, (code >> 5) & 31u, (code >> 10) & 7u, (code >> 13) & 7u, ((code >> 16) & 1u) != 0u, B, l);
 }
 
 // ---- wall pricing: azul_core.hpp's score_boards for one player in lanes 0..24 --------------------------------------------
@@ -684,6 +716,7 @@ struct Out2 {
     uint8_t *rec;        // test stream: the record after the move
     u32 pitch;           // bytes between the mask rows of consecutive games
     u32 e;
+    u32 *dw3;            // OUT == 1: lane 0 -> action, lane 1 -> reward, lanes 2.. -> packed: the three 4-byte records of a move leave in ONE store
 };
 
 template <int OUT>
@@ -692,8 +725,17 @@ AZ_FN void outputs2(const G2 &g, const Out2 &o, i32 a, i32 reward, u32 dn, u32 l
     if (OUT == 0) return;
     const i32 av = a >= 0 ? a : -1;
     if (OUT == 1) {
-        // every lane of the half stores the same value to the same address: one request, no exec masking
-        o.action[o.e] = av; o.reward[o.e] = reward; o.packed[o.e] = pack_move(a, dn, reward); o.done[o.e] = (uint8_t)dn;
+        // A store instruction costs this kernel ~45 cycles of a wave's time (ten times a vector instruction: measured by leaving
+        // stores out), so the three 4-byte records of a move leave in ONE instruction -- lane 0 of the half writes the action, lane 1
+        // the reward, the other lanes the compact record (same address, same data: no exec masking) -- and `done` in a second one.
+#if defined(AZ2_X_NO_SCALAR_STORES)
+        if (l > 64u)
+#endif
+        {
+            const u32 pk = pack_move(a, dn, reward);
+            o.dw3[o.e] = l == 0u ? (u32)av : (l == 1u ? (u32)reward : pk);
+            o.done[o.e] = (uint8_t)dn;
+        }
     } else {
         if (l == 0u) {
             if (o.action) o.action[o.e] = av;
@@ -705,7 +747,92 @@ AZ_FN void outputs2(const G2 &g, const Out2 &o, i32 a, i32 reward, u32 dn, u32 l
     }
 }
 
+// The legal mask of a decision as the byte row the policy net consumes (byte a = 30 r + l of the game's row = bit l of word r).
+// PAD (rows of >= 192 bytes, 8-byte aligned): the 180 bits are concatenated (the six 30-bit row words back to back), lane j < 23 of
+// the half takes bits 8 j .. 8 j + 7, spreads them into eight 0 / 1 bytes (two 24-bit multiplies) and ONE 8-byte store per lane
+// writes bytes 0 .. 183 of the row (180 .. 183 are padding; lanes 23.. repeat lane 22: no exec masking).  Otherwise: six stores
+// of 30 bytes, byte 30 r + l from lane l.
+template <bool PAD>
+AZ_FN void store_mask_row2(const Out2 &o, u32 m0, u32 m1, u32 m2, u32 m3, u32 m4, u32 m5, u32 b0, u32 b1, u32 b2, u32 b3, u32 b4, u32 b5, u32 l)
+{
+#if defined(AZ2_X_NO_MASK_STORES)
+    return;
+#endif
+    if (PAD) {
+        const u64 q0 = (u64)m0 | ((u64)m1 << 30) | ((u64)m2 << 60);
+        const u64 q1 = ((u64)m2 >> 4) | ((u64)m3 << 26) | ((u64)m4 << 56);
+        const u64 q2 = ((u64)m4 >> 8) | ((u64)m5 << 22);
+        const u32 j = l < 22u ? l : 22u;
+        const u64 qs = j < 8u ? q0 : (j < 16u ? q1 : q2);
+        const u32 by = (u32)(qs >> (8u * (j & 7u))) & 0xffu;
+        const u32 lo = ((by & 15u) * 0x00204081u) & 0x01010101u, hi = ((by >> 4) * 0x00204081u) & 0x01010101u;
+        *(u64 *)(o.mask + (o.e * o.pitch + 8u * j)) = (u64)lo | ((u64)hi << 32);
+    } else {
+        uint8_t *row = o.mask + (o.e * o.pitch + l);
+        if (l < 30u) {
+            row[0] = (uint8_t)b0; row[30] = (uint8_t)b1; row[60] = (uint8_t)b2; row[90] = (uint8_t)b3; row[120] = (uint8_t)b4; row[150] = (uint8_t)b5;
+        }
+    }
+}
+
 struct Counters2 { u64 *episodes; u32 *stuck; double *stat_sum; };
+
+// Everything of a move that follows do_move2 (g.B already holds the sources after the move): what-if score of the mover, next
+// player or end of round (scoring, end of game, next round), shaped reward, outputs, episode statistics and reset.
+template <bool LID, int OUT>
+AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin, const Counters2 &cnt, const Out2 &o, u32 me, bool filled,
+                      i32 a, SegProf *prof_)
+{
+    (void)prof_;
+    const u32 l = k.l;
+    // a move only changes the MOVER's lines and floor; the pricing of his full lines only when one more of them filled
+    i32 wc = me ? g.wc1 : g.wc0;
+#if defined(AZ2_ALWAYS_WALLPTS)
+    {
+#else
+    if (wave_any(filled)) {
+#endif
+        i32 fresh = wall_points2(me ? g.wall1 : g.wall0, full_lines2(me ? g.cp1 : g.cp0, k), k);
+        wc = filled ? fresh : wc;
+    }
+    const i32 wi = clamp0((me ? g.score1 : g.score0) + floor_penalty(me ? g.floor1 : g.floor0) + wc);
+    g.wc0 = me ? g.wc0 : wc; g.wc1 = me ? wc : g.wc1;
+    g.wi0 = me ? g.wi0 : wi; g.wi1 = me ? wi : g.wi1;
+    const bool eor = g.B == 0u;                              // :306 is_end_of_round (the token counts)
+    g.cur = eor ? g.cur : (g.cur < 2u ? g.cur + 1u : 1u);    // :313 next_player
+    u32 st = ST_OK;
+    AZ_STAMP(SEG_AFTERMOVE);
+    if (AZ_UNLIKELY(wave_any(eor))) {
+        if (eor) {
+            count_score2<LID>(g, k);                         // :307 (also resets the what-if cache)
+            if (g.over) g.eog = 1;                           // :308-309
+        }
+        AZ_STAMP(SEG_SCORE);
+        if (eor & !g.over) st = new_round2<LID>(g, r, margin, k);      // :311
+        AZ_STAMP(SEG_NEWROUND);
+    }
+    const i32 phi = g.wi0 - g.wi1;
+    const i32 reward = phi - g.pscore;
+    g.pscore = phi;
+    const u32 dn = g.over ? 1u : 0u;
+    outputs2<OUT>(g, o, a, reward, dn, l);
+    AZ_STAMP(SEG_TAIL);
+    u32 ret = st != ST_OK ? (0x100u | st) : dn;
+    if (AZ_UNLIKELY(wave_any((dn != 0u) & (st == ST_OK)))) {
+        if ((dn != 0u) & (st == ST_OK)) {
+#if !defined(AZ2_X_NO_STATS)
+            if (l == 0u) {
+                for (u32 q = 0; q < 10u; q++) cnt.stat_sum[q] += game_stat2(g, q);
+                *cnt.episodes += 1ull;
+            }
+#endif
+            u32 st2 = episode_reset2<LID>(g, first_player, r, margin, k);     // GameRunner.reset(): Azul(rules) ... new_round()
+            if (st2) ret = 0x100u | st2;
+        }
+        AZ_STAMP(SEG_RESET);
+    }
+    return ret;
+}
 
 // One env move of flat random-agent self-play for the two games of a wave (selfplay_step of azul_core.hpp).
 // Returns 0 = move played, 1 = game ended with this move, 2 = stuck, 0x100 | status on a rule error.
@@ -720,30 +847,19 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     (void)prof_;
     AZ_STAMP(SEG_LOOP);
     const u32 l = k.l;
-    // -- the two MT19937 words of this move's random(), fetched speculatively (independent of the mask: overlaps with it).
-    //    Refilling the window is state-neutral; a fetch that would cross a regeneration is left to the rare path below.
-    if (wave_any(r.pos + 2u > r.wend)) {
-        bool easy = (r.pos + 2u > r.wend) & (r.pos + 2u <= 624u);
-        u32 i = r.pos + l;
-        u32 raw = r.lds[i < 624u ? i : 623u];
-        r.win = easy ? temper2(raw) : r.win;
-        r.wbase = easy ? r.pos : r.wbase;
-        r.wend = easy ? (r.pos + 32u < 624u ? r.pos + 32u : 624u) : r.wend;
+    // -- the two MT19937 words of this move's random(), fetched speculatively (independent of the mask: overlaps with it): one
+    //    8-byte read of the tempered copy; words that straddle / follow a regeneration are left to the rare path below
+    const bool hard = r.pos + 2u > 624u;
+    u32 wa, wb;
+    {
+        const u32 i = hard ? 622u : r.pos;
+        wa = r.tlds[i]; wb = r.tlds[i + 1u];
     }
-    const u32 off = r.pos - r.wbase;
-    u32 wa = hbcast(r.win, off), wb = hbcast(r.win, off + 1u);
-    const bool hard = r.pos + 2u > r.wend;               // still not served: the two words straddle / follow a regeneration
 
     Mask2 m;
     legal_mask2(g, k, m);
-    if (OUT == 1 || (OUT == 2 && o.mask)) {
-        // byte a = 30 r + l of the game's row: six stores of 30 bytes (lanes 30, 31 own no action)
-        uint8_t *row = o.mask + (o.e * o.pitch + l);
-        if (l < 30u) {
-#pragma unroll
-            for (u32 w = 0; w < 6u; w++) row[30u * w] = (uint8_t)m.bit[w];
-        }
-    }
+    if (OUT == 1 || (OUT == 2 && o.mask))
+        store_mask_row2<(PAD && OUT == 1)>(o, m.m[0], m.m[1], m.m[2], m.m[3], m.m[4], m.m[5], m.bit[0], m.bit[1], m.bit[2], m.bit[3], m.bit[4], m.bit[5], l);
     if ((OUT == 1 && BITS) || (OUT == 2 && o.maskbits)) {
         // the same 180 bits packed (bit a & 63 of word a >> 6): the six 30-bit row words concatenated
         const u64 q0 = (u64)m.m[0] | ((u64)m.m[1] << 30) | ((u64)m.m[2] << 60);
@@ -796,8 +912,13 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     const bool hit = (((mword >> l) & 1u) != 0u) & ((u32)__popc(mword & ((1u << l) - 1u)) == want - base);
     const u32 who = hb(hit);
     const u32 ln = (u32)__builtin_ctz(who | 0x80000000u);
-    const u32 code = hbcast(k.lcode, ln) | (prow_ << 13) | ((30u * prow_ + ln) << 17);
-    const i32 a = (i32)(code >> 17);
+    // (display, colour) of the answering lane: ln = d + 6 c decoded arithmetically (K2::lcode holds the same as lane constants, but
+    // fetching it from lane ln is an LDS round trip on the move's chain: ~100 cycles against ~10 instructions)
+    const u32 ac = (ln * 43u) >> 8, ad = ln - 6u * ac;               // ln / 6, ln % 6 for ln < 32
+    const bool a_disp = ad != 0u;
+    const u32 a_db = a_disp ? 5u * ad - 5u : 0u;
+    const u32 a_src = a_disp ? a_db + ac : 25u + ac;
+    const i32 a = (i32)(30u * prow_ + ln);
     AZ_STAMP(SEG_SAMPLE);
 
     u32 ret = 0;
@@ -813,54 +934,171 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     }
     if (!nomove) {
         const u32 me = me2(g);
-        const bool filled = do_move2<LID>(g, code, m.B, l);    // azul.py:304
+        const bool filled = do_move2f<LID>(g, a_src, a_db, ac, prow_, a_disp, m.B, l);    // azul.py:304
         g.moves += 1u;
         AZ_STAMP(SEG_MOVE);
-        // a move only changes the MOVER's lines and floor; the pricing of his full lines only when one more of them filled
+        g.B = hb(g.cs != 0u) & 0x7fffffffu;                      // the sources after the move (next move's mask reads it)
+        ret = after_move2<LID, OUT>(g, first_player, k, r, margin, cnt, o, me, filled, a, prof_);
+    }
+    return ret;
+}
+
+// ---- the benchmarked loop: the same moves, ROTATED so that one move's instruction chain is short -------------------------------
+// A move is a serial chain -- mask -> counts -> cumulative weights -> sample -> action -> move -> what-if score -> reward -- and two
+// waves per SIMD (4096 games) cannot hide the latency of a dependent instruction (~8.6 cycles against ~2.9 for independent ones,
+// tools/issue_model.hip): the kernel ran one instruction per ~9 cycles and wave.  But only part of that chain is loop-carried:
+//     sample(t) -> do_move(t) -> [mask, counts, weights, random words of move t+1] -> sample(t+1)
+// while the what-if score, the reward and the stores of move t hang off do_move(t) as a side chain.  The loop below therefore keeps
+// the DECISION OF THE NEXT MOVE PREPARED (Prep2: everything about a decision that depends on the state alone) and its common
+// iteration is ONE basic block in which the side chain of move t and the preparation of move t+1 are independent instruction
+// streams for the scheduler to interleave.  Everything unusual -- a decision at a boundary of the cumulative weights, random words
+// across a regeneration, nothing legal, the end of a round / game -- is tested once per wave and takes selfplay_step2 / after_move2,
+// the code above, on the very same state; then the next decision is prepared afresh.  Same moves, same bytes.
+struct Prep2 {
+    u32 m0, m1, m2, m3, m4, m5;          // legal_mask2 of the state: the six mask words ...
+    u32 b0, b1, b2, b3, b4, b5;          // ... and my bit of each (named scalars: an array indexed by a select chain would be turned into
+                                         // an indexed load and pin the whole struct in scratch memory)
+    u32 B;
+    u32 p2, p3, p4, p5;          // legal actions in mask words 0 .. w-1 (p1 == J)
+    u32 J, M;
+    double total, sJ, u;         // cum(J + M) + 0.0, S[J], random() of the two words at r.pos
+    bool unusual;                // nothing legal / a finished game handed in / the two words straddle a regeneration
+};
+
+// prepare2 in two halves, so that the common path can put independent work between the LDS requests and their use:
+// prepare2_request: mask, counts, the addresses, the two LDS reads (table pair, random words); prepare2_finish: the three doubles.
+struct PrepLoads2 { double2 fs; u32 wa, wb; };
+
+AZ_FN void prepare2_request(const G2 &g, const K2 &k, const Rng2 &r, const Tab2 &T, Prep2 &P, PrepLoads2 &q)
+{
+    Mask2 m;
+    legal_mask2(g, k, m);
+    P.m0 = m.m[0]; P.m1 = m.m[1]; P.m2 = m.m[2]; P.m3 = m.m[3]; P.m4 = m.m[4]; P.m5 = m.m[5];
+    P.b0 = m.bit[0]; P.b1 = m.bit[1]; P.b2 = m.bit[2]; P.b3 = m.bit[3]; P.b4 = m.bit[4]; P.b5 = m.bit[5];
+    P.B = m.B;
+    const u32 c0 = __popc(m.m[0]), c1 = __popc(m.m[1]), c2 = __popc(m.m[2]), c3 = __popc(m.m[3]), c4 = __popc(m.m[4]), c5 = __popc(m.m[5]);
+    P.J = c0;
+    P.p2 = c0 + c1; P.p3 = P.p2 + c2; P.p4 = P.p3 + c3; P.p5 = P.p4 + c4;
+    const u32 L = P.p5 + c5;
+    const bool nomove = (L == 0u) | (g.eog != 0u);
+    const u32 M = L - P.J, Mc = M ? M : 1u;
+    P.M = M;
+    q.fs = T.fs[8u * (P.J < 31u ? P.J : 30u) + 31u - (u32)__builtin_clz(Mc)];
+    const bool hard = r.pos + 2u > 624u;
+    const u32 i = hard ? 622u : r.pos;
+    q.wa = r.tlds[i]; q.wb = r.tlds[i + 1u];                // genrand_uint32() twice: the tempered words, one 8-byte LDS read
+    P.unusual = nomove | hard;
+}
+
+AZ_FN void prepare2_finish(Prep2 &P, const PrepLoads2 &q)
+{
+    P.sJ = q.fs.y;
+    P.total = ((double)P.M + (P.M ? q.fs.x : q.fs.y)) + 0.0;
+    P.u = ((double)(q.wa >> 5) * 67108864.0 + (double)(q.wb >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+AZ_FN void prepare2(const G2 &g, const K2 &k, const Rng2 &r, const Tab2 &T, Prep2 &P)
+{
+    PrepLoads2 q;
+    prepare2_request(g, k, r, T, P, q);
+    prepare2_finish(P, q);
+}
+
+template <bool LID, int OUT, bool PAD, bool BITS>
+AZ_FN u32 selfplay_rotated2(G2 &g, Prep2 &P, u32 first_player, const K2 &k, Rng2 &r, const Tab2 &T, u64 margin, const Counters2 &cnt,
+                            const Out2 &o, SegProf *prof_ = nullptr)
+{
+    (void)prof_;
+    const u32 l = k.l;
+    // Control flow: a SEQUENCE of wave-uniform if-blocks without else branches or early exits (the loop around this function has a
+    // per-game exit, so its body is structurised as a whole: nested if / else with the whole game state live turned into chains of
+    // flow blocks with ~100 register copies per move; a sequence of if-blocks joins without copies on the common path).
+    // -- RandomAgent's draw on the prepared weights (selfplay_step2's arithmetic)
+    const double x = P.u * P.total;
+    const double d = x - P.sJ;
+    const u32 fl = (u32)d;
+    const double fr = d - (double)fl;
+    const bool edge = (x < P.sJ) | !(fr > 1e-9 && fr < 1.0 - 1e-9) | (fl + 1u > P.M);
+    const bool general = wave_any(P.unusual | edge | (g.over != 0u));
+    u32 ret = 0;
+    if (AZ_UNLIKELY(general)) {
+        // [1] the whole move the general way for both games of the wave (nothing has been changed yet), then a fresh preparation
+        ret = selfplay_step2<LID, OUT, PAD, BITS>(g, first_player, k, r, T, margin, cnt, o, prof_);
+        prepare2(g, k, r, T, P);
+    }
+    u32 me = 0;
+    i32 a = 0;
+    bool filled = false;
+    if (!general) {
+        // [2] the common decision: mask row out, action from the ordinal, the move itself
+        AZ_STAMP(SEG_LOOP);
+        if (OUT == 1 || (OUT == 2 && o.mask))
+            store_mask_row2<(PAD && OUT == 1)>(o, P.m0, P.m1, P.m2, P.m3, P.m4, P.m5, P.b0, P.b1, P.b2, P.b3, P.b4, P.b5, l);
+        if ((OUT == 1 && BITS) || (OUT == 2 && o.maskbits)) {
+            const u64 q0 = (u64)P.m0 | ((u64)P.m1 << 30) | ((u64)P.m2 << 60);
+            const u64 q1 = ((u64)P.m2 >> 4) | ((u64)P.m3 << 26) | ((u64)P.m4 << 56);
+            const u64 q2 = ((u64)P.m4 >> 8) | ((u64)P.m5 << 22);
+            const u32 q = l < 2u ? l : 2u;
+            o.maskbits[o.e * 3u + q] = q == 0u ? q0 : (q == 1u ? q1 : q2);
+        }
+        AZ_STAMP(SEG_MASK);
+        r.pos += 2u;
+        const u32 want = P.J + fl;                               // ordinal - 1 of the chosen legal action
+        const bool g1 = want >= P.J, g2 = want >= P.p2, g3 = want >= P.p3, g4 = want >= P.p4, g5 = want >= P.p5;
+        // (the words and prefix counts pass through an empty asm first: a select chain over fields of a struct that is reached through a
+        // reference is folded into ONE load from a selected address before the struct is split into registers, which pins it in scratch)
+        u32 m0 = P.m0, m1 = P.m1, m2 = P.m2, m3 = P.m3, m4 = P.m4, m5 = P.m5, q1 = P.J, q2 = P.p2, q3 = P.p3, q4 = P.p4, q5 = P.p5;
+        asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4), "+v"(m5));
+        asm volatile("" : "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5));
+        const u32 mword = g5 ? m5 : g4 ? m4 : g3 ? m3 : g2 ? m2 : g1 ? m1 : m0;
+        const u32 base = g5 ? q5 : g4 ? q4 : g3 ? q3 : g2 ? q2 : g1 ? q1 : 0u;
+        const u32 prow_ = (u32)g1 + (u32)g2 + (u32)g3 + (u32)g4 + (u32)g5;
+        const bool hit = (((mword >> l) & 1u) != 0u) & ((u32)__popc(mword & ((1u << l) - 1u)) == want - base);
+        const u32 who = hb(hit);
+        const u32 ln = (u32)__builtin_ctz(who | 0x80000000u);
+        const u32 code = hbcast(k.lcode, ln) | (prow_ << 13) | ((30u * prow_ + ln) << 17);
+        a = (i32)(code >> 17);
+        AZ_STAMP(SEG_SAMPLE);
+        me = me2(g);
+        filled = do_move2<LID>(g, code, P.B, l);                 // azul.py:304
+        g.moves += 1u;
+        AZ_STAMP(SEG_MOVE);
+        g.B = hb(g.cs != 0u) & 0x7fffffffu;
+    }
+    const bool round_over = !general & wave_any(g.B == 0u);
+    if (AZ_UNLIKELY(round_over)) {
+        // [3] a round (perhaps a game) ends in at least one of the two games: the general tail for both, a fresh preparation
+        ret = after_move2<LID, OUT>(g, first_player, k, r, margin, cnt, o, me, filled, a, prof_);
+        prepare2(g, k, r, T, P);
+    }
+    if (!general & !round_over) {
+        // [4] nobody's round ended: next player, then two independent instruction streams in one block --
+        g.cur = g.cur < 2u ? g.cur + 1u : 1u;                    // :313 next_player
+        // (a) the loop-carried stream: the decision of move t + 1 up to its two LDS requests
+        PrepLoads2 q;
+        prepare2_request(g, k, r, T, P, q);
+        // (b) the side chain of move t: what-if score of the mover (game_runner.py:48-50) ...
         i32 wc = me ? g.wc1 : g.wc0;
-#if defined(AZ2_ALWAYS_WALLPTS)
+#if defined(AZ2_ROT_ALWAYS_WALLPTS)
         {
 #else
         if (wave_any(filled)) {
 #endif
             i32 fresh = wall_points2(me ? g.wall1 : g.wall0, full_lines2(me ? g.cp1 : g.cp0, k), k);
-            wc = filled ? fresh : wc;
+            wc = filled ? fresh : wc;                            // (a line that did not fill leaves the pricing of the full lines as it was)
         }
+        __builtin_amdgcn_sched_barrier(0);                       // (a) and (b) above: free to interleave; the rest below the requests
+        // ... shaped reward, stores: under the LDS requests' latency
         const i32 wi = clamp0((me ? g.score1 : g.score0) + floor_penalty(me ? g.floor1 : g.floor0) + wc);
         g.wc0 = me ? g.wc0 : wc; g.wc1 = me ? wc : g.wc1;
         g.wi0 = me ? g.wi0 : wi; g.wi1 = me ? wi : g.wi1;
-        g.B = hb(g.cs != 0u) & 0x7fffffffu;                      // the sources after the move (next move's mask reads it)
-        const bool eor = g.B == 0u;                              // :306 is_end_of_round (the token counts)
-        g.cur = eor ? g.cur : (g.cur < 2u ? g.cur + 1u : 1u);    // :313 next_player
-        u32 st = ST_OK;
-        AZ_STAMP(SEG_AFTERMOVE);
-        if (AZ_UNLIKELY(wave_any(eor))) {
-            if (eor) {
-                count_score2<LID>(g, k);                         // :307 (also resets the what-if cache)
-                if (g.over) g.eog = 1;                           // :308-309
-            }
-            AZ_STAMP(SEG_SCORE);
-            if (eor & !g.over) st = new_round2<LID>(g, r, margin, k);      // :311
-            AZ_STAMP(SEG_NEWROUND);
-        }
         const i32 phi = g.wi0 - g.wi1;
         const i32 reward = phi - g.pscore;
         g.pscore = phi;
-        const u32 dn = g.over ? 1u : 0u;
-        outputs2<OUT>(g, o, a, reward, dn, l);
+        outputs2<OUT>(g, o, a, reward, 0u, l);
+        __builtin_amdgcn_sched_barrier(0);
+        prepare2_finish(P, q);
         AZ_STAMP(SEG_TAIL);
-        ret = st != ST_OK ? (0x100u | st) : dn;
-        if (AZ_UNLIKELY(wave_any((dn != 0u) & (st == ST_OK)))) {
-            if ((dn != 0u) & (st == ST_OK)) {
-                if (l == 0u) {
-                    for (u32 q = 0; q < 10u; q++) cnt.stat_sum[q] += game_stat2(g, q);
-                    *cnt.episodes += 1ull;
-                }
-                u32 st2 = episode_reset2<LID>(g, first_player, r, margin, k);     // GameRunner.reset(): Azul(rules) ... new_round()
-                if (st2) ret = 0x100u | st2;
-            }
-            AZ_STAMP(SEG_RESET);
-        }
     }
     return ret;
 }

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 asm = os.path.join(ROOT, "gpurun_out", "azul_kernels.s")
 os.makedirs(os.path.dirname(asm), exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-                       "-Wno-unused-value", "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", asm,
+                       "-Wno-unused-value", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", asm,
                        os.path.join(ROOT, "azul_deep_reinforcement_learning_amd", "csrc", "azul_kernels.hip")], stderr=subprocess.DEVNULL)
 s = open(asm).read()
 want = sys.argv[1:] or ["azul_selfplay2_kernelILb1ELi1E", "azul_selfplay_kernelILb1ELi1E"]

@@ -268,7 +268,9 @@ class BatchedAzul:
     def selfplay(self, n_steps, mask=None, action=None, reward=None, done=None, records=None, maskbits=None, packed=None):
         """`n_steps` env moves for every game in one launch; outputs are preallocated tensors or None.  `mask` may be a
         [T][N][180] view of a wider [T][N][pitch] buffer (alloc_trajectory(mask_pitch=192)): the row pitch is taken from its
-        strides."""
+        strides.  Batches of 3 or 4 players play the same flat loop (mask -> RandomAgent -> Azul.step, a fresh Azul + new_round()
+        at each game end: start them with init() + new_round()); their `reward` stream is all zero (the shaped reward is
+        GameRunner's, two players: game_runner.py:50), `records` rows are 256-byte wide records, mask rows are dense."""
         pitch = L.NUM_ACTIONS
         if mask is not None:
             pitch = mask.stride(-2)
@@ -295,7 +297,8 @@ class BatchedAzul:
                 t["maskbits"] = torch.zeros((n_steps, n, 3), dtype=torch.int64, device=self.device)
             t["packed"] = torch.zeros((n_steps, n), dtype=torch.int32, device=self.device)
         if with_records:
-            t["records"] = self._new((n_steps, n, L.RECORD_BYTES), torch.uint8)
+            # zeroed: a 3-player batch leaves the fourth player's bytes and the reserved tail of a wide record untouched
+            t["records"] = torch.zeros((n_steps, n, self.record_dtype.itemsize), dtype=torch.uint8, device=self.device)
         return t
 
     def counters(self):

@@ -259,4 +259,79 @@ AZ_FN double game_stat_np(const GameN<P> &g, u32 q)
     }
 }
 
+// ---- flat random-agent self-play for P players (row N4): the loop  mask -> RandomAgent -> Azul.step  on a register-resident game
+// (game_runner.py:87-97 works on any mask, azul.py:296-313 is P-generic), a fresh Azul(players=P, rules) + new_round() whenever a
+// game ends or nobody can move.  GameRunner's shaped reward is two-player (game_runner.py:50): the reward stream carries zeros.
+// Same output conventions as selfplay_step (OUT 0 / 1 / 2); `rec` snapshots are 256-byte wide records.
+template <bool LID, u32 P>
+AZ_FN u32 restart_np(GameN<P> &g, u32 first_player, Rng &r)
+{
+    game_ctor_np<LID>(g, first_player, r);
+    return new_round_np<LID>(g, r);
+}
+
+template <bool LID, u32 P, int OUT>
+AZ_FN void selfplay_outputs_np(const GameN<P> &g, const OutV &ov, const OutS &os, i32 a, u32 dn)
+{
+    if (OUT == 1) {
+        vu32 l = lane();
+        vst_u32(ov.p32, sel(l == 1u, splat(0u), sel(l == 2u, splat(pack_move(a, dn, 0)), splat((u32)(a >= 0 ? a : -1)))));
+        vst_u8(ov.p8, splat(dn));
+    } else if (OUT == 2) {
+        if (os.action) stu_i32(os.action, a >= 0 ? a : -1);
+        if (os.reward) stu_i32(os.reward, 0);
+        if (os.done) stu_u8(os.done, dn);
+        if (os.packed) stu_i32((i32 *)os.packed, (i32)pack_move(a, dn, 0));
+        if (os.rec) gamen_store(g, os.rec);
+    }
+}
+
+template <bool LID, u32 P, int OUT>
+AZ_FN u32 selfplay_step_np(GameN<P> &g, u32 first_player, const LaneConst &k, Rng &r, const SampleTab &T, const Counters &cnt,
+                           const OutV &ov, const OutS &os)
+{
+    Mask m;
+    legal_mask_np(g, k, m);
+    if (OUT == 1) {
+        vu32 l = lane();
+        vst_u8(ov.pm, m.b0);
+        vst_u8_at(ov.pm, 64, m.b1);
+        vst_u8(ov.pm2, sel(l < 52u, m.b2, splat((u32)(m.m2 >> 51) & 1u)));
+        vu32 lo = sel(l == 0u, splat((u32)m.m0), sel(l == 1u, splat((u32)m.m1), splat((u32)m.m2)));
+        vu32 hi = sel(l == 0u, splat((u32)(m.m0 >> 32)), sel(l == 1u, splat((u32)(m.m1 >> 32)), splat((u32)(m.m2 >> 32))));
+        vst_u64(ov.p64, lo, hi);
+    } else if (OUT == 2) {
+        if (os.mask) mask_write(m, os.mask);
+        if (os.maskbits) mask_write_bits(m, os.maskbits);
+    }
+    u32 code = 0;
+    i32 a = g.eog ? -2 : random_agent(m, r, T, k, code);
+    if (AZ_UNLIKELY(a < 0)) {
+        // nothing legal (hazard H3) or a finished game handed in: report, restart the slot
+        AZ_LANE0(*cnt.stuck += 1u);
+        selfplay_outputs_np<LID, P, OUT>(g, ov, os, -1, 2u);
+        u32 st0 = restart_np<LID>(g, first_player, r);
+        return st0 ? (0x100u | st0) : 2u;
+    }
+    do_move_np<LID>(g, code);                            // azul.py:304
+    u32 st = ST_OK;
+    if (sources_board_np(g) == 0u) {                     // :306 (the token counts)
+        count_score_np<LID>(g, k);                       // :307
+        if (walls_end_game_np(g)) g.eog = 1;             // :308-309
+        else st = new_round_np<LID>(g, r);               // :311
+    } else {
+        g.cur = (g.cur < P) ? g.cur + 1u : 1u;           // :313 next_player
+    }
+    const u32 dn = g.eog ? 1u : 0u;
+    selfplay_outputs_np<LID, P, OUT>(g, ov, os, a, dn);
+    if (AZ_UNLIKELY(st != ST_OK)) return 0x100u | st;
+    if (AZ_UNLIKELY(dn != 0u)) {
+        for (u32 q = 0; q < 10u; q++) { double sv = game_stat_np(g, q); AZ_LANE0(cnt.stat_sum[q] += sv); }
+        AZ_LANE0(*cnt.episodes += 1ull);
+        st = restart_np<LID>(g, first_player, r);
+        if (st) return 0x100u | st;
+    }
+    return dn;
+}
+
 } // namespace az

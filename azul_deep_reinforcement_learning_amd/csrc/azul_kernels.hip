@@ -514,6 +514,57 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
 }
 
 
+// Flat random-agent self-play for THREE and FOUR players (row N4): one game per wavefront on the 256-byte wide record, persistent
+// like azul_selfplay_kernel (the game and its MT19937 stream stay in registers / LDS for the whole launch).  Dense 180-byte mask rows.
+template <u32 P, bool LID, int OUT>
+__global__ void __launch_bounds__(64) azul_np_selfplay_kernel(BatchDev b, TrajArgs t)
+{
+    __shared__ u32 mt_lds[624];
+    __shared__ double fr_lds[T_ROWS * T_BINADES];
+    const u32 gi = blockIdx.x;
+    const size_t N = b.n;
+    uint8_t *rec = b.state + (size_t)gi * NP_RECORD_BYTES;
+    LaneConst k;
+    lane_consts(k);
+    SampleTab tab;
+    sample_tab_load(tab, b.T, fr_lds);
+    GameN<P> g;
+    gamen_load(g, rec);
+    Rng r;
+    rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]);
+    r.margin = b.draw_margin;
+    Counters cnt = {b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10};
+    OutV ov;
+    OutS os = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t sm = 0, sb = 0, sa = 0, sr = 0, sd = 0, sc = 0, sp = 0;
+    if (OUT == 1) {
+        outv_open(ov, gi, b.n, t.mask, t.maskbits, t.action, t.reward, t.done, t.packed);
+    } else {
+        outv_open(ov, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (OUT == 2) {
+            os.mask = t.mask ? t.mask + (size_t)gi * AZUL_NUM_ACTIONS : nullptr;
+            os.maskbits = t.maskbits ? t.maskbits + (size_t)gi * 3 : nullptr;
+            os.action = t.action ? t.action + gi : nullptr;
+            os.reward = t.reward ? t.reward + gi : nullptr;
+            os.done = t.done ? t.done + gi : nullptr;
+            os.rec = t.rec ? t.rec + (size_t)gi * NP_RECORD_BYTES : nullptr;
+            os.packed = t.packed ? t.packed + gi : nullptr;
+            sp = os.packed ? N : 0;
+            sm = os.mask ? N * AZUL_NUM_ACTIONS : 0; sb = os.maskbits ? N * 3 : 0; sa = os.action ? N : 0;
+            sr = os.reward ? N : 0; sd = os.done ? N : 0; sc = os.rec ? N * NP_RECORD_BYTES : 0;      // a NULL stream stays NULL
+        }
+    }
+#pragma unroll 1
+    for (int s = 0; s < t.n_steps; s++) {
+        u32 f = selfplay_step_np<LID, P, OUT>(g, b.rules.first_player, k, r, tab, cnt, ov, os);
+        if (f & 0x100u) break;      // rule error (box empty): leave the game as it is
+        if (OUT == 1) outv_next(ov);
+        if (OUT == 2) { os.mask += sm; os.maskbits += sb; os.action += sa; os.reward += sr; os.done += sd; os.rec += sc; os.packed += sp; }
+    }
+    gamen_store(g, rec);
+    rng_close(r, b.mtpos + gi);
+}
+
 #include "azul_selfplay2.hpp"
 
 // Flat self-play, TWO GAMES PER WAVEFRONT (azul_selfplay2.hpp): grid = ceil(N / 2) one-wave workgroups; lanes 0..31 own game
@@ -1357,9 +1408,36 @@ int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev,
 {
     BATCH_GUARD(b, stream);
     if (!b || n_steps < 0) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: bad arguments");
-    if (b->players != 2) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: GameRunner self-play is two-player (game_runner.py:50)");
     if (mask_row_bytes < AZUL_NUM_ACTIONS) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: mask rows hold 180 bytes, mask_row_bytes >= 180");
     if (n_steps == 0) return AZUL_SUCCESS;
+    if (b->players != 2) {
+        // three / four players (row N4): the flat loop mask -> RandomAgent -> Azul.step with a fresh Azul + new_round() at each game end;
+        // one game per wavefront on the wide record, dense mask rows, `reward` all zero (the shaped reward is GameRunner's: two players)
+        if (mask_dev && mask_row_bytes != AZUL_NUM_ACTIONS)
+            return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: 3- and 4-player batches write dense 180-byte mask rows");
+        TrajArgs t = {n_steps, mask_dev, (u64 *)maskbits_dev, action_dev, reward_dev, done_dev, rec_dev, packed_dev};
+        const bool none = !mask_dev && !maskbits_dev && !action_dev && !reward_dev && !done_dev && !rec_dev && !packed_dev;
+        const bool full = mask_dev && maskbits_dev && action_dev && reward_dev && done_dev && packed_dev && !rec_dev;
+        const dim3 grid(b->d.n), block(64);
+        const hipStream_t st = (hipStream_t)stream;
+        const bool lid = b->d.rules.tile_pool == POOL_LID;
+#define AZ_LAUNCH_NP(PP, LID) do { \
+            if (none) hipLaunchKernelGGL((azul_np_selfplay_kernel<PP, LID, 0>), grid, block, 0, st, b->d, t); \
+            else if (full) hipLaunchKernelGGL((azul_np_selfplay_kernel<PP, LID, 1>), grid, block, 0, st, b->d, t); \
+            else hipLaunchKernelGGL((azul_np_selfplay_kernel<PP, LID, 2>), grid, block, 0, st, b->d, t); } while (0)
+        const bool pair = b->timing && b->timed_pairs < AZ_TIMED_PAIRS;       // per-launch event pair inside a timed region (as below)
+        if (pair) {
+            while ((int)b->lev.size() < 2 * (b->timed_pairs + 1)) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); b->lev.push_back(e); }
+            HIP_TRY(hipEventRecord(b->lev[2 * b->timed_pairs], st));
+        }
+        if (b->players == 3) { if (lid) AZ_LAUNCH_NP(3, true); else AZ_LAUNCH_NP(3, false); }
+        else { if (lid) AZ_LAUNCH_NP(4, true); else AZ_LAUNCH_NP(4, false); }
+#undef AZ_LAUNCH_NP
+        HIP_TRY(hipGetLastError());
+        if (pair) { HIP_TRY(hipEventRecord(b->lev[2 * b->timed_pairs + 1], st)); b->timed_pairs++; }
+        if (b->timing) b->timed_launches++;
+        return AZUL_SUCCESS;
+    }
     const int version = selfplay_kernel_version();
     if (version == 2 && (u64)n_steps * b->d.n * (u64)(rec_dev && mask_row_bytes < AZUL_RECORD_BYTES ? AZUL_RECORD_BYTES : mask_row_bytes) >= (1ull << 32))
         return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: a trajectory stream of one launch must stay below 4 GiB (use fewer moves per launch)");

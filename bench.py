@@ -286,6 +286,40 @@ def facade_config1(budget_s=8.0, max_games=150):
                                    "integration/azulnet (GameRunner / RandomAgent / check_all_valid on libazulhip.so), seeds 0..%d" % (games - 1)}}
 
 
+def players_selfplay(games, chunk=256, launches=6):
+    """Row N4: the persistent self-play kernel for 3 and 4 players (one game per wavefront on the 256-byte wide record; the loop
+    mask -> RandomAgent -> Azul.step, fresh game at each game end), all five trajectory streams written, dense mask rows."""
+    import torch
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    res = {}
+    for P in (3, 4):
+        env = BatchedAzul(games, players=P)
+        env.seed(0)
+        env.init()
+        env.new_round()
+        bufs = env.alloc_trajectory(chunk, packed_mask=True)
+        run = lambda: env.selfplay(chunk, bufs["mask"], bufs["action"], bufs["reward"], bufs["done"], maskbits=bufs["maskbits"], packed=bufs["packed"])
+        run()
+        torch.cuda.synchronize()
+        stuck0 = int(env.counters()["stuck"].sum())
+        t0 = time.perf_counter()
+        env.timing_begin()
+        for _ in range(launches):
+            run()
+        _, _, kms, kn = env.timing_end()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        c = env.counters()
+        moves = games * chunk * launches - (int(c["stuck"].sum()) - stuck0)
+        res["players_%d" % P] = {"value": moves / dt, "unit": "env steps/s", "avg_launch_ms": kms / max(kn, 1), "episodes_finished": int(c["episodes"].sum()),
+                                 "workload": "%d concurrent %d-player games (five displays, like the reference), RandomAgent for every seat, rules Lid + "
+                                             "random first player, %d moves per launch" % (games, P, chunk)}
+        del env, bufs
+        torch.cuda.empty_cache()
+    res["kernel"] = "azul_np_selfplay_kernel (one game per wavefront)"
+    return res
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` as a plain command: start the N ranks as FRESH child processes (torch.distributed.run) before this
     process has imported torch or touched a GPU, pass every argument through, relay the launcher's exit code."""
@@ -464,10 +498,11 @@ def main():
         except Exception as e:
             ex = {"error": repr(e)}
         if world == 1:
-            try:
-                ex["facade_config1"] = facade_config1()
-            except Exception as e:
-                ex["facade_config1"] = {"error": repr(e)}
+            for name, fn in (("facade_config1", facade_config1), ("players_selfplay", lambda: players_selfplay(G))):
+                try:
+                    ex[name] = fn()
+                except Exception as e:
+                    ex[name] = {"error": repr(e)}
         wd.cancel()
         if rank == 0:
             out["extra"] = ex

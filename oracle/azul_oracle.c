@@ -788,6 +788,62 @@ int oz_stream_advance(oz_runner *q, oz_rng *r, int n_steps,
     return OZ_OK;
 }
 
+/* The flat random-agent loop for `players` players (row N4; what azul_batch_selfplay plays for 3- and 4-player batches):
+ *     random.seed(seed); g = Azul(players=P, rules=rules); g.new_round()
+ *     repeat: a = RandomAgent().get_a_output(None, mask of g)   (game_runner.py:87-97: any mask)
+ *             g.step(*nn_deserialize(a))                         (azul.py:296-313: P-generic)
+ *             when g.end_of_game (or nothing was legal, hazard H3): a fresh Azul(players=P, rules=rules) + new_round()
+ * GameRunner's shaped reward is two-player (game_runner.py:50): this stream carries none.  rec_after: the 256-byte wide record
+ * after the move, before a restart. */
+int oz_stream_np_start(oz_game *g, oz_rng *r, uint64_t seed, int players, int first_player, int tile_pool)
+{
+    oz_rng_seed(r, seed);
+    int st = oz_init(g, players, first_player, tile_pool, r);
+    if (st) return st;
+    return oz_new_round(g, r);
+}
+
+int oz_stream_np_advance(oz_game *g, oz_rng *r, int first_player, int n_steps, uint8_t *mask, int32_t *action, uint8_t *done,
+                         uint8_t *rec_after, uint64_t *stuck_count, uint64_t *episodes, double *stats_sum)
+{
+    const int players = g->players, tile_pool = g->tile_pool;
+    for (int t = 0; t < n_steps; t++) {
+        uint8_t m[180];
+        oz_check_all_valid(g, m);
+        if (mask) memcpy(mask + (size_t)t * 180, m, 180);
+        int a = oz_random_agent(m, r);
+        int dn;
+        if (a < 0) {
+            if (stuck_count) (*stuck_count)++;
+            dn = 2;
+        } else {
+            int d, c, p;
+            oz_deserialize(a, &d, &c, &p);
+            int st = oz_step(g, d, c, p, r);
+            if (st) return st;
+            dn = g->end_of_game ? 1 : 0;
+        }
+        if (action) action[t] = a;
+        if (done) done[t] = (uint8_t)dn;
+        if (rec_after) oz_pack_np(g, rec_after + (size_t)t * 256);
+        if (dn) {
+            if (dn == 1) {
+                if (stats_sum) {
+                    double s[10];
+                    oz_get_statistics(g, s);
+                    for (int i = 0; i < 10; i++) stats_sum[i] += s[i];
+                }
+                if (episodes) (*episodes)++;
+            }
+            int st = oz_init(g, players, first_player, tile_pool, r);
+            if (st) return st;
+            st = oz_new_round(g, r);
+            if (st) return st;
+        }
+    }
+    return OZ_OK;
+}
+
 typedef struct {
     uint64_t seed_base;
     int n_streams, n_steps, n_threads, tid, first_player, tile_pool;

@@ -422,6 +422,103 @@ def gen_players():
     print("wrote traj_players.npz (%d streams; endings: %s)" % (len(index), dict(ends)))
 
 
+SELFPLAY_FIELDS = ["mask", "action", "done", "displays", "center", "pattern_lines", "walls", "floors", "score", "cur", "nfp", "eog_flag",
+                   "turn_counter", "box", "lid", "first_player_stats", "floor_penalty", "max_combo", "completed_lines", "rng_words"]
+
+
+def play_players_selfplay(seed, players, rules, n_moves):
+    """The flat random-agent loop for P players, every decision by the reference's own RandomAgent on the process-global stream:
+        random.seed(seed); g = Azul(players=P, rules=rules); g.new_round()
+        repeat: a = RandomAgent().get_a_output(None, mask of g); g.step(*nn_deserialize(a)); when g.end_of_game: a fresh Azul + new_round()
+    (game_runner.py:87-97 works on any mask; azul.py:296-313 is P-generic).  Recorded per move: mask before, action, done, the
+    whole state after the move (before the restart), the words of the stream consumed so far (restart draws included)."""
+    from azulnet import nn_deserialize
+    rows = {k: [] for k in SELFPLAY_FIELDS}
+    random.seed(seed)
+    words = [0, words_pos()]
+
+    def sync():
+        pos = words_pos()
+        d = pos - words[1]
+        if d < 0:
+            d += 624
+        words[0] += d
+        words[1] = pos
+        return words[0]
+
+    agent = RandomAgent()
+    g = Azul(players=players, rules=dict(rules))
+    g.new_round()
+    episodes = stuck = 0
+    stats_sum = np.zeros(10)
+    for t in range(n_moves):
+        mask = check_all_valid(g)
+        try:
+            a = int(agent.get_a_output(None, torch.from_numpy(np.asarray(mask)[None, :])))
+        except ValueError:                             # hazard H3: nothing legal (raised before random() is drawn)
+            a = -1
+        r = rows
+        r["mask"].append(np.packbits(mask, bitorder="little"))
+        r["action"].append(a)
+        if a >= 0:
+            g.step(*nn_deserialize(a))
+        done = 2 if a < 0 else int(bool(g.end_of_game))
+        r["done"].append(done)
+        r["displays"].append(np.array(g.game_board_displays, dtype=np.uint8))
+        r["center"].append(np.array(g.game_board_center, dtype=np.uint8))
+        r["pattern_lines"].append(np.array(g.pattern_lines, dtype=np.uint8))
+        r["walls"].append(np.array(g.walls, dtype=np.uint8))
+        r["floors"].append(np.array(g.floors, dtype=np.uint8))
+        r["score"].append(np.array(g.score, dtype=np.int16))
+        r["cur"].append(g.current_player)
+        r["nfp"].append(g.next_first_player)
+        r["eog_flag"].append(bool(g.end_of_game))
+        r["turn_counter"].append(g.turn_counter)
+        r["box"].append(np.array(g.box_tiles, dtype=np.uint8) if g.tile_pool == "Lid" else np.zeros(5, np.uint8))
+        r["lid"].append(np.array(g.lid_tiles, dtype=np.uint8) if g.tile_pool == "Lid" else np.zeros(5, np.uint8))
+        r["first_player_stats"].append(np.array(g.first_player_stats, dtype=np.uint16))
+        r["floor_penalty"].append(np.array(g.floor_penalty, dtype=np.int16))
+        r["max_combo"].append(np.array(g.max_combo, dtype=np.uint8))
+        r["completed_lines"].append(np.array(g.completed_lines, dtype=np.uint8))
+        if done:
+            if done == 1:
+                st = g.get_statistics()
+                stats_sum += np.array([float(st[k]) for k in ["player_score", "opponent_score", "rounds", "percent_first_player", "floor_penalty",
+                                                               "max_combo", "completed_rows", "completed_columns", "completed_colors", "win_percent"]])
+                episodes += 1
+            else:
+                stuck += 1
+            g = Azul(players=players, rules=dict(rules))
+            g.new_round()
+        r["rng_words"].append(sync())
+    out = {k: np.array(v) for k, v in rows.items()}
+    out.update({"episodes": np.array(episodes), "stuck": np.array(stuck), "stats_sum": stats_sum})
+    return out
+
+
+def gen_players_selfplay():
+    """Row N4: the flat self-play loop for 3 and 4 players (what azul_batch_selfplay plays for such batches)."""
+    blob, index = {}, []
+    for players in (3, 4):
+        for name, (rules, fp, pool) in PLAYER_RULESETS.items():
+            rules = {k: (players if v == "P" else v) for k, v in rules.items()}
+            fp = players if fp == "P" else fp
+            for seed in range(3):
+                key = "p%d_%s_s%d" % (players, name, seed)
+                d = play_players_selfplay(1000 + seed, players, rules, 360)
+                for k, v in d.items():
+                    blob[key + "_" + k] = v
+                index.append((players, fp, pool, 1000 + seed, key))
+    blob["index_players"] = np.array([i[0] for i in index])
+    blob["index_first"] = np.array([i[1] for i in index])
+    blob["index_pool"] = np.array([i[2] for i in index])
+    blob["index_seed"] = np.array([i[3] for i in index])
+    blob["index_key"] = np.array([i[4] for i in index])
+    np.savez_compressed(os.path.join(OUT, "traj_players_selfplay.npz"), **blob)
+    print("wrote traj_players_selfplay.npz (%d streams, %d episodes, %d stuck)" % (
+        len(index), sum(int(blob[i[4] + "_episodes"]) for i in index), sum(int(blob[i[4] + "_stuck"]) for i in index)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("reference:", os.path.dirname(azulnet.__file__))
@@ -434,12 +531,16 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "players":
         gen_players()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "players_selfplay":
+        gen_players_selfplay()
+        return
     gen_rng()
     gen_boards()
     gen_trajectories()
     gen_policy_contract()
     gen_a2c_update()
     gen_players()
+    gen_players_selfplay()
 
 
 if __name__ == "__main__":

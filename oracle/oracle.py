@@ -112,6 +112,8 @@ def lib():
         "oz_unpack_np": (None, [P(Game), u8p, C.c_int]),
         "oz_stream_start": (C.c_int, [P(Runner), P(Rng), C.c_uint64, C.c_int, C.c_int]),
         "oz_stream_advance": (C.c_int, [P(Runner), P(Rng), C.c_int, u8p, i32p, i32p, u8p, u8p, u64p, u64p, f64p]),
+        "oz_stream_np_start": (C.c_int, [P(Game), P(Rng), C.c_uint64, C.c_int, C.c_int, C.c_int]),
+        "oz_stream_np_advance": (C.c_int, [P(Game), P(Rng), C.c_int, C.c_int, u8p, i32p, u8p, u8p, u64p, u64p, f64p]),
         "oz_bench_selfplay": (C.c_uint64, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u64p]),
     }
     for name, (res, args) in sig.items():
@@ -234,6 +236,40 @@ class Stream:
 
     def record(self):
         return pack(self.q)
+
+    def rng_state(self):
+        return np.ctypeslib.as_array(self.r.mt).copy(), int(self.r.idx)
+
+
+class StreamNP:
+    """One flat random-agent stream for `players` players on the wide record (oz_stream_np_*): ``random.seed(s); Azul(players=P,
+    rules); new_round(); RandomAgent picks every move; a fresh Azul + new_round() when a game ends``."""
+
+    def __init__(self, seed, players, first_player=FIRST_RANDOM, tile_pool=POOL_LID):
+        self.g, self.r = Game(), Rng()
+        self.first = first_player
+        self.stuck = C.c_uint64(0)
+        self.episodes = C.c_uint64(0)
+        self.stats_sum = np.zeros(10, dtype=np.float64)
+        rc = lib().oz_stream_np_start(C.byref(self.g), C.byref(self.r), int(seed), players, first_player, tile_pool)
+        if rc:
+            raise RuntimeError("oz_stream_np_start -> %d" % rc)
+
+    def advance(self, n_steps, want_records=True):
+        mask = np.zeros((n_steps, 180), dtype=np.uint8)
+        action = np.zeros(n_steps, dtype=np.int32)
+        done = np.zeros(n_steps, dtype=np.uint8)
+        recs = np.zeros((n_steps, 256), dtype=np.uint8) if want_records else None
+        rc = lib().oz_stream_np_advance(C.byref(self.g), C.byref(self.r), self.first, n_steps, _p(mask, C.c_uint8), _p(action, C.c_int32),
+                                        _p(done, C.c_uint8), _p(recs, C.c_uint8), C.byref(self.stuck), C.byref(self.episodes),
+                                        _p(self.stats_sum, C.c_double))
+        if rc:
+            raise RuntimeError("oz_stream_np_advance -> %d" % rc)
+        return {"mask": mask, "action": action, "done": done,
+                "rec_after": None if recs is None else recs.view(RECORD_NP_DTYPE).reshape(n_steps)}
+
+    def record(self):
+        return pack_np(self.g)
 
     def rng_state(self):
         return np.ctypeslib.as_array(self.r.mt).copy(), int(self.r.idx)

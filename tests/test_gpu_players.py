@@ -176,9 +176,71 @@ def test_game_runner_entries_are_refused_for_more_than_two_players():
         env.reset()
     with pytest.raises(L.AzulHipError):
         env.get_state()
+    tr = env.alloc_trajectory(4, mask_pitch=192)                        # 3 / 4 players: self-play exists, with dense mask rows only
     with pytest.raises(L.AzulHipError):
-        env.selfplay(4)
+        env.selfplay(4, tr["mask"], tr["action"], tr["reward"], tr["done"])
     with pytest.raises(L.AzulHipError):
         BatchedAzul(4, players=5)
     with pytest.raises(Exception):
         BatchedAzul(4, players=3, rules={"first_player": 4})            # IllegalRule: 1..players
+
+
+def test_persistent_selfplay_for_three_and_four_players_replays_the_reference(golden_dir):
+    """azul_batch_selfplay on 3- and 4-player batches (azul_np_selfplay_kernel: one launch, games resident in registers) against
+    tests/golden/traj_players_selfplay.npz -- streams played by the REAL reference (Azul(players=P).step with the reference's
+    RandomAgent on the global stream, fresh game at each game end) -- and against the oracle's records, RNG positions and counters."""
+    import torch
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    gold = np.load(os.path.join(golden_dir, "traj_players_selfplay.npz"))
+    groups = {}
+    for i, key in enumerate(gold["index_key"]):
+        groups.setdefault((int(gold["index_players"][i]), int(gold["index_first"][i]), int(gold["index_pool"][i])), []).append(
+            (int(gold["index_seed"][i]), str(key)))
+    assert len(groups) == 6
+    for (P, first, pool), members in groups.items():
+        members.sort()
+        seeds = [m[0] for m in members]
+        assert seeds == list(range(seeds[0], seeds[0] + len(seeds)))
+        rules = {"tile_pool": "Lid" if pool == 1 else "Random"}
+        if first >= 0:
+            rules["first_player"] = "Random" if first == 0 else first
+        T = len(gold[members[0][1] + "_action"])
+        for variant in ("records", "full", "none"):
+            env = BatchedAzul(len(seeds), rules=rules, players=P, device="cuda:0")
+            env.seed(seeds[0])
+            env.init()                                            # Azul(players=P, rules)
+            env.new_round()
+            if variant == "records":                              # OUT == 2: any subset of the streams + record snapshots
+                tr = env.alloc_trajectory(T, with_records=True)
+                env.selfplay(T, tr["mask"], tr["action"], tr["reward"], tr["done"], records=tr["records"])
+            elif variant == "full":                               # OUT == 1: all streams, lane-distributed stores
+                tr = env.alloc_trajectory(T, packed_mask=True)
+                env.selfplay(T, tr["mask"], tr["action"], tr["reward"], tr["done"], maskbits=tr["maskbits"], packed=tr["packed"])
+            else:                                                 # OUT == 0, in two launches
+                env.selfplay(T // 2)
+                env.selfplay(T - T // 2)
+            torch.cuda.synchronize()
+            recs = env.get_records()
+            cnt = env.counters()
+            for g, (seed, key) in enumerate(members):
+                s = oz.StreamNP(seed, P, first if first >= 0 else oz.FIRST_ABSENT, pool)
+                o = s.advance(T)
+                if variant != "none":
+                    mask = tr["mask"][:, g].cpu().numpy()
+                    assert np.array_equal(np.packbits(mask.astype(bool), axis=1, bitorder="little"), gold[key + "_mask"]), (key, variant)
+                    assert np.array_equal(tr["action"][:, g].cpu().numpy(), gold[key + "_action"]), (key, variant)
+                    assert np.array_equal(tr["done"][:, g].cpu().numpy(), gold[key + "_done"]), (key, variant)
+                    assert not tr["reward"][:, g].any()
+                if variant == "records":
+                    got = tr["records"][:, g].cpu().numpy()
+                    assert got.tobytes() == o["rec_after"].tobytes(), key
+                if variant == "full":
+                    from azul_deep_reinforcement_learning_amd.parallel import unpack_moves
+                    a, d, r = unpack_moves(tr["packed"][:, g])
+                    assert np.array_equal(a.cpu().numpy(), gold[key + "_action"]) and np.array_equal(d.cpu().numpy(), gold[key + "_done"])
+                    bits = tr["maskbits"][:, g].cpu().numpy().view(np.uint8).reshape(T, 24)[:, :23]
+                    assert np.array_equal(bits, gold[key + "_mask"]), key
+                assert recs[g].tobytes() == s.record().tobytes(), (key, variant)
+                assert env.get_rng(g)[1] == s.rng_state()[1] and np.array_equal(env.get_rng(g)[0], s.rng_state()[0]), (key, variant)
+                assert int(cnt["episodes"][g]) == int(gold[key + "_episodes"]) and int(cnt["stuck"][g]) == int(gold[key + "_stuck"])
+                assert np.allclose(cnt["stat_sums"][g], gold[key + "_stats_sum"], rtol=0, atol=1e-9), key

@@ -12,8 +12,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-s", "-C", _HERE], stdout=subprocess.DEVNULL)
-        L = C.CDLL(os.path.join(_HERE, "libhostcheck.so"))
+        name = os.environ.get("AZUL_HOSTCHECK_LIB", "libhostcheck.so")      # tests/hostcheck/run_sanitizers.sh: libhostcheck_asan.so
+        subprocess.check_call(["make", "-s", "-C", _HERE, name], stdout=subprocess.DEVNULL)
+        L = C.CDLL(os.path.join(_HERE, name))
         L.hc_stream_new.restype = C.c_void_p
         L.hc_stream_new.argtypes = [C.c_ulonglong, C.c_int, C.c_int]
         L.hc_stream_free.argtypes = [C.c_void_p]

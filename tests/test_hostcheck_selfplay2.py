@@ -1,0 +1,114 @@
+"""The benchmarked code on CPU: csrc/azul_selfplay2.hpp (two games per wavefront; selfplay_step2 and the rotated loop) compiled
+UNMODIFIED by g++ and run under the lockstep 64-lane emulation of tests/hostcheck/simt, against the oracle -- masks, actions,
+rewards, done flags, record snapshots, final records, all 624 MT19937 words + positions, episode counters and statistics sums,
+for every output variant of the kernel (padded one-store mask rows, bit-packed masks, dense rows, run-time subsets, no outputs),
+an odd batch (the last wave plays one game) and three rule sets.  Also: the emulator's own cross-lane operations against their
+definitions, and the same runs under UBSan / ASan (tests/hostcheck/Makefile; the logs are kept under profiles/).
+Reference: azulnet/game_runner.py:43-55, 76-97; azulnet/azul.py:64-313."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as oz
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostcheck")
+RULES = {"lid_randomfirst": (0, 1), "random_first1": (1, 0), "lid_first2": (2, 1)}      # (first_player code, tile_pool code)
+
+
+def load(name=None):
+    name = name or os.environ.get("AZUL_SIMT_LIB", "libsimt_selfplay2.so")        # run_sanitizers.sh: the _ubsan / _asan builds
+    subprocess.check_call(["make", "-s", "-C", HERE, name], stdout=subprocess.DEVNULL)
+    L = C.CDLL(os.path.join(HERE, name))
+    L.sh2_selfplay.restype = C.c_longlong
+    L.sh2_selfplay.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_ulonglong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6
+    return L
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def run_case(L, first, pool, n, T, variant, rotated, seed0, margin=0):
+    """n games seeded seed0 + g (the oracle provides the state after random.seed; GameRunner(); reset()), T moves through the emulated
+    wave code; returns everything the kernel would have written."""
+    streams = [oz.Stream(seed0 + g, first_player=first if first else oz.FIRST_RANDOM, tile_pool=pool) for g in range(n)]
+    state = np.stack([np.frombuffer(s.record().tobytes(), np.uint8) for s in streams]).copy()
+    mt = np.stack([s.rng_state()[0] for s in streams]).astype(np.uint32).copy()
+    pos = np.array([s.rng_state()[1] for s in streams], dtype=np.uint32)
+    ep, stuck, ss = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros((n, 10))
+    pitch = 192 if variant in (0, 1) else 180
+    out = {}
+    if variant != 4:
+        out = {"mask": np.full((T, n, pitch), 0xEE, np.uint8), "action": np.full((T, n), -7, np.int32), "reward": np.full((T, n), -7, np.int32),
+               "done": np.full((T, n), 9, np.uint8)}
+        if variant in (0, 2):
+            out["maskbits"] = np.zeros((T, n, 3), np.uint64)
+        if variant != 3:
+            out["packed"] = np.zeros((T, n), np.uint32)
+        else:
+            out["rec"] = np.zeros((T, n, 128), np.uint8)
+    ops = L.sh2_selfplay(n, ptr(state), ptr(mt), ptr(pos), ptr(ep), ptr(stuck), ptr(ss), first, pool, margin, T, variant, rotated,
+                         ptr(out.get("mask")), pitch, ptr(out.get("maskbits")), ptr(out.get("action")), ptr(out.get("reward")),
+                         ptr(out.get("done")), ptr(out.get("packed")), ptr(out.get("rec")))
+    assert ops > 0
+    return streams, state, mt, pos, ep, stuck, ss, out, ops
+
+
+def check_case(L, first, pool, n, T, variant, rotated, seed0, margin=0):
+    streams, state, mt, pos, ep, stuck, ss, out, ops = run_case(L, first, pool, n, T, variant, rotated, seed0, margin)
+    for g, s in enumerate(streams):
+        o = s.advance(T)
+        tag = (first, pool, variant, rotated, g)
+        if variant != 4:
+            assert np.array_equal(out["mask"][:, g, :180], o["mask"]), tag
+            assert np.array_equal(out["action"][:, g], o["action"]) and np.array_equal(out["reward"][:, g], o["reward"]), tag
+            assert np.array_equal(out["done"][:, g], o["done"]), tag
+        if "maskbits" in out:
+            bits = out["maskbits"][:, g].view(np.uint8).reshape(T, 24)[:, :23]
+            assert np.array_equal(bits, np.packbits(o["mask"].astype(bool), axis=1, bitorder="little")), tag
+        if "packed" in out:
+            p = out["packed"][:, g]
+            a = (p & 0xFF).astype(np.int32)
+            a[a == 0xFF] = -1
+            assert np.array_equal(a, o["action"]) and np.array_equal((p >> 8) & 0xFF, o["done"]), tag
+            assert np.array_equal((p >> 16).astype(np.uint16).view(np.int16).astype(np.int32), o["reward"]), tag
+        if "rec" in out:
+            assert out["rec"][:, g].tobytes() == o["rec_after"].tobytes(), tag
+        assert state[g].tobytes() == s.record().tobytes(), tag
+        assert np.array_equal(mt[g], s.rng_state()[0]) and int(pos[g]) == s.rng_state()[1], tag
+        assert int(ep[g]) == int(s.episodes.value) and int(stuck[g]) == int(s.stuck.value), tag
+        assert np.allclose(ss[g], s.stats_sum, rtol=0, atol=1e-9), tag
+    if variant in (0, 1):
+        assert not out["mask"][:, :, 184:].any() or (out["mask"][:, :, 184:] == 0xEE).all()      # bytes 184.. of a padded row are never written
+    return ops
+
+
+def test_emulated_cross_lane_operations_match_their_definitions():
+    assert load().sh2_selftest() == 0
+
+
+@pytest.mark.parametrize("ruleset", sorted(RULES))
+def test_selfplay_step2_under_lockstep_emulation_equals_the_oracle(ruleset):
+    L = load()
+    first, pool = RULES[ruleset]
+    total = 0
+    for variant in (0, 1, 2, 3, 4):
+        total += check_case(L, first, pool, n=5, T=130, variant=variant, rotated=0, seed0=300 + 10 * variant)
+    assert total > 30000                                   # cross-lane operations emulated
+
+
+@pytest.mark.parametrize("ruleset", ["lid_randomfirst", "random_first1"])
+def test_rotated_loop_under_lockstep_emulation_equals_the_oracle(ruleset):
+    L = load()
+    first, pool = RULES[ruleset]
+    for variant in (0, 3):
+        check_case(L, first, pool, n=4, T=130, variant=variant, rotated=1, seed0=700 + variant)
+
+
+def test_factory_draw_fp64_path_under_emulation():
+    """A draw margin that covers every draw sends the whole factory draw through the literal fp64 code and the sequential loop."""
+    L = load()
+    check_case(L, 0, 1, n=2, T=90, variant=3, rotated=0, seed0=55, margin=0x7fffffff)

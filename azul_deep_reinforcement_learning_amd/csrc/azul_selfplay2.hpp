@@ -759,12 +759,15 @@ AZ_FN void store_mask_row2(const Out2 &o, u32 m0, u32 m1, u32 m2, u32 m3, u32 m4
     return;
 #endif
     if (PAD) {
-        const u64 q0 = (u64)m0 | ((u64)m1 << 30) | ((u64)m2 << 60);
-        const u64 q1 = ((u64)m2 >> 4) | ((u64)m3 << 26) | ((u64)m4 << 56);
-        const u64 q2 = ((u64)m4 >> 8) | ((u64)m5 << 22);
-        const u32 j = l < 22u ? l : 22u;
-        const u64 qs = j < 8u ? q0 : (j < 16u ? q1 : q2);
-        const u32 by = (u32)(qs >> (8u * (j & 7u))) & 0xffu;
+        // the 180 bits as six dwords (the 30-bit row words back to back); lane j's eight bits are byte j & 3 of dword j >> 2 -- a
+        // byte-aligned field, picked with lane-constant masks (no lane-dependent control flow) and one bit-field extract
+        const u32 D0 = m0 | (m1 << 30), D1 = (m1 >> 2) | (m2 << 28), D2 = (m2 >> 4) | (m3 << 26), D3 = (m3 >> 6) | (m4 << 24),
+                  D4 = (m4 >> 8) | (m5 << 22), D5 = m5 >> 10;
+        const u32 j = l < 22u ? l : 22u, ds = j >> 2;
+        const u32 M0 = ds == 0u ? ~0u : 0u, M1 = ds == 1u ? ~0u : 0u, M2 = ds == 2u ? ~0u : 0u, M3 = ds == 3u ? ~0u : 0u, M4 = ds == 4u ? ~0u : 0u,
+                  M5 = ds == 5u ? ~0u : 0u;
+        const u32 D = (D0 & M0) | (D1 & M1) | (D2 & M2) | (D3 & M3) | (D4 & M4) | (D5 & M5);
+        const u32 by = (D >> (8u * (j & 3u))) & 0xffu;
         const u32 lo = ((by & 15u) * 0x00204081u) & 0x01010101u, hi = ((by >> 4) * 0x00204081u) & 0x01010101u;
         *(u64 *)(o.mask + (o.e * o.pitch + 8u * j)) = (u64)lo | ((u64)hi << 32);
     } else {

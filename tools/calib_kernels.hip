@@ -38,6 +38,17 @@ __global__ void calib_write_u8_rows192(unsigned char *dst, size_t n_rows)
     }
 }
 
+__global__ void calib_write_u64_rows192(unsigned char *dst, size_t n_rows)
+{
+    // round 3's mask write-out: rows at a 192-byte pitch, a wave writes TWO adjacent rows with ONE 8-byte store per lane
+    // (lanes 0..22 of a half -> bytes 8 j .. 8 j + 7 of the half's row, lanes 23..31 repeat lane 22: 184 bytes per row)
+    size_t pair = (size_t)blockIdx.x;
+    unsigned l = threadIdx.x & 31u, half = threadIdx.x >> 5;
+    unsigned j = l < 22u ? l : 22u;
+    for (; 2 * pair + 1 < n_rows; pair += gridDim.x)
+        *(unsigned long long *)(dst + (2 * pair + half) * 192 + 8u * j) = 0x0101010101010101ull * j;
+}
+
 __global__ void calib_write_u32(unsigned *dst, size_t n_words)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
@@ -57,10 +68,11 @@ int main()
         calib_read_u32<<<4096, 256>>>(a, sink, bytes / 4);
         calib_write_u8_rows<<<8192, 64>>>(b, rows);
         calib_write_u8_rows192<<<8192, 64>>>(b, bytes / 192);
+        calib_write_u64_rows192<<<8192, 64>>>(b, bytes / 192);
         calib_write_u32<<<4096, 256>>>((unsigned *)b, bytes / 4);
     }
     hipDeviceSynchronize();
-    printf("calib: read_u32 bytes=%zu write_u8_rows bytes=%zu write_u8_rows192 bytes=%zu write_u32 bytes=%zu\n", bytes, rows * 180,
-           (bytes / 192 / 2) * 2 * 192, bytes);
+    printf("calib: read_u32 bytes=%zu write_u8_rows bytes=%zu write_u8_rows192 bytes=%zu write_u64_rows192 bytes=%zu write_u32 bytes=%zu\n", bytes,
+           rows * 180, (bytes / 192 / 2) * 2 * 192, (bytes / 192 / 2) * 2 * 184, bytes);
     return 0;
 }

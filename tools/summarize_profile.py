@@ -57,6 +57,8 @@ if "calib_write_u8_rows:WRITE_SIZE" in calib:
     fac["write_bytes_per_counted_KB_u8_rows"] = (GiB // 180 * 180) / calib["calib_write_u8_rows:WRITE_SIZE"]
 if "calib_write_u8_rows192:WRITE_SIZE" in calib:
     fac["write_bytes_per_counted_KB_u8_rows192"] = ((GiB // 192 // 2) * 2 * 192) / calib["calib_write_u8_rows192:WRITE_SIZE"]
+if "calib_write_u64_rows192:WRITE_SIZE" in calib:
+    fac["write_bytes_per_counted_KB_u64_rows192"] = ((GiB // 192 // 2) * 2 * 184) / calib["calib_write_u64_rows192:WRITE_SIZE"]
 if "calib_write_u32:WRITE_SIZE" in calib:
     fac["write_bytes_per_counted_KB_u32"] = GiB / calib["calib_write_u32:WRITE_SIZE"]
 summary["calibration_factors"] = fac
@@ -65,6 +67,9 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     pitch = bench["config"].get("mask_row_pitch_bytes", 180)
     payload = pitch + 4 + 4 + 1 + 4 + (24 if bench["config"].get("mask_bits_stream", True) else 0)     # mask row, action, reward, done, compact record (+ mask bits)
     wkey = "write_bytes_per_counted_KB_u8_rows192" if pitch >= 192 and "write_bytes_per_counted_KB_u8_rows192" in fac else "write_bytes_per_counted_KB_u8_rows"
+    if pitch >= 192 and "write_bytes_per_counted_KB_u64_rows192" in fac:      # round 3: one 8-byte store per lane, 184 bytes per padded row
+        wkey = "write_bytes_per_counted_KB_u64_rows192"
+        payload = 184 + 4 + 4 + 1 + 4 + (24 if bench["config"].get("mask_bits_stream", True) else 0)
     w = pmc["WRITE_SIZE"]["mean"] * fac.get(wkey, 1024.0)
     summary["hbm_bytes_per_launch"] = {"fetch": f, "write": w, "total": f + w,
                                         "write_calibration": wkey if "WRITE_SIZE" in pmc else None,
@@ -74,7 +79,8 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                "games": bench["config"]["games_per_gpu"], "moves_per_launch": bench["config"]["moves_per_launch"],
                "bytes_per_move": (f + w) / waves_steps_for_traffic, "write_bytes_per_move": w / waves_steps_for_traffic,
                "payload_bytes_written_per_move": payload,
-               "launch": "azul_selfplay_kernel, %d games x %d moves" % (bench["config"]["games_per_gpu"], bench["config"]["moves_per_launch"])}, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+               "kernel": bench["roofline"].get("kernel", "?"),
+               "launch": "%s, %d games x %d moves" % (bench["roofline"].get("kernel", "?"), bench["config"]["games_per_gpu"], bench["config"]["moves_per_launch"])}, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 waves_steps = bench["config"]["games_per_gpu"] * bench["config"]["moves_per_launch"]
 if "SQ_INSTS_VALU" in pmc:
     summary["per_wave_step"] = {k: pmc[k]["mean"] / waves_steps for k in pmc if k.startswith("SQ_")}

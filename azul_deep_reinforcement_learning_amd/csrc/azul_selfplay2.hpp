@@ -861,6 +861,20 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
 
     Mask2 m;
     legal_mask2(g, k, m);
+    // -- RandomAgent (game_runner.py:87-97): counts of the legal actions first -- they address the weight table, and that LDS read
+    //    is on the move's chain: what does not need its answer (the mask row's bytes and stores) is placed between the request and
+    //    its use (the scheduler does not know an LDS round trip costs ~60-100 cycles)
+    const u32 c0 = __popc(m.m[0]), c1 = __popc(m.m[1]), c2 = __popc(m.m[2]), c3 = __popc(m.m[3]), c4 = __popc(m.m[4]), c5 = __popc(m.m[5]);
+    const u32 J = c0;                                    // legal floor moves (row 0: a < 30, weight 0.01)
+    const u32 p1 = c0, p2 = p1 + c1, p3 = p2 + c2, p4 = p3 + c3, p5 = p4 + c4, L = p5 + c5;
+    const bool nomove = (L == 0u) | (g.eog != 0u);        // ValueError in the reference (raised before random()) / a finished game handed in
+    const u32 M = L - J, Mc = M ? M : 1u;
+    // (random()'s conversion sits BEFORE the request: the two words were asked for ~40 instructions ago, and a use of them after the
+    // request would make the compiler wait for both reads there)
+    const double u01 = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0);      // random()
+    __builtin_amdgcn_sched_barrier(0);
+    const double2 fs = T.fs[8u * (J < 31u ? J : 30u) + 31u - (u32)__builtin_clz(Mc)];      // {Fr[J][ilog2 M], S[J]}
+    __builtin_amdgcn_sched_barrier(0);
     if (OUT == 1 || (OUT == 2 && o.mask))
         store_mask_row2<(PAD && OUT == 1)>(o, m.m[0], m.m[1], m.m[2], m.m[3], m.m[4], m.m[5], m.bit[0], m.bit[1], m.bit[2], m.bit[3], m.bit[4], m.bit[5], l);
     if ((OUT == 1 && BITS) || (OUT == 2 && o.maskbits)) {
@@ -872,21 +886,14 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
         const u32 q = l < 2u ? l : 2u;
         o.maskbits[o.e * 3u + q] = q == 0u ? q0 : (q == 1u ? q1 : q2);
     }
+    __builtin_amdgcn_sched_barrier(0);
     AZ_STAMP(SEG_MASK);
-
-    // -- RandomAgent (game_runner.py:87-97): ordinal of the chosen legal action
-    const u32 c0 = __popc(m.m[0]), c1 = __popc(m.m[1]), c2 = __popc(m.m[2]), c3 = __popc(m.m[3]), c4 = __popc(m.m[4]), c5 = __popc(m.m[5]);
-    const u32 J = c0;                                    // legal floor moves (row 0: a < 30, weight 0.01)
-    const u32 p1 = c0, p2 = p1 + c1, p3 = p2 + c2, p4 = p3 + c3, p5 = p4 + c4, L = p5 + c5;
-    const bool nomove = (L == 0u) | (g.eog != 0u);        // ValueError in the reference (raised before random()) / a finished game handed in
-    const u32 M = L - J, Mc = M ? M : 1u;
-    const double2 fs = T.fs[8u * (J < 31u ? J : 30u) + 31u - (u32)__builtin_clz(Mc)];      // {Fr[J][ilog2 M], S[J]}
     const double sJ = fs.y;
     // cum(J + M) = M + Fr[J][ilog2 M] (M >= 1), S[J] (M == 0); written as ONE sum so that both table values are used
     // unconditionally (a conditional use makes the compiler split the 16-byte read and branch around half of it)
     const double total = ((double)M + (M ? fs.x : sJ)) + 0.0;
     // pattern moves: cum(J + mm) = mm + Fr[J][ilog2 mm]; away from integer boundaries floor(x - S[J]) + 1 IS the ordinal
-    double x = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0) * total;
+    double x = u01 * total;
     double d = x - sJ;
     u32 fl = (u32)d;
     double fr = d - (double)fl;

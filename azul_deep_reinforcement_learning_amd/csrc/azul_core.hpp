@@ -34,7 +34,7 @@ enum { T_ROWS = 31, T_BINADES = 8, T_WORDS = T_ROWS * T_BINADES + T_ROWS };   //
 // s_memtime deltas are accumulated per segment and added to a global buffer when the wave ends.  The real kernel
 // contains no stamp; never quote the diagnostic build's run time, only its SHARES (tools/segment_profile.py).
 enum { SEG_MASK = 0, SEG_SAMPLE, SEG_MOVE, SEG_AFTERMOVE, SEG_TAIL, SEG_NEWROUND, SEG_SCORE, SEG_RESET, SEG_LOOP, SEG_COUNT };
-#if defined(AZ_PROFILE_SEGMENTS) && AZ_DEVICE_BUILD
+#if defined(AZ_PROFILE_SEGMENTS)
 struct SegProf { u64 last; u64 acc[SEG_COUNT]; };
 // (null-safe: callers outside the self-play kernels pass no SegProf -- an unguarded store would be undefined behaviour, which the
 // compiler is free to "optimise" into dropping the code behind the stamp: such a build ran the policy rollout 26 % faster, and wrong)
@@ -109,9 +109,7 @@ AZ_FN void rng_twist(Rng &r)
 {
     // genrand_uint32's regeneration loop; ascending 64-wide chunks are legal because element i needs
     // OLD mt[i], mt[i+1] and (i<227: OLD mt[i+397] | i>=227: NEW mt[i-227]); see DESIGN.md.
-#if AZ_DEVICE_BUILD
 #pragma unroll 1
-#endif
     for (u32 k = 0; k < 10; k++) {
         vu32 i = lane() + k * 64u;
         vbool act = i < 624u;
@@ -174,9 +172,7 @@ AZ_FN u32 rng_below(Rng &r, u32 n, u32 bits)
 AZ_FN void rng_close(Rng &r, u32 *pos_out)
 {
     if (r.dirty & 1u) {
-#if AZ_DEVICE_BUILD
 #pragma unroll 1
-#endif
         for (u32 k = 0; k < 10; k++) {
             vu32 i = lane() + k * 64u;
             vu32 w = lds_ld(r.lds, i, i < 624u);
@@ -659,9 +655,7 @@ AZ_FN u32 deal_factories(vu32 &cs, u64 &box, u64 &lid, Rng &r)
     vu32 l = lane();
     cs = sel(l == 30u, splat(1u), splat(0u));            // :71,:73
     if (!LID) {
-#if AZ_DEVICE_BUILD
 #pragma unroll 1
-#endif
         for (u32 t = 0; t < 20u; t++) {
             u32 color = rng_below(r, 5u, 3u);            // :78 randrange(0,5,1)
             cs = cs + sel(l == (t >> 2) * 5u + color, splat(1u), splat(0u));   // :88
@@ -707,13 +701,9 @@ AZ_FN u32 deal_factories(vu32 &cs, u64 &box, u64 &lid, Rng &r)
         // the common round: twenty branch-free integer draws, one display (four draws) per loop trip
         u32 plo = (u32)P;                                  // prefix sums of colours 0..3 (the only ones compared)
         vu32 sh = (l & 3u) * 8u;
-#if AZ_DEVICE_BUILD
 #pragma unroll 1
-#endif
         for (u32 d = 0; d < 5u; d++) {
-#if AZ_DEVICE_BUILD
 #pragma unroll
-#endif
             for (u32 j = 0; j < 4u; j++) {
                 vu32 pc = (plo >> sh) & 0xffu;
                 u32 color = popc64(ballot(((pc << 21) <= readlane(kthi, d * 4u + j)) & (l < 4u)));
@@ -725,9 +715,7 @@ AZ_FN u32 deal_factories(vu32 &cs, u64 &box, u64 &lid, Rng &r)
         r.pos += 40u;
         return ST_OK;
     }
-#if AZ_DEVICE_BUILD
 #pragma unroll 1
-#endif
     for (u32 t = 0; t < 20u; t++) {
         u32 total = (u32)(P >> 32) & 0xffu;
         if (AZ_UNLIKELY(total == 0u)) {                                              // :81-83, :85
@@ -847,9 +835,7 @@ AZ_FN u32 checked_step(Game &g, const LaneConst &k, Rng &r, i32 a)
 template <bool LID>
 AZ_FN u32 runner_opponent_loop(Game &g, const LaneConst &k, Rng &r, const SampleTab &T, bool until_player1_only)
 {
-#if AZ_DEVICE_BUILD
 #pragma unroll 1
-#endif
     for (u32 guard = 0; guard < 4096u; guard++) {
         Mask m;
         legal_mask(g, k, m);

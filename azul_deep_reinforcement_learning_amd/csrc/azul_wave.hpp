@@ -25,7 +25,6 @@ typedef int64_t  i64;
 #endif
 #include <hip/hip_runtime.h>
 #define AZ_FN __device__ __forceinline__
-#define AZ_DEVICE_BUILD 1
 
 namespace wv {
 typedef u32    vu32;

@@ -13,7 +13,6 @@ typedef int64_t  i64;
 
 #include <string.h>
 #define AZ_FN static inline
-#define AZ_DEVICE_BUILD 0
 
 namespace wv {
 struct vbool { bool v[64]; };

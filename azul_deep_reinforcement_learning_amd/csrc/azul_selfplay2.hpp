@@ -805,7 +805,11 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
     g.cur = eor ? g.cur : (g.cur < 2u ? g.cur + 1u : 1u);    // :313 next_player
     u32 st = ST_OK;
     AZ_STAMP(SEG_AFTERMOVE);
-    if (AZ_UNLIKELY(wave_any(eor))) {
+    // (ONE wave-uniform test for the end of a round and for a game that is over -- a test costs ~33 cycles even when it falls through;
+    // the episode-end block further down branches on a flag that is already scalar.  `over` without the end of a round: a state
+    // handed in with a complete wall row and the flag clear)
+    bool any_done = false;
+    if (AZ_UNLIKELY(wave_any(eor | (g.over != 0u)))) {
         if (eor) {
             count_score2<LID>(g, k);                         // :307 (also resets the what-if cache)
             if (g.over) g.eog = 1;                           // :308-309
@@ -813,6 +817,7 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
         AZ_STAMP(SEG_SCORE);
         if (eor & !g.over) st = new_round2<LID>(g, r, margin, k);      // :311
         AZ_STAMP(SEG_NEWROUND);
+        any_done = wave_any((g.over != 0u) & (st == ST_OK));
     }
     const i32 phi = g.wi0 - g.wi1;
     const i32 reward = phi - g.pscore;
@@ -821,7 +826,7 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
     outputs2<OUT>(g, o, a, reward, dn, l);
     AZ_STAMP(SEG_TAIL);
     u32 ret = st != ST_OK ? (0x100u | st) : dn;
-    if (AZ_UNLIKELY(wave_any((dn != 0u) & (st == ST_OK)))) {
+    if (AZ_UNLIKELY(any_done)) {
         if ((dn != 0u) & (st == ST_OK)) {
 #if !defined(AZ2_X_NO_STATS)
             if (l == 0u) {
@@ -902,7 +907,10 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     r.pos += (hard | nomove) ? 0u : 2u;
     // ONE test for everything unusual about this decision (a random() that crosses a regeneration, a draw at a boundary of the
     // cumulative weights, nothing legal); the stuck slot itself is restarted further down
-    if (AZ_UNLIKELY(wave_any((hard | edge) & !nomove))) {
+    // (a wave-uniform test -- vector compare, VCC, scalar branch -- costs ~33 cycles even when it falls through, tools/pattern_cost.hip:
+    // "nothing legal" rides on this one, and the stuck-slot block below branches on a flag that is already scalar)
+    bool any_nomove = false;
+    if (AZ_UNLIKELY(wave_any(hard | edge | nomove))) {
         if (hard & !nomove) {
             wa = rng2_u32(r, l); wb = rng2_u32(r, l);
             x = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0) * total;
@@ -911,6 +919,7 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
             edge = (x < sJ) | !(fr > 1e-9 && fr < 1.0 - 1e-9) | (fl + 1u > M);
         }
         if (edge & !nomove) kg = sample_slow2(T, x, sJ, J, M, L);
+        any_nomove = wave_any(nomove);
     }
     // kg-th legal action: its pattern row (= mask word) from the prefix counts (half-uniform compares), then ONE rank test per lane;
     // the lane that answers holds (display, colour) as a constant, the row is the word index
@@ -932,7 +941,7 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     AZ_STAMP(SEG_SAMPLE);
 
     u32 ret = 0;
-    if (AZ_UNLIKELY(wave_any(nomove))) {
+    if (AZ_UNLIKELY(any_nomove)) {
         if (nomove) {
             // stuck (hazard H3), or handed an already finished game: report, restart the slot
             if (l == 0u) *cnt.stuck += 1u;

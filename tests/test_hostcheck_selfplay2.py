@@ -112,3 +112,78 @@ def test_factory_draw_fp64_path_under_emulation():
     """A draw margin that covers every draw sends the whole factory draw through the literal fp64 code and the sequential loop."""
     L = load()
     check_case(L, 0, 1, n=2, T=90, variant=3, rotated=0, seed0=55, margin=0x7fffffff)
+
+
+def test_stuck_slot_and_finished_game_under_emulation():
+    """Hazard H3 (nothing legal although the round is not over: only the first-player token is left): the wave restarts the slot
+    (done == 2, action -1, no random() consumed by the failed decision) in the half concerned while the sibling half plays on --
+    the rare block that sits behind a scalar flag in selfplay_step2.  (A game handed in with its end_of_game flag set takes the
+    same block on the device; the reference raises GameEnded there, so the oracle's stream has no counterpart: GPU tests cover it.)"""
+    L = load()
+    n, T = 4, 40
+    streams = [oz.Stream(900 + g) for g in range(n)]
+    for s in streams:
+        s.advance(7)
+    # games 1 and 2 (different waves, different halves): nothing legal
+    recs = []
+    for g in (1, 2):
+        r_ = streams[g].record().copy()
+        r_["displays"][:] = 0
+        r_["center"][:] = [0, 0, 0, 0, 0, 1]
+        recs.append((streams[g], r_))
+    for s, rec in recs:
+        q = oz.unpack(rec, tile_pool=oz.POOL_LID, first_player=oz.FIRST_RANDOM)
+        C.memmove(C.byref(s.q), C.byref(q), C.sizeof(q))
+    state = np.stack([np.frombuffer(s.record().tobytes(), np.uint8) for s in streams]).copy()
+    mt = np.stack([s.rng_state()[0] for s in streams]).astype(np.uint32).copy()
+    pos = np.array([s.rng_state()[1] for s in streams], dtype=np.uint32)
+    ep, stuck, ss = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros((n, 10))
+    mask = np.zeros((T, n, 180), np.uint8)
+    action, reward, done = np.zeros((T, n), np.int32), np.zeros((T, n), np.int32), np.zeros((T, n), np.uint8)
+    rec = np.zeros((T, n, 128), np.uint8)
+    assert L.sh2_selfplay(n, ptr(state), ptr(mt), ptr(pos), ptr(ep), ptr(stuck), ptr(ss), 0, 1, 0, T, 3, 0, ptr(mask), 180, None, ptr(action),
+                          ptr(reward), ptr(done), None, ptr(rec)) > 0
+    assert action[0, 1] == -1 and done[0, 1] == 2 and action[0, 2] == -1 and done[0, 2] == 2
+    for g, s in enumerate(streams):
+        stuck0 = int(s.stuck.value)
+        o = s.advance(T)
+        assert np.array_equal(mask[:, g], o["mask"]) and np.array_equal(action[:, g], o["action"]), g
+        assert np.array_equal(reward[:, g], o["reward"]) and np.array_equal(done[:, g], o["done"]), g
+        assert rec[:, g].tobytes() == o["rec_after"].tobytes(), g
+        assert state[g].tobytes() == s.record().tobytes() and int(pos[g]) == s.rng_state()[1] and np.array_equal(mt[g], s.rng_state()[0]), g
+        assert int(stuck[g]) == int(s.stuck.value) - stuck0
+
+
+def test_rule_error_stops_one_game_and_leaves_its_sibling_alone():
+    """"Lid" pool with box and lid both empty when a round has to be dealt (the reference raises inside random.choices, azul.py:85-87):
+    the game concerned stops where it is -- its last move's outputs are written, nothing after -- and the other game of the same
+    wave plays on, move for move like the oracle.  (The loop's per-game exit sits behind a wave-uniform flag that only the rare
+    blocks set.)"""
+    L = load()
+    n, T = 2, 60
+    streams = [oz.Stream(4000 + g) for g in range(n)]
+    for s in streams:
+        s.advance(5)
+    rec = streams[0].record().copy()
+    rec["displays"][:] = 0
+    rec["center"][:] = [1, 0, 0, 0, 0, 0]                 # one tile left, no token: the next move ends the round
+    rec["box"][:] = 0
+    rec["lid"][:] = 0
+    rec["pattern_lines"][:] = 0                           # no full line returns tiles to the lid
+    q = oz.unpack(rec, tile_pool=oz.POOL_LID, first_player=oz.FIRST_RANDOM)
+    C.memmove(C.byref(streams[0].q), C.byref(q), C.sizeof(q))
+    state = np.stack([np.frombuffer(s.record().tobytes(), np.uint8) for s in streams]).copy()
+    mt = np.stack([s.rng_state()[0] for s in streams]).astype(np.uint32).copy()
+    pos = np.array([s.rng_state()[1] for s in streams], dtype=np.uint32)
+    ep, stuck, ss = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros((n, 10))
+    mask = np.zeros((T, n, 180), np.uint8)
+    action, reward, done = np.full((T, n), -7, np.int32), np.full((T, n), -7, np.int32), np.full((T, n), 9, np.uint8)
+    assert L.sh2_selfplay(n, ptr(state), ptr(mt), ptr(pos), ptr(ep), ptr(stuck), ptr(ss), 0, 1, 0, T, 3, 0, ptr(mask), 180, None, ptr(action),
+                          ptr(reward), ptr(done), None, None) > 0
+    assert 0 <= action[0, 0] < 180 and (action[1:, 0] == -7).all() and (done[1:, 0] == 9).all()      # game 0 stopped after its first move
+    after = state[0].view(oz.RECORD_DTYPE)[0]
+    assert not after["box"].any() and int(after["center"][0]) == 0
+    o = streams[1].advance(T)                                                                          # its sibling: the oracle's game
+    assert np.array_equal(action[:, 1], o["action"]) and np.array_equal(reward[:, 1], o["reward"]) and np.array_equal(done[:, 1], o["done"])
+    assert np.array_equal(mask[:, 1], o["mask"]) and state[1].tobytes() == streams[1].record().tobytes()
+    assert int(pos[1]) == streams[1].rng_state()[1]

@@ -9,6 +9,7 @@ I/O and ``__eq__``.  ``Azul(players=3)`` / ``Azul(players=4)`` behave like the r
 """
 import json
 import random
+import struct
 
 import numpy as np
 
@@ -115,39 +116,57 @@ class Azul:
     def _backend(self):
         return fb.backend(self._first_code, self._pool_code, self.players)
 
+    # the record as a struct format (little endian, no padding; include/azul_hip.h): struct.pack range-checks every value for free
+    _FMT2 = struct.Struct("<25B6BB50B2B2I2h5B5BH2H2h2B6BhH")                      # 128 bytes, two players
+    _FMTN = struct.Struct("<25B6BB100B4B4I4h5B5BH4H4h4B12BB51x")                   # 256 bytes, three / four players (absent players: zero)
+    _RANGES = (("game_board_displays", 0, 255), ("game_board_center", 0, 255), ("pattern_lines", 0, 255), ("floors", 0, 7),
+               ("score", -32768, 32767), ("box_tiles", 0, 255), ("lid_tiles", 0, 255), ("first_player_stats", 0, 65535),
+               ("floor_penalty", -32768, 32767), ("max_combo", 0, 255), ("completed_lines", 0, 255))
+
     def _to_record(self, runner=None):
+        """The attributes packed into the game record (128 bytes; 256 for three / four players).  Callers write the attributes
+        freely (numpy arrays, Python ints), so every value is range-checked against what its record field holds: struct.pack does
+        that while it packs (one C call instead of a dozen numpy reductions and field assignments)."""
         P = self.players
         wide = P != 2
-        rec = np.zeros((), dtype=RECORD_NP_DTYPE if wide else RECORD_DTYPE)
-        if wide:
-            rec["players"] = P
+        pad = 4 - P if wide else 0
+        lid = self.tile_pool == "Lid"
+        try:
+            fl = np.ravel(self.floors).tolist()
+            if max(fl) > 7:
+                raise struct.error("floors")
+            z = [0] * pad
+            vals = (np.ravel(self.game_board_displays).tolist() + np.ravel(self.game_board_center).tolist()
+                    + [pack_flags(self._player(self.current_player), self._player(self.next_first_player), self.end_of_game)]
+                    + np.ravel(self.pattern_lines).tolist() + [0] * (25 * pad) + fl + z
+                    + walls_to_bits(self.walls).tolist() + z + np.ravel(self.score).tolist() + z
+                    + (np.ravel(self.box_tiles).tolist() + np.ravel(self.lid_tiles).tolist() if lid else [0] * 10)
+                    + [int(self.turn_counter)]
+                    + np.ravel(self.first_player_stats).astype(np.int64).tolist() + z
+                    + np.ravel(self.floor_penalty).astype(np.int64).tolist() + z
+                    + np.ravel(self.max_combo).astype(np.int64).tolist() + z
+                    + np.ravel(self.completed_lines).astype(np.int64).tolist() + [0] * (3 * pad))
+            if wide:
+                raw = self._FMTN.pack(*vals, P)
+            else:
+                raw = self._FMT2.pack(*vals, int(runner.player_score) if runner is not None else 0,
+                                      int(runner.move_counter) if runner is not None else 0)
+        except (struct.error, TypeError, ValueError):
+            for (name, l, h) in self._RANGES:             # name the offender the slow way
+                if not hasattr(self, name):
+                    continue
+                v = np.asarray(getattr(self, name))
+                if v.size and (v.min() < l or v.max() > h):
+                    raise ValueError("%s outside the range the GPU record holds [%d, %d]" % (name, l, h))
+            raise ValueError("an attribute does not fit the GPU record (shape of a %d-player game, current_player / next_first_player in "
+                             "0..%d, turn_counter / player_score / move_counter in their 16-bit fields)" % (P, P))
+        return np.frombuffer(raw, dtype=RECORD_NP_DTYPE if wide else RECORD_DTYPE)[0]
 
-        def fit(name, value, lo, hi):
-            v = np.asarray(value)
-            if v.min() < lo or v.max() > hi:
-                raise ValueError("%s outside the range the GPU record holds [%d, %d]" % (name, lo, hi))
-            return v
-
-        rec["displays"] = fit("game_board_displays", self.game_board_displays, 0, 255)
-        rec["center"] = fit("game_board_center", self.game_board_center, 0, 255)
-        rec["flags"] = pack_flags(fit("current_player", self.current_player, 0, P),
-                                  fit("next_first_player", self.next_first_player, 0, P), self.end_of_game)
-        rec["pattern_lines"][:P] = fit("pattern_lines", self.pattern_lines, 0, 255)
-        rec["floors"][:P] = fit("floors", self.floors, 0, 7)
-        rec["walls"][:P] = walls_to_bits(self.walls)
-        rec["score"][:P] = fit("score", self.score, -32768, 32767)
-        if self.tile_pool == "Lid":
-            rec["box"] = fit("box_tiles", self.box_tiles, 0, 255)
-            rec["lid"] = fit("lid_tiles", self.lid_tiles, 0, 255)
-        rec["turn_counter"] = fit("turn_counter", self.turn_counter, 0, 65535)
-        rec["first_player_stats"][:P] = fit("first_player_stats", self.first_player_stats, 0, 65535)
-        rec["floor_penalty"][:P] = fit("floor_penalty", self.floor_penalty, -32768, 32767)
-        rec["max_combo"][:P] = fit("max_combo", self.max_combo, 0, 255)
-        rec["completed_lines"][:P] = fit("completed_lines", self.completed_lines, 0, 255)
-        if runner is not None:
-            rec["player_score"] = fit("player_score", runner.player_score, -32768, 32767)
-            rec["move_counter"] = fit("move_counter", runner.move_counter, 0, 65535)
-        return rec
+    def _player(self, v):
+        v = int(v)
+        if not 0 <= v <= self.players:
+            raise ValueError("player")
+        return v
 
     def _from_record(self, rec, runner=None):
         P = self.players

@@ -16,240 +16,7 @@
 // :87-97 (RandomAgent); azulnet/nn_runner.py:17-47.
 #pragma once
 
-namespace az2 {
-
-// ---- observation: game_runner.py:56-72, 136 values; value j of my game for j = lane + 32 i ------------------------------------------
-// (layout as azul_core.hpp's observe: cells 0..30 | pattern_lines[order[0]] | pattern_lines[order[1]] | walls[order[0]] | walls[order[1]] |
-// floors | scores | next first player, seen from player `persp`)
-template <int I>
-AZ_FN u32 observe_val2(const G2 &g, u32 o0 /* half-uniform: 0 / 1 */, u32 l)
-{
-    const u32 cpa = o0 ? g.cp1 : g.cp0, cpb = o0 ? g.cp0 : g.cp1;
-    const u32 wall_a = o0 ? g.wall1 : g.wall0, wall_b = o0 ? g.wall0 : g.wall1;
-    if (I == 0) {
-        const u32 pa0 = hread(cpa, 0u);
-        return l < 31u ? g.cs : pa0;                                   // j = 31: order[0]'s cell 0
-    }
-    if (I == 1) {                                                       // j = 32 + l: order[0] cells 1..24 (l < 24), order[1] cells 0..7
-        const u32 va = hread(cpa, l + 1u), vb = hread(cpb, l - 24u);
-        return l < 24u ? va : vb;
-    }
-    if (I == 2) {                                                       // j = 64 + l: order[1] cells 8..24 (l < 17), walls[order[0]] bits 0..14
-        const u32 vb = hread(cpb, l + 8u);
-        return l < 17u ? vb : (wall_a >> ((l - 17u) & 31u)) & 1u;
-    }
-    if (I == 3)                                                         // j = 96 + l: walls[order[0]] bits 15..24 (l < 10), walls[order[1]] bits 0..21
-        return l < 10u ? (wall_a >> (l + 15u)) & 1u : (wall_b >> ((l - 10u) & 31u)) & 1u;
-    // j = 128 + l (l < 8): walls[order[1]] bits 22..24, floors, scores, next first player
-    const u32 floor_a = o0 ? g.floor1 : g.floor0, floor_b = o0 ? g.floor0 : g.floor1;
-    const i32 score_a = o0 ? g.score1 : g.score0, score_b = o0 ? g.score0 : g.score1;
-    const u32 pnfp = g.nfp > 0u ? (((g.nfp - 1u - o0) & 1u) + 1u) : 0u;     // game_runner.py:58-61
-    u32 v = (wall_b >> ((l + 22u) & 31u)) & 1u;
-    v = l == 3u ? floor_a : v;
-    v = l == 4u ? floor_b : v;
-    v = l == 5u ? (u32)score_a : v;
-    v = l == 6u ? (u32)score_b : v;
-    v = l == 7u ? pnfp : v;
-    return v;
-}
-
-// writes the 136 floats of my game to `lds_row` (the network's A operand) and to `glob` (trajectory slot)
-AZ_FN void observe2(const G2 &g, u32 persp, float *lds_row, float *glob, u32 l)
-{
-    const u32 o0 = persp & 1u;
-    float v0 = (float)(i32)observe_val2<0>(g, o0, l), v1 = (float)(i32)observe_val2<1>(g, o0, l), v2 = (float)(i32)observe_val2<2>(g, o0, l),
-          v3 = (float)(i32)observe_val2<3>(g, o0, l), v4 = (float)(i32)observe_val2<4>(g, o0, l);
-    lds_row[l] = v0; lds_row[l + 32u] = v1; lds_row[l + 64u] = v2; lds_row[l + 96u] = v3;
-    glob[l] = v0; glob[l + 32u] = v1; glob[l + 64u] = v2; glob[l + 96u] = v3;
-    if (l < 8u) { lds_row[l + 128u] = v4; glob[l + 128u] = v4; }
-}
-
-// ---- RandomAgent.get_a_output (game_runner.py:87-97): selfplay_step2's decision as a function --------------------------------------
-// Returns false when nothing is legal (ValueError in the reference, raised BEFORE random() is called: no words consumed).
-AZ_FN bool random_agent2(const Mask2 &m, Rng2 &r, const Tab2 &T, const K2 &k, u32 &code)
-{
-    const u32 l = k.l;
-    const u32 c0 = __popc(m.m[0]), c1 = __popc(m.m[1]), c2 = __popc(m.m[2]), c3 = __popc(m.m[3]), c4 = __popc(m.m[4]), c5 = __popc(m.m[5]);
-    const u32 J = c0;
-    const u32 p1 = c0, p2 = p1 + c1, p3 = p2 + c2, p4 = p3 + c3, p5 = p4 + c4, L = p5 + c5;
-    code = 0;
-    if (L == 0u) return false;
-    const u32 M = L - J, Mc = M ? M : 1u;
-    const double2 fs = T.fs[8u * (J < 31u ? J : 30u) + 31u - (u32)__builtin_clz(Mc)];
-    const double sJ = fs.y;
-    const double total = ((double)M + (M ? fs.x : sJ)) + 0.0;
-    const double x = rng2_random(r, l) * total;
-    const double d = x - sJ;
-    const u32 fl = (u32)d;
-    const double fr = d - (double)fl;
-    u32 kg = J + fl + 1u;
-    const bool edge = (x < sJ) | !(fr > 1e-9 && fr < 1.0 - 1e-9) | (fl + 1u > M);
-    if (AZ_UNLIKELY(edge)) kg = sample_slow2(T, x, sJ, J, M, L);
-    const u32 want = kg - 1u;
-    const bool g1 = want >= p1, g2 = want >= p2, g3 = want >= p3, g4 = want >= p4, g5 = want >= p5;
-    const u32 mword = g5 ? m.m[5] : g4 ? m.m[4] : g3 ? m.m[3] : g2 ? m.m[2] : g1 ? m.m[1] : m.m[0];
-    const u32 base = g5 ? p5 : g4 ? p4 : g3 ? p3 : g2 ? p2 : g1 ? p1 : 0u;
-    const u32 prow_ = (u32)g1 + (u32)g2 + (u32)g3 + (u32)g4 + (u32)g5;
-    const bool hit = (((mword >> l) & 1u) != 0u) & ((u32)__popc(mword & ((1u << l) - 1u)) == want - base);
-    const u32 ln = (u32)__builtin_ctz(hb(hit) | 0x80000000u);
-    code = hbcast(k.lcode, ln) | (prow_ << 13) | ((30u * prow_ + ln) << 17);
-    return true;
-}
-
-// the same packing for an action given by number (azul_core.hpp's action_code)
-AZ_FN u32 action_code2(u32 a, const K2 &k)
-{
-    const u32 prow_ = a / 30u, ln = a - 30u * prow_;
-    return hbcast(k.lcode, ln) | (prow_ << 13) | (a << 17);
-}
-
-// ---- Azul.step's body for a legal move (azul_core.hpp's apply_step: move_and_score + new_round), what-if caches kept ----------------
-template <bool LID>
-AZ_FN u32 apply_step2(G2 &g, u32 code, Rng2 &r, u64 margin, const K2 &k)
-{
-    const u32 me = me2(g);
-    const bool filled = do_move2<LID>(g, code, g.B, k.l);               // azul.py:304
-    i32 wc = me ? g.wc1 : g.wc0;
-    if (wave_any(filled)) {
-        const i32 fresh = wall_points2(me ? g.wall1 : g.wall0, full_lines2(me ? g.cp1 : g.cp0, k), k);
-        wc = filled ? fresh : wc;
-    }
-    const i32 wi = clamp0((me ? g.score1 : g.score0) + floor_penalty(me ? g.floor1 : g.floor0) + wc);
-    g.wc0 = me ? g.wc0 : wc; g.wc1 = me ? wc : g.wc1;
-    g.wi0 = me ? g.wi0 : wi; g.wi1 = me ? wi : g.wi1;
-    g.B = hb(g.cs != 0u) & 0x7fffffffu;
-    const bool eor = g.B == 0u;                                        // :306
-    g.cur = eor ? g.cur : (g.cur < 2u ? g.cur + 1u : 1u);              // :313
-    u32 st = ST_OK;
-    // (rare events are tested per wave and kept out of line: two waves per SIMD cannot hide a taken branch's instruction refetch)
-    if (AZ_UNLIKELY(wave_any(eor))) {
-        if (eor) {
-            count_score2<LID>(g, k);                                   // :307
-            if (g.over) g.eog = 1;                                     // :308-309
-            else st = new_round2<LID>(g, r, margin, k);                // :311
-        }
-    }
-    return st;
-}
-
-// Azul.step with the legality test of azul.py:298-302 (azul_core.hpp's checked_step); `m` is the mask of the current state
-template <bool LID>
-AZ_FN u32 checked_step2(G2 &g, i32 a, const Mask2 &m, Rng2 &r, u64 margin, const K2 &k)
-{
-    if (g.eog) return ST_GAME_ENDED;
-    if (a < 0 || a >= 180) return ST_BAD_ACTION;
-    const u32 row = (u32)a / 30u, bit = (u32)a - 30u * row;
-    const u32 word = row == 0u ? m.m[0] : row == 1u ? m.m[1] : row == 2u ? m.m[2] : row == 3u ? m.m[3] : row == 4u ? m.m[4] : m.m[5];
-    if (((word >> bit) & 1u) == 0u) return ST_ILLEGAL_MOVE;             // state untouched
-    return apply_step2<LID>(g, action_code2((u32)a, k), r, margin, k);
-}
-
-AZ_FN u32 mask_count2(const Mask2 &m) { return __popc(m.m[0]) + __popc(m.m[1]) + __popc(m.m[2]) + __popc(m.m[3]) + __popc(m.m[4]) + __popc(m.m[5]); }
-
-AZ_FN void episode_stats2(const G2 &g, const Counters2 &cnt, u32 l)
-{
-    if (l == 0u) {
-        for (u32 q = 0; q < 10u; q++) cnt.stat_sum[q] += game_stat2(g, q);
-        *cnt.episodes += 1ull;
-    }
-}
-
-template <bool LID>
-AZ_FN u32 reset2(G2 &g, u32 first_player, Rng2 &r, u64 margin, const K2 &k)
-{
-    u32 st = episode_reset2<LID>(g, first_player, r, margin, k);
-    prime2(g, k);
-    return st;
-}
-
-// One env move of policy-driven self-play (azul_kernels.hip's env_policy_step: the same decisions in the same order, with ONE reset site)
-template <bool LID>
-AZ_FN u32 policy_step2(G2 &g, i32 av, const Mask2 &m /* of the current state: the one that was published */, u32 first_player, Rng2 &r, u64 margin,
-                        const Counters2 &cnt, const K2 &k, i32 &rew, u32 &dn)
-{
-    rew = 0; dn = 0;
-    // "no action" is legitimate only when nothing is legal (hazard H3)
-    bool stuck = false;
-    if (AZ_UNLIKELY(wave_any(av < 0))) stuck = (av < 0) & (g.eog == 0u) & (mask_count2(m) == 0u);
-    u32 st = ST_OK;
-    bool restart = false;
-    if (!stuck) {
-        st = checked_step2<LID>(g, av, m, r, margin, k);
-        const bool dirty = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION);
-        if (dirty) {
-            g.moves += 1u;
-            const i32 phi = g.wi0 - g.wi1;                             // game_runner.py:48-50 (the what-if caches are current)
-            rew = phi - g.pscore;
-            g.pscore = phi;
-            dn = g.over ? 1u : 0u;                                     // is_end_of_game(): the walls, not the record's flag
-            restart = dn && st == ST_OK;
-        } else if (st == ST_GAME_ENDED) {                               // a finished game handed in: restart the slot, report done
-            dn = 1u;
-            restart = true;
-        }
-    }
-    if (AZ_UNLIKELY(wave_any(stuck | restart))) {
-        if (stuck | restart) {
-            if (stuck) { if (k.l == 0u) *cnt.stuck += 1u; dn = 2u; }
-            else if (st == ST_OK) episode_stats2(g, cnt, k.l);         // (a game handed in finished is not counted: st == ST_GAME_ENDED)
-            u32 st0 = reset2<LID>(g, first_player, r, margin, k);
-            st = stuck ? (st0 ? st0 : (u32)ST_STUCK) : st0;
-        }
-    }
-    return st;
-}
-
-// GameRunner's opponent loop (game_runner.py:46-47 / :84): azul_core.hpp's runner_opponent_loop
-template <bool LID>
-AZ_FN u32 opponent_loop2(G2 &g, Rng2 &r, const Tab2 &T, u64 margin, const K2 &k, bool until_player1_only)
-{
-#pragma unroll 1
-    for (u32 guard = 0; guard < 4096u; guard++) {
-        Mask2 m;
-        legal_mask2(g, k, m);
-        const bool keep = until_player1_only ? (g.cur != 1u) : ((g.cur != 1u || mask_count2(m) < 2u) && !g.over);
-        if (!keep) break;
-        u32 code;
-        if (!random_agent2(m, r, T, k, code)) return ST_STUCK;
-        if (g.eog) return ST_GAME_ENDED;
-        u32 st = apply_step2<LID>(g, code, r, margin, k);
-        if (st) return st;
-        g.moves += 1u;
-    }
-    return ST_OK;
-}
-
-// One AGENT step of NNRunner.run_episode (azul_kernels.hip's env_agent_step over azul_core.hpp's runner_step, statement for statement)
-template <bool LID>
-AZ_FN u32 agent_step2(G2 &g, i32 av, const Mask2 &m /* of the current state */, u32 first_player, Rng2 &r, const Tab2 &T, u64 margin,
-                       const Counters2 &cnt, const K2 &k, i32 &rew, u32 &dn)
-{
-    rew = 0;
-    dn = g.over ? 1u : 0u;
-    u32 st = checked_step2<LID>(g, av, m, r, margin, k);                // game_runner.py:44
-    if (!st) {
-        g.moves += 1u;                                                  // :45
-        st = opponent_loop2<LID>(g, r, T, margin, k, false);            // :46-47
-        if (!st) {
-            const i32 phi = g.wi0 - g.wi1;                             // :48-50
-            rew = phi - g.pscore;                                      // :51
-            g.pscore = phi;                                            // :52
-            dn = g.over ? 1u : 0u;                                     // :55
-        }
-    }
-    const bool dirty = !(st == ST_ILLEGAL_MOVE || st == ST_BAD_ACTION);
-    if (st == ST_STUCK) { if (k.l == 0u) *cnt.stuck += 1u; dn = 2u; rew = 0; }   // hazard H3: nobody can move
-    else if (st == ST_GAME_ENDED) dn = 1u;
-    else if (st == ST_OK && dn) episode_stats2(g, cnt, k.l);
-    if (dirty && dn) {
-        u32 st2 = reset2<LID>(g, first_player, r, margin, k);
-        if (!st2) st2 = opponent_loop2<LID>(g, r, T, margin, k, true);
-        if (st == ST_OK) st = st2;
-    }
-    return st;
-}
-
-} // namespace az2
+#include "azul_env2.hpp"
 
 constexpr u32 PR2_WAVES = 8, PR2_AHEAD = 8;
 

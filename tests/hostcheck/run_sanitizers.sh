@@ -1,12 +1,12 @@
 #!/bin/bash
 # TEST-ONLY: the CPU logic checks of the device code under AddressSanitizer + UndefinedBehaviorSanitizer (GPU sanitizers do not
 # exist on this pool).  Builds the sanitizer variants of both host emulations -- the one-game-per-wave core behind the
-# wv:: vector emulation (hostcheck.cpp) and the benchmarked two-games-per-wave code under the lockstep emulation (simt/) -- and
+# wv:: vector emulation (hostcheck.cpp) and the two-games-per-wave self-play code and the policy rollout kernel's env side under the lockstep emulation (simt/) -- and
 # runs the emulation test files against them.  Usage: tests/hostcheck/run_sanitizers.sh [log file]
 set -u
 cd "$(dirname "$0")/../.."
 LOG=${1:-profiles/round3_sanitizers.txt}
-make -s -C tests/hostcheck libhostcheck_asan.so libsimt_selfplay2_asan.so libsimt_selfplay2_ubsan.so || exit 1
+make -s -C tests/hostcheck libhostcheck_asan.so libsimt_selfplay2_asan.so libsimt_selfplay2_ubsan.so libsimt_env2_asan.so libsimt_env2_ubsan.so || exit 1
 ASAN=$(gcc -print-file-name=libasan.so); UBSAN=$(gcc -print-file-name=libubsan.so)
 {
   echo "# $(date -u +%FT%TZ)  g++ $(g++ -dumpversion)  -fsanitize=address,undefined -fno-sanitize-recover=all (an error aborts the test process)"
@@ -18,4 +18,9 @@ ASAN=$(gcc -print-file-name=libasan.so); UBSAN=$(gcc -print-file-name=libubsan.s
   echo "## the same, ASan + UBSan (fibers announced to ASan with __sanitizer_start/finish_switch_fiber)"
   LD_PRELOAD="$ASAN $UBSAN" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:detect_stack_use_after_return=0 AZUL_SIMT_LIB=libsimt_selfplay2_asan.so \
     timeout 1500 python -m pytest tests/test_hostcheck_selfplay2.py -q -p no:cacheprovider 2>&1 | tail -4
+  echo "## env side of the persistent policy rollout kernel (azul_env2.hpp, unmodified) under the lockstep emulation, UBSan"
+  LD_PRELOAD="$UBSAN" AZUL_SIMT_ENV_LIB=libsimt_env2_ubsan.so timeout 1500 python -m pytest tests/test_hostcheck_env2.py -q -p no:cacheprovider 2>&1 | tail -4
+  echo "## the same, ASan + UBSan"
+  LD_PRELOAD="$ASAN $UBSAN" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:detect_stack_use_after_return=0 AZUL_SIMT_ENV_LIB=libsimt_env2_asan.so \
+    timeout 1500 python -m pytest tests/test_hostcheck_env2.py -q -p no:cacheprovider 2>&1 | tail -4
 } | tee "$LOG"

@@ -240,22 +240,32 @@ AZ_FN void rng2_attach_tempered(Rng2 &r, u32 *tlds, u32 l)
     lds_sync();
 }
 
+// genrand_uint32's regeneration, ascending 32-wide chunks: element i needs OLD mt[i], OLD mt[i+1] (NEW mt[0] for i == 623) and
+// (i < 227: OLD mt[i+397], 12.4 chunks ahead | i >= 227: NEW mt[i-227], 7.09 chunks back) -- so the sources of a chunk are never
+// written inside its own GROUP of seven chunks: a group's 21 LDS reads are issued together and its writes follow in one go
+// (three groups, six fences, instead of twenty dependent read -> write round trips; the words are the same).
+// One rolled loop over the groups: the code is inlined at every site that can run into the end of the state.
 AZ_FN void rng2_twist(Rng2 &r, u32 l)
 {
-    // genrand_uint32's regeneration; ascending 32-wide chunks are legal for the same reason as 64-wide ones:
-    // element i needs OLD mt[i], mt[i+1] and (i < 227: OLD mt[i+397] | i >= 227: NEW mt[i-227], at least 7 chunks back)
 #pragma unroll 1
-    for (u32 q = 0; q < 20u; q++) {
-        u32 i = l + q * 32u;
-        bool act = i < 624u;
-        u32 i1 = i == 623u ? 0u : i + 1u;
-        u32 i2 = i < 227u ? i + 397u : i - 227u;
-        u32 a = 0, b = 0, c = 0;
-        if (act) { a = r.lds[i]; b = r.lds[i1]; c = r.lds[i2]; }
-        u32 y = (a & 0x80000000u) | (b & 0x7fffffffu);
-        u32 v = c ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+    for (u32 q0 = 0; q0 < 21u; q0 += 7u) {
+        u32 v[7];
+#pragma unroll
+        for (u32 q = 0; q < 7u; q++) {
+            const u32 i = l + (q0 + q) * 32u;
+            const u32 ic = i < 624u ? i : 623u;              // (chunk 19 is half empty, "chunk 20" empty: those lanes repeat element 623 and write nothing)
+            const u32 i1 = ic == 623u ? 0u : ic + 1u;
+            const u32 i2 = ic < 227u ? ic + 397u : ic - 227u;
+            const u32 a = r.lds[ic], b = r.lds[i1], c = r.lds[i2];
+            const u32 y = (a & 0x80000000u) | (b & 0x7fffffffu);
+            v[q] = c ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+        }
         lds_sync();
-        if (act) { r.lds[i] = v; if (r.tlds) r.tlds[i] = temper2(v); }
+#pragma unroll
+        for (u32 q = 0; q < 7u; q++) {
+            const u32 i = l + (q0 + q) * 32u;
+            if (i < 624u) { r.lds[i] = v[q]; if (r.tlds) r.tlds[i] = temper2(v[q]); }
+        }
         lds_sync();
     }
     r.dirty = 1;
@@ -283,23 +293,24 @@ AZ_FN u32 rng2_u32(Rng2 &r, u32 l)
 // random_random(): (a >> 5, b >> 6) -> (a * 2^26 + b) / 2^53, exact
 AZ_FN double rng2_random(Rng2 &r, u32 l)
 {
-    u32 a, b;
+    u32 a = 0, b = 0;
     if (r.pos + 2u <= r.wend) {
         u32 off = r.pos - r.wbase;
         a = hbcast(r.win, off);
         b = hbcast(r.win, off + 1u);
         r.pos += 2u;
     } else {
-        a = rng2_u32(r, l);
-        b = rng2_u32(r, l);
+        // (ONE call site for both words: the regeneration is inlined wherever a word is fetched)
+#pragma unroll 1
+        for (u32 w = 0; w < 2u; w++) { a = b; b = rng2_u32(r, l); }
     }
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
 }
 
 AZ_FN u32 rng2_below(Rng2 &r, u32 n, u32 bits, u32 l)
 {
-    u32 v = rng2_u32(r, l) >> (32u - bits);
-    while (v >= n) v = rng2_u32(r, l) >> (32u - bits);
+    u32 v;
+    do { v = rng2_u32(r, l) >> (32u - bits); } while (v >= n);
     return v;
 }
 
@@ -572,17 +583,9 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
     }
     // "Lid" pool: every draw is one random.choices = one random() = two MT words; see azul_core.hpp for the exactness argument
     // (integer decision P_c * 2^53 <= K * T unless K*T lies within `margin` of a multiple of 2^32, then the literal fp64 code).
-    const bool batched = r.pos + 40u <= 624u;
-    u32 klo = 0, khi = 0;
-    if (batched) {
-        u32 wa = 0, wb = 0;
-        if (l < 20u) { wa = temper2(r.lds[r.pos + 2u * l]) >> 5; wb = temper2(r.lds[r.pos + 2u * l + 1u]) >> 6; }
-        klo = (wa << 26) | wb;
-        khi = wa >> 6;
-    }
     if ((g.box & 0xffffffffffull) == 0ull) {
         // the box is empty when the round starts: the first draw refills it from the lid (:81-83) -- done here, so that the
-        // whole round can take the parallel path below
+        // whole round can take the parallel path below (no random number is involved: random.choices raises before random())
         g.box = g.lid; g.lid = 0;
         if ((g.box & 0xffffffffffull) == 0ull) return ST_BOX_EMPTY;
     }
@@ -590,6 +593,27 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
     const u32 blo = (u32)g.box;
     const u32 p0 = blo & 0xffu, p1 = p0 + ((blo >> 8) & 0xffu), p2 = p1 + ((blo >> 16) & 0xffu), p3 = p2 + (blo >> 24);
     const u32 T0 = p3 + ((u32)(g.box >> 32) & 0xffu);
+    // The round's 40 words in one go: lane t takes the two words of draw t.  When they straddle a regeneration (6 % of the rounds)
+    // and the round cannot run dry (T0 >= 20: exactly 40 words will be consumed), the words before it are read, the state is
+    // regenerated, and the words after it are read -- instead of twenty serial draws through the window.
+    const bool room = r.pos + 40u <= 624u;
+    const bool batched = room | (T0 >= 20u);
+    u32 klo = 0, khi = 0;
+    if (batched) {
+        const u32 i0 = r.pos + 2u * l, i1 = i0 + 1u;
+        u32 wa = 0, wb = 0;
+        if (l < 20u) { if (i0 < 624u) wa = r.lds[i0]; if (i1 < 624u) wb = r.lds[i1]; }
+        if (!room) {
+            const u32 p = r.pos;
+            lds_sync();
+            rng2_twist(r, l);
+            if (l < 20u) { if (i0 >= 624u) wa = r.lds[i0 - 624u]; if (i1 >= 624u) wb = r.lds[i1 - 624u]; }
+            r.pos = p - 624u;                                // (wraps; the round's forty words bring it to p + 40 - 624)
+        }
+        wa = temper2(wa) >> 5; wb = temper2(wb) >> 6;
+        klo = (wa << 26) | wb;
+        khi = wa >> 6;
+    }
     const bool pre = batched && T0 >= 20u;               // no refill can happen: draw t sees total T0 - t
     u32 kthi = 0, risky = 0, kt0hi = 0;
     if (pre) {
@@ -644,7 +668,13 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
         }
         u32 Klo, Khi;
         if (batched) { Klo = hread(klo, t); Khi = hread(khi, t); r.pos += 2u; }
-        else { u32 a27 = rng2_u32(r, l) >> 5, b26 = rng2_u32(r, l) >> 6; Klo = (a27 << 26) | b26; Khi = a27 >> 6; }
+        else {
+            u32 wa_ = 0, wb_ = 0;
+#pragma unroll 1
+            for (u32 w = 0; w < 2u; w++) { wa_ = wb_; wb_ = rng2_u32(r, l); }
+            const u32 a27 = wa_ >> 5, b26 = wb_ >> 6;
+            Klo = (a27 << 26) | b26; Khi = a27 >> 6;
+        }
         u64 KT = (u64)Klo * total + (((u64)Khi * total) << 32);
         u32 color;
         if (((KT - margin) >> 32) == ((KT + margin) >> 32)) {
@@ -912,7 +942,14 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     bool any_nomove = false;
     if (AZ_UNLIKELY(wave_any(hard | edge | nomove))) {
         if (hard & !nomove) {
-            wa = rng2_u32(r, l); wb = rng2_u32(r, l);
+            // CPython's index is 623 (the first word is the last of this state) or 624: regenerate, then read the tempered copy
+            const bool one = r.pos == 623u;
+            const u32 last = r.tlds[623];
+            lds_sync();
+            rng2_twist(r, l);
+            const u32 t0 = r.tlds[0], t1 = r.tlds[1];
+            wa = one ? last : t0; wb = one ? t0 : t1;
+            r.pos = one ? 1u : 2u;
             x = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0) * total;
             d = x - sJ; fl = (u32)d; fr = d - (double)fl;
             kg = J + fl + 1u;

@@ -31,10 +31,12 @@ def ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def run_case(L, first, pool, n, T, variant, rotated, seed0, margin=0):
+def run_case(L, first, pool, n, T, variant, rotated, seed0, margin=0, prepare=None):
     """n games seeded seed0 + g (the oracle provides the state after random.seed; GameRunner(); reset()), T moves through the emulated
     wave code; returns everything the kernel would have written."""
     streams = [oz.Stream(seed0 + g, first_player=first if first else oz.FIRST_RANDOM, tile_pool=pool) for g in range(n)]
+    if prepare:
+        prepare(streams)
     state = np.stack([np.frombuffer(s.record().tobytes(), np.uint8) for s in streams]).copy()
     mt = np.stack([s.rng_state()[0] for s in streams]).astype(np.uint32).copy()
     pos = np.array([s.rng_state()[1] for s in streams], dtype=np.uint32)
@@ -57,8 +59,8 @@ def run_case(L, first, pool, n, T, variant, rotated, seed0, margin=0):
     return streams, state, mt, pos, ep, stuck, ss, out, ops
 
 
-def check_case(L, first, pool, n, T, variant, rotated, seed0, margin=0):
-    streams, state, mt, pos, ep, stuck, ss, out, ops = run_case(L, first, pool, n, T, variant, rotated, seed0, margin)
+def check_case(L, first, pool, n, T, variant, rotated, seed0, margin=0, prepare=None):
+    streams, state, mt, pos, ep, stuck, ss, out, ops = run_case(L, first, pool, n, T, variant, rotated, seed0, margin, prepare)
     for g, s in enumerate(streams):
         o = s.advance(T)
         tag = (first, pool, variant, rotated, g)
@@ -112,6 +114,23 @@ def test_factory_draw_fp64_path_under_emulation():
     """A draw margin that covers every draw sends the whole factory draw through the literal fp64 code and the sequential loop."""
     L = load()
     check_case(L, 0, 1, n=2, T=90, variant=3, rotated=0, seed0=55, margin=0x7fffffff)
+
+
+@pytest.mark.parametrize("ruleset", ["lid_randomfirst", "random_first1"])
+def test_factory_draw_across_an_mt19937_regeneration(ruleset):
+    """The forty words of a round's factory draw straddle the regeneration of the 624-word state (CPython's index anywhere in
+    586..624 when the round starts): the words before it are read, the state is regenerated (three groups of chunks), the words
+    after it are read.  34 games whose streams start at every second index from 558 on reach their first round end -- and
+    several more -- inside the run; every word of the final states is compared."""
+    L = load()
+    first, pool = RULES[ruleset]
+
+    def prepare(streams):
+        for g, s in enumerate(streams):
+            s.r.idx = 558 + 2 * g + (g & 1)
+
+    for variant, rotated in ((3, 0), (0, 1)):
+        check_case(L, first, pool, n=34, T=40, variant=variant, rotated=rotated, seed0=1200, prepare=prepare)
 
 
 def test_stuck_slot_and_finished_game_under_emulation():

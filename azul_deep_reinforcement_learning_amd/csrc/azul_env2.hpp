@@ -99,16 +99,16 @@ AZ_FN u32 apply_step2(G2 &g, u32 code, Rng2 &r, u64 margin, const K2 &k)
 {
     const u32 me = me2(g);
     const bool filled = do_move2<LID>(g, code, g.B, k.l);               // azul.py:304
+    g.B = hb(g.cs != 0u) & 0x7fffffffu;
+    const bool eor = g.B == 0u;                                        // :306 (then count_score2 prices the lines for real and clears the cache)
     i32 wc = me ? g.wc1 : g.wc0;
-    if (wave_any(filled)) {
+    if (wave_any(filled & !eor)) {
         const i32 fresh = wall_points2(me ? g.wall1 : g.wall0, full_lines2(me ? g.cp1 : g.cp0, k), k);
         wc = filled ? fresh : wc;
     }
     const i32 wi = clamp0((me ? g.score1 : g.score0) + floor_penalty(me ? g.floor1 : g.floor0) + wc);
     g.wc0 = me ? g.wc0 : wc; g.wc1 = me ? wc : g.wc1;
     g.wi0 = me ? g.wi0 : wi; g.wi1 = me ? wi : g.wi1;
-    g.B = hb(g.cs != 0u) & 0x7fffffffu;
-    const bool eor = g.B == 0u;                                        // :306
     g.cur = eor ? g.cur : (g.cur < 2u ? g.cur + 1u : 1u);              // :313
     u32 st = ST_OK;
     // (rare events are tested per wave and kept out of line: two waves per SIMD cannot hide a taken branch's instruction refetch)

@@ -602,15 +602,17 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
     if (batched) {
         const u32 i0 = r.pos + 2u * l, i1 = i0 + 1u;
         u32 wa = 0, wb = 0;
-        if (l < 20u) { if (i0 < 624u) wa = r.lds[i0]; if (i1 < 624u) wb = r.lds[i1]; }
+        const u32 *words = r.tlds ? r.tlds : r.lds;          // (the tempered copy when the kernel keeps one)
+        if (l < 20u) { if (i0 < 624u) wa = words[i0]; if (i1 < 624u) wb = words[i1]; }
         if (!room) {
             const u32 p = r.pos;
             lds_sync();
             rng2_twist(r, l);
-            if (l < 20u) { if (i0 >= 624u) wa = r.lds[i0 - 624u]; if (i1 >= 624u) wb = r.lds[i1 - 624u]; }
+            if (l < 20u) { if (i0 >= 624u) wa = words[i0 - 624u]; if (i1 >= 624u) wb = words[i1 - 624u]; }
             r.pos = p - 624u;                                // (wraps; the round's forty words bring it to p + 40 - 624)
         }
-        wa = temper2(wa) >> 5; wb = temper2(wb) >> 6;
+        if (!r.tlds) { wa = temper2(wa); wb = temper2(wb); }
+        wa >>= 5; wb >>= 6;
         klo = (wa << 26) | wb;
         khi = wa >> 6;
     }
@@ -819,11 +821,13 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
     (void)prof_;
     const u32 l = k.l;
     // a move only changes the MOVER's lines and floor; the pricing of his full lines only when one more of them filled
+    // (not when the move ends the round: count_score2 below prices the lines for real and clears the cache)
+    const bool eor = g.B == 0u;                              // :306 is_end_of_round (the token counts)
     i32 wc = me ? g.wc1 : g.wc0;
 #if defined(AZ2_ALWAYS_WALLPTS)
     {
 #else
-    if (wave_any(filled)) {
+    if (wave_any(filled & !eor)) {
 #endif
         i32 fresh = wall_points2(me ? g.wall1 : g.wall0, full_lines2(me ? g.cp1 : g.cp0, k), k);
         wc = filled ? fresh : wc;
@@ -831,7 +835,6 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
     const i32 wi = clamp0((me ? g.score1 : g.score0) + floor_penalty(me ? g.floor1 : g.floor0) + wc);
     g.wc0 = me ? g.wc0 : wc; g.wc1 = me ? wc : g.wc1;
     g.wi0 = me ? g.wi0 : wi; g.wi1 = me ? wi : g.wi1;
-    const bool eor = g.B == 0u;                              // :306 is_end_of_round (the token counts)
     g.cur = eor ? g.cur : (g.cur < 2u ? g.cur + 1u : 1u);    // :313 next_player
     u32 st = ST_OK;
     AZ_STAMP(SEG_AFTERMOVE);

@@ -30,7 +30,7 @@ for l in body:
     cnt[cur]+=1
     if op.startswith('s_'): scnt[cur]+=1
     if op.startswith('v_'): vcnt[cur]+=1
-src={f:open('/root/repo/azul_deep_reinforcement_learning_amd/csrc/'+f).read().split('\n') for f in ('azul_core.hpp','azul_kernels.hip','azul_wave.hpp','azul_policy.hpp','azul_tables.hpp')}
+src={f:open('/root/repo/azul_deep_reinforcement_learning_amd/csrc/'+f).read().split('\n') for f in ('azul_core.hpp','azul_kernels.hip','azul_wave.hpp','azul_policy.hpp','azul_tables.hpp','azul_selfplay2.hpp','azul_env2.hpp','azul_rollout2.hpp','azul_core_np.hpp')}
 print("total", sum(cnt.values()), "scalar", sum(scnt.values()), "vector", sum(vcnt.values()))
 # group by function: find enclosing function name by scanning backwards for 'AZ_FN'
 def func_of(f,ln):

@@ -335,13 +335,13 @@ struct Mask2 {
 // the boards are kept in the game state: rebuilt here after loading / scoring / a reset, patched arithmetically by do_move2.
 AZ_FN u32 ok_board2(u32 cp, u32 wall, const K2 &k)
 {
+    // cell (r, c) accepts colour c when row r holds no OTHER colour and the wall cell is free -- written as ONE compare: a ballot of
+    // an and / or of compares goes through a 0 / 1 register and a second compare (5 instructions instead of 3)
     const u32 l = k.l;
-    u32 pme = hb(cp != 0u) & 0x1ffffffu;
-    u32 rb = (pme >> (k.prow * 5u)) & 31u;
-    u32 own = (rb >> k.pcol) & 1u;
-    bool alone = (rb == 0u) | (((rb & (rb - 1u)) == 0u) & (own != 0u));
-    bool free_ = ((wall >> l) & 1u) == 0u;
-    return hb(alone & free_ & (l < 25u)) & 0x1ffffffu;
+    const u32 pme = hb(cp != 0u) & 0x1ffffffu;
+    const u32 rb = (pme >> (k.prow * 5u)) & 31u;
+    const u32 bad = (rb & ~(1u << k.pcol)) | ((wall >> l) & 1u);
+    return hb(bad == 0u) & 0x1ffffffu;
 }
 
 AZ_FN void legal_mask2(const G2 &g, const K2 &k, Mask2 &out)
@@ -622,7 +622,7 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
         u32 tt = T0 - l;
         u32 lo = klo * tt, hi = khi * tt + __umulhi(klo, tt);
         u32 mg = (u32)margin;
-        risky = hb(((lo < mg) | (lo >= 0u - mg)) & (l < 20u));
+        risky = hb(lo + mg < 2u * mg) & 0xfffffu;        // lo within mg of a multiple of 2^32, one compare (mg < 2^31)
         kthi = hi;
         kt0hi = khi * T0 + __umulhi(klo, T0);            // K_t * T0: for the first guess only
     }
@@ -634,22 +634,24 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
         // unique fixed point, which is the sequential result.  Boundaries move by one tile in ~100 per draw: two or three
         // passes in practice, at most 21.
         const u32 below = (1u << l) - 1u;
-        const bool draw = l < 20u;
         // first guess: the colour drawn from the UNDEPLETED box, P_c * 2^53 <= K_t * T0 -- the expected boundaries of draw t,
         // (P_c - n_c(t)) / (T0 - t) ~ P_c / T0 (any start reaches the same fixed point; this one needs fewer passes)
         u32 col = (u32)((p0 << 21) <= kt0hi) + (u32)((p1 << 21) <= kt0hi) + (u32)((p2 << 21) <= kt0hi) + (u32)((p3 << 21) <= kt0hi);
         u32 b0 = 0, b1 = 0, b2 = 0, b3 = 0;               // draws with colour <= c, as of the pass that confirmed the colours
 #pragma unroll 1
         for (u32 it = 0; it < 21u; it++) {
-            b0 = hb(draw & (col == 0u)); b1 = hb(draw & (col <= 1u)); b2 = hb(draw & (col <= 2u)); b3 = hb(draw & (col <= 3u));
+            b0 = hb(col == 0u) & 0xfffffu; b1 = hb(col <= 1u) & 0xfffffu; b2 = hb(col <= 2u) & 0xfffffu; b3 = hb(col <= 3u) & 0xfffffu;
             u32 n0 = (u32)__popc(b0 & below), n1 = (u32)__popc(b1 & below), n2 = (u32)__popc(b2 & below), n3 = (u32)__popc(b3 & below);
             u32 nc = (u32)(((p0 - n0) << 21) <= kthi) + (u32)(((p1 - n1) << 21) <= kthi) + (u32)(((p2 - n2) << 21) <= kthi) +
                      (u32)(((p3 - n3) << 21) <= kthi);
-            bool changed = draw & (nc != col);
+            const u32 changed = hb(nc != col) & 0xfffffu;
             col = nc;
-            if (hb(changed) == 0u) break;                // the boards b0..b3 were taken from the colours that have just been confirmed
+            if (changed == 0u) break;                // the boards b0..b3 were taken from the colours that have just been confirmed
         }
-        const u32 e0 = b0, e1 = b1 & ~b0, e2 = b2 & ~b1, e3 = b3 & ~b2, e4 = 0xfffffu & ~b3;
+        u32 e0 = b0, e1 = b1 & ~b0, e2 = b2 & ~b1, e3 = b3 & ~b2, e4 = 0xfffffu & ~b3;
+        // (the five boards pass through an empty asm: otherwise each is computed inside a branch of the colour select below, which
+        // then becomes three nested divergent branches instead of four v_cndmask)
+        asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4));
         // display d receives draws 4d .. 4d+3: lane 5d + c counts those of colour c (:88)
         const u32 ec = k.pcol == 0u ? e0 : k.pcol == 1u ? e1 : k.pcol == 2u ? e2 : k.pcol == 3u ? e3 : e4;
         g.cs = l < 25u ? (u32)__popc((ec >> (4u * k.prow)) & 0xfu) : g.cs;

@@ -80,7 +80,9 @@ AZ_FN bool random_agent2(const Mask2 &m, Rng2 &r, const Tab2 &T, const K2 &k, u3
     const u32 mword = g5 ? m.m[5] : g4 ? m.m[4] : g3 ? m.m[3] : g2 ? m.m[2] : g1 ? m.m[1] : m.m[0];
     const u32 base = g5 ? p5 : g4 ? p4 : g3 ? p3 : g2 ? p2 : g1 ? p1 : 0u;
     const u32 prow_ = (u32)g1 + (u32)g2 + (u32)g3 + (u32)g4 + (u32)g5;
-    const bool hit = (((mword >> l) & 1u) != 0u) & ((u32)__popc(mword & ((1u << l) - 1u)) == want - base);
+    // my bit is set AND its rank among the word's set bits is the wanted one, as ONE compare (a ballot of an and of two compares goes
+    // through a 0 / 1 register): 2 (rank - wanted) + bit == 1
+    const bool hit = (((u32)__popc(mword & ((1u << l) - 1u)) - (want - base)) << 1) + ((mword >> l) & 1u) == 1u;
     const u32 ln = (u32)__builtin_ctz(hb(hit) | 0x80000000u);
     code = hbcast(k.lcode, ln) | (prow_ << 13) | ((30u * prow_ + ln) << 17);
     return true;

@@ -970,7 +970,9 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     const u32 mword = g5 ? m.m[5] : g4 ? m.m[4] : g3 ? m.m[3] : g2 ? m.m[2] : g1 ? m.m[1] : m.m[0];
     const u32 base = g5 ? p5 : g4 ? p4 : g3 ? p3 : g2 ? p2 : g1 ? p1 : 0u;
     const u32 prow_ = (u32)g1 + (u32)g2 + (u32)g3 + (u32)g4 + (u32)g5;
-    const bool hit = (((mword >> l) & 1u) != 0u) & ((u32)__popc(mword & ((1u << l) - 1u)) == want - base);
+    // my bit is set AND its rank among the word's set bits is the wanted one, as ONE compare (a ballot of an and of two compares goes
+    // through a 0 / 1 register): 2 (rank - wanted) + bit == 1
+    const bool hit = (((u32)__popc(mword & ((1u << l) - 1u)) - (want - base)) << 1) + ((mword >> l) & 1u) == 1u;
     const u32 who = hb(hit);
     const u32 ln = (u32)__builtin_ctz(who | 0x80000000u);
     // (display, colour) of the answering lane: ln = d + 6 c decoded arithmetically (K2::lcode holds the same as lane constants, but
@@ -1114,7 +1116,8 @@ AZ_FN u32 selfplay_rotated2(G2 &g, Prep2 &P, u32 first_player, const K2 &k, Rng2
         const u32 mword = g5 ? m5 : g4 ? m4 : g3 ? m3 : g2 ? m2 : g1 ? m1 : m0;
         const u32 base = g5 ? q5 : g4 ? q4 : g3 ? q3 : g2 ? q2 : g1 ? q1 : 0u;
         const u32 prow_ = (u32)g1 + (u32)g2 + (u32)g3 + (u32)g4 + (u32)g5;
-        const bool hit = (((mword >> l) & 1u) != 0u) & ((u32)__popc(mword & ((1u << l) - 1u)) == want - base);
+        // (selfplay_step2's single compare)
+        const bool hit = (((u32)__popc(mword & ((1u << l) - 1u)) - (want - base)) << 1) + ((mword >> l) & 1u) == 1u;
         const u32 who = hb(hit);
         const u32 ln = (u32)__builtin_ctz(who | 0x80000000u);
         const u32 code = hbcast(k.lcode, ln) | (prow_ << 13) | ((30u * prow_ + ln) << 17);

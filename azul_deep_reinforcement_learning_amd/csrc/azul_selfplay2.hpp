@@ -30,7 +30,19 @@ using namespace az;
 
 AZ_FN u32 wlane() { return wv::lane(); }
 AZ_FN bool upper() { return (wlane() & 32u) != 0u; }
+// my half's word of a wave ballot.  The select becomes ONE v_lshrrev_b64 by (lane & 32): a quarter-rate instruction (~8 cycles of the pipe),
+// but the kernel is bound by the number of instructions a wave issues, not by pipe cycles -- the two full-rate instructions of
+// (lo & mlo) | (hi & mhi) with per-lane masks measured 4.6 % SLOWER (-DAZ2_HSEL_MASKS, round 3)
+#if defined(AZ2_HSEL_MASKS)
+AZ_FN u32 hsel(u64 b)
+{
+    u32 mhi = 0u - (wlane() >> 5), mlo = (wlane() >> 5) - 1u;
+    asm("" : "+v"(mhi), "+v"(mlo));
+    return ((u32)b & mlo) | ((u32)(b >> 32) & mhi);
+}
+#else
 AZ_FN u32 hsel(u64 b) { return upper() ? (u32)(b >> 32) : (u32)b; }
+#endif
 // the half's 32 lanes as a bitboard
 AZ_FN u32 hb(bool p) { return hsel(__builtin_amdgcn_ballot_w64(p)); }
 // value of lane `idx` of MY half, idx per lane (a gather through the LDS crossbar; idx in 0..31)

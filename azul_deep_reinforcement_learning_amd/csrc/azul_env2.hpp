@@ -73,7 +73,7 @@ AZ_FN bool random_agent2(const Mask2 &m, Rng2 &r, const Tab2 &T, const K2 &k, u3
     const u32 fl = (u32)d;
     const double fr = d - (double)fl;
     u32 kg = J + fl + 1u;
-    const bool edge = (x < sJ) | !(fr > 1e-9 && fr < 1.0 - 1e-9) | (fl + 1u > M);
+    const bool edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (fl + 1u > M);
     if (AZ_UNLIKELY(edge)) kg = sample_slow2(T, x, sJ, J, M, L);
     const u32 want = kg - 1u;
     const bool g1 = want >= p1, g2 = want >= p2, g3 = want >= p3, g4 = want >= p4, g5 = want >= p5;

@@ -950,7 +950,10 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     u32 fl = (u32)d;
     double fr = d - (double)fl;
     u32 kg = J + fl + 1u;
-    bool edge = (x < sJ) | !(fr > 1e-9 && fr < 1.0 - 1e-9) | (fl + 1u > M);
+    // "x is not safely inside a pattern move's unit interval": fr within 1e-9 of 0 or 1 as ONE compare, |fr - 0.5| >= 0.5 - 1e-9 (the
+    // subtraction's rounding, 2^-54, is far inside the margin; the slow path gives the fast path's answer wherever both apply).  x < S[J]
+    // (inside the floor moves) needs no test of its own: then -1 < d < 0, fl == 0 and fr == d < 0.
+    bool edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (fl + 1u > M);
     r.pos += (hard | nomove) ? 0u : 2u;
     // ONE test for everything unusual about this decision (a random() that crosses a regeneration, a draw at a boundary of the
     // cumulative weights, nothing legal); the stuck slot itself is restarted further down
@@ -970,7 +973,7 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
             x = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0) * total;
             d = x - sJ; fl = (u32)d; fr = d - (double)fl;
             kg = J + fl + 1u;
-            edge = (x < sJ) | !(fr > 1e-9 && fr < 1.0 - 1e-9) | (fl + 1u > M);
+            edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (fl + 1u > M);
         }
         if (edge & !nomove) kg = sample_slow2(T, x, sJ, J, M, L);
         any_nomove = wave_any(nomove);
@@ -1093,7 +1096,7 @@ AZ_FN u32 selfplay_rotated2(G2 &g, Prep2 &P, u32 first_player, const K2 &k, Rng2
     const double d = x - P.sJ;
     const u32 fl = (u32)d;
     const double fr = d - (double)fl;
-    const bool edge = (x < P.sJ) | !(fr > 1e-9 && fr < 1.0 - 1e-9) | (fl + 1u > P.M);
+    const bool edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (fl + 1u > P.M);
     const bool general = wave_any(P.unusual | edge | (g.over != 0u));
     u32 ret = 0;
     if (AZ_UNLIKELY(general)) {

@@ -807,12 +807,13 @@ AZ_FN void store_mask_row2(const Out2 &o, u32 m0, u32 m1, u32 m2, u32 m3, u32 m4
     if (PAD) {
         // the 180 bits as six dwords (the 30-bit row words back to back); lane j's eight bits are byte j & 3 of dword j >> 2 -- a
         // byte-aligned field, picked with lane-constant masks (no lane-dependent control flow) and one bit-field extract
-        const u32 D0 = m0 | (m1 << 30), D1 = (m1 >> 2) | (m2 << 28), D2 = (m2 >> 4) | (m3 << 26), D3 = (m3 >> 6) | (m4 << 24),
-                  D4 = (m4 >> 8) | (m5 << 22), D5 = m5 >> 10;
-        const u32 j = l < 22u ? l : 22u, ds = j >> 2;
-        const u32 M0 = ds == 0u ? ~0u : 0u, M1 = ds == 1u ? ~0u : 0u, M2 = ds == 2u ? ~0u : 0u, M3 = ds == 3u ? ~0u : 0u, M4 = ds == 4u ? ~0u : 0u,
-                  M5 = ds == 5u ? ~0u : 0u;
-        const u32 D = (D0 & M0) | (D1 & M1) | (D2 & M2) | (D3 & M3) | (D4 & M4) | (D5 & M5);
+        u32 D0 = m0 | (m1 << 30), D1 = (m1 >> 2) | (m2 << 28), D2 = (m2 >> 4) | (m3 << 26), D3 = (m3 >> 6) | (m4 << 24),
+            D4 = (m4 >> 8) | (m5 << 22), D5 = m5 >> 10;
+        const u32 j = l < 22u ? l : 22u;
+        // five v_cndmask on lane-constant conditions (the dwords pass through an empty asm: otherwise each is computed inside a branch of
+        // the select, which turns into nested divergent branches)
+        asm volatile("" : "+v"(D0), "+v"(D1), "+v"(D2), "+v"(D3), "+v"(D4), "+v"(D5));
+        const u32 D = j < 4u ? D0 : j < 8u ? D1 : j < 12u ? D2 : j < 16u ? D3 : j < 20u ? D4 : D5;
         const u32 by = (D >> (8u * (j & 3u))) & 0xffu;
         const u32 lo = ((by & 15u) * 0x00204081u) & 0x01010101u, hi = ((by >> 4) * 0x00204081u) & 0x01010101u;
         *(u64 *)(o.mask + (o.e * o.pitch + 8u * j)) = (u64)lo | ((u64)hi << 32);
@@ -954,13 +955,14 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     // subtraction's rounding, 2^-54, is far inside the margin; the slow path gives the fast path's answer wherever both apply).  x < S[J]
     // (inside the floor moves) needs no test of its own: then -1 < d < 0, fl == 0 and fr == d < 0.
     bool edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (fl + 1u > M);
-    r.pos += (hard | nomove) ? 0u : 2u;
+    r.pos += 2u;                                             // (taken back in the block below when no random() was consumed here)
     // ONE test for everything unusual about this decision (a random() that crosses a regeneration, a draw at a boundary of the
     // cumulative weights, nothing legal); the stuck slot itself is restarted further down
     // (a wave-uniform test -- vector compare, VCC, scalar branch -- costs ~33 cycles even when it falls through, tools/pattern_cost.hip:
     // "nothing legal" rides on this one, and the stuck-slot block below branches on a flag that is already scalar)
     bool any_nomove = false;
     if (AZ_UNLIKELY(wave_any(hard | edge | nomove))) {
+        r.pos -= (hard | nomove) ? 2u : 0u;
         if (hard & !nomove) {
             // CPython's index is 623 (the first word is the last of this state) or 624: regenerate, then read the tempered copy
             const bool one = r.pos == 623u;

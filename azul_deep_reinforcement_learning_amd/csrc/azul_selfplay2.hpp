@@ -464,9 +464,11 @@ struct Score2 { u32 val, pos; u32 rowdone, colordone, coldone; };
 
 AZ_FN u32 run_length2(u32 bits, u32 pos)
 {
-    u32 up = (u32)__builtin_ctz(~(bits >> pos));
-    u32 below = ~bits & ((1u << pos) - 1u);
-    u32 down = below != 0u ? pos + (u32)__builtin_clz(below | 1u) - 32u : pos;
+    // ones at and above pos, plus the ones directly below it: the highest ZERO below pos decides; a sentinel bit under the shifted
+    // zero map makes "no zero below" the same formula (no compare + select around count-leading-zeros of 0)
+    const u32 up = (u32)__builtin_ctz(~(bits >> pos));
+    const u32 below = ~bits & ((1u << pos) - 1u);
+    const u32 down = pos + (u32)__builtin_clz((below << 1) | 1u) - 31u;
     return up + down;
 }
 
@@ -480,7 +482,7 @@ AZ_FN void score2(u32 w /* per lane: the wall the placement is priced against */
     u32 v = (((t & 0x108421u) * 0x111110u) >> 20) & 31u;
     u32 vr = run_length2(v, k.prow);                                   // :244-257
     u32 both = hr + vr;
-    s.pos = (hr == 1u && vr == 1u) ? 1u : ((hr > 1u && vr > 1u) ? both : both - 1u);     // :258-263
+    s.pos = both - ((hr < vr ? hr : vr) > 1u ? 0u : 1u);                                  // :258-263 (1 + 1 - 1 is the lone tile's point)
     bool rd = rowbits == 31u, cd = ((w >> k.pcol) & 0x108421u) == 0x108421u, kd = v == 31u;
     s.val = s.pos + (rd ? 2u : 0u) + (cd ? 10u : 0u) + (kd ? 7u : 0u);                    // :266-288
     s.rowdone = hb(rd); s.colordone = hb(cd); s.coldone = hb(kd);

@@ -100,7 +100,7 @@ template <bool LID>
 AZ_FN u32 apply_step2(G2 &g, u32 code, Rng2 &r, u64 margin, const K2 &k)
 {
     const u32 me = me2(g);
-    const bool filled = do_move2<LID>(g, code, g.B, k.l);               // azul.py:304
+    const bool filled = do_move2<LID>(g, code, g.B, k);               // azul.py:304
     g.B = hb(g.cs != 0u) & 0x7fffffffu;
     const bool eor = g.B == 0u;                                        // :306 (then count_score2 prices the lines for real and clears the cache)
     i32 wc = me ? g.wc1 : g.wc0;

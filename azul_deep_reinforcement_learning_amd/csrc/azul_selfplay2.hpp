@@ -54,6 +54,8 @@ AZ_FN u32 hread(u32 v, u32 idx) { return (u32)__builtin_amdgcn_ds_bpermute((int)
 // the same for a HALF-UNIFORM idx.  (Measured: the LDS crossbar beats a v_readlane pair per half + select -- two instructions and one
 // wait against seven instructions with SGPR hazards: 1.125 vs 1.195 ms per 512-move launch.)
 AZ_FN u32 hbcast(u32 v, u32 idx) { return hread(v, idx); }
+// the same with the half's byte offset handed in (K2::h4): one address instruction instead of two
+AZ_FN u32 hread4(u32 v, u32 idx, u32 h4) { return (u32)__builtin_amdgcn_ds_bpermute((int)((idx << 2) | h4), (int)v); }
 template <u32 IDX>
 AZ_FN u32 hbcast_c(u32 v)
 {
@@ -113,12 +115,15 @@ struct K2 {
     u32 lcode;           // (d, c) decoded once, LaneConst::acode's packing without row and action number
     u32 rowp1;           // l < 25: row + 1, else 0xff
     u32 prow, pcol, pbcol, pbelow, pcolboard;      // pattern cell l < 25: row, colour, board column, bits 0..l, cells of that board column
+    u32 h4;              // byte offset of my half in a ds_bpermute address: (lane & 32) << 2
 };
 
 AZ_FN void k2_init(K2 &k)
 {
     const u32 l = wlane() & 31u;
     k.l = l;
+    k.h4 = (wlane() & 32u) << 2;
+    asm volatile("" : "+v"(k.h4));     // opaque: (idx << 2) | h4 stays ONE v_lshl_or_b32 (else it is re-associated into or + shift)
     {
         const u32 d = l % 6u, c = l / 6u;
         const u32 sp = d == 0u ? c + 25u : (d - 1u) * 5u + c;
@@ -410,15 +415,16 @@ AZ_FN u32 sample_slow2(const Tab2 &T, double x, double sJ, u32 J, u32 M, u32 L)
 
 // ---- move: azul.py:118-161.  Returns whether the targeted pattern line is full afterwards ------------------------------------
 template <bool LID>
-AZ_FN bool do_move2f(G2 &g, u32 src, u32 db, u32 c, u32 row, bool from_display, u32 B /* sources before the move */, u32 l)
+AZ_FN bool do_move2f(G2 &g, u32 src, u32 db, u32 c, u32 row, bool from_display, u32 B /* sources before the move */, const K2 &k)
 {
+    const u32 l = k.l;
     const u32 me = me2(g);
     // the three cell gathers of a move depend on the chosen action only: requested together (ONE LDS round trip on the move's chain)
     const u32 cell = 5u * ((row ? row : 1u) - 1u) + c;
     u32 mine = me ? g.cp1 : g.cp0;
-    u32 n = hbcast(g.cs, src);                                         // :127 / :136
-    const u32 moved = hread(g.cs, l - 25u + db);                       // :131
-    const u32 old = hbcast(mine, cell);
+    u32 n = hread4(g.cs, src, k.h4);                                   // :127 / :136
+    const u32 moved = hread4(g.cs, l - 25u + db, k.h4);                // :131
+    const u32 old = hread4(mine, cell, k.h4);
 #if defined(AZ2_EXPERIMENT_EXTRA_LDS)
     n = hread(n, l);                                                   // TIMING EXPERIMENT: one more dependent LDS round trip (identity)
 #endif
@@ -454,9 +460,9 @@ AZ_FN bool do_move2f(G2 &g, u32 src, u32 db, u32 c, u32 row, bool from_display, 
 }
 
 template <bool LID>
-AZ_FN bool do_move2(G2 &g, u32 code, u32 B /* sources before the move */, u32 l)
+AZ_FN bool do_move2(G2 &g, u32 code, u32 B /* sources before the move */, const K2 &k)
 {
-    return do_move2f<LID>(g, code & 31u, (code >> 5) & 31u, (code >> 10) & 7u, (code >> 13) & 7u, ((code >> 16) & 1u) != 0u, B, l);
+    return do_move2f<LID>(g, code & 31u, (code >> 5) & 31u, (code >> 10) & 7u, (code >> 13) & 7u, ((code >> 16) & 1u) != 0u, B, k);
 }
 
 // ---- wall pricing: azul_core.hpp's score_boards for one player in lanes 0..24 --------------------------------------------
@@ -1016,7 +1022,7 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     }
     if (!nomove) {
         const u32 me = me2(g);
-        const bool filled = do_move2f<LID>(g, a_src, a_db, ac, prow_, a_disp, m.B, l);    // azul.py:304
+        const bool filled = do_move2f<LID>(g, a_src, a_db, ac, prow_, a_disp, m.B, k);    // azul.py:304
         g.moves += 1u;
         AZ_STAMP(SEG_MOVE);
         g.B = hb(g.cs != 0u) & 0x7fffffffu;                      // the sources after the move (next move's mask reads it)
@@ -1143,7 +1149,7 @@ AZ_FN u32 selfplay_rotated2(G2 &g, Prep2 &P, u32 first_player, const K2 &k, Rng2
         a = (i32)(code >> 17);
         AZ_STAMP(SEG_SAMPLE);
         me = me2(g);
-        filled = do_move2<LID>(g, code, P.B, l);                 // azul.py:304
+        filled = do_move2<LID>(g, code, P.B, k);                 // azul.py:304
         g.moves += 1u;
         AZ_STAMP(SEG_MOVE);
         g.B = hb(g.cs != 0u) & 0x7fffffffu;

@@ -614,14 +614,10 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
 #if !defined(AZ2_ROTATED_LOOP)    // default: one selfplay_step2 per move; -DAZ2_ROTATED_LOOP: the rotated loop (measured 2 % slower)
     // A uniform counted loop (scalar loop control: a per-game `break` costs ~16 exec-mask instructions per move).  A game stopped by a
     // rule error (box and lid empty when a round has to be dealt: crafted states only) stays as it is: its lanes skip the later moves.
-    bool dead = false;
-    bool bail = false;
+    bool dead = false;               // (set inside the rare blocks only: the common path carries no test for it)
 #pragma unroll 1
     for (int s = 0; s < t.n_steps; s++) {
-        if (!dead) {
-            const u32 f = az2::selfplay_step2<LID, OUT, PAD, BITS>(g, b.rules.first_player, k, r, tab, margin, cnt, o, pp, bail);
-            dead = (f & 0x100u) != 0u;
-        }
+        if (!dead) az2::selfplay_step2<LID, OUT, PAD, BITS>(g, b.rules.first_player, k, r, tab, margin, cnt, o, pp, dead);
         o.e += b.n;
     }
 #else

@@ -839,7 +839,7 @@ struct Counters2 { u64 *episodes; u32 *stuck; double *stat_sum; };
 // player or end of round (scoring, end of game, next round), shaped reward, outputs, episode statistics and reset.
 template <bool LID, int OUT>
 AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin, const Counters2 &cnt, const Out2 &o, u32 me, bool filled,
-                      i32 a, SegProf *prof_, bool &bail /* wave-uniform: set when a rule error stopped one of the two games */)
+                      i32 a, SegProf *prof_, bool &dead /* per game, only ever set: a rule error stopped it (set in the rare blocks: nothing on the common path) */)
 {
     (void)prof_;
     const u32 l = k.l;
@@ -874,7 +874,7 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
         if (eor & !g.over) st = new_round2<LID>(g, r, margin, k);      // :311
         AZ_STAMP(SEG_NEWROUND);
         any_done = wave_any((g.over != 0u) & (st == ST_OK));
-        bail |= wave_any(st != ST_OK);
+        dead |= st != ST_OK;
     }
     const i32 phi = g.wi0 - g.wi1;
     const i32 reward = phi - g.pscore;
@@ -894,7 +894,7 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
             u32 st2 = episode_reset2<LID>(g, first_player, r, margin, k);     // GameRunner.reset(): Azul(rules) ... new_round()
             if (st2) ret = 0x100u | st2;
         }
-        bail |= wave_any((ret & 0x100u) != 0u);
+        dead |= (ret & 0x100u) != 0u;
         AZ_STAMP(SEG_RESET);
     }
     return ret;
@@ -908,7 +908,7 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
 // for the whole wave with one scalar branch (wave_any, hinted unlikely -> placed out of line) and handled per half inside.
 template <bool LID, int OUT, bool PAD, bool BITS>
 AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Tab2 &T, u64 margin, const Counters2 &cnt, const Out2 &o,
-                        SegProf *prof_, bool &bail /* wave-uniform, only ever set: a rule error stopped one of the two games in this move */)
+                        SegProf *prof_, bool &dead /* per game, only ever set: a rule error stopped it in this move */)
 {
     (void)prof_;
     AZ_STAMP(SEG_LOOP);
@@ -1020,7 +1020,7 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
             u32 st0 = episode_reset2<LID>(g, first_player, r, margin, k);
             ret = st0 ? (0x100u | st0) : 2u;
         }
-        bail |= wave_any((ret & 0x100u) != 0u);
+        dead |= (ret & 0x100u) != 0u;
         AZ_STAMP(SEG_RESET);
     }
     if (!nomove) {
@@ -1029,7 +1029,7 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
         g.moves += 1u;
         AZ_STAMP(SEG_MOVE);
         g.B = hb(g.cs != 0u) & 0x7fffffffu;                      // the sources after the move (next move's mask reads it)
-        ret = after_move2<LID, OUT>(g, first_player, k, r, margin, cnt, o, me, filled, a, prof_, bail);
+        ret = after_move2<LID, OUT>(g, first_player, k, r, margin, cnt, o, me, filled, a, prof_, dead);
     }
     return ret;
 }
@@ -1101,7 +1101,7 @@ AZ_FN u32 selfplay_rotated2(G2 &g, Prep2 &P, u32 first_player, const K2 &k, Rng2
 {
     (void)prof_;
     const u32 l = k.l;
-    bool bail = false;           // (this loop keeps the per-game exit on the returned status)
+    bool dead = false;           // (this loop keeps the per-game exit on the returned status)
     // Control flow: a SEQUENCE of wave-uniform if-blocks without else branches or early exits (the loop around this function has a
     // per-game exit, so its body is structurised as a whole: nested if / else with the whole game state live turned into chains of
     // flow blocks with ~100 register copies per move; a sequence of if-blocks joins without copies on the common path).
@@ -1115,7 +1115,7 @@ AZ_FN u32 selfplay_rotated2(G2 &g, Prep2 &P, u32 first_player, const K2 &k, Rng2
     u32 ret = 0;
     if (AZ_UNLIKELY(general)) {
         // [1] the whole move the general way for both games of the wave (nothing has been changed yet), then a fresh preparation
-        ret = selfplay_step2<LID, OUT, PAD, BITS>(g, first_player, k, r, T, margin, cnt, o, prof_, bail);
+        ret = selfplay_step2<LID, OUT, PAD, BITS>(g, first_player, k, r, T, margin, cnt, o, prof_, dead);
         prepare2(g, k, r, T, P);
     }
     u32 me = 0;
@@ -1161,7 +1161,7 @@ AZ_FN u32 selfplay_rotated2(G2 &g, Prep2 &P, u32 first_player, const K2 &k, Rng2
     const bool round_over = !general & wave_any(g.B == 0u);
     if (AZ_UNLIKELY(round_over)) {
         // [3] a round (perhaps a game) ends in at least one of the two games: the general tail for both, a fresh preparation
-        ret = after_move2<LID, OUT>(g, first_player, k, r, margin, cnt, o, me, filled, a, prof_, bail);
+        ret = after_move2<LID, OUT>(g, first_player, k, r, margin, cnt, o, me, filled, a, prof_, dead);
         prepare2(g, k, r, T, P);
     }
     if (!general & !round_over) {

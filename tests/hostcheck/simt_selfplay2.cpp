@@ -59,12 +59,9 @@ static void wave_body(WaveJob *j)
     az2::Out2 o = {j->mask, j->maskbits, j->action, j->reward, j->done, j->packed, j->rec, j->pitch, gi,
                    l == 0u ? (u32 *)j->action : (l == 1u ? (u32 *)j->reward : j->packed)};
     if (!j->rotated) {
-        bool dead = false, bail = false;
+        bool dead = false;
         for (int s = 0; s < j->n_steps; s++) {
-            if (!dead) {
-                const u32 f = az2::selfplay_step2<LID, OUT, PAD, BITS>(g, j->first_player, k, r, tab, j->margin, cnt, o, nullptr, bail);
-                dead = (f & 0x100u) != 0u;
-            }
+            if (!dead) az2::selfplay_step2<LID, OUT, PAD, BITS>(g, j->first_player, k, r, tab, j->margin, cnt, o, nullptr, dead);
             o.e += j->n;
         }
     } else {

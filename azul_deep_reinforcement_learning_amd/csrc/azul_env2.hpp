@@ -111,7 +111,7 @@ AZ_FN u32 apply_step2(G2 &g, u32 code, Rng2 &r, u64 margin, const K2 &k)
     const i32 wi = clamp0((me ? g.score1 : g.score0) + floor_penalty(me ? g.floor1 : g.floor0) + wc);
     g.wc0 = me ? g.wc0 : wc; g.wc1 = me ? wc : g.wc1;
     g.wi0 = me ? g.wi0 : wi; g.wi1 = me ? wi : g.wi1;
-    g.cur = eor ? g.cur : (g.cur < 2u ? g.cur + 1u : 1u);              // :313
+    g.cur = eor ? g.cur : (g.cur & 1u) + 1u;              // :313
     u32 st = ST_OK;
     // (rare events are tested per wave and kept out of line: two waves per SIMD cannot hide a taken branch's instruction refetch)
     if (AZ_UNLIKELY(wave_any(eor))) {

@@ -858,7 +858,7 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
     const i32 wi = clamp0((me ? g.score1 : g.score0) + floor_penalty(me ? g.floor1 : g.floor0) + wc);
     g.wc0 = me ? g.wc0 : wc; g.wc1 = me ? wc : g.wc1;
     g.wi0 = me ? g.wi0 : wi; g.wi1 = me ? wi : g.wi1;
-    g.cur = eor ? g.cur : (g.cur < 2u ? g.cur + 1u : 1u);    // :313 next_player
+    g.cur = eor ? g.cur : (g.cur & 1u) + 1u;    // :313 next_player
     u32 st = ST_OK;
     AZ_STAMP(SEG_AFTERMOVE);
     // (ONE wave-uniform test for the end of a round and for a game that is over -- a test costs ~33 cycles even when it falls through;
@@ -1166,7 +1166,7 @@ AZ_FN u32 selfplay_rotated2(G2 &g, Prep2 &P, u32 first_player, const K2 &k, Rng2
     }
     if (!general & !round_over) {
         // [4] nobody's round ended: next player, then two independent instruction streams in one block --
-        g.cur = g.cur < 2u ? g.cur + 1u : 1u;                    // :313 next_player
+        g.cur = (g.cur & 1u) + 1u;                    // :313 next_player
         // (a) the loop-carried stream: the decision of move t + 1 up to its two LDS requests
         PrepLoads2 q;
         prepare2_request(g, k, r, T, P, q);

@@ -148,8 +148,13 @@ struct G2 {
     u32 cs, cp0, cp1;
     u32 wall0, wall1, floor0, floor1;
     i32 score0, score1;
-    u32 cur, nfp, eog, turn, fps, fpen, maxc;
-    u64 box, lid, compl_;
+    u32 cur, nfp, eog, turn, fps;
+    // statistics, one register per player (packed into the record's bytes by g2_store only: scoring adds to them as they are)
+    i32 fp0, fp1;               // floor_penalty[p], low 16 bits stored
+    u32 mc0, mc1;               // max_combo[p], low byte stored
+    u32 cl0, cl1;               // completed_lines[p][0..2], one byte each (24 bits stored)
+    u64 box, lid;
+    u32 lidp;                   // per lane: tiles of colour l (< 5) that scoring has returned to the lid since the last fold (lid_fold2)
     i32 pscore;
     u32 moves;
     i32 wc0, wc1, wi0, wi1;     // what-if cache (game_runner.py:48-50), see azul_core.hpp
@@ -180,15 +185,18 @@ AZ_FN void g2_load(G2 &g, const uint8_t *rec, u32 l)
     g.lid = (u64)(w4 >> 8) | ((u64)(w5 & 0xffffu) << 24);
     g.turn = w5 >> 16;
     g.fps = hread(t, 6);
-    g.fpen = hread(t, 7);
+    { const u32 fpen = hread(t, 7); g.fp0 = (i32)(int16_t)(fpen & 0xffffu); g.fp1 = (i32)(int16_t)(fpen >> 16); }
     u32 w8 = hread(t, 8), w9 = hread(t, 9), w10 = hread(t, 10);
-    g.maxc = w8 & 0xffffu;
-    g.compl_ = (u64)(w8 >> 16) | ((u64)w9 << 16);
+    g.mc0 = w8 & 0xffu; g.mc1 = (w8 >> 8) & 0xffu;
+    g.cl0 = (w8 >> 16) | ((w9 & 0xffu) << 16); g.cl1 = w9 >> 8;
     g.pscore = (i32)(int16_t)(w10 & 0xffffu);
     g.moves = w10 >> 16;
     g.wc0 = g.wc1 = 0; g.wi0 = g.wi1 = 0; g.over = 0;
+    g.lidp = 0;
     g.B = hb(g.cs != 0u) & 0x7fffffffu;
 }
+
+AZ_FN u64 lid_fold2(u32 lidp, u32 l);
 
 AZ_FN void g2_store(const G2 &g, uint8_t *rec, u32 l)
 {
@@ -200,17 +208,18 @@ AZ_FN void g2_store(const G2 &g, uint8_t *rec, u32 l)
     if (l < 25u) rec[57u + l] = (uint8_t)g.cp1;
     if (l == 25u) rec[82] = (uint8_t)g.floor0;
     if (l == 26u) rec[83] = (uint8_t)g.floor1;
+    const u64 lid = g.lid + lid_fold2(g.lidp, l);        // (the tally scoring keeps per lane, folded into the record's bytes)
     u32 t = 0;
     t = l == 0u ? g.wall0 : t;
     t = l == 1u ? g.wall1 : t;
     t = l == 2u ? (((u32)g.score0 & 0xffffu) | ((u32)g.score1 << 16)) : t;
     t = l == 3u ? (u32)g.box : t;
-    t = l == 4u ? ((u32)((g.box >> 32) & 0xffu) | ((u32)g.lid << 8)) : t;
-    t = l == 5u ? ((u32)((g.lid >> 24) & 0xffffu) | (g.turn << 16)) : t;
+    t = l == 4u ? ((u32)((g.box >> 32) & 0xffu) | ((u32)lid << 8)) : t;
+    t = l == 5u ? ((u32)((lid >> 24) & 0xffffu) | (g.turn << 16)) : t;
     t = l == 6u ? g.fps : t;
-    t = l == 7u ? g.fpen : t;
-    t = l == 8u ? ((g.maxc & 0xffffu) | ((u32)(g.compl_ & 0xffffu) << 16)) : t;
-    t = l == 9u ? (u32)(g.compl_ >> 16) : t;
+    t = l == 7u ? (((u32)g.fp0 & 0xffffu) | ((u32)g.fp1 << 16)) : t;
+    t = l == 8u ? ((g.mc0 & 0xffu) | ((g.mc1 & 0xffu) << 8) | (g.cl0 << 16)) : t;
+    t = l == 9u ? (((g.cl0 >> 16) & 0xffu) | (g.cl1 << 8)) : t;
     t = l == 10u ? (((u32)g.pscore & 0xffffu) | (g.moves << 16)) : t;
     if (l < 11u) ((u32 *)(rec + 84))[l] = t;
 }
@@ -520,21 +529,26 @@ AZ_FN void prime2(G2 &g, const K2 &k)
     g.ok1 = ok_board2(g.cp1, g.wall1, k);
 }
 
-// Σ_r r * [line (r, c) is full] for the five colours, as the byte vector the lid receives (azul.py:220-222): lane c sums its colour
-// (rows 1, 3 weigh one bit, rows 2, 3 two, row 4 four), lanes 0..3 are packed into the low word with two DPP steps
-AZ_FN u64 lid_return2(u32 F, u32 l)
+// Σ_r r * [line (r, c) is full] for my colour c = l (< 5): the tiles the lid receives (azul.py:220-222; rows 1, 3 weigh one bit, rows 2, 3
+// two, row 4 four).  Scoring only ADDS this to a per-lane tally (G2::lidp); the byte vector the record holds is formed when the lid is
+// looked at -- a round that starts with an empty box, a record store -- by lid_fold2: lanes 0..3 are packed into the low word with two
+// DPP steps, lane 4 is the fifth byte (two cross-lane broadcasts that a round end no longer pays for).
+AZ_FN u32 lid_tally2(u32 F, u32 l)
 {
     const u32 t = (F >> (l < 5u ? l : 0u)) & 0x108421u;                      // bits 5 r of colour l
-    u32 s = (u32)__popc(t & 0x8020u) + 2u * (u32)__popc(t & 0x8400u) + 4u * (u32)__popc(t & 0x100000u);
-    u32 v = l < 4u ? s << (8u * l) : 0u;
-    v |= dpp0<0x111, 0xf>(v);                                               // row_shr:1
-    v |= dpp0<0x112, 0xf>(v);                                               // row_shr:2  -> lane 3 holds bytes 0..3
-    return (u64)hbcast_c<3>(v) | ((u64)hbcast_c<4>(s) << 32);
+    return (u32)__popc(t & 0x8020u) + 2u * (u32)__popc(t & 0x8400u) + 4u * (u32)__popc(t & 0x100000u);
+}
+AZ_FN u64 lid_fold2(u32 lidp, u32 l)
+{
+    u32 v = l < 4u ? lidp << (8u * l) : 0u;
+    v += dpp0<0x111, 0xf>(v);                                               // row_shr:1
+    v += dpp0<0x112, 0xf>(v);                                               // row_shr:2  -> lane 3 holds bytes 0..3 (sums below 256 each)
+    return (u64)hbcast_c<3>(v) | ((u64)hbcast_c<4>(lidp) << 32);
 }
 
 // count_wall + count_floor for one player (azul.py:200-290), committed
 template <bool LID>
-AZ_FN void count_player2(u32 &wall, u32 &cp, u32 &floor_, i32 &score, u32 &maxc8, u32 &compl24, i32 &fpen16, u64 &lid, const K2 &k)
+AZ_FN void count_player2(u32 &wall, u32 &cp, u32 &floor_, i32 &score, u32 &maxc8, u32 &compl24, i32 &fpen16, u32 &lidp, const K2 &k)
 {
     // (no "any full line?" branch: with F == 0 every term below is zero, and without the branch the two players' chains sit in ONE
     // basic block, where the scheduler interleaves them -- the kernel is bound by dependent-issue latency)
@@ -545,7 +559,7 @@ AZ_FN void count_player2(u32 &wall, u32 &cp, u32 &floor_, i32 &score, u32 &maxc8
     const i32 cnt = (i32)hsum(on ? s.val : 0u);                                        // :289
     maxc8 = umax(maxc8, hmax(on ? s.pos : 0u));                                        // :264
     compl24 += (u32)__popc(s.rowdone & F) + ((u32)__popc(s.colordone & F) << 8) + ((u32)__popc(s.coldone & F) << 16);   // :270,:278,:286
-    if (LID) lid += lid_return2(F, k.l);                                                    // :220-222
+    if (LID) lidp += lid_tally2(F, k.l);                                                    // :220-222
     wall |= F;                                                                         // :219
     cp = (cp == k.rowp1) ? 0u : cp;                                                    // :218
     i32 pen = floor_penalty(floor_);
@@ -557,15 +571,9 @@ AZ_FN void count_player2(u32 &wall, u32 &cp, u32 &floor_, i32 &score, u32 &maxc8
 template <bool LID>
 AZ_FN void count_score2(G2 &g, const K2 &k)
 {
-    u32 mc0 = g.maxc & 0xffu, mc1 = (g.maxc >> 8) & 0xffu;
-    u32 cl0 = (u32)g.compl_ & 0xffffffu, cl1 = (u32)(g.compl_ >> 24) & 0xffffffu;
-    i32 fp0 = (i32)(int16_t)(g.fpen & 0xffffu), fp1 = (i32)(int16_t)(g.fpen >> 16);
-    count_player2<LID>(g.wall0, g.cp0, g.floor0, g.score0, mc0, cl0, fp0, g.lid, k);
-    count_player2<LID>(g.wall1, g.cp1, g.floor1, g.score1, mc1, cl1, fp1, g.lid, k);
-    g.maxc = (mc0 & 0xffu) | ((mc1 & 0xffu) << 8);
-    // byte-wise counters (no carries between them in the reference's floats either: each stays below 256 for real games)
-    g.compl_ = (u64)(cl0 & 0xffffffu) | ((u64)(cl1 & 0xffffffu) << 24);
-    g.fpen = ((u32)fp0 & 0xffffu) | (((u32)fp1 & 0xffffu) << 16);
+    count_player2<LID>(g.wall0, g.cp0, g.floor0, g.score0, g.mc0, g.cl0, g.fp0, g.lidp, k);
+    count_player2<LID>(g.wall1, g.cp1, g.floor1, g.score1, g.mc1, g.cl1, g.fp1, g.lidp, k);
+    // (byte-wise counters: no carries between them in the reference's floats either -- each stays below 256 for real games)
     g.wc0 = g.wc1 = 0; g.wi0 = g.score0; g.wi1 = g.score1;
     g.over = (any_row_full(g.wall0) | any_row_full(g.wall1)) ? 1u : 0u;
     g.ok0 = ok_board2(g.cp0, g.wall0, k);                // walls and lines changed
@@ -606,7 +614,7 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
     if ((g.box & 0xffffffffffull) == 0ull) {
         // the box is empty when the round starts: the first draw refills it from the lid (:81-83) -- done here, so that the
         // whole round can take the parallel path below (no random number is involved: random.choices raises before random())
-        g.box = g.lid; g.lid = 0;
+        g.box = g.lid + lid_fold2(g.lidp, l); g.lid = 0; g.lidp = 0;
         if ((g.box & 0xffffffffffull) == 0ull) return ST_BOX_EMPTY;
     }
     // prefix sums of the box: p_c = box_0 + .. + box_c (c < 4), T0 = all five
@@ -685,7 +693,7 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
     for (u32 t = 0; t < 20u; t++) {
         u32 total = (u32)(P >> 32) & 0xffu;
         if (total == 0u) {                                                           // :81-83, :85
-            g.box = g.lid; g.lid = 0;
+            g.box = g.lid + lid_fold2(g.lidp, l); g.lid = 0; g.lidp = 0;
             P = ((g.box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;
             total = (u32)(P >> 32) & 0xffu;
             if (total == 0u) return ST_BOX_EMPTY;
@@ -729,13 +737,14 @@ AZ_FN u32 episode_reset2(G2 &g, u32 first_player, Rng2 &r, u64 margin, const K2 
     g.cs = 0; g.cp0 = 0; g.cp1 = 0;
     g.wall0 = g.wall1 = 0; g.score0 = g.score1 = 0; g.floor0 = g.floor1 = 0;
     g.cur = 0; g.eog = 0; g.turn = 0;
-    g.fps = 0; g.fpen = 0; g.maxc = 0; g.compl_ = 0;
+    g.fps = 0; g.fp0 = g.fp1 = 0; g.mc0 = g.mc1 = 0; g.cl0 = g.cl1 = 0;
     g.wc0 = g.wc1 = 0; g.wi0 = g.wi1 = 0; g.over = 0;
     g.ok0 = g.ok1 = 0x1ffffffu;                          // empty lines, empty walls: every row accepts every colour
     if (first_player == 0u) g.nfp = 1u + rng2_below(r, 2u, 2u, k.l);     // random.choice([1, 2]) (:37)
     else g.nfp = first_player;
     if (LID) { g.box = 0x1414141414ull; g.lid = 0; }
     else { g.box = 0; g.lid = 0; }
+    g.lidp = 0;
     g.pscore = 0;
     g.moves = 0;
     return new_round2<LID>(g, r, margin, k);
@@ -749,11 +758,11 @@ AZ_FN double game_stat2(const G2 &g, u32 q)
     case 1: return (double)g.score1;
     case 2: return (double)g.turn;
     case 3: return f0 / (f0 + f1) * 100;
-    case 4: return -(double)(i32)(int16_t)(g.fpen & 0xffffu);
-    case 5: return (double)(g.maxc & 0xffu);
-    case 6: return (double)(g.compl_ & 0xffu);
-    case 7: return (double)((g.compl_ >> 16) & 0xffu);
-    case 8: return (double)((g.compl_ >> 8) & 0xffu);
+    case 4: return -(double)(i32)(int16_t)((u32)g.fp0 & 0xffffu);
+    case 5: return (double)(g.mc0 & 0xffu);
+    case 6: return (double)(g.cl0 & 0xffu);
+    case 7: return (double)((g.cl0 >> 16) & 0xffu);
+    case 8: return (double)((g.cl0 >> 8) & 0xffu);
     default: return g.score0 > g.score1 ? 1.0 : 0.0;
     }
 }

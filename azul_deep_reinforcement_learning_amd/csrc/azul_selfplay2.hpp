@@ -628,15 +628,19 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
     const bool batched = room | (T0 >= 20u);
     u32 klo = 0, khi = 0;
     if (batched) {
-        const u32 i0 = r.pos + 2u * l, i1 = i0 + 1u;
-        u32 wa = 0, wb = 0;
+        // (every lane reads, lanes 20.. repeat draw 19's words: no lane-dependent control flow; a word beyond this state's 624 is
+        // read at its place in the NEXT state -- unused before the regeneration, read again after it)
+        const u32 lc = l < 20u ? l : 19u;
+        const u32 i0 = r.pos + 2u * lc, i1 = i0 + 1u;
+        const u32 j0 = i0 < 624u ? i0 : i0 - 624u, j1 = i1 < 624u ? i1 : i1 - 624u;
         const u32 *words = r.tlds ? r.tlds : r.lds;          // (the tempered copy when the kernel keeps one)
-        if (l < 20u) { if (i0 < 624u) wa = words[i0]; if (i1 < 624u) wb = words[i1]; }
+        u32 wa = words[j0], wb = words[j1];
         if (!room) {
             const u32 p = r.pos;
             lds_sync();
             rng2_twist(r, l);
-            if (l < 20u) { if (i0 >= 624u) wa = words[i0 - 624u]; if (i1 >= 624u) wb = words[i1 - 624u]; }
+            const u32 na = words[j0], nb = words[j1];
+            wa = i0 < 624u ? wa : na; wb = i1 < 624u ? wb : nb;
             r.pos = p - 624u;                                // (wraps; the round's forty words bring it to p + 40 - 624)
         }
         if (!r.tlds) { wa = temper2(wa); wb = temper2(wb); }
@@ -645,15 +649,12 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
         khi = wa >> 6;
     }
     const bool pre = batched && T0 >= 20u;               // no refill can happen: draw t sees total T0 - t
-    u32 kthi = 0, risky = 0, kt0hi = 0;
-    if (pre) {
-        u32 tt = T0 - l;
-        u32 lo = klo * tt, hi = khi * tt + __umulhi(klo, tt);
-        u32 mg = (u32)margin;
-        risky = hb(lo + mg < 2u * mg) & 0xfffffu;        // lo within mg of a multiple of 2^32, one compare (mg < 2^31)
-        kthi = hi;
-        kt0hi = khi * T0 + __umulhi(klo, T0);            // K_t * T0: for the first guess only
-    }
+    // (computed whether or not they will be used: a dozen instructions against a divergent branch around them)
+    const u32 tt = T0 - l;
+    const u32 lo = klo * tt, kthi = khi * tt + __umulhi(klo, tt);
+    const u32 mg = (u32)margin;
+    const u32 risky = hb(lo + mg < 2u * mg) & 0xfffffu;  // lo within mg of a multiple of 2^32, one compare (mg < 2^31)
+    const u32 kt0hi = khi * T0 + __umulhi(klo, T0);      // K_t * T0: for the first guess only
     if (pre && risky == 0u) {
         // The common round: twenty integer draws WITHOUT a 20-step serial loop.  Lane t owns draw t:
         //     colour_t = #{c < 4 : (P_c - n_c(t)) * 2^53 <= K_t * T_t},   n_c(t) = #{s < t : colour_s <= c}

@@ -145,6 +145,38 @@ def test_long_run_soak_many_regenerations(torch_cuda):
         assert np.array_equal(cnt["stat_sums"][g], s.stats_sum)
 
 
+@pytest.mark.parametrize("rules,fp,pool", RULESETS[:2])
+def test_factory_draw_and_decisions_across_an_mt19937_regeneration(torch_cuda, rules, fp, pool):
+    """CPython's index placed at every value from 556 to 624 when the run starts (70 games): within a few moves a move's two
+    words, a round's forty words or a reset's words straddle the regeneration of the 624-word state -- the cases the kernel handles
+    with "read the words before it, regenerate (three groups of chunks), read the words after it".  Everything the kernel writes and
+    all 624 words + the index of every game equal the oracle's stream started from the same state."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    n, steps, base = 70, 60, 5100
+    env = BatchedAzul(n, rules=rules)
+    _start(env, base)
+    streams = [oz.Stream(base + g, fp, pool) for g in range(n)]
+    for g, s in enumerate(streams):
+        s.r.idx = 556 + g - (1 if g == 69 else 0)            # 556 .. 624 (twice 624)
+        mt, pos = s.rng_state()
+        env.set_rng(g, mt, pos)
+    t = env.alloc_trajectory(steps, with_records=True)
+    env.selfplay(steps, t["mask"], t["action"], t["reward"], t["done"], t["records"])
+    torch_cuda.cuda.synchronize()
+    act, rew, dn = t["action"].cpu().numpy(), t["reward"].cpu().numpy(), t["done"].cpu().numpy()
+    msk, rec = t["mask"].cpu().numpy(), t["records"].cpu().numpy()
+    final = env.get_records()
+    for g, s in enumerate(streams):
+        o = s.advance(steps)
+        assert np.array_equal(o["action"], act[:, g]) and np.array_equal(o["mask"], msk[:, g]), g
+        assert np.array_equal(o["reward"], rew[:, g]) and np.array_equal(o["done"], dn[:, g]), g
+        assert o["rec_after"].tobytes() == rec[:, g].tobytes(), g
+        assert s.record().tobytes() == final[g].tobytes(), g
+        mt, pos = s.rng_state()
+        gmt, gpos = env.get_rng(g)
+        assert np.array_equal(mt, gmt) and pos == gpos, g
+
+
 def test_policy_step_handles_stuck_and_finished_slots(torch_cuda):
     """azul_batch_policy_step: action -1 on a slot without legal moves -> done == 2 / STUCK and a fresh episode; a
     finished game handed in restarts too; a legal action on a normal slot plays."""

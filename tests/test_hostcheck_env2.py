@@ -100,8 +100,10 @@ def emulate(L, state, mt, pos, first, pool, opponent, actions, margin=0):
     return o, ops
 
 
-def check_rollout(L, first, pool, opponent, n, T, seed0, warm=0, margin=0):
+def check_rollout(L, first, pool, opponent, n, T, seed0, warm=0, margin=0, pos0=None):
     state, mt, pos = start_batch(n, seed0, first, pool, warm)
+    if pos0 is not None:
+        pos[:] = pos0                                        # any index 0..624 is a valid CPython state
     rng = np.random.default_rng(seed0)
     exp = []
     for g in range(n):
@@ -145,6 +147,15 @@ def test_game_runner_step_with_random_opponent_under_emulation_equals_the_oracle
     first, pool = RULES[ruleset]
     ops, episodes = check_rollout(L, first, pool, True, n=5, T=90, seed0=140)
     assert episodes >= 5 and ops > 10000
+
+
+@pytest.mark.parametrize("opponent", [False, True])
+def test_rollout_env_across_an_mt19937_regeneration(opponent):
+    """The streams start at indices 560 .. 624: the opponent's draws, a round's forty words or a reset's words straddle the
+    regeneration of the 624-word state within the first moves (deal2's "read, regenerate, read" path and the window refill)."""
+    L = load()
+    n = 33
+    check_rollout(L, 0, 1, opponent, n=n, T=45, seed0=2300, warm=1, pos0=np.array([560 + 2 * g for g in range(n)], np.uint32))
 
 
 def test_factory_draw_fp64_path_in_the_rollout_env():

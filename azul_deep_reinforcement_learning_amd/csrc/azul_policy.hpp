@@ -78,26 +78,33 @@ __device__ __forceinline__ u32 row_sum_u(u32 v)
 
 constexpr int HEAD_PER_LANE = 12;
 
-// x[j]: the lane's 12 logits; okbits: bit j set when action 12c+j is legal; g: the lane's game (uniform inside a 16-lane row).
+// x[j]: the lane's 12 logits; row: the game's 180 logits (LDS or global: the chosen action's logit is read back from there); okbits: bit
+// j set when action 12c+j is legal; g: the lane's game (uniform inside a 16-lane row).
 // Lane c == 0 of every row whose `store` is true writes the three results of its game.
-__device__ __forceinline__ void policy_head_rows(const float (&x)[HEAD_PER_LANE], u32 okbits, u64 seed, u64 counter, u32 g, u32 l,
+// The per-lane loops are BRANCH-FREE (round 3): the first version's `if (ok && pick < 0 && target < cum)` became twelve divergent
+// regions per lane (26 exec-mask saves, 58 register copies in 670 instructions).  Now the twelve crossing tests are the sign bits of
+// target - cum_j collected into a bit mask, the pick is its lowest bit among the legal ones, and the chosen action's logit is read
+// back from `row` instead of being tracked through the loop.  Same additions in the same order: the same numbers as before.
+__device__ __forceinline__ void policy_head_rows(const float (&x)[HEAD_PER_LANE], const float *row, u32 okbits, u64 seed, u64 counter, u32 g, u32 l,
                                                  bool store, i32 *action, float *logp, float *entropy, u32 id_base, i32 *lds_action = nullptr,
                                                  const float *u_ready = nullptr /* the game's uniform, when the caller drew it ahead of time */)
 {
     const u32 c = l & 15u, grp = l >> 4;
     const float NEG = -3.0e38f;
     float m = NEG;
+#pragma unroll
     for (int j = 0; j < HEAD_PER_LANE; j++) m = fmaxf(m, ((okbits >> j) & 1u) ? x[j] : NEG);
     m = row_max(m);
     const u32 cnt = row_sum_u((u32)__popc(okbits));
-    float z[HEAD_PER_LANE], e[HEAD_PER_LANE];
+    float e[HEAD_PER_LANE];
     float mine = 0.f, zs = 0.f;
+#pragma unroll
     for (int j = 0; j < HEAD_PER_LANE; j++) {
-        bool ok = (okbits >> j) & 1u;
-        z[j] = ok ? x[j] - m : 0.f;
-        e[j] = ok ? __expf(z[j]) : 0.f;
+        const bool ok = (okbits >> j) & 1u;
+        const float z = ok ? x[j] - m : 0.f;
+        e[j] = ok ? __expf(z) : 0.f;
         mine += e[j];
-        zs += z[j];
+        zs += z;
     }
     const float S = row_sum(mine);
     const float logS = __logf(S);
@@ -110,26 +117,31 @@ __device__ __forceinline__ void policy_head_rows(const float (&x)[HEAD_PER_LANE]
     const float u = u_ready ? *u_ready : policy_uniform(seed, counter, id_base + g);
     const float target = u * S;
     float cum = incl - mine;
-    int pick = -1, lastok = 0;
-    float zpick = 0.f, zlast = 0.f;
-    for (int j = 0; j < HEAD_PER_LANE; j++) {
-        bool ok = (okbits >> j) & 1u;
-        cum += e[j];
-        if (ok) { lastok = j; zlast = z[j]; }
-        if (ok && pick < 0 && (argmax ? z[j] == 0.f : target < cum)) { pick = j; zpick = z[j]; }
+    u32 cross = 0;                                       // bit j: target < cum_j (sampling) / x_j == m (argmax)
+    if (argmax) {                                        // (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < HEAD_PER_LANE; j++) cross |= (x[j] == m ? 1u : 0u) << j;
+    } else {
+#pragma unroll
+        for (int j = 0; j < HEAD_PER_LANE; j++) {
+            cum += e[j];
+            cross |= (__builtin_bit_cast(u32, target - cum) >> 31) << j;      // the sign of target - cum_j (no NaNs: finite logits)
+        }
     }
-    const u64 hit = __ballot(pick >= 0), any = __ballot(okbits != 0u);
+    const u32 pickmask = cross & okbits;
+    const int pick = pickmask ? (int)__builtin_ctz(pickmask) : -1;
+    const int lastok = okbits ? 31 - (int)__builtin_clz(okbits) : 0;
+    const u64 hit = __ballot(pickmask != 0u), any = __ballot(okbits != 0u);
     const u32 hit16 = (u32)(hit >> (16u * grp)) & 0xffffu, any16 = (u32)(any >> (16u * grp)) & 0xffffu;
     // fp32 round-off can push the target past the last cumulative sum: then the last legal action is taken
     const u32 lane_sel = hit16 ? (u32)__builtin_ctz(hit16) : (any16 ? 31u - (u32)__builtin_clz(any16) : 0u);
     const int jmine = hit16 ? pick : lastok;
-    const float zmine = hit16 ? zpick : zlast;
     const int src = (int)((16u * grp + lane_sel) << 2);
     const int jsel = __builtin_amdgcn_ds_bpermute(src, jmine);
-    const float zsel = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, zmine)));
     const i32 chosen = cnt == 0u ? -1 : (i32)(HEAD_PER_LANE * lane_sel) + jsel;     // no legal action (stuck game): the rollout sends -1
     if (lds_action && c == 0u) lds_action[grp] = chosen;
     if (store && c == 0u) {
+        const float zsel = row[chosen < 0 ? 0 : chosen] - m;                         // log-softmax numerator of the chosen action
         action[g] = chosen;
         logp[g] = cnt == 0u ? 0.f : zsel - logS;
         entropy[g] = cnt == 0u ? 0.f : ent;
@@ -159,7 +171,7 @@ __global__ void __launch_bounds__(64) azul_policy_head_kernel(const float *logit
     const float *lg = logits + (size_t)gc * AZUL_NUM_ACTIONS + (c < 15u ? 12u * c : 0u);
     for (int j = 0; j < HEAD_PER_LANE; j++) x[j] = lg[j];
     u32 okbits = head_mask_bits(mask + (size_t)gc * AZUL_NUM_ACTIONS, c);
-    policy_head_rows(x, okbits, seed, counter, gc, l, g < n, action, logp, entropy, id_base);
+    policy_head_rows(x, logits + (size_t)gc * AZUL_NUM_ACTIONS, okbits, seed, counter, gc, l, g < n, action, logp, entropy, id_base);
 }
 
 // ---- fused ActorCritic forward + head ------------------------------------------------------------------------------
@@ -338,7 +350,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         float x[HEAD_PER_LANE];
         const float *lg = lgS + hrow * PF_LOG_STRIDE + (c < 15u ? 12u * c : 0u);
         for (int j = 0; j < HEAD_PER_LANE; j++) x[j] = lg[j];
-        policy_head_rows(x, okbits, seed, counter, hgc, l, hg < n, action, logp, entropy, id_base);
+        policy_head_rows(x, lgS + hrow * PF_LOG_STRIDE, okbits, seed, counter, hgc, l, hg < n, action, logp, entropy, id_base);
     }
     PF_STAMP();
 #if defined(AZ_PF_PROFILE)
@@ -544,7 +556,7 @@ __global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(Batc
             u64 field = lo >> off;
             if (off > 52u) field |= hi << (64u - off);
             const u32 okbits = c < 15u ? (u32)field & 0xfffu : 0u;
-            policy_head_rows(x, okbits, a.seed, counter + (u64)t, hg < n ? hg : n - 1u, l, hg < n, a.action + row_t, a.logp + row_t,
+            policy_head_rows(x, lgS + hrow * PF_LOG_STRIDE, okbits, a.seed, counter + (u64)t, hg < n ? hg : n - 1u, l, hg < n, a.action + row_t, a.logp + row_t,
                              a.entropy + row_t, b.id_base, actS + 4u * hw, &u_head);
         }
         lds_barrier();

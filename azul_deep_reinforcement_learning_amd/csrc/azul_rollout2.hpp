@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
             u64 field = lo >> off;
             if (off > 52u) field |= hi << (64u - off);
             const u32 okbits = c < 15u ? (u32)field & 0xfffu : 0u;
-            policy_head_rows(x, okbits, a.seed, counter + (u64)t, hg < n ? hg : n - 1u, lane, hg < n, a.action + row_t, a.logp + row_t,
+            policy_head_rows(x, lgS + hrow * PF_LOG_STRIDE, okbits, a.seed, counter + (u64)t, hg < n ? hg : n - 1u, lane, hg < n, a.action + row_t, a.logp + row_t,
                              a.entropy + row_t, b.id_base, actS + 4u * w, &u_head);
         } else if (w == 7u) {
             // the critic, on a wave that idles during the head, summed exactly like azul_policy_forward_kernel: lane (row c, quarter q)

@@ -183,10 +183,12 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
         az2::legal_mask2(g, k, m);
         const size_t cell = (size_t)slot * n + gi;
         uint8_t *row = a.mask + cell * AZUL_NUM_ACTIONS + l;
+#if !defined(PR2_X_NO_MASK_STORES)       // (TIMING EXPERIMENT switch: wrong results)
         if (l < 30u) {
 #pragma unroll
             for (u32 ww = 0; ww < 6u; ww++) row[30u * ww] = (uint8_t)m.bit[ww];
         }
+#endif
         if (l == 0u) {                                   // the 180 bits packed: the six 30-bit row words concatenated
             maskS[gl][0] = (u64)m.m[0] | ((u64)m.m[1] << 30) | ((u64)m.m[2] << 60);
             maskS[gl][1] = ((u64)m.m[2] >> 4) | ((u64)m.m[3] << 26) | ((u64)m.m[4] << 56);

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Games-per-GPU sweep of the self-play kernel (profiles/round3_games_sweep.txt): gpurun -- bash tools/games_sweep.sh
+for G in 1024 2048 3072 4096 8192; do
+  python3 bench.py --games $G --steps 8 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('games %6d: %.3f G env steps/s, launch %.4f ms, %s' % ($G, d['value']/1e9, d['roofline']['avg_launch_ms'], d['parity_gate_after_timed_region'][:2]))"
+done
+python3 - <<'PY'
+# the same launch without any output stream (timing only)
+import torch, time
+from azul_deep_reinforcement_learning_amd import BatchedAzul
+for G in (2048, 4096):
+    env = BatchedAzul(G); env.seed(0); env.runner_init(); env.runner_init()
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(8): env.selfplay(512, None, None, None, None)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 8
+    print("games %d no outputs: launch %.4f ms" % (G, dt * 1e3))
+PY

@@ -26,9 +26,12 @@ constexpr int PR2_HOIST1 = 4, PR2_HOIST2 = 8, PR2_ADEPTH = 4;
 #if defined(PR2_EXPERIMENT_NO_WEIGHT_LOADS)
 // TIMING EXPERIMENT ONLY (wrong results): the matrix phases without their weight stream
 #define PR2_LOAD1(vo, s) make_float2((float)(vo) + (float)(s), 1.0f)
+#define PR2_LOAD1Q(vo, s) make_float4((float)(vo) + (float)(s), 1.0f, 2.0f, 3.0f)
 #define PR2_LOAD2(NT_, s) make_float2((float)voff + (float)(s), 1.0f)
 #else
 #define PR2_LOAD1(vo, s) __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs1, vo, (4 * (s)) * PF_H2 * 4, 0))
+// waves 0..3: FOUR adjacent hidden columns per lane and k-step in one 16-byte load (two column pairs)
+#define PR2_LOAD1Q(vo, s) __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, (4 * (s)) * PF_H2 * 4, 0))
 #define PR2_LOAD2(NT_, s) ((NT_) == 2 ? __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs2, voff, (4 * (s)) * PF_ACT * 4, 0)) \
                                       : make_float2(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, voff, (4 * (s)) * PF_ACT * 4, 0)), 0.f))
 #endif
@@ -36,12 +39,14 @@ constexpr int PR2_HOIST1 = 4, PR2_HOIST2 = 8, PR2_ADEPTH = 4;
 __device__ __forceinline__ void pr2_request1(bool two, const __amdgpu_buffer_rsrc_t rs1, u32 voffA, u32 voffB, float2 (&preA)[PR2_HOIST1],
                                              float2 (&preB)[PR2_HOIST1])
 {
-#pragma unroll
-    for (int s = 0; s < PR2_HOIST1; s++) preA[s] = PR2_LOAD1(voffA, s);
     if (two) {
 #pragma unroll
-        for (int s = 0; s < PR2_HOIST1; s++) preB[s] = PR2_LOAD1(voffB, s);
+        for (int s = 0; s < PR2_HOIST1; s++) { const float4 t = PR2_LOAD1Q(voffA, s); preA[s] = make_float2(t.x, t.y); preB[s] = make_float2(t.z, t.w); }
+    } else {
+#pragma unroll
+        for (int s = 0; s < PR2_HOIST1; s++) preA[s] = PR2_LOAD1(voffA, s);
     }
+    (void)voffB;
 }
 
 __device__ __forceinline__ void pr2_request2(bool two, const __amdgpu_buffer_rsrc_t rs2, u32 voff, float2 (&pre)[PR2_HOIST2])
@@ -64,7 +69,10 @@ __device__ __forceinline__ void pr2_layer1(const __amdgpu_buffer_rsrc_t rs1, u32
 #pragma unroll
     for (int s = 0; s < PR2_HOIST1; s++) { bwA[s] = preA[s]; if (NP == 2) bwB[s] = preB[s]; }
 #pragma unroll
-    for (int s = PR2_HOIST1; s < (int)PR2_AHEAD; s++) { bwA[s] = PR2_LOAD1(voffA, s); if (NP == 2) bwB[s] = PR2_LOAD1(voffB, s); }
+    for (int s = PR2_HOIST1; s < (int)PR2_AHEAD; s++) {
+        if (NP == 2) { const float4 t = PR2_LOAD1Q(voffA, s); bwA[s] = make_float2(t.x, t.y); bwB[s] = make_float2(t.z, t.w); }
+        else bwA[s] = PR2_LOAD1(voffA, s);
+    }
     // A fragments PR2_ADEPTH k-steps ahead: a step is only 64..128 cycles of matrix pipe per wave, an LDS round trip is longer
     float af[PF_IN / 4];
 #pragma unroll
@@ -72,7 +80,10 @@ __device__ __forceinline__ void pr2_layer1(const __amdgpu_buffer_rsrc_t rs1, u32
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < PF_IN / 4; s++) {
-        if (s + (int)PR2_AHEAD < PF_IN / 4) { bwA[s + PR2_AHEAD] = PR2_LOAD1(voffA, s + PR2_AHEAD); if (NP == 2) bwB[s + PR2_AHEAD] = PR2_LOAD1(voffB, s + PR2_AHEAD); }
+        if (s + (int)PR2_AHEAD < PF_IN / 4) {
+            if (NP == 2) { const float4 t = PR2_LOAD1Q(voffA, s + PR2_AHEAD); bwA[s + PR2_AHEAD] = make_float2(t.x, t.y); bwB[s + PR2_AHEAD] = make_float2(t.z, t.w); }
+            else bwA[s + PR2_AHEAD] = PR2_LOAD1(voffA, s + PR2_AHEAD);
+        }
         if (s + PR2_ADEPTH < PF_IN / 4) af[s + PR2_ADEPTH] = ap[4 * (s + PR2_ADEPTH)];
         const float av = af[s];
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bwA[s].x, acc[0], 0, 0, 0);
@@ -204,7 +215,8 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
         if (l == 0u) { maskS[gl][0] = 0; maskS[gl][1] = 0; maskS[gl][2] = 0; }
     }
 
-    const u32 colA = two ? 64u * w + 2u * c : 256u + 32u * (w - 4u) + 2u * c, colB = colA + 32u;
+    // (waves 0..3: lane c owns the FOUR adjacent columns 64w + 4c .. + 3 -- one 16-byte load per k-step; waves 4..7: a pair, 8 bytes)
+    const u32 colA = two ? 64u * w + 4u * c : 256u + 32u * (w - 4u) + 2u * c, colB = colA + 2u;
     const bool liveA = colA < (u32)PF_H2, liveB = two && colB < (u32)PF_H2;
     const u32 voffA = ((liveA ? colA : 0u) + q * (u32)PF_H2) * 4u, voffB = ((liveB ? colB : 0u) + q * (u32)PF_H2) * 4u;
     const u32 voff2 = ((PR2_L2COL0 < (u32)PF_ACT ? PR2_L2COL0 : 0u) + q * (u32)PF_ACT) * 4u;
@@ -226,7 +238,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
         PR2_STAMP(1);                                    // waiting for the slowest env wave
         {
             // layer 1: pairs of adjacent hidden columns per lane (one 8-byte load per k-step and pair: a 16-lane group reads 128 contiguous
-            // bytes of a k-row).  Waves 0..3 own two pairs (columns 64w + 2c + j and 64w + 32 + 2c + j), waves 4..7 one (256 + 32 (w - 4) +
+            // bytes of a k-row).  Waves 0..3 own two pairs, FOUR adjacent columns 64w + 4c + j (one 16-byte load per k-step), waves 4..7 one (256 + 32 (w - 4) +
             // 2c + j): 24 tiles over 8 waves, six per SIMD.
             pf_f32x4 acc[4];
             for (int j = 0; j < 4; j++) acc[j] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
@@ -332,5 +344,6 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     }
 #undef PR2_L2COL0
 #undef PR2_LOAD1
+#undef PR2_LOAD1Q
 #undef PR2_LOAD2
 }

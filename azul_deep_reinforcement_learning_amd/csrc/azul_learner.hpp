@@ -145,6 +145,9 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
 #define voff2 (((f2live ? f2col0 : 0u) + q * (u32)PF_ACT) * 4u)
     const float b2c_v = W.b2c[0];                        // (wave-uniform: a scalar register)
 #define LG_LOAD_W1(s, j) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, voff1 + 4u * (j), (4 * (s)) * PF_H2 * 4, 0))
+// (the lane's three adjacent columns as one 8-byte and one 4-byte load: two vector-memory instructions per k-step instead of three)
+#define LG_LOAD_W1P(s) __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs1, voff1, (4 * (s)) * PF_H2 * 4, 0))
+#define LG_LOAD_W1_3(dst, s) do { const float2 p_ = LG_LOAD_W1P(s); (dst)[0] = p_.x; (dst)[1] = p_.y; (dst)[2] = LG_LOAD_W1(s, 2); } while (0)
 
     // register-resident partial gradients of this workgroup
     pf_f32x4 gW2[3][6];                                  // dW2a_t tiles: hidden tiles 3 (w & 3) + i, action tiles 6 (w >> 2) + j
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
     float ob[LG_OBS_PER_THREAD];
     float pre1[LG_AHEAD][3];                             // layer 1's first weight fragments, requested at the end of the previous pass
     float2 pre2[LG_AHEAD];                               // the same for the two 180-wide GEMMs (layer 2, dh)
-#define LG_REQUEST_W1() do { _Pragma("unroll") for (int s = 0; s < (int)LG_AHEAD; s++) for (int j = 0; j < 3; j++) pre1[s][j] = LG_LOAD_W1(s, j); } while (0)
+#define LG_REQUEST_W1() do { _Pragma("unroll") for (int s = 0; s < (int)LG_AHEAD; s++) LG_LOAD_W1_3(pre1[s], s); } while (0)
     LG_REQUEST_W1();
     if (tid < (u32)LG_M) idxS[0][tid] = LG_FETCH_IDX(blockIdx.x);
     lds_barrier();
@@ -205,7 +208,7 @@ __global__ void __launch_bounds__(64 * LG_WAVES) azul_a2c_grad_kernel(PolicyWeig
             for (int s = 0; s < LG_ADEPTH; s++) for (int u = 0; u < LG_SUB; u++) af[s][u] = ap[u * PF_GAMES * PF_OBS_STRIDE + 4 * s];
 #pragma unroll
             for (int s = 0; s < PF_IN / 4; s++) {
-                if (s + (int)LG_AHEAD < PF_IN / 4) for (int j = 0; j < 3; j++) bw[s + LG_AHEAD][j] = LG_LOAD_W1(s + LG_AHEAD, j);
+                if (s + (int)LG_AHEAD < PF_IN / 4) LG_LOAD_W1_3(bw[s + LG_AHEAD], s + LG_AHEAD);
                 if (s + LG_ADEPTH < PF_IN / 4) for (int u = 0; u < LG_SUB; u++) af[s + LG_ADEPTH][u] = ap[u * PF_GAMES * PF_OBS_STRIDE + 4 * (s + LG_ADEPTH)];
                 float av[LG_SUB];
                 for (int u = 0; u < LG_SUB; u++) av[u] = af[s][u];

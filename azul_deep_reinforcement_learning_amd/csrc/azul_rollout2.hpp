@@ -18,11 +18,17 @@
 
 #include "azul_env2.hpp"
 
-constexpr u32 PR2_WAVES = 8, PR2_AHEAD = 8;
+#ifndef PR2_AHEAD_N
+#define PR2_AHEAD_N 6      // (k-steps of layer-1 weights in flight: 3..6 measured alike, 8 and 12 slower -- profiles/round3_policy_rollout_phases.txt)
+#endif
+#ifndef PR2_ADEPTH_N
+#define PR2_ADEPTH_N 4
+#endif
+constexpr u32 PR2_WAVES = 8, PR2_AHEAD = PR2_AHEAD_N;
 
 // The first weight fragments of a matrix phase are REQUESTED A PHASE EARLIER (layer 1's before the env step, layer 2's before layer 1's
 // epilogue) and stay in flight across the LDS-only barriers: the matrix pipe does not wait for L2 after each barrier.
-constexpr int PR2_HOIST1 = 4, PR2_HOIST2 = 8, PR2_ADEPTH = 4;
+constexpr int PR2_HOIST1 = 4, PR2_HOIST2 = 8, PR2_ADEPTH = PR2_ADEPTH_N;
 #if defined(PR2_EXPERIMENT_NO_WEIGHT_LOADS)
 // TIMING EXPERIMENT ONLY (wrong results): the matrix phases without their weight stream
 #define PR2_LOAD1(vo, s) make_float2((float)(vo) + (float)(s), 1.0f)

@@ -28,7 +28,13 @@ constexpr u32 PR2_WAVES = 8, PR2_AHEAD = PR2_AHEAD_N;
 
 // The first weight fragments of a matrix phase are REQUESTED A PHASE EARLIER (layer 1's before the env step, layer 2's before layer 1's
 // epilogue) and stay in flight across the LDS-only barriers: the matrix pipe does not wait for L2 after each barrier.
-constexpr int PR2_HOIST1 = 4, PR2_HOIST2 = 8, PR2_ADEPTH = PR2_ADEPTH_N;
+#ifndef PR2_HOIST1_N
+#define PR2_HOIST1_N 4
+#endif
+#ifndef PR2_HOIST2_N
+#define PR2_HOIST2_N 6     // (2..6 measured alike, 8 and 12 slower: too many layer-2 fragments in flight hold up layer 1's tail)
+#endif
+constexpr int PR2_HOIST1 = PR2_HOIST1_N, PR2_HOIST2 = PR2_HOIST2_N, PR2_ADEPTH = PR2_ADEPTH_N;
 #if defined(PR2_EXPERIMENT_NO_WEIGHT_LOADS)
 // TIMING EXPERIMENT ONLY (wrong results): the matrix phases without their weight stream
 #define PR2_LOAD1(vo, s) make_float2((float)(vo) + (float)(s), 1.0f)

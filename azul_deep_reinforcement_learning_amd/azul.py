@@ -19,6 +19,20 @@ from .batch import IllegalRule, parse_rules
 from .records import RECORD_DTYPE, RECORD_NP_DTYPE, bits_to_walls, pack_flags, unpack_flags, walls_to_bits
 
 
+def _ilist(x, name):
+    """An attribute's values as Python ints.  The reference's attributes are int arrays, but callers assign freely: a float array
+    holding integers (game.score = np.array([3., 0.])) is accepted like the reference accepts it; a fractional value is named."""
+    a = np.ravel(x)
+    if a.dtype.kind == "f":
+        ai = a.astype(np.int64)
+        if not np.array_equal(ai, a):
+            raise ValueError("%s must hold integral values" % name)
+        a = ai
+    elif a.dtype.kind == "b":
+        a = a.astype(np.int64)
+    return a.tolist()
+
+
 class IllegalMove(Exception):
     pass
 
@@ -132,26 +146,28 @@ class Azul:
         pad = 4 - P if wide else 0
         lid = self.tile_pool == "Lid"
         try:
-            fl = np.ravel(self.floors).tolist()
+            fl = _ilist(self.floors, "floors")
             if max(fl) > 7:
                 raise struct.error("floors")
             z = [0] * pad
-            vals = (np.ravel(self.game_board_displays).tolist() + np.ravel(self.game_board_center).tolist()
+            vals = (_ilist(self.game_board_displays, "game_board_displays") + _ilist(self.game_board_center, "game_board_center")
                     + [pack_flags(self._player(self.current_player), self._player(self.next_first_player), self.end_of_game)]
-                    + np.ravel(self.pattern_lines).tolist() + [0] * (25 * pad) + fl + z
-                    + walls_to_bits(self.walls).tolist() + z + np.ravel(self.score).tolist() + z
-                    + (np.ravel(self.box_tiles).tolist() + np.ravel(self.lid_tiles).tolist() if lid else [0] * 10)
+                    + _ilist(self.pattern_lines, "pattern_lines") + [0] * (25 * pad) + fl + z
+                    + walls_to_bits(self.walls).tolist() + z + _ilist(self.score, "score") + z
+                    + (_ilist(self.box_tiles, "box_tiles") + _ilist(self.lid_tiles, "lid_tiles") if lid else [0] * 10)
                     + [int(self.turn_counter)]
-                    + np.ravel(self.first_player_stats).astype(np.int64).tolist() + z
-                    + np.ravel(self.floor_penalty).astype(np.int64).tolist() + z
-                    + np.ravel(self.max_combo).astype(np.int64).tolist() + z
-                    + np.ravel(self.completed_lines).astype(np.int64).tolist() + [0] * (3 * pad))
+                    + _ilist(self.first_player_stats, "first_player_stats") + z
+                    + _ilist(self.floor_penalty, "floor_penalty") + z
+                    + _ilist(self.max_combo, "max_combo") + z
+                    + _ilist(self.completed_lines, "completed_lines") + [0] * (3 * pad))
             if wide:
                 raw = self._FMTN.pack(*vals, P)
             else:
                 raw = self._FMT2.pack(*vals, int(runner.player_score) if runner is not None else 0,
                                       int(runner.move_counter) if runner is not None else 0)
-        except (struct.error, TypeError, ValueError):
+        except (struct.error, TypeError, ValueError) as err:
+            if "must hold integral values" in str(err):
+                raise
             for (name, l, h) in self._RANGES:             # name the offender the slow way
                 if not hasattr(self, name):
                     continue

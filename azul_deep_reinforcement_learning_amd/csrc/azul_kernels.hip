@@ -70,6 +70,7 @@ struct OpArgs {
     i32 *potential;          // [N]   out
     double *stats;           // [N][10] out
     uint8_t *player;         // [N]   out: current_player after the op
+    uint8_t *rng_dirty;      // [N]   out: the op regenerated the game's 624 MT19937 words (Rng::dirty; 0 for ops that do not draw)
     u32 first;               // the launch covers games first .. first + grid - 1; row i of the arrays above belongs to game first + i
 };
 
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
     Game g;
     game_load(g, rec);
     game_prime<LID>(g, k);
-    u32 st = ST_OK;
+    u32 st = ST_OK, rdirty = 0;
     if (act && a.op != OP_QUERY) {
         Rng r;
         const bool use_rng = op_needs_rng(a.op);
@@ -270,7 +271,9 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
         }
         if (dirty_state) game_store(g, rec);
         if (use_rng) rng_close(r, b.mtpos + gi);
+        rdirty = r.dirty & 1u;
     }
+    if (a.rng_dirty) AZ_LANE0(a.rng_dirty[oi] = (uint8_t)rdirty);
     if (a.status && act) AZ_LANE0(a.status[oi] = (uint8_t)st);
     // queries on the post-op state
     if (a.mask) {
@@ -314,7 +317,7 @@ __global__ void __launch_bounds__(64) azul_np_op_kernel(BatchDev b, OpArgs a)
     sample_tab_load(tab, b.T, fr_lds);
     GameN<P> g;
     gamen_load(g, rec);
-    u32 st = ST_OK;
+    u32 st = ST_OK, rdirty = 0;
     if (act && a.op != OP_QUERY) {
         Rng r;
         const bool use_rng = op_needs_rng(a.op);
@@ -370,7 +373,9 @@ __global__ void __launch_bounds__(64) azul_np_op_kernel(BatchDev b, OpArgs a)
         }
         if (dirty_state) gamen_store(g, rec);
         if (use_rng) rng_close(r, b.mtpos + gi);
+        rdirty = r.dirty & 1u;
     }
+    if (a.rng_dirty) AZ_LANE0(a.rng_dirty[oi] = (uint8_t)rdirty);
     if (a.status && act) AZ_LANE0(a.status[oi] = (uint8_t)st);
     if (a.mask) {
         Mask m;
@@ -1309,6 +1314,7 @@ struct CallScratch {             // device scratch of one call; the pinned mirro
     u32 pos;                     // (pinned mirror only: the stream index, in and out)
     i32 reward, action_out, potential;
     uint8_t status, done, flags, player;
+    uint8_t rng_dirty, pad_[3];  // the kernel regenerated the 624 words (written by every call: 0 for ops that do not draw)
     uint8_t mask_in[AZUL_NUM_ACTIONS];
     uint8_t mask[AZUL_NUM_ACTIONS];
     float obs[AZUL_OBS_SIZE];
@@ -1332,7 +1338,9 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     const hipStream_t st = (hipStream_t)stream;
     if (!b->call_dev) {
         HIP_TRY(hipMalloc((void **)&b->call_dev, sizeof(CallScratch)));
+        HIP_TRY(hipMemsetAsync(b->call_dev, 0, sizeof(CallScratch), st));      // no uninitialised byte ever travels back
         HIP_TRY(hipHostMalloc((void **)&b->call_pin, sizeof(CallScratch), hipHostMallocDefault));
+        memset(b->call_pin, 0, sizeof(CallScratch));
     }
     CallScratch *D = (CallScratch *)b->call_dev, *H = (CallScratch *)b->call_pin;
     const size_t RB = (size_t)b->rec_bytes;
@@ -1370,7 +1378,7 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     if (c->want & AZUL_WANT_FLAGS) a.flags = &D->flags;
     if (c->want & AZUL_WANT_POTENTIAL) a.potential = &D->potential;
     if (c->want & AZUL_WANT_STATS) a.stats = D->stats;
-    H->status = AZUL_OK; H->done = 0; H->reward = 0;
+    a.rng_dirty = &D->rng_dirty;
     if (int rc = launch_op(b, a, stream, 1)) return rc;
     // ---- results: the scalar head of the scratch always (24 bytes), the rest on request
     HIP_TRY(hipMemcpyAsync(&H->reward, &D->reward, offsetof(CallScratch, mask_in) - offsetof(CallScratch, reward), hipMemcpyDeviceToHost, st));
@@ -1380,16 +1388,21 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     if (c->want & AZUL_WANT_STATS) HIP_TRY(hipMemcpyAsync(H->stats, D->stats, sizeof(H->stats), hipMemcpyDeviceToHost, st));
     if (c->want & AZUL_WANT_RECORD) HIP_TRY(hipMemcpyAsync(H->record, b->d.state + g * RB, RB, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    c->status = H->status; c->reward = H->reward; c->done = H->done; c->action = H->action_out; c->flags = H->flags; c->potential = H->potential;
+    // the scratch's result head is shared by all ops: only what THIS op / `want` produced is handed out, the rest reads zero
+    c->status = H->status;
+    c->reward = c->op == AZUL_CALL_RUNNER_STEP ? H->reward : 0;
+    c->done = c->op == AZUL_CALL_RUNNER_STEP ? H->done : 0;
+    c->action = c->op == AZUL_CALL_SAMPLE_MASK ? H->action_out : 0;
+    c->flags = (c->want & AZUL_WANT_FLAGS) ? H->flags : 0;
+    c->potential = (c->want & AZUL_WANT_POTENTIAL) ? H->potential : 0;
     c->pos_out = H->pos;
     if (c->want & AZUL_WANT_MASK) memcpy(c->mask, H->mask, AZUL_NUM_ACTIONS);
     if (c->want & AZUL_WANT_OBS) memcpy(c->obs, H->obs, sizeof(H->obs));
     if (c->want & AZUL_WANT_STATS) memcpy(c->stats, H->stats, sizeof(H->stats));
     if (c->want & AZUL_WANT_RECORD) memcpy(c->record_out, H->record, RB);
-    // a call draws far fewer than 624 words, so the words were regenerated iff the index moved backwards (an index of 624 -- a
-    // freshly seeded stream -- regenerates at the first draw).  `pos_in` is the caller's statement of the index before the call;
-    // without mt_in the caller passes the index it last received.
-    c->rng_regenerated = (c->pos_out < c->pos_in) ? 1 : 0;
+    // whether the 624 words were regenerated is the kernel's own statement (Rng::dirty, written next to the status): it does not
+    // depend on the caller's `pos_in`, which is only the index uploaded together with mt_in
+    c->rng_regenerated = H->rng_dirty ? 1 : 0;
     if (c->rng_regenerated && c->mt_out) {
         HIP_TRY(hipMemcpyAsync(H->mt, b->d.mt + g * 624, sizeof(H->mt), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

@@ -43,27 +43,6 @@ def _count(h2d=0, d2h=0, launches=0, syncs=0):
 _RNG = {"be": None, "state": None, "pos": 0}
 
 
-class StepwiseBackend:
-    """A backend that exposes the steps of a facade call separately -- put / push_rng / op_* / pull_rng / get -- e.g. the host
-    emulation of the device core in tests/hostcheck.  `call` strings them together in the order the fused entry performs them."""
-
-    def call(self, op, args=(), rec=None, draws=False, mutates=True):
-        self.put(rec)
-        if draws:
-            self.push_rng()
-        out = getattr(self, op)(*args)
-        if draws:
-            self.pull_rng()
-        return out, (self.get() if mutates else None)
-
-    def sample(self, mask):
-        self.push_rng()
-        a = self.op_sample_mask(mask)
-        if a >= 0:
-            self.pull_rng()
-        return a
-
-
 # facade op -> (AZUL_CALL_*, results wanted, takes an argument)
 _OPS = {
     "op_init": (L.CALL_INIT, 0), "op_new_round": (L.CALL_NEW_ROUND, 0), "op_move": (L.CALL_MOVE, 0),
@@ -175,7 +154,7 @@ class HipBackend:
         return int(c.action)
 
 
-_FACTORY = HipBackend      # tests/hostcheck swaps in its 64-lane host emulation of the SAME core for CPU-only logic checks
+_FACTORY = HipBackend      # the class behind backend(): the product has exactly this one (no CPU path)
 _CACHE = {}
 
 

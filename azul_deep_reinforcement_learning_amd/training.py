@@ -103,8 +103,10 @@ class BatchedTrainer:
             self.history[k].append(v)
         return row
 
-    def train(self, net_name=None, batches=1000, log_every=None, checkpoint_every=1000):
-        """nn_runner.py:49-84: `batches` updates; with a `net_name` the CSV log and the checkpoints go to results_dir."""
+    def train(self, net_name=None, batches=1000, log_every=None, checkpoint_every=1000, checkpoint_ring=False):
+        """nn_runner.py:49-84: `batches` updates; with a `net_name` the CSV log and the checkpoints go to results_dir.
+        checkpoint_ring: whether the periodic checkpoints carry the trajectory ring (~75 KB per game, save_checkpoint) -- off by
+        default: a periodic file is a restart point, not a bit-exact continuation; call save_checkpoint(path) for the latter."""
         log_every = max(1, batches // 1000) if log_every is None else log_every             # nn_runner.py:79
         path = None
         if net_name is not None:
@@ -124,7 +126,7 @@ class BatchedTrainer:
                     csv.writer(fh, delimiter=",", quotechar='"', quoting=csv.QUOTE_MINIMAL).writerow(
                         [last["batch"]] + [last[k] for k in AGENT_STAT_KEYS] + [last[k] for k in STAT_KEYS])
             if net_name is not None and self.batch % checkpoint_every == 0:                # nn_runner.py:83-84
-                self.save_checkpoint(os.path.join(self.results_dir, net_name + ".pt"))
+                self.save_checkpoint(os.path.join(self.results_dir, net_name + ".pt"), save_ring=checkpoint_ring)
                 self.export_mx(os.path.join(self.results_dir, net_name + ".mx"))            # the reference's file name and content
         return last
 
@@ -180,7 +182,8 @@ class BatchedTrainer:
 
     def load_checkpoint(self, path):
         ro = self.rollout
-        ck = torch.load(path, map_location=ro.device, weights_only=False)
+        # (on the CPU first: the ring of a large batch is GBs and every tensor is copied into its resident buffer below, one at a time)
+        ck = torch.load(path, map_location="cpu", weights_only=False)
         if (ck["n_games"], ck["parts"], ck["window"]) != (ro.n, ro.parts, ro.T):
             raise ValueError("checkpoint was written for n_games=%d parts=%d window=%d" % (ck["n_games"], ck["parts"], ck["window"]))
         ro.synchronize()
@@ -214,6 +217,11 @@ class BatchedTrainer:
                 ro.traj[p] = ro._window_views(ro.rings[p], (ro.windows_played - 1) % ro.ring)
             self.learner.load_ring_state(ro, ck.get("learner_ring"))
         else:
+            if "ring_buffers" in ck and ro.ring > 1:
+                import warnings
+                warnings.warn("checkpoint %s holds a trajectory ring of %s windows, this rollout uses %d: the ring is NOT restored -- the "
+                              "resumed run restarts its books with the next window and no longer equals the uninterrupted one"
+                              % (path, ck.get("ring"), ro.ring))
             self.learner.load_ring_state(ro, None)
         torch.cuda.synchronize(ro.device)
         self.batch = int(ck["batch"])

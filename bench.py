@@ -138,7 +138,7 @@ def _timed(world, dev, fn):
     return float(el.item()), res
 
 
-def extras(games, world=1, rank=0, dev=None, seed_base=0, backend="nccl"):
+def extras(games, world=1, rank=0, dev=None, seed_base=0, backend="nccl", phase=None):
     """Driver-observed secondary lines (after the headline measurement; EVERY rank runs them): BASELINE configs[2] (N = 1) /
     configs[4] (N > 1) -- the policy in the loop, one launch per 32-move window, games sharded by global id -- and the training loop
     (NNRunner.train batched; N > 1: data parallel, the step is rollout -> selection -> gradients -> ALL-REDUCE of the global sample
@@ -149,6 +149,8 @@ def extras(games, world=1, rank=0, dev=None, seed_base=0, backend="nccl"):
     from azul_deep_reinforcement_learning_amd import BatchedActorCritic, PolicyRollout
     from azul_deep_reinforcement_learning_amd.learner import A2CLearner
     res = {}
+    phase = phase if phase is not None else [""]
+    phase[0] = "policy_config"
     window, windows = 32, 40
     base = seed_base + rank * games                     # CPython seeds and Philox keys follow the GLOBAL game id
     coll = "RCCL" if backend == "nccl" else backend
@@ -185,6 +187,7 @@ def extras(games, world=1, rank=0, dev=None, seed_base=0, backend="nccl"):
                      "flop_per_env_move": FWD_FLOP_PER_GAME, "event_bracket_ms": kms, "host_elapsed_ms": dt * 1e3, "scope": "rank 0's GPU"}}
     del ro
     torch.cuda.empty_cache()
+    phase[0] = "training"
 
     torch.manual_seed(0)                                # every rank starts from the same parameters (and keeps them: same updates)
     net = BatchedActorCritic(136, 180, 180).cuda()
@@ -318,6 +321,32 @@ def players_selfplay(games, chunk=256, launches=6):
         torch.cuda.empty_cache()
     res["kernel"] = "azul_np_selfplay_kernel (one game per wavefront)"
     return res
+
+
+WATCHDOG_EXIT_CODE = 3
+
+
+def start_watchdog(timeout_s, rank, out, phase, _exit=os._exit):
+    """The secondary measurements run under a deadline.  When it passes, a GPU process of this job is stuck (a kernel that does not
+    finish, a collective that one rank never entered): rank 0 still prints the headline line -- with the phase that was running under
+    `extra.error` -- and EVERY rank leaves with a NON-ZERO exit code, so that torchrun / spawn_ranks / the caller see a failed run.
+    No retry, no re-exec."""
+    import threading
+
+    def give_up():
+        if rank == 0 and out is not None:
+            out["extra"] = {"error": "secondary measurements exceeded %d s in phase '%s'; exit code %d" % (timeout_s, phase[0], WATCHDOG_EXIT_CODE),
+                            "hung_phase": phase[0]}
+            print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        sys.stderr.write("bench.py: watchdog fired on rank %d in phase '%s'\n" % (rank, phase[0]))
+        sys.stderr.flush()
+        _exit(WATCHDOG_EXIT_CODE)
+
+    wd = threading.Timer(timeout_s, give_up)
+    wd.daemon = True
+    wd.start()
+    return wd
 
 
 def spawn_ranks(args):
@@ -480,25 +509,17 @@ def main():
     if not args.no_extras:
         # secondary lines, run by EVERY rank (N > 1: the data-parallel training step has collectives).  The headline must survive them: an
         # exception is reported under `extra`; if a rank hangs, every rank's watchdog fires, rank 0 prints the headline and all exit.
-        import threading
-
-        def give_up():
-            if rank == 0:
-                out["extra"] = {"error": "secondary measurements exceeded %d s" % args.extras_timeout}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-
-        wd = threading.Timer(args.extras_timeout, give_up)
-        wd.daemon = True
-        wd.start()
+        phase = ["policy_config / training"]             # what the watchdog reports: the secondary measurement that was running
+        wd = start_watchdog(args.extras_timeout, rank, out, phase)
         del bufs, env, gather
         torch.cuda.empty_cache()
         try:
-            ex = extras(G, world, rank, dev, args.seed_base, backend)
+            ex = extras(G, world, rank, dev, args.seed_base, backend, phase)
         except Exception as e:
             ex = {"error": repr(e)}
         if world == 1:
             for name, fn in (("facade_config1", facade_config1), ("players_selfplay", lambda: players_selfplay(G))):
+                phase[0] = name
                 try:
                     ex[name] = fn()
                 except Exception as e:

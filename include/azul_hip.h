@@ -207,13 +207,13 @@ typedef struct azul_call {
     uint32_t want;
     const void *record_in;          /* NULL or the game's record (azul_batch_record_bytes bytes; validated like azul_batch_set_state) */
     const uint32_t *mt_in;          /* NULL or 624 words: the stream to draw from (random.getstate()[1][:624]) */
-    uint32_t pos_in;                /* the stream's index BEFORE the call: random.getstate()[1][624] with mt_in, else the pos_out last received */
+    uint32_t pos_in;                /* with mt_in: the stream's index to install, random.getstate()[1][624]; ignored without mt_in */
     const uint8_t *mask_in;         /* AZUL_CALL_SAMPLE_MASK: uint8[180] */
     void *record_out;               /* AZUL_WANT_RECORD */
     uint32_t *mt_out;               /* NULL or room for 624 words, written only when rng_regenerated */
     /* out */
     uint32_t pos_out;               /* index of the game's stream after the call */
-    int32_t rng_regenerated;        /* the call regenerated the 624 words (they are in mt_out if given) */
+    int32_t rng_regenerated;        /* the call regenerated the 624 words (reported by the kernel itself; they are in mt_out if given) */
     int32_t status;                 /* AZUL_OK / AZUL_ILLEGAL_MOVE / ... */
     int32_t reward, done;           /* AZUL_CALL_RUNNER_STEP */
     int32_t action;                 /* AZUL_CALL_SAMPLE_MASK (-1: nothing legal) */

@@ -95,3 +95,36 @@ def test_single_gpu_line_keeps_its_shape():
     assert out["n_gpus"] == 1 and out["roofline"]["bound"] == "hbm" and out["roofline"]["frac"] > 0
     assert "nothing is exchanged" in out["config"]["parallelism"]
     assert out["extra"]["training"]["n_gpus"] == 1 and out["extra"]["policy_config"]["roofline"]["bound"] == "mfma"
+
+
+def test_watchdog_prints_the_headline_and_exits_non_zero(capsys):
+    """A hang inside the secondary measurements (a GPU process that does not come back, a collective one rank never entered) must not
+    be reported as success: the watchdog prints rank 0's headline with the phase that was running, then leaves with a NON-ZERO code."""
+    sys.path.insert(0, ROOT)
+    import bench
+    codes = []
+    out = {"metric": "m", "value": 1.0}
+    phase = ["training"]
+    wd = bench.start_watchdog(0.05, 0, out, phase, _exit=codes.append)
+    wd.join(5)
+    assert codes == [bench.WATCHDOG_EXIT_CODE] and bench.WATCHDOG_EXIT_CODE != 0
+    line = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    got = json.loads(line[0])
+    assert got["value"] == 1.0 and got["extra"]["hung_phase"] == "training" and "exceeded" in got["extra"]["error"]
+    # other ranks print nothing but leave with the same code
+    codes.clear()
+    wd = bench.start_watchdog(0.05, 1, None, ["players_selfplay"], _exit=codes.append)
+    wd.join(5)
+    assert codes == [bench.WATCHDOG_EXIT_CODE]
+    assert not [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+
+
+def test_watchdog_exit_code_reaches_the_shell():
+    """The real os._exit path, in a child process: exit code 3, the JSON line flushed before it."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; "
+            "bench.start_watchdog(0.05, 0, {'value': 2.0}, ['facade_config1']); time.sleep(30)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert json.loads(r.stdout.strip().splitlines()[-1])["extra"]["hung_phase"] == "facade_config1"
+    assert "watchdog fired" in r.stderr

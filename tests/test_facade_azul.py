@@ -347,3 +347,20 @@ def test_first_player_rule_range_follows_the_number_of_players(facade):
         seen.add(facade.Azul(players=3, rules={"first_player": "Random"}).next_first_player)
     assert seen == {1, 2, 3}
     random.seed()
+
+
+def test_float_typed_attributes_are_accepted_like_the_reference(facade, resources_dir):
+    """Callers assign attributes freely (reference tests/test_azul.py:75, tests/test_game_runner.py:38,46); the reference's arrays
+    are int arrays but nothing stops game.score = np.array([3., 0.]).  Integral floats work as before; a fractional value is named."""
+    g = load(facade, resources_dir, "game_end_of_round_1")
+    twin = load(facade, resources_dir, "game_end_of_round_1")
+    g.score = np.array([3.0, 0.0])
+    twin.score = np.array([3, 0])
+    g.floors = g.floors.astype(float)
+    g.pattern_lines = g.pattern_lines.astype(np.float32)
+    g.count_score()
+    twin.count_score()
+    assert g == twin and g.score.dtype.kind == "i"
+    g.score = np.array([1.5, 0.0])
+    with pytest.raises(ValueError, match="score must hold integral values"):
+        g.count_score()

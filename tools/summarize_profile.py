@@ -70,15 +70,21 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     if pitch >= 192 and "write_bytes_per_counted_KB_u64_rows192" in fac:      # round 3: one 8-byte store per lane, 184 bytes per padded row
         wkey = "write_bytes_per_counted_KB_u64_rows192"
         payload = 184 + 4 + 4 + 1 + 4 + (24 if bench["config"].get("mask_bits_stream", True) else 0)
-    w = pmc["WRITE_SIZE"]["mean"] * fac.get(wkey, 1024.0)
+    # WRITE_SIZE counts whole 32-byte sectors and is exact for stores (MI355X_MICROARCH.md, HBM / rocprofv3 section): 1024 bytes per
+    # counted KB.  The calibration kernels confirm it -- `calib_write_u64_rows192` stores 184 payload bytes into every 192-byte row and
+    # the counter reports the 192: payload / counter = 981.3 B per counted KB is the PAYLOAD fraction (184 / 192), not an HBM-byte
+    # correction (round 3 multiplied by it and understated the write traffic by 4 %).
+    w = pmc["WRITE_SIZE"]["mean"] * 1024.0
     summary["hbm_bytes_per_launch"] = {"fetch": f, "write": w, "total": f + w,
-                                        "write_calibration": wkey if "WRITE_SIZE" in pmc else None,
+                                        "write_bytes_per_counted_KB": 1024.0,
+                                        "payload_per_counted_KB_in_calibration": fac.get(wkey),
                                         "payload_bytes_written_per_move": payload,
-                                        "note": "counter KB x calibration factor measured in this path's access widths"}
+                                        "write_amplification": w / waves_steps_for_traffic / payload,
+                                        "note": "FETCH_SIZE x the read calibration of this path's access widths; WRITE_SIZE x 1024 (exact for stores)"}
     json.dump({"bytes_per_launch": f + w, "fetch": f, "write": w, "source": "profiles/%s_summary.json" % name,
                "games": bench["config"]["games_per_gpu"], "moves_per_launch": bench["config"]["moves_per_launch"],
                "bytes_per_move": (f + w) / waves_steps_for_traffic, "write_bytes_per_move": w / waves_steps_for_traffic,
-               "payload_bytes_written_per_move": payload,
+               "payload_bytes_written_per_move": payload, "write_amplification": w / waves_steps_for_traffic / payload,
                "kernel": bench["roofline"].get("kernel", "?"),
                "launch": "%s, %d games x %d moves" % (bench["roofline"].get("kernel", "?"), bench["config"]["games_per_gpu"], bench["config"]["moves_per_launch"])}, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 waves_steps = bench["config"]["games_per_gpu"] * bench["config"]["moves_per_launch"]

@@ -164,11 +164,21 @@ static int pidx(const oz_game *g)
     return p;
 }
 
-int oz_init(oz_game *g, int players, int first_player, int tile_pool, oz_rng *r)
+/* ---- beyond the reference: D displays, the finite bag (see the OZ_EXT_* flags in azul_oracle.h) ---- */
+static int nd(const oz_game *g) { return g->n_displays > 0 ? g->n_displays : 5; }          /* azul.py:19 unless OZ_EXT_DISPLAYS_2P1 */
+static int64_t *drow(oz_game *g, int d) { return d < 5 ? g->displays[d] : g->xdisplays[d - 5]; }
+static const int64_t *drow_c(const oz_game *g, int d) { return d < 5 ? g->displays[d] : g->xdisplays[d - 5]; }
+/* tiles are tracked (box / lid) under the reference's "Lid" pool (azul.py:48-52) and under the finite bag */
+static int tracks_tiles(const oz_game *g) { return g->tile_pool == OZ_POOL_LID || (g->ext & OZ_EXT_FINITE_BAG); }
+
+int oz_init_ext(oz_game *g, int players, int first_player, int tile_pool, int ext, oz_rng *r)
 {
     /* azul.py:18-61 */
     memset(g, 0, sizeof(*g));
     g->players = players;
+    g->ext = ext;
+    /* rulebook, "Setup": "In a 2-player game, place 5 Factory displays ... 3-player game: 7 ... 4-player game: 9" */
+    g->n_displays = (ext & OZ_EXT_DISPLAYS_2P1) ? 2 * players + 1 : 5;
     if (first_player == 0) {                                   /* "Random", azul.py:36-37: random.choice([1..players]) */
         g->next_first_player = 1 + (int)oz_rng_randbelow(r, (uint32_t)players);
     } else if (first_player > 0) {                             /* azul.py:38-41 */
@@ -179,11 +189,20 @@ int oz_init(oz_game *g, int players, int first_player, int tile_pool, oz_rng *r)
     }
     g->tile_pool = tile_pool;
     if (tile_pool == OZ_POOL_LID) {                            /* azul.py:48-52 */
+        if (ext & OZ_EXT_FINITE_BAG) return OZ_ILLEGAL_RULE;   /* the "Lid" pool already is a finite bag */
         for (int c = 0; c < 5; c++) { g->box[c] = 20; g->lid[c] = 0; }
     } else if (tile_pool != OZ_POOL_RANDOM) {
         return OZ_ILLEGAL_RULE;
+    } else if (ext & OZ_EXT_FINITE_BAG) {
+        /* rulebook, "Setup": "Fill the bag with the 100 tiles (20 of each color)" */
+        for (int c = 0; c < 5; c++) { g->box[c] = 20; g->lid[c] = 0; }
     }
     return OZ_OK;
+}
+
+int oz_init(oz_game *g, int players, int first_player, int tile_pool, oz_rng *r)
+{
+    return oz_init_ext(g, players, first_player, tile_pool, 0, r);
 }
 
 int oz_new_round(oz_game *g, oz_rng *r)
@@ -200,25 +219,42 @@ int oz_new_round(oz_game *g, oz_rng *r)
     for (int c = 0; c < 5; c++) g->center[c] = 0;
     g->center[5] = 1;
     memset(g->displays, 0, sizeof(g->displays));
-    for (int i = 0; i < 5; i++) {
+    memset(g->xdisplays, 0, sizeof(g->xdisplays));
+    for (int i = 0; i < nd(g); i++) {                           /* azul.py:75: range(5) */
         for (int j = 0; j < 4; j++) {
-            if (g->tile_pool == OZ_POOL_RANDOM) {
+            if (g->tile_pool == OZ_POOL_RANDOM && !(g->ext & OZ_EXT_FINITE_BAG)) {
                 /* azul.py:78 random.randrange(0,5,1) -> _randbelow(5) */
-                g->displays[i][oz_rng_randbelow(r, 5)] += 1;
+                drow(g, i)[oz_rng_randbelow(r, 5)] += 1;
             }
-            if (g->tile_pool == OZ_POOL_LID) {
+            if (tracks_tiles(g)) {
                 int64_t total = 0;
                 for (int c = 0; c < 5; c++) total += g->box[c];
                 if (total == 0) {                               /* azul.py:81-83 */
+                    /* rulebook, "Preparing the next round": "If the bag is empty, refill it with all the tiles that you have placed
+                     * in the lid of the game box and then continue filling the remaining Factory displays." */
                     for (int c = 0; c < 5; c++) { g->box[c] = g->lid[c]; g->lid[c] = 0; }
                 }
                 total = 0;
                 for (int c = 0; c < 5; c++) total += g->box[c];      /* azul.py:85 */
-                if (total == 0) return OZ_BOX_EMPTY;            /* reference: ValueError out of random.choices */
-                double w[5];
-                for (int c = 0; c < 5; c++) w[c] = (double)g->box[c] / (double)total;   /* azul.py:87 */
-                int color = oz_rng_choices(r, w, 5);
-                g->displays[i][color] += 1;                     /* azul.py:88 */
+                if (total == 0) {
+                    /* rulebook: "In the rare case that you run out of tiles again while there are none left in the lid, start the
+                     * new round as usual even though not all Factory displays are properly filled." */
+                    if (g->ext & OZ_EXT_SHORT_DEAL) return OZ_OK;
+                    return OZ_BOX_EMPTY;                        /* reference: ValueError out of random.choices (TODO azul.py:86) */
+                }
+                int color;
+                if (g->tile_pool == OZ_POOL_LID) {
+                    double w[5];
+                    for (int c = 0; c < 5; c++) w[c] = (double)g->box[c] / (double)total;   /* azul.py:87 */
+                    color = oz_rng_choices(r, w, 5);
+                } else {
+                    /* finite bag for the "Random" pool (the TODO at azul.py:72): one of the `total` tiles in the bag, uniformly --
+                     * random.randrange(total) = _randbelow(total) -- tiles ordered by colour; pure integer arithmetic */
+                    int64_t k = (int64_t)oz_rng_randbelow(r, (uint32_t)total), cum = 0;
+                    color = 0;
+                    for (int c = 0; c < 5; c++) { cum += g->box[c]; if (k < cum) { color = c; break; } }
+                }
+                drow(g, i)[color] += 1;                         /* azul.py:88 */
                 g->box[color] -= 1;                             /* azul.py:89 */
             }
         }
@@ -240,10 +276,11 @@ void oz_move(oz_game *g, int display, int color, int pattern)
     int p = pidx(g);
     int64_t nr_tiles;
     if (display != 0) {
-        nr_tiles = g->displays[display - 1][color];             /* :127 */
-        g->displays[display - 1][color] = 0;                    /* :129 */
-        for (int c = 0; c < 5; c++) g->center[c] += g->displays[display - 1][c];   /* :131 */
-        for (int c = 0; c < 5; c++) g->displays[display - 1][c] = 0;               /* :133 */
+        int64_t *dsp = drow(g, display - 1);
+        nr_tiles = dsp[color];                                  /* :127 */
+        dsp[color] = 0;                                         /* :129 */
+        for (int c = 0; c < 5; c++) g->center[c] += dsp[c];     /* :131 */
+        for (int c = 0; c < 5; c++) dsp[c] = 0;                 /* :133 */
     } else {
         nr_tiles = g->center[color];                            /* :136 */
         g->center[color] = 0;                                   /* :138 */
@@ -260,11 +297,11 @@ void oz_move(oz_game *g, int display, int color, int pattern)
         } else {
             g->pattern_lines[p][pattern - 1][color] = pattern;                             /* :152 */
             add_to_floor(g, -overflow);                                                    /* :154 */
-            if (g->tile_pool == OZ_POOL_LID) g->lid[color] += -overflow;                   /* :156-157 */
+            if (tracks_tiles(g)) g->lid[color] += -overflow;                               /* :156-157 */
         }
     } else {
         add_to_floor(g, nr_tiles);                                                         /* :159 */
-        if (g->tile_pool == OZ_POOL_LID) g->lid[color] += nr_tiles;                        /* :160-161 */
+        if (tracks_tiles(g)) g->lid[color] += nr_tiles;                                    /* :160-161 */
     }
 }
 
@@ -273,7 +310,7 @@ int oz_is_legal_move(const oz_game *g, int display, int color, int pattern)
     /* azul.py:162-176 */
     int p = pidx(g);
     if (display > 0) {
-        if (g->displays[display - 1][color] < 1) return 0;
+        if (drow_c(g, display - 1)[color] < 1) return 0;
     } else {
         if (g->center[color] < 1) return 0;
     }
@@ -298,7 +335,7 @@ int oz_is_end_of_round(const oz_game *g)
 {
     /* azul.py:182-183 (the first-player token counts) */
     int nz = 0;
-    for (int d = 0; d < 5; d++) for (int c = 0; c < 5; c++) nz += (g->displays[d][c] != 0);
+    for (int d = 0; d < nd(g); d++) for (int c = 0; c < 5; c++) nz += (drow_c(g, d)[c] != 0);
     for (int c = 0; c < 6; c++) nz += (g->center[c] != 0);
     return nz < 1;
 }
@@ -340,7 +377,7 @@ static int64_t count_wall(oz_game *g, int player)
             if (g->pattern_lines[player][pattern][color] == pattern + 1) {                 /* :216 */
                 g->pattern_lines[player][pattern][color] = 0;                              /* :218 */
                 g->walls[player][pattern][color] = 1;                                      /* :219 */
-                if (g->tile_pool == OZ_POOL_LID) g->lid[color] += pattern;                 /* :220-222 */
+                if (tracks_tiles(g)) g->lid[color] += pattern;                             /* :220-222 */
                 int64_t pos_count = 0, bonus_count = 0;
                 int only_row = 1, only_col = 1;
                 for (int i = to_wall_position(color, pattern) + 1; i < 5; i++) {           /* :230-236 */
@@ -378,6 +415,9 @@ static int64_t count_wall(oz_game *g, int player)
                         if (k == 4) { bonus_count += 7; g->completed_lines[player][2] += 1; }
                     } else break;
                 }
+                /* OZ_EXT_END_BONUS: the line bonuses are paid once, when the game has ended (oz_end_game_bonus); the
+                 * completed_lines statistics are still counted as the lines complete */
+                if (g->ext & OZ_EXT_END_BONUS) bonus_count = 0;
                 count += pos_count + bonus_count;                                          /* :289 */
             }
         }
@@ -396,6 +436,33 @@ void oz_count_score(oz_game *g)
     }
 }
 
+void oz_end_game_bonus(oz_game *g)
+{
+    /* rulebook, "End of the game": "Once the game has ended, score additional points if you have achieved the following goals:
+     * Gain 2 points for each complete horizontal line of 5 consecutive tiles on your wall.  Gain 7 points for each complete
+     * vertical line of 5 consecutive tiles on your wall.  Gain 10 points for each color of which you have placed all 5 tiles on
+     * your wall."  Paid once, after the last round's scoring and its clamp (azul.py:294-295). */
+    for (int p = 0; p < g->players; p++) {
+        int64_t bonus = 0;
+        for (int row = 0; row < 5; row++) {                     /* horizontal lines */
+            int n = 0;
+            for (int c = 0; c < 5; c++) n += (g->walls[p][row][c] != 0);
+            if (n == 5) bonus += 2;
+        }
+        for (int col = 0; col < 5; col++) {                     /* vertical lines: board column of (row, colour) is (colour + row) % 5 */
+            int n = 0;
+            for (int row = 0; row < 5; row++) n += (g->walls[p][row][from_wall_position(col, row)] != 0);
+            if (n == 5) bonus += 7;
+        }
+        for (int c = 0; c < 5; c++) {                           /* colours */
+            int n = 0;
+            for (int row = 0; row < 5; row++) n += (g->walls[p][row][c] != 0);
+            if (n == 5) bonus += 10;
+        }
+        g->score[p] += bonus;
+    }
+}
+
 int oz_step(oz_game *g, int display, int color, int pattern, oz_rng *r)
 {
     /* azul.py:296-313 */
@@ -404,7 +471,10 @@ int oz_step(oz_game *g, int display, int color, int pattern, oz_rng *r)
     oz_move(g, display, color, pattern);
     if (oz_is_end_of_round(g)) {
         oz_count_score(g);
-        if (oz_is_end_of_game(g)) g->end_of_game = 1;
+        if (oz_is_end_of_game(g)) {
+            g->end_of_game = 1;
+            if (g->ext & OZ_EXT_END_BONUS) oz_end_game_bonus(g);
+        }
         else return oz_new_round(g, r);
     } else {
         oz_next_player(g);
@@ -496,6 +566,76 @@ void oz_get_state(const oz_game *g, int perspective, int64_t out[136])
     }
     int k = 0;
     for (int d = 0; d < 5; d++) for (int c = 0; c < 5; c++) out[k++] = g->displays[d][c];
+    for (int c = 0; c < 6; c++) out[k++] = g->center[c];
+    for (int i = 0; i < g->players; i++) for (int r = 0; r < 5; r++) for (int c = 0; c < 5; c++) out[k++] = g->pattern_lines[order[i]][r][c];
+    for (int i = 0; i < g->players; i++) for (int r = 0; r < 5; r++) for (int c = 0; c < 5; c++) out[k++] = g->walls[order[i]][r][c];
+    for (int i = 0; i < g->players; i++) out[k++] = g->floors[order[i]];
+    for (int i = 0; i < g->players; i++) out[k++] = g->score[order[i]];
+    out[k++] = pnfp;
+}
+
+/* ---- the same wrapper functions for D displays / P players (beyond the reference: game_runner.py hard-codes 6, 180 and two players) ---- */
+int oz_num_actions(const oz_game *g) { return (nd(g) + 1) * 5 * 6; }                         /* game_runner.py:115: 6*5*6 */
+int oz_obs_size(const oz_game *g) { return nd(g) * 5 + 6 + g->players * 52 + 1; }           /* game_runner.py:65-72 */
+
+void oz_deserialize_x(const oz_game *g, int a, int *display, int *color, int *pattern)
+{
+    /* game_runner.py:107-111 with 6 -> D + 1 */
+    const int S = nd(g) + 1;
+    *display = a % S;
+    *color = (a / S) % 5;
+    *pattern = a / (5 * S);
+}
+
+void oz_check_all_valid_x(const oz_game *g, uint8_t *out)
+{
+    /* game_runner.py:113-117 */
+    const int n = oz_num_actions(g);
+    for (int i = 0; i < n; i++) {
+        int d, c, p;
+        oz_deserialize_x(g, i, &d, &c, &p);
+        out[i] = (uint8_t)oz_is_legal_move(g, d, c, p);
+    }
+}
+
+int oz_random_agent_x(const uint8_t *mask, int n_actions, oz_rng *r)
+{
+    /* game_runner.py:87-97: weight 0.01 for pattern == 0 (the first n_actions / 6 actions), 1.0 otherwise, times the mask;
+     * random.choices(range(n_actions), weights) */
+    double cum[OZ_MAX_ACTIONS];
+    double acc = 0.0;
+    const int floor_moves = n_actions / 6;
+    for (int a = 0; a < n_actions; a++) {
+        double w = (a < floor_moves ? 0.01 : 1.0) * (mask[a] ? 1.0 : 0.0);
+        acc = (a == 0) ? w : acc + w;
+        cum[a] = acc;
+    }
+    double total = cum[n_actions - 1] + 0.0;
+    if (total <= 0.0) return -1;
+    double x = oz_rng_random(r) * total;
+    int lo = 0, hi = n_actions - 1;                 /* bisect_right(cum, x, 0, n-1) */
+    while (lo < hi) {
+        int mid = (lo + hi) / 2;
+        if (x < cum[mid]) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+void oz_get_state_x(const oz_game *g, int perspective, int64_t *out)
+{
+    /* game_runner.py:56-72: order = [perspective] + the other players ascending (a set of small ints iterates in order) */
+    int order[OZ_MAXP];
+    int n = 0;
+    order[n++] = perspective;
+    for (int p = 0; p < g->players; p++) if (p != perspective) order[n++] = p;
+    int64_t pnfp = 0;
+    if (g->next_first_player > 0) {
+        int m = (g->next_first_player - 1 - perspective) % g->players;
+        if (m < 0) m += g->players;
+        pnfp = m + 1;
+    }
+    int k = 0;
+    for (int d = 0; d < nd(g); d++) for (int c = 0; c < 5; c++) out[k++] = drow_c(g, d)[c];
     for (int c = 0; c < 6; c++) out[k++] = g->center[c];
     for (int i = 0; i < g->players; i++) for (int r = 0; r < 5; r++) for (int c = 0; c < 5; c++) out[k++] = g->pattern_lines[order[i]][r][c];
     for (int i = 0; i < g->players; i++) for (int r = 0; r < 5; r++) for (int c = 0; c < 5; c++) out[k++] = g->walls[order[i]][r][c];
@@ -695,6 +835,12 @@ int oz_pack_np(const oz_game *g, uint8_t rec[256])
     for (int p = 0; p < P; p++) { CHK(g->max_combo[p], 0, 255); rec[188 + p] = (uint8_t)g->max_combo[p]; }
     for (int p = 0; p < P; p++) for (int k = 0; k < 3; k++) { CHK(g->completed_lines[p][k], 0, 255); rec[192 + p * 3 + k] = (uint8_t)g->completed_lines[p][k]; }
     rec[204] = (uint8_t)P;
+    /* beyond the reference: factory displays 5 .. 8 live in bytes 208 .. 227 and byte 205 holds their total number when it is not
+     * the reference's five -- a five-display record is byte for byte what it was */
+    if (nd(g) != 5) {
+        rec[205] = (uint8_t)nd(g);
+        for (int d = 5; d < nd(g); d++) for (int c = 0; c < 5; c++) { CHK(g->xdisplays[d - 5][c], 0, 255); rec[208 + (d - 5) * 5 + c] = (uint8_t)g->xdisplays[d - 5][c]; }
+    }
 #undef CHK
     return bad ? -1 : 0;
 }
@@ -726,6 +872,8 @@ void oz_unpack_np(oz_game *g, const uint8_t rec[256], int tile_pool)
     for (int p = 0; p < P; p++) g->floor_penalty[p] = get16s(rec + 180 + 2 * p);
     for (int p = 0; p < P; p++) g->max_combo[p] = rec[188 + p];
     for (int p = 0; p < P; p++) for (int k = 0; k < 3; k++) g->completed_lines[p][k] = rec[192 + p * 3 + k];
+    g->n_displays = rec[205] ? rec[205] : 5;
+    for (int d = 5; d < g->n_displays && d < OZ_MAX_DISPLAYS; d++) for (int c = 0; c < 5; c++) g->xdisplays[d - 5][c] = rec[208 + (d - 5) * 5 + c];
 }
 
 /* ------------------------------------------------------------------------- */
@@ -836,6 +984,57 @@ int oz_stream_np_advance(oz_game *g, oz_rng *r, int first_player, int n_steps, u
                 if (episodes) (*episodes)++;
             }
             int st = oz_init(g, players, first_player, tile_pool, r);
+            if (st) return st;
+            st = oz_new_round(g, r);
+            if (st) return st;
+        }
+    }
+    return OZ_OK;
+}
+
+/* The same flat loop under extended rules (flags in g->ext; ext == 0 reproduces oz_stream_np_*): mask rows and the sampler follow the
+ * game's action space (oz_num_actions). */
+int oz_stream_x_start(oz_game *g, oz_rng *r, uint64_t seed, int players, int first_player, int tile_pool, int ext)
+{
+    oz_rng_seed(r, seed);
+    int st = oz_init_ext(g, players, first_player, tile_pool, ext, r);
+    if (st) return st;
+    return oz_new_round(g, r);
+}
+
+int oz_stream_x_advance(oz_game *g, oz_rng *r, int first_player, int n_steps, uint8_t *mask, int32_t *action, uint8_t *done,
+                        uint8_t *rec_after, uint64_t *stuck_count, uint64_t *episodes, double *stats_sum)
+{
+    const int players = g->players, tile_pool = g->tile_pool, ext = g->ext, na = oz_num_actions(g);
+    for (int t = 0; t < n_steps; t++) {
+        uint8_t m[OZ_MAX_ACTIONS];
+        oz_check_all_valid_x(g, m);
+        if (mask) memcpy(mask + (size_t)t * na, m, (size_t)na);
+        int a = g->end_of_game ? -1 : oz_random_agent_x(m, na, r);
+        int dn;
+        if (a < 0) {
+            if (stuck_count) (*stuck_count)++;
+            dn = 2;
+        } else {
+            int d, c, p;
+            oz_deserialize_x(g, a, &d, &c, &p);
+            int st = oz_step(g, d, c, p, r);
+            if (st) return st;
+            dn = g->end_of_game ? 1 : 0;
+        }
+        if (action) action[t] = a;
+        if (done) done[t] = (uint8_t)dn;
+        if (rec_after) oz_pack_np(g, rec_after + (size_t)t * 256);
+        if (dn) {
+            if (dn == 1) {
+                if (stats_sum) {
+                    double s[10];
+                    oz_get_statistics(g, s);
+                    for (int i = 0; i < 10; i++) stats_sum[i] += s[i];
+                }
+                if (episodes) (*episodes)++;
+            }
+            int st = oz_init_ext(g, players, first_player, tile_pool, ext, r);
             if (st) return st;
             st = oz_new_round(g, r);
             if (st) return st;

@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libazul_oracle.so")
 
 POOL_RANDOM, POOL_LID = 0, 1
+# extended rules, beyond the reference (azul_oracle.h OZ_EXT_*; "parity unpinned")
+EXT_DISPLAYS_2P1, EXT_END_BONUS, EXT_SHORT_DEAL, EXT_FINITE_BAG = 1, 2, 4, 8
 FIRST_RANDOM, FIRST_ABSENT = 0, -1
 OK, ILLEGAL_MOVE, GAME_ENDED, STUCK, ILLEGAL_RULE, BOX_EMPTY = range(6)
 
@@ -55,6 +57,7 @@ class Game(C.Structure):
         ("first_player_stats", C.c_double * 4), ("floor_penalty", C.c_double * 4),
         ("max_combo", C.c_double * 4), ("completed_lines", (C.c_double * 3) * 4),
         ("box", C.c_int64 * 5), ("lid", C.c_int64 * 5),
+        ("n_displays", C.c_int32), ("ext", C.c_int32), ("xdisplays", (C.c_int64 * 5) * 4),
     ]
 
     def arr(self, name):
@@ -114,6 +117,16 @@ def lib():
         "oz_stream_advance": (C.c_int, [P(Runner), P(Rng), C.c_int, u8p, i32p, i32p, u8p, u8p, u64p, u64p, f64p]),
         "oz_stream_np_start": (C.c_int, [P(Game), P(Rng), C.c_uint64, C.c_int, C.c_int, C.c_int]),
         "oz_stream_np_advance": (C.c_int, [P(Game), P(Rng), C.c_int, C.c_int, u8p, i32p, u8p, u8p, u64p, u64p, f64p]),
+        "oz_init_ext": (C.c_int, [P(Game), C.c_int, C.c_int, C.c_int, C.c_int, P(Rng)]),
+        "oz_end_game_bonus": (None, [P(Game)]),
+        "oz_num_actions": (C.c_int, [P(Game)]),
+        "oz_obs_size": (C.c_int, [P(Game)]),
+        "oz_deserialize_x": (None, [P(Game), C.c_int, P(C.c_int), P(C.c_int), P(C.c_int)]),
+        "oz_check_all_valid_x": (None, [P(Game), u8p]),
+        "oz_random_agent_x": (C.c_int, [u8p, C.c_int, P(Rng)]),
+        "oz_get_state_x": (None, [P(Game), C.c_int, P(C.c_int64)]),
+        "oz_stream_x_start": (C.c_int, [P(Game), P(Rng), C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "oz_stream_x_advance": (C.c_int, [P(Game), P(Rng), C.c_int, C.c_int, u8p, i32p, u8p, u8p, u64p, u64p, f64p]),
         "oz_bench_selfplay": (C.c_uint64, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u64p]),
     }
     for name, (res, args) in sig.items():
@@ -168,7 +181,8 @@ RECORD_NP_DTYPE = np.dtype([
     ("pattern_lines", "u1", (4, 5, 5)), ("floors", "u1", (4,)), ("walls", "<u4", (4,)),
     ("score", "<i2", (4,)), ("box", "u1", (5,)), ("lid", "u1", (5,)), ("turn_counter", "<u2"),
     ("first_player_stats", "<u2", (4,)), ("floor_penalty", "<i2", (4,)), ("max_combo", "u1", (4,)),
-    ("completed_lines", "u1", (4, 3)), ("players", "u1"), ("pad", "u1", (51,)),
+    ("completed_lines", "u1", (4, 3)), ("players", "u1"),
+    ("n_displays", "u1"), ("pad0", "u1", (2,)), ("xdisplays", "u1", (4, 5)), ("pad", "u1", (28,)),     # beyond the reference: displays 5..8
 ])
 assert RECORD_NP_DTYPE.itemsize == 256
 
@@ -180,13 +194,26 @@ def pack_np(game):
     return rec.view(RECORD_NP_DTYPE)[0]
 
 
-def unpack_np(rec, tile_pool=POOL_RANDOM):
+def unpack_np(rec, tile_pool=POOL_RANDOM, ext=0):
     a = np.asarray(rec)
     raw = np.frombuffer(a.tobytes(), dtype=np.uint8).copy()
     assert raw.size == 256
     g = Game()
     lib().oz_unpack_np(C.byref(g), _p(raw, C.c_uint8), tile_pool)
+    g.ext = ext
     return g
+
+
+def check_all_valid_x(game):
+    out = np.zeros(lib().oz_num_actions(C.byref(game)), dtype=np.uint8)
+    lib().oz_check_all_valid_x(C.byref(game), _p(out, C.c_uint8))
+    return out.astype(bool)
+
+
+def get_state_x(game, perspective=0):
+    out = np.zeros(lib().oz_obs_size(C.byref(game)), dtype=np.int64)
+    lib().oz_get_state_x(C.byref(game), perspective, _p(out, C.c_int64))
+    return out
 
 
 def check_all_valid(game):
@@ -265,6 +292,41 @@ class StreamNP:
                                         _p(self.stats_sum, C.c_double))
         if rc:
             raise RuntimeError("oz_stream_np_advance -> %d" % rc)
+        return {"mask": mask, "action": action, "done": done,
+                "rec_after": None if recs is None else recs.view(RECORD_NP_DTYPE).reshape(n_steps)}
+
+    def record(self):
+        return pack_np(self.g)
+
+    def rng_state(self):
+        return np.ctypeslib.as_array(self.r.mt).copy(), int(self.r.idx)
+
+
+class StreamX:
+    """One flat random-agent stream under EXTENDED rules (oz_stream_x_*; ext = 0 is StreamNP): ``random.seed(s); Azul(players=P, rules);
+    new_round(); RandomAgent picks every move; a fresh game when one ends``.  Mask rows are `num_actions` bytes wide."""
+
+    def __init__(self, seed, players, first_player=FIRST_RANDOM, tile_pool=POOL_LID, ext=0):
+        self.g, self.r = Game(), Rng()
+        self.first = first_player
+        self.stuck = C.c_uint64(0)
+        self.episodes = C.c_uint64(0)
+        self.stats_sum = np.zeros(10, dtype=np.float64)
+        rc = lib().oz_stream_x_start(C.byref(self.g), C.byref(self.r), int(seed), players, first_player, tile_pool, ext)
+        if rc:
+            raise RuntimeError("oz_stream_x_start -> %d" % rc)
+        self.num_actions = lib().oz_num_actions(C.byref(self.g))
+
+    def advance(self, n_steps, want_records=True):
+        mask = np.zeros((n_steps, self.num_actions), dtype=np.uint8)
+        action = np.zeros(n_steps, dtype=np.int32)
+        done = np.zeros(n_steps, dtype=np.uint8)
+        recs = np.zeros((n_steps, 256), dtype=np.uint8) if want_records else None
+        rc = lib().oz_stream_x_advance(C.byref(self.g), C.byref(self.r), self.first, n_steps, _p(mask, C.c_uint8), _p(action, C.c_int32),
+                                       _p(done, C.c_uint8), _p(recs, C.c_uint8), C.byref(self.stuck), C.byref(self.episodes),
+                                       _p(self.stats_sum, C.c_double))
+        if rc:
+            raise RuntimeError("oz_stream_x_advance -> %d" % rc)
         return {"mask": mask, "action": action, "done": done,
                 "rec_after": None if recs is None else recs.view(RECORD_NP_DTYPE).reshape(n_steps)}
 

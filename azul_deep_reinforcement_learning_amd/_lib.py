@@ -10,12 +10,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libazulhip.so")
 
 RECORD_BYTES, NUM_ACTIONS, OBS_SIZE, MT_WORDS, NUM_STATS = 128, 180, 136, 624, 10
-RECORD_BYTES_WIDE = 256         # batches of 3 or 4 players
+RECORD_BYTES_WIDE = 256         # batches of 3 or 4 players and extended-rule batches
+MAX_ACTIONS, MAX_OBS = 300, 260
+# extended rules (beyond the reference, "parity unpinned": include/azul_hip.h AZUL_RULE_*)
+RULE_DISPLAYS_2P1, RULE_END_BONUS, RULE_SHORT_DEAL, RULE_FINITE_BAG = 1, 2, 4, 8
 SUCCESS, ERR_INVALID, ERR_HIP, ERR_RANGE, ERR_RULE = 0, -1, -2, -3, -4
 OK, ILLEGAL_MOVE, GAME_ENDED, STUCK, BAD_ACTION, BOX_EMPTY = 0, 1, 2, 3, 4, 5
 POOL_RANDOM, POOL_LID = 0, 1
 FIRST_RANDOM = 0
 PERSP_PLAYER0, PERSP_PLAYER1, PERSP_CURRENT = 0, 1, 2
+PERSP_MOVER = 7
 FLAG_END_OF_ROUND, FLAG_END_OF_GAME, FLAG_ENDED_FLAG = 1, 2, 4
 A2C_FLAT_SIZE = 82082          # k-major flat layout of the parameters / gradient / Adam moments (82081 + 1 pad)
 POLICY_ARGMAX = 0xFFFFFFFFFFFFFFFF        # `seed` value: np.argmax instead of sampling (agent.py action_selection="Max")
@@ -34,7 +38,7 @@ class AzulCall(C.Structure):
                 ("record_out", C.c_void_p), ("mt_out", C.c_void_p),
                 ("pos_out", C.c_uint32), ("rng_regenerated", C.c_int32), ("status", C.c_int32), ("reward", C.c_int32), ("done", C.c_int32),
                 ("action", C.c_int32), ("flags", C.c_int32), ("potential", C.c_int32),
-                ("mask", C.c_uint8 * 180), ("obs", C.c_float * 136), ("stats", C.c_double * 10)]
+                ("mask", C.c_uint8 * (MAX_ACTIONS + 4)), ("obs", C.c_float * MAX_OBS), ("stats", C.c_double * 10)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/azul_hip.h
@@ -43,7 +47,12 @@ SIGNATURES = {
     "azul_version": (C.c_char_p, []),
     "azul_batch_create": (_i, [C.POINTER(_vp), _i, _i, _i]),
     "azul_batch_create_players": (_i, [C.POINTER(_vp), _i, _i, _i, _i]),
+    "azul_batch_create_rules": (_i, [C.POINTER(_vp), _i, _i, _i, _i, C.c_uint]),
     "azul_batch_players": (_i, [_vp]),
+    "azul_batch_displays": (_i, [_vp]),
+    "azul_batch_rule_flags": (C.c_uint, [_vp]),
+    "azul_batch_num_actions": (_i, [_vp]),
+    "azul_batch_obs_size": (_i, [_vp]),
     "azul_batch_record_bytes": (_i, [_vp]),
     "azul_batch_destroy": (_i, [_vp]),
     "azul_batch_size": (_i, [_vp]),

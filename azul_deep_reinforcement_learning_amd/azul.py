@@ -15,8 +15,8 @@ import numpy as np
 
 from . import _lib as L
 from . import facade_backend as fb
-from .batch import IllegalRule, parse_rules
-from .records import RECORD_DTYPE, RECORD_NP_DTYPE, bits_to_walls, pack_flags, unpack_flags, walls_to_bits
+from .batch import IllegalRule, parse_ext_rules, parse_rules
+from .records import RECORD_DTYPE, RECORD_NP_DTYPE, all_displays, bits_to_walls, pack_flags, unpack_flags, walls_to_bits
 
 
 def _ilist(x, name):
@@ -48,7 +48,12 @@ class Azul:
     def __init__(self, players=2, state_file=None, rules={}):
         if players not in (2, 3, 4):
             raise ValueError("Azul is a game for 2, 3 or 4 players")
-        self.game_board_displays = np.zeros((5, 5), dtype=int)
+        self._first_code, self._pool_code = parse_rules(rules, players)      # raises IllegalRule (azul.py:41,54)
+        # extended rules (beyond the reference, "parity unpinned"; batch.parse_ext_rules): all off unless the rules dict asks for them
+        self._ext = parse_ext_rules(rules, players)
+        self._displays = 2 * players + 1 if self._ext & L.RULE_DISPLAYS_2P1 else 5
+        self._sources = self._displays + 1                                   # action = display + sources * colour + 5 * sources * pattern
+        self.game_board_displays = np.zeros((self._displays, 5), dtype=int)
         self.game_board_center = np.zeros(6, dtype=int)
         self.pattern_lines = np.zeros((players, 5, 5), dtype=int)
         self.walls = np.zeros((players, 5, 5), dtype=bool)
@@ -63,13 +68,13 @@ class Azul:
         self.max_combo = np.zeros(players)
         self.completed_lines = np.zeros((players, 3))
         self.rules = rules
-        self._first_code, self._pool_code = parse_rules(rules, players)      # raises IllegalRule (azul.py:41,54)
         if self._first_code == L.FIRST_RANDOM:
             self.next_first_player = random.choice(list(range(1, players + 1)))   # azul.py:37, the global stream
         else:
             self.next_first_player = self._first_code
         self.tile_pool = "Lid" if self._pool_code == L.POOL_LID else "Random"
-        if self.tile_pool == "Lid":
+        self._tracked = self.tile_pool == "Lid" or bool(self._ext & L.RULE_FINITE_BAG)
+        if self._tracked:
             self.box_tiles = np.array([20, 20, 20, 20, 20])
             self.lid_tiles = np.array([0, 0, 0, 0, 0])
         if state_file is not None:
@@ -128,11 +133,11 @@ class Azul:
     # attributes <-> 128-byte record
     # ------------------------------------------------------------------------------------------
     def _backend(self):
-        return fb.backend(self._first_code, self._pool_code, self.players)
+        return fb.backend(self._first_code, self._pool_code, self.players, self._ext)
 
     # the record as a struct format (little endian, no padding; include/azul_hip.h): struct.pack range-checks every value for free
     _FMT2 = struct.Struct("<25B6BB50B2B2I2h5B5BH2H2h2B6BhH")                      # 128 bytes, two players
-    _FMTN = struct.Struct("<25B6BB100B4B4I4h5B5BH4H4h4B12BB51x")                   # 256 bytes, three / four players (absent players: zero)
+    _FMTN = struct.Struct("<25B6BB100B4B4I4h5B5BH4H4h4B12BBB2x20B28x")             # 256 bytes, the wide record (absent players / displays: zero)
     _RANGES = (("game_board_displays", 0, 255), ("game_board_center", 0, 255), ("pattern_lines", 0, 255), ("floors", 0, 7),
                ("score", -32768, 32767), ("box_tiles", 0, 255), ("lid_tiles", 0, 255), ("first_player_stats", 0, 65535),
                ("floor_penalty", -32768, 32767), ("max_combo", 0, 255), ("completed_lines", 0, 255))
@@ -142,15 +147,19 @@ class Azul:
         freely (numpy arrays, Python ints), so every value is range-checked against what its record field holds: struct.pack does
         that while it packs (one C call instead of a dozen numpy reductions and field assignments)."""
         P = self.players
-        wide = P != 2
+        wide = P != 2 or self._ext != 0
         pad = 4 - P if wide else 0
-        lid = self.tile_pool == "Lid"
+        lid = self._tracked
+        D = self._displays
         try:
             fl = _ilist(self.floors, "floors")
             if max(fl) > 7:
                 raise struct.error("floors")
             z = [0] * pad
-            vals = (_ilist(self.game_board_displays, "game_board_displays") + _ilist(self.game_board_center, "game_board_center")
+            disp = _ilist(self.game_board_displays, "game_board_displays")
+            if len(disp) != 5 * D:
+                raise struct.error("displays")
+            vals = (disp[:25] + _ilist(self.game_board_center, "game_board_center")
                     + [pack_flags(self._player(self.current_player), self._player(self.next_first_player), self.end_of_game)]
                     + _ilist(self.pattern_lines, "pattern_lines") + [0] * (25 * pad) + fl + z
                     + walls_to_bits(self.walls).tolist() + z + _ilist(self.score, "score") + z
@@ -161,7 +170,7 @@ class Azul:
                     + _ilist(self.max_combo, "max_combo") + z
                     + _ilist(self.completed_lines, "completed_lines") + [0] * (3 * pad))
             if wide:
-                raw = self._FMTN.pack(*vals, P)
+                raw = self._FMTN.pack(*vals, P, 0 if D == 5 else D, *(disp[25:] + [0] * (45 - 5 * D)))
             else:
                 raw = self._FMT2.pack(*vals, int(runner.player_score) if runner is not None else 0,
                                       int(runner.move_counter) if runner is not None else 0)
@@ -178,6 +187,10 @@ class Azul:
                              "0..%d, turn_counter / player_score / move_counter in their 16-bit fields)" % (P, P))
         return np.frombuffer(raw, dtype=RECORD_NP_DTYPE if wide else RECORD_DTYPE)[0]
 
+    def _action(self, display, color, pattern):
+        """nn_serialize (game_runner.py:102-103) with 6 -> displays + 1"""
+        return int(display) + self._sources * int(color) + 5 * self._sources * int(pattern)
+
     def _player(self, v):
         v = int(v)
         if not 0 <= v <= self.players:
@@ -186,14 +199,14 @@ class Azul:
 
     def _from_record(self, rec, runner=None):
         P = self.players
-        self.game_board_displays = rec["displays"].astype(int)
+        self.game_board_displays = all_displays(rec).astype(int)
         self.game_board_center = rec["center"].astype(int)
         self.current_player, self.next_first_player, self.end_of_game = unpack_flags(rec["flags"])
         self.pattern_lines = rec["pattern_lines"][:P].astype(int)
         self.floors = rec["floors"][:P].astype(int)
         self.walls = bits_to_walls(rec["walls"][:P])
         self.score = rec["score"][:P].astype(int)
-        if self.tile_pool == "Lid":
+        if self._tracked:
             self.box_tiles = rec["box"].astype(int)
             self.lid_tiles = rec["lid"].astype(int)
         self.turn_counter = int(rec["turn_counter"])
@@ -220,14 +233,14 @@ class Azul:
             raise ValueError("Total of weights must be finite")      # what random.choices raises in the reference
 
     def move(self, display, color, pattern):
-        self._run("op_move", display + 6 * color + 30 * pattern)
+        self._run("op_move", self._action(display, color, pattern))
 
     def is_legal_move(self, display, color, pattern):
         mask = self._run("op_mask", mutates=False)
-        return bool(mask[display + 6 * color + 30 * pattern])
+        return bool(mask[self._action(display, color, pattern)])
 
     def legal_mask(self):
-        """All 180 is_legal_move answers at once (what check_all_valid returns)."""
+        """All is_legal_move answers at once (what check_all_valid returns): 180, or (displays + 1) * 30 with the 2P+1 displays rule."""
         return self._run("op_mask", mutates=False)
 
     def next_player(self):
@@ -243,7 +256,7 @@ class Azul:
         self._run("op_count_score")
 
     def step(self, display, color, pattern):
-        st = self._run("op_step", display + 6 * color + 30 * pattern, draws=True)
+        st = self._run("op_step", self._action(display, color, pattern), draws=True)
         if st in _STATUS_EXC:
             raise _STATUS_EXC[st]
         if st == L.BOX_EMPTY:

@@ -1,4 +1,5 @@
-"""BatchedAzul: N concurrent two-player Azul games resident on one MI355X.
+"""BatchedAzul: N concurrent Azul games (two players like the reference's GameRunner; three / four players and extended rules for the
+rule methods and flat self-play) resident on one MI355X.
 
 Host-side mirror of the reference's env wrapper for the batched case: the method names follow
 ``azulnet.GameRunner`` (``reset`` / ``step`` / ``get_state`` / ``get_valid_moves``; reference
@@ -40,6 +41,47 @@ def parse_rules(rules, players=2):
     return first, pool
 
 
+def parse_ext_rules(rules, players=2):
+    """The extended-rule keys of a rules dict -> AZUL_RULE_* flags.  BEYOND THE REFERENCE ("parity unpinned"): the reference knows none of
+    these keys and ignores unknown ones (azul.py:35-56); all default to the reference's behaviour.
+        "displays": 5 (default) | "2P+1" (or the number 2 * players + 1)    the rulebook's 5 / 7 / 9 factory displays
+        "bonuses": "round" (default, azul.py:266-288) | "end"               +2 / +7 / +10 once, when the game has ended
+        "short_deal": False | True                                          bag and lid empty: deal what is left instead of raising
+        "finite_bag": False | True                                          tile_pool "Random" draws from a 100-tile bag"""
+    flags = 0
+    d = rules.get("displays", 5)
+    if d == "2P+1" or (type(d) == int and d == 2 * players + 1 and d != 5):
+        flags |= L.RULE_DISPLAYS_2P1
+    elif d != 5:
+        raise IllegalRule
+    b = rules.get("bonuses", "round")
+    if b == "end":
+        flags |= L.RULE_END_BONUS
+    elif b != "round":
+        raise IllegalRule
+    if rules.get("short_deal", False):
+        flags |= L.RULE_SHORT_DEAL
+    if rules.get("finite_bag", False):
+        if rules.get("tile_pool", "Random") != "Random":
+            raise IllegalRule
+        flags |= L.RULE_FINITE_BAG
+    return flags
+
+
+def ext_rules_dict(flags):
+    """AZUL_RULE_* flags -> the rules-dict keys parse_ext_rules reads."""
+    d = {}
+    if flags & L.RULE_DISPLAYS_2P1:
+        d["displays"] = "2P+1"
+    if flags & L.RULE_END_BONUS:
+        d["bonuses"] = "end"
+    if flags & L.RULE_SHORT_DEAL:
+        d["short_deal"] = True
+    if flags & L.RULE_FINITE_BAG:
+        d["finite_bag"] = True
+    return d
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -56,20 +98,31 @@ def _dev_view(ptr, shape, typestr, device):
 
 
 class BatchedAzul:
-    def __init__(self, n_games, rules={"first_player": "Random", "tile_pool": "Lid"}, device=None, seed=None, players=2):
-        """players = 3 or 4: the reference's Azul(players=...) (five displays, azul.py:19); such batches hold 256-byte records
-        (records.RECORD_NP_DTYPE) and support the Azul rule methods, not the two-player GameRunner ones."""
+    def __init__(self, n_games, rules={"first_player": "Random", "tile_pool": "Lid"}, device=None, seed=None, players=2, ext_rules=None):
+        """players = 3 or 4: the reference's Azul(players=...) (five displays, azul.py:19).  Extended rules (beyond the reference,
+        "parity unpinned") through the rules dict (parse_ext_rules: "displays": "2P+1", "bonuses": "end", "short_deal", "finite_bag")
+        or as AZUL_RULE_* flags in `ext_rules`.  Batches of 3 / 4 players and extended-rule batches hold 256-byte wide records
+        (records.RECORD_NP_DTYPE) and support the Azul rule methods, the sampler, masks, observations and selfplay -- not the
+        two-player GameRunner / policy entries."""
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedAzul needs an MI355X: there is no CPU path")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.n = int(n_games)
         self.rules = dict(rules)
         self.players = int(players)
-        self.record_dtype = RECORD_DTYPE if self.players == 2 else RECORD_NP_DTYPE
         first, pool = parse_rules(rules, self.players)
+        self.ext = parse_ext_rules(rules, self.players) | (int(ext_rules) if ext_rules else 0)
+        if (self.ext & L.RULE_FINITE_BAG) and pool != L.POOL_RANDOM:
+            raise IllegalRule
+        self.rules.update(ext_rules_dict(self.ext))
+        self.wide = self.players != 2 or self.ext != 0
+        self.record_dtype = RECORD_NP_DTYPE if self.wide else RECORD_DTYPE
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
-            L.check(L.lib.azul_batch_create_players(C.byref(self._h), self.n, self.players, first, pool))
+            L.check(L.lib.azul_batch_create_rules(C.byref(self._h), self.n, self.players, first, pool, self.ext))
+        self.displays = int(L.lib.azul_batch_displays(self._h))
+        self.num_actions = int(L.lib.azul_batch_num_actions(self._h))
+        self.obs_size = int(L.lib.azul_batch_obs_size(self._h))
         if seed is not None:
             self.seed(seed)
 
@@ -217,12 +270,12 @@ class BatchedAzul:
         return reward, done.bool(), st
 
     def get_state(self, perspective=0, out=None):
-        obs = self._new((self.n, L.OBS_SIZE), torch.float32) if out is None else out
+        obs = self._new((self.n, self.obs_size), torch.float32) if out is None else out
         L.check(L.lib.azul_batch_observe(self._h, int(perspective), _ptr(obs), self._stream()))
         return obs
 
     def get_valid_moves(self, out=None):
-        m = self._new((self.n, L.NUM_ACTIONS), torch.uint8) if out is None else out
+        m = self._new((self.n, self.num_actions), torch.uint8) if out is None else out
         L.check(L.lib.azul_batch_legal_mask(self._h, _ptr(m), self._stream()))
         return m if out is not None else m.bool()
 
@@ -232,8 +285,10 @@ class BatchedAzul:
         return a
 
     def sample_mask(self, mask, active=None):
-        """RandomAgent.get_a_output for caller-supplied masks [N][180] (one random.choices draw per game)."""
+        """RandomAgent.get_a_output for caller-supplied masks [N][num_actions] (one random.choices draw per game)."""
         m = self._dev(mask, torch.uint8)
+        if tuple(m.shape) != (self.n, self.num_actions):
+            raise ValueError("mask must be [N][%d]" % self.num_actions)
         a = torch.full((self.n,), -1, dtype=torch.int32, device=self.device)
         L.check(L.lib.azul_batch_sample_mask(self._h, _ptr(m), _ptr(self._dev(active, torch.uint8)), _ptr(a), self._stream()))
         return a
@@ -245,8 +300,10 @@ class BatchedAzul:
 
     # -- policy-driven self-play (config 3) ----------------------------------------------------------
     def observe_all(self, perspective=L.PERSP_CURRENT, obs=None, mask=None, player=None):
-        obs = self._new((self.n, L.OBS_SIZE), torch.float32) if obs is None else obs
-        mask = self._new((self.n, L.NUM_ACTIONS), torch.uint8) if mask is None else mask
+        obs = self._new((self.n, self.obs_size), torch.float32) if obs is None else obs
+        mask = self._new((self.n, self.num_actions), torch.uint8) if mask is None else mask
+        if self.wide and perspective == L.PERSP_CURRENT:
+            perspective = L.PERSP_MOVER
         player = self._new((self.n,), torch.uint8) if player is None else player
         L.check(L.lib.azul_batch_observe_all(self._h, int(perspective), _ptr(obs), _ptr(mask), _ptr(player), self._stream()))
         return obs, mask, player
@@ -268,14 +325,15 @@ class BatchedAzul:
     def selfplay(self, n_steps, mask=None, action=None, reward=None, done=None, records=None, maskbits=None, packed=None):
         """`n_steps` env moves for every game in one launch; outputs are preallocated tensors or None.  `mask` may be a
         [T][N][180] view of a wider [T][N][pitch] buffer (alloc_trajectory(mask_pitch=192)): the row pitch is taken from its
-        strides.  Batches of 3 or 4 players play the same flat loop (mask -> RandomAgent -> Azul.step, a fresh Azul + new_round()
-        at each game end: start them with init() + new_round()); their `reward` stream is all zero (the shaped reward is
-        GameRunner's, two players: game_runner.py:50), `records` rows are 256-byte wide records, mask rows are dense."""
-        pitch = L.NUM_ACTIONS
+        strides.  Batches of 3 or 4 players and extended-rule batches play the same flat loop (mask -> RandomAgent -> Azul.step, a
+        fresh Azul + new_round() at each game end: start them with init() + new_round()); their `reward` stream is all zero (the shaped
+        reward is GameRunner's, two players: game_runner.py:50), `records` rows are 256-byte wide records, mask rows num_actions bytes
+        (a padded pitch -- 192 / 256 / 320 for 5 / 7 / 9 displays -- takes the one-store-per-row path)."""
+        pitch = self.num_actions
         if mask is not None:
             pitch = mask.stride(-2)
-            if mask.stride(-1) != 1 or mask.shape[-1] != L.NUM_ACTIONS or (mask.dim() == 3 and mask.shape[0] > 1 and mask.stride(0) != self.n * pitch):
-                raise ValueError("mask must be [T][N][180] uint8 with contiguous rows and a uniform row pitch")
+            if mask.stride(-1) != 1 or mask.shape[-1] != self.num_actions or (mask.dim() == 3 and mask.shape[0] > 1 and mask.stride(0) != self.n * pitch):
+                raise ValueError("mask must be [T][N][%d] uint8 with contiguous rows and a uniform row pitch" % self.num_actions)
         L.check(L.lib.azul_batch_selfplay_strided(self._h, int(n_steps), _ptr(mask), int(pitch), _ptr(maskbits), _ptr(action), _ptr(reward),
                                                   _ptr(done), _ptr(packed), _ptr(records), self._stream()))
 
@@ -285,16 +343,17 @@ class BatchedAzul:
         contiguous arrays the multi-GPU all-gather ships.  `mask_pitch` (e.g. 192): the byte mask is a [T][N][180] view of a
         [T][N][mask_pitch] buffer, so that every game's row starts 64-byte aligned (whole-sector stores)."""
         n = self.n
-        pitch = L.NUM_ACTIONS if mask_pitch is None else int(mask_pitch)
-        store = torch.zeros((n_steps, n, pitch), dtype=torch.uint8, device=self.device) if pitch != L.NUM_ACTIONS else \
-            self._new((n_steps, n, L.NUM_ACTIONS), torch.uint8)
-        t = {"mask": store[:, :, :L.NUM_ACTIONS],
+        NA = self.num_actions
+        pitch = NA if mask_pitch is None else int(mask_pitch)
+        store = torch.zeros((n_steps, n, pitch), dtype=torch.uint8, device=self.device) if pitch != NA else \
+            self._new((n_steps, n, NA), torch.uint8)
+        t = {"mask": store[:, :, :NA],
              "action": self._new((n_steps, n), torch.int32),
              "reward": self._new((n_steps, n), torch.int32),
              "done": self._new((n_steps, n), torch.uint8)}
         if packed_mask:
             if mask_bits is None or mask_bits:          # mask_bits=False: only the compact record (what the all-gather ships by default)
-                t["maskbits"] = torch.zeros((n_steps, n, 3), dtype=torch.int64, device=self.device)
+                t["maskbits"] = torch.zeros((n_steps, n, (NA + 63) // 64), dtype=torch.int64, device=self.device)
             t["packed"] = torch.zeros((n_steps, n), dtype=torch.int32, device=self.device)
         if with_records:
             # zeroed: a 3-player batch leaves the fourth player's bytes and the reserved tail of a wide record untouched

@@ -9,7 +9,9 @@
 // Kernels
 //   azul_seed_kernel            one THREAD per game: CPython init_by_array is a strictly sequential 1247-step recurrence
 //   azul_op_kernel              one wave per game: every single-call rule / runner entry point of the ABI
-//   azul_np_op_kernel           the rule entries for batches of 3- and 4-player games (row N4; azul_core_np.hpp, 256-byte records)
+//   azul_x_op_kernel            the rule entries for batches of 3- / 4-player games and for extended-rule batches (row N4;
+//                               azul_rules_x.hpp: two games per wavefront, 256-byte wide records)
+//   azul_x_selfplay_kernel      their persistent flat self-play loop
 //   azul_selfplay_kernel        one wave per game, state register-resident across n_steps env moves (the hot path)
 //   azul_returns_kernel         discounted returns over a trajectory window
 //   azul_policy.hpp             policy head, fused ActorCritic forward, persistent policy rollout (rows N1 / N2)
@@ -26,7 +28,6 @@
 
 #include "../../include/azul_hip.h"
 #include "azul_core.hpp"
-#include "azul_core_np.hpp"
 #include "azul_tables.hpp"
 
 using namespace az;
@@ -300,99 +301,6 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
     if (a.player) AZ_LANE0(a.player[oi] = (uint8_t)g.cur);
 }
 
-// Rule entries for 3 and 4 players (row N4): Azul.__init__ / new_round / move / is_legal_move (mask) / next_player / is_end_of_round /
-// is_end_of_game / count_score / step / get_statistics, plus the RandomAgent sampler on the game's own or a caller's mask.
-// The env wrapper (GameRunner) is two-player in the reference (game_runner.py:50,57), so there is no runner / self-play entry here.
-template <u32 P, bool LID>
-__global__ void __launch_bounds__(64) azul_np_op_kernel(BatchDev b, OpArgs a)
-{
-    __shared__ u32 mt_lds[624];
-    __shared__ double fr_lds[T_ROWS * T_BINADES];
-    const u32 oi = blockIdx.x, gi = oi + a.first;      // game of the batch / row of the caller's arrays
-    const bool act = a.active ? (a.active[oi] != 0) : true;
-    uint8_t *rec = b.state + (size_t)gi * NP_RECORD_BYTES;
-    LaneConst k;
-    lane_consts(k);
-    SampleTab tab;
-    sample_tab_load(tab, b.T, fr_lds);
-    GameN<P> g;
-    gamen_load(g, rec);
-    u32 st = ST_OK, rdirty = 0;
-    if (act && a.op != OP_QUERY) {
-        Rng r;
-        const bool use_rng = op_needs_rng(a.op);
-        rng_attach(r, b.mt + (size_t)gi * 624u, mt_lds, use_rng ? b.mtpos[gi] : 0u);
-        r.margin = b.draw_margin;
-        bool dirty_state = true;
-        switch (a.op) {
-        case OP_INIT:
-            game_ctor_np<LID>(g, b.rules.first_player, r);
-            break;
-        case OP_NEW_ROUND:
-            st = new_round_np<LID>(g, r);
-            break;
-        case OP_MOVE: {
-            i32 av = a.actions[oi];
-            if (av < 0 || av >= 180) { st = ST_BAD_ACTION; dirty_state = false; break; }
-            do_move_np<LID>(g, action_code((u32)av));
-        } break;
-        case OP_NEXT_PLAYER:
-            g.cur = (g.cur < P) ? g.cur + 1u : 1u;
-            break;
-        case OP_COUNT_SCORE:
-            count_score_np<LID>(g, k);
-            break;
-        case OP_STEP:
-            st = checked_step_np<LID>(g, k, r, a.actions[oi]);
-            dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION);
-            break;
-        case OP_RANDOM_ACTION: {
-            Mask m;
-            legal_mask_np(g, k, m);
-            u32 code;
-            i32 av = random_agent(m, r, tab, k, code);
-            AZ_LANE0(a.actions_out[oi] = av);
-            dirty_state = false;
-        } break;
-        case OP_SAMPLE_MASK: {
-            const uint8_t *mi = a.mask_in + (size_t)oi * AZUL_NUM_ACTIONS;
-            vu32 l = lane();
-            Mask m;
-            m.b0 = ld_u8(mi, l, l < 64u) != 0u ? 1u : 0u;
-            m.b1 = ld_u8(mi, l + 64u, l < 64u) != 0u ? 1u : 0u;
-            m.b2 = ld_u8(mi, l + 128u, l < 52u) != 0u ? 1u : 0u;
-            m.m0 = ballot(m.b0 != 0u); m.m1 = ballot(m.b1 != 0u); m.m2 = ballot(m.b2 != 0u);
-            u32 code;
-            i32 av = random_agent(m, r, tab, k, code);
-            AZ_LANE0(a.actions_out[oi] = av);
-            dirty_state = false;
-        } break;
-        default:
-            dirty_state = false;
-            break;
-        }
-        if (dirty_state) gamen_store(g, rec);
-        if (use_rng) rng_close(r, b.mtpos + gi);
-        rdirty = r.dirty & 1u;
-    }
-    if (a.rng_dirty) AZ_LANE0(a.rng_dirty[oi] = (uint8_t)rdirty);
-    if (a.status && act) AZ_LANE0(a.status[oi] = (uint8_t)st);
-    if (a.mask) {
-        Mask m;
-        legal_mask_np(g, k, m);
-        mask_write(m, a.mask + (size_t)oi * AZUL_NUM_ACTIONS);
-    }
-    if (a.flags) {
-        u32 f = (sources_board_np(g) == 0u ? AZUL_FLAG_END_OF_ROUND : 0) | (walls_end_game_np(g) ? AZUL_FLAG_END_OF_GAME : 0) |
-                (g.eog ? AZUL_FLAG_ENDED_FLAG : 0);
-        AZ_LANE0(a.flags[oi] = (uint8_t)f);
-    }
-    if (a.stats) {
-        for (u32 q = 0; q < 10u; q++) { double sv = game_stat_np(g, q); AZ_LANE0(a.stats[(size_t)oi * 10 + q] = sv); }
-    }
-    if (a.player) AZ_LANE0(a.player[oi] = (uint8_t)g.cur);
-}
-
 // Discounted returns over the time-major trajectory of one launch window (reference loop: nn_runner.py:70-76,
 // qval = reward + gamma * qval backwards within an episode).  One thread per game walks its column backwards;
 // `done[t][g] != 0` ends an episode at move t; `carry[g]` holds the return flowing in from the NEXT window
@@ -519,57 +427,6 @@ __global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs 
 }
 
 
-// Flat random-agent self-play for THREE and FOUR players (row N4): one game per wavefront on the 256-byte wide record, persistent
-// like azul_selfplay_kernel (the game and its MT19937 stream stay in registers / LDS for the whole launch).  Dense 180-byte mask rows.
-template <u32 P, bool LID, int OUT>
-__global__ void __launch_bounds__(64) azul_np_selfplay_kernel(BatchDev b, TrajArgs t)
-{
-    __shared__ u32 mt_lds[624];
-    __shared__ double fr_lds[T_ROWS * T_BINADES];
-    const u32 gi = blockIdx.x;
-    const size_t N = b.n;
-    uint8_t *rec = b.state + (size_t)gi * NP_RECORD_BYTES;
-    LaneConst k;
-    lane_consts(k);
-    SampleTab tab;
-    sample_tab_load(tab, b.T, fr_lds);
-    GameN<P> g;
-    gamen_load(g, rec);
-    Rng r;
-    rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]);
-    r.margin = b.draw_margin;
-    Counters cnt = {b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10};
-    OutV ov;
-    OutS os = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t sm = 0, sb = 0, sa = 0, sr = 0, sd = 0, sc = 0, sp = 0;
-    if (OUT == 1) {
-        outv_open(ov, gi, b.n, t.mask, t.maskbits, t.action, t.reward, t.done, t.packed);
-    } else {
-        outv_open(ov, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-        if (OUT == 2) {
-            os.mask = t.mask ? t.mask + (size_t)gi * AZUL_NUM_ACTIONS : nullptr;
-            os.maskbits = t.maskbits ? t.maskbits + (size_t)gi * 3 : nullptr;
-            os.action = t.action ? t.action + gi : nullptr;
-            os.reward = t.reward ? t.reward + gi : nullptr;
-            os.done = t.done ? t.done + gi : nullptr;
-            os.rec = t.rec ? t.rec + (size_t)gi * NP_RECORD_BYTES : nullptr;
-            os.packed = t.packed ? t.packed + gi : nullptr;
-            sp = os.packed ? N : 0;
-            sm = os.mask ? N * AZUL_NUM_ACTIONS : 0; sb = os.maskbits ? N * 3 : 0; sa = os.action ? N : 0;
-            sr = os.reward ? N : 0; sd = os.done ? N : 0; sc = os.rec ? N * NP_RECORD_BYTES : 0;      // a NULL stream stays NULL
-        }
-    }
-#pragma unroll 1
-    for (int s = 0; s < t.n_steps; s++) {
-        u32 f = selfplay_step_np<LID, P, OUT>(g, b.rules.first_player, k, r, tab, cnt, ov, os);
-        if (f & 0x100u) break;      // rule error (box empty): leave the game as it is
-        if (OUT == 1) outv_next(ov);
-        if (OUT == 2) { os.mask += sm; os.maskbits += sb; os.action += sa; os.reward += sr; os.done += sd; os.rec += sc; os.packed += sp; }
-    }
-    gamen_store(g, rec);
-    rng_close(r, b.mtpos + gi);
-}
-
 #include "azul_selfplay2.hpp"
 
 // Flat self-play, TWO GAMES PER WAVEFRONT (azul_selfplay2.hpp): grid = ceil(N / 2) one-wave workgroups; lanes 0..31 own game
@@ -642,6 +499,31 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
     az2::rng2_close(r, gmt, b.mtpos + gi, l);
 }
 
+#include "azul_rules_x.hpp"
+
+// Rule entries for batches of three / four players and for extended-rule batches (row N4): one launch = one rule call per game, two games
+// per wavefront (azx::op_body_x).  grid = ceil(count / 2) one-wave workgroups.
+template <u32 P, u32 D>
+__global__ void __launch_bounds__(64) azul_x_op_kernel(azx::XBatchDev b, azx::XOp a)
+{
+    __shared__ u32 mt_lds[2][624];
+    __shared__ double2 tab_lds[azx::Dim<D>::TROWS * 8];
+    azx::op_body_x<P, D>(b, a, blockIdx.x, mt_lds, tab_lds);
+}
+
+// Their flat random-agent self-play, persistent like azul_selfplay2_kernel (two games per wavefront, state in VGPRs, MT19937 streams and
+// their tempered copies in LDS, XCD-aware game placement).
+template <u32 P, u32 D, int OUT, bool PAD, bool BITS>
+__global__ void __launch_bounds__(64) azul_x_selfplay_kernel(azx::XBatchDev b, azx::XTraj t)
+{
+    __shared__ u32 mt_lds[2][624];
+    __shared__ u32 mtt_lds[2][624];
+    __shared__ double2 tab_lds[azx::Dim<D>::TROWS * 8];
+    const u32 nb = gridDim.x, xcd = blockIdx.x & 7u, q8 = nb >> 3, rem = nb & 7u;
+    const u32 wave_id = xcd * q8 + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);      // every XCD plays a contiguous range of games
+    azx::selfplay_body_x<P, D, OUT, PAD, BITS>(b, t, wave_id, mt_lds, mtt_lds, tab_lds);
+}
+
 #include "azul_policy.hpp"
 #include "azul_rollout2.hpp"
 #include "azul_learner.hpp"
@@ -652,8 +534,12 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
 struct azul_batch {
     BatchDev d;          // `T` is written once by azul_batch_create
     int device;          // the device the batch's arrays live on: every entry runs there (DeviceGuard)
-    int players;         // 2 (128-byte records, every entry) or 3 / 4 (256-byte records, the rule entries: row N4)
-    int rec_bytes;
+    int players;         // 2, 3 or 4
+    int rec_bytes;       // 128 (two players under the reference's rules: every entry) or 256 (the wide record: the x path below)
+    bool x;              // three / four players, or any extended rule: the azul_rules_x.hpp kernels (rule entries + flat self-play)
+    unsigned ext;        // AZUL_RULE_* flags (0: the reference's rules)
+    int displays;        // 5, or 2 * players + 1 with AZUL_RULE_DISPLAYS_2P1
+    double *Tx;          // x path: the sampling table as {Fr[J][b], S[J]} pairs for 5 (displays + 1) + 1 rows
     hipEvent_t ev0, ev1; // bracket of a timed region (azul_timing_begin / _end)
     std::vector<hipEvent_t> lev;   // event pairs around the individual self-play launches of a timed region
     int timed_launches;  // launches since azul_timing_begin
@@ -716,11 +602,18 @@ struct DeviceGuard {
 extern "C" {
 
 const char *azul_last_error_string(void) { return g_err.c_str(); }
-const char *azul_version(void) { return "azul-mi355x 0.2 (gfx950; rule entries: one game per wavefront, self-play: two games per wavefront)"; }
+const char *azul_version(void)
+{
+    return "azul-mi355x 0.4 (gfx950; two-player rule entries: one game per wavefront; self-play, 3 / 4 players and extended rules: two games per wavefront)"
+#if defined(AZ_TIMING_EXPERIMENTS)
+           " [AZ_TIMING_EXPERIMENTS: NOT a shippable build -- timing switches that produce wrong results are compiled in]"
+#endif
+        ;
+}
 
 static void batch_free(azul_batch *b)
 {
-    void *bufs[] = {b->d.state, b->d.mt, b->d.mtpos, (void *)b->d.T, b->d.episodes, b->d.stuck, b->d.stat_sum, b->d.prof};
+    void *bufs[] = {b->d.state, b->d.mt, b->d.mtpos, (void *)b->d.T, b->d.episodes, b->d.stuck, b->d.stat_sum, b->d.prof, b->Tx};
     for (void *p : bufs) if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -751,6 +644,13 @@ static int batch_alloc(azul_batch *b, int n_games, int first_player, int tile_po
     std::vector<double> hT((size_t)T_WORDS);
     if (!build_sample_tab(hT.data())) return fail(AZUL_ERR_INVALID, "weight-table decomposition check failed on this host");
     HIP_TRY(hipMemcpy((void *)b->d.T, hT.data(), hT.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (b->x) {
+        const int rows = 5 * (b->displays + 1) + 1;
+        std::vector<double> hX((size_t)rows * 16);
+        if (!build_sample_pairs(rows, hX.data())) return fail(AZUL_ERR_INVALID, "weight-table decomposition check failed on this host");
+        HIP_TRY(hipMalloc((void **)&b->Tx, hX.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(b->Tx, hX.data(), hX.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemset(b->d.state, 0, N * RB));
     HIP_TRY(hipMemset(b->d.mt, 0, N * 624 * sizeof(u32)));
     {   // a defined stream even before azul_batch_seed: index 624 over an all-zero state is never used un-seeded
@@ -772,16 +672,29 @@ int azul_batch_create(azul_batch_t **out, int n_games, int first_player, int til
 
 int azul_batch_create_players(azul_batch_t **out, int n_games, int players, int first_player, int tile_pool)
 {
+    return azul_batch_create_rules(out, n_games, players, first_player, tile_pool, 0u);
+}
+
+int azul_batch_create_rules(azul_batch_t **out, int n_games, int players, int first_player, int tile_pool, unsigned rule_flags)
+{
     if (!out || n_games <= 0) return fail(AZUL_ERR_INVALID, "azul_batch_create: bad arguments");
     if (players < 2 || players > 4) return fail(AZUL_ERR_INVALID, "players must be 2, 3 or 4");
     if (first_player < 0 || first_player > players) return fail(AZUL_ERR_RULE, "first_player must be 0 (Random) or 1 .. players");
     if (tile_pool != AZUL_POOL_RANDOM && tile_pool != AZUL_POOL_LID) return fail(AZUL_ERR_RULE, "tile_pool must be AZUL_POOL_RANDOM or AZUL_POOL_LID");
+    if (rule_flags & ~(AZUL_RULE_DISPLAYS_2P1 | AZUL_RULE_END_BONUS | AZUL_RULE_SHORT_DEAL | AZUL_RULE_FINITE_BAG))
+        return fail(AZUL_ERR_RULE, "unknown AZUL_RULE_* flag");
+    if ((rule_flags & AZUL_RULE_FINITE_BAG) && tile_pool != AZUL_POOL_RANDOM)
+        return fail(AZUL_ERR_RULE, "AZUL_RULE_FINITE_BAG applies to tile_pool Random (the Lid pool already is a finite bag)");
     *out = nullptr;
     azul_batch *b = new azul_batch();
     memset(&b->d, 0, sizeof(b->d));
     b->device = -1;
     b->players = players;
-    b->rec_bytes = players == 2 ? AZUL_RECORD_BYTES : AZUL_RECORD_BYTES_WIDE;
+    b->ext = rule_flags;
+    b->displays = (rule_flags & AZUL_RULE_DISPLAYS_2P1) ? 2 * players + 1 : 5;
+    b->x = players != 2 || rule_flags != 0u;
+    b->rec_bytes = b->x ? AZUL_RECORD_BYTES_WIDE : AZUL_RECORD_BYTES;
+    b->Tx = nullptr;
     b->ev0 = b->ev1 = nullptr;
     b->timing = false;
     b->timed_launches = 0;
@@ -803,6 +716,10 @@ int azul_batch_destroy(azul_batch_t *b)
 
 int azul_batch_size(const azul_batch_t *b) { return b ? (int)b->d.n : 0; }
 int azul_batch_players(const azul_batch_t *b) { return b ? b->players : 0; }
+int azul_batch_displays(const azul_batch_t *b) { return b ? b->displays : 0; }
+unsigned azul_batch_rule_flags(const azul_batch_t *b) { return b ? b->ext : 0u; }
+int azul_batch_num_actions(const azul_batch_t *b) { return b ? (b->displays + 1) * 30 : 0; }                              /* game_runner.py:115 */
+int azul_batch_obs_size(const azul_batch_t *b) { return b ? 5 * b->displays + 6 + 52 * b->players + 1 : 0; }             /* game_runner.py:65-72 */
 int azul_batch_record_bytes(const azul_batch_t *b) { return b ? b->rec_bytes : 0; }
 void *azul_batch_state_dev(azul_batch_t *b) { return b ? b->d.state : nullptr; }
 void *azul_batch_mt_dev(azul_batch_t *b) { return b ? b->d.mt : nullptr; }
@@ -818,9 +735,10 @@ static int check_range(const azul_batch_t *b, int first, int count)
 static int record_in_domain(const azul_batch_t *b, const uint8_t *p)
 {
     const u32 P = (u32)b->players;
+    const bool wide = b->rec_bytes == AZUL_RECORD_BYTES_WIDE;
     u32 flags = p[31];
     if ((flags & 7u) > P || ((flags >> 3) & 7u) > P || (flags & 0x80u)) return fail(AZUL_ERR_RANGE, "flags: players are 0..P");
-    const uint8_t *floors = p + (P == 2 ? 82 : 132), *walls = p + (P == 2 ? 84 : 136), *box = p + (P == 2 ? 96 : 160);
+    const uint8_t *floors = p + (wide ? 132 : 82), *walls = p + (wide ? 136 : 84), *box = p + (wide ? 160 : 96);
     for (u32 q = 0; q < P; q++) {
         if (floors[q] > 7) return fail(AZUL_ERR_RANGE, "floors are 0..7 (azul.py:120-123)");
         u32 w;
@@ -830,7 +748,9 @@ static int record_in_domain(const azul_batch_t *b, const uint8_t *p)
     u32 sb = 0, sl = 0;
     for (int c = 0; c < 5; c++) { sb += box[c]; sl += box[5 + c]; }
     if (sb > 255 || sl > 255) return fail(AZUL_ERR_RANGE, "box / lid hold at most 255 tiles in total");
-    if (P != 2 && p[204] != P) return fail(AZUL_ERR_RANGE, "wide record: byte 204 must hold the batch's number of players");
+    if (wide && p[204] != P) return fail(AZUL_ERR_RANGE, "wide record: byte 204 must hold the batch's number of players");
+    if (wide && p[205] != (b->displays == 5 ? 0 : b->displays))
+        return fail(AZUL_ERR_RANGE, "wide record: byte 205 must hold the batch's number of displays (0 for the reference's five)");
     return AZUL_SUCCESS;
 }
 
@@ -923,37 +843,67 @@ int azul_batch_seed(azul_batch_t *b, uint64_t seed_base, const uint64_t *seeds_h
     return AZUL_SUCCESS;
 }
 
-static bool np_supported(const OpArgs &a)
+static azx::XBatchDev xdev(const azul_batch_t *b)
 {
+    azx::XBatchDev x;
+    x.state = b->d.state; x.mt = b->d.mt; x.mtpos = b->d.mtpos; x.episodes = b->d.episodes; x.stuck = b->d.stuck; x.stat_sum = b->d.stat_sum;
+    x.n = b->d.n; x.draw_margin = b->d.draw_margin;
+    x.rules.first_player = b->d.rules.first_player;
+    x.rules.pool = (b->ext & AZUL_RULE_FINITE_BAG) ? (u32)azx::XPOOL_BAG : (b->d.rules.tile_pool == POOL_LID ? (u32)azx::XPOOL_LID : (u32)azx::XPOOL_RANDOM);
+    x.rules.end_bonus = (b->ext & AZUL_RULE_END_BONUS) ? 1u : 0u;
+    x.rules.short_deal = (b->ext & AZUL_RULE_SHORT_DEAL) ? 1u : 0u;
+    x.tab = (const double2 *)b->Tx;
+    return x;
+}
+
+// (players, displays) -> the instantiation; `call` is a macro body that uses PP / DD
+#define AZ_X_DISPATCH(b, call) do { \
+        const int pd_ = (b)->players * 16 + (b)->displays; \
+        if (pd_ == 2 * 16 + 5) { constexpr u32 PP = 2, DD = 5; call; } \
+        else if (pd_ == 3 * 16 + 5) { constexpr u32 PP = 3, DD = 5; call; } \
+        else if (pd_ == 3 * 16 + 7) { constexpr u32 PP = 3, DD = 7; call; } \
+        else if (pd_ == 4 * 16 + 5) { constexpr u32 PP = 4, DD = 5; call; } \
+        else { constexpr u32 PP = 4, DD = 9; call; } } while (0)
+
+static int launch_op_x(azul_batch_t *b, const OpArgs &a, void *stream, int count)
+{
+    // the entries that mirror Azul's own methods (and the RandomAgent sampler, check_all_valid, get_state): P-generic in the reference;
+    // GameRunner.step / reset / the what-if potential are two-player there (game_runner.py:50) and stay with two-player reference batches
+    azx::XOp x;
+    memset(&x, 0, sizeof(x));
     switch (a.op) {
-    case OP_QUERY: return !a.obs && !a.potential;       // get_state / the what-if potential are GameRunner's: two players
-    case OP_INIT: case OP_NEW_ROUND: case OP_MOVE: case OP_NEXT_PLAYER: case OP_COUNT_SCORE: case OP_STEP:
-    case OP_RANDOM_ACTION: case OP_SAMPLE_MASK: return true;
-    default: return false;
+    case OP_QUERY: x.op = azx::XOP_QUERY; break;
+    case OP_INIT: x.op = azx::XOP_INIT; break;
+    case OP_NEW_ROUND: x.op = azx::XOP_NEW_ROUND; break;
+    case OP_MOVE: x.op = azx::XOP_MOVE; break;
+    case OP_NEXT_PLAYER: x.op = azx::XOP_NEXT_PLAYER; break;
+    case OP_COUNT_SCORE: x.op = azx::XOP_COUNT_SCORE; break;
+    case OP_STEP: x.op = azx::XOP_STEP; break;
+    case OP_RANDOM_ACTION: x.op = azx::XOP_RANDOM_ACTION; break;
+    case OP_SAMPLE_MASK: x.op = azx::XOP_SAMPLE_MASK; break;
+    default: x.op = -1; break;
     }
+    if (x.op < 0 || a.potential || a.reward || a.done)
+        return fail(AZUL_ERR_INVALID, "this entry mirrors GameRunner's two-player step / reset / shaped reward (game_runner.py:43-55, 76-85): batches of "
+                                      "three / four players and extended-rule batches support the Azul rule entries, the sampler, the mask and the observation");
+    x.actions = a.actions; x.active = a.active; x.mask_in = a.mask_in; x.actions_out = a.actions_out; x.status = a.status; x.mask = a.mask;
+    x.obs = a.obs; x.persp = a.persp; x.flags = a.flags; x.stats = a.stats; x.player = a.player; x.rng_dirty = a.rng_dirty;
+    x.first = a.first; x.count = count < 0 ? b->d.n : (u32)count;
+    const dim3 grid((x.count + 1u) / 2u), block(64);
+    const azx::XBatchDev xb = xdev(b);
+    AZ_X_DISPATCH(b, hipLaunchKernelGGL((azul_x_op_kernel<PP, DD>), grid, block, 0, (hipStream_t)stream, xb, x));
+    HIP_TRY(hipGetLastError());
+    return AZUL_SUCCESS;
 }
 
 static int launch_op(azul_batch_t *b, const OpArgs &a, void *stream, int count = -1)
 {
     if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
+    if (b->x) return launch_op_x(b, a, stream, count);
     const dim3 grid(count < 0 ? b->d.n : (u32)count), block(64);      // games a.first .. a.first + grid - 1
     const hipStream_t st = (hipStream_t)stream;
-    const bool lid = b->d.rules.tile_pool == POOL_LID;
-    if (b->players == 2) {
-        if (lid) hipLaunchKernelGGL(azul_op_kernel<true>, grid, block, 0, st, b->d, a);
-        else hipLaunchKernelGGL(azul_op_kernel<false>, grid, block, 0, st, b->d, a);
-    } else {
-        if (!np_supported(a))
-            return fail(AZUL_ERR_INVALID, "this entry mirrors GameRunner, which the reference defines for two players only (game_runner.py:50,57); "
-                                          "3- and 4-player batches support the Azul rule entries");
-        if (b->players == 3) {
-            if (lid) hipLaunchKernelGGL((azul_np_op_kernel<3, true>), grid, block, 0, st, b->d, a);
-            else hipLaunchKernelGGL((azul_np_op_kernel<3, false>), grid, block, 0, st, b->d, a);
-        } else {
-            if (lid) hipLaunchKernelGGL((azul_np_op_kernel<4, true>), grid, block, 0, st, b->d, a);
-            else hipLaunchKernelGGL((azul_np_op_kernel<4, false>), grid, block, 0, st, b->d, a);
-        }
-    }
+    if (b->d.rules.tile_pool == POOL_LID) hipLaunchKernelGGL(azul_op_kernel<true>, grid, block, 0, st, b->d, a);
+    else hipLaunchKernelGGL(azul_op_kernel<false>, grid, block, 0, st, b->d, a);
     HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }
@@ -965,6 +915,10 @@ static OpArgs op_args(int op)
     a.op = op;
     return a;
 }
+
+// perspective of an observation: a player 0 .. P-1, AZUL_PERSP_MOVER (any batch), or -- two-player reference batches -- AZUL_PERSP_CURRENT
+static bool persp_ok(const azul_batch_t *b, int p) { return p == AZUL_PERSP_MOVER || (p >= 0 && (b->x ? p < b->players : p <= 2)); }
+static int persp_of(const azul_batch_t *b, int p) { return p == AZUL_PERSP_MOVER ? (b->x ? AZUL_PERSP_MOVER : AZUL_PERSP_CURRENT) : p; }
 
 int azul_batch_init(azul_batch_t *b, const uint8_t *active_dev, void *stream)
 {
@@ -1061,8 +1015,8 @@ int azul_batch_runner_step(azul_batch_t *b, const int32_t *actions_dev, const ui
 int azul_batch_observe(azul_batch_t *b, int perspective, float *obs_dev, void *stream)
 {
     BATCH_GUARD(b, stream);
-    if (!obs_dev || perspective < 0 || perspective > 2) return fail(AZUL_ERR_INVALID, "azul_batch_observe: bad arguments");
-    OpArgs a = op_args(OP_QUERY); a.obs = obs_dev; a.persp = perspective;
+    if (!b || !obs_dev || !persp_ok(b, perspective)) return fail(AZUL_ERR_INVALID, "azul_batch_observe: bad arguments");
+    OpArgs a = op_args(OP_QUERY); a.obs = obs_dev; a.persp = persp_of(b, perspective);
     return launch_op(b, a, stream);
 }
 
@@ -1101,8 +1055,8 @@ int azul_batch_agent_step(azul_batch_t *b, const int32_t *actions_dev, const uin
 int azul_batch_observe_all(azul_batch_t *b, int perspective, float *obs_dev, uint8_t *mask_dev, uint8_t *player_dev, void *stream)
 {
     BATCH_GUARD(b, stream);
-    if (perspective < 0 || perspective > 2) return fail(AZUL_ERR_INVALID, "azul_batch_observe_all: bad perspective");
-    OpArgs a = op_args(OP_QUERY); a.persp = perspective; a.obs = obs_dev; a.mask = mask_dev; a.player = player_dev;
+    if (!b || !persp_ok(b, perspective)) return fail(AZUL_ERR_INVALID, "azul_batch_observe_all: bad perspective");
+    OpArgs a = op_args(OP_QUERY); a.persp = persp_of(b, perspective); a.obs = obs_dev; a.mask = mask_dev; a.player = player_dev;
     return launch_op(b, a, stream);
 }
 
@@ -1174,7 +1128,8 @@ int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random,
 {
     BATCH_GUARD(b, stream);
     if (!b || n_steps < 0) return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: bad arguments");
-    if (b->players != 2) return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: GameRunner self-play is two-player (game_runner.py:50)");
+    if (b->x) return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: the policy entries are compiled for the reference's two-player game "
+                                            "(ActorCritic(136, 180): 180 actions, 136 observations; game_runner.py:50) -- not for 3 / 4 players or extended rules");
     if (num_inputs != PF_IN || hidden_size != PF_HID || num_actions != PF_ACT)
         return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: only ActorCritic(136, 180, hidden 180) is compiled in");
     if (!w1t_dev || !b1_dev || !w2c_dev || !b2c_dev || !w2a_t_dev || !b2a_dev || !obs_dev || !mask_dev || !player_dev || !action_dev ||
@@ -1315,9 +1270,9 @@ struct CallScratch {             // device scratch of one call; the pinned mirro
     i32 reward, action_out, potential;
     uint8_t status, done, flags, player;
     uint8_t rng_dirty, pad_[3];  // the kernel regenerated the 624 words (written by every call: 0 for ops that do not draw)
-    uint8_t mask_in[AZUL_NUM_ACTIONS];
-    uint8_t mask[AZUL_NUM_ACTIONS];
-    float obs[AZUL_OBS_SIZE];
+    uint8_t mask_in[AZUL_MAX_ACTIONS + 4];
+    uint8_t mask[AZUL_MAX_ACTIONS + 4];
+    float obs[AZUL_MAX_OBS];
     double stats[AZUL_NUM_STATS];
     uint8_t record[AZUL_RECORD_BYTES_WIDE];
     u32 mt[AZUL_MT_WORDS];
@@ -1334,6 +1289,8 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     if (c->op == AZUL_CALL_SAMPLE_MASK && !c->mask_in) return fail(AZUL_ERR_INVALID, "azul_game_call: AZUL_CALL_SAMPLE_MASK needs mask_in");
     if ((c->want & AZUL_WANT_RECORD) && !c->record_out) return fail(AZUL_ERR_INVALID, "azul_game_call: AZUL_WANT_RECORD needs record_out");
     if (c->mt_in && c->pos_in > 624u) return fail(AZUL_ERR_INVALID, "azul_game_call: index outside 0..624");
+    if ((c->want & AZUL_WANT_OBS) && !persp_ok(b, c->arg)) return fail(AZUL_ERR_INVALID, "azul_game_call: AZUL_WANT_OBS needs a perspective in arg");
+    const size_t NA = (size_t)azul_batch_num_actions(b), NOBS = (size_t)azul_batch_obs_size(b);
     if (c->record_in) if (int rc = record_in_domain(b, (const uint8_t *)c->record_in)) return rc;
     const hipStream_t st = (hipStream_t)stream;
     if (!b->call_dev) {
@@ -1361,8 +1318,8 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
         H->action_in = c->arg;
         size_t nb = sizeof(i32);
         if (c->op == AZUL_CALL_SAMPLE_MASK) {                     // action_in .. mask_in is one contiguous piece of the scratch
-            memcpy(H->mask_in, c->mask_in, AZUL_NUM_ACTIONS);
-            nb = offsetof(CallScratch, mask_in) + AZUL_NUM_ACTIONS;
+            memcpy(H->mask_in, c->mask_in, NA);
+            nb = offsetof(CallScratch, mask_in) + NA;
         }
         HIP_TRY(hipMemcpyAsync(D, H, nb, hipMemcpyHostToDevice, st));
     }
@@ -1374,7 +1331,7 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     if (c->op == AZUL_CALL_RUNNER_STEP) { a.reward = &D->reward; a.done = &D->done; }
     if (c->op == AZUL_CALL_SAMPLE_MASK) { a.mask_in = D->mask_in; a.actions_out = &D->action_out; }
     if (c->want & AZUL_WANT_MASK) a.mask = D->mask;
-    if (c->want & AZUL_WANT_OBS) { a.obs = D->obs; a.persp = c->arg; }
+    if (c->want & AZUL_WANT_OBS) { a.obs = D->obs; a.persp = persp_of(b, c->arg); }
     if (c->want & AZUL_WANT_FLAGS) a.flags = &D->flags;
     if (c->want & AZUL_WANT_POTENTIAL) a.potential = &D->potential;
     if (c->want & AZUL_WANT_STATS) a.stats = D->stats;
@@ -1383,8 +1340,8 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     // ---- results: the scalar head of the scratch always (24 bytes), the rest on request
     HIP_TRY(hipMemcpyAsync(&H->reward, &D->reward, offsetof(CallScratch, mask_in) - offsetof(CallScratch, reward), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&H->pos, b->d.mtpos + g, sizeof(u32), hipMemcpyDeviceToHost, st));
-    if (c->want & AZUL_WANT_MASK) HIP_TRY(hipMemcpyAsync(H->mask, D->mask, AZUL_NUM_ACTIONS, hipMemcpyDeviceToHost, st));
-    if (c->want & AZUL_WANT_OBS) HIP_TRY(hipMemcpyAsync(H->obs, D->obs, sizeof(H->obs), hipMemcpyDeviceToHost, st));
+    if (c->want & AZUL_WANT_MASK) HIP_TRY(hipMemcpyAsync(H->mask, D->mask, NA, hipMemcpyDeviceToHost, st));
+    if (c->want & AZUL_WANT_OBS) HIP_TRY(hipMemcpyAsync(H->obs, D->obs, NOBS * sizeof(float), hipMemcpyDeviceToHost, st));
     if (c->want & AZUL_WANT_STATS) HIP_TRY(hipMemcpyAsync(H->stats, D->stats, sizeof(H->stats), hipMemcpyDeviceToHost, st));
     if (c->want & AZUL_WANT_RECORD) HIP_TRY(hipMemcpyAsync(H->record, b->d.state + g * RB, RB, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1396,8 +1353,8 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     c->flags = (c->want & AZUL_WANT_FLAGS) ? H->flags : 0;
     c->potential = (c->want & AZUL_WANT_POTENTIAL) ? H->potential : 0;
     c->pos_out = H->pos;
-    if (c->want & AZUL_WANT_MASK) memcpy(c->mask, H->mask, AZUL_NUM_ACTIONS);
-    if (c->want & AZUL_WANT_OBS) memcpy(c->obs, H->obs, sizeof(H->obs));
+    if (c->want & AZUL_WANT_MASK) memcpy(c->mask, H->mask, NA);
+    if (c->want & AZUL_WANT_OBS) memcpy(c->obs, H->obs, NOBS * sizeof(float));
     if (c->want & AZUL_WANT_STATS) memcpy(c->stats, H->stats, sizeof(H->stats));
     if (c->want & AZUL_WANT_RECORD) memcpy(c->record_out, H->record, RB);
     // whether the 624 words were regenerated is the kernel's own statement (Rng::dirty, written next to the status): it does not
@@ -1425,29 +1382,32 @@ int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev,
     if (!b || n_steps < 0) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: bad arguments");
     if (mask_row_bytes < AZUL_NUM_ACTIONS) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: mask rows hold 180 bytes, mask_row_bytes >= 180");
     if (n_steps == 0) return AZUL_SUCCESS;
-    if (b->players != 2) {
-        // three / four players (row N4): the flat loop mask -> RandomAgent -> Azul.step with a fresh Azul + new_round() at each game end;
-        // one game per wavefront on the wide record, dense mask rows, `reward` all zero (the shaped reward is GameRunner's: two players)
-        if (mask_dev && mask_row_bytes != AZUL_NUM_ACTIONS)
-            return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: 3- and 4-player batches write dense 180-byte mask rows");
-        TrajArgs t = {n_steps, mask_dev, (u64 *)maskbits_dev, action_dev, reward_dev, done_dev, rec_dev, packed_dev};
+    if (b->x) {
+        // three / four players and extended-rule batches (row N4): the flat loop mask -> RandomAgent -> Azul.step with a fresh Azul + new_round()
+        // at each game end; two games per wavefront on the wide record (azul_rules_x.hpp); `reward` all zero (the shaped reward is
+        // GameRunner's: two players)
+        const int NA = azul_batch_num_actions(b), NAP = (NA + 7) / 8 * 8;
+        if (mask_row_bytes < NA) return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: mask rows hold azul_batch_num_actions bytes, mask_row_bytes must not be smaller");
+        if ((u64)n_steps * b->d.n * (u64)(rec_dev && mask_row_bytes < AZUL_RECORD_BYTES_WIDE ? AZUL_RECORD_BYTES_WIDE : mask_row_bytes) >= (1ull << 32))
+            return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: a trajectory stream of one launch must stay below 4 GiB (use fewer moves per launch)");
+        const azx::XBatchDev xb = xdev(b);
+        const azx::XTraj t = {n_steps, mask_dev, (u64 *)maskbits_dev, action_dev, reward_dev, done_dev, rec_dev, packed_dev, (u32)mask_row_bytes};
         const bool none = !mask_dev && !maskbits_dev && !action_dev && !reward_dev && !done_dev && !rec_dev && !packed_dev;
-        const bool full = mask_dev && maskbits_dev && action_dev && reward_dev && done_dev && packed_dev && !rec_dev;
-        const dim3 grid(b->d.n), block(64);
+        const bool core = mask_dev && action_dev && reward_dev && done_dev && packed_dev && !rec_dev;     // + maskbits_dev or not
+        // padded rows (8-byte aligned, room for ceil(NA / 8) 8-byte chunks; five displays: >= 192 like the two-player kernel) take the
+        // one-store-per-row path
+        const bool pad = mask_row_bytes % 8 == 0 && mask_row_bytes >= (b->displays == 5 ? 192 : NAP) && ((uintptr_t)mask_dev & 7u) == 0u;
+        const dim3 grid((b->d.n + 1u) / 2u), block(64);
         const hipStream_t st = (hipStream_t)stream;
-        const bool lid = b->d.rules.tile_pool == POOL_LID;
-#define AZ_LAUNCH_NP(PP, LID) do { \
-            if (none) hipLaunchKernelGGL((azul_np_selfplay_kernel<PP, LID, 0>), grid, block, 0, st, b->d, t); \
-            else if (full) hipLaunchKernelGGL((azul_np_selfplay_kernel<PP, LID, 1>), grid, block, 0, st, b->d, t); \
-            else hipLaunchKernelGGL((azul_np_selfplay_kernel<PP, LID, 2>), grid, block, 0, st, b->d, t); } while (0)
         const bool pair = b->timing && b->timed_pairs < AZ_TIMED_PAIRS;       // per-launch event pair inside a timed region (as below)
         if (pair) {
             while ((int)b->lev.size() < 2 * (b->timed_pairs + 1)) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); b->lev.push_back(e); }
             HIP_TRY(hipEventRecord(b->lev[2 * b->timed_pairs], st));
         }
-        if (b->players == 3) { if (lid) AZ_LAUNCH_NP(3, true); else AZ_LAUNCH_NP(3, false); }
-        else { if (lid) AZ_LAUNCH_NP(4, true); else AZ_LAUNCH_NP(4, false); }
-#undef AZ_LAUNCH_NP
+        if (none) AZ_X_DISPATCH(b, hipLaunchKernelGGL((azul_x_selfplay_kernel<PP, DD, 0, false, false>), grid, block, 0, st, xb, t));
+        else if (core && pad && maskbits_dev) AZ_X_DISPATCH(b, hipLaunchKernelGGL((azul_x_selfplay_kernel<PP, DD, 1, true, true>), grid, block, 0, st, xb, t));
+        else if (core && pad) AZ_X_DISPATCH(b, hipLaunchKernelGGL((azul_x_selfplay_kernel<PP, DD, 1, true, false>), grid, block, 0, st, xb, t));
+        else AZ_X_DISPATCH(b, hipLaunchKernelGGL((azul_x_selfplay_kernel<PP, DD, 2, false, false>), grid, block, 0, st, xb, t));
         HIP_TRY(hipGetLastError());
         if (pair) { HIP_TRY(hipEventRecord(b->lev[2 * b->timed_pairs + 1], st)); b->timed_pairs++; }
         if (b->timing) b->timed_launches++;
@@ -1497,8 +1457,8 @@ int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev,
 int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_t *maskbits_dev, int32_t *action_dev,
                         int32_t *reward_dev, uint8_t *done_dev, uint32_t *packed_dev, uint8_t *rec_dev, void *stream)
 {
-    return azul_batch_selfplay_strided(b, n_steps, mask_dev, AZUL_NUM_ACTIONS, maskbits_dev, action_dev, reward_dev, done_dev, packed_dev, rec_dev,
-                                       stream);
+    return azul_batch_selfplay_strided(b, n_steps, mask_dev, b ? azul_batch_num_actions(b) : AZUL_NUM_ACTIONS, maskbits_dev, action_dev, reward_dev,
+                                       done_dev, packed_dev, rec_dev, stream);
 }
 
 int azul_batch_counters(azul_batch_t *b, uint64_t *episodes_host, uint32_t *stuck_host, double *stat_sums_host, void *stream)

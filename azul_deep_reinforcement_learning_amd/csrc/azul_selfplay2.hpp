@@ -592,35 +592,34 @@ AZ_FN u32 new_round2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
     return st;
 }
 
+// The factory draw itself (azul.py:71-89) on the cell register of five displays + centre + token; shared with the P-player rules
+// (azul_rules_x.hpp).  short_deal (beyond the reference, row N4): bag and lid both empty -> the round starts with what could be dealt
+// instead of ST_BOX_EMPTY (where the reference raises, azul.py:86-87); the two-player kernels pass false.
 template <bool LID>
-AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
+AZ_FN u32 deal_tiles2(u32 &cs, u64 &box, u64 &lid, u32 &lidp, Rng2 &r, u64 margin, bool short_deal, const K2 &k)
 {
     const u32 l = k.l;
-    g.cur = g.nfp;
-    g.fps += (g.nfp == 1u) ? 1u : 0x10000u;              // :67 (numpy [-1] == player 2 when nfp == 0)
-    g.turn += 1u;
-    g.nfp = 0;
-    g.cs = l == 30u ? 1u : 0u;                           // :71,:73
+    cs = l == 30u ? 1u : 0u;                             // :71,:73
     if (!LID) {
 #pragma unroll 1
         for (u32 t = 0; t < 20u; t++) {
             u32 color = rng2_below(r, 5u, 3u, l);        // :78 randrange(0,5,1)
-            g.cs += (l == (t >> 2) * 5u + color) ? 1u : 0u;   // :88
+            cs += (l == (t >> 2) * 5u + color) ? 1u : 0u;   // :88
         }
         return ST_OK;
     }
     // "Lid" pool: every draw is one random.choices = one random() = two MT words; see azul_core.hpp for the exactness argument
     // (integer decision P_c * 2^53 <= K * T unless K*T lies within `margin` of a multiple of 2^32, then the literal fp64 code).
-    if ((g.box & 0xffffffffffull) == 0ull) {
+    if ((box & 0xffffffffffull) == 0ull) {
         // the box is empty when the round starts: the first draw refills it from the lid (:81-83) -- done here, so that the
         // whole round can take the parallel path below (no random number is involved: random.choices raises before random())
-        g.box = g.lid + lid_fold2(g.lidp, l); g.lid = 0; g.lidp = 0;
-        if ((g.box & 0xffffffffffull) == 0ull) return ST_BOX_EMPTY;
+        box = lid + lid_fold2(lidp, l); lid = 0; lidp = 0;
+        if ((box & 0xffffffffffull) == 0ull) return short_deal ? (u32)ST_OK : (u32)ST_BOX_EMPTY;
     }
     // prefix sums of the box: p_c = box_0 + .. + box_c (c < 4), T0 = all five
-    const u32 blo = (u32)g.box;
+    const u32 blo = (u32)box;
     const u32 p0 = blo & 0xffu, p1 = p0 + ((blo >> 8) & 0xffu), p2 = p1 + ((blo >> 16) & 0xffu), p3 = p2 + (blo >> 24);
-    const u32 T0 = p3 + ((u32)(g.box >> 32) & 0xffu);
+    const u32 T0 = p3 + ((u32)(box >> 32) & 0xffu);
     // The round's 40 words in one go: lane t takes the two words of draw t.  When they straddle a regeneration (6 % of the rounds)
     // and the round cannot run dry (T0 >= 20: exactly 40 words will be consumed), the words before it are read, the state is
     // regenerated, and the words after it are read -- instead of twenty serial draws through the window.
@@ -683,21 +682,21 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
         asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4));
         // display d receives draws 4d .. 4d+3: lane 5d + c counts those of colour c (:88)
         const u32 ec = k.pcol == 0u ? e0 : k.pcol == 1u ? e1 : k.pcol == 2u ? e2 : k.pcol == 3u ? e3 : e4;
-        g.cs = l < 25u ? (u32)__popc((ec >> (4u * k.prow)) & 0xfu) : g.cs;
+        cs = l < 25u ? (u32)__popc((ec >> (4u * k.prow)) & 0xfu) : cs;
         const u32 take_lo = (u32)__popc(e0) | ((u32)__popc(e1) << 8) | ((u32)__popc(e2) << 16) | ((u32)__popc(e3) << 24);
-        g.box -= (u64)take_lo | ((u64)(u32)__popc(e4) << 32);      // :89 (no borrows: a colour is only drawn while the box holds it)
+        box -= (u64)take_lo | ((u64)(u32)__popc(e4) << 32);      // :89 (no borrows: a colour is only drawn while the box holds it)
         r.pos += 40u;
         return ST_OK;
     }
-    u64 P = ((g.box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;     // byte c = box_0 + .. + box_c
+    u64 P = ((box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;     // byte c = box_0 + .. + box_c
 #pragma unroll 1
     for (u32 t = 0; t < 20u; t++) {
         u32 total = (u32)(P >> 32) & 0xffu;
         if (total == 0u) {                                                           // :81-83, :85
-            g.box = g.lid + lid_fold2(g.lidp, l); g.lid = 0; g.lidp = 0;
-            P = ((g.box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;
+            box = lid + lid_fold2(lidp, l); lid = 0; lidp = 0;
+            P = ((box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;
             total = (u32)(P >> 32) & 0xffu;
-            if (total == 0u) return ST_BOX_EMPTY;
+            if (total == 0u) return short_deal ? (u32)ST_OK : (u32)ST_BOX_EMPTY;
         }
         u32 Klo, Khi;
         if (batched) { Klo = hread(klo, t); Khi = hread(khi, t); r.pos += 2u; }
@@ -716,19 +715,29 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
         } else {
             // weights = box_c / total (fp64, correctly rounded division), cumulative left to right, x = random() * cum[-1]
             double tot = (double)total;
-            double q0 = (double)((u32)g.box & 0xffu) / tot, q1 = (double)((u32)(g.box >> 8) & 0xffu) / tot,
-                   q2 = (double)((u32)(g.box >> 16) & 0xffu) / tot, q3 = (double)((u32)(g.box >> 24) & 0xffu) / tot,
-                   q4 = (double)((u32)(g.box >> 32) & 0xffu) / tot;
+            double q0 = (double)((u32)box & 0xffu) / tot, q1 = (double)((u32)(box >> 8) & 0xffu) / tot,
+                   q2 = (double)((u32)(box >> 16) & 0xffu) / tot, q3 = (double)((u32)(box >> 24) & 0xffu) / tot,
+                   q4 = (double)((u32)(box >> 32) & 0xffu) / tot;
             double c0 = q0, c1 = c0 + q1, c2 = c1 + q2, c3 = c2 + q3, c4 = c3 + q4;
             double u = ((double)Khi * 4294967296.0 + (double)Klo) * (1.0 / 9007199254740992.0);
             double x = u * (c4 + 0.0);
             color = (u32)!(x < c0) + (u32)!(x < c1) + (u32)!(x < c2) + (u32)!(x < c3);    // bisect_right(cum, x, 0, 4)
         }
-        g.box -= 1ull << (8u * color);                   // :89
+        box -= 1ull << (8u * color);                   // :89
         P -= (0x0101010101ull << (8u * color)) & 0xffffffffffull;
-        g.cs += (l == (t >> 2) * 5u + color) ? 1u : 0u;  // :88
+        cs += (l == (t >> 2) * 5u + color) ? 1u : 0u;  // :88
     }
     return ST_OK;
+}
+
+template <bool LID>
+AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
+{
+    g.cur = g.nfp;
+    g.fps += (g.nfp == 1u) ? 1u : 0x10000u;              // :67 (numpy [-1] == player 2 when nfp == 0)
+    g.turn += 1u;
+    g.nfp = 0;
+    return deal_tiles2<LID>(g.cs, g.box, g.lid, g.lidp, r, margin, false, k);
 }
 
 // Azul.__init__ + GameRunner's reset bookkeeping (azul.py:18-61, game_runner.py:76-82), then the first round

@@ -39,4 +39,27 @@ static inline bool build_sample_tab(double *tab /* T_WORDS */)
     return ok;
 }
 
+// The same decomposition for an action space with `rows - 1` floor actions (the P-player rules on D displays, azul_rules_x.hpp:
+// rows = 5 (D + 1) + 1, at most 5 (rows - 1) pattern moves), as the {Fr[J][b], S[J]} pairs the kernels read with one 16-byte load:
+// out[2 (8 J + b)] = Fr[J][b], out[2 (8 J + b) + 1] = S[J].  Returns false if the identity ever failed.
+static inline bool build_sample_pairs(int rows, double *out /* [rows * 8 * 2] */)
+{
+    const int mmax = 5 * (rows - 1);
+    bool ok = mmax < 256;
+    double s = 0.0;
+    for (int J = 0; J < rows; J++) {
+        if (J > 0) s = s + 0.01;
+        double fr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double c = s;
+        for (int m = 1; m <= mmax; m++) {
+            c = c + 1.0;
+            const int b = 31 - __builtin_clz((unsigned)m);
+            if (m == (1 << b)) fr[b] = c - (double)m;
+            if ((double)m + fr[b] != c) ok = false;
+        }
+        for (int b = 0; b < 8; b++) { out[2 * (8 * J + b)] = fr[b]; out[2 * (8 * J + b) + 1] = s; }
+    }
+    return ok;
+}
+
 } // namespace az

@@ -51,13 +51,13 @@ _OPS = {
     "op_statistics": (L.CALL_QUERY, L.WANT_STATS), "op_potential": (L.CALL_QUERY, L.WANT_POTENTIAL),
     "op_runner_init": (L.CALL_RUNNER_INIT, 0), "op_runner_reset": (L.CALL_RUNNER_RESET, 0), "op_runner_step": (L.CALL_RUNNER_STEP, 0),
 }
-_WANT_BYTES = ((L.WANT_MASK, 180), (L.WANT_OBS, 544), (L.WANT_STATS, 80))
+_WANT_BYTES = ((L.WANT_MASK, 180), (L.WANT_OBS, 544), (L.WANT_STATS, 80))          # (the reference's sizes; traffic accounting only)
 
 
 class HipBackend:
     """1-game BatchedAzul per rule set, created lazily on the current CUDA device; every facade call is one azul_game_call."""
 
-    def __init__(self, first_player, tile_pool, players=2):
+    def __init__(self, first_player, tile_pool, players=2, ext=0):
         import torch
         from .batch import BatchedAzul
         if not torch.cuda.is_available():
@@ -66,14 +66,15 @@ class HipBackend:
         self.torch = torch
         rules = {"first_player": "Random" if first_player == L.FIRST_RANDOM else int(first_player),
                  "tile_pool": "Lid" if tile_pool == L.POOL_LID else "Random"}
-        self.env = BatchedAzul(1, rules=rules, players=players)
+        self.env = BatchedAzul(1, rules=rules, players=players, ext_rules=ext)
+        self.num_actions, self.obs_size = self.env.num_actions, self.env.obs_size
         self.c = L.AzulCall()
         self.c.game = 0
         self._rec_in = np.zeros(1, dtype=self.env.record_dtype)
         self._rec_out = np.zeros(1, dtype=self.env.record_dtype)
         self._mt_in = np.zeros(624, dtype=np.uint32)
         self._mt_out = np.zeros(624, dtype=np.uint32)
-        self._mask_in = np.zeros(180, dtype=np.uint8)
+        self._mask_in = np.zeros(self.num_actions, dtype=np.uint8)
         self.c.record_out = self._rec_out.ctypes.data
         self.c.mt_out = self._mt_out.ctypes.data
         self._resident = None                # bytes of the record the device holds
@@ -132,9 +133,9 @@ class HipBackend:
         if op == "op_runner_step":
             return (int(c.reward), bool(c.done), int(c.status)), new
         if op == "op_mask":
-            return np.frombuffer(bytes(c.mask), dtype=np.uint8).astype(bool), new
+            return np.frombuffer(bytes(c.mask), dtype=np.uint8)[:self.num_actions].astype(bool), new
         if op == "op_observe":
-            return np.array(c.obs[:], dtype=np.float32).astype(np.int64), new
+            return np.array(c.obs[:self.obs_size], dtype=np.float32).astype(np.int64), new
         if op == "op_statistics":
             return np.array(c.stats[:], dtype=np.float64), new
         if op == "op_flags":
@@ -147,7 +148,10 @@ class HipBackend:
         """RandomAgent.get_a_output on a caller's mask (game_runner.py:87-97): one random.choices draw on this backend's stream."""
         c = self.c
         c.op, c.arg, c.want, c.record_in = L.CALL_SAMPLE_MASK, 0, 0, None
-        self._mask_in[:] = np.asarray(mask, dtype=np.uint8).reshape(-1)[:180]
+        m = np.asarray(mask, dtype=np.uint8).reshape(-1)
+        if m.size != self.num_actions:
+            raise ValueError("this backend samples masks of %d actions" % self.num_actions)
+        self._mask_in[:] = m
         c.mask_in = self._mask_in.ctypes.data
         h2d = 184 + self._submit(True)
         _count(h2d=h2d, d2h=24 + (2496 if c.rng_regenerated else 0), launches=1, syncs=1 + (1 if c.rng_regenerated else 0))
@@ -158,17 +162,23 @@ _FACTORY = HipBackend      # the class behind backend(): the product has exactly
 _CACHE = {}
 
 
-def backend(first_player, tile_pool, players=2):
-    key = (_FACTORY, int(first_player), int(tile_pool), int(players))
+def backend(first_player, tile_pool, players=2, ext=0):
+    key = (_FACTORY, int(first_player), int(tile_pool), int(players), int(ext))
     if key not in _CACHE:
-        _CACHE[key] = _FACTORY(int(first_player), int(tile_pool), int(players))
+        _CACHE[key] = _FACTORY(int(first_player), int(tile_pool), int(players), int(ext))
     return _CACHE[key]
 
 
-def sampling_backend():
-    """The backend RandomAgent draws on: the one that holds the global stream if there is one (any rule set can run the sampler),
-    so that a GameRunner loop never moves the 624 words."""
+def sampling_backend(num_actions=180):
+    """The backend RandomAgent draws on: the one that holds the global stream if there is one (any rule set with the same action space
+    can run the sampler), so that a GameRunner loop never moves the 624 words.  Masks of 240 / 300 actions (seven / nine displays,
+    beyond the reference) are sampled on a backend of that action space."""
     be = _RNG["be"]
-    if be is not None and type(be) is _FACTORY:
+    if be is not None and type(be) is _FACTORY and getattr(be, "num_actions", 180) == num_actions:
         return be
-    return backend(1, L.POOL_RANDOM)
+    if num_actions == 180:
+        return backend(1, L.POOL_RANDOM)
+    players = {240: 3, 300: 4}.get(num_actions)
+    if players is None:
+        raise ValueError("a legal mask holds 180, 240 or 300 actions")
+    return backend(1, L.POOL_RANDOM, players, L.RULE_DISPLAYS_2P1)

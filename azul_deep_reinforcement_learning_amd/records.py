@@ -42,7 +42,10 @@ RECORD_NP_DTYPE = np.dtype([
     ("max_combo", "u1", (4,)),
     ("completed_lines", "u1", (4, 3)),
     ("players", "u1"),
-    ("reserved", "u1", (51,)),
+    ("n_displays", "u1"),            # 0 = the reference's five; 7 / 9 with the 2P+1 displays rule (beyond the reference)
+    ("reserved0", "u1", (2,)),
+    ("xdisplays", "u1", (4, 5)),     # factory displays 5 .. 8
+    ("reserved", "u1", (28,)),
 ])
 assert RECORD_NP_DTYPE.itemsize == 256
 
@@ -70,6 +73,26 @@ def bits_to_walls(bits):
     return (((b >> _WALL_SHIFTS) & 1) != 0).reshape(b.shape[0], 5, 5)
 
 
+def record_displays(rec):
+    """Number of factory displays a record describes: 5 unless the wide record says otherwise."""
+    return (int(rec["n_displays"]) or 5) if "n_displays" in rec.dtype.names else 5
+
+
+def all_displays(rec):
+    """displays[D][5] of a record (the reference's five, then the extra ones of the 2P+1 rule)."""
+    D = record_displays(rec)
+    return rec["displays"] if D == 5 else np.concatenate([rec["displays"], rec["xdisplays"][:D - 5]])
+
+
+def set_displays(rec, displays):
+    d = np.asarray(displays)
+    D = d.shape[0]
+    rec["displays"] = d[:5]
+    if D != 5:
+        rec["n_displays"] = D
+        rec["xdisplays"][:D - 5] = d[5:]
+
+
 def record_players(rec):
     """Number of players a record describes: 2 for the 128-byte record, the `players` byte of the 256-byte wide record."""
     return int(rec["players"]) if "players" in rec.dtype.names else 2
@@ -82,7 +105,7 @@ def record_to_json(rec):
     cur, nfp, eog = unpack_flags(rec["flags"])
     P = record_players(rec)
     d = {
-        "game_board_displays": rec["displays"].astype(int).tolist(),
+        "game_board_displays": all_displays(rec).astype(int).tolist(),
         "game_board_center": rec["center"].astype(int).tolist(),
         "pattern_lines": rec["pattern_lines"][:P].astype(int).tolist(),
         "walls": bits_to_walls(rec["walls"][:P]).astype(int).tolist(),
@@ -100,9 +123,11 @@ def record_to_json(rec):
         "x_max_combo": rec["max_combo"][:P].astype(int).tolist(),
         "x_completed_lines": rec["completed_lines"][:P].astype(int).tolist(),
     }
-    if P == 2:
+    if "player_score" in rec.dtype.names:
         d["x_player_score"] = int(rec["player_score"])
         d["x_move_counter"] = int(rec["move_counter"])
+    elif P == 2:
+        d["x_wide"] = True           # a two-player game of an extended-rule batch lives in the wide record
     return d
 
 
@@ -113,10 +138,12 @@ def json_to_record(d):
     P = int(d.get("players", 2))
     if P not in (2, 3, 4):
         raise ValueError("Azul is a game for 2, 3 or 4 players")
-    rec = np.zeros((), dtype=RECORD_DTYPE if P == 2 else RECORD_NP_DTYPE)
-    if P != 2:
+    D = len(d["game_board_displays"])
+    wide = P != 2 or D != 5 or bool(d.get("x_wide", False))
+    rec = np.zeros((), dtype=RECORD_NP_DTYPE if wide else RECORD_DTYPE)
+    if wide:
         rec["players"] = P
-    rec["displays"] = np.asarray(d["game_board_displays"])
+    set_displays(rec, d["game_board_displays"]) if wide else rec.__setitem__("displays", np.asarray(d["game_board_displays"]))
     rec["center"] = np.asarray(d["game_board_center"])
     rec["pattern_lines"][:P] = np.asarray(d["pattern_lines"])
     rec["walls"][:P] = walls_to_bits(np.asarray(d["walls"]))
@@ -131,7 +158,7 @@ def json_to_record(d):
                        ("x_completed_lines", "completed_lines")):
         if key in d:
             rec[field][:P] = np.asarray(d[key])
-    if P == 2:
+    if not wide:
         for key, field in (("x_player_score", "player_score"), ("x_move_counter", "move_counter")):
             if key in d:
                 rec[field] = np.asarray(d[key])

@@ -290,36 +290,43 @@ def facade_config1(budget_s=8.0, max_games=150):
 
 
 def players_selfplay(games, chunk=256, launches=6):
-    """Row N4: the persistent self-play kernel for 3 and 4 players (one game per wavefront on the 256-byte wide record; the loop
-    mask -> RandomAgent -> Azul.step, fresh game at each game end), all five trajectory streams written, dense mask rows."""
+    """Row N4: the persistent self-play kernel for 3 and 4 players (azul_x_selfplay_kernel: two games per wavefront on the 256-byte wide
+    record; the loop mask -> RandomAgent -> Azul.step, fresh game at each game end), mask + action + reward + done + compact record
+    written (mask rows padded to 192 / 256 / 320 bytes).  Two lines per player count: the reference's rules (five displays), and the
+    extended rules -- 2P+1 displays, end-of-game bonuses, short deal: beyond the reference, parity unpinned."""
     import torch
     from azul_deep_reinforcement_learning_amd import BatchedAzul
+    from azul_deep_reinforcement_learning_amd import _lib as L
     res = {}
     for P in (3, 4):
-        env = BatchedAzul(games, players=P)
-        env.seed(0)
-        env.init()
-        env.new_round()
-        bufs = env.alloc_trajectory(chunk, packed_mask=True)
-        run = lambda: env.selfplay(chunk, bufs["mask"], bufs["action"], bufs["reward"], bufs["done"], maskbits=bufs["maskbits"], packed=bufs["packed"])
-        run()
-        torch.cuda.synchronize()
-        stuck0 = int(env.counters()["stuck"].sum())
-        t0 = time.perf_counter()
-        env.timing_begin()
-        for _ in range(launches):
+        for ext, tag in ((0, "players_%d" % P), (L.RULE_DISPLAYS_2P1 | L.RULE_END_BONUS | L.RULE_SHORT_DEAL, "players_%d_displays_%d" % (P, 2 * P + 1))):
+            env = BatchedAzul(games, players=P, ext_rules=ext)
+            env.seed(0)
+            env.init()
+            env.new_round()
+            bufs = env.alloc_trajectory(chunk, packed_mask=True, mask_pitch={5: 192, 7: 256, 9: 320}[env.displays], mask_bits=False)
+            run = lambda: env.selfplay(chunk, bufs["mask"], bufs["action"], bufs["reward"], bufs["done"], packed=bufs["packed"])
             run()
-        _, _, kms, kn = env.timing_end()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        c = env.counters()
-        moves = games * chunk * launches - (int(c["stuck"].sum()) - stuck0)
-        res["players_%d" % P] = {"value": moves / dt, "unit": "env steps/s", "avg_launch_ms": kms / max(kn, 1), "episodes_finished": int(c["episodes"].sum()),
-                                 "workload": "%d concurrent %d-player games (five displays, like the reference), RandomAgent for every seat, rules Lid + "
-                                             "random first player, %d moves per launch" % (games, P, chunk)}
-        del env, bufs
-        torch.cuda.empty_cache()
-    res["kernel"] = "azul_np_selfplay_kernel (one game per wavefront)"
+            torch.cuda.synchronize()
+            stuck0 = int(env.counters()["stuck"].sum())
+            t0 = time.perf_counter()
+            env.timing_begin()
+            for _ in range(launches):
+                run()
+            _, _, kms, kn = env.timing_end()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            c = env.counters()
+            moves = games * chunk * launches - (int(c["stuck"].sum()) - stuck0)
+            res[tag] = {"value": moves / dt, "unit": "env steps/s", "avg_launch_ms": kms / max(kn, 1),
+                        "kernel_env_steps_per_s": games * chunk / (kms / max(kn, 1) / 1e3), "episodes_finished": int(c["episodes"].sum()),
+                        "num_actions": env.num_actions,
+                        "workload": "%d concurrent %d-player games, %d displays%s, RandomAgent for every seat, rules Lid + random first player, "
+                                    "%d moves per launch" % (games, P, env.displays, "" if not ext else
+                                                             " + end-of-game bonuses + short deal (beyond the reference, parity unpinned)", chunk)}
+            del env, bufs
+            torch.cuda.empty_cache()
+    res["kernel"] = "azul_x_selfplay_kernel (two games per wavefront)"
     return res
 
 

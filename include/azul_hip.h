@@ -61,7 +61,10 @@
  *   188   4  u8  max_combo[4]              azul.py:33
  *   192  12  u8  completed_lines[4][3]     azul.py:58
  *   204   1  u8  players                   azul.py:28
- *   205  51      reserved (zero)
+ *   205   1  u8  n_displays                0 = the reference's five (a five-display record is byte for byte what it was); else 7 / 9
+ *   206   2  u8  reserved0                 zero
+ *   208  20  u8  xdisplays[4][5]           factory displays 5 .. 8, beyond the reference's five (AZUL_RULE_DISPLAYS_2P1); zero otherwise
+ *   228  28      reserved (zero)
  *
  * Random numbers: every game owns a CPython-exact MT19937 stream (624 words + index), i.e. what the
  * reference consumes through the process-global `random` module (azul.py:37,78,87; game_runner.py:97).
@@ -77,8 +80,10 @@ extern "C" {
 
 #define AZUL_RECORD_BYTES 128
 #define AZUL_RECORD_BYTES_WIDE 256   /* batches of 3 or 4 players */
-#define AZUL_NUM_ACTIONS  180
-#define AZUL_OBS_SIZE     136
+#define AZUL_NUM_ACTIONS  180          /* the reference's action space: 6 sources x 5 colours x 6 rows (game_runner.py:102-117) */
+#define AZUL_OBS_SIZE     136          /* the reference's two-player observation (game_runner.py:65-72) */
+#define AZUL_MAX_ACTIONS  300          /* (9 + 1) sources x 5 x 6: four players with AZUL_RULE_DISPLAYS_2P1 (azul_batch_num_actions) */
+#define AZUL_MAX_OBS      260          /* 5 * 9 + 6 + 52 * 4 + 1 (azul_batch_obs_size) */
 #define AZUL_MT_WORDS     624
 #define AZUL_NUM_STATS    10
 
@@ -101,11 +106,20 @@ extern "C" {
 #define AZUL_POOL_RANDOM   0
 #define AZUL_POOL_LID      1
 #define AZUL_FIRST_RANDOM  0      /* "Random"; 1 or 2 = fixed first player */
+/* Extended rules (azul_batch_create_rules), all OFF by default -- BEYOND THE REFERENCE, "parity unpinned": the reference implements none of
+ * them (five displays for any number of players, azul.py:19 and the TODO at tests/test_azul.py:14; TODOs at azul.py:72,86; line bonuses
+ * per round, azul.py:266-288).  Source: the published Azul rulebook, restated in oracle/azul_oracle.c (OZ_EXT_*) and, independently, in
+ * tests/ext_rules_model.py. */
+#define AZUL_RULE_DISPLAYS_2P1  1u  /* 5 / 7 / 9 factory displays for 2 / 3 / 4 players: (D + 1) * 30 actions, a = source + (D + 1) colour + 5 (D + 1) row */
+#define AZUL_RULE_END_BONUS     2u  /* +2 per complete row, +7 per complete column, +10 per complete colour ONCE at the end of the game (not per round) */
+#define AZUL_RULE_SHORT_DEAL    4u  /* bag and lid both empty at a draw: the round starts with what could be dealt (instead of AZUL_BOX_EMPTY) */
+#define AZUL_RULE_FINITE_BAG    8u  /* tile_pool Random draws WITHOUT replacement from a 100-tile bag, discards go to the lid: _randbelow(tiles left) */
 
 /* observation perspective (game_runner.py:56 `perspective`) */
 #define AZUL_PERSP_PLAYER0  0
 #define AZUL_PERSP_PLAYER1  1
-#define AZUL_PERSP_CURRENT  2     /* current_player - 1, as opponent_move uses (game_runner.py:38) */
+#define AZUL_PERSP_CURRENT  2     /* current_player - 1, as opponent_move uses (game_runner.py:38); two-player reference batches */
+#define AZUL_PERSP_MOVER    7     /* the same for ANY batch (with three / four players 2 is a player) */
 
 /* flags written by azul_batch_flags */
 #define AZUL_FLAG_END_OF_ROUND 1  /* azul.py:182-183 */
@@ -126,8 +140,19 @@ int azul_batch_create(azul_batch_t **out, int n_games, int first_player, int til
  * _step / _statistics, the state and RNG I/O, azul_batch_random_action / _sample_mask -- while the entries that mirror
  * GameRunner (two-player in the reference: game_runner.py:50,57) return AZUL_ERR_INVALID. */
 int azul_batch_create_players(azul_batch_t **out, int n_games, int players, int first_player, int tile_pool);
+/* The same with extended-rule flags (AZUL_RULE_*; 0 = azul_batch_create_players).  Batches of three / four players and batches with any
+ * flag set hold 256-byte wide records and support the entries that mirror Azul's own methods (azul_batch_init / _new_round / _move /
+ * _legal_mask / _next_player / _flags / _count_score / _step / _statistics), azul_batch_random_action / _sample_mask, azul_batch_observe
+ * (get_state for P players, game_runner.py:56-72), the state and RNG I/O and azul_batch_selfplay; mask rows are azul_batch_num_actions
+ * bytes, observations azul_batch_obs_size floats.  The entries that mirror GameRunner.step / reset and the policy entries (compiled for
+ * 180 actions / 136 observations) return AZUL_ERR_INVALID for them.  AZUL_RULE_FINITE_BAG with AZUL_POOL_LID: AZUL_ERR_RULE. */
+int azul_batch_create_rules(azul_batch_t **out, int n_games, int players, int first_player, int tile_pool, unsigned rule_flags);
 int azul_batch_players(const azul_batch_t *b);
-int azul_batch_record_bytes(const azul_batch_t *b);       /* 128, or 256 for 3 / 4 players */
+int azul_batch_displays(const azul_batch_t *b);            /* 5, or 2 * players + 1 */
+unsigned azul_batch_rule_flags(const azul_batch_t *b);
+int azul_batch_num_actions(const azul_batch_t *b);         /* (displays + 1) * 30: 180 / 240 / 300   (game_runner.py:115) */
+int azul_batch_obs_size(const azul_batch_t *b);            /* 5 displays + 6 + 52 players + 1: 136 for the reference's game (game_runner.py:65-72) */
+int azul_batch_record_bytes(const azul_batch_t *b);       /* 128, or 256 for 3 / 4 players and extended-rule batches */
 int azul_batch_destroy(azul_batch_t *b);
 int azul_batch_size(const azul_batch_t *b);
 /* device pointers of the resident arrays (for zero-copy views): records [N][128] u8, MT words [N][624] u32, MT index [N] u32 */
@@ -197,7 +222,7 @@ enum { AZUL_CALL_QUERY = 0, AZUL_CALL_INIT, AZUL_CALL_NEW_ROUND, AZUL_CALL_MOVE,
        AZUL_CALL_STEP, AZUL_CALL_RUNNER_INIT, AZUL_CALL_RUNNER_RESET, AZUL_CALL_RUNNER_STEP, AZUL_CALL_SAMPLE_MASK };
 #define AZUL_WANT_RECORD     1u    /* the game's record after the call -> record_out */
 #define AZUL_WANT_MASK       2u    /* legal mask of the state after the call -> mask[180] */
-#define AZUL_WANT_OBS        4u    /* get_state(perspective = arg) -> obs[136] (two players) */
+#define AZUL_WANT_OBS        4u    /* get_state(perspective = arg: a player, or AZUL_PERSP_MOVER) -> obs[azul_batch_obs_size] */
 #define AZUL_WANT_FLAGS      8u    /* AZUL_FLAG_* -> flags */
 #define AZUL_WANT_POTENTIAL 16u    /* game_runner.py:48-50 -> potential (two players) */
 #define AZUL_WANT_STATS     32u    /* get_statistics -> stats[10] */
@@ -208,7 +233,7 @@ typedef struct azul_call {
     const void *record_in;          /* NULL or the game's record (azul_batch_record_bytes bytes; validated like azul_batch_set_state) */
     const uint32_t *mt_in;          /* NULL or 624 words: the stream to draw from (random.getstate()[1][:624]) */
     uint32_t pos_in;                /* with mt_in: the stream's index to install, random.getstate()[1][624]; ignored without mt_in */
-    const uint8_t *mask_in;         /* AZUL_CALL_SAMPLE_MASK: uint8[180] */
+    const uint8_t *mask_in;         /* AZUL_CALL_SAMPLE_MASK: uint8[azul_batch_num_actions] */
     void *record_out;               /* AZUL_WANT_RECORD */
     uint32_t *mt_out;               /* NULL or room for 624 words, written only when rng_regenerated */
     /* out */
@@ -218,8 +243,8 @@ typedef struct azul_call {
     int32_t reward, done;           /* AZUL_CALL_RUNNER_STEP */
     int32_t action;                 /* AZUL_CALL_SAMPLE_MASK (-1: nothing legal) */
     int32_t flags, potential;
-    uint8_t mask[AZUL_NUM_ACTIONS];
-    float obs[AZUL_OBS_SIZE];
+    uint8_t mask[AZUL_MAX_ACTIONS + 4];   /* azul_batch_num_actions bytes are written */
+    float obs[AZUL_MAX_OBS];              /* azul_batch_obs_size floats are written */
     double stats[AZUL_NUM_STATS];
 } azul_call_t;
 int azul_game_call(azul_batch_t *b, azul_call_t *call, void *stream);

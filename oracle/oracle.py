@@ -182,7 +182,7 @@ RECORD_NP_DTYPE = np.dtype([
     ("score", "<i2", (4,)), ("box", "u1", (5,)), ("lid", "u1", (5,)), ("turn_counter", "<u2"),
     ("first_player_stats", "<u2", (4,)), ("floor_penalty", "<i2", (4,)), ("max_combo", "u1", (4,)),
     ("completed_lines", "u1", (4, 3)), ("players", "u1"),
-    ("n_displays", "u1"), ("pad0", "u1", (2,)), ("xdisplays", "u1", (4, 5)), ("pad", "u1", (28,)),     # beyond the reference: displays 5..8
+    ("n_displays", "u1"), ("reserved0", "u1", (2,)), ("xdisplays", "u1", (4, 5)), ("pad", "u1", (28,)),     # beyond the reference: displays 5..8
 ])
 assert RECORD_NP_DTYPE.itemsize == 256
 

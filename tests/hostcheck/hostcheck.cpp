@@ -6,7 +6,6 @@
 
 #include "azul_wave_host.hpp"      // defines AZ_WAVE_HPP: the device header csrc/azul_wave.hpp is skipped
 #include "azul_core.hpp"
-#include "azul_core_np.hpp"
 #include "azul_tables.hpp"
 
 using namespace az;
@@ -67,35 +66,6 @@ static int advance(HostStream *h, int n_steps, uint8_t *mask, int32_t *action, i
 
 
 #define BY_POOL(pool, call_true, call_false) ((pool) == POOL_LID ? (call_true) : (call_false))
-
-// ---- row N4: the 3 / 4 player core (azul_core_np.hpp) on one 256-byte record ----
-// op: 0 init, 1 new_round, 2 move, 3 next_player, 4 count_score, 5 step; queries (mask / flags / stats) are taken AFTER the op
-template <u32 P, bool LID>
-static int np_op(uint8_t *rec, int first_player, int op, int action, u32 *mt, u32 *pos, uint8_t *mask180, int *flags, double *stats10)
-{
-    static u32 lds[624];
-    LaneConst k; lane_consts(k);
-    GameN<P> g; gamen_load(g, rec);
-    Rng r; rng_attach(r, mt, lds, *pos);
-    u32 st = ST_OK;
-    bool dirty = true;
-    switch (op) {
-    case 0: game_ctor_np<LID>(g, (u32)first_player, r); break;
-    case 1: st = new_round_np<LID>(g, r); break;
-    case 2: do_move_np<LID>(g, action_code((u32)action)); break;
-    case 3: g.cur = (g.cur < P) ? g.cur + 1u : 1u; break;
-    case 4: count_score_np<LID>(g, k); break;
-    case 5: st = checked_step_np<LID>(g, k, r, action); dirty = !(st == ST_ILLEGAL_MOVE || st == ST_GAME_ENDED || st == ST_BAD_ACTION); break;
-    default: dirty = false; break;
-    }
-    if (dirty) gamen_store(g, rec);
-    rng_close(r, pos);
-    if (mask180) { Mask m; legal_mask_np(g, k, m); mask_write(m, mask180); }
-    if (flags) *flags = (sources_board_np(g) == 0u ? 1 : 0) | (walls_end_game_np(g) ? 2 : 0) | (g.eog ? 4 : 0);
-    if (stats10) for (u32 q = 0; q < 10u; q++) stats10[q] = game_stat_np(g, q);
-    return (int)st;
-}
-
 
 extern "C" {
 
@@ -290,20 +260,6 @@ int hc_sample_mask(const uint8_t *mask180, u32 *mt, u32 *pos)
     i32 a = random_agent(m, r, table(), k, code);
     rng_close(r, pos);
     return a;
-}
-
-
-int hc_np_op(uint8_t *rec, int players, int first_player, int tile_pool, int op, int action, u32 *mt, u32 *pos, uint8_t *mask180, int *flags,
-             double *stats10)
-{
-    const bool lid = tile_pool == POOL_LID;
-    if (players == 3) return lid ? np_op<3, true>(rec, first_player, op, action, mt, pos, mask180, flags, stats10)
-                                 : np_op<3, false>(rec, first_player, op, action, mt, pos, mask180, flags, stats10);
-    if (players == 4) return lid ? np_op<4, true>(rec, first_player, op, action, mt, pos, mask180, flags, stats10)
-                                 : np_op<4, false>(rec, first_player, op, action, mt, pos, mask180, flags, stats10);
-    if (players == 2) return lid ? np_op<2, true>(rec, first_player, op, action, mt, pos, mask180, flags, stats10)
-                                 : np_op<2, false>(rec, first_player, op, action, mt, pos, mask180, flags, stats10);
-    return -1;
 }
 
 } // extern "C"

@@ -38,13 +38,50 @@ def lib():
         L.hc_next_player.argtypes = [C.c_void_p]
         L.hc_statistics.argtypes = [C.c_void_p, C.c_void_p]
         L.hc_sample_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.hc_np_op.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
         _lib = L
     return _lib
 
 
 def ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---- the P-player / D-display rules (csrc/azul_rules_x.hpp) under the lockstep wave emulation (simt_rules_x.cpp) ----
+_xlib = None
+XOP = {"query": 0, "init": 1, "new_round": 2, "move": 3, "next_player": 4, "count_score": 5, "step": 6, "random_action": 7, "sample_mask": 8}
+EXT_DISPLAYS_2P1, EXT_END_BONUS, EXT_SHORT_DEAL, EXT_FINITE_BAG = 1, 2, 4, 8
+
+
+def xlib():
+    global _xlib
+    if _xlib is None:
+        name = os.environ.get("AZUL_SIMT_X_LIB", "libsimt_rules_x.so")
+        subprocess.check_call(["make", "-s", "-C", _HERE, name], stdout=subprocess.DEVNULL)
+        L = C.CDLL(os.path.join(_HERE, name))
+        L.shx_op.restype = C.c_int
+        L.shx_op.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_ulonglong, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 5
+        _xlib = L
+    return _xlib
+
+
+def x_op(rec, players, first, pool, ext, op, action, mt, pos, mask_in=None, want_mask=False, want_flags=False, want_stats=False, want_obs=None,
+         margin=0):
+    """One rule call of the emulated azul_x_op_kernel body on one 256-byte record.  `pool` / `ext`: the ABI's tile_pool and AZUL_RULE_*
+    flags.  Returns a dict: status, mask, flags, stats, obs, action, player, rng_dirty."""
+    D = 2 * players + 1 if ext & EXT_DISPLAYS_2P1 else 5
+    NA, NOBS = (D + 1) * 30, 5 * D + 6 + 52 * players + 1
+    mask = np.zeros(NA, np.uint8) if want_mask else None
+    obs = np.zeros(NOBS, np.float32) if want_obs is not None else None
+    stats = np.zeros(10) if want_stats else None
+    flags, act, player, dirty = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    xpool = 2 if ext & EXT_FINITE_BAG else int(pool)
+    mi = None if mask_in is None else np.ascontiguousarray(mask_in, dtype=np.uint8)
+    st = xlib().shx_op(ptr(rec), players, D, int(first), xpool, int(bool(ext & EXT_END_BONUS)), int(bool(ext & EXT_SHORT_DEAL)), margin,
+                       XOP[op] if isinstance(op, str) else op, int(action), ptr(mt), ptr(pos), ptr(mi), ptr(mask), ptr(obs),
+                       int(want_obs) if want_obs is not None else 0, C.cast(C.byref(flags), C.c_void_p), ptr(stats),
+                       C.cast(C.byref(act), C.c_void_p), C.cast(C.byref(player), C.c_void_p), C.cast(C.byref(dirty), C.c_void_p))
+    return {"status": st, "mask": mask, "flags": flags.value, "stats": stats, "obs": obs, "action": act.value, "player": player.value,
+            "rng_dirty": dirty.value}
 
 
 class HostStream:
@@ -104,11 +141,12 @@ class EmuBackend(StepwiseBackend):
     core, compiled for the host with the 64-lane emulation.  Lets the facade's logic (and, in the build
     container, the reference's own test files) run without a GPU.  Never selected by the product."""
 
-    def __new__(cls, first_player, tile_pool, players=2):
-        return super().__new__(EmuBackendNP if int(players) != 2 and cls is EmuBackend else cls)
+    def __new__(cls, first_player, tile_pool, players=2, ext=0):
+        return super().__new__(EmuBackendX if (int(players) != 2 or int(ext)) and cls is EmuBackend else cls)
 
-    def __init__(self, first_player, tile_pool, players=2):
+    def __init__(self, first_player, tile_pool, players=2, ext=0):
         self.fp, self.pool = int(first_player), int(tile_pool)
+        self.num_actions, self.obs_size = 180, 136
         self.rec = np.zeros(128, np.uint8)
         self.mt = np.zeros(624, np.uint32)
         self.pos = np.array([624], np.uint32)
@@ -187,54 +225,61 @@ class EmuBackend(StepwiseBackend):
         return lib().hc_sample_mask(ptr(m), ptr(self.mt), ptr(self.pos))
 
 
-class EmuBackendNP(EmuBackend):
-    """The 3 / 4 player core (csrc/azul_core_np.hpp) behind the same interface: 256-byte wide records, Azul's own methods."""
+class EmuBackendX(EmuBackend):
+    """Three / four players and extended rules (csrc/azul_rules_x.hpp: the body of azul_x_op_kernel under the lockstep wave emulation)
+    behind the same interface: 256-byte wide records, Azul's own methods, the sampler, get_state."""
 
-    def __init__(self, first_player, tile_pool, players):
+    def __init__(self, first_player, tile_pool, players, ext=0):
         super().__init__(first_player, tile_pool)
-        self.players = int(players)
+        self.players, self.ext = int(players), int(ext)
+        D = 2 * self.players + 1 if self.ext & EXT_DISPLAYS_2P1 else 5
+        self.num_actions, self.obs_size = (D + 1) * 30, 5 * D + 6 + 52 * self.players + 1
         self.rec = np.zeros(256, np.uint8)
 
     def get(self):
         from azul_deep_reinforcement_learning_amd.records import RECORD_NP_DTYPE
         return self.rec.copy().view(RECORD_NP_DTYPE)[0]
 
-    def _op(self, op, action=0, mask=False, flags=False, stats=False):
-        m = np.zeros(180, np.uint8) if mask else None
-        f = C.c_int(0)
-        s = np.zeros(10) if stats else None
-        st = lib().hc_np_op(ptr(self.rec), self.players, self.fp, self.pool, op, int(action), ptr(self.mt), ptr(self.pos), ptr(m),
-                            C.cast(C.byref(f), C.c_void_p) if flags else None, ptr(s))
-        return st, m, f.value, s
+    def _op(self, op, action=0, **kw):
+        return x_op(self.rec, self.players, self.fp, self.pool, self.ext, op, action, self.mt, self.pos, **kw)
 
     def op_init(self):
-        self._op(0)
+        self._op("init")
 
     def op_new_round(self):
-        return self._op(1)[0]
+        return self._op("new_round")["status"]
 
     def op_move(self, action):
-        self._op(2, action)
+        self._op("move", action)
 
     def op_next_player(self):
-        self._op(3)
+        self._op("next_player")
 
     def op_count_score(self):
-        self._op(4)
+        self._op("count_score")
 
     def op_step(self, action):
-        return self._op(5, action)[0]
+        return self._op("step", action)["status"]
 
     def op_flags(self):
-        return self._op(99, flags=True)[2]
+        return self._op("query", want_flags=True)["flags"]
 
     def op_mask(self):
-        return self._op(99, mask=True)[1].astype(bool)
+        return self._op("query", want_mask=True)["mask"].astype(bool)
 
     def op_statistics(self):
-        return self._op(99, stats=True)[3]
+        return self._op("query", want_stats=True)["stats"]
+
+    def op_observe(self, perspective):
+        return self._op("query", want_obs=int(perspective))["obs"].astype(np.int64)
+
+    def op_sample_mask(self, mask):
+        m = np.ascontiguousarray(np.asarray(mask, dtype=np.uint8).reshape(-1))
+        if m.size != self.num_actions:
+            raise ValueError("this backend samples masks of %d actions" % self.num_actions)
+        return self._op("sample_mask", mask_in=m)["action"]
 
     def _two_players_only(self, *a, **k):
-        raise RuntimeError("GameRunner entries are two-player (game_runner.py:50,57)")
+        raise RuntimeError("GameRunner.step / reset and the what-if potential are two-player (game_runner.py:43-55, 76-85)")
 
-    op_observe = op_potential = op_runner_init = op_runner_reset = op_runner_step = _two_players_only
+    op_potential = op_runner_init = op_runner_reset = op_runner_step = _two_players_only

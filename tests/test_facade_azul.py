@@ -364,3 +364,51 @@ def test_float_typed_attributes_are_accepted_like_the_reference(facade, resource
     g.score = np.array([1.5, 0.0])
     with pytest.raises(ValueError, match="score must hold integral values"):
         g.count_score()
+
+
+@pytest.mark.parametrize("players", [2, 3, 4])
+def test_beyond_the_reference_parity_unpinned_extended_rules_through_the_facade(facade, players):
+    """Azul(players=P, rules={"displays": "2P+1", "bonuses": "end", "short_deal": True, ...}): the extended rules (beyond the reference:
+    azul.py:19,72,86,266-288 -- parity unpinned) through the single-game API on the global `random` stream, against the oracle's
+    restatement, move by move: attributes, masks of (2P+2) * 30 actions, the stream's position."""
+    import ctypes as C
+    from oracle import oracle as oz
+    Lz = oz.lib()
+    ext = oz.EXT_DISPLAYS_2P1 | oz.EXT_END_BONUS | oz.EXT_SHORT_DEAL
+    rules = {"first_player": "Random", "tile_pool": "Lid", "displays": "2P+1", "bonuses": "end", "short_deal": True}
+    random.seed(31)
+    r = oz.seeded_rng(31)
+    og = oz.Game()
+    assert Lz.oz_init_ext(C.byref(og), players, 0, oz.POOL_LID, ext, C.byref(r)) == 0
+    g = facade.Azul(players=players, rules=rules)
+    D = 2 * players + 1
+    assert g.game_board_displays.shape == (D, 5) and g.next_first_player == og.next_first_player
+    g.new_round()
+    assert Lz.oz_new_round(C.byref(og), C.byref(r)) == 0
+    S = D + 1
+    picker = np.random.RandomState(5)
+    for t in range(400):
+        rec = oz.pack_np(og)
+        assert np.array_equal(g.game_board_displays, np.concatenate([rec["displays"], rec["xdisplays"]])[:D]), t
+        assert np.array_equal(g.game_board_center, rec["center"]) and np.array_equal(g.score, rec["score"][:players]), t
+        assert np.array_equal(g.pattern_lines, rec["pattern_lines"][:players]) and np.array_equal(g.floors, rec["floors"][:players]), t
+        assert (g.current_player, g.next_first_player, bool(g.end_of_game)) == (og.current_player, og.next_first_player, bool(og.end_of_game)), t
+        assert np.array_equal(g.box_tiles, rec["box"]) and np.array_equal(g.lid_tiles, rec["lid"]), t
+        if og.end_of_game:
+            break
+        mask = g.legal_mask()
+        want = oz.check_all_valid_x(og)
+        assert mask.shape == (S * 30,) and np.array_equal(mask, want), t
+        if not want.any():
+            break
+        a = int(picker.choice(np.flatnonzero(want)))
+        d, c, p = a % S, (a // S) % 5, a // (5 * S)
+        assert g.is_legal_move(d, c, p)
+        g.step(d, c, p)
+        assert Lz.oz_step(C.byref(og), d, c, p, C.byref(r)) == 0
+        st = random.getstate()
+        assert st[1][624] == int(r.idx) and np.array_equal(np.array(st[1][:624], dtype=np.uint32), np.ctypeslib.as_array(r.mt)), t
+    assert og.end_of_game and t > 30
+    with pytest.raises(facade.azul.GameEnded):
+        g.step(0, 0, 0)
+    random.seed()

@@ -1,5 +1,5 @@
 """Row N4 on the GPU: batches of three- and four-player games (azul_batch_create_players, 256-byte wide records, kernels of
-csrc/azul_core_np.hpp) replay the reference's Azul(players=3|4) streams (tests/golden/traj_players.npz, generated from the real
+csrc/azul_rules_x.hpp: two games per wavefront) replay the reference's Azul(players=3|4) streams (tests/golden/traj_players.npz, generated from the real
 reference) through the C ABI: azul_batch_init / _new_round / _legal_mask / _step / _flags / _statistics, IllegalMove and
 GameEnded statuses, RNG positions; the single rule methods (move, count_score, next_player) against the oracle; and the
 entries that mirror the two-player GameRunner are refused.  Reference: azulnet/azul.py:18-33, 64-89, 118-191, 192-315."""
@@ -186,7 +186,7 @@ def test_game_runner_entries_are_refused_for_more_than_two_players():
 
 
 def test_persistent_selfplay_for_three_and_four_players_replays_the_reference(golden_dir):
-    """azul_batch_selfplay on 3- and 4-player batches (azul_np_selfplay_kernel: one launch, games resident in registers) against
+    """azul_batch_selfplay on 3- and 4-player batches (azul_x_selfplay_kernel: one launch, two games per wavefront resident in registers) against
     tests/golden/traj_players_selfplay.npz -- streams played by the REAL reference (Azul(players=P).step with the reference's
     RandomAgent on the global stream, fresh game at each game end) -- and against the oracle's records, RNG positions and counters."""
     import torch

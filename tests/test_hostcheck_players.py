@@ -1,6 +1,7 @@
-"""Row N4: the 3 / 4 player device core (csrc/azul_core_np.hpp), compiled for the host against the 64-lane emulation
-(tests/hostcheck), replays the reference's Azul(players=3|4) streams of tests/golden/traj_players.npz bit for bit -- a logic
-check of the wave-level code before it reaches a GPU (the -m gpu twin is tests/test_gpu_players.py).  CPU only."""
+"""Row N4: the 3 / 4 player rule entries (csrc/azul_rules_x.hpp: the body of azul_x_op_kernel, two games per wavefront), compiled for
+the host and run under the lockstep 64-lane emulation (tests/hostcheck/simt), replay the reference's Azul(players=3|4) streams of
+tests/golden/traj_players.npz bit for bit -- a logic check of the wave-level code before it reaches a GPU (the -m gpu twin is
+tests/test_gpu_players.py).  CPU only."""
 import ctypes as C
 import os
 
@@ -10,16 +11,12 @@ import pytest
 from oracle import oracle as oz
 from tests.hostcheck import hostcheck as hc
 
-OP_INIT, OP_NEW_ROUND, OP_MOVE, OP_NEXT_PLAYER, OP_COUNT_SCORE, OP_STEP, OP_NONE = 0, 1, 2, 3, 4, 5, 99
+OP_INIT, OP_NEW_ROUND, OP_MOVE, OP_NEXT_PLAYER, OP_COUNT_SCORE, OP_STEP, OP_NONE = "init", "new_round", "move", "next_player", "count_score", "step", "query"
 
 
 def np_op(rec, players, first, pool, op, action, mt, pos, want_mask=False, want_flags=False, want_stats=False):
-    mask = np.zeros(180, np.uint8) if want_mask else None
-    flags = C.c_int(0)
-    stats = np.zeros(10) if want_stats else None
-    st = hc.lib().hc_np_op(hc.ptr(rec), players, first, pool, op, action, hc.ptr(mt), hc.ptr(pos), hc.ptr(mask),
-                           C.cast(C.byref(flags), C.c_void_p) if want_flags else None, hc.ptr(stats))
-    return st, mask, flags.value, stats
+    o = hc.x_op(rec, players, first, pool, 0, op, action, mt, pos, want_mask=want_mask, want_flags=want_flags, want_stats=want_stats)
+    return o["status"], o["mask"], o["flags"], o["stats"]
 
 
 @pytest.fixture(scope="module")

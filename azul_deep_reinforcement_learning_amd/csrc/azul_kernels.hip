@@ -853,6 +853,7 @@ static azx::XBatchDev xdev(const azul_batch_t *b)
     x.rules.end_bonus = (b->ext & AZUL_RULE_END_BONUS) ? 1u : 0u;
     x.rules.short_deal = (b->ext & AZUL_RULE_SHORT_DEAL) ? 1u : 0u;
     x.tab = (const double2 *)b->Tx;
+    x.prof = b->d.prof;
     return x;
 }
 

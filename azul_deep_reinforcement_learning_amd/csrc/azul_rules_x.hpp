@@ -749,8 +749,10 @@ AZ_FN void outputs_x(const GX<P, D> &g, const Out2 &o, i32 a, u32 dn, u32 l)
 // returns 0 = move played, 1 = game ended with this move, 2 = stuck, 0x100 | status on a rule error
 template <u32 P, u32 D, int OUT, bool PAD, bool BITS>
 AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2 &r, const TabX &T, u64 margin, const Counters2 &cnt,
-                          const Out2 &o, bool &dead)
+                          const Out2 &o, bool &dead, SegProf *prof_ = nullptr)
 {
+    (void)prof_;
+    AZ_STAMP(SEG_LOOP);
     const K2 &k = K.k;
     const u32 l = k.l;
     // the two MT19937 words of this move's random(), fetched speculatively from the tempered copy (az2::selfplay_step2)
@@ -773,6 +775,7 @@ AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2
     const double2 fs = T.fs[8u * (J < Dim<D>::TROWS ? J : Dim<D>::TROWS - 1u) + 31u - (u32)__builtin_clz(Mc)];  // {Fr[J][ilog2 M], S[J]}
     if (OUT == 1 || (OUT == 2 && o.mask)) store_mask_x<D, (PAD && OUT == 1)>(o, m, l);
     if ((OUT == 1 && BITS) || (OUT == 2 && o.maskbits)) store_maskbits_x<D>(o, m, l);
+    AZ_STAMP(SEG_MASK);
     const double sJ = fs.y;
     const double total = ((double)M + (M ? fs.x : sJ)) + 0.0;
     double x = u01 * total;
@@ -804,6 +807,7 @@ AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2
     }
     Choice<D> ch;
     pick_action_x<D>(m, pre, kg, k, ch);
+    AZ_STAMP(SEG_SAMPLE);
 
     u32 ret = 0;
     if (AZ_UNLIKELY(any_nomove)) {
@@ -815,29 +819,35 @@ AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2
             ret = st0 ? (0x100u | st0) : 2u;
         }
         dead |= (ret & 0x100u) != 0u;
+        AZ_STAMP(SEG_RESET);
     }
     if (!nomove) {
         do_move_x(g, ch.s, ch.c, ch.row, rules.pool != (u32)XPOOL_RANDOM, K);        // azul.py:304
         sources_x(g);
+        AZ_STAMP(SEG_MOVE);
         const bool eor = (g.B0 | g.B1) == 0u;                 // :306 is_end_of_round (the token counts)
         g.cur = eor ? g.cur : (g.cur < P ? g.cur + 1u : 1u);  // :313 next_player
         u32 st = ST_OK;
         bool any_done = false;
+        AZ_STAMP(SEG_AFTERMOVE);
         if (AZ_UNLIKELY(wave_any(eor))) {
             if (eor) {
                 count_score_x(g, rules.pool != (u32)XPOOL_RANDOM, rules.end_bonus != 0u, K);     // :307
+                AZ_STAMP(SEG_SCORE);
                 if (g.over) {                                 // :308-309
                     g.eog = 1;
                     if (rules.end_bonus) end_game_bonus_x(g);
                 } else {
                     st = new_round_x(g, rules, r, margin, K); // :311
                 }
+                AZ_STAMP(SEG_NEWROUND);
             }
             any_done = wave_any(eor & (g.over != 0u));
             dead |= st != ST_OK;
         }
         const u32 dn = g.eog ? 1u : 0u;
         outputs_x<P, D, OUT>(g, o, ch.a, dn, l);
+        AZ_STAMP(SEG_TAIL);
         ret = st != ST_OK ? (0x100u | st) : dn;
         if (AZ_UNLIKELY(any_done)) {
             if (dn != 0u) {
@@ -849,6 +859,7 @@ AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2
                 if (st2) ret = 0x100u | st2;
             }
             dead |= (ret & 0x100u) != 0u;
+            AZ_STAMP(SEG_RESET);
         }
     }
     return ret;
@@ -891,6 +902,7 @@ struct XBatchDev {
     u64 draw_margin;
     RulesX rules;
     const double2 *tab;  // {Fr[J][b], S[J]} pairs, Dim<D>::TROWS x 8
+    u64 *prof;           // [SEG_COUNT] segment cycle sums (only written by the -DAZ_PROFILE_SEGMENTS diagnostic build)
 };
 
 enum { XOP_QUERY = 0, XOP_INIT, XOP_NEW_ROUND, XOP_MOVE, XOP_NEXT_PLAYER, XOP_COUNT_SCORE, XOP_STEP, XOP_RANDOM_ACTION, XOP_SAMPLE_MASK };
@@ -1056,11 +1068,22 @@ AZ_FN void selfplay_body_x(const XBatchDev &b, const XTraj &t, u32 wave_id, u32 
     Out2 o = {t.mask, t.maskbits, t.action, t.reward, t.done, t.packed, t.rec, t.mask_stride, gi,
               l == 0u ? (u32 *)t.action : (l == 1u ? (u32 *)t.reward : t.packed)};
     bool dead = false;               // a game stopped by a rule error (bag and lid empty without the short-deal rule) stays as it is
+#if defined(AZ_PROFILE_SEGMENTS)
+    SegProf prof;
+    for (int q = 0; q < SEG_COUNT; q++) prof.acc[q] = 0;
+    prof.last = __builtin_amdgcn_s_memtime();
+    SegProf *pp = &prof;
+#else
+    SegProf *pp = nullptr;
+#endif
 #pragma unroll 1
     for (int s = 0; s < t.n_steps; s++) {
-        if (!dead) selfplay_step_x<P, D, OUT, PAD, BITS>(g, b.rules, K, r, tab, b.draw_margin, cnt, o, dead);
+        if (!dead) selfplay_step_x<P, D, OUT, PAD, BITS>(g, b.rules, K, r, tab, b.draw_margin, cnt, o, dead, pp);
         o.e += b.n;
     }
+#if defined(AZ_PROFILE_SEGMENTS)
+    if (lane == 0u) for (int q = 0; q < SEG_COUNT; q++) atomicAdd((unsigned long long *)(b.prof + q), (unsigned long long)prof.acc[q]);
+#endif
     gx_store(g, rec, l);
     rng2_close(r, gmt, b.mtpos + gi, l);
 }

@@ -76,7 +76,7 @@ long long shx_selfplay(int n_games, int players, int displays, uint8_t *state, u
     for (u32 w = 0; w < ((u32)n_games + 1u) / 2u; w++) {
         XJob *j = (XJob *)calloc(1, sizeof(XJob));
         j->b = {state, mt, mtpos, episodes, stuck, stat_sum, (u32)n_games, margin ? margin : AZ_DRAW_MARGIN,
-                {(u32)first_player, (u32)pool, (u32)end_bonus, (u32)short_deal}, (const double2 *)tab};
+                {(u32)first_player, (u32)pool, (u32)end_bonus, (u32)short_deal}, (const double2 *)tab, nullptr};
         j->t = {n_steps, mask, maskbits, action, reward, done, rec, packed, (u32)pitch};
         j->players = players; j->displays = displays; j->variant = variant; j->wave = w;
         ops += (long long)simt::run_wave(fn, j);
@@ -96,7 +96,7 @@ int shx_op(uint8_t *rec, int players, int displays, int first_player, int pool, 
     XJob *j = (XJob *)calloc(1, sizeof(XJob));
     u64 episodes = 0; u32 stuck = 0; double stat_sum[10] = {0};
     j->b = {rec, mt, pos, &episodes, &stuck, stat_sum, 1u, margin ? margin : AZ_DRAW_MARGIN,
-            {(u32)first_player, (u32)pool, (u32)end_bonus, (u32)short_deal}, (const double2 *)tab};
+            {(u32)first_player, (u32)pool, (u32)end_bonus, (u32)short_deal}, (const double2 *)tab, nullptr};
     i32 act_in = action, act_out = 0;
     uint8_t status = 0, fl = 0, pl = 0, rd = 0;
     memset(&j->op, 0, sizeof(j->op));

@@ -81,7 +81,7 @@ def test_beyond_the_reference_parity_unpinned_selfplay_equals_the_oracle(players
             mts, poss = env.get_rng_range()
             if variant != "none":
                 mask_all, act_all, done_all = tr["mask"].cpu().numpy(), tr["action"].cpu().numpy(), tr["done"].cpu().numpy()
-                assert not tr["reward"].any()
+                rew_all = tr["reward"].cpu().numpy()
             for g in range(n):
                 tag = (P, ext, first, pool, variant, g)
                 s = oz.StreamX(seed0 + g, P, first_player=first, tile_pool=pool, ext=ext)
@@ -107,6 +107,7 @@ def test_beyond_the_reference_parity_unpinned_selfplay_equals_the_oracle(players
                 if variant != "none":
                     assert np.array_equal(mask_all[:, g], o["mask"]), tag
                     assert np.array_equal(act_all[:, g], o["action"]) and np.array_equal(done_all[:, g], o["done"]), tag
+                    assert not rew_all[:, g].any(), tag          # GameRunner's shaped reward is two-player (game_runner.py:50)
                 if variant == "records":
                     got = tr["records"][:, g].cpu().numpy()
                     assert got.tobytes() == o["rec_after"].tobytes(), tag

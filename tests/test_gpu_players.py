@@ -173,12 +173,17 @@ def test_game_runner_entries_are_refused_for_more_than_two_players():
     env.seed(1)
     env.init()
     with pytest.raises(L.AzulHipError):
-        env.reset()
+        env.reset()                                                     # GameRunner.reset / step / the shaped reward: two players (game_runner.py:50)
     with pytest.raises(L.AzulHipError):
-        env.get_state()
-    tr = env.alloc_trajectory(4, mask_pitch=192)                        # 3 / 4 players: self-play exists, with dense mask rows only
+        env.step(np.zeros(4, np.int32))
     with pytest.raises(L.AzulHipError):
-        env.selfplay(4, tr["mask"], tr["action"], tr["reward"], tr["done"])
+        env.score_preview()
+    env.new_round()
+    assert env.get_state().shape == (4, 5 * 5 + 6 + 52 * 3 + 1)         # get_state itself is P-generic in the reference (game_runner.py:56-72)
+    with pytest.raises(L.AzulHipError):
+        env.get_state(perspective=3)                                    # players are 0 .. P-1
+    tr = env.alloc_trajectory(4, mask_pitch=192)                        # padded mask rows are fine (round 3 refused them for 3 / 4 players)
+    env.selfplay(4, tr["mask"], tr["action"], tr["reward"], tr["done"])
     with pytest.raises(L.AzulHipError):
         BatchedAzul(4, players=5)
     with pytest.raises(Exception):

@@ -22,18 +22,33 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from azul_deep_reinforcement_learning_amd import BatchedAzul  # noqa: E402
 
-env = BatchedAzul(4096)
-env.seed(0); env.runner_init(); env.runner_init()
-t = env.alloc_trajectory(256, packed_mask=True)
-for _ in range(8):
-    env.selfplay(256, t["mask"], t["action"], t["reward"], t["done"], maskbits=t["maskbits"], packed=t["packed"])
-torch.cuda.synchronize()
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+ext = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+warm = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+if P == 2 and ext == 0:
+    env = BatchedAzul(4096)
+    env.seed(0); env.runner_init(); env.runner_init()
+    t = env.alloc_trajectory(256, packed_mask=True)
+    run = lambda: env.selfplay(256, t["mask"], t["action"], t["reward"], t["done"], maskbits=t["maskbits"], packed=t["packed"])
+else:
+    env = BatchedAzul(4096, players=P, ext_rules=ext)
+    env.seed(0); env.init(); env.new_round()
+    t = env.alloc_trajectory(256, packed_mask=True, mask_pitch={5: 192, 7: 256, 9: 320}[env.displays], mask_bits=False)
+    run = lambda: env.selfplay(256, t["mask"], t["action"], t["reward"], t["done"], packed=t["packed"])
 cyc = np.zeros(9, dtype=np.uint64)
+for _ in range(warm):                                   # games start in lockstep: let their rounds drift apart before measuring
+    run()
+torch.cuda.synchronize()
+L.check(L.lib.azul_batch_segment_profile(env._h, cyc.ctypes.data_as(C.c_void_p), 9, 1))
+for _ in range(8):
+    run()
+torch.cuda.synchronize()
 L.check(L.lib.azul_batch_segment_profile(env._h, cyc.ctypes.data_as(C.c_void_p), 9, 1))
 names = ["mask+mask out", "sample (RandomAgent)", "do_move", "after move (what-if / next player)", "tail (reward, outputs)",
          "new_round", "count_score", "reset (ctor)", "loop overhead"]
 tot = float(cyc.sum())
 moves = 4096 * 256 * 8
+print("players %d, rule flags %d, %d warm-up launches" % (P, ext, warm))
 for n, c in zip(names, cyc):
     print("%-38s %6.2f %%   %8.1f cycles/move" % (n, 100.0 * float(c) / tot, float(c) / moves))
 print("total %.0f cycles/move (diagnostic build)" % (tot / moves))

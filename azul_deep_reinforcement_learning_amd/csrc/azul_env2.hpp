@@ -138,12 +138,10 @@ AZ_FN u32 checked_step2(G2 &g, i32 a, const Mask2 &m, Rng2 &r, u64 margin, const
 
 AZ_FN u32 mask_count2(const Mask2 &m) { return __popc(m.m[0]) + __popc(m.m[1]) + __popc(m.m[2]) + __popc(m.m[3]) + __popc(m.m[4]) + __popc(m.m[5]); }
 
-AZ_FN void episode_stats2(const G2 &g, const Counters2 &cnt, u32 l)
+AZ_FN void episode_stats2(const G2 &g, Counters2 &cnt, u32 l)
 {
-    if (l == 0u) {
-        for (u32 q = 0; q < 10u; q++) cnt.stat_sum[q] += game_stat2(g, q);
-        *cnt.episodes += 1ull;
-    }
+    const double f0 = (double)(g.fps & 0xffffu), f1 = (double)(g.fps >> 16);
+    counters2_episode(cnt, stat_lane(l, g.score0, g.score1, g.turn, f0 / (f0 + f1) * 100, g.fp0, g.mc0, g.cl0));
 }
 
 template <bool LID>
@@ -157,7 +155,7 @@ AZ_FN u32 reset2(G2 &g, u32 first_player, Rng2 &r, u64 margin, const K2 &k)
 // One env move of policy-driven self-play (azul_kernels.hip's env_policy_step: the same decisions in the same order, with ONE reset site)
 template <bool LID>
 AZ_FN u32 policy_step2(G2 &g, i32 av, const Mask2 &m /* of the current state: the one that was published */, u32 first_player, Rng2 &r, u64 margin,
-                        const Counters2 &cnt, const K2 &k, i32 &rew, u32 &dn)
+                        Counters2 &cnt, const K2 &k, i32 &rew, u32 &dn)
 {
     rew = 0; dn = 0;
     // "no action" is legitimate only when nothing is legal (hazard H3)
@@ -182,7 +180,7 @@ AZ_FN u32 policy_step2(G2 &g, i32 av, const Mask2 &m /* of the current state: th
     }
     if (AZ_UNLIKELY(wave_any(stuck | restart))) {
         if (stuck | restart) {
-            if (stuck) { if (k.l == 0u) *cnt.stuck += 1u; dn = 2u; }
+            if (stuck) { cnt.stuck_add += 1u; dn = 2u; }
             else if (st == ST_OK) episode_stats2(g, cnt, k.l);         // (a game handed in finished is not counted: st == ST_GAME_ENDED)
             u32 st0 = reset2<LID>(g, first_player, r, margin, k);
             st = stuck ? (st0 ? st0 : (u32)ST_STUCK) : st0;
@@ -214,7 +212,7 @@ AZ_FN u32 opponent_loop2(G2 &g, Rng2 &r, const Tab2 &T, u64 margin, const K2 &k,
 // One AGENT step of NNRunner.run_episode (azul_kernels.hip's env_agent_step over azul_core.hpp's runner_step, statement for statement)
 template <bool LID>
 AZ_FN u32 agent_step2(G2 &g, i32 av, const Mask2 &m /* of the current state */, u32 first_player, Rng2 &r, const Tab2 &T, u64 margin,
-                       const Counters2 &cnt, const K2 &k, i32 &rew, u32 &dn)
+                       Counters2 &cnt, const K2 &k, i32 &rew, u32 &dn)
 {
     rew = 0;
     dn = g.over ? 1u : 0u;
@@ -230,7 +228,7 @@ AZ_FN u32 agent_step2(G2 &g, i32 av, const Mask2 &m /* of the current state */, 
         }
     }
     const bool dirty = !(st == ST_ILLEGAL_MOVE || st == ST_BAD_ACTION);
-    if (st == ST_STUCK) { if (k.l == 0u) *cnt.stuck += 1u; dn = 2u; rew = 0; }   // hazard H3: nobody can move
+    if (st == ST_STUCK) { cnt.stuck_add += 1u; dn = 2u; rew = 0; }   // hazard H3: nobody can move
     else if (st == ST_GAME_ENDED) dn = 1u;
     else if (st == ST_OK && dn) episode_stats2(g, cnt, k.l);
     if (dirty && dn) {

@@ -462,7 +462,8 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
     az2::rng2_open(r, gmt, mt_lds[half], b.mtpos[gi], l);
     az2::rng2_attach_tempered(r, mtt_lds[half], l);
     const u64 margin = b.draw_margin;
-    az2::Counters2 cnt = {b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10};
+    az2::Counters2 cnt;
+    az2::counters2_open(cnt, b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10, l);
     az2::Out2 o = {t.mask, t.maskbits, t.action, t.reward, t.done, t.packed, t.rec, mask_stride, gi,
                    l == 0u ? (u32 *)t.action : (l == 1u ? (u32 *)t.reward : t.packed)};
 #if defined(AZ_PROFILE_SEGMENTS)
@@ -497,6 +498,7 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
 #endif
     az2::g2_store(g, rec, l);
     az2::rng2_close(r, gmt, b.mtpos + gi, l);
+    az2::counters2_close(cnt, l);
 }
 
 #include "azul_rules_x.hpp"

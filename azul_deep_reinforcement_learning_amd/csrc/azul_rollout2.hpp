@@ -195,7 +195,8 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     u32 *gmt = b.mt + (size_t)gic * 624u;
     az2::rng2_open(r, gmt, mtS[gl], b.mtpos[gic], l);
     const u64 margin = b.draw_margin;
-    az2::Counters2 cnt = {b.episodes + gic, b.stuck + gic, b.stat_sum + (size_t)gic * 10};
+    az2::Counters2 cnt;
+    az2::counters2_open(cnt, b.episodes + gic, b.stuck + gic, b.stat_sum + (size_t)gic * 10, l);
     u32 st_last = ST_OK;
     float *orow = obsS + gl * PF_OBS_STRIDE;
     __syncthreads();                                     // tables / biases staged
@@ -343,6 +344,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     if (live) {
         az2::g2_store(g, rec, l);
         az2::rng2_close(r, gmt, b.mtpos + gi, l);
+        az2::counters2_close(cnt, l);
         if (a.status && l == 0u) a.status[gi] = (uint8_t)st_last;
     }
     if (a.counter_dev && tid == 0u) {

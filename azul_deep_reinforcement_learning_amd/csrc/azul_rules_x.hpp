@@ -402,6 +402,10 @@ AZ_FN void count_score_x(GX<P, D> &g, bool tracked, bool end_bonus, const KX<D> 
 {
     const K2 &k = K.k;
     bool over = false;
+    // (the two rule switches as per-lane masks behind an empty asm: as uniform conditions they become scalar branches between the
+    // players' blocks, and the P independent chains are only interleaved by the scheduler inside ONE basic block)
+    u32 tmask = tracked ? ~0u : 0u, bmask = end_bonus ? 0u : ~0u;
+    asm volatile("" : "+v"(tmask), "+v"(bmask));
 #pragma unroll
     for (u32 p = 0; p < P; p++) {
         const u32 F = full_lines2(g.cp[p], k);                                             // :216
@@ -409,10 +413,10 @@ AZ_FN void count_score_x(GX<P, D> &g, bool tracked, bool end_bonus, const KX<D> 
         score2(g.wall[p] | (F & k.pbelow), k, s);                                          // :219: placements in ascending (row, colour) order
         const bool on = ((F >> k.l) & 1u) != 0u;
         // beyond the reference (end_bonus): the +2 / +10 / +7 of :266-288 are not part of the round's count
-        const i32 cnt = (i32)hsum(on ? (end_bonus ? s.pos : s.val) : 0u);                  // :289
+        const i32 cnt = (i32)hsum(on ? s.pos + ((s.val - s.pos) & bmask) : 0u);            // :289
         g.mc[p] = umax(g.mc[p], hmax(on ? s.pos : 0u));                                    // :264
         g.cl[p] += (u32)__popc(s.rowdone & F) + ((u32)__popc(s.colordone & F) << 8) + ((u32)__popc(s.coldone & F) << 16);   // :270,:278,:286
-        g.lidp += tracked ? lid_tally2(F, k.l) : 0u;                                       // :220-222
+        g.lidp += lid_tally2(F, k.l) & tmask;                                              // :220-222
         g.wall[p] |= F;
         g.cp[p] = (g.cp[p] == k.rowp1) ? 0u : g.cp[p];                                     // :218
         const i32 pen = floor_penalty(g.floor_[p]);
@@ -458,9 +462,10 @@ AZ_FN void add_tile(u32 &cs0, u32 &cs1, u32 d, u32 colour, u32 l)
     if (Dim<D>::WIDE) cs1 += ((l == cell) & hi) ? 1u : 0u;
 }
 
-// the draws of a round, one after the other (every pool; any D): used where the parallel draw of az2::deal_tiles2 does not apply
+// the draws of a round one after the other, for the pools whose draws consume a data-dependent number of words: "Random"
+// (_randbelow(5) per tile, azul.py:78) and -- beyond the reference -- the finite bag (_randbelow(tiles left) per tile)
 template <u32 D>
-AZ_FN u32 deal_serial_x(u32 &cs0, u32 &cs1, u64 &box, u64 &lid, u32 &lidp, u32 pool, bool short_deal, Rng2 &r, u64 margin, u32 l)
+AZ_FN u32 deal_serial_x(u32 &cs0, u32 &cs1, u64 &box, u64 &lid, u32 &lidp, u32 pool, bool short_deal, Rng2 &r, u32 l)
 {
     if (pool == (u32)XPOOL_RANDOM) {
 #pragma unroll 1
@@ -471,44 +476,19 @@ AZ_FN u32 deal_serial_x(u32 &cs0, u32 &cs1, u64 &box, u64 &lid, u32 &lidp, u32 p
 #pragma unroll 1
     for (u32 t = 0; t < 4u * D; t++) {
         u32 total = (u32)(Pp >> 32) & 0xffu;
-        if (total == 0u) {                                                           // :81-83, :85
+        if (total == 0u) {                                                           // the bag is empty: refill it from the lid (like :81-83)
             box = lid + lid_fold2(lidp, l); lid = 0; lidp = 0;
             Pp = ((box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;
             total = (u32)(Pp >> 32) & 0xffu;
             if (total == 0u) return short_deal ? (u32)ST_OK : (u32)ST_BOX_EMPTY;     // beyond the reference: the short deal
         }
-        u32 color;
-        if (pool == (u32)XPOOL_BAG) {
-            // beyond the reference: the nth of the `total` tiles left, tiles ordered by colour; random.randrange(total) = _randbelow
-            const u32 nth = rng2_below(r, total, 32u - (u32)__builtin_clz(total), l);
-            const u32 pc = ((u32)Pp >> ((l & 3u) * 8u)) & 0xffu;
-            color = (u32)__popc(hb((pc <= nth) & (l < 4u)));
-        } else {
-            // "Lid" (:87): random.choices over box_c / total; azul_core.hpp's exactness argument (integer decision unless K * T lies within
-            // `margin` of a multiple of 2^32, then the literal fp64 code)
-            u32 wa_ = 0, wb_ = 0;
-#pragma unroll 1
-            for (u32 w = 0; w < 2u; w++) { wa_ = wb_; wb_ = rng2_u32(r, l); }
-            const u32 a27 = wa_ >> 5, b26 = wb_ >> 6;
-            const u32 Klo = (a27 << 26) | b26, Khi = a27 >> 6;
-            const u64 KT = (u64)Klo * total + (((u64)Khi * total) << 32);
-            if (((KT - margin) >> 32) == ((KT + margin) >> 32)) {
-                const u32 pc = ((u32)Pp >> ((l & 3u) * 8u)) & 0xffu;
-                color = (u32)__popc(hb(((pc << 21) <= (u32)(KT >> 32)) & (l < 4u)));
-            } else {
-                const double tot = (double)total;
-                const double q0 = (double)((u32)box & 0xffu) / tot, q1 = (double)((u32)(box >> 8) & 0xffu) / tot,
-                             q2 = (double)((u32)(box >> 16) & 0xffu) / tot, q3 = (double)((u32)(box >> 24) & 0xffu) / tot,
-                             q4 = (double)((u32)(box >> 32) & 0xffu) / tot;
-                const double c0 = q0, c1 = c0 + q1, c2 = c1 + q2, c3 = c2 + q3, c4 = c3 + q4;
-                const double u = ((double)Khi * 4294967296.0 + (double)Klo) * (1.0 / 9007199254740992.0);
-                const double x = u * (c4 + 0.0);
-                color = (u32)!(x < c0) + (u32)!(x < c1) + (u32)!(x < c2) + (u32)!(x < c3);    // bisect_right(cum, x, 0, 4)
-            }
-        }
-        box -= 1ull << (8u * color);                   // :89
+        // the nth of the `total` tiles left, tiles ordered by colour; random.randrange(total) = _randbelow(total)
+        const u32 nth = rng2_below(r, total, 32u - (u32)__builtin_clz(total), l);
+        const u32 pc = ((u32)Pp >> ((l & 3u) * 8u)) & 0xffu;
+        const u32 color = (u32)__popc(hb((pc <= nth) & (l < 4u)));
+        box -= 1ull << (8u * color);
         Pp -= (0x0101010101ull << (8u * color)) & 0xffffffffffull;
-        add_tile<D>(cs0, cs1, t >> 2, color, l);       // :88
+        add_tile<D>(cs0, cs1, t >> 2, color, l);
     }
     return ST_OK;
 }
@@ -524,13 +504,13 @@ AZ_FN u32 new_round_x(GX<P, D> &g, const RulesX &rules, Rng2 &r, u64 margin, con
     }
     g.turn += 1u;
     g.nfp = 0;
-    u32 st;
-    if (!Dim<D>::WIDE && rules.pool == (u32)XPOOL_LID) {
-        st = deal_tiles2<true>(g.cs0, g.box, g.lid, g.lidp, r, margin, rules.short_deal != 0u, K.k);     // the parallel draw (five displays)
+    g.cs0 = l == 30u ? 1u : 0u;                                       // :71,:73
+    g.cs1 = 0u;
+    u32 st = ST_OK;
+    if (rules.pool == (u32)XPOOL_LID) {
+        st = deal_lid2<4u * D, Dim<D>::XCELLS>(g.cs0, g.cs1, g.box, g.lid, g.lidp, r, margin, rules.short_deal != 0u, K.k);
     } else {
-        g.cs0 = l == 30u ? 1u : 0u;                                   // :71,:73
-        g.cs1 = 0u;
-        st = deal_serial_x<D>(g.cs0, g.cs1, g.box, g.lid, g.lidp, rules.pool, rules.short_deal != 0u, r, margin, l);
+        st = deal_serial_x<D>(g.cs0, g.cs1, g.box, g.lid, g.lidp, rules.pool, rules.short_deal != 0u, r, l);
     }
     sources_x(g);
     return st;
@@ -748,7 +728,7 @@ AZ_FN void outputs_x(const GX<P, D> &g, const Out2 &o, i32 a, u32 dn, u32 l)
 
 // returns 0 = move played, 1 = game ended with this move, 2 = stuck, 0x100 | status on a rule error
 template <u32 P, u32 D, int OUT, bool PAD, bool BITS>
-AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2 &r, const TabX &T, u64 margin, const Counters2 &cnt,
+AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2 &r, const TabX &T, u64 margin, Counters2 &cnt,
                           const Out2 &o, bool &dead, SegProf *prof_ = nullptr)
 {
     (void)prof_;
@@ -813,7 +793,7 @@ AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2
     if (AZ_UNLIKELY(any_nomove)) {
         if (nomove) {
             // stuck (hazard H3), or handed an already finished game: report, restart the slot
-            if (l == 0u) *cnt.stuck += 1u;
+            cnt.stuck_add += 1u;
             outputs_x<P, D, OUT>(g, o, -1, 2u, l);
             const u32 st0 = restart_x(g, rules, r, margin, K);
             ret = st0 ? (0x100u | st0) : 2u;
@@ -851,9 +831,11 @@ AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2
         ret = st != ST_OK ? (0x100u | st) : dn;
         if (AZ_UNLIKELY(any_done)) {
             if (dn != 0u) {
-                if (l == 0u) {
-                    for (u32 q = 0; q < 10u; q++) cnt.stat_sum[q] += game_stat_x(g, q);
-                    *cnt.episodes += 1ull;
+                {
+                    double fsum = 0.0;
+#pragma unroll
+                    for (u32 p = 0; p < P; p++) fsum += (double)g.fps[p];          // first_player_stats.sum(): left to right
+                    counters2_episode(cnt, stat_lane(l, g.score[0], g.score[1], g.turn, (double)g.fps[0] / fsum * 100, g.fpen[0], g.mc[0], g.cl[0]));
                 }
                 const u32 st2 = restart_x(g, rules, r, margin, K);      // a fresh Azul(players = P, rules) + new_round()
                 if (st2) ret = 0x100u | st2;
@@ -1064,7 +1046,8 @@ AZ_FN void selfplay_body_x(const XBatchDev &b, const XTraj &t, u32 wave_id, u32 
     u32 *gmt = b.mt + (size_t)gi * 624u;
     rng2_open(r, gmt, mt_lds[half], b.mtpos[gi], l);
     rng2_attach_tempered(r, mtt_lds[half], l);
-    const Counters2 cnt = {b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10};
+    Counters2 cnt;
+    counters2_open(cnt, b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10, l);
     Out2 o = {t.mask, t.maskbits, t.action, t.reward, t.done, t.packed, t.rec, t.mask_stride, gi,
               l == 0u ? (u32 *)t.action : (l == 1u ? (u32 *)t.reward : t.packed)};
     bool dead = false;               // a game stopped by a rule error (bag and lid empty without the short-deal rule) stays as it is
@@ -1086,6 +1069,7 @@ AZ_FN void selfplay_body_x(const XBatchDev &b, const XTraj &t, u32 wave_id, u32 
 #endif
     gx_store(g, rec, l);
     rng2_close(r, gmt, b.mtpos + gi, l);
+    counters2_close(cnt, l);
 }
 
 } // namespace azx

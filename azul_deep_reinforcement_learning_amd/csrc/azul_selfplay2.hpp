@@ -592,11 +592,130 @@ AZ_FN u32 new_round2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
     return st;
 }
 
-// The factory draw itself (azul.py:71-89) on the cell register of five displays + centre + token; shared with the P-player rules
-// (azul_rules_x.hpp).  short_deal (beyond the reference, row N4): bag and lid both empty -> the round starts with what could be dealt
-// instead of ST_BOX_EMPTY (where the reference raises, azul.py:86-87); the two-player kernels pass false.
+// n <= 32 consecutive "Lid" draws of a round at once, when the box holds at least n tiles (no refill can happen inside): az2::deal_tiles2's parallel fixed point for any number of draws -- lane t owns draw t,
+//     colour_t = #{c < 4 : (P_c - n_c(t)) * 2^53 <= K_t * (T0 - t)},   n_c(t) = #{s < t : colour_s <= c},
+// iterated from a first guess until nothing changes (the unique fixed point is the sequential result) -- with azul_core.hpp's exactness
+// argument (a draw whose K * T lies within `margin` of a multiple of 2^32 sends the n draws through the literal fp64 code, one after
+// the other, on the words already fetched) and the same handling of a regeneration inside the 2 n words.
+// XC: cells of the second cell register (displays 5 ..: azul_rules_x.hpp; 0 = the reference's five displays, cs1 unused).
+template <u32 XC>
+AZ_FN void deal_batch2(u32 &cs0, u32 &cs1, u64 &box, Rng2 &r, u64 margin, u32 t0 /* first draw of the batch within the round */, u32 n, const K2 &k)
+{
+    const u32 l = k.l;
+    const u32 nmask = n >= 32u ? 0xffffffffu : (1u << n) - 1u;
+    const u32 blo = (u32)box;
+    const u32 p0 = blo & 0xffu, p1 = p0 + ((blo >> 8) & 0xffu), p2 = p1 + ((blo >> 16) & 0xffu), p3 = p2 + (blo >> 24);
+    const u32 T0 = p3 + ((u32)(box >> 32) & 0xffu);
+    const bool room = r.pos + 2u * n <= 624u;
+    const u32 lc = l < n ? l : n - 1u;
+    const u32 i0 = r.pos + 2u * lc, i1 = i0 + 1u;
+    const u32 j0 = i0 < 624u ? i0 : i0 - 624u, j1 = i1 < 624u ? i1 : i1 - 624u;
+    const u32 *words = r.tlds ? r.tlds : r.lds;
+    u32 wa = words[j0], wb = words[j1];
+    if (!room) {
+        const u32 p = r.pos;
+        lds_sync();
+        rng2_twist(r, l);
+        const u32 na = words[j0], nb = words[j1];
+        wa = i0 < 624u ? wa : na; wb = i1 < 624u ? wb : nb;
+        r.pos = p - 624u;                                // (wraps; the 2 n words bring it to p + 2 n - 624)
+    }
+    if (!r.tlds) { wa = temper2(wa); wb = temper2(wb); }
+    wa >>= 5; wb >>= 6;
+    const u32 klo = (wa << 26) | wb, khi = wa >> 6;      // K_t, the 53-bit integer of random() (random() == K / 2^53)
+    const u32 tt = T0 - l;                               // draw t sees T0 - t tiles (valid for l < n <= T0)
+    const u32 lo = klo * tt, kthi = khi * tt + __umulhi(klo, tt);
+    const u32 mg = (u32)margin;
+    const u32 risky = hb(lo + mg < 2u * mg) & nmask;
+    u32 col = 0;
+    if (risky == 0u) {
+        const u32 below = (1u << l) - 1u;
+        const u32 kt0hi = khi * T0 + __umulhi(klo, T0);  // first guess: the colour drawn from the undepleted box
+        col = (u32)((p0 << 21) <= kt0hi) + (u32)((p1 << 21) <= kt0hi) + (u32)((p2 << 21) <= kt0hi) + (u32)((p3 << 21) <= kt0hi);
+#pragma unroll 1
+        for (u32 it = 0; it < 34u; it++) {
+            const u32 b0 = hb(col == 0u) & nmask, b1 = hb(col <= 1u) & nmask, b2 = hb(col <= 2u) & nmask, b3 = hb(col <= 3u) & nmask;
+            const u32 n0 = (u32)__popc(b0 & below), n1 = (u32)__popc(b1 & below), n2 = (u32)__popc(b2 & below), n3 = (u32)__popc(b3 & below);
+            const u32 nc = (u32)(((p0 - n0) << 21) <= kthi) + (u32)(((p1 - n1) << 21) <= kthi) + (u32)(((p2 - n2) << 21) <= kthi) +
+                           (u32)(((p3 - n3) << 21) <= kthi);
+            const u32 changed = hb(nc != col) & nmask;
+            col = nc;
+            if (changed == 0u) break;
+        }
+    } else {
+        // the same draws one after the other on the fetched words, each decided by the integer comparison or, inside the margin, by the literal fp64 code
+        u64 Pp = ((box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;
+        u64 bx = box;
+#pragma unroll 1
+        for (u32 t = 0; t < n; t++) {
+            const u32 total = T0 - t;
+            const u32 Klo = hread(klo, t), Khi = hread(khi, t);
+            const u64 KT = (u64)Klo * total + (((u64)Khi * total) << 32);
+            u32 color;
+            if (((KT - margin) >> 32) == ((KT + margin) >> 32)) {
+                const u32 pc = ((u32)Pp >> ((l & 3u) * 8u)) & 0xffu;
+                color = (u32)__popc(hb(((pc << 21) <= (u32)(KT >> 32)) & (l < 4u)));
+            } else {
+                const double tot = (double)total;
+                const double q0 = (double)((u32)bx & 0xffu) / tot, q1 = (double)((u32)(bx >> 8) & 0xffu) / tot,
+                             q2 = (double)((u32)(bx >> 16) & 0xffu) / tot, q3 = (double)((u32)(bx >> 24) & 0xffu) / tot,
+                             q4 = (double)((u32)(bx >> 32) & 0xffu) / tot;
+                const double c0 = q0, c1 = c0 + q1, c2 = c1 + q2, c3 = c2 + q3, c4 = c3 + q4;
+                const double u = ((double)Khi * 4294967296.0 + (double)Klo) * (1.0 / 9007199254740992.0);
+                const double x = u * (c4 + 0.0);
+                color = (u32)!(x < c0) + (u32)!(x < c1) + (u32)!(x < c2) + (u32)!(x < c3);
+            }
+            bx -= 1ull << (8u * color);
+            Pp -= (0x0101010101ull << (8u * color)) & 0xffffffffffull;
+            col = l == t ? color : col;
+        }
+    }
+    // commit: the draws of each colour as boards, the box, the cells of displays d0 .. d0 + n / 4 - 1
+    u32 e0 = hb(col == 0u) & nmask, e1 = hb(col == 1u) & nmask, e2 = hb(col == 2u) & nmask, e3 = hb(col == 3u) & nmask, e4 = hb(col == 4u) & nmask;
+    asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4));
+    const u32 ec = k.pcol == 0u ? e0 : k.pcol == 1u ? e1 : k.pcol == 2u ? e2 : k.pcol == 3u ? e3 : e4;
+    // display d receives the round's draws 4 d .. 4 d + 3, i.e. bits 4 d - t0 .. of this batch (none when they lie outside it)
+    {
+        const u32 mine = (u32)(((u64)0xfu << (4u * k.prow)) >> t0) & nmask;                 // cs0: lane 5 d + c, display d = prow
+        cs0 += l < 25u ? (u32)__popc(ec & mine) : 0u;
+    }
+    if (XC > 0u) {
+        const u32 mine = (u32)(((u64)0xfu << (4u * (5u + k.prow))) >> t0) & nmask;          // cs1: lane 5 (d - 5) + c
+        cs1 += l < XC ? (u32)__popc(ec & mine) : 0u;
+    }
+    const u32 take_lo = (u32)__popc(e0) | ((u32)__popc(e1) << 8) | ((u32)__popc(e2) << 16) | ((u32)__popc(e3) << 24);
+    box -= (u64)take_lo | ((u64)(u32)__popc(e4) << 32);  // :89 (no borrows: a colour is only drawn while the box holds it)
+    r.pos += 2u * n;
+}
+
+// The "Lid" pool's draws of a round (azul.py:79-89; NDRAWS = 4 per display) in batches of up to 32 -- as many as the box holds; an empty
+// box is refilled from the lid (:81-83) and the dealing continues; box and lid both empty: ST_BOX_EMPTY (where the reference raises,
+// :85-87) or -- short_deal, beyond the reference (row N4) -- the round starts with what could be dealt.  (Round 3 dealt a round whose
+// box held fewer than 20 tiles one draw at a time: one round in four or five.)
+template <u32 NDRAWS, u32 XC>
+AZ_FN u32 deal_lid2(u32 &cs0, u32 &cs1, u64 &box, u64 &lid, u32 &lidp, Rng2 &r, u64 margin, bool short_deal, const K2 &k)
+{
+    u32 done = 0;
+#pragma unroll 1
+    while (done < NDRAWS) {
+        u32 T = byte_sum5(box);
+        if (T == 0u) {
+            box = lid + lid_fold2(lidp, k.l); lid = 0; lidp = 0;
+            T = byte_sum5(box);
+            if (T == 0u) return short_deal ? (u32)ST_OK : (u32)ST_BOX_EMPTY;
+        }
+        u32 n = NDRAWS - done;
+        n = n < 32u ? n : 32u;
+        n = n < T ? n : T;
+        deal_batch2<XC>(cs0, cs1, box, r, margin, done, n, k);
+        done += n;
+    }
+    return ST_OK;
+}
+
+// The factory draw itself (azul.py:71-89) on the cell register of five displays + centre + token.
 template <bool LID>
-AZ_FN u32 deal_tiles2(u32 &cs, u64 &box, u64 &lid, u32 &lidp, Rng2 &r, u64 margin, bool short_deal, const K2 &k)
+AZ_FN u32 deal_tiles2(u32 &cs, u64 &box, u64 &lid, u32 &lidp, Rng2 &r, u64 margin, const K2 &k)
 {
     const u32 l = k.l;
     cs = l == 30u ? 1u : 0u;                             // :71,:73
@@ -608,126 +727,8 @@ AZ_FN u32 deal_tiles2(u32 &cs, u64 &box, u64 &lid, u32 &lidp, Rng2 &r, u64 margi
         }
         return ST_OK;
     }
-    // "Lid" pool: every draw is one random.choices = one random() = two MT words; see azul_core.hpp for the exactness argument
-    // (integer decision P_c * 2^53 <= K * T unless K*T lies within `margin` of a multiple of 2^32, then the literal fp64 code).
-    if ((box & 0xffffffffffull) == 0ull) {
-        // the box is empty when the round starts: the first draw refills it from the lid (:81-83) -- done here, so that the
-        // whole round can take the parallel path below (no random number is involved: random.choices raises before random())
-        box = lid + lid_fold2(lidp, l); lid = 0; lidp = 0;
-        if ((box & 0xffffffffffull) == 0ull) return short_deal ? (u32)ST_OK : (u32)ST_BOX_EMPTY;
-    }
-    // prefix sums of the box: p_c = box_0 + .. + box_c (c < 4), T0 = all five
-    const u32 blo = (u32)box;
-    const u32 p0 = blo & 0xffu, p1 = p0 + ((blo >> 8) & 0xffu), p2 = p1 + ((blo >> 16) & 0xffu), p3 = p2 + (blo >> 24);
-    const u32 T0 = p3 + ((u32)(box >> 32) & 0xffu);
-    // The round's 40 words in one go: lane t takes the two words of draw t.  When they straddle a regeneration (6 % of the rounds)
-    // and the round cannot run dry (T0 >= 20: exactly 40 words will be consumed), the words before it are read, the state is
-    // regenerated, and the words after it are read -- instead of twenty serial draws through the window.
-    const bool room = r.pos + 40u <= 624u;
-    const bool batched = room | (T0 >= 20u);
-    u32 klo = 0, khi = 0;
-    if (batched) {
-        // (every lane reads, lanes 20.. repeat draw 19's words: no lane-dependent control flow; a word beyond this state's 624 is
-        // read at its place in the NEXT state -- unused before the regeneration, read again after it)
-        const u32 lc = l < 20u ? l : 19u;
-        const u32 i0 = r.pos + 2u * lc, i1 = i0 + 1u;
-        const u32 j0 = i0 < 624u ? i0 : i0 - 624u, j1 = i1 < 624u ? i1 : i1 - 624u;
-        const u32 *words = r.tlds ? r.tlds : r.lds;          // (the tempered copy when the kernel keeps one)
-        u32 wa = words[j0], wb = words[j1];
-        if (!room) {
-            const u32 p = r.pos;
-            lds_sync();
-            rng2_twist(r, l);
-            const u32 na = words[j0], nb = words[j1];
-            wa = i0 < 624u ? wa : na; wb = i1 < 624u ? wb : nb;
-            r.pos = p - 624u;                                // (wraps; the round's forty words bring it to p + 40 - 624)
-        }
-        if (!r.tlds) { wa = temper2(wa); wb = temper2(wb); }
-        wa >>= 5; wb >>= 6;
-        klo = (wa << 26) | wb;
-        khi = wa >> 6;
-    }
-    const bool pre = batched && T0 >= 20u;               // no refill can happen: draw t sees total T0 - t
-    // (computed whether or not they will be used: a dozen instructions against a divergent branch around them)
-    const u32 tt = T0 - l;
-    const u32 lo = klo * tt, kthi = khi * tt + __umulhi(klo, tt);
-    const u32 mg = (u32)margin;
-    const u32 risky = hb(lo + mg < 2u * mg) & 0xfffffu;  // lo within mg of a multiple of 2^32, one compare (mg < 2^31)
-    const u32 kt0hi = khi * T0 + __umulhi(klo, T0);      // K_t * T0: for the first guess only
-    if (pre && risky == 0u) {
-        // The common round: twenty integer draws WITHOUT a 20-step serial loop.  Lane t owns draw t:
-        //     colour_t = #{c < 4 : (P_c - n_c(t)) * 2^53 <= K_t * T_t},   n_c(t) = #{s < t : colour_s <= c}
-        // (P_c = prefix sums of the box when the round starts).  Iterate  colours <- f(colours)  from n = 0: after i passes
-        // the first i draws are final (draw t only depends on draws s < t), so a pass that changes nothing has reached the
-        // unique fixed point, which is the sequential result.  Boundaries move by one tile in ~100 per draw: two or three
-        // passes in practice, at most 21.
-        const u32 below = (1u << l) - 1u;
-        // first guess: the colour drawn from the UNDEPLETED box, P_c * 2^53 <= K_t * T0 -- the expected boundaries of draw t,
-        // (P_c - n_c(t)) / (T0 - t) ~ P_c / T0 (any start reaches the same fixed point; this one needs fewer passes)
-        u32 col = (u32)((p0 << 21) <= kt0hi) + (u32)((p1 << 21) <= kt0hi) + (u32)((p2 << 21) <= kt0hi) + (u32)((p3 << 21) <= kt0hi);
-        u32 b0 = 0, b1 = 0, b2 = 0, b3 = 0;               // draws with colour <= c, as of the pass that confirmed the colours
-#pragma unroll 1
-        for (u32 it = 0; it < 21u; it++) {
-            b0 = hb(col == 0u) & 0xfffffu; b1 = hb(col <= 1u) & 0xfffffu; b2 = hb(col <= 2u) & 0xfffffu; b3 = hb(col <= 3u) & 0xfffffu;
-            u32 n0 = (u32)__popc(b0 & below), n1 = (u32)__popc(b1 & below), n2 = (u32)__popc(b2 & below), n3 = (u32)__popc(b3 & below);
-            u32 nc = (u32)(((p0 - n0) << 21) <= kthi) + (u32)(((p1 - n1) << 21) <= kthi) + (u32)(((p2 - n2) << 21) <= kthi) +
-                     (u32)(((p3 - n3) << 21) <= kthi);
-            const u32 changed = hb(nc != col) & 0xfffffu;
-            col = nc;
-            if (changed == 0u) break;                // the boards b0..b3 were taken from the colours that have just been confirmed
-        }
-        u32 e0 = b0, e1 = b1 & ~b0, e2 = b2 & ~b1, e3 = b3 & ~b2, e4 = 0xfffffu & ~b3;
-        // (the five boards pass through an empty asm: otherwise each is computed inside a branch of the colour select below, which
-        // then becomes three nested divergent branches instead of four v_cndmask)
-        asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4));
-        // display d receives draws 4d .. 4d+3: lane 5d + c counts those of colour c (:88)
-        const u32 ec = k.pcol == 0u ? e0 : k.pcol == 1u ? e1 : k.pcol == 2u ? e2 : k.pcol == 3u ? e3 : e4;
-        cs = l < 25u ? (u32)__popc((ec >> (4u * k.prow)) & 0xfu) : cs;
-        const u32 take_lo = (u32)__popc(e0) | ((u32)__popc(e1) << 8) | ((u32)__popc(e2) << 16) | ((u32)__popc(e3) << 24);
-        box -= (u64)take_lo | ((u64)(u32)__popc(e4) << 32);      // :89 (no borrows: a colour is only drawn while the box holds it)
-        r.pos += 40u;
-        return ST_OK;
-    }
-    u64 P = ((box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;     // byte c = box_0 + .. + box_c
-#pragma unroll 1
-    for (u32 t = 0; t < 20u; t++) {
-        u32 total = (u32)(P >> 32) & 0xffu;
-        if (total == 0u) {                                                           // :81-83, :85
-            box = lid + lid_fold2(lidp, l); lid = 0; lidp = 0;
-            P = ((box & 0xffffffffffull) * 0x0101010101ull) & 0xffffffffffull;
-            total = (u32)(P >> 32) & 0xffu;
-            if (total == 0u) return short_deal ? (u32)ST_OK : (u32)ST_BOX_EMPTY;
-        }
-        u32 Klo, Khi;
-        if (batched) { Klo = hread(klo, t); Khi = hread(khi, t); r.pos += 2u; }
-        else {
-            u32 wa_ = 0, wb_ = 0;
-#pragma unroll 1
-            for (u32 w = 0; w < 2u; w++) { wa_ = wb_; wb_ = rng2_u32(r, l); }
-            const u32 a27 = wa_ >> 5, b26 = wb_ >> 6;
-            Klo = (a27 << 26) | b26; Khi = a27 >> 6;
-        }
-        u64 KT = (u64)Klo * total + (((u64)Khi * total) << 32);
-        u32 color;
-        if (((KT - margin) >> 32) == ((KT + margin) >> 32)) {
-            u32 pc = ((u32)P >> ((l & 3u) * 8u)) & 0xffu;
-            color = (u32)__popc(hb(((pc << 21) <= (u32)(KT >> 32)) & (l < 4u)));
-        } else {
-            // weights = box_c / total (fp64, correctly rounded division), cumulative left to right, x = random() * cum[-1]
-            double tot = (double)total;
-            double q0 = (double)((u32)box & 0xffu) / tot, q1 = (double)((u32)(box >> 8) & 0xffu) / tot,
-                   q2 = (double)((u32)(box >> 16) & 0xffu) / tot, q3 = (double)((u32)(box >> 24) & 0xffu) / tot,
-                   q4 = (double)((u32)(box >> 32) & 0xffu) / tot;
-            double c0 = q0, c1 = c0 + q1, c2 = c1 + q2, c3 = c2 + q3, c4 = c3 + q4;
-            double u = ((double)Khi * 4294967296.0 + (double)Klo) * (1.0 / 9007199254740992.0);
-            double x = u * (c4 + 0.0);
-            color = (u32)!(x < c0) + (u32)!(x < c1) + (u32)!(x < c2) + (u32)!(x < c3);    // bisect_right(cum, x, 0, 4)
-        }
-        box -= 1ull << (8u * color);                   // :89
-        P -= (0x0101010101ull << (8u * color)) & 0xffffffffffull;
-        cs += (l == (t >> 2) * 5u + color) ? 1u : 0u;  // :88
-    }
-    return ST_OK;
+    u32 none = 0;
+    return deal_lid2<20u, 0u>(cs, none, box, lid, lidp, r, margin, false, k);
 }
 
 template <bool LID>
@@ -737,7 +738,7 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
     g.fps += (g.nfp == 1u) ? 1u : 0x10000u;              // :67 (numpy [-1] == player 2 when nfp == 0)
     g.turn += 1u;
     g.nfp = 0;
-    return deal_tiles2<LID>(g.cs, g.box, g.lid, g.lidp, r, margin, false, k);
+    return deal_tiles2<LID>(g.cs, g.box, g.lid, g.lidp, r, margin, k);
 }
 
 // Azul.__init__ + GameRunner's reset bookkeeping (azul.py:18-61, game_runner.py:76-82), then the first round
@@ -852,12 +853,56 @@ AZ_FN void store_mask_row2(const Out2 &o, u32 m0, u32 m1, u32 m2, u32 m3, u32 m4
     }
 }
 
-struct Counters2 { u64 *episodes; u32 *stuck; double *stat_sum; };
+// Per-game counters of a launch (azul_batch_counters): finished episodes, stuck resets, and the sums of get_statistics() over finished
+// games.  They live in REGISTERS while a kernel runs -- lane q < 10 of the half carries stat_sum[q], loaded when the kernel opens the
+// game and written back when it closes it; the additions happen in the order the games end, so the sums are bit for bit what ten
+// read-modify-writes per finished game gave (round 3), without their memory round trips on the episode-end path.
+struct Counters2 {
+    u64 *episodes; u32 *stuck; double *stat_sum;     // the game's slots in the batch's arrays
+    double acc;                                      // lane q < 10: stat_sum[q] so far
+    u32 ep_add, stuck_add;                           // half-uniform: this launch's increments
+};
+
+AZ_FN void counters2_open(Counters2 &c, u64 *episodes, u32 *stuck, double *stat_sum, u32 l)
+{
+    c.episodes = episodes; c.stuck = stuck; c.stat_sum = stat_sum;
+    c.acc = l < 10u ? stat_sum[l] : 0.0;
+    c.ep_add = 0; c.stuck_add = 0;
+}
+
+AZ_FN void counters2_close(const Counters2 &c, u32 l)
+{
+    if (l < 10u) c.stat_sum[l] = c.acc;
+    if (l == 0u) { *c.episodes += (u64)c.ep_add; *c.stuck += c.stuck_add; }
+}
+
+// get_statistics() of a finished game, value q in lane q (azul.py:314-315, key order of game_runner.py:12): the integer statistics are
+// picked with lane-constant selects and converted once; the percentage is the one true double
+AZ_FN double stat_lane(u32 l, i32 score0, i32 score1, u32 turn, double pct_first, i32 fpen0, u32 mc0, u32 cl0)
+{
+    i32 v = score0;
+    v = l == 1u ? score1 : v;
+    v = l == 2u ? (i32)turn : v;
+    v = l == 4u ? -(i32)(int16_t)((u32)fpen0 & 0xffffu) : v;
+    v = l == 5u ? (i32)(mc0 & 0xffu) : v;
+    v = l == 6u ? (i32)(cl0 & 0xffu) : v;
+    v = l == 7u ? (i32)((cl0 >> 16) & 0xffu) : v;
+    v = l == 8u ? (i32)((cl0 >> 8) & 0xffu) : v;
+    v = l == 9u ? (score0 > score1 ? 1 : 0) : v;
+    const double d = (double)v;
+    return l == 3u ? pct_first : (l < 10u ? d : 0.0);
+}
+
+AZ_FN void counters2_episode(Counters2 &c, double stat_of_my_lane)
+{
+    c.acc = c.acc + stat_of_my_lane;
+    c.ep_add += 1u;
+}
 
 // Everything of a move that follows do_move2 (g.B already holds the sources after the move): what-if score of the mover, next
 // player or end of round (scoring, end of game, next round), shaped reward, outputs, episode statistics and reset.
 template <bool LID, int OUT>
-AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin, const Counters2 &cnt, const Out2 &o, u32 me, bool filled,
+AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin, Counters2 &cnt, const Out2 &o, u32 me, bool filled,
                       i32 a, SegProf *prof_, bool &dead /* per game, only ever set: a rule error stopped it (set in the rare blocks: nothing on the common path) */)
 {
     (void)prof_;
@@ -905,9 +950,9 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
     if (AZ_UNLIKELY(any_done)) {
         if ((dn != 0u) & (st == ST_OK)) {
 #if !defined(AZ2_X_NO_STATS)
-            if (l == 0u) {
-                for (u32 q = 0; q < 10u; q++) cnt.stat_sum[q] += game_stat2(g, q);
-                *cnt.episodes += 1ull;
+            {
+                const double f0 = (double)(g.fps & 0xffffu), f1 = (double)(g.fps >> 16);
+                counters2_episode(cnt, stat_lane(l, g.score0, g.score1, g.turn, f0 / (f0 + f1) * 100, g.fp0, g.mc0, g.cl0));
             }
 #endif
             u32 st2 = episode_reset2<LID>(g, first_player, r, margin, k);     // GameRunner.reset(): Azul(rules) ... new_round()
@@ -926,7 +971,7 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
 // every rare event (window refill across a regeneration, stuck slot, sampler boundary case, end of round, end of game) is tested
 // for the whole wave with one scalar branch (wave_any, hinted unlikely -> placed out of line) and handled per half inside.
 template <bool LID, int OUT, bool PAD, bool BITS>
-AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Tab2 &T, u64 margin, const Counters2 &cnt, const Out2 &o,
+AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Tab2 &T, u64 margin, Counters2 &cnt, const Out2 &o,
                         SegProf *prof_, bool &dead /* per game, only ever set: a rule error stopped it in this move */)
 {
     (void)prof_;
@@ -1034,7 +1079,7 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     if (AZ_UNLIKELY(any_nomove)) {
         if (nomove) {
             // stuck (hazard H3), or handed an already finished game: report, restart the slot
-            if (l == 0u) *cnt.stuck += 1u;
+            cnt.stuck_add += 1u;
             outputs2<OUT>(g, o, -1, 0, 2u, l);
             u32 st0 = episode_reset2<LID>(g, first_player, r, margin, k);
             ret = st0 ? (0x100u | st0) : 2u;
@@ -1115,7 +1160,7 @@ AZ_FN void prepare2(const G2 &g, const K2 &k, const Rng2 &r, const Tab2 &T, Prep
 }
 
 template <bool LID, int OUT, bool PAD, bool BITS>
-AZ_FN u32 selfplay_rotated2(G2 &g, Prep2 &P, u32 first_player, const K2 &k, Rng2 &r, const Tab2 &T, u64 margin, const Counters2 &cnt,
+AZ_FN u32 selfplay_rotated2(G2 &g, Prep2 &P, u32 first_player, const K2 &k, Rng2 &r, const Tab2 &T, u64 margin, Counters2 &cnt,
                             const Out2 &o, SegProf *prof_ = nullptr)
 {
     (void)prof_;

@@ -59,7 +59,8 @@ static void env_wave(EnvJob *j)
     az2::Rng2 r;
     u32 *gmt = j->mt + (size_t)gic * 624u;
     az2::rng2_open(r, gmt, j->mt_lds[half], j->mtpos[gic], l);
-    az2::Counters2 cnt = {j->episodes + gic, j->stuck + gic, j->stat_sum + (size_t)gic * 10};
+    az2::Counters2 cnt;
+    az2::counters2_open(cnt, j->episodes + gic, j->stuck + gic, j->stat_sum + (size_t)gic * 10, l);
     u32 st_last = ST_OK;
     float *orow = j->obs_lds[half];
     az2::Mask2 m;
@@ -95,6 +96,7 @@ static void env_wave(EnvJob *j)
     if (live) {
         az2::g2_store(g, rec, l);
         az2::rng2_close(r, gmt, j->mtpos + gi, l);
+        az2::counters2_close(cnt, l);
         if (l == 0u) j->status[gi] = (uint8_t)st_last;
     }
 }

@@ -55,7 +55,8 @@ static void wave_body(WaveJob *j)
     u32 *gmt = j->mt + (size_t)gi * 624u;
     az2::rng2_open(r, gmt, j->mt_lds[half], j->mtpos[gi], l);
     az2::rng2_attach_tempered(r, j->mtt_lds[half], l);
-    az2::Counters2 cnt = {j->episodes + gi, j->stuck + gi, j->stat_sum + (size_t)gi * 10};
+    az2::Counters2 cnt;
+    az2::counters2_open(cnt, j->episodes + gi, j->stuck + gi, j->stat_sum + (size_t)gi * 10, l);
     az2::Out2 o = {j->mask, j->maskbits, j->action, j->reward, j->done, j->packed, j->rec, j->pitch, gi,
                    l == 0u ? (u32 *)j->action : (l == 1u ? (u32 *)j->reward : j->packed)};
     if (!j->rotated) {
@@ -75,6 +76,7 @@ static void wave_body(WaveJob *j)
     }
     az2::g2_store(g, rec, l);
     az2::rng2_close(r, gmt, j->mtpos + gi, l);
+    az2::counters2_close(cnt, l);
 }
 
 template <bool LID>

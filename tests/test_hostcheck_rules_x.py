@@ -200,3 +200,20 @@ def test_line_bonuses_on_dense_walls_per_round_and_at_the_end(players, ext):
         ra = np.stack([s.advance(60)["rec_after"]["score"] for s in a])
         rb = np.stack([s.advance(60)["rec_after"]["score"] for s in b])
         assert not np.array_equal(ra, rb)
+
+
+def near_the_end_of_the_state(streams):
+    """Stream positions spread over the last hundred words of the MT19937 state: the round that is dealt after the first ~11 moves then
+    fetches its 40 / 56 / 72 words across a regeneration for several of the games."""
+    for i, s in enumerate(streams):
+        s.r.idx = 624 - 100 + 6 * i
+
+
+@pytest.mark.parametrize("players,ext", [(3, 0), (3, oz.EXT_DISPLAYS_2P1), (4, oz.EXT_DISPLAYS_2P1 | oz.EXT_SHORT_DEAL)])
+def test_factory_draw_across_a_regeneration_and_through_the_fp64_path(players, ext):
+    """The parallel draw (five displays: az2::deal_tiles2; seven / nine: deal_parallel_x, 28 or 32 + 4 draws) with its words straddling an
+    MT19937 regeneration, and -- with a draw margin that covers every draw -- the literal fp64 decision on the fetched words."""
+    L = load()
+    check_streams(L, players, oz.FIRST_RANDOM, oz.POOL_LID, ext, n=16, T=40, variant=3, seed0=300, prepare=near_the_end_of_the_state)
+    check_streams(L, players, oz.FIRST_RANDOM, oz.POOL_LID, ext, n=4, T=60, variant=3, seed0=310, margin=0x7fffffff)
+    check_streams(L, players, oz.FIRST_RANDOM, oz.POOL_LID, ext, n=8, T=30, variant=3, seed0=320, margin=0x7fffffff, prepare=near_the_end_of_the_state)

@@ -26,6 +26,14 @@
 #include <string>
 #include <vector>
 
+// The timing-experiment switches that make a kernel produce WRONG RESULTS (they leave out stores, LDS round trips or weight loads to
+// price them: DESIGN.md 3, 9) are only accepted together with -DAZ_TIMING_EXPERIMENTS, which azul_version() reports -- a library
+// built with one of them cannot be mistaken for the product (tests/test_abi_and_host_logic.py checks the shipped library's version).
+#if !defined(AZ_TIMING_EXPERIMENTS) && (defined(AZ2_EXPERIMENT_NO_LDS) || defined(AZ2_X_NO_SCALAR_STORES) || defined(AZ2_X_NO_MASK_STORES) || \
+                                        defined(AZ2_X_NO_STATS) || defined(PR2_EXPERIMENT_NO_WEIGHT_LOADS) || defined(PR2_X_NO_MASK_STORES))
+#error "this switch produces wrong results: timing experiments only, add -DAZ_TIMING_EXPERIMENTS (reported by azul_version())"
+#endif
+
 #include "../../include/azul_hip.h"
 #include "azul_core.hpp"
 #include "azul_tables.hpp"
@@ -72,6 +80,8 @@ struct OpArgs {
     double *stats;           // [N][10] out
     uint8_t *player;         // [N]   out: current_player after the op
     uint8_t *rng_dirty;      // [N]   out: the op regenerated the game's 624 MT19937 words (Rng::dirty; 0 for ops that do not draw)
+    uint8_t *rec_out;        // [N][record bytes] out: the game's record after the op
+    u32 *pos_out;            // [N]   out: index of the game's MT19937 stream after the op
     u32 first;               // the launch covers games first .. first + grid - 1; row i of the arrays above belongs to game first + i
 };
 
@@ -276,6 +286,8 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
     }
     if (a.rng_dirty) AZ_LANE0(a.rng_dirty[oi] = (uint8_t)rdirty);
     if (a.status && act) AZ_LANE0(a.status[oi] = (uint8_t)st);
+    if (a.rec_out) game_store(g, a.rec_out + (size_t)oi * AZUL_RECORD_BYTES);
+    if (a.pos_out) AZ_LANE0(a.pos_out[oi] = b.mtpos[gi]);      // (written by rng_close above when the op drew)
     // queries on the post-op state
     if (a.mask) {
         Mask m;
@@ -547,8 +559,7 @@ struct azul_batch {
     int timed_launches;  // launches since azul_timing_begin
     int timed_pairs;     // of which bracketed by their own event pair (the first AZ_TIMED_PAIRS)
     bool timing;
-    uint8_t *call_dev;   // azul_game_call: device scratch of one call (CallScratch), allocated by the first call
-    uint8_t *call_pin;   // ... and its pinned host mirror (+ staging for record / MT words)
+    uint8_t *call_pin;   // azul_game_call: one call's arguments / results (CallScratch) in pinned, device-visible host memory
 };
 enum { AZ_TIMED_PAIRS = 256 };
 
@@ -620,7 +631,6 @@ static void batch_free(azul_batch *b)
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     for (hipEvent_t e : b->lev) (void)hipEventDestroy(e);
-    if (b->call_dev) (void)hipFree(b->call_dev);
     if (b->call_pin) (void)hipHostFree(b->call_pin);
     delete b;
 }
@@ -701,7 +711,7 @@ int azul_batch_create_rules(azul_batch_t **out, int n_games, int players, int fi
     b->timing = false;
     b->timed_launches = 0;
     b->timed_pairs = 0;
-    b->call_dev = b->call_pin = nullptr;
+    b->call_pin = nullptr;
     int rc = batch_alloc(b, n_games, first_player, tile_pool);
     if (rc != AZUL_SUCCESS) { batch_free(b); return rc; }      // nothing leaks when an allocation fails half way
     *out = b;
@@ -891,6 +901,7 @@ static int launch_op_x(azul_batch_t *b, const OpArgs &a, void *stream, int count
                                       "three / four players and extended-rule batches support the Azul rule entries, the sampler, the mask and the observation");
     x.actions = a.actions; x.active = a.active; x.mask_in = a.mask_in; x.actions_out = a.actions_out; x.status = a.status; x.mask = a.mask;
     x.obs = a.obs; x.persp = a.persp; x.flags = a.flags; x.stats = a.stats; x.player = a.player; x.rng_dirty = a.rng_dirty;
+    x.rec_out = a.rec_out; x.pos_out = a.pos_out;
     x.first = a.first; x.count = count < 0 ? b->d.n : (u32)count;
     const dim3 grid((x.count + 1u) / 2u), block(64);
     const azx::XBatchDev xb = xdev(b);
@@ -1267,9 +1278,9 @@ int azul_batch_score_preview(azul_batch_t *b, int32_t *potential_dev, void *stre
 }
 
 // ---- azul_game_call: one method call of the single-game API in one submission + one synchronisation ---------------------------
-struct CallScratch {             // device scratch of one call; the pinned mirror has the same layout
-    i32 action_in;
-    u32 pos;                     // (pinned mirror only: the stream index, in and out)
+struct CallScratch {             // one call's arguments and results in PINNED, device-visible host memory: the rule kernel reads its action /
+    i32 action_in;               // mask straight from it and writes every result straight into it (zero-copy over PCIe: a few hundred bytes),
+    u32 pos;                     // so a call is [record / stream uploads when stale] -> ONE launch -> ONE synchronisation
     i32 reward, action_out, potential;
     uint8_t status, done, flags, player;
     uint8_t rng_dirty, pad_[3];  // the kernel regenerated the 624 words (written by every call: 0 for ops that do not draw)
@@ -1277,8 +1288,8 @@ struct CallScratch {             // device scratch of one call; the pinned mirro
     uint8_t mask[AZUL_MAX_ACTIONS + 4];
     float obs[AZUL_MAX_OBS];
     double stats[AZUL_NUM_STATS];
-    uint8_t record[AZUL_RECORD_BYTES_WIDE];
-    u32 mt[AZUL_MT_WORDS];
+    uint8_t record[AZUL_RECORD_BYTES_WIDE];      // staging of record_in, then the record after the call
+    u32 mt[AZUL_MT_WORDS];                       // staging of mt_in / mt_out
 };
 
 int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
@@ -1296,16 +1307,14 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     const size_t NA = (size_t)azul_batch_num_actions(b), NOBS = (size_t)azul_batch_obs_size(b);
     if (c->record_in) if (int rc = record_in_domain(b, (const uint8_t *)c->record_in)) return rc;
     const hipStream_t st = (hipStream_t)stream;
-    if (!b->call_dev) {
-        HIP_TRY(hipMalloc((void **)&b->call_dev, sizeof(CallScratch)));
-        HIP_TRY(hipMemsetAsync(b->call_dev, 0, sizeof(CallScratch), st));      // no uninitialised byte ever travels back
-        HIP_TRY(hipHostMalloc((void **)&b->call_pin, sizeof(CallScratch), hipHostMallocDefault));
+    if (!b->call_pin) {
+        HIP_TRY(hipHostMalloc((void **)&b->call_pin, sizeof(CallScratch), hipHostMallocDefault));      // pinned + mapped: kernels address it directly
         memset(b->call_pin, 0, sizeof(CallScratch));
     }
-    CallScratch *D = (CallScratch *)b->call_dev, *H = (CallScratch *)b->call_pin;
+    CallScratch *H = (CallScratch *)b->call_pin;
     const size_t RB = (size_t)b->rec_bytes;
     const size_t g = (size_t)c->game;
-    // ---- inputs: staged in the pinned mirror, copied asynchronously
+    // ---- inputs that live in device arrays: only when the caller says the device copies are stale
     if (c->record_in) {
         memcpy(H->record, c->record_in, RB);
         HIP_TRY(hipMemcpyAsync(b->d.state + g * RB, H->record, RB, hipMemcpyHostToDevice, st));
@@ -1315,40 +1324,31 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
         H->pos = c->pos_in;
         HIP_TRY(hipMemcpyAsync(b->d.mt + g * 624, H->mt, sizeof(H->mt), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(b->d.mtpos + g, &H->pos, sizeof(u32), hipMemcpyHostToDevice, st));
+        if (c->record_in || (c->want & AZUL_WANT_RECORD)) HIP_TRY(hipStreamSynchronize(st));      // H->record / H->pos are written by the kernel below
+    } else if (c->record_in && (c->want & AZUL_WANT_RECORD)) {
+        HIP_TRY(hipStreamSynchronize(st));               // the staged record must have left H->record before the kernel overwrites it
     }
-    const bool takes_action = c->op == AZUL_CALL_MOVE || c->op == AZUL_CALL_STEP || c->op == AZUL_CALL_RUNNER_STEP;
-    if (takes_action || c->op == AZUL_CALL_SAMPLE_MASK) {
-        H->action_in = c->arg;
-        size_t nb = sizeof(i32);
-        if (c->op == AZUL_CALL_SAMPLE_MASK) {                     // action_in .. mask_in is one contiguous piece of the scratch
-            memcpy(H->mask_in, c->mask_in, NA);
-            nb = offsetof(CallScratch, mask_in) + NA;
-        }
-        HIP_TRY(hipMemcpyAsync(D, H, nb, hipMemcpyHostToDevice, st));
-    }
-    // ---- the rule kernel on this one game
+    // ---- the rule kernel on this one game: arguments read from, results written to the pinned block
+    H->action_in = c->arg;
+    if (c->op == AZUL_CALL_SAMPLE_MASK) memcpy(H->mask_in, c->mask_in, NA);
     OpArgs a = op_args(op_of[c->op]);
     a.first = (u32)c->game;
-    a.actions = &D->action_in;
-    a.status = &D->status;
-    if (c->op == AZUL_CALL_RUNNER_STEP) { a.reward = &D->reward; a.done = &D->done; }
-    if (c->op == AZUL_CALL_SAMPLE_MASK) { a.mask_in = D->mask_in; a.actions_out = &D->action_out; }
-    if (c->want & AZUL_WANT_MASK) a.mask = D->mask;
-    if (c->want & AZUL_WANT_OBS) { a.obs = D->obs; a.persp = persp_of(b, c->arg); }
-    if (c->want & AZUL_WANT_FLAGS) a.flags = &D->flags;
-    if (c->want & AZUL_WANT_POTENTIAL) a.potential = &D->potential;
-    if (c->want & AZUL_WANT_STATS) a.stats = D->stats;
-    a.rng_dirty = &D->rng_dirty;
+    a.actions = &H->action_in;
+    a.status = &H->status;
+    if (c->op == AZUL_CALL_RUNNER_STEP) { a.reward = &H->reward; a.done = &H->done; }
+    if (c->op == AZUL_CALL_SAMPLE_MASK) { a.mask_in = H->mask_in; a.actions_out = &H->action_out; }
+    if (c->want & AZUL_WANT_MASK) a.mask = H->mask;
+    if (c->want & AZUL_WANT_OBS) { a.obs = H->obs; a.persp = persp_of(b, c->arg); }
+    if (c->want & AZUL_WANT_FLAGS) a.flags = &H->flags;
+    if (c->want & AZUL_WANT_POTENTIAL) a.potential = &H->potential;
+    if (c->want & AZUL_WANT_STATS) a.stats = H->stats;
+    if (c->want & AZUL_WANT_RECORD) a.rec_out = H->record;
+    a.rng_dirty = &H->rng_dirty;
+    a.pos_out = &H->pos;
+    H->status = AZUL_OK;
     if (int rc = launch_op(b, a, stream, 1)) return rc;
-    // ---- results: the scalar head of the scratch always (24 bytes), the rest on request
-    HIP_TRY(hipMemcpyAsync(&H->reward, &D->reward, offsetof(CallScratch, mask_in) - offsetof(CallScratch, reward), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&H->pos, b->d.mtpos + g, sizeof(u32), hipMemcpyDeviceToHost, st));
-    if (c->want & AZUL_WANT_MASK) HIP_TRY(hipMemcpyAsync(H->mask, D->mask, NA, hipMemcpyDeviceToHost, st));
-    if (c->want & AZUL_WANT_OBS) HIP_TRY(hipMemcpyAsync(H->obs, D->obs, NOBS * sizeof(float), hipMemcpyDeviceToHost, st));
-    if (c->want & AZUL_WANT_STATS) HIP_TRY(hipMemcpyAsync(H->stats, D->stats, sizeof(H->stats), hipMemcpyDeviceToHost, st));
-    if (c->want & AZUL_WANT_RECORD) HIP_TRY(hipMemcpyAsync(H->record, b->d.state + g * RB, RB, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    // the scratch's result head is shared by all ops: only what THIS op / `want` produced is handed out, the rest reads zero
+    // the result head is shared by all ops: only what THIS op / `want` produced is handed out, the rest reads zero
     c->status = H->status;
     c->reward = c->op == AZUL_CALL_RUNNER_STEP ? H->reward : 0;
     c->done = c->op == AZUL_CALL_RUNNER_STEP ? H->done : 0;

@@ -903,6 +903,8 @@ struct XOp {
     double *stats;           // [count][10] out
     uint8_t *player;         // [count] out
     uint8_t *rng_dirty;      // [count] out: the op regenerated the game's MT19937 words
+    uint8_t *rec_out;        // [count][256] out: the game's record after the op
+    u32 *pos_out;            // [count] out: index of the game's MT19937 stream after the op
     u32 first, count;        // the launch covers games first .. first + count - 1; row i of the arrays belongs to game first + i
 };
 
@@ -1005,6 +1007,8 @@ AZ_FN void op_body_x(const XBatchDev &b, const XOp &a, u32 pair /* games 2 pair,
     }
     if (a.rng_dirty && l == 0u) a.rng_dirty[oi] = (uint8_t)rdirty;
     if (a.status && act && l == 0u) a.status[oi] = (uint8_t)st;
+    if (a.rec_out) gx_store(g, a.rec_out + (size_t)oi * AZUL_RECORD_BYTES_WIDE, l);
+    if (a.pos_out && l == 0u) a.pos_out[oi] = b.mtpos[gi];       // (written by rng2_close above when the op drew)
     // queries on the post-op state
     if (a.mask) {
         MaskX<D> m;

@@ -49,7 +49,10 @@ _OPS = {
     "op_next_player": (L.CALL_NEXT_PLAYER, 0), "op_count_score": (L.CALL_COUNT_SCORE, 0), "op_step": (L.CALL_STEP, 0),
     "op_flags": (L.CALL_QUERY, L.WANT_FLAGS), "op_mask": (L.CALL_QUERY, L.WANT_MASK), "op_observe": (L.CALL_QUERY, L.WANT_OBS),
     "op_statistics": (L.CALL_QUERY, L.WANT_STATS), "op_potential": (L.CALL_QUERY, L.WANT_POTENTIAL),
-    "op_runner_init": (L.CALL_RUNNER_INIT, 0), "op_runner_reset": (L.CALL_RUNNER_RESET, 0), "op_runner_step": (L.CALL_RUNNER_STEP, 0),
+    "op_runner_init": (L.CALL_RUNNER_INIT, 0), "op_runner_reset": (L.CALL_RUNNER_RESET, 0),
+    # GameRunner.step also brings back the legal mask of the state it leaves: the caller's next question is get_valid_moves()
+    # (nn_runner.py:22-30, game_runner.py:73-75), which is then answered without a submission while the record is unchanged
+    "op_runner_step": (L.CALL_RUNNER_STEP, L.WANT_MASK),
 }
 _WANT_BYTES = ((L.WANT_MASK, 180), (L.WANT_OBS, 544), (L.WANT_STATS, 80))          # (the reference's sizes; traffic accounting only)
 
@@ -78,6 +81,7 @@ class HipBackend:
         self.c.record_out = self._rec_out.ctypes.data
         self.c.mt_out = self._mt_out.ctypes.data
         self._resident = None                # bytes of the record the device holds
+        self._mask_for, self._mask = None, None   # the legal mask a call brought back, and the record bytes it belongs to
 
     def _submit(self, draws):
         """Run self.c; for a drawing call: hand the global stream over (only if the device copy is stale) and install the advanced
@@ -105,12 +109,17 @@ class HipBackend:
     def call(self, op, args=(), rec=None, draws=False, mutates=True):
         """One facade method: `rec` = the caller's packed attributes; returns (result, record after the call or None)."""
         c = self.c
+        rb = rec.tobytes()
+        # GameRunner's player_score / move_counter (the last four bytes of the 128-byte record) only matter to GameRunner's own calls: the
+        # Azul-level calls pack them as zero, and must neither re-send the record nor miss the cached mask because of them
+        game = len(rb) - 4 if (len(rb) == L.RECORD_BYTES and not op.startswith("op_runner")) else len(rb)
+        if op == "op_mask" and self._mask_for is not None and rb[:game] == self._mask_for[:game]:
+            return self._mask.copy(), None   # the previous call already computed this state's mask (the bytes are compared, not a flag)
         c.op, want = _OPS[op]
         c.arg = int(args[0]) if args else 0
         c.mask_in = None
-        rb = rec.tobytes()
         h2d = 4 if args else 0
-        if rb != self._resident:
+        if self._resident is None or rb[:game] != self._resident[:game]:
             self._rec_in[0] = rec
             c.record_in = self._rec_in.ctypes.data
             h2d += len(rb)
@@ -128,8 +137,10 @@ class HipBackend:
         if mutates:
             new = self._rec_out[0].copy()
             self._resident = new.tobytes()
-        else:
+        elif c.record_in is not None:
             self._resident = rb
+        if want & L.WANT_MASK and new is not None:
+            self._mask_for, self._mask = self._resident, np.frombuffer(bytes(c.mask), dtype=np.uint8)[:self.num_actions].astype(bool)
         if op == "op_runner_step":
             return (int(c.reward), bool(c.done), int(c.status)), new
         if op == "op_mask":

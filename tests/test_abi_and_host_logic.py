@@ -112,3 +112,15 @@ def test_argument_validation_needs_no_gpu():
                                          one, None, None) == L.ERR_INVALID
     with pytest.raises(L.AzulHipError):
         L.check(lib.azul_batch_selfplay(None, 4, None, None, None, None, None, None, None, None))
+
+
+def test_shipped_library_is_not_a_timing_experiment_build():
+    """The switches that price a kernel's stores / LDS round trips / weight loads by leaving them out produce wrong results; they need
+    -DAZ_TIMING_EXPERIMENTS, which azul_version() reports.  The library the package loads must be a clean build."""
+    from azul_deep_reinforcement_learning_amd import _lib as L
+    v = L.lib.azul_version().decode()
+    assert "AZ_TIMING_EXPERIMENTS" not in v and v.startswith("azul-mi355x"), v
+    src = open(os.path.join(ROOT, "azul_deep_reinforcement_learning_amd", "csrc", "azul_kernels.hip")).read()
+    for sw in ("AZ2_EXPERIMENT_NO_LDS", "AZ2_X_NO_SCALAR_STORES", "AZ2_X_NO_MASK_STORES", "AZ2_X_NO_STATS", "PR2_EXPERIMENT_NO_WEIGHT_LOADS",
+               "PR2_X_NO_MASK_STORES"):
+        assert "defined(%s)" % sw in src.split("#error")[0], sw          # every wrong-result switch is behind the guard

@@ -43,15 +43,18 @@ AZ_FN u32 observe_val2(const G2 &g, u32 o0 /* half-uniform: 0 / 1 */, u32 l)
     return v;
 }
 
-// writes the 136 floats of my game to `lds_row` (the network's A operand) and to `glob` (trajectory slot)
+// writes the 136 floats of my game to `lds_row` (the network's A operand) and, when given, to `glob` (trajectory slot)
 AZ_FN void observe2(const G2 &g, u32 persp, float *lds_row, float *glob, u32 l)
 {
     const u32 o0 = persp & 1u;
     float v0 = (float)(i32)observe_val2<0>(g, o0, l), v1 = (float)(i32)observe_val2<1>(g, o0, l), v2 = (float)(i32)observe_val2<2>(g, o0, l),
           v3 = (float)(i32)observe_val2<3>(g, o0, l), v4 = (float)(i32)observe_val2<4>(g, o0, l);
     lds_row[l] = v0; lds_row[l + 32u] = v1; lds_row[l + 64u] = v2; lds_row[l + 96u] = v3;
-    glob[l] = v0; glob[l + 32u] = v1; glob[l + 64u] = v2; glob[l + 96u] = v3;
-    if (l < 8u) { lds_row[l + 128u] = v4; glob[l + 128u] = v4; }
+    if (l < 8u) lds_row[l + 128u] = v4;
+    if (glob) {          // (the rollout kernel passes NULL: its trajectory slot is filled from the LDS rows by waves that idle during the head phase)
+        glob[l] = v0; glob[l + 32u] = v1; glob[l + 64u] = v2; glob[l + 96u] = v3;
+        if (l < 8u) glob[l + 128u] = v4;
+    }
 }
 
 // ---- RandomAgent.get_a_output (game_runner.py:87-97): selfplay_step2's decision as a function --------------------------------------

@@ -1150,6 +1150,8 @@ int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random,
         !reward_dev || !done_dev || !value_dev || !logp_dev || !entropy_dev)
         return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: NULL pointer");
     if (((uintptr_t)w1t_dev & 7u) != 0) return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: w1t_dev must be 8-byte aligned");
+    if (((uintptr_t)obs_dev & 15u) != 0 || ((uintptr_t)mask_dev & 3u) != 0)
+        return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: obs_dev must be 16-byte aligned, mask_dev 4-byte aligned");
     PolicyWeights W = {w1t_dev, b1_dev, w2c_dev, b2c_dev, w2a_t_dev, b2a_dev};
     RolloutArgs a = {n_steps, obs_dev, mask_dev, player_dev, action_dev, reward_dev, done_dev, value_dev, logp_dev, entropy_dev, status_dev,
                      (u64)seed, (u64)counter, (u64 *)counter_dev};

@@ -203,23 +203,43 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
 
     // observation + legal mask of the current state -> LDS (network / head) and trajectory slot `slot`
     az2::Mask2 m;                                        // legal mask of the published state: the next env step tests the action against it
+    // The env phase only writes LDS (observation row, packed mask bits) + the player byte; the trajectory slot's 544-byte observation and
+    // 180-byte mask of every game are copied out of LDS by flush() below, on waves that idle during the head phase: eleven vector
+    // stores per game pair leave the env phase, which every other phase of the move waits for.
     auto publish = [&](u32 slot) {
         az2::legal_mask2(g, k, m);
-        const size_t cell = (size_t)slot * n + gi;
-        uint8_t *row = a.mask + cell * AZUL_NUM_ACTIONS + l;
-#if !defined(PR2_X_NO_MASK_STORES)       // (TIMING EXPERIMENT switch: wrong results)
-        if (l < 30u) {
-#pragma unroll
-            for (u32 ww = 0; ww < 6u; ww++) row[30u * ww] = (uint8_t)m.bit[ww];
-        }
-#endif
         if (l == 0u) {                                   // the 180 bits packed: the six 30-bit row words concatenated
             maskS[gl][0] = (u64)m.m[0] | ((u64)m.m[1] << 30) | ((u64)m.m[2] << 60);
             maskS[gl][1] = ((u64)m.m[2] >> 4) | ((u64)m.m[3] << 26) | ((u64)m.m[4] << 56);
             maskS[gl][2] = ((u64)m.m[4] >> 8) | ((u64)m.m[5] << 22);
-            a.player[cell] = (uint8_t)g.cur;
+            a.player[(size_t)slot * n + gi] = (uint8_t)g.cur;
         }
-        az2::observe2(g, OPP ? 0u : az2::me2(g), orow, a.obs + cell * PF_IN, l);
+        az2::observe2(g, OPP ? 0u : az2::me2(g), orow, nullptr, l);
+    };
+    // trajectory slot `slot` of the workgroup's 16 games <- the LDS rows: the 16 x 136 floats are contiguous in the [T+1][N][136]
+    // array (16-byte chunks), the 16 x 180 mask bytes in [T+1][N][180] (dwords: four bits of the packed mask spread into four bytes).
+    // `idx` in 0..191 over the three copying waves.
+    auto flush = [&](u32 slot, u32 idx) {
+        const size_t cell0 = (size_t)slot * n + g0;
+        float *og = a.obs + cell0 * PF_IN;
+#pragma unroll
+        for (u32 rep = 0; rep < 3u; rep++) {
+            const u32 j = idx + 192u * rep;              // 16-byte chunk: row j / 34, floats 4 (j % 34) ..
+            const u32 row = j / 34u, c4 = j - 34u * row;
+            if (j < 16u * 34u && g0 + row < n) *(float4 *)(og + 4u * j) = *(const float4 *)(obsS + row * PF_OBS_STRIDE + 4u * c4);
+        }
+#if !defined(PR2_X_NO_MASK_STORES)       // (TIMING EXPERIMENT switch: wrong results)
+        u32 *mg = (u32 *)(a.mask + cell0 * AZUL_NUM_ACTIONS);
+#pragma unroll
+        for (u32 rep = 0; rep < 4u; rep++) {
+            const u32 d = idx + 192u * rep;              // dword: row d / 45, actions 4 (d % 45) ..
+            const u32 row = d / 45u, a0 = 4u * (d - 45u * row);
+            if (d < 16u * 45u && g0 + row < n) {
+                const u32 nib = (u32)(maskS[row][a0 >> 6] >> (a0 & 63u)) & 0xfu;
+                mg[d] = (nib * 0x00204081u) & 0x01010101u;
+            }
+        }
+#endif
     };
     if (live) publish(0u);
     else {
@@ -307,7 +327,9 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
             const u32 okbits = c < 15u ? (u32)field & 0xfffu : 0u;
             policy_head_rows(x, lgS + hrow * PF_LOG_STRIDE, okbits, a.seed, counter + (u64)t, hg < n ? hg : n - 1u, lane, hg < n, a.action + row_t, a.logp + row_t,
                              a.entropy + row_t, b.id_base, actS + 4u * w, &u_head);
-        } else if (w == 7u) {
+        } else if (w < 7u) {
+            flush((u32)t, 64u * (w - 4u) + lane);        // waves 4..6: the trajectory slot of this move's decision
+        } else {
             // the critic, on a wave that idles during the head, summed exactly like azul_policy_forward_kernel: lane (row c, quarter q)
             // sums k = q (mod 4), then the quarters are added (model.py:22-26)
             float sum = 0.f;
@@ -331,6 +353,8 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
             publish((u32)t + 1u);
         }
     }
+    lds_barrier();                                       // the rows of the state after the last move
+    if (w >= 4u && w < 7u) flush((u32)a.n_steps, 64u * (w - 4u) + lane);
 #if defined(AZ_PROFILE_SEGMENTS)
     if (lane == 0u && w == 5u) {
         for (int i = 0; i < 5; i++) atomicAdd((unsigned long long *)(b.prof + i), (unsigned long long)pr_acc[i]);

@@ -298,7 +298,8 @@ int azul_policy_forward(const float *obs_dev /*[N][136]*/, const uint8_t *mask_d
  * (like azul_batch_agent_step, perspective 0) -- then slot n_steps receives the state after the last move.  Games and RNG
  * streams stay in registers / LDS for the whole launch.  Layouts are time-major: obs [T+1][N][136], mask [T+1][N][180],
  * player [T+1][N], action / reward / done / value / logp / entropy [T][N]; status [N] (optional) is the last move's status.
- * The results are bit-identical to n_steps x (azul_policy_forward + azul_batch_policy_step / _agent_step). */
+ * The results are bit-identical to n_steps x (azul_policy_forward + azul_batch_policy_step / _agent_step).  obs_dev must be 16-byte
+ * aligned, mask_dev 4-byte aligned (the slots are written in 16-byte / 4-byte pieces). */
 int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random, const float *w1t_dev, const float *b1_dev,
                               const float *w2c_dev, const float *b2c_dev, const float *w2a_t_dev, const float *b2a_dev, int num_inputs,
                               int hidden_size, int num_actions, uint64_t seed, uint64_t counter, uint64_t *counter_dev, float *obs_dev,

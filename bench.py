@@ -474,6 +474,18 @@ def main():
                                                                                           tj.get("source", "profiles/hbm_traffic.json"))
             except Exception:
                 traffic = None
+        issue = None
+        isf = os.path.join(ROOT, "profiles", "issue_rate.json")
+        if os.path.exists(isf):
+            try:
+                ij = json.load(open(isf))    # SQ instruction counters + GRBM cycles of an EARLIER rocprofv3 --pmc run of this command (see `source`)
+                issue = {k: ij.get(k) for k in ("instr_per_game_move", "valu_per_game_move", "salu_per_game_move", "cycles_per_instr_per_simd",
+                                                "saturation_cycles_per_instr_per_simd", "frac", "waves_per_simd", "wait_any_share_of_wave_cycles")}
+                issue["note"] = ("not measured in this run: %s.  The kernel is instruction-issue bound: frac = cycles per wave-instruction per SIMD with "
+                                 "saturated SIMDs (8192 games, four waves per SIMD) / the same at this workload's two waves per SIMD" % ij.get("source", isf))
+                issue["saturation_source"] = ij.get("saturation_source")
+            except Exception:
+                issue = None
         kernel_name = "azul_selfplay2_kernel" if os.environ.get("AZUL_SELFPLAY_KERNEL", "2")[:1] != "1" else "azul_selfplay_kernel"
         coll = "RCCL" if backend == "nccl" else backend
         if gather:
@@ -507,6 +519,7 @@ def main():
                          "event_bracket_ms": bracket_ms, "host_elapsed_ms": elapsed * 1e3,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * G * T, "scope": "rank 0's GPU",
                          "limiter": "instruction issue / dependent-issue latency at two waves per SIMD, not HBM (DESIGN.md 3)",
+                         "issue": issue,
                          "note": "working set is cache resident; the path is issue/latency bound, see DESIGN.md"},
             "parity_gate": gate, "parity_gate_after_timed_region": gate_end,
             "episodes_finished": int(cnt["episodes"].sum()), "stuck_resets": stuck,

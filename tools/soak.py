@@ -1,10 +1,15 @@
 """One-off soak (not part of the test suite): 4096 games x 1,048,576 self-play moves each on the GPU (4.3 G moves, ~2.4 s),
 then 25 games replayed by the oracle and compared bit for bit (final record).  Round 1 result: PASS, 76.2 M episodes, 0 stuck."""
-import sys, time
+import hashlib, sys, time
 sys.path.insert(0, '.')
+sys.path.insert(0, 'tools')
 import numpy as np, torch
 from azul_deep_reinforcement_learning_amd import BatchedAzul
 from oracle import oracle as oz
+from azul_deep_reinforcement_learning_amd import _lib as L
+from provenance import csrc_hash
+print("csrc sha256 %s | libazulhip.so sha256 %s | %s" % (csrc_hash(), hashlib.sha256(open(L.LIB_PATH, "rb").read()).hexdigest()[:16],
+                                                        L.lib.azul_version().decode()), flush=True)
 n, T, launches = 4096, 2048, 512          # 1,048,576 moves per game, 4.3 G moves in total
 env = BatchedAzul(n); env.seed(123456); env.runner_init(); env.runner_init()
 t0 = time.time()

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
+sys.path.insert(0, __file__.rsplit("/", 1)[0])
 from azul_deep_reinforcement_learning_amd import BatchedActorCritic, PolicyRollout  # noqa: E402
 
 import hashlib  # noqa: E402
@@ -18,9 +19,10 @@ from azul_deep_reinforcement_learning_amd import _lib as L  # noqa: E402
 windows = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 # provenance of a raw log: which library, which harness, which network (a claim of bit-identity is only as good as the log it cites)
-print("libazulhip.so sha256 %s | %s | soak_rollout.py sha256 %s | source rev %s" % (
-    hashlib.sha256(open(L.LIB_PATH, "rb").read()).hexdigest()[:16], L.lib.azul_version().decode(),
-    hashlib.sha256(open(__file__, "rb").read()).hexdigest()[:16], os.environ.get("AZUL_SOURCE_REV", "?")))
+from provenance import csrc_hash  # noqa: E402  (tools/provenance.py: sha256 over csrc/ + include/azul_hip.h)
+print("csrc sha256 %s | libazulhip.so sha256 %s | %s | soak_rollout.py sha256 %s" % (
+    csrc_hash(), hashlib.sha256(open(L.LIB_PATH, "rb").read()).hexdigest()[:16], L.lib.azul_version().decode(),
+    hashlib.sha256(open(__file__, "rb").read()).hexdigest()[:16]))
 for opponent in (None, "random"):
     runs = []
     for persistent in (False, True):

@@ -90,6 +90,33 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
 waves_steps = bench["config"]["games_per_gpu"] * bench["config"]["moves_per_launch"]
 if "SQ_INSTS_VALU" in pmc:
     summary["per_wave_step"] = {k: pmc[k]["mean"] / waves_steps for k in pmc if k.startswith("SQ_")}
+# ---- the issue side ("VALU utilisation / occupancy alongside the HBM fraction"): the kernel is bound by the rate at which a
+# SIMD issues this instruction mix, so the checkable figure is cycles per wave-instruction per SIMD against the rate the same kernel
+# reaches when the SIMDs are saturated with waves (the 8192-game run of tools/games_sweep.sh: twice the waves, same instructions per move)
+if "SQ_INSTS_VALU" in pmc and "SQ_INSTS_SALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
+    wave_instr = pmc["SQ_INSTS_VALU"]["mean"] + pmc["SQ_INSTS_SALU"]["mean"]
+    cycles = pmc["GRBM_GUI_ACTIVE"]["mean"] / 8.0                     # summed over the 8 XCDs
+    N_SIMD = 1024
+    issue = {"instr_per_game_move": wave_instr / waves_steps, "valu_per_game_move": pmc["SQ_INSTS_VALU"]["mean"] / waves_steps,
+             "salu_per_game_move": pmc["SQ_INSTS_SALU"]["mean"] / waves_steps, "wave_instr_per_launch": wave_instr,
+             "cycles_per_launch": cycles, "clock_ghz": cycles / float(sp["AverageNs"]),
+             "waves_per_simd": pmc["SQ_WAVES"]["mean"] / N_SIMD if "SQ_WAVES" in pmc else None,
+             "cycles_per_instr_per_simd": cycles * N_SIMD / wave_instr,
+             "wait_any_share_of_wave_cycles": (pmc["SQ_WAIT_ANY"]["mean"] / pmc["SQ_WAVE_CYCLES"]["mean"]) if "SQ_WAIT_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc else None,
+             "source": "profiles/%s_summary.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU ..., GRBM_GUI_ACTIVE in its own pass)" % name}
+    sweep = os.path.join(dst, "%s_games_sweep.txt" % name)
+    if os.path.exists(sweep):
+        vals = {}
+        for ln in open(sweep):
+            if ln.startswith("games") and "G env steps/s" in ln:
+                vals[int(ln.split()[1].rstrip(":"))] = float(ln.split()[2])
+        if 4096 in vals and 8192 in vals:
+            # same instructions per game-move, twice the waves per SIMD: cycles per instruction scale with 1 / throughput
+            issue["saturation_cycles_per_instr_per_simd"] = issue["cycles_per_instr_per_simd"] * vals[4096] / vals[8192]
+            issue["saturation_source"] = "profiles/%s_games_sweep.txt: %.3f G env steps/s at 4096 games, %.3f G at 8192 (four waves per SIMD)" % (name, vals[4096], vals[8192])
+            issue["frac"] = issue["saturation_cycles_per_instr_per_simd"] / issue["cycles_per_instr_per_simd"]
+    summary["issue"] = issue
+    json.dump(issue, open(os.path.join(dst, "issue_rate.json"), "w"), indent=1)
 summary["bench"] = {k: bench[k] for k in ("value", "ms_per_step", "roofline", "cpu_baseline") if k in bench}
 json.dump(summary, open(os.path.join(dst, "%s_summary.json" % name), "w"), indent=1)
 print(json.dumps(summary, indent=1))

@@ -86,6 +86,7 @@ SIGNATURES = {
     "azul_policy_head": (_i, [_vp, _vp, _u64, _u64, _vp, _i, _u32, _vp, _vp, _vp, _vp]),
     "azul_policy_forward": (_i, [_vp] * 8 + [_i, _i, _i, _u64, _u64, _vp, _i, _i, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "azul_batch_policy_rollout": (_i, [_vp, _i, _i] + [_vp] * 6 + [_i, _i, _i, _u64, _u64, _vp] + [_vp] * 10 + [_vp]),
+    "azul_batch_policy_rollout_returns": (_i, [_vp, _i, _i] + [_vp] * 6 + [_i, _i, _i, _u64, _u64, _vp] + [_vp] * 10 + [_vp, C.c_float, _vp]),
     "azul_a2c_gradients": (_i, [_vp, _vp, _vp, _vp, _i, C.c_float] + [_vp] * 7 + [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "azul_a2c_apply_adam": (_i, [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _i] + [_vp] * 8 + [_vp, _vp, C.c_float, _vp, _vp]),
     "azul_select_episode_samples": (_i, [_vp, _vp, _i, _i, _i, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1140,6 +1140,18 @@ int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random,
                               uint8_t *mask_dev, uint8_t *player_dev, int32_t *action_dev, int32_t *reward_dev, uint8_t *done_dev,
                               float *value_dev, float *logp_dev, float *entropy_dev, uint8_t *status_dev, void *stream)
 {
+    return azul_batch_policy_rollout_returns(b, n_steps, opponent_random, w1t_dev, b1_dev, w2c_dev, b2c_dev, w2a_t_dev, b2a_dev, num_inputs, hidden_size,
+                                             num_actions, seed, counter, counter_dev, obs_dev, mask_dev, player_dev, action_dev, reward_dev, done_dev,
+                                             value_dev, logp_dev, entropy_dev, status_dev, nullptr, 0.f, stream);
+}
+
+int azul_batch_policy_rollout_returns(azul_batch_t *b, int n_steps, int opponent_random, const float *w1t_dev, const float *b1_dev,
+                                      const float *w2c_dev, const float *b2c_dev, const float *w2a_t_dev, const float *b2a_dev, int num_inputs,
+                                      int hidden_size, int num_actions, uint64_t seed, uint64_t counter, uint64_t *counter_dev, float *obs_dev,
+                                      uint8_t *mask_dev, uint8_t *player_dev, int32_t *action_dev, int32_t *reward_dev, uint8_t *done_dev,
+                                      float *value_dev, float *logp_dev, float *entropy_dev, uint8_t *status_dev, float *returns_dev, float gamma,
+                                      void *stream)
+{
     BATCH_GUARD(b, stream);
     if (!b || n_steps < 0) return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: bad arguments");
     if (b->x) return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: the policy entries are compiled for the reference's two-player game "
@@ -1154,7 +1166,7 @@ int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random,
         return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout: obs_dev must be 16-byte aligned, mask_dev 4-byte aligned");
     PolicyWeights W = {w1t_dev, b1_dev, w2c_dev, b2c_dev, w2a_t_dev, b2a_dev};
     RolloutArgs a = {n_steps, obs_dev, mask_dev, player_dev, action_dev, reward_dev, done_dev, value_dev, logp_dev, entropy_dev, status_dev,
-                     (u64)seed, (u64)counter, (u64 *)counter_dev};
+                     returns_dev, gamma, (u64)seed, (u64)counter, (u64 *)counter_dev};
     const hipStream_t st = (hipStream_t)stream;
     const bool lid = b->d.rules.tile_pool == POOL_LID;
     // AZUL_ROLLOUT_KERNEL=1 selects the one-game-per-wave kernel (azul_policy.hpp) for A/B measurements; default: the env side on
@@ -1167,6 +1179,8 @@ int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random,
         else if (opponent_random) hipLaunchKernelGGL((azul_policy_rollout2_kernel<false, true>), grid2, block2, 0, st, b->d, W, a);
         else hipLaunchKernelGGL((azul_policy_rollout2_kernel<false, false>), grid2, block2, 0, st, b->d, W, a);
         HIP_TRY(hipGetLastError());
+        if (returns_dev && n_steps > 32)       // the kernel keeps a window's rewards in 32 lanes: longer windows get the separate scan
+            return azul_discounted_returns(reward_dev, done_dev, returns_dev, nullptr, gamma, n_steps, (int)b->d.n, stream);
         return AZUL_SUCCESS;
     }
     const dim3 grid((b->d.n + PF_GAMES - 1) / PF_GAMES), block(64 * PR_WAVES);
@@ -1175,6 +1189,7 @@ int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random,
     else if (opponent_random) hipLaunchKernelGGL((azul_policy_rollout_kernel<false, true>), grid, block, 0, st, b->d, W, a);
     else hipLaunchKernelGGL((azul_policy_rollout_kernel<false, false>), grid, block, 0, st, b->d, W, a);
     HIP_TRY(hipGetLastError());
+    if (returns_dev) return azul_discounted_returns(reward_dev, done_dev, returns_dev, nullptr, gamma, n_steps, (int)b->d.n, stream);
     return AZUL_SUCCESS;
 }
 

@@ -393,6 +393,8 @@ struct RolloutArgs {
     float *logp;         // [T][N]
     float *entropy;      // [T][N]
     uint8_t *status;     // [N]  status of the last move
+    float *returns;      // [T][N] optional: the window's discounted returns (nn_runner.py:70-76), written by the kernel itself when T <= 32
+    float gamma;
     u64 seed, counter;
     u64 *counter_dev;    // optional [2]: [0] added to `counter`, advanced by n_steps; [1] completion ticket
 };

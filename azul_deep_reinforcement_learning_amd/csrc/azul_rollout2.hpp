@@ -198,6 +198,8 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     az2::Counters2 cnt;
     az2::counters2_open(cnt, b.episodes + gic, b.stuck + gic, b.stat_sum + (size_t)gic * 10, l);
     u32 st_last = ST_OK;
+    i32 win_rew = 0;
+    u32 win_done = 0;
     float *orow = obsS + gl * PF_OBS_STRIDE;
     __syncthreads();                                     // tables / biases staged
 
@@ -350,6 +352,8 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
             st_last = OPP ? az2::agent_step2<LID>(g, av, m, b.rules.first_player, r, tab, margin, cnt, k, rew, dn)
                           : az2::policy_step2<LID>(g, av, m, b.rules.first_player, r, margin, cnt, k, rew, dn);
             if (l == 0u) { a.reward[row_t + gi] = rew; a.done[row_t + gi] = (uint8_t)dn; }
+            win_rew = l == ((u32)t & 31u) ? rew : win_rew;           // lane t of the half keeps step t (the returns scan below)
+            win_done = l == ((u32)t & 31u) ? dn : win_done;
             publish((u32)t + 1u);
         }
     }
@@ -365,6 +369,21 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
         atomicMax((unsigned long long *)(b.prof + 8), (unsigned long long)pr_r1);
     }
 #endif
+    if (live && a.returns && a.n_steps <= 32) {
+        // the window's discounted returns (azul_returns_kernel's scan, statement for statement: q = reward + gamma * q backwards, an
+        // episode end resets q; nn_runner.py:70-76) from the rewards / done flags this half kept in its lanes: no second launch
+        float q = 0.f;
+        float mine = 0.f;
+#pragma unroll 1
+        for (int t = a.n_steps - 1; t >= 0; t--) {
+            const i32 rt = (i32)az2::hread((u32)win_rew, (u32)t);
+            const u32 dt = az2::hread(win_done, (u32)t);
+            if (dt) q = 0.f;
+            q = (float)rt + a.gamma * q;
+            mine = l == (u32)t ? q : mine;
+        }
+        if (l < (u32)a.n_steps) a.returns[(size_t)l * n + gi] = mine;
+    }
     if (live) {
         az2::g2_store(g, rec, l);
         az2::rng2_close(r, gmt, b.mtpos + gi, l);

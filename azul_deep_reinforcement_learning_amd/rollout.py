@@ -200,13 +200,13 @@ class PolicyRollout:
         if self.persistent:
             env, w, pol = self.envs[p], self.work[p], self.policy
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            L.check(L.lib.azul_batch_policy_rollout(
+            # (ring == 1: the window's returns have no carry across its end -- the rollout kernel writes them itself, no second launch)
+            L.check(L.lib.azul_batch_policy_rollout_returns(
                 env._h, T, 1 if self.opponent == "random" else 0, _p(self.w1t), _p(self.b1), _p(self.w2c), _p(pol.critic_linear2.bias),
                 _p(self.w2a_t), _p(pol.actor_linear2.bias), L.OBS_SIZE, self.H, L.NUM_ACTIONS, self.sample_seed, 0, _p(w["counter"]),
                 _p(tr["obs"]), _p(tr["mask"]), _p(tr["player"]), _p(tr["action"]), _p(tr["reward"]), _p(tr["done"]), _p(tr["value"]),
-                _p(tr["log_prob"]), _p(tr["entropy"]), _p(w["status"]), st))
+                _p(tr["log_prob"]), _p(tr["entropy"]), _p(w["status"]), _p(tr["returns"]) if self.ring == 1 else None, C.c_float(gamma), st))
             if self.ring == 1:
-                L.check(L.lib.azul_discounted_returns(_p(tr["reward"]), _p(tr["done"]), _p(tr["returns"]), None, C.c_float(gamma), T, self.h, st))
                 return
             # returns of the new window and, chained backwards through the ring, of the older windows: the value flowing out of a
             # window's first step flows into the window before it (nn_runner.py:70-76 across window boundaries) -- one launch

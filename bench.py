@@ -183,7 +183,7 @@ def extras(games, world=1, rank=0, dev=None, seed_base=0, backend="nccl", phase=
                    "parallelism": "games sharded by global id; no collective: the C1 trajectory records stay in the HBM of the rank that "
                                   "produced them (DESIGN.md 7)"},
         "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "kernel": "azul_policy_rollout2_kernel (+ azul_returns_kernel)", "avg_window_ms": kms / windows,
+                     "traffic": None, "kernel": "azul_policy_rollout2_kernel (writes the window's discounted returns itself)", "avg_window_ms": kms / windows,
                      "flop_per_env_move": FWD_FLOP_PER_GAME, "event_bracket_ms": kms, "host_elapsed_ms": dt * 1e3, "scope": "rank 0's GPU"}}
     del ro
     torch.cuda.empty_cache()

@@ -305,6 +305,16 @@ int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random,
                               int hidden_size, int num_actions, uint64_t seed, uint64_t counter, uint64_t *counter_dev, float *obs_dev,
                               uint8_t *mask_dev, uint8_t *player_dev, int32_t *action_dev, int32_t *reward_dev, uint8_t *done_dev,
                               float *value_dev, float *logp_dev, float *entropy_dev, uint8_t *status_dev, void *stream);
+/* The same launch also writing the window's discounted returns (nn_runner.py:70-76: q = reward + gamma * q backwards within an episode,
+ * no carry across the window's end: what azul_discounted_returns(reward, done, returns, NULL, gamma, n_steps, N) computes, bit for bit) into
+ * returns_dev [T][N] -- for windows of up to 32 moves from the rewards the kernel still holds in registers, without a second launch
+ * (longer windows: the separate scan is launched behind the kernel).  returns_dev NULL: azul_batch_policy_rollout. */
+int azul_batch_policy_rollout_returns(azul_batch_t *b, int n_steps, int opponent_random, const float *w1t_dev, const float *b1_dev,
+                                      const float *w2c_dev, const float *b2c_dev, const float *w2a_t_dev, const float *b2a_dev, int num_inputs,
+                                      int hidden_size, int num_actions, uint64_t seed, uint64_t counter, uint64_t *counter_dev, float *obs_dev,
+                                      uint8_t *mask_dev, uint8_t *player_dev, int32_t *action_dev, int32_t *reward_dev, uint8_t *done_dev,
+                                      float *value_dev, float *logp_dev, float *entropy_dev, uint8_t *status_dev, float *returns_dev, float gamma,
+                                      void *stream);
 /* The A2C update's gradients (Agent.update, agent.py:39-58) for n_samples recorded (observation, mask, action, q-value) samples:
  * forward and backward of  L = mean_i( -logp_i[a_i] * adv_i + 0.5 * adv_i^2 + 0.1 * (-mean_{j legal} logp_i[j]) ),  adv = q - V
  * (advantage not detached, like the reference), on the f32 matrix cores.  `inv_n_total` = 1 / (samples of the whole batch over

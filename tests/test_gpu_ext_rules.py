@@ -301,3 +301,50 @@ def test_sizes_refusals_and_rule_errors():
     rec["n_displays"][0] = 0
     with pytest.raises(L.AzulHipError):
         env.set_records(rec)
+
+
+@pytest.mark.parametrize("players,ext", [(3, 0), (4, oz.EXT_DISPLAYS_2P1 | oz.EXT_END_BONUS | oz.EXT_SHORT_DEAL)])
+def test_full_size_batches_are_shard_invariant_and_conserve_tiles(players, ext):
+    """BASELINE-size properties for row N4's kernels (the counterpart of tests/test_full_size_configs.py): 32,768 games in one batch vs
+    eight batches of 4096 seeded by global id -- compact records, final records, RNG positions and counters byte-identical per global
+    id (a game does not depend on the GPU count or on its wave's sibling) --, sampled ids replayed through the oracle, and 100 tiles
+    conserved in every one of the 32,768 final records."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    P, G, SHARDS, T, base = players, 4096, 8, 256, 77000
+    big = BatchedAzul(SHARDS * G, players=P, ext_rules=ext)
+    big.seed(base)
+    big.init()
+    big.new_round()
+    tb = big.alloc_trajectory(T, packed_mask=True, mask_pitch={5: 192, 7: 256, 9: 320}[big.displays], mask_bits=False)
+    packs = []
+    for _ in range(2):
+        big.selfplay(T, tb["mask"], tb["action"], tb["reward"], tb["done"], packed=tb["packed"])
+        packs.append(tb["packed"].clone())
+    torch.cuda.synchronize()
+    big_rec, big_pos, big_cnt = big.get_records(), big.get_rng_range()[1], big.counters()
+    assert (_conserved(big_rec, P, big.displays) == 100).all()
+    assert int(big_cnt["episodes"].sum()) > SHARDS * G * 4
+    for k in range(SHARDS):
+        env = BatchedAzul(G, players=P, ext_rules=ext)
+        env.seed(base + k * G)
+        env.init()
+        env.new_round()
+        ts = env.alloc_trajectory(T, packed_mask=True, mask_pitch={5: 192, 7: 256, 9: 320}[env.displays], mask_bits=False)
+        for i in range(2):
+            env.selfplay(T, ts["mask"], ts["action"], ts["reward"], ts["done"], packed=ts["packed"])
+            assert torch.equal(ts["packed"], packs[i][:, k * G:(k + 1) * G]), (k, i)
+        torch.cuda.synchronize()
+        assert env.get_records().tobytes() == big_rec[k * G:(k + 1) * G].tobytes(), k
+        assert np.array_equal(env.get_rng_range()[1], big_pos[k * G:(k + 1) * G]), k
+        c = env.counters()
+        assert np.array_equal(c["episodes"], big_cnt["episodes"][k * G:(k + 1) * G]) and np.array_equal(c["stuck"], big_cnt["stuck"][k * G:(k + 1) * G])
+        del env, ts
+    pk = torch.cat(packs).cpu().numpy().view(np.uint32)
+    for gid in list(range(0, SHARDS * G, 2731)) + [G - 1, G, SHARDS * G - 1]:
+        s = oz.StreamX(base + gid, P, ext=ext)
+        o = s.advance(2 * T, want_records=False)
+        p = pk[:, gid]
+        a = np.where((p & 0xFF) == 0xFF, (p >> 16).astype(np.int32), (p & 0xFF).astype(np.int32))
+        a[a == 0xFFFF] = -1
+        assert np.array_equal(a, o["action"]) and np.array_equal((p >> 8) & 0xFF, o["done"]), gid
+        assert s.record().tobytes() == big_rec[gid].tobytes() and s.rng_state()[1] == int(big_pos[gid]), gid

@@ -22,15 +22,17 @@ from .records import RECORD_DTYPE, RECORD_NP_DTYPE, all_displays, bits_to_walls,
 def _ilist(x, name):
     """An attribute's values as Python ints.  The reference's attributes are int arrays, but callers assign freely: a float array
     holding integers (game.score = np.array([3., 0.])) is accepted like the reference accepts it; a fractional value is named."""
-    a = np.ravel(x)
-    if a.dtype.kind == "f":
-        ai = a.astype(np.int64)
-        if not np.array_equal(ai, a):
+    a = x if type(x) is np.ndarray else np.asarray(x)
+    k = a.dtype.kind
+    if k == "i" or k == "u":
+        return a.ravel().tolist()
+    if k == "f":                                     # (a handful of values: plain Python is quicker than two numpy passes)
+        vals = a.ravel().tolist()
+        ints = [int(v) for v in vals]
+        if ints != vals:
             raise ValueError("%s must hold integral values" % name)
-        a = ai
-    elif a.dtype.kind == "b":
-        a = a.astype(np.int64)
-    return a.tolist()
+        return ints
+    return a.ravel().astype(np.int64).tolist()
 
 
 class IllegalMove(Exception):

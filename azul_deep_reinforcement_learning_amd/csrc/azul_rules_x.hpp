@@ -18,9 +18,12 @@
 // Layout inside a half (l = lane & 31):
 //   cs0       lane 5 d + c = displays[d][c] for d < 5, lane 25 + c = center[c], lane 30 = token          (az2's cs)
 //   cs1       lane 5 (d - 5) + c = displays[d][c] for d >= 5                                              (only when D > 5)
-//   cp[p]     lane 5 r + c = pattern_lines[p][r][c], one register per player
-//   everything else half-uniform; per-player values are arrays indexed by compile-time constants (scoring walks the players) or
-//   through select chains on the mover's index (pick / put) -- no run-time indexed memory.
+//   cpk       lane 5 r + c = pattern_lines[p][r][c] of ALL players, one byte per player (byte p): the mover's cell is a bit field
+//             at 8 * me -- no per-player registers to select between on the move's path
+//   floors    half-uniform, byte p = floors[p] (the record's dword); okv lane p = player p's "row accepts colour" board
+//   everything else half-uniform; the remaining per-player values are arrays indexed by compile-time constants (scoring walks the
+//   players) -- no run-time indexed memory.  (Round 4's first version kept cp / floor / ok as per-player registers behind
+//   v_cndmask chains on the mover's index: measured 10-15 % of the launch for three / four players.)
 // Legal mask: per pattern row r, bit q = source + (D + 1) colour (< 5 (D + 1)) of a 30- / 40- / 50-bit row word; lane l owns bit l of the
 // low 32 and (D > 5) bit 32 + l of the rest.
 //
@@ -86,10 +89,11 @@ AZ_FN void kx_init(KX<D> &K)
 template <u32 P, u32 D>
 struct GX {
     u32 cs0, cs1;
-    u32 cp[P];
-    u32 wall[P], floor_[P];
+    u32 cpk;                    // lane 5 r + c: byte p = pattern_lines[p][r][c]
+    u32 floors;                 // half-uniform: byte p = floors[p]
+    u32 wall[P];
     i32 score[P];
-    u32 ok[P];                  // derived: "row r accepts colour c" boards (az2::ok_board2)
+    u32 okv;                    // derived: lane p = player p's "row r accepts colour c" board (az2::ok_board2)
     u32 fps[P];                 // first_player_stats
     i32 fpen[P];                // floor_penalty (16 bits stored)
     u32 mc[P], cl[P];           // max_combo (8 bits), completed_lines (3 x 8 bits)
@@ -135,7 +139,11 @@ AZ_FN void prime_x(GX<P, D> &g, const KX<D> &K)
 {
     bool over = false;
 #pragma unroll
-    for (u32 p = 0; p < P; p++) { over = over | any_row_full(g.wall[p]); g.ok[p] = ok_board2(g.cp[p], g.wall[p], K.k); }
+    for (u32 p = 0; p < P; p++) {
+        over = over | any_row_full(g.wall[p]);
+        const u32 o = ok_board2((g.cpk >> (8u * p)) & 0xffu, g.wall[p], K.k);
+        g.okv = K.k.l == p ? o : g.okv;
+    }
     g.over = over ? 1u : 0u;
     sources_x(g);
 }
@@ -150,8 +158,9 @@ AZ_FN void gx_load(GX<P, D> &g, const uint8_t *rec, u32 l)
     g.cs0 = l < 31u ? a : 0u;
     g.cs1 = 0u;
     if (Dim<D>::WIDE) g.cs1 = l < Dim<D>::XCELLS ? (u32)rec[208u + l] : 0u;
+    g.cpk = 0;
 #pragma unroll
-    for (u32 p = 0; p < P; p++) g.cp[p] = l < 25u ? (u32)rec[32u + 25u * p + l] : 0u;
+    for (u32 p = 0; p < P; p++) g.cpk |= (l < 25u ? (u32)rec[32u + 25u * p + l] : 0u) << (8u * p);
     const u32 t = l < 19u ? ((const u32 *)(rec + 132))[l] : 0u;          // bytes 132 .. 207
     const u32 fl = hread(t, 0), sa = hread(t, 5), sb = hread(t, 6), b7 = hread(t, 7), b8 = hread(t, 8), b9 = hread(t, 9);
     const u32 fa = hread(t, 10), fb = hread(t, 11), pa = hread(t, 12), pb = hread(t, 13), mc = hread(t, 14);
@@ -163,7 +172,6 @@ AZ_FN void gx_load(GX<P, D> &g, const uint8_t *rec, u32 l)
     const u32 cl[4] = {c0 & 0xffffffu, (c0 >> 24) | ((c1 & 0xffffu) << 8), (c1 >> 16) | ((c2 & 0xffu) << 16), c2 >> 8};
 #pragma unroll
     for (u32 p = 0; p < P; p++) {
-        g.floor_[p] = (fl >> (8u * p)) & 0xffu;
         g.wall[p] = wl[p];
         g.score[p] = (i32)(int16_t)sc[p];
         g.fps[p] = fs[p];
@@ -171,13 +179,13 @@ AZ_FN void gx_load(GX<P, D> &g, const uint8_t *rec, u32 l)
         g.mc[p] = (mc >> (8u * p)) & 0xffu;
         g.cl[p] = cl[p];
     }
+    g.floors = P == 4u ? fl : fl & ((1u << (8u * (P & 3u))) - 1u);
     g.box = (u64)b7 | ((u64)(b8 & 0xffu) << 32);
     g.lid = (u64)(b8 >> 8) | ((u64)(b9 & 0xffffu) << 24);
     g.turn = b9 >> 16;
     g.lidp = 0;
     g.over = 0; g.B0 = g.B1 = 0;
-#pragma unroll
-    for (u32 p = 0; p < P; p++) g.ok[p] = 0;
+    g.okv = 0;
 }
 
 template <u32 P, u32 D>
@@ -187,13 +195,13 @@ AZ_FN void gx_store(const GX<P, D> &g, uint8_t *rec, u32 l)
     rec[l] = (uint8_t)(l == 31u ? flags : g.cs0);
     if (Dim<D>::WIDE) { if (l < Dim<D>::XCELLS) rec[208u + l] = (uint8_t)g.cs1; }
 #pragma unroll
-    for (u32 p = 0; p < P; p++) { if (l < 25u) rec[32u + 25u * p + l] = (uint8_t)g.cp[p]; }
+    for (u32 p = 0; p < P; p++) { if (l < 25u) rec[32u + 25u * p + l] = (uint8_t)(g.cpk >> (8u * p)); }
     const u64 lid = g.lid + lid_fold2(g.lidp, l);
-    u32 fl = 0, mc = 0;
+    const u32 fl = g.floors;
+    u32 mc = 0;
     u32 sc[4] = {0, 0, 0, 0}, fs[4] = {0, 0, 0, 0}, pn[4] = {0, 0, 0, 0}, cl[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
 #pragma unroll
     for (u32 p = 0; p < P; p++) {
-        fl |= (g.floor_[p] & 0xffu) << (8u * p);
         mc |= (g.mc[p] & 0xffu) << (8u * p);
         wl[p] = g.wall[p];
         sc[p] = (u32)g.score[p] & 0xffffu;
@@ -231,7 +239,7 @@ struct MaskX {
 template <u32 P, u32 D>
 AZ_FN void legal_mask_x(const GX<P, D> &g, const KX<D> &K, MaskX<D> &out)
 {
-    const u32 okm = pick<P>(g.ok, mex(g));
+    const u32 okm = hread4(g.okv, mex(g), K.k.h4);
 #pragma unroll
     for (u32 w = 0; w < Dim<D>::NW; w++) {
         const u32 B = (Dim<D>::WIDE && K.sreg[w]) ? g.B1 : g.B0;
@@ -366,10 +374,11 @@ AZ_FN void do_move_x(GX<P, D> &g, u32 s, u32 c, u32 row, bool tracked, const KX<
     const u32 src = from_display ? db + c : 25u + c;
     const u32 dreg = hi ? g.cs1 : g.cs0;
     const u32 cell = 5u * ((row ? row : 1u) - 1u) + c;
-    u32 mine = pick<P>(g.cp, me);
+    const u32 sh = 8u * me;                                            // the mover's byte of cpk / floors
     const u32 n = hread4(dreg, src, h4);                               // :127 / :136
     const u32 moved = hread4(dreg, l - 25u + db, h4);                  // :131 the rest of the display slides into the centre
-    const u32 old = hread4(mine, cell, h4);
+    const u32 old = hread4((g.cpk >> sh) & 0xffu, cell, h4);
+    u32 okm = hread4(g.okv, me, h4);
     const bool token = (!from_display) & (((g.B0 >> 30) & 1u) != 0u);  // :140
     const bool centre = (l >= 25u) & (l < 30u) & (l != 25u + c) & from_display;
     const bool disp = (l >= db) & (l < db + 5u) & from_display;
@@ -378,21 +387,19 @@ AZ_FN void do_move_x(GX<P, D> &g, u32 s, u32 c, u32 row, bool tracked, const KX<
     g.cs0 = gone0 ? 0u : grown;
     if (Dim<D>::WIDE) g.cs1 = (disp & hi) ? 0u : g.cs1;
     g.nfp = token ? g.cur : g.nfp;                                     // :142
-    u32 fl = pick<P>(g.floor_, me) + (token ? 1u : 0u);                // :143 (the cap of :120-123 is applied once, below: it is monotone)
+    u32 fl = ((g.floors >> sh) & 0xffu) + (token ? 1u : 0u);           // :143 (the cap of :120-123 is applied once, below: it is monotone)
     const i32 overflow = row ? (i32)row - (i32)old - (i32)n : -(i32)n; // :147
     const u32 spill = overflow < 0 ? (u32)(-overflow) : 0u;
     const u32 newv = overflow < 0 ? row : old + n;                     // :150 / :152
-    mine = ((l == cell) & (row != 0u)) ? newv : mine;
-    put<P>(g.cp, me, mine);
+    g.cpk = ((l == cell) & (row != 0u)) ? (g.cpk & ~(0xffu << sh)) | (newv << sh) : g.cpk;
     {   // the row now holds colour c only (the move was legal: the row was empty or held c, the wall cell is free)
-        const u32 sh = 5u * ((row ? row : 1u) - 1u);
-        u32 okm = pick<P>(g.ok, me);
-        okm = row ? ((okm & ~(31u << sh)) | (1u << (sh + c))) : okm;
-        put<P>(g.ok, me, okm);
+        const u32 rs = 5u * ((row ? row : 1u) - 1u);
+        okm = row ? ((okm & ~(31u << rs)) | (1u << (rs + c))) : okm;
+        g.okv = l == me ? okm : g.okv;
     }
     fl += spill;                                                       // :154 / :159
     fl = fl < 7u ? fl : 7u;
-    put<P>(g.floor_, me, fl);
+    g.floors = (g.floors & ~(0xffu << sh)) | (fl << sh);
     g.lid += tracked ? (u64)spill << (8u * c) : 0ull;                  // :156-157 / :160-161
 }
 
@@ -408,7 +415,8 @@ AZ_FN void count_score_x(GX<P, D> &g, bool tracked, bool end_bonus, const KX<D> 
     asm volatile("" : "+v"(tmask), "+v"(bmask));
 #pragma unroll
     for (u32 p = 0; p < P; p++) {
-        const u32 F = full_lines2(g.cp[p], k);                                             // :216
+        const u32 cells = (g.cpk >> (8u * p)) & 0xffu;
+        const u32 F = full_lines2(cells, k);                                               // :216
         Score2 s;
         score2(g.wall[p] | (F & k.pbelow), k, s);                                          // :219: placements in ascending (row, colour) order
         const bool on = ((F >> k.l) & 1u) != 0u;
@@ -418,14 +426,16 @@ AZ_FN void count_score_x(GX<P, D> &g, bool tracked, bool end_bonus, const KX<D> 
         g.cl[p] += (u32)__popc(s.rowdone & F) + ((u32)__popc(s.colordone & F) << 8) + ((u32)__popc(s.coldone & F) << 16);   // :270,:278,:286
         g.lidp += lid_tally2(F, k.l) & tmask;                                              // :220-222
         g.wall[p] |= F;
-        g.cp[p] = (g.cp[p] == k.rowp1) ? 0u : g.cp[p];                                     // :218
-        const i32 pen = floor_penalty(g.floor_[p]);
+        const u32 left = (cells == k.rowp1) ? 0u : cells;                                  // :218
+        g.cpk = (g.cpk & ~(0xffu << (8u * p))) | (left << (8u * p));
+        const i32 pen = floor_penalty((g.floors >> (8u * p)) & 0xffu);
         g.fpen[p] += pen;                                                                  // :208
-        g.floor_[p] = 0;                                                                   // :209
         g.score[p] = clamp0(g.score[p] + pen + cnt);                                       // :292-295
         over = over | any_row_full(g.wall[p]);
-        g.ok[p] = ok_board2(g.cp[p], g.wall[p], k);
+        const u32 o = ok_board2(left, g.wall[p], k);
+        g.okv = k.l == p ? o : g.okv;
     }
+    g.floors = 0;                                                                          // :209
     g.over = over ? 1u : 0u;
 }
 
@@ -522,10 +532,9 @@ AZ_FN void game_ctor_x(GX<P, D> &g, const RulesX &rules, Rng2 &r, const KX<D> &K
 {
     g.cs0 = 0; g.cs1 = 0;
 #pragma unroll
-    for (u32 p = 0; p < P; p++) {
-        g.cp[p] = 0; g.wall[p] = 0; g.floor_[p] = 0; g.score[p] = 0; g.fps[p] = 0; g.fpen[p] = 0; g.mc[p] = 0; g.cl[p] = 0;
-        g.ok[p] = 0x1ffffffu;                                         // empty lines, empty walls: every row accepts every colour
-    }
+    for (u32 p = 0; p < P; p++) { g.wall[p] = 0; g.score[p] = 0; g.fps[p] = 0; g.fpen[p] = 0; g.mc[p] = 0; g.cl[p] = 0; }
+    g.cpk = 0; g.floors = 0;
+    g.okv = 0x1ffffffu;                                               // empty lines, empty walls: every row accepts every colour
     g.cur = 0; g.eog = 0; g.turn = 0; g.over = 0; g.B0 = g.B1 = 0;
     // random.choice(list(range(1, P + 1))) (:37) == _randbelow(P): rejection on getrandbits(P.bit_length())
     if (rules.first_player == 0u) g.nfp = 1u + rng2_below(r, P, P == 4u ? 3u : 2u, K.k.l);
@@ -639,13 +648,8 @@ AZ_FN void observe_x(const GX<P, D> &g, u32 persp, float *out, u32 l)
         const u32 pp = po == 0u ? persp : (po - 1u < persp ? po - 1u : po);
         const u32 wp = wo == 0u ? persp : (wo - 1u < persp ? wo - 1u : wo);
         const u32 fp = fo == 0u ? persp : (fo - 1u < persp ? fo - 1u : fo);
-        u32 v_pat = 0;
-#pragma unroll
-        for (u32 p = 0; p < P; p++) {
-            const u32 gp = hread(g.cp[p], pc);
-            v_pat = pp == p ? gp : v_pat;
-        }
-        const u32 v_wall = (pick<P>(g.wall, wp) >> wc) & 1u, v_floor = pick<P>(g.floor_, fp), v_score = (u32)pick<P>(g.score, fp);
+        const u32 v_pat = (hread(g.cpk, pc) >> (8u * pp)) & 0xffu;
+        const u32 v_wall = (pick<P>(g.wall, wp) >> wc) & 1u, v_floor = (g.floors >> (8u * fp)) & 0xffu, v_score = (u32)pick<P>(g.score, fp);
         u32 v = j < A ? v_disp : j < Bc ? v_cen : j < Cp ? v_pat : j < Dw ? v_wall : j < Ef ? v_floor : j < Fs ? v_score : pnfp;
         if (j < N) out[j] = (float)(i32)v;
     }

@@ -1,0 +1,32 @@
+"""Housekeeping that protects the evidence: the figures the docs quote live in ONE generated table, and every tracked bit-identity log
+of this round cites the sha256 of the csrc/ it ran on -- the same hash DESIGN.md cites for it."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_numbers_md_is_what_the_generator_prints():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "numbers_table.py")], capture_output=True, text=True, check=True).stdout
+    assert open(os.path.join(ROOT, "NUMBERS.md")).read() == out, "regenerate: python tools/numbers_table.py > NUMBERS.md"
+
+
+def test_tracked_soak_logs_cite_the_csrc_they_ran_on_and_design_cites_the_same():
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for name in ("round4_selfplay_soak_raw.txt", "round4_rollout_soak_raw.txt"):
+        text = open(os.path.join(ROOT, "profiles", name)).read()
+        m = re.search(r"csrc sha256 ([0-9a-f]{16})", text)
+        assert m, name
+        assert ("PASS" in text) or ("IDENTICAL" in text), name
+        assert "MISMATCH" not in text and "FAIL" not in text, name
+        assert re.search(re.escape(name) + r"[^\n]*" + m.group(1), design) or re.search(m.group(1) + r"[^\n]*" + re.escape(name), design), \
+            "DESIGN.md must cite %s together with the csrc hash %s it ran on" % (name, m.group(1))
+
+
+def test_provenance_tool_hashes_the_product_sources():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import provenance
+    h = provenance.csrc_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", h)

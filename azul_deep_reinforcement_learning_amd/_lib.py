@@ -29,7 +29,7 @@ _vp, _i, _u64, _u32 = C.c_void_p, C.c_int, C.c_uint64, C.c_uint32
 # azul_game_call (include/azul_hip.h): ops, result bits and the call block
 (CALL_QUERY, CALL_INIT, CALL_NEW_ROUND, CALL_MOVE, CALL_NEXT_PLAYER, CALL_COUNT_SCORE, CALL_STEP, CALL_RUNNER_INIT, CALL_RUNNER_RESET,
  CALL_RUNNER_STEP, CALL_SAMPLE_MASK) = range(11)
-WANT_RECORD, WANT_MASK, WANT_OBS, WANT_FLAGS, WANT_POTENTIAL, WANT_STATS = 1, 2, 4, 8, 16, 32
+WANT_RECORD, WANT_MASK, WANT_OBS, WANT_FLAGS, WANT_POTENTIAL, WANT_STATS, WANT_NEXT_ACTION, WANT_POS_IN = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class AzulCall(C.Structure):
@@ -37,7 +37,7 @@ class AzulCall(C.Structure):
                 ("record_in", C.c_void_p), ("mt_in", C.c_void_p), ("pos_in", C.c_uint32), ("mask_in", C.c_void_p),
                 ("record_out", C.c_void_p), ("mt_out", C.c_void_p),
                 ("pos_out", C.c_uint32), ("rng_regenerated", C.c_int32), ("status", C.c_int32), ("reward", C.c_int32), ("done", C.c_int32),
-                ("action", C.c_int32), ("flags", C.c_int32), ("potential", C.c_int32),
+                ("action", C.c_int32), ("flags", C.c_int32), ("potential", C.c_int32), ("next_action", C.c_int32), ("reserved0", C.c_int32),
                 ("mask", C.c_uint8 * (MAX_ACTIONS + 4)), ("obs", C.c_float * MAX_OBS), ("stats", C.c_double * 10)]
 
 

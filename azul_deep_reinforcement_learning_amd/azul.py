@@ -144,10 +144,49 @@ class Azul:
                ("score", -32768, 32767), ("box_tiles", 0, 255), ("lid_tiles", 0, 255), ("first_player_stats", 0, 65535),
                ("floor_penalty", -32768, 32767), ("max_combo", 0, 255), ("completed_lines", 0, 255))
 
+    _ARRAYS = ("game_board_displays", "game_board_center", "pattern_lines", "walls", "floors", "score", "first_player_stats",
+               "floor_penalty", "max_combo", "completed_lines", "box_tiles", "lid_tiles")
+
+    def _scalars(self, runner):
+        return (self.current_player, self.next_first_player, self.end_of_game, self.turn_counter, self.players,
+                (runner.player_score, runner.move_counter) if runner is not None else None)
+
+    def _remember(self, rec, runner):
+        """The record the attributes were just unpacked from, with what it takes to tell later that nobody touched them: the array
+        objects themselves and their bytes (callers write them in place), the scalars."""
+        d = self.__dict__
+        self._memo = [rec, [(n, d[n], d[n].tobytes()) for n in self._ARRAYS if n in d], self._scalars(runner), runner is not None, None]
+
+    def _remembered(self, runner):
+        m = getattr(self, "_memo", None)
+        if m is None:
+            return None
+        d = self.__dict__
+        for (n, a, raw) in m[1]:
+            if d.get(n) is not a or a.tobytes() != raw:
+                return None
+        sc = self._scalars(runner)
+        if sc[:5] != m[2][:5]:
+            return None
+        if sc[5] == m[2][5]:
+            return m[0]
+        if not m[3] or runner is not None:
+            return None                                   # (GameRunner's counters were edited)
+        if m[4] is None:                                  # an Azul-level call on a GameRunner's game: the counters pack as zero
+            rec = m[0].copy()
+            rec["player_score"] = 0
+            rec["move_counter"] = 0
+            m[4] = rec
+        return m[4]
+
     def _to_record(self, runner=None):
         """The attributes packed into the game record (128 bytes; 256 for three / four players).  Callers write the attributes
         freely (numpy arrays, Python ints), so every value is range-checked against what its record field holds: struct.pack does
-        that while it packs (one C call instead of a dozen numpy reductions and field assignments)."""
+        that while it packs (one C call instead of a dozen numpy reductions and field assignments).  Attributes that are still
+        the arrays the last call unpacked, byte for byte, are not packed again."""
+        rec = self._remembered(runner)
+        if rec is not None:
+            return rec
         P = self.players
         wide = P != 2 or self._ext != 0
         pad = 4 - P if wide else 0
@@ -199,8 +238,38 @@ class Azul:
             raise ValueError("player")
         return v
 
+    _TAIL2 = struct.Struct("<2I2h10xH2H2h8xhH")      # the two-player record from byte 84: walls, score, turn counter, stats, GameRunner's counters
+
+    def _from_record2(self, rec, runner):
+        """_from_record for the 128-byte record: one widening of the bytes, the attributes are slices of it (same dtypes and shapes)."""
+        raw = rec.tobytes()
+        b = np.frombuffer(raw, dtype=np.uint8).astype(int)
+        f = b[106:124].astype(float)
+        w0, w1, s0, s1, tc, f0, f1, p0, p1, ps, mc = self._TAIL2.unpack_from(raw, 84)
+        self.game_board_displays = b[0:25].reshape(5, 5)
+        self.game_board_center = b[25:31]
+        self.current_player, self.next_first_player, self.end_of_game = unpack_flags(raw[31])
+        self.pattern_lines = b[32:82].reshape(2, 5, 5)
+        self.floors = b[82:84]
+        self.walls = bits_to_walls(rec["walls"])
+        self.score = np.array((s0, s1))
+        if self._tracked:
+            self.box_tiles = b[96:101]
+            self.lid_tiles = b[101:106]
+        self.turn_counter = tc
+        self.first_player_stats = np.array((f0, f1), dtype=float)
+        self.floor_penalty = np.array((p0, p1), dtype=float)
+        self.max_combo = f[10:12]
+        self.completed_lines = f[12:18].reshape(2, 3)
+        if runner is not None:
+            runner.player_score = ps
+            runner.move_counter = mc
+        self._remember(rec, runner)
+
     def _from_record(self, rec, runner=None):
         P = self.players
+        if rec.dtype.itemsize == 128:
+            return self._from_record2(rec, runner)
         self.game_board_displays = all_displays(rec).astype(int)
         self.game_board_center = rec["center"].astype(int)
         self.current_player, self.next_first_player, self.end_of_game = unpack_flags(rec["flags"])
@@ -219,6 +288,7 @@ class Azul:
         if runner is not None:
             runner.player_score = int(rec["player_score"])
             runner.move_counter = int(rec["move_counter"])
+        self._remember(rec, runner)
 
     def _run(self, op, *args, draws=False, mutates=True, runner=None):
         out, rec = self._backend().call(op, args, self._to_record(runner), draws, mutates)

@@ -16,6 +16,7 @@ from . import _lib as L
 from .records import RECORD_DTYPE, RECORD_NP_DTYPE, STAT_KEYS
 
 _RULE_POOL = {"Random": L.POOL_RANDOM, "Lid": L.POOL_LID}
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)       # current stream of a device as an integer handle
 
 
 class IllegalRule(Exception):
@@ -134,6 +135,8 @@ class BatchedAzul:
 
     # -- plumbing --------------------------------------------------------------------------------
     def _stream(self):
+        if _RAW_STREAM is not None and self.device.index is not None:
+            return C.c_void_p(_RAW_STREAM(self.device.index))      # the same handle, without building a torch.cuda.Stream per call
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _new(self, shape, dtype):

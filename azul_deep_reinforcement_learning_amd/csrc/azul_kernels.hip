@@ -82,6 +82,9 @@ struct OpArgs {
     uint8_t *rng_dirty;      // [N]   out: the op regenerated the game's 624 MT19937 words (Rng::dirty; 0 for ops that do not draw)
     uint8_t *rec_out;        // [N][record bytes] out: the game's record after the op
     u32 *pos_out;            // [N]   out: index of the game's MT19937 stream after the op
+    i32 *next_action;        // [N]   out: RandomAgent's choice on the state after the op, drawn at the stream's index after the op WITHOUT moving it
+                             //       (-1: nothing legal, -2: not available -- the op failed / did not draw, or the draw would cross a regeneration)
+    u32 pos_set;             // 0, or 1 + the stream index to install before the op (single-game calls: the host's index is the authority)
     u32 first;               // the launch covers games first .. first + grid - 1; row i of the arrays above belongs to game first + i
 };
 
@@ -192,11 +195,12 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
     game_load(g, rec);
     game_prime<LID>(g, k);
     u32 st = ST_OK, rdirty = 0;
+    i32 spec = -2;
     if (act && a.op != OP_QUERY) {
         Rng r;
         const bool use_rng = op_needs_rng(a.op);
         // the 2.5 KB MT19937 state is staged into LDS lazily, by the first draw (most single steps never draw)
-        rng_attach(r, b.mt + (size_t)gi * 624u, mt_lds, use_rng ? b.mtpos[gi] : 0u);
+        rng_attach(r, b.mt + (size_t)gi * 624u, mt_lds, use_rng ? (a.pos_set ? a.pos_set - 1u : b.mtpos[gi]) : 0u);
         r.margin = b.draw_margin;
         bool dirty_state = true;
         switch (a.op) {
@@ -281,9 +285,20 @@ __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
             break;
         }
         if (dirty_state) game_store(g, rec);
+        if (a.next_action && use_rng && st == ST_OK && r.pos + 2u <= 624u) {
+            // the question a GameRunner loop asks next (nn_runner.py:22-30 with RandomAgent: get_valid_moves -> get_a_output): answered
+            // here from the two words the stream would hand out next, index restored -- the caller advances it when it plays the answer
+            const u32 keep = r.pos;
+            Mask m;
+            legal_mask(g, k, m);
+            u32 code;
+            spec = random_agent(m, r, tab, k, code);
+            r.pos = keep;
+        }
         if (use_rng) rng_close(r, b.mtpos + gi);
         rdirty = r.dirty & 1u;
     }
+    if (a.next_action) AZ_LANE0(a.next_action[oi] = spec);
     if (a.rng_dirty) AZ_LANE0(a.rng_dirty[oi] = (uint8_t)rdirty);
     if (a.status && act) AZ_LANE0(a.status[oi] = (uint8_t)st);
     if (a.rec_out) game_store(g, a.rec_out + (size_t)oi * AZUL_RECORD_BYTES);
@@ -1298,7 +1313,7 @@ int azul_batch_score_preview(azul_batch_t *b, int32_t *potential_dev, void *stre
 struct CallScratch {             // one call's arguments and results in PINNED, device-visible host memory: the rule kernel reads its action /
     i32 action_in;               // mask straight from it and writes every result straight into it (zero-copy over PCIe: a few hundred bytes),
     u32 pos;                     // so a call is [record / stream uploads when stale] -> ONE launch -> ONE synchronisation
-    i32 reward, action_out, potential;
+    i32 reward, action_out, potential, next_action;
     uint8_t status, done, flags, player;
     uint8_t rng_dirty, pad_[3];  // the kernel regenerated the 624 words (written by every call: 0 for ops that do not draw)
     uint8_t mask_in[AZUL_MAX_ACTIONS + 4];
@@ -1321,6 +1336,8 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     if ((c->want & AZUL_WANT_RECORD) && !c->record_out) return fail(AZUL_ERR_INVALID, "azul_game_call: AZUL_WANT_RECORD needs record_out");
     if (c->mt_in && c->pos_in > 624u) return fail(AZUL_ERR_INVALID, "azul_game_call: index outside 0..624");
     if ((c->want & AZUL_WANT_OBS) && !persp_ok(b, c->arg)) return fail(AZUL_ERR_INVALID, "azul_game_call: AZUL_WANT_OBS needs a perspective in arg");
+    if ((c->want & AZUL_WANT_NEXT_ACTION) && b->x) return fail(AZUL_ERR_INVALID, "azul_game_call: AZUL_WANT_NEXT_ACTION is for two-player reference batches");
+    if ((c->want & AZUL_WANT_POS_IN) && c->pos_in > 624u) return fail(AZUL_ERR_INVALID, "azul_game_call: index outside 0..624");
     const size_t NA = (size_t)azul_batch_num_actions(b), NOBS = (size_t)azul_batch_obs_size(b);
     if (c->record_in) if (int rc = record_in_domain(b, (const uint8_t *)c->record_in)) return rc;
     const hipStream_t st = (hipStream_t)stream;
@@ -1360,6 +1377,8 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     if (c->want & AZUL_WANT_POTENTIAL) a.potential = &H->potential;
     if (c->want & AZUL_WANT_STATS) a.stats = H->stats;
     if (c->want & AZUL_WANT_RECORD) a.rec_out = H->record;
+    if (c->want & AZUL_WANT_NEXT_ACTION) a.next_action = &H->next_action;
+    if ((c->want & AZUL_WANT_POS_IN) && !c->mt_in) a.pos_set = 1u + c->pos_in;
     a.rng_dirty = &H->rng_dirty;
     a.pos_out = &H->pos;
     H->status = AZUL_OK;
@@ -1372,6 +1391,7 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     c->action = c->op == AZUL_CALL_SAMPLE_MASK ? H->action_out : 0;
     c->flags = (c->want & AZUL_WANT_FLAGS) ? H->flags : 0;
     c->potential = (c->want & AZUL_WANT_POTENTIAL) ? H->potential : 0;
+    c->next_action = (c->want & AZUL_WANT_NEXT_ACTION) ? H->next_action : -2;
     c->pos_out = H->pos;
     if (c->want & AZUL_WANT_MASK) memcpy(c->mask, H->mask, NA);
     if (c->want & AZUL_WANT_OBS) memcpy(c->obs, H->obs, NOBS * sizeof(float));

@@ -5,6 +5,15 @@ A facade call = ONE ``azul_game_call``: the object's numpy attributes packed int
 synchronisation.  The record is only sent when it differs from what the device already holds (the facade's attributes are
 caller-writable numpy arrays, so the packed bytes are compared, not a dirty flag).
 
+A call that changes a two-player game also answers the two questions the reference's loops ask next (nn_runner.py:22-30,
+game_runner.py:37-42): the legal mask of the state it leaves (AZUL_WANT_MASK) and what ``RandomAgent.get_a_output`` draws on that
+mask from the stream as the call leaves it (AZUL_WANT_NEXT_ACTION: computed, the stream's index NOT moved).  ``get_valid_moves()``
+and ``RandomAgent.get_a_output(mask)`` are then served from these answers -- no submission -- when, and only when, their inputs are
+the ones the answers were computed from: the same record bytes; the same mask bytes and a global ``random`` state equal to the one
+this backend installed.  Playing the remembered draw advances the global stream by the one ``random()`` it stands for, and the next
+drawing call tells the device (AZUL_WANT_POS_IN).  Anything else -- a host draw in between, a re-seed, an edited mask or board --
+takes the ordinary path.  A GameRunner loop with RandomAgent is one submission per agent step.
+
 Randomness stays the reference's: the process-global CPython ``random`` stream.  A call that draws runs on the game's device
 stream; afterwards the advanced state is installed with ``random.setstate`` -- so ``random.seed(1); Azul().new_round()`` gives
 the reference's board exactly (reference tests/test_azul.py:36-39) while every draw is computed on the GPU.  The 624 words
@@ -54,7 +63,10 @@ _OPS = {
     # (nn_runner.py:22-30, game_runner.py:73-75), which is then answered without a submission while the record is unchanged
     "op_runner_step": (L.CALL_RUNNER_STEP, L.WANT_MASK),
 }
-_WANT_BYTES = ((L.WANT_MASK, 180), (L.WANT_OBS, 544), (L.WANT_STATS, 80))          # (the reference's sizes; traffic accounting only)
+# two-player reference games: the calls after which a loop asks "which moves are legal" and "what does RandomAgent play" next
+ASK_AHEAD = True          # (False: every question is its own submission -- the A/B of tests/test_facade_ask_ahead.py and bench.py)
+_ASK_AHEAD = {"op_new_round", "op_step", "op_runner_reset", "op_runner_step"}
+_WANT_BYTES = ((L.WANT_MASK, 180), (L.WANT_OBS, 544), (L.WANT_STATS, 80), (L.WANT_NEXT_ACTION, 4))          # (the reference's sizes; traffic accounting only)
 
 
 class HipBackend:
@@ -70,11 +82,15 @@ class HipBackend:
         rules = {"first_player": "Random" if first_player == L.FIRST_RANDOM else int(first_player),
                  "tile_pool": "Lid" if tile_pool == L.POOL_LID else "Random"}
         self.env = BatchedAzul(1, rules=rules, players=players, ext_rules=ext)
-        self.num_actions, self.obs_size = self.env.num_actions, self.env.obs_size
+        self._setup(self.env.num_actions, self.env.obs_size, self.env.record_dtype, players == 2 and not ext)
+
+    def _setup(self, num_actions, obs_size, record_dtype, reference_game):
+        self.num_actions, self.obs_size = num_actions, obs_size
+        self.ask_ahead = bool(reference_game)          # AZUL_WANT_NEXT_ACTION: two-player reference batches
         self.c = L.AzulCall()
         self.c.game = 0
-        self._rec_in = np.zeros(1, dtype=self.env.record_dtype)
-        self._rec_out = np.zeros(1, dtype=self.env.record_dtype)
+        self._rec_in = np.zeros(1, dtype=record_dtype)
+        self._rec_out = np.zeros(1, dtype=record_dtype)
         self._mt_in = np.zeros(624, dtype=np.uint32)
         self._mt_out = np.zeros(624, dtype=np.uint32)
         self._mask_in = np.zeros(self.num_actions, dtype=np.uint8)
@@ -82,6 +98,11 @@ class HipBackend:
         self.c.mt_out = self._mt_out.ctypes.data
         self._resident = None                # bytes of the record the device holds
         self._mask_for, self._mask = None, None   # the legal mask a call brought back, and the record bytes it belongs to
+        self._ahead = None                   # (mask bytes, stream state installed by that call, its index, RandomAgent's draw on them)
+
+    def _game_call(self):
+        """The one place that touches the device: self.c through azul_game_call on this backend's 1-game batch."""
+        L.check(L.lib.azul_game_call(self.env._h, C.byref(self.c), self.env._stream()))
 
     def _submit(self, draws):
         """Run self.c; for a drawing call: hand the global stream over (only if the device copy is stale) and install the advanced
@@ -91,14 +112,16 @@ class HipBackend:
         if draws:
             st = random.getstate()
             if _RNG["be"] is self and _RNG["state"] == st:
-                c.mt_in, c.pos_in = None, _RNG["pos"]              # the device stream IS the global stream
+                c.mt_in, c.pos_in = None, _RNG["pos"]              # the device's words ARE the global stream's; the host's index is the authority
+                c.want |= L.WANT_POS_IN                            # (it moves without the device when a remembered draw is played)
             else:
                 self._mt_in[:] = st[1][:624]
                 c.mt_in, c.pos_in = self._mt_in.ctypes.data, st[1][624]
                 h2d += 2500
         else:
             c.mt_in, c.pos_in = None, 0
-        L.check(L.lib.azul_game_call(self.env._h, C.byref(c), self.env._stream()))
+        self._ahead = None
+        self._game_call()
         if draws:
             words = tuple(self._mt_out.tolist()) if c.rng_regenerated else st[1][:624]
             new = (3, words + (int(c.pos_out),), st[2])
@@ -125,6 +148,9 @@ class HipBackend:
             h2d += len(rb)
         else:
             c.record_in = None
+        ahead = ASK_AHEAD and self.ask_ahead and op in _ASK_AHEAD
+        if ahead:
+            want |= L.WANT_MASK | L.WANT_NEXT_ACTION
         c.want = want | (L.WANT_RECORD if mutates else 0)
         try:
             h2d += self._submit(draws)
@@ -140,7 +166,10 @@ class HipBackend:
         elif c.record_in is not None:
             self._resident = rb
         if want & L.WANT_MASK and new is not None:
-            self._mask_for, self._mask = self._resident, np.frombuffer(bytes(c.mask), dtype=np.uint8)[:self.num_actions].astype(bool)
+            m8 = np.frombuffer(bytes(c.mask), dtype=np.uint8)[:self.num_actions]
+            self._mask_for, self._mask = self._resident, m8.astype(bool)
+            if ahead and c.next_action >= 0 and _RNG["be"] is self:
+                self._ahead = (m8.tobytes(), _RNG["state"], _RNG["pos"], int(c.next_action))
         if op == "op_runner_step":
             return (int(c.reward), bool(c.done), int(c.status)), new
         if op == "op_mask":
@@ -158,10 +187,19 @@ class HipBackend:
     def sample(self, mask):
         """RandomAgent.get_a_output on a caller's mask (game_runner.py:87-97): one random.choices draw on this backend's stream."""
         c = self.c
-        c.op, c.arg, c.want, c.record_in = L.CALL_SAMPLE_MASK, 0, 0, None
         m = np.asarray(mask, dtype=np.uint8).reshape(-1)
         if m.size != self.num_actions:
             raise ValueError("this backend samples masks of %d actions" % self.num_actions)
+        ah, self._ahead = self._ahead, None
+        if ah is not None and _RNG["be"] is self and _RNG["state"] is ah[1]:
+            st = random.getstate()
+            if st == ah[1] and m.tobytes() == ah[0]:
+                # the draw the last call already made on exactly this mask and this stream: play it -- the stream moves on by one random()
+                new = (3, st[1][:624] + (ah[2] + 2,), st[2])
+                random.setstate(new)
+                _RNG["state"], _RNG["pos"] = new, ah[2] + 2
+                return ah[3]
+        c.op, c.arg, c.want, c.record_in = L.CALL_SAMPLE_MASK, 0, 0, None
         self._mask_in[:] = m
         c.mask_in = self._mask_in.ctypes.data
         h2d = 184 + self._submit(True)

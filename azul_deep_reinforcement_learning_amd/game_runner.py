@@ -60,7 +60,8 @@ class GameRunner:
         """One move of `self.opponent` for the player to move (game_runner.py:37-42), policy evaluated on the host."""
         seat = self.game.current_player - 1
         legal = torch.from_numpy(self.get_valid_moves()[None, :])
-        choice = self.opponent.get_a_output(self.get_state(perspective=seat), legal)
+        # (RandomAgent never looks at the state -- game_runner.py:93-97 -- so the observation is not computed for it)
+        choice = self.opponent.get_a_output(None if self._device_opponent() else self.get_state(perspective=seat), legal)
         self.game.step(*nn_deserialize(choice))
         self.move_counter += 1
 

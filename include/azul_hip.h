@@ -226,13 +226,19 @@ enum { AZUL_CALL_QUERY = 0, AZUL_CALL_INIT, AZUL_CALL_NEW_ROUND, AZUL_CALL_MOVE,
 #define AZUL_WANT_FLAGS      8u    /* AZUL_FLAG_* -> flags */
 #define AZUL_WANT_POTENTIAL 16u    /* game_runner.py:48-50 -> potential (two players) */
 #define AZUL_WANT_STATS     32u    /* get_statistics -> stats[10] */
+#define AZUL_WANT_NEXT_ACTION 64u  /* two-player reference batches, ops that draw: what RandomAgent.get_a_output (game_runner.py:87-97) answers on the
+                                      state after the call -- the question a GameRunner loop asks next (nn_runner.py:22-30) -- computed from the two
+                                      words the stream hands out next, WITHOUT moving its index -> next_action.  A caller that plays the answer (same
+                                      mask, stream untouched in between) advances the index by one random(), two words, itself: AZUL_WANT_POS_IN on
+                                      its next call */
+#define AZUL_WANT_POS_IN    128u   /* ops that draw, mt_in NULL: install pos_in as the stream's index before the op (the words stay) */
 typedef struct azul_call {
     /* in */
     int32_t op, game, arg;
     uint32_t want;
     const void *record_in;          /* NULL or the game's record (azul_batch_record_bytes bytes; validated like azul_batch_set_state) */
     const uint32_t *mt_in;          /* NULL or 624 words: the stream to draw from (random.getstate()[1][:624]) */
-    uint32_t pos_in;                /* with mt_in: the stream's index to install, random.getstate()[1][624]; ignored without mt_in */
+    uint32_t pos_in;                /* with mt_in or AZUL_WANT_POS_IN: the stream's index to install, random.getstate()[1][624]; ignored otherwise */
     const uint8_t *mask_in;         /* AZUL_CALL_SAMPLE_MASK: uint8[azul_batch_num_actions] */
     void *record_out;               /* AZUL_WANT_RECORD */
     uint32_t *mt_out;               /* NULL or room for 624 words, written only when rng_regenerated */
@@ -243,6 +249,9 @@ typedef struct azul_call {
     int32_t reward, done;           /* AZUL_CALL_RUNNER_STEP */
     int32_t action;                 /* AZUL_CALL_SAMPLE_MASK (-1: nothing legal) */
     int32_t flags, potential;
+    int32_t next_action;            /* AZUL_WANT_NEXT_ACTION: the action; -1 nothing legal; -2 not available (the op failed or did not draw, or the draw
+                                       would cross the regeneration of the 624 words: ask AZUL_CALL_SAMPLE_MASK) */
+    int32_t reserved0;
     uint8_t mask[AZUL_MAX_ACTIONS + 4];   /* azul_batch_num_actions bytes are written */
     float obs[AZUL_MAX_OBS];              /* azul_batch_obs_size floats are written */
     double stats[AZUL_NUM_STATS];

@@ -32,7 +32,7 @@ def main():
         if not hip:
             fh.write("from tests.hostcheck import hostcheck as hc\n"
                      "import azul_deep_reinforcement_learning_amd.facade_backend as fb\n"
-                     "fb._FACTORY = hc.EmuBackend\n")
+                     "fb._FACTORY = hc.call_backend_class()\n")
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     cmd = [sys.executable, "-m", "pytest", "-p", "no:cacheprovider", "-q", "--rootdir", tmp, "-c", os.devnull,
            "--confcutdir", tmp,

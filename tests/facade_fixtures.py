@@ -11,7 +11,7 @@ def facade(request):
     saved = fb._FACTORY
     if request.param == "emu":
         from tests.hostcheck import hostcheck as hc
-        fb._FACTORY = hc.EmuBackend
+        fb._FACTORY = hc.call_backend_class()      # the product's host logic on the emulated device core
     else:
         fb._FACTORY = fb.HipBackend
     import azul_deep_reinforcement_learning_amd as pkg

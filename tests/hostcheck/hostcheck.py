@@ -113,33 +113,10 @@ class HostStream:
         return {"rec": rec, "mt": mt, "pos": int(pos[0]), "episodes": int(ep[0]), "stuck": int(stuck[0]), "stat_sum": ss}
 
 
-class StepwiseBackend:
-    """TEST-ONLY: a facade backend that exposes the steps of a facade call separately -- put / push_rng / op_* / pull_rng / get -- for
-    the host emulation of the device core below.  `call` strings them together in the order the product's fused entry
-    (azul_game_call behind facade_backend.HipBackend) performs them."""
-
-    def call(self, op, args=(), rec=None, draws=False, mutates=True):
-        self.put(rec)
-        if draws:
-            self.push_rng()
-        out = getattr(self, op)(*args)
-        if draws:
-            self.pull_rng()
-        return out, (self.get() if mutates else None)
-
-    def sample(self, mask):
-        self.push_rng()
-        a = self.op_sample_mask(mask)
-        if a >= 0:
-            self.pull_rng()
-        return a
-
-
-
-class EmuBackend(StepwiseBackend):
-    """TEST-ONLY stand-in for azul_deep_reinforcement_learning_amd.facade_backend.HipBackend: the same device
-    core, compiled for the host with the 64-lane emulation.  Lets the facade's logic (and, in the build
-    container, the reference's own test files) run without a GPU.  Never selected by the product."""
+class EmuBackend:
+    """TEST-ONLY stand-in for the DEVICE side of a facade call: the same device core, compiled for the host with the 64-lane emulation,
+    one method per rule-kernel op on a record / MT19937 state it holds like the 1-game batch does.  EmuCallBackend below puts the
+    product's own host logic (facade_backend.HipBackend) on top of it.  Never selected by the product."""
 
     def __new__(cls, first_player, tile_pool, players=2, ext=0):
         return super().__new__(EmuBackendX if (int(players) != 2 or int(ext)) and cls is EmuBackend else cls)
@@ -283,3 +260,94 @@ class EmuBackendX(EmuBackend):
         raise RuntimeError("GameRunner.step / reset and the what-if potential are two-player (game_runner.py:43-55, 76-85)")
 
     op_potential = op_runner_init = op_runner_reset = op_runner_step = _two_players_only
+
+
+def _call_backend_class():
+    """facade_backend.HipBackend with its ONE device-touching method (_game_call: azul_game_call on a 1-game batch) replaced by an
+    interpreter of the same call block on the emulated device core above -- every other line (what is sent, what is remembered, when
+    the global random stream moves) is the product's, so the CPU suite and the sanitizer passes run the facade's real host logic."""
+    import ctypes as C
+    import azul_deep_reinforcement_learning_amd.facade_backend as fb
+    from azul_deep_reinforcement_learning_amd import _lib as L
+    from azul_deep_reinforcement_learning_amd.records import RECORD_DTYPE, RECORD_NP_DTYPE
+
+    DRAWING = (L.CALL_INIT, L.CALL_NEW_ROUND, L.CALL_STEP, L.CALL_RUNNER_INIT, L.CALL_RUNNER_RESET, L.CALL_RUNNER_STEP, L.CALL_SAMPLE_MASK)
+
+    class EmuCallBackend(fb.HipBackend):
+        def __init__(self, first_player, tile_pool, players=2, ext=0):
+            self.dev = EmuBackend(first_player, tile_pool, players, ext)
+            self._setup(self.dev.num_actions, self.dev.obs_size, RECORD_DTYPE if self.dev.rec.size == 128 else RECORD_NP_DTYPE,
+                        int(players) == 2 and not int(ext))
+            self.calls = 0
+
+        def _game_call(self):          # (include/azul_hip.h: azul_game_call, statement by statement)
+            c, e = self.c, self.dev
+            self.calls += 1
+            NA, RB = self.num_actions, e.rec.size
+            draws = c.op in DRAWING
+            if c.record_in:
+                e.rec[:] = np.frombuffer(C.string_at(c.record_in, RB), np.uint8)
+            if c.mt_in:
+                e.mt[:] = np.frombuffer(C.string_at(c.mt_in, 2496), np.uint32)
+                e.pos[0] = c.pos_in
+            elif (c.want & L.WANT_POS_IN) and draws:
+                e.pos[0] = c.pos_in
+            mt0 = e.mt.copy()
+            st, c.reward, c.done, c.action = 0, 0, 0, 0
+            if c.op == L.CALL_INIT:
+                e.op_init()
+            elif c.op == L.CALL_NEW_ROUND:
+                st = e.op_new_round()
+            elif c.op == L.CALL_MOVE:
+                e.op_move(c.arg)
+            elif c.op == L.CALL_NEXT_PLAYER:
+                e.op_next_player()
+            elif c.op == L.CALL_COUNT_SCORE:
+                e.op_count_score()
+            elif c.op == L.CALL_STEP:
+                st = e.op_step(c.arg)
+            elif c.op == L.CALL_RUNNER_INIT:
+                st = e.op_runner_init()
+            elif c.op == L.CALL_RUNNER_RESET:
+                st = e.op_runner_reset()
+            elif c.op == L.CALL_RUNNER_STEP:
+                c.reward, done, st = e.op_runner_step(c.arg)
+                c.done = int(done)
+            elif c.op == L.CALL_SAMPLE_MASK:
+                c.action = e.op_sample_mask(np.frombuffer(C.string_at(c.mask_in, NA), np.uint8))
+            c.status = int(st or 0)
+            base = C.addressof(c)
+            if c.want & L.WANT_MASK:
+                m = np.ascontiguousarray(e.op_mask(), dtype=np.uint8)
+                C.memmove(base + L.AzulCall.mask.offset, m.ctypes.data, NA)
+            if c.want & L.WANT_OBS:
+                o = np.ascontiguousarray(e.op_observe(c.arg), dtype=np.float32)
+                C.memmove(base + L.AzulCall.obs.offset, o.ctypes.data, 4 * self.obs_size)
+            c.flags = e.op_flags() if c.want & L.WANT_FLAGS else 0
+            c.potential = e.op_potential() if c.want & L.WANT_POTENTIAL else 0
+            if c.want & L.WANT_STATS:
+                sv = np.ascontiguousarray(e.op_statistics(), dtype=np.float64)
+                C.memmove(base + L.AzulCall.stats.offset, sv.ctypes.data, 80)
+            if c.want & L.WANT_RECORD:
+                C.memmove(c.record_out, e.rec.ctypes.data, RB)
+            c.next_action = -2
+            if (c.want & L.WANT_NEXT_ACTION) and draws and c.status == 0 and int(e.pos[0]) + 2 <= 624:
+                keep = int(e.pos[0])
+                c.next_action = e.op_sample_mask(np.ascontiguousarray(e.op_mask(), dtype=np.uint8))
+                e.pos[0] = keep
+            c.pos_out = int(e.pos[0])
+            c.rng_regenerated = int(bool((e.mt != mt0).any()))
+            if c.rng_regenerated and c.mt_out:
+                C.memmove(c.mt_out, e.mt.ctypes.data, 2496)
+
+    return EmuCallBackend
+
+
+_ECB = None
+
+
+def call_backend_class():
+    global _ECB
+    if _ECB is None:
+        _ECB = _call_backend_class()
+    return _ECB

@@ -124,3 +124,25 @@ def test_shipped_library_is_not_a_timing_experiment_build():
     for sw in ("AZ2_EXPERIMENT_NO_LDS", "AZ2_X_NO_SCALAR_STORES", "AZ2_X_NO_MASK_STORES", "AZ2_X_NO_STATS", "PR2_EXPERIMENT_NO_WEIGHT_LOADS",
                "PR2_X_NO_MASK_STORES"):
         assert "defined(%s)" % sw in src.split("#error")[0], sw          # every wrong-result switch is behind the guard
+
+
+def test_call_block_layout_is_the_headers(tmp_path):
+    """azul_call_t as the Python mirror (_lib.AzulCall) declares it == as a C compiler lays out include/azul_hip.h: every field's
+    offset and the size, so a facade call never reads a result from the wrong bytes."""
+    import subprocess
+    from azul_deep_reinforcement_learning_amd import _lib as L
+    names = [f[0] for f in L.AzulCall._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "azul_hip.h"\nint main(void) {\n' +
+                   "".join('  printf("%s %%zu\\n", offsetof(azul_call_t, %s));\n' % (n, n) for n in names) +
+                   '  printf("sizeof %zu\\n", sizeof(azul_call_t));\n  return 0;\n}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n in names:
+        assert int(got[n]) == getattr(L.AzulCall, n).offset, n
+    assert int(got["sizeof"]) == ctypes.sizeof(L.AzulCall)
+    # every want bit of the header is mirrored
+    text = open(os.path.join(ROOT, "include", "azul_hip.h")).read()
+    for name, val in re.findall(r"#define AZUL_(WANT_[A-Z_]+)\s+(\d+)u", text):
+        assert getattr(L, name) == int(val), name

@@ -412,3 +412,42 @@ def test_beyond_the_reference_parity_unpinned_extended_rules_through_the_facade(
     with pytest.raises(facade.azul.GameEnded):
         g.step(0, 0, 0)
     random.seed()
+
+
+def test_in_place_edits_between_calls_are_seen(facade):
+    """The facade does not pack attributes again that are still the arrays the last call unpacked, byte for byte -- so a write INTO one
+    of them (the reference's tests do that: tests/test_azul.py edits pattern_lines and walls in place), a rebound attribute, or an edited
+    scalar must each invalidate that shortcut."""
+    random.seed(3)
+    g = facade.Azul()
+    g.new_round()
+    c = int(np.flatnonzero(g.game_board_displays[0])[0])
+    # is_legal_move(display, color, pattern): display 1 is game_board_displays[0], pattern 1 the first line (azul.py:162-176)
+    assert g.is_legal_move(1, c, 1) and g.is_legal_move(1, c, 1)
+    keep = int(g.game_board_displays[0, c])
+    g.game_board_displays[0, c] = 0                                   # in place: the colour is no longer on the display
+    assert not g.is_legal_move(1, c, 1)
+    g.game_board_displays[0, c] = keep
+    assert g.is_legal_move(1, c, 1)
+    g.walls[g.current_player - 1, 0, c] = True                        # in place: the first wall row already holds the colour
+    assert not g.is_legal_move(1, c, 1) and g.is_legal_move(1, c, 2)
+    g.walls = np.zeros((2, 5, 5), dtype=bool)                         # rebound
+    assert g.is_legal_move(1, c, 1)
+    g.current_player = 3 - g.current_player                           # a scalar
+    g.pattern_lines[g.current_player - 1, 1, (c + 1) % 5] = 1         # the new mover's second line holds another colour
+    assert not g.is_legal_move(1, c, 2) and g.is_legal_move(1, c, 1)
+    # GameRunner's own counters are part of its record
+    r = facade.GameRunner()
+    r.reset()
+    a = int(np.flatnonzero(r.get_valid_moves())[0])
+    twin = facade.GameRunner()
+    twin.game, twin.player_score, twin.move_counter = r.game, r.player_score, r.move_counter
+    st = random.getstate()
+    import copy
+    twin.game = copy.deepcopy(r.game)
+    rew0, _ = r.step(a)
+    random.setstate(st)
+    twin.player_score += 5
+    rew1, _ = twin.step(a)
+    assert rew1 == rew0 - 5 and twin.game == r.game
+    random.seed()

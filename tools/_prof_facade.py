@@ -16,4 +16,4 @@ episode(999)
 pr = cProfile.Profile(); pr.enable()
 for s in range(40): episode(s)
 pr.disable()
-st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(18); print(st.getvalue()[:4000])
+st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(32); print(st.getvalue()[:7000])

@@ -37,7 +37,7 @@ class AzulCall(C.Structure):
                 ("record_in", C.c_void_p), ("mt_in", C.c_void_p), ("pos_in", C.c_uint32), ("mask_in", C.c_void_p),
                 ("record_out", C.c_void_p), ("mt_out", C.c_void_p),
                 ("pos_out", C.c_uint32), ("rng_regenerated", C.c_int32), ("status", C.c_int32), ("reward", C.c_int32), ("done", C.c_int32),
-                ("action", C.c_int32), ("flags", C.c_int32), ("potential", C.c_int32), ("next_action", C.c_int32), ("reserved0", C.c_int32),
+                ("action", C.c_int32), ("flags", C.c_int32), ("potential", C.c_int32), ("next_action", C.c_int32), ("obs_persp", C.c_int32),
                 ("mask", C.c_uint8 * (MAX_ACTIONS + 4)), ("obs", C.c_float * MAX_OBS), ("stats", C.c_double * 10)]
 
 

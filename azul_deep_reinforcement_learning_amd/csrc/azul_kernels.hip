@@ -1335,7 +1335,9 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     if (c->op == AZUL_CALL_SAMPLE_MASK && !c->mask_in) return fail(AZUL_ERR_INVALID, "azul_game_call: AZUL_CALL_SAMPLE_MASK needs mask_in");
     if ((c->want & AZUL_WANT_RECORD) && !c->record_out) return fail(AZUL_ERR_INVALID, "azul_game_call: AZUL_WANT_RECORD needs record_out");
     if (c->mt_in && c->pos_in > 624u) return fail(AZUL_ERR_INVALID, "azul_game_call: index outside 0..624");
-    if ((c->want & AZUL_WANT_OBS) && !persp_ok(b, c->arg)) return fail(AZUL_ERR_INVALID, "azul_game_call: AZUL_WANT_OBS needs a perspective in arg");
+    const int obs_persp = c->op == AZUL_CALL_QUERY ? c->arg : c->obs_persp;
+    if ((c->want & AZUL_WANT_OBS) && !persp_ok(b, obs_persp))
+        return fail(AZUL_ERR_INVALID, "azul_game_call: AZUL_WANT_OBS needs a perspective (AZUL_CALL_QUERY: arg; other ops: obs_persp)");
     if ((c->want & AZUL_WANT_NEXT_ACTION) && b->x) return fail(AZUL_ERR_INVALID, "azul_game_call: AZUL_WANT_NEXT_ACTION is for two-player reference batches");
     if ((c->want & AZUL_WANT_POS_IN) && c->pos_in > 624u) return fail(AZUL_ERR_INVALID, "azul_game_call: index outside 0..624");
     const size_t NA = (size_t)azul_batch_num_actions(b), NOBS = (size_t)azul_batch_obs_size(b);
@@ -1372,7 +1374,7 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     if (c->op == AZUL_CALL_RUNNER_STEP) { a.reward = &H->reward; a.done = &H->done; }
     if (c->op == AZUL_CALL_SAMPLE_MASK) { a.mask_in = H->mask_in; a.actions_out = &H->action_out; }
     if (c->want & AZUL_WANT_MASK) a.mask = H->mask;
-    if (c->want & AZUL_WANT_OBS) { a.obs = H->obs; a.persp = persp_of(b, c->arg); }
+    if (c->want & AZUL_WANT_OBS) { a.obs = H->obs; a.persp = persp_of(b, obs_persp); }
     if (c->want & AZUL_WANT_FLAGS) a.flags = &H->flags;
     if (c->want & AZUL_WANT_POTENTIAL) a.potential = &H->potential;
     if (c->want & AZUL_WANT_STATS) a.stats = H->stats;

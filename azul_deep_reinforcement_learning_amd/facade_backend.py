@@ -12,7 +12,9 @@ and ``RandomAgent.get_a_output(mask)`` are then served from these answers -- no 
 the ones the answers were computed from: the same record bytes; the same mask bytes and a global ``random`` state equal to the one
 this backend installed.  Playing the remembered draw advances the global stream by the one ``random()`` it stands for, and the next
 drawing call tells the device (AZUL_WANT_POS_IN).  Anything else -- a host draw in between, a re-seed, an edited mask or board --
-takes the ordinary path.  A GameRunner loop with RandomAgent is one submission per agent step.
+takes the ordinary path.  ``GameRunner.step`` brings the agent's observation as well (AZUL_WANT_OBS, ``obs_persp`` 0) for the
+``get_state()`` that opens the next iteration of nn_runner.py:22-30, served while no other submission has happened and the record is
+unchanged.  A GameRunner loop -- RandomAgent's or a network's -- is one submission per agent step.
 
 Randomness stays the reference's: the process-global CPython ``random`` stream.  A call that draws runs on the game's device
 stream; afterwards the advanced state is installed with ``random.setstate`` -- so ``random.seed(1); Azul().new_round()`` gives
@@ -65,6 +67,7 @@ _OPS = {
 }
 # two-player reference games: the calls after which a loop asks "which moves are legal" and "what does RandomAgent play" next
 ASK_AHEAD = True          # (False: every question is its own submission -- the A/B of tests/test_facade_ask_ahead.py and bench.py)
+_ASK_OBS = {"op_runner_step": 0}     # ... and "what does the agent see" (GameRunner.get_state(): the agent is player 1, perspective 0; nn_runner.py:22)
 _ASK_AHEAD = {"op_new_round", "op_step", "op_runner_reset", "op_runner_step"}
 _WANT_BYTES = ((L.WANT_MASK, 180), (L.WANT_OBS, 544), (L.WANT_STATS, 80), (L.WANT_NEXT_ACTION, 4))          # (the reference's sizes; traffic accounting only)
 
@@ -99,6 +102,8 @@ class HipBackend:
         self._resident = None                # bytes of the record the device holds
         self._mask_for, self._mask = None, None   # the legal mask a call brought back, and the record bytes it belongs to
         self._ahead = None                   # (mask bytes, stream state installed by that call, its index, RandomAgent's draw on them)
+        self._obs_for = None                 # (record bytes, perspective, submission number): self.c.obs still holds that observation
+        self._seq = 0                        # submissions so far
 
     def _game_call(self):
         """The one place that touches the device: self.c through azul_game_call on this backend's 1-game batch."""
@@ -121,6 +126,7 @@ class HipBackend:
         else:
             c.mt_in, c.pos_in = None, 0
         self._ahead = None
+        self._seq += 1
         self._game_call()
         if draws:
             words = tuple(self._mt_out.tolist()) if c.rng_regenerated else st[1][:624]
@@ -138,6 +144,10 @@ class HipBackend:
         game = len(rb) - 4 if (len(rb) == L.RECORD_BYTES and not op.startswith("op_runner")) else len(rb)
         if op == "op_mask" and self._mask_for is not None and rb[:game] == self._mask_for[:game]:
             return self._mask.copy(), None   # the previous call already computed this state's mask (the bytes are compared, not a flag)
+        if op == "op_observe" and self._obs_for is not None:
+            of = self._obs_for
+            if of[2] == self._seq and int(args[0]) == of[1] and rb[:game] == of[0][:game]:
+                return np.array(c.obs[:self.obs_size], dtype=np.float32).astype(np.int64), None      # brought back by the last submission
         c.op, want = _OPS[op]
         c.arg = int(args[0]) if args else 0
         c.mask_in = None
@@ -151,6 +161,9 @@ class HipBackend:
         ahead = ASK_AHEAD and self.ask_ahead and op in _ASK_AHEAD
         if ahead:
             want |= L.WANT_MASK | L.WANT_NEXT_ACTION
+            if op in _ASK_OBS:
+                want |= L.WANT_OBS
+                c.obs_persp = _ASK_OBS[op]
         c.want = want | (L.WANT_RECORD if mutates else 0)
         try:
             h2d += self._submit(draws)
@@ -170,6 +183,8 @@ class HipBackend:
             self._mask_for, self._mask = self._resident, m8.astype(bool)
             if ahead and c.next_action >= 0 and _RNG["be"] is self:
                 self._ahead = (m8.tobytes(), _RNG["state"], _RNG["pos"], int(c.next_action))
+            if ahead and op in _ASK_OBS:
+                self._obs_for = (self._resident, _ASK_OBS[op], self._seq)
         if op == "op_runner_step":
             return (int(c.reward), bool(c.done), int(c.status)), new
         if op == "op_mask":

@@ -222,7 +222,7 @@ enum { AZUL_CALL_QUERY = 0, AZUL_CALL_INIT, AZUL_CALL_NEW_ROUND, AZUL_CALL_MOVE,
        AZUL_CALL_STEP, AZUL_CALL_RUNNER_INIT, AZUL_CALL_RUNNER_RESET, AZUL_CALL_RUNNER_STEP, AZUL_CALL_SAMPLE_MASK };
 #define AZUL_WANT_RECORD     1u    /* the game's record after the call -> record_out */
 #define AZUL_WANT_MASK       2u    /* legal mask of the state after the call -> mask[180] */
-#define AZUL_WANT_OBS        4u    /* get_state(perspective = arg: a player, or AZUL_PERSP_MOVER) -> obs[azul_batch_obs_size] */
+#define AZUL_WANT_OBS        4u    /* get_state(perspective: a player, or AZUL_PERSP_MOVER; AZUL_CALL_QUERY: in arg, other ops: in obs_persp) -> obs[azul_batch_obs_size] */
 #define AZUL_WANT_FLAGS      8u    /* AZUL_FLAG_* -> flags */
 #define AZUL_WANT_POTENTIAL 16u    /* game_runner.py:48-50 -> potential (two players) */
 #define AZUL_WANT_STATS     32u    /* get_statistics -> stats[10] */
@@ -251,7 +251,7 @@ typedef struct azul_call {
     int32_t flags, potential;
     int32_t next_action;            /* AZUL_WANT_NEXT_ACTION: the action; -1 nothing legal; -2 not available (the op failed or did not draw, or the draw
                                        would cross the regeneration of the 624 words: ask AZUL_CALL_SAMPLE_MASK) */
-    int32_t reserved0;
+    int32_t obs_persp;              /* in: perspective of AZUL_WANT_OBS for ops whose `arg` is an action (AZUL_CALL_QUERY reads it from arg) */
     uint8_t mask[AZUL_MAX_ACTIONS + 4];   /* azul_batch_num_actions bytes are written */
     float obs[AZUL_MAX_OBS];              /* azul_batch_obs_size floats are written */
     double stats[AZUL_NUM_STATS];

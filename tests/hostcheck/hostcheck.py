@@ -321,7 +321,7 @@ def _call_backend_class():
                 m = np.ascontiguousarray(e.op_mask(), dtype=np.uint8)
                 C.memmove(base + L.AzulCall.mask.offset, m.ctypes.data, NA)
             if c.want & L.WANT_OBS:
-                o = np.ascontiguousarray(e.op_observe(c.arg), dtype=np.float32)
+                o = np.ascontiguousarray(e.op_observe(c.arg if c.op == L.CALL_QUERY else c.obs_persp), dtype=np.float32)
                 C.memmove(base + L.AzulCall.obs.offset, o.ctypes.data, 4 * self.obs_size)
             c.flags = e.op_flags() if c.want & L.WANT_FLAGS else 0
             c.potential = e.op_potential() if c.want & L.WANT_POTENTIAL else 0

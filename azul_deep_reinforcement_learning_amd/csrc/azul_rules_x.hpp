@@ -815,17 +815,19 @@ AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2
         bool any_done = false;
         AZ_STAMP(SEG_AFTERMOVE);
         if (AZ_UNLIKELY(wave_any(eor))) {
+            // (two divergent regions with wave-uniform stamps between them, like az2::after_move2: the diagnostic build's lane 0 sees
+            // the round ends of BOTH games of the wave)
+            if (eor) count_score_x(g, rules.pool != (u32)XPOOL_RANDOM, rules.end_bonus != 0u, K);         // :307
+            AZ_STAMP(SEG_SCORE);
             if (eor) {
-                count_score_x(g, rules.pool != (u32)XPOOL_RANDOM, rules.end_bonus != 0u, K);     // :307
-                AZ_STAMP(SEG_SCORE);
                 if (g.over) {                                 // :308-309
                     g.eog = 1;
                     if (rules.end_bonus) end_game_bonus_x(g);
                 } else {
                     st = new_round_x(g, rules, r, margin, K); // :311
                 }
-                AZ_STAMP(SEG_NEWROUND);
             }
+            AZ_STAMP(SEG_NEWROUND);
             any_done = wave_any(eor & (g.over != 0u));
             dead |= st != ST_OK;
         }

@@ -155,7 +155,7 @@ class Azul:
         """The record the attributes were just unpacked from, with what it takes to tell later that nobody touched them: the array
         objects themselves and their bytes (callers write them in place), the scalars."""
         d = self.__dict__
-        self._memo = [rec, [(n, d[n], d[n].tobytes()) for n in self._ARRAYS if n in d], self._scalars(runner), runner is not None, None]
+        self._memo = [rec, [(n, d[n], d[n].tobytes()) for n in self._ARRAYS if n in d], self._scalars(runner), runner is not None]
 
     def _remembered(self, runner):
         m = getattr(self, "_memo", None)
@@ -172,12 +172,9 @@ class Azul:
             return m[0]
         if not m[3] or runner is not None:
             return None                                   # (GameRunner's counters were edited)
-        if m[4] is None:                                  # an Azul-level call on a GameRunner's game: the counters pack as zero
-            rec = m[0].copy()
-            rec["player_score"] = 0
-            rec["move_counter"] = 0
-            m[4] = rec
-        return m[4]
+        # an Azul-level call on a GameRunner's game: the record as the runner's last call left it -- its last four bytes hold the
+        # runner's counters where a fresh pack writes zeros, and facade_backend.call ignores exactly those bytes for Azul-level calls
+        return m[0]
 
     def _to_record(self, runner=None):
         """The attributes packed into the game record (128 bytes; 256 for three / four players).  Callers write the attributes

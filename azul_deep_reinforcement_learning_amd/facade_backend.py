@@ -69,6 +69,7 @@ _OPS = {
 ASK_AHEAD = True          # (False: every question is its own submission -- the A/B of tests/test_facade_ask_ahead.py and bench.py)
 _ASK_OBS = {"op_runner_step": 0}     # ... and "what does the agent see" (GameRunner.get_state(): the agent is player 1, perspective 0; nn_runner.py:22)
 _ASK_AHEAD = {"op_new_round", "op_step", "op_runner_reset", "op_runner_step"}
+_WANT_D2H = {}
 _WANT_BYTES = ((L.WANT_MASK, 180), (L.WANT_OBS, 544), (L.WANT_STATS, 80), (L.WANT_NEXT_ACTION, 4))          # (the reference's sizes; traffic accounting only)
 
 
@@ -170,8 +171,15 @@ class HipBackend:
         except Exception:
             self._resident = None            # the library refused the call (e.g. a record outside the kernels' domain)
             raise
-        d2h = 24 + sum(n for bit, n in _WANT_BYTES if want & bit) + (len(rb) if mutates else 0) + (2496 if (draws and c.rng_regenerated) else 0)
-        _count(h2d=h2d, d2h=d2h, launches=1, syncs=1 + (1 if (draws and c.rng_regenerated) else 0))
+        wb = _WANT_D2H.get(want)
+        if wb is None:
+            wb = _WANT_D2H[want] = 24 + sum(n for bit, n in _WANT_BYTES if want & bit)
+        regen = 1 if (draws and c.rng_regenerated) else 0
+        t = _TRAFFIC
+        t["h2d"] += h2d
+        t["d2h"] += wb + (len(rb) if mutates else 0) + 2496 * regen
+        t["launches"] += 1
+        t["syncs"] += 1 + regen
         new = None
         if mutates:
             new = self._rec_out[0].copy()

@@ -117,9 +117,9 @@ class RandomAgent:
 
     def get_a_output(self, state, valid_moves):
         from . import facade_backend as fb
-        mask = np.asarray(valid_moves.numpy() if hasattr(valid_moves, "numpy") else valid_moves).reshape(-1)
+        mask = valid_moves.numpy() if hasattr(valid_moves, "numpy") else np.asarray(valid_moves)
         # 180 actions in the reference; 240 / 300 with the 2P+1 displays rule (beyond the reference): weight 0.01 for the floor row
-        a = fb.sampling_backend(mask.size).sample(mask.astype(np.uint8))
+        a = fb.sampling_backend(mask.size).sample(mask)
         if a < 0:
             raise ValueError("Total of weights must be greater than zero")
         return a

@@ -15,7 +15,7 @@ def test_numbers_md_is_what_the_generator_prints():
 
 def test_tracked_soak_logs_cite_the_csrc_they_ran_on_and_design_cites_the_same():
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
-    for name in ("round4_selfplay_soak_raw.txt", "round4_rollout_soak_raw.txt"):
+    for name in ("round4_selfplay_soak_raw.txt", "round4_rollout_soak_raw.txt", "round4_players_soak_raw.txt"):
         text = open(os.path.join(ROOT, "profiles", name)).read()
         m = re.search(r"csrc sha256 ([0-9a-f]{16})", text)
         assert m, name

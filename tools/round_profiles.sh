@@ -30,6 +30,7 @@ else
   timeout -k 10 300 python3 tools/learn_check.py 3000 2>&1 | grep -v amdgpu.ids > $R/learning_curve.txt
   timeout -k 10 400 python3 tools/soak.py 2>&1 | grep -v amdgpu.ids > $R/selfplay_soak_raw.txt
   timeout -k 10 600 python3 tools/soak_rollout.py 300 2>&1 | grep -v "amdgpu.ids\|UserWarning\|Consider using\|print(" > $R/rollout_soak_raw.txt
+  timeout -k 10 600 python3 tools/soak_players.py 2>&1 | grep -v amdgpu.ids > $R/players_soak_raw.txt
 fi
 echo done $PART > $R/DONE_$PART
 ls $R

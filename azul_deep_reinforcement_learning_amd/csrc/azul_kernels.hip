@@ -916,7 +916,7 @@ static int launch_op_x(azul_batch_t *b, const OpArgs &a, void *stream, int count
                                       "three / four players and extended-rule batches support the Azul rule entries, the sampler, the mask and the observation");
     x.actions = a.actions; x.active = a.active; x.mask_in = a.mask_in; x.actions_out = a.actions_out; x.status = a.status; x.mask = a.mask;
     x.obs = a.obs; x.persp = a.persp; x.flags = a.flags; x.stats = a.stats; x.player = a.player; x.rng_dirty = a.rng_dirty;
-    x.rec_out = a.rec_out; x.pos_out = a.pos_out;
+    x.rec_out = a.rec_out; x.pos_out = a.pos_out; x.next_action = a.next_action; x.pos_set = a.pos_set;
     x.first = a.first; x.count = count < 0 ? b->d.n : (u32)count;
     const dim3 grid((x.count + 1u) / 2u), block(64);
     const azx::XBatchDev xb = xdev(b);
@@ -1338,7 +1338,6 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     const int obs_persp = c->op == AZUL_CALL_QUERY ? c->arg : c->obs_persp;
     if ((c->want & AZUL_WANT_OBS) && !persp_ok(b, obs_persp))
         return fail(AZUL_ERR_INVALID, "azul_game_call: AZUL_WANT_OBS needs a perspective (AZUL_CALL_QUERY: arg; other ops: obs_persp)");
-    if ((c->want & AZUL_WANT_NEXT_ACTION) && b->x) return fail(AZUL_ERR_INVALID, "azul_game_call: AZUL_WANT_NEXT_ACTION is for two-player reference batches");
     if ((c->want & AZUL_WANT_POS_IN) && c->pos_in > 624u) return fail(AZUL_ERR_INVALID, "azul_game_call: index outside 0..624");
     const size_t NA = (size_t)azul_batch_num_actions(b), NOBS = (size_t)azul_batch_obs_size(b);
     if (c->record_in) if (int rc = record_in_domain(b, (const uint8_t *)c->record_in)) return rc;

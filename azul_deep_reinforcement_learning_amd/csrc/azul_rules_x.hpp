@@ -911,6 +911,9 @@ struct XOp {
     uint8_t *rng_dirty;      // [count] out: the op regenerated the game's MT19937 words
     uint8_t *rec_out;        // [count][256] out: the game's record after the op
     u32 *pos_out;            // [count] out: index of the game's MT19937 stream after the op
+    i32 *next_action;        // [count] out: RandomAgent's choice on the state after the op, drawn at the stream's index after the op WITHOUT moving
+                             //         it (-1: nothing legal, -2: not available: the op failed / did not draw, or the draw would cross a regeneration)
+    u32 pos_set;             // 0, or 1 + the stream index to install before the op (single-game calls: the host's index is the authority)
     u32 first, count;        // the launch covers games first .. first + count - 1; row i of the arrays belongs to game first + i
 };
 
@@ -949,11 +952,12 @@ AZ_FN void op_body_x(const XBatchDev &b, const XOp &a, u32 pair /* games 2 pair,
     prime_x(g, K);
     const bool tracked = b.rules.pool != (u32)XPOOL_RANDOM;
     u32 st = ST_OK, rdirty = 0;
+    i32 spec = -2;
     if (act && a.op != XOP_QUERY) {
         const bool use_rng = xop_draws(a.op);
         Rng2 r;
         u32 *gmt = b.mt + (size_t)gi * 624u;
-        rng2_open(r, gmt, mt_lds[half], use_rng ? b.mtpos[gi] : 0u, l);
+        rng2_open(r, gmt, mt_lds[half], use_rng ? (a.pos_set ? a.pos_set - 1u : b.mtpos[gi]) : 0u, l);
         bool dirty_state = true;
         switch (a.op) {
         case XOP_INIT:
@@ -1008,9 +1012,19 @@ AZ_FN void op_body_x(const XBatchDev &b, const XOp &a, u32 pair /* games 2 pair,
             break;
         }
         if (dirty_state) gx_store(g, rec, l);
+        if (a.next_action && use_rng && st == ST_OK && r.pos + 2u <= 624u) {
+            // the question a mask -> RandomAgent -> step loop asks next, answered from the two words the stream would hand out next;
+            // the index is restored: the caller advances it when it plays the answer (azul_game_call: AZUL_WANT_NEXT_ACTION / _POS_IN)
+            const u32 keep = r.pos;
+            MaskX<D> m;
+            legal_mask_x(g, K, m);
+            spec = random_agent_x<D>(m, r, tab, K.k);
+            r.pos = keep;
+        }
         if (use_rng) rng2_close(r, gmt, b.mtpos + gi, l);
         rdirty = r.dirty;
     }
+    if (a.next_action && l == 0u) a.next_action[oi] = spec;
     if (a.rng_dirty && l == 0u) a.rng_dirty[oi] = (uint8_t)rdirty;
     if (a.status && act && l == 0u) a.status[oi] = (uint8_t)st;
     if (a.rec_out) gx_store(g, a.rec_out + (size_t)oi * AZUL_RECORD_BYTES_WIDE, l);

@@ -5,7 +5,7 @@ A facade call = ONE ``azul_game_call``: the object's numpy attributes packed int
 synchronisation.  The record is only sent when it differs from what the device already holds (the facade's attributes are
 caller-writable numpy arrays, so the packed bytes are compared, not a dirty flag).
 
-A call that changes a two-player game also answers the two questions the reference's loops ask next (nn_runner.py:22-30,
+A call that changes a game also answers the two questions the reference's loops ask next (nn_runner.py:22-30,
 game_runner.py:37-42): the legal mask of the state it leaves (AZUL_WANT_MASK) and what ``RandomAgent.get_a_output`` draws on that
 mask from the stream as the call leaves it (AZUL_WANT_NEXT_ACTION: computed, the stream's index NOT moved).  ``get_valid_moves()``
 and ``RandomAgent.get_a_output(mask)`` are then served from these answers -- no submission -- when, and only when, their inputs are
@@ -70,7 +70,7 @@ ASK_AHEAD = True          # (False: every question is its own submission -- the 
 _ASK_OBS = {"op_runner_step": 0}     # ... and "what does the agent see" (GameRunner.get_state(): the agent is player 1, perspective 0; nn_runner.py:22)
 _ASK_AHEAD = {"op_new_round", "op_step", "op_runner_reset", "op_runner_step"}
 _WANT_D2H = {}
-_WANT_BYTES = ((L.WANT_MASK, 180), (L.WANT_OBS, 544), (L.WANT_STATS, 80), (L.WANT_NEXT_ACTION, 4))          # (the reference's sizes; traffic accounting only)
+_WANT_BYTES = ((L.WANT_MASK, 180), (L.WANT_OBS, 544), (L.WANT_STATS, 80), (L.WANT_NEXT_ACTION, 4), (L.WANT_FLAGS, 1))          # (the reference's sizes; traffic accounting only)
 
 
 class HipBackend:
@@ -86,11 +86,11 @@ class HipBackend:
         rules = {"first_player": "Random" if first_player == L.FIRST_RANDOM else int(first_player),
                  "tile_pool": "Lid" if tile_pool == L.POOL_LID else "Random"}
         self.env = BatchedAzul(1, rules=rules, players=players, ext_rules=ext)
-        self._setup(self.env.num_actions, self.env.obs_size, self.env.record_dtype, players == 2 and not ext)
+        self._setup(self.env.num_actions, self.env.obs_size, self.env.record_dtype)
 
-    def _setup(self, num_actions, obs_size, record_dtype, reference_game):
+    def _setup(self, num_actions, obs_size, record_dtype):
         self.num_actions, self.obs_size = num_actions, obs_size
-        self.ask_ahead = bool(reference_game)          # AZUL_WANT_NEXT_ACTION: two-player reference batches
+        self.ask_ahead = True                          # (a backend's own switch next to the module's ASK_AHEAD)
         self.c = L.AzulCall()
         self.c.game = 0
         self._rec_in = np.zeros(1, dtype=record_dtype)
@@ -104,6 +104,7 @@ class HipBackend:
         self._mask_for, self._mask = None, None   # the legal mask a call brought back, and the record bytes it belongs to
         self._ahead = None                   # (mask bytes, stream state installed by that call, its index, RandomAgent's draw on them)
         self._obs_for = None                 # (record bytes, perspective, submission number): self.c.obs still holds that observation
+        self._flags_for = None               # (record bytes, AZUL_FLAG_* of that state)
         self._seq = 0                        # submissions so far
 
     def _game_call(self):
@@ -126,8 +127,7 @@ class HipBackend:
                 h2d += 2500
         else:
             c.mt_in, c.pos_in = None, 0
-        self._ahead = None
-        self._seq += 1
+        self._seq += 1                       # (the remembered draw stays: it is checked against mask bytes and stream state when it is used)
         self._game_call()
         if draws:
             words = tuple(self._mt_out.tolist()) if c.rng_regenerated else st[1][:624]
@@ -145,6 +145,8 @@ class HipBackend:
         game = len(rb) - 4 if (len(rb) == L.RECORD_BYTES and not op.startswith("op_runner")) else len(rb)
         if op == "op_mask" and self._mask_for is not None and rb[:game] == self._mask_for[:game]:
             return self._mask.copy(), None   # the previous call already computed this state's mask (the bytes are compared, not a flag)
+        if op == "op_flags" and self._flags_for is not None and rb[:game] == self._flags_for[0][:game]:
+            return self._flags_for[1], None  # is_end_of_round / is_end_of_game of the state the last call left
         if op == "op_observe" and self._obs_for is not None:
             of = self._obs_for
             if of[2] == self._seq and int(args[0]) == of[1] and rb[:game] == of[0][:game]:
@@ -161,7 +163,7 @@ class HipBackend:
             c.record_in = None
         ahead = ASK_AHEAD and self.ask_ahead and op in _ASK_AHEAD
         if ahead:
-            want |= L.WANT_MASK | L.WANT_NEXT_ACTION
+            want |= L.WANT_MASK | L.WANT_NEXT_ACTION | L.WANT_FLAGS
             if op in _ASK_OBS:
                 want |= L.WANT_OBS
                 c.obs_persp = _ASK_OBS[op]
@@ -193,6 +195,8 @@ class HipBackend:
                 self._ahead = (m8.tobytes(), _RNG["state"], _RNG["pos"], int(c.next_action))
             if ahead and op in _ASK_OBS:
                 self._obs_for = (self._resident, _ASK_OBS[op], self._seq)
+            if ahead:
+                self._flags_for = (self._resident, int(c.flags))
         if op == "op_runner_step":
             return (int(c.reward), bool(c.done), int(c.status)), new
         if op == "op_mask":

@@ -226,7 +226,7 @@ enum { AZUL_CALL_QUERY = 0, AZUL_CALL_INIT, AZUL_CALL_NEW_ROUND, AZUL_CALL_MOVE,
 #define AZUL_WANT_FLAGS      8u    /* AZUL_FLAG_* -> flags */
 #define AZUL_WANT_POTENTIAL 16u    /* game_runner.py:48-50 -> potential (two players) */
 #define AZUL_WANT_STATS     32u    /* get_statistics -> stats[10] */
-#define AZUL_WANT_NEXT_ACTION 64u  /* two-player reference batches, ops that draw: what RandomAgent.get_a_output (game_runner.py:87-97) answers on the
+#define AZUL_WANT_NEXT_ACTION 64u  /* ops that draw: what RandomAgent.get_a_output (game_runner.py:87-97) answers on the
                                       state after the call -- the question a GameRunner loop asks next (nn_runner.py:22-30) -- computed from the two
                                       words the stream hands out next, WITHOUT moving its index -> next_action.  A caller that plays the answer (same
                                       mask, stream untouched in between) advances the index by one random(), two words, itself: AZUL_WANT_POS_IN on

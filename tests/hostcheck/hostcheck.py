@@ -59,13 +59,13 @@ def xlib():
         subprocess.check_call(["make", "-s", "-C", _HERE, name], stdout=subprocess.DEVNULL)
         L = C.CDLL(os.path.join(_HERE, name))
         L.shx_op.restype = C.c_int
-        L.shx_op.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_ulonglong, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 5
+        L.shx_op.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_ulonglong, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 6 + [C.c_uint]
         _xlib = L
     return _xlib
 
 
 def x_op(rec, players, first, pool, ext, op, action, mt, pos, mask_in=None, want_mask=False, want_flags=False, want_stats=False, want_obs=None,
-         margin=0):
+         margin=0, want_next=False, pos_set=None):
     """One rule call of the emulated azul_x_op_kernel body on one 256-byte record.  `pool` / `ext`: the ABI's tile_pool and AZUL_RULE_*
     flags.  Returns a dict: status, mask, flags, stats, obs, action, player, rng_dirty."""
     D = 2 * players + 1 if ext & EXT_DISPLAYS_2P1 else 5
@@ -73,15 +73,16 @@ def x_op(rec, players, first, pool, ext, op, action, mt, pos, mask_in=None, want
     mask = np.zeros(NA, np.uint8) if want_mask else None
     obs = np.zeros(NOBS, np.float32) if want_obs is not None else None
     stats = np.zeros(10) if want_stats else None
-    flags, act, player, dirty = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    flags, act, player, dirty, nxt = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(-2)
     xpool = 2 if ext & EXT_FINITE_BAG else int(pool)
     mi = None if mask_in is None else np.ascontiguousarray(mask_in, dtype=np.uint8)
     st = xlib().shx_op(ptr(rec), players, D, int(first), xpool, int(bool(ext & EXT_END_BONUS)), int(bool(ext & EXT_SHORT_DEAL)), margin,
                        XOP[op] if isinstance(op, str) else op, int(action), ptr(mt), ptr(pos), ptr(mi), ptr(mask), ptr(obs),
                        int(want_obs) if want_obs is not None else 0, C.cast(C.byref(flags), C.c_void_p), ptr(stats),
-                       C.cast(C.byref(act), C.c_void_p), C.cast(C.byref(player), C.c_void_p), C.cast(C.byref(dirty), C.c_void_p))
+                       C.cast(C.byref(act), C.c_void_p), C.cast(C.byref(player), C.c_void_p), C.cast(C.byref(dirty), C.c_void_p),
+                       C.cast(C.byref(nxt), C.c_void_p) if want_next else None, 0 if pos_set is None else 1 + int(pos_set))
     return {"status": st, "mask": mask, "flags": flags.value, "stats": stats, "obs": obs, "action": act.value, "player": player.value,
-            "rng_dirty": dirty.value}
+            "rng_dirty": dirty.value, "next_action": nxt.value}
 
 
 class HostStream:
@@ -217,8 +218,12 @@ class EmuBackendX(EmuBackend):
         from azul_deep_reinforcement_learning_amd.records import RECORD_NP_DTYPE
         return self.rec.copy().view(RECORD_NP_DTYPE)[0]
 
+    want_next, last_next = False, -2       # AZUL_WANT_NEXT_ACTION of the call being interpreted / the emulated kernel's answer
+
     def _op(self, op, action=0, **kw):
-        return x_op(self.rec, self.players, self.fp, self.pool, self.ext, op, action, self.mt, self.pos, **kw)
+        out = x_op(self.rec, self.players, self.fp, self.pool, self.ext, op, action, self.mt, self.pos, want_next=self.want_next, **kw)
+        self.last_next = out["next_action"]
+        return out
 
     def op_init(self):
         self._op("init")
@@ -276,8 +281,7 @@ def _call_backend_class():
     class EmuCallBackend(fb.HipBackend):
         def __init__(self, first_player, tile_pool, players=2, ext=0):
             self.dev = EmuBackend(first_player, tile_pool, players, ext)
-            self._setup(self.dev.num_actions, self.dev.obs_size, RECORD_DTYPE if self.dev.rec.size == 128 else RECORD_NP_DTYPE,
-                        int(players) == 2 and not int(ext))
+            self._setup(self.dev.num_actions, self.dev.obs_size, RECORD_DTYPE if self.dev.rec.size == 128 else RECORD_NP_DTYPE)
             self.calls = 0
 
         def _game_call(self):          # (include/azul_hip.h: azul_game_call, statement by statement)
@@ -294,6 +298,9 @@ def _call_backend_class():
                 e.pos[0] = c.pos_in
             mt0 = e.mt.copy()
             st, c.reward, c.done, c.action = 0, 0, 0, 0
+            own_answer = hasattr(e, "last_next")           # the P-player core's kernel body answers AZUL_WANT_NEXT_ACTION itself
+            if own_answer:
+                e.want_next, e.last_next = bool(c.want & L.WANT_NEXT_ACTION), -2
             if c.op == L.CALL_INIT:
                 e.op_init()
             elif c.op == L.CALL_NEW_ROUND:
@@ -316,6 +323,8 @@ def _call_backend_class():
             elif c.op == L.CALL_SAMPLE_MASK:
                 c.action = e.op_sample_mask(np.frombuffer(C.string_at(c.mask_in, NA), np.uint8))
             c.status = int(st or 0)
+            if own_answer:
+                nxt, e.want_next = e.last_next, False
             base = C.addressof(c)
             if c.want & L.WANT_MASK:
                 m = np.ascontiguousarray(e.op_mask(), dtype=np.uint8)
@@ -331,7 +340,9 @@ def _call_backend_class():
             if c.want & L.WANT_RECORD:
                 C.memmove(c.record_out, e.rec.ctypes.data, RB)
             c.next_action = -2
-            if (c.want & L.WANT_NEXT_ACTION) and draws and c.status == 0 and int(e.pos[0]) + 2 <= 624:
+            if own_answer:
+                c.next_action = nxt if (c.want & L.WANT_NEXT_ACTION) else -2
+            elif (c.want & L.WANT_NEXT_ACTION) and draws and c.status == 0 and int(e.pos[0]) + 2 <= 624:
                 keep = int(e.pos[0])
                 c.next_action = e.op_sample_mask(np.ascontiguousarray(e.op_mask(), dtype=np.uint8))
                 e.pos[0] = keep

@@ -88,7 +88,7 @@ long long shx_selfplay(int n_games, int players, int displays, uint8_t *state, u
 // one rule call on ONE game (the wave's other half stays idle): record [256], stream (624 words + index), results on request
 int shx_op(uint8_t *rec, int players, int displays, int first_player, int pool, int end_bonus, int short_deal, unsigned long long margin, int op,
            int action, u32 *mt, u32 *pos, const uint8_t *mask_in, uint8_t *mask_out, float *obs, int persp, int *flags, double *stats10,
-           int *action_out, int *player, int *rng_dirty)
+           int *action_out, int *player, int *rng_dirty, int *next_action /* NULL: not asked for */, unsigned pos_set /* 0, or 1 + index */)
 {
     lane_fn fn = pick_fn(players, displays, false);
     double *tab = table_for(displays);
@@ -103,6 +103,8 @@ int shx_op(uint8_t *rec, int players, int displays, int first_player, int pool, 
     j->op.op = op; j->op.actions = &act_in; j->op.mask_in = mask_in; j->op.actions_out = &act_out; j->op.status = &status;
     j->op.mask = mask_out; j->op.obs = obs; j->op.persp = persp; j->op.flags = &fl; j->op.stats = stats10; j->op.player = &pl;
     j->op.rng_dirty = &rd; j->op.first = 0; j->op.count = 1;
+    i32 nxt = -2;
+    j->op.next_action = next_action ? &nxt : nullptr; j->op.pos_set = pos_set;
     j->players = players; j->displays = displays; j->wave = 0;
     simt::run_wave(fn, j);
     free(j);
@@ -110,6 +112,7 @@ int shx_op(uint8_t *rec, int players, int displays, int first_player, int pool, 
     if (action_out) *action_out = act_out;
     if (player) *player = pl;
     if (rng_dirty) *rng_dirty = rd;
+    if (next_action) *next_action = nxt;
     return status;
 }
 

@@ -178,8 +178,44 @@ def test_ask_ahead_bits_of_the_call_block():
             assert c.next_action == -2
             seen["straddle"] += 1
     assert seen["ahead"] > 10
-    # three / four players and extended rules: refused, not ignored
-    envx = BatchedAzul(1, players=3, device="cuda:0")
-    cx = L.AzulCall()
-    cx.op, cx.want = L.CALL_QUERY, L.WANT_NEXT_ACTION
-    assert L.lib.azul_game_call(envx._h, C.byref(cx), None) == L.ERR_INVALID
+    # three / four players and extended rules: the P-player rule kernel answers the same question -- checked against its own sampler
+    # (AZUL_CALL_SAMPLE_MASK, which tests/test_gpu_players.py / test_gpu_ext_rules.py pin to the oracle) on the mask the step returned
+    for (P, ext) in ((3, 0), (4, L.RULE_DISPLAYS_2P1 | L.RULE_END_BONUS | L.RULE_SHORT_DEAL)):
+        envx = BatchedAzul(2, players=P, ext_rules=ext, device="cuda:0")
+        envx.seed(77)
+        envx.init()
+        envx.new_round()
+        NA = envx.num_actions
+        cx = L.AzulCall()
+        recx = np.zeros(1, dtype=envx.record_dtype)
+        cx.record_out, cx.game = recx.ctypes.data, 1
+        cx.op, cx.want = L.CALL_QUERY, L.WANT_MASK
+        L.check(L.lib.azul_game_call(envx._h, C.byref(cx), None))
+        asked = 0
+        for t in range(60):
+            mask = np.frombuffer(bytes(cx.mask), np.uint8)[:NA].copy()
+            if not mask.any():
+                break
+            a = int(np.flatnonzero(mask)[t % int(mask.sum())])
+            cx.op, cx.arg, cx.want, cx.mask_in = L.CALL_STEP, a, L.WANT_RECORD | L.WANT_MASK | L.WANT_NEXT_ACTION | L.WANT_FLAGS, None
+            L.check(L.lib.azul_game_call(envx._h, C.byref(cx), None))
+            assert cx.status == 0
+            if cx.flags & L.FLAG_END_OF_GAME:
+                break
+            pos, nxt = int(cx.pos_out), int(cx.next_action)
+            mask = np.frombuffer(bytes(cx.mask), np.uint8)[:NA].copy()
+            if pos + 2 > 624:
+                assert nxt == -2
+                continue
+            probe = L.AzulCall()
+            probe.game, probe.op, probe.want, probe.mask_in = 1, L.CALL_SAMPLE_MASK, 0, mask.ctypes.data
+            L.check(L.lib.azul_game_call(envx._h, C.byref(probe), None))      # the stream's index had not moved: this is the same draw
+            assert probe.action == nxt and probe.pos_out == pos + 2, (P, t)
+            cx.op, cx.want, cx.pos_in = L.CALL_QUERY, 0, 0
+            # put the index back for the next step (the probe consumed the draw): AZUL_WANT_POS_IN on a drawing call
+            back = L.AzulCall()
+            back.game, back.op, back.want, back.pos_in, back.mask_in = 1, L.CALL_SAMPLE_MASK, L.WANT_POS_IN, pos, mask.ctypes.data
+            L.check(L.lib.azul_game_call(envx._h, C.byref(back), None))
+            assert back.action == nxt and back.pos_out == pos + 2
+            asked += 1
+        assert asked > 10

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Copy the summaries of gpurun_out/<tag>/ (tools/round_profiles.sh a + b) into profiles/<name>_* and regenerate NUMBERS.md:
+#   bash tools/collect_round_profiles.sh r4_final4 round4
+set -eu
+T=${1:?tag}; N=${2:?name}; R=gpurun_out/$T
+python3 tools/summarize_profile.py $T $N > /dev/null
+cp $R/games_sweep.txt profiles/${N}_games_sweep.txt
+cp $R/segment_shares.txt profiles/${N}_segment_shares.txt
+cp $R/policy_rollout_phases.txt profiles/${N}_policy_rollout_phases.txt
+cp $R/${T}_mfma_counters.json profiles/${N}_mfma_counters.json
+cp $R/${T}_train_kernel_stats.csv profiles/${N}_train_kernel_stats.csv
+cp $R/policy_bench.json profiles/${N}_policy_bench.json
+cp "$(ls $R/policy_stats/*/*_kernel_stats.csv | head -1)" profiles/${N}_policy_kernel_stats.csv
+for k in players_kernel players_displays2p1_kernel; do
+  cp $R/${T}_${k}_kernel_stats.csv profiles/${N}_${k}_kernel_stats.csv
+  cp $R/${T}_${k}_pmc.json profiles/${N}_${k}_pmc.json
+done
+cp $R/learning_curve.txt profiles/${N}_learning_curve.txt
+for s in selfplay rollout players; do cp $R/${s}_soak_raw.txt profiles/${N}_${s}_soak_raw.txt; done
+python3 tools/numbers_table.py > NUMBERS.md
+echo "profiles/${N}_* <- $R (csrc sha256 $(cat $R/csrc_sha256.txt))"

@@ -4,11 +4,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "azul_hip.h"             // the ABI's constants (record / mask / observation sizes, flags)
 #include "azul_wave_host.hpp"      // defines AZ_WAVE_HPP: the device header csrc/azul_wave.hpp is skipped
 #include "azul_core.hpp"
 #include "azul_tables.hpp"
 
 using namespace az;
+#include "azul_ops.hpp"        // the two-player rule kernel's body (op_body), unmodified: hc_op below
 
 static double g_T[T_WORDS];
 static double g_fr[T_ROWS * T_BINADES];
@@ -260,6 +262,47 @@ int hc_sample_mask(const uint8_t *mask180, u32 *mt, u32 *pos)
     i32 a = random_agent(m, r, table(), k, code);
     rng_close(r, pos);
     return a;
+}
+
+// ONE rule call exactly as azul_op_kernel performs it (csrc/azul_ops.hpp: op_body) on one game in host memory: record [128], stream (624
+// words + index), results on request (NULL: not asked for).  op: the OP_* of azul_ops.hpp.  Returns the status byte.
+int hc_op(uint8_t *rec, int first_player, int tile_pool, unsigned long long margin, int op, int action, u32 *mt, u32 *pos, unsigned pos_set,
+          const uint8_t *mask_in, uint8_t *mask_out, float *obs, int persp, int *flags, int *potential, double *stats10, int *reward,
+          int *done, int *action_out, int *player, int *rng_dirty, int *next_action, uint8_t *rec_out, unsigned long long *episodes,
+          unsigned *stuck, double *stat_sum10)
+{
+    table();
+    static u32 mt_lds[624];
+    static double fr_lds[T_ROWS * T_BINADES];
+    u64 ep = episodes ? *episodes : 0; u32 sk = stuck ? *stuck : 0; double ss[10] = {0};
+    if (stat_sum10) memcpy(ss, stat_sum10, sizeof(ss));
+    BatchDev b;
+    memset(&b, 0, sizeof(b));
+    b.state = rec; b.mt = mt; b.mtpos = pos; b.T = g_T; b.episodes = &ep; b.stuck = &sk; b.stat_sum = ss; b.n = 1;
+    b.rules.first_player = (u32)first_player; b.rules.tile_pool = (u32)tile_pool; b.draw_margin = margin ? margin : AZ_DRAW_MARGIN;
+    OpArgs a;
+    memset(&a, 0, sizeof(a));
+    i32 act_in = action, act_out = 0, rew = 0, pot = 0, nxt = -2;
+    uint8_t status = 0, dn = 0, fl = 0, pl = 0, rd = 0;
+    u32 pos_after = 0;
+    a.op = op; a.actions = &act_in; a.mask_in = mask_in; a.actions_out = &act_out; a.status = &status;
+    a.reward = reward ? &rew : nullptr; a.done = done ? &dn : nullptr; a.mask = mask_out; a.obs = obs; a.persp = persp;
+    a.flags = flags ? &fl : nullptr; a.potential = potential ? &pot : nullptr; a.stats = stats10; a.player = &pl; a.rng_dirty = &rd;
+    a.rec_out = rec_out; a.pos_out = &pos_after; a.next_action = next_action ? &nxt : nullptr; a.pos_set = pos_set; a.first = 0;
+    if (tile_pool == POOL_LID) op_body<true>(b, a, 0u, mt_lds, fr_lds);
+    else op_body<false>(b, a, 0u, mt_lds, fr_lds);
+    if (flags) *flags = fl;
+    if (potential) *potential = pot;
+    if (reward) *reward = rew;
+    if (done) *done = dn;
+    if (action_out) *action_out = act_out;
+    if (player) *player = pl;
+    if (rng_dirty) *rng_dirty = rd;
+    if (next_action) *next_action = nxt;
+    if (episodes) *episodes = ep;
+    if (stuck) *stuck = sk;
+    if (stat_sum10) memcpy(stat_sum10, ss, sizeof(ss));
+    return status;
 }
 
 } // extern "C"

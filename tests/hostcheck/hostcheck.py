@@ -38,6 +38,8 @@ def lib():
         L.hc_next_player.argtypes = [C.c_void_p]
         L.hc_statistics.argtypes = [C.c_void_p, C.c_void_p]
         L.hc_sample_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hc_op.restype = C.c_int
+        L.hc_op.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ulonglong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 13
         _lib = L
     return _lib
 
@@ -148,59 +150,77 @@ class EmuBackend:
         from azul_deep_reinforcement_learning_amd.records import RECORD_DTYPE
         return self.rec.copy().view(RECORD_DTYPE)[0]
 
+    # ---- one rule call = op_body of csrc/azul_ops.hpp (the body of azul_op_kernel) on the emulated wave: hc_op ----
+    OP = {"query": 0, "init": 1, "new_round": 2, "move": 3, "next_player": 4, "count_score": 5, "step": 6, "runner_init": 7,
+          "runner_reset": 8, "runner_step": 9, "random_action": 10, "sample_mask": 11}
+    want_next, last_next = False, -2       # AZUL_WANT_NEXT_ACTION of the call being interpreted / the emulated kernel's answer
+    pos_set = None                         # AZUL_WANT_POS_IN: the index the next drawing op installs first
+
+    def _op(self, op, action=0, mask_in=None, want_mask=False, want_obs=None, want_flags=False, want_potential=False, want_stats=False):
+        mask = np.zeros(180, np.uint8) if want_mask else None
+        obs = np.zeros(136, np.float32) if want_obs is not None else None
+        stats = np.zeros(10) if want_stats else None
+        ints = {k: C.c_int(0) for k in ("flags", "potential", "reward", "done", "action", "player", "dirty")}
+        nxt = C.c_int(-2)
+        mi = None if mask_in is None else np.ascontiguousarray(mask_in, dtype=np.uint8)
+        ref = lambda k: C.cast(C.byref(ints[k]), C.c_void_p)
+        st = lib().hc_op(ptr(self.rec), self.fp, self.pool, 0, self.OP[op], int(action), ptr(self.mt), ptr(self.pos),
+                         0 if self.pos_set is None else 1 + int(self.pos_set), ptr(mi), ptr(mask), ptr(obs),
+                         int(want_obs) if want_obs is not None else 0, ref("flags") if want_flags else None,
+                         ref("potential") if want_potential else None, ptr(stats), ref("reward"), ref("done"), ref("action"), ref("player"),
+                         ref("dirty"), C.cast(C.byref(nxt), C.c_void_p) if self.want_next else None, None, None, None, None)
+        self.pos_set = None
+        self.last_next = nxt.value
+        out = {k: v.value for k, v in ints.items()}
+        out.update(status=st, mask=mask, obs=obs, stats=stats)
+        return out
+
     def op_init(self):
-        lib().hc_init(ptr(self.rec), self.fp, self.pool, ptr(self.mt), ptr(self.pos))
+        self._op("init")
 
     def op_new_round(self):
-        return lib().hc_new_round(ptr(self.rec), self.pool, ptr(self.mt), ptr(self.pos))
+        return self._op("new_round")["status"]
 
     def op_move(self, action):
-        lib().hc_move(ptr(self.rec), int(action), self.pool)
+        self._op("move", action)
 
     def op_next_player(self):
-        lib().hc_next_player(ptr(self.rec))
+        self._op("next_player")
 
     def op_count_score(self):
-        lib().hc_count_score(ptr(self.rec), self.pool)
+        self._op("count_score")
 
     def op_step(self, action):
-        return lib().hc_step(ptr(self.rec), int(action), self.fp, self.pool, ptr(self.mt), ptr(self.pos))
+        return self._op("step", action)["status"]
 
     def op_flags(self):
-        return lib().hc_flags(ptr(self.rec))
+        return self._op("query", want_flags=True)["flags"]
 
     def op_mask(self):
-        m = np.zeros(180, np.uint8)
-        lib().hc_mask(ptr(self.rec), ptr(m))
-        return m.astype(bool)
+        return self._op("query", want_mask=True)["mask"].astype(bool)
 
     def op_observe(self, perspective):
-        o = np.zeros(136, np.float32)
-        lib().hc_observe(ptr(self.rec), int(perspective), ptr(o))
-        return o.astype(np.int64)
+        return self._op("query", want_obs=int(perspective))["obs"].astype(np.int64)
 
     def op_statistics(self):
-        s = np.zeros(10, np.float64)
-        lib().hc_statistics(ptr(self.rec), ptr(s))
-        return s
+        return self._op("query", want_stats=True)["stats"]
 
     def op_potential(self):
-        return lib().hc_potential(ptr(self.rec), self.pool)
+        return self._op("query", want_potential=True)["potential"]
 
     def op_runner_init(self):
-        return lib().hc_runner_reset(ptr(self.rec), self.fp, self.pool, ptr(self.mt), ptr(self.pos), 1)
+        return self._op("runner_init")["status"]
 
     def op_runner_reset(self):
-        return lib().hc_runner_reset(ptr(self.rec), self.fp, self.pool, ptr(self.mt), ptr(self.pos), 0)
+        return self._op("runner_reset")["status"]
 
     def op_runner_step(self, action):
-        rew, dn = C.c_int(0), C.c_int(0)
-        st = lib().hc_runner_step(ptr(self.rec), int(action), self.fp, self.pool, ptr(self.mt), ptr(self.pos), C.byref(rew), C.byref(dn))
-        return rew.value, bool(dn.value), st
+        o = self._op("runner_step", action)
+        return o["reward"], bool(o["done"]), o["status"]
 
     def op_sample_mask(self, mask):
         m = np.ascontiguousarray(np.asarray(mask, dtype=np.uint8).reshape(-1)[:180])
-        return lib().hc_sample_mask(ptr(m), ptr(self.mt), ptr(self.pos))
+        return self._op("sample_mask", mask_in=m)["action"]
 
 
 class EmuBackendX(EmuBackend):
@@ -218,10 +238,10 @@ class EmuBackendX(EmuBackend):
         from azul_deep_reinforcement_learning_amd.records import RECORD_NP_DTYPE
         return self.rec.copy().view(RECORD_NP_DTYPE)[0]
 
-    want_next, last_next = False, -2       # AZUL_WANT_NEXT_ACTION of the call being interpreted / the emulated kernel's answer
-
     def _op(self, op, action=0, **kw):
-        out = x_op(self.rec, self.players, self.fp, self.pool, self.ext, op, action, self.mt, self.pos, want_next=self.want_next, **kw)
+        out = x_op(self.rec, self.players, self.fp, self.pool, self.ext, op, action, self.mt, self.pos, want_next=self.want_next,
+                   pos_set=self.pos_set, **kw)
+        self.pos_set = None
         self.last_next = out["next_action"]
         return out
 
@@ -276,6 +296,9 @@ def _call_backend_class():
     from azul_deep_reinforcement_learning_amd import _lib as L
     from azul_deep_reinforcement_learning_amd.records import RECORD_DTYPE, RECORD_NP_DTYPE
 
+    NAMES = {L.CALL_QUERY: "query", L.CALL_INIT: "init", L.CALL_NEW_ROUND: "new_round", L.CALL_MOVE: "move", L.CALL_NEXT_PLAYER: "next_player",
+             L.CALL_COUNT_SCORE: "count_score", L.CALL_STEP: "step", L.CALL_RUNNER_INIT: "runner_init", L.CALL_RUNNER_RESET: "runner_reset",
+             L.CALL_RUNNER_STEP: "runner_step", L.CALL_SAMPLE_MASK: "sample_mask"}
     DRAWING = (L.CALL_INIT, L.CALL_NEW_ROUND, L.CALL_STEP, L.CALL_RUNNER_INIT, L.CALL_RUNNER_RESET, L.CALL_RUNNER_STEP, L.CALL_SAMPLE_MASK)
 
     class EmuCallBackend(fb.HipBackend):
@@ -295,57 +318,36 @@ def _call_backend_class():
                 e.mt[:] = np.frombuffer(C.string_at(c.mt_in, 2496), np.uint32)
                 e.pos[0] = c.pos_in
             elif (c.want & L.WANT_POS_IN) and draws:
-                e.pos[0] = c.pos_in
+                e.pos_set = int(c.pos_in)                  # (the kernel body installs it: OpArgs::pos_set / XOp::pos_set)
             mt0 = e.mt.copy()
-            st, c.reward, c.done, c.action = 0, 0, 0, 0
-            own_answer = hasattr(e, "last_next")           # the P-player core's kernel body answers AZUL_WANT_NEXT_ACTION itself
-            if own_answer:
-                e.want_next, e.last_next = bool(c.want & L.WANT_NEXT_ACTION), -2
-            if c.op == L.CALL_INIT:
-                e.op_init()
-            elif c.op == L.CALL_NEW_ROUND:
-                st = e.op_new_round()
-            elif c.op == L.CALL_MOVE:
-                e.op_move(c.arg)
-            elif c.op == L.CALL_NEXT_PLAYER:
-                e.op_next_player()
-            elif c.op == L.CALL_COUNT_SCORE:
-                e.op_count_score()
-            elif c.op == L.CALL_STEP:
-                st = e.op_step(c.arg)
-            elif c.op == L.CALL_RUNNER_INIT:
-                st = e.op_runner_init()
-            elif c.op == L.CALL_RUNNER_RESET:
-                st = e.op_runner_reset()
-            elif c.op == L.CALL_RUNNER_STEP:
-                c.reward, done, st = e.op_runner_step(c.arg)
-                c.done = int(done)
-            elif c.op == L.CALL_SAMPLE_MASK:
-                c.action = e.op_sample_mask(np.frombuffer(C.string_at(c.mask_in, NA), np.uint8))
-            c.status = int(st or 0)
-            if own_answer:
-                nxt, e.want_next = e.last_next, False
+            # ONE call of the kernel body, like the product's one launch: the op, then the queries on the state it leaves
+            name = NAMES[c.op]
+            if isinstance(e, EmuBackendX) and (name.startswith("runner") or c.want & L.WANT_POTENTIAL):
+                e._two_players_only()                       # (three / four players: refused like the library refuses it)
+            kw = {"want_mask": bool(c.want & L.WANT_MASK), "want_flags": bool(c.want & L.WANT_FLAGS), "want_stats": bool(c.want & L.WANT_STATS),
+                  "want_obs": (int(c.arg if c.op == L.CALL_QUERY else c.obs_persp) if c.want & L.WANT_OBS else None)}
+            if c.want & L.WANT_POTENTIAL:
+                kw["want_potential"] = True
+            if c.op == L.CALL_SAMPLE_MASK:
+                kw["mask_in"] = np.frombuffer(C.string_at(c.mask_in, NA), np.uint8)
+            e.want_next = bool(c.want & L.WANT_NEXT_ACTION)
+            out = e._op(name, c.arg, **kw)
+            e.want_next = False
+            c.status = int(out["status"])
+            c.reward, c.done = (int(out.get("reward", 0)), int(out.get("done", 0))) if c.op == L.CALL_RUNNER_STEP else (0, 0)
+            c.action = int(out["action"]) if c.op == L.CALL_SAMPLE_MASK else 0
             base = C.addressof(c)
             if c.want & L.WANT_MASK:
-                m = np.ascontiguousarray(e.op_mask(), dtype=np.uint8)
-                C.memmove(base + L.AzulCall.mask.offset, m.ctypes.data, NA)
+                C.memmove(base + L.AzulCall.mask.offset, np.ascontiguousarray(out["mask"], dtype=np.uint8).ctypes.data, NA)
             if c.want & L.WANT_OBS:
-                o = np.ascontiguousarray(e.op_observe(c.arg if c.op == L.CALL_QUERY else c.obs_persp), dtype=np.float32)
-                C.memmove(base + L.AzulCall.obs.offset, o.ctypes.data, 4 * self.obs_size)
-            c.flags = e.op_flags() if c.want & L.WANT_FLAGS else 0
-            c.potential = e.op_potential() if c.want & L.WANT_POTENTIAL else 0
+                C.memmove(base + L.AzulCall.obs.offset, np.ascontiguousarray(out["obs"], dtype=np.float32).ctypes.data, 4 * self.obs_size)
+            c.flags = int(out["flags"]) if c.want & L.WANT_FLAGS else 0
+            c.potential = int(out.get("potential", 0)) if c.want & L.WANT_POTENTIAL else 0
             if c.want & L.WANT_STATS:
-                sv = np.ascontiguousarray(e.op_statistics(), dtype=np.float64)
-                C.memmove(base + L.AzulCall.stats.offset, sv.ctypes.data, 80)
+                C.memmove(base + L.AzulCall.stats.offset, np.ascontiguousarray(out["stats"], dtype=np.float64).ctypes.data, 80)
             if c.want & L.WANT_RECORD:
                 C.memmove(c.record_out, e.rec.ctypes.data, RB)
-            c.next_action = -2
-            if own_answer:
-                c.next_action = nxt if (c.want & L.WANT_NEXT_ACTION) else -2
-            elif (c.want & L.WANT_NEXT_ACTION) and draws and c.status == 0 and int(e.pos[0]) + 2 <= 624:
-                keep = int(e.pos[0])
-                c.next_action = e.op_sample_mask(np.ascontiguousarray(e.op_mask(), dtype=np.uint8))
-                e.pos[0] = keep
+            c.next_action = int(e.last_next) if (c.want & L.WANT_NEXT_ACTION) else -2
             c.pos_out = int(e.pos[0])
             c.rng_regenerated = int(bool((e.mt != mt0).any()))
             if c.rng_regenerated and c.mt_out:

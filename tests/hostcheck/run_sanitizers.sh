@@ -6,12 +6,12 @@
 set -u
 cd "$(dirname "$0")/../.."
 LOG=${1:-profiles/round4_sanitizers.txt}
-make -s -C tests/hostcheck libhostcheck_asan.so libsimt_selfplay2_asan.so libsimt_selfplay2_ubsan.so libsimt_env2_asan.so libsimt_env2_ubsan.so libsimt_rules_x_asan.so libsimt_rules_x_ubsan.so || exit 1
+make -s -C tests/hostcheck libhostcheck_asan.so libsimt_selfplay2_asan.so libsimt_selfplay2_ubsan.so libsimt_env2_asan.so libsimt_env2_ubsan.so libsimt_rules_x_asan.so libsimt_rules_x_ubsan.so libsimt_rollout2_asan.so libsimt_rollout2_ubsan.so libsimt_learner_asan.so libsimt_learner_ubsan.so || exit 1
 ASAN=$(gcc -print-file-name=libasan.so); UBSAN=$(gcc -print-file-name=libubsan.so)
 {
   echo "# $(date -u +%FT%TZ)  g++ $(g++ -dumpversion)  -fsanitize=address,undefined -fno-sanitize-recover=all (an error aborts the test process)"
   echo "## csrc sha256 $(python tools/provenance.py)"
-  echo "## one-game-per-wave two-player core (hostcheck.cpp on azul_core.hpp), ASan + UBSan"
+  echo "## one-game-per-wave two-player core and the rule kernel's body (hostcheck.cpp on azul_core.hpp + azul_ops.hpp), ASan + UBSan"
   LD_PRELOAD="$ASAN $UBSAN" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 AZUL_HOSTCHECK_LIB=libhostcheck_asan.so \
     timeout 1500 python -m pytest tests/test_hostcheck_core.py tests/test_random_states.py tests/test_facade_runner.py -m "not gpu" -q -p no:cacheprovider 2>&1 | tail -4
   echo "## P-player / D-display rules + extended rules (azul_rules_x.hpp, unmodified: the bodies of azul_x_op_kernel / azul_x_selfplay_kernel) under the lockstep emulation, UBSan"
@@ -29,4 +29,14 @@ ASAN=$(gcc -print-file-name=libasan.so); UBSAN=$(gcc -print-file-name=libubsan.s
   echo "## the same, ASan + UBSan"
   LD_PRELOAD="$ASAN $UBSAN" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:detect_stack_use_after_return=0 AZUL_SIMT_ENV_LIB=libsimt_env2_asan.so \
     timeout 1500 python -m pytest tests/test_hostcheck_env2.py -q -p no:cacheprovider 2>&1 | tail -4
+  echo "## the persistent policy rollout kernels THEMSELVES (azul_rollout2.hpp / azul_policy.hpp, unmodified: workgroups of 8 / 16 emulated waves, MFMA + buffer loads + s_barrier emulated), UBSan"
+  LD_PRELOAD="$UBSAN" AZUL_SIMT_ROLLOUT_LIB=libsimt_rollout2_ubsan.so timeout 1500 python -m pytest tests/test_hostcheck_rollout2.py -q -p no:cacheprovider 2>&1 | tail -4
+  echo "## the same, ASan + UBSan"
+  LD_PRELOAD="$ASAN $UBSAN" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:detect_stack_use_after_return=0 AZUL_SIMT_ROLLOUT_LIB=libsimt_rollout2_asan.so \
+    timeout 1500 python -m pytest tests/test_hostcheck_rollout2.py -q -p no:cacheprovider 2>&1 | tail -4
+  echo "## the A2C gradient kernel and the ActorCritic forward + head kernel (azul_learner.hpp / azul_policy.hpp, unmodified) against torch autograd, UBSan"
+  LD_PRELOAD="$UBSAN" AZUL_SIMT_LEARNER_LIB=libsimt_learner_ubsan.so timeout 1500 python -m pytest tests/test_hostcheck_learner.py -q -p no:cacheprovider 2>&1 | tail -4
+  echo "## the same, ASan + UBSan"
+  LD_PRELOAD="$ASAN $UBSAN" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:detect_stack_use_after_return=0 AZUL_SIMT_LEARNER_LIB=libsimt_learner_asan.so \
+    timeout 1500 python -m pytest tests/test_hostcheck_learner.py -q -p no:cacheprovider 2>&1 | tail -4
 } | tee "$LOG"

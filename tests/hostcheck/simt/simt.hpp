@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #include <ucontext.h>
 
 #if defined(__SANITIZE_ADDRESS__)
@@ -28,7 +29,7 @@ extern "C" void __sanitizer_finish_switch_fiber(void *fake_stack_save, const voi
 namespace simt {
 
 enum { W = 64, MAXPATH = 48, STACK_BYTES = 1 << 20 };
-enum Op { OP_NONE = 0, OP_BALLOT, OP_READLANE, OP_BPERMUTE, OP_DPP, OP_SWAP16, OP_BARRIER, OP_READFIRST };
+enum Op { OP_NONE = 0, OP_BALLOT, OP_READLANE, OP_BPERMUTE, OP_DPP, OP_SWAP16, OP_BARRIER, OP_READFIRST, OP_MFMA16X4, OP_WGBARRIER };
 
 struct Lane {
     ucontext_t ctx;
@@ -51,11 +52,15 @@ struct Wave {
     void (*fn)(void *);
     void *arg;
     uint64_t collectives;
+    int id;                     // wave of its workgroup (run_workgroup); 0 for run_wave
+    bool at_wg_barrier;         // every live lane is parked at s_barrier: the wave waits for the workgroup's other waves
 };
 
 static Wave *g_wave = nullptr;
 
 static inline unsigned lane_id() { return (unsigned)g_wave->cur; }
+static inline unsigned wave_id() { return (unsigned)g_wave->id; }
+static inline unsigned thread_id() { return 64u * wave_id() + lane_id(); }      // threadIdx.x of a one-dimensional workgroup
 
 static void to_scheduler()
 {
@@ -175,26 +180,68 @@ static void execute_group(Wave *w, const bool *in)
         }
         break;
     case OP_BARRIER: break;
+    case OP_MFMA16X4: {
+        // v_mfma_f32_16x16x4_f32: D = A (16 x 4) * B (4 x 16) + C.  Lane l supplies A[l % 16][l / 16] and B[l / 16][l % 16] and holds
+        // C / D[4 (l / 16) + r][l % 16] for r = 0..3 (CDNA3 ISA guide, "MFMA 16x16x4 F32" register layout); the four products of an
+        // element are added in ascending k with fused multiply-adds.  Executed with all 64 lanes (EXEC is ignored by the hardware too).
+        for (int l = 0; l < W; l++) if (!in[l]) { fprintf(stderr, "simt: MFMA issued with lane %d inactive\n", l); abort(); }
+        float A[16][4], B[4][16];
+        for (int l = 0; l < W; l++) {
+            uint32_t ua = (uint32_t)w->lane[l].a, ub = (uint32_t)w->lane[l].b;
+            memcpy(&A[l % 16][l / 16], &ua, 4);
+            memcpy(&B[l / 16][l % 16], &ub, 4);
+        }
+        for (int l = 0; l < W; l++) {
+            Lane &x = w->lane[l];
+            uint32_t cu[4] = {(uint32_t)x.c, (uint32_t)(x.c >> 32), (uint32_t)x.d, (uint32_t)(x.d >> 32)}, du[4];
+            for (int r = 0; r < 4; r++) {
+                float acc;
+                memcpy(&acc, &cu[r], 4);
+                const int i = 4 * (l / 16) + r, j = l % 16;
+                for (int k = 0; k < 4; k++) acc = fmaf(A[i][k], B[k][j], acc);
+                memcpy(&du[r], &acc, 4);
+            }
+            x.r0 = (uint64_t)du[0] | ((uint64_t)du[1] << 32);
+            x.r1 = (uint64_t)du[2] | ((uint64_t)du[3] << 32);
+        }
+    } break;
+    case OP_WGBARRIER:
+        // s_barrier: handled by run_workgroup (the wave waits for the others); a PARTIAL group here is a divergent barrier
+        for (int l = 0; l < W; l++) if (!in[l] && w->lane[l].state != 2) { fprintf(stderr, "simt: s_barrier reached by part of wave %d only\n", w->id); abort(); }
+        w->at_wg_barrier = true;
+        return;                                                      // (the lanes stay parked)
     default: fprintf(stderr, "simt: empty group\n"); abort();
     }
     for (int l = 0; l < W; l++) if (in[l]) w->lane[l].state = 0;
 }
 
-// run fn(arg) on 64 lanes in lockstep; returns the number of cross-lane operations executed
-static uint64_t run_wave(void (*fn)(void *), void *arg)
+static Wave *wave_create(void (*fn)(void *), void *arg, int id, size_t stack_bytes)
 {
     Wave *w = (Wave *)calloc(1, sizeof(Wave));
-    g_wave = w;
-    w->fn = fn; w->arg = arg; w->cur = -1;
+    w->fn = fn; w->arg = arg; w->cur = -1; w->id = id;
     for (int l = 0; l < W; l++) {
         Lane &x = w->lane[l];
-        x.stack = (char *)malloc(STACK_BYTES);
+        x.stack = (char *)malloc(stack_bytes);
         getcontext(&x.ctx);
         x.ctx.uc_stack.ss_sp = x.stack;
-        x.ctx.uc_stack.ss_size = STACK_BYTES;
+        x.ctx.uc_stack.ss_size = stack_bytes;
         x.ctx.uc_link = &w->main;
+        g_wave = w;
         makecontext(&x.ctx, trampoline, 0);
     }
+    return w;
+}
+
+static void wave_destroy(Wave *w)
+{
+    for (int l = 0; l < W; l++) free(w->lane[l].stack);
+    free(w);
+}
+
+// run the wave until every lane has finished or the wave waits at a workgroup barrier; returns false when it has finished
+static bool wave_advance(Wave *w, size_t stack_bytes)
+{
+    g_wave = w;
     for (;;) {
         bool any = false;
         for (int l = 0; l < W; l++) {
@@ -203,7 +250,7 @@ static uint64_t run_wave(void (*fn)(void *), void *arg)
             any = true;
             w->cur = l;
 #if SIMT_ASAN
-            __sanitizer_start_switch_fiber(&w->main_fake, x.stack, STACK_BYTES);
+            __sanitizer_start_switch_fiber(&w->main_fake, x.stack, stack_bytes);
 #endif
             swapcontext(&w->main, &x.ctx);
 #if SIMT_ASAN
@@ -212,16 +259,63 @@ static uint64_t run_wave(void (*fn)(void *), void *arg)
             w->cur = -1;
         }
         if (any) continue;
+        // the earliest group -- but lanes waiting at s_barrier go LAST: a half of the wave that skipped a divergent region and ran on to
+        // the barrier at the top of the NEXT loop iteration sits at a lower code address than the lanes still inside the region, and the
+        // hardware reaches that barrier only after the region (address order is execution order only up to a loop's back edge)
         int first = -1;
-        for (int l = 0; l < W; l++) if (w->lane[l].state == 1 && (first < 0 || path_cmp(w->lane[l], w->lane[first]) < 0)) first = l;
-        if (first < 0) break;                                        // every lane has finished
+        bool others = false;
+        for (int l = 0; l < W; l++) if (w->lane[l].state == 1 && w->lane[l].op != OP_WGBARRIER) others = true;
+        for (int l = 0; l < W; l++) {
+            const Lane &x = w->lane[l];
+            if (x.state != 1 || (others && x.op == OP_WGBARRIER)) continue;
+            if (first < 0 || path_cmp(x, w->lane[first]) < 0) first = l;
+        }
+        if (first < 0) return false;                                 // every lane has finished
         bool in[W];
-        for (int l = 0; l < W; l++) in[l] = w->lane[l].state == 1 && path_cmp(w->lane[l], w->lane[first]) == 0;
+        for (int l = 0; l < W; l++) in[l] = w->lane[l].state == 1 && w->lane[l].op == w->lane[first].op && path_cmp(w->lane[l], w->lane[first]) == 0;
         execute_group(w, in);
+        if (w->at_wg_barrier) return true;
     }
+}
+
+// run fn(arg) on 64 lanes in lockstep; returns the number of cross-lane operations executed
+static uint64_t run_wave(void (*fn)(void *), void *arg)
+{
+    Wave *w = wave_create(fn, arg, 0, STACK_BYTES);
+    if (wave_advance(w, STACK_BYTES)) { fprintf(stderr, "simt: s_barrier in a single-wave run\n"); abort(); }
     uint64_t n = w->collectives;
-    for (int l = 0; l < W; l++) free(w->lane[l].stack);
-    free(w);
+    wave_destroy(w);
+    g_wave = nullptr;
+    return n;
+}
+
+// run fn(arg) as ONE WORKGROUP of n_waves wavefronts (threadIdx.x = 64 wave + lane): the waves take turns, each running until it
+// finishes or waits at s_barrier; when every unfinished wave waits there, all are released.  (Waves only meet at barriers: LDS
+// traffic between them is ordered by those, like on the hardware.)  Returns the number of cross-lane operations executed.
+static uint64_t run_workgroup(void (*fn)(void *), void *arg, int n_waves, size_t stack_bytes = 256u << 10)
+{
+    enum { MAXWAVES = 16 };
+    if (n_waves < 1 || n_waves > MAXWAVES) { fprintf(stderr, "simt: 1..16 waves per workgroup\n"); abort(); }
+    Wave *ws[MAXWAVES];
+    bool done[MAXWAVES];
+    for (int i = 0; i < n_waves; i++) { ws[i] = wave_create(fn, arg, i, stack_bytes); done[i] = false; }
+    for (;;) {
+        int waiting = 0, live = 0;
+        for (int i = 0; i < n_waves; i++) {
+            if (done[i]) continue;
+            if (!ws[i]->at_wg_barrier) done[i] = !wave_advance(ws[i], stack_bytes);
+            if (!done[i]) { live++; waiting += ws[i]->at_wg_barrier ? 1 : 0; }
+        }
+        if (live == 0) break;
+        if (waiting != live) { fprintf(stderr, "simt: workgroup neither finished nor at a barrier\n"); abort(); }
+        for (int i = 0; i < n_waves; i++) {
+            if (done[i]) continue;
+            ws[i]->at_wg_barrier = false;
+            for (int l = 0; l < W; l++) if (ws[i]->lane[l].state == 1) ws[i]->lane[l].state = 0;     // (all of them are parked at the barrier)
+        }
+    }
+    uint64_t n = 0;
+    for (int i = 0; i < n_waves; i++) { n += ws[i]->collectives; wave_destroy(ws[i]); }
     g_wave = nullptr;
     return n;
 }
@@ -244,6 +338,35 @@ static inline Pair permlane16_swap(uint32_t vdst, uint32_t vsrc, bool, bool)
     return p;
 }
 static inline void wave_barrier() { park(OP_BARRIER, 0); }
+static inline void wg_barrier() { park(OP_WGBARRIER, 0); }
+template <class V4>
+static inline V4 mfma_f32_16x16x4f32(float a, float b, V4 c)
+{
+    uint32_t ua, ub, cu[4];
+    memcpy(&ua, &a, 4); memcpy(&ub, &b, 4);
+    for (int r = 0; r < 4; r++) { float f = c[r]; memcpy(&cu[r], &f, 4); }
+    park(OP_MFMA16X4, ua, ub, (uint64_t)cu[0] | ((uint64_t)cu[1] << 32), (uint64_t)cu[2] | ((uint64_t)cu[3] << 32));
+    const Lane &me = g_wave->lane[g_wave->cur];
+    const uint32_t du[4] = {(uint32_t)me.r0, (uint32_t)(me.r0 >> 32), (uint32_t)me.r1, (uint32_t)(me.r1 >> 32)};
+    V4 d = c;
+    for (int r = 0; r < 4; r++) { float f; memcpy(&f, &du[r], 4); d[r] = f; }
+    return d;
+}
+// buffer resources: base + size; an access outside [0, size) reads 0 like the hardware's range check -- and is COUNTED, so that a
+// test can require that the kernel never relies on it
+struct Rsrc { const char *base; uint32_t bytes; };
+static uint64_t g_buffer_oob = 0;
+template <int N>
+struct Words { uint32_t v[N]; };
+template <int N>
+static inline Words<N> buffer_load(Rsrc r, uint32_t voff, uint32_t soff)
+{
+    Words<N> out;
+    const uint64_t at = (uint64_t)voff + soff;
+    if (at + 4u * N > r.bytes) { g_buffer_oob++; memset(&out, 0, sizeof(out)); return out; }
+    memcpy(&out, r.base + at, sizeof(out));
+    return out;
+}
 static inline uint32_t mbcnt_lo(uint32_t mask, uint32_t base) { unsigned l = lane_id(); return base + (uint32_t)__builtin_popcount(mask & (l >= 32u ? 0xffffffffu : ((1u << l) - 1u))); }
 static inline uint32_t mbcnt_hi(uint32_t mask, uint32_t base) { unsigned l = lane_id(); return base + (l > 32u ? (uint32_t)__builtin_popcount(mask & ((1u << (l - 32u)) - 1u)) : 0u); }
 

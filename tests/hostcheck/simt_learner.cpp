@@ -1,0 +1,71 @@
+// simt_learner.cpp -- TEST-ONLY: the A2C gradient kernel (csrc/azul_learner.hpp: azul_a2c_grad_kernel -- forward + backward of the
+// reference's loss on the f32 matrix cores, weight-gradient tiles in registers) and the ActorCritic forward + head kernel
+// (csrc/azul_policy.hpp: azul_policy_forward_kernel), UNMODIFIED, as workgroups of emulated wavefronts (simt/simt.hpp) -- a CPU check of
+// their arithmetic against torch autograd and, under ASan / UBSan, of every LDS and global index they form.
+#define __HIPCC__ 1
+#include "azul_hip.h"
+#include "azul_wave.hpp"
+#include "azul_core.hpp"
+#include "azul_tables.hpp"
+using namespace az;
+#include "azul_ops.hpp"
+#include "azul_selfplay2.hpp"
+#include "azul_policy.hpp"
+#include "azul_rollout2.hpp"
+#include "azul_learner.hpp"
+
+struct GradJob { PolicyWeights W; LearnerArgs a; };
+static void grad_lane(void *arg) { GradJob *j = (GradJob *)arg; azul_a2c_grad_kernel(j->W, j->a); }
+
+struct FwdJob { const float *obs; const uint8_t *mask; PolicyWeights W; u64 seed, counter; u32 n; float *value; i32 *action; float *logp, *entropy, *logits; u32 id_base; };
+static void fwd_lane(void *arg)
+{
+    FwdJob *j = (FwdJob *)arg;
+    azul_policy_forward_kernel(j->obs, j->mask, j->W, j->seed, j->counter, nullptr, 0, j->n, j->value, j->action, j->logp, j->entropy, j->logits, j->id_base);
+}
+
+extern "C" {
+
+unsigned long long sl_buffer_oob() { return simt::g_buffer_oob; }
+void sl_layout(int *out) { out[0] = LG_P_W1; out[1] = LG_P_B1; out[2] = LG_P_W2C; out[3] = LG_P_B2C; out[4] = LG_P_W2A; out[5] = LG_P_B2A; out[6] = LG_P_LOSS; out[7] = LG_P_TOTAL; }
+
+// the gradient kernel on n samples with `parts` workgroups, then azul_a2c_reduce_kernel's sum in workgroup order -> grad [LG_P_TOTAL]
+long long sl_gradients(int n, int parts, const float *obs, const uint8_t *mask, const i32 *action, const float *qvals, const i32 *index, float inv_n,
+                       const float *w1t, const float *b1, const float *w2c, const float *b2c, const float *w2a_t, const float *b2a,
+                       const float *w2a, float *partial /* [parts][LG_P_TOTAL] */, float *grad)
+{
+    GradJob j;
+    memset(&j, 0, sizeof(j));
+    j.W = {w1t, b1, w2c, b2c, w2a_t, b2a};
+    j.a.obs = obs; j.a.mask = mask; j.a.action = action; j.a.qvals = qvals; j.a.n = (u32)n; j.a.inv_n = inv_n; j.a.w2a = w2a;
+    j.a.partial = partial; j.a.index = index;
+    simt::g_grid_dim = {(unsigned)parts, 1, 1};
+    long long ops = 0;
+    for (int blk = 0; blk < parts; blk++) {
+        simt::g_block_idx = {(unsigned)blk, 0, 0};
+        ops += (long long)simt::run_workgroup(grad_lane, &j, (int)LG_WAVES, 512u << 10);
+    }
+    for (int p = 0; p < LG_P_TOTAL; p++) {                 // (azul_a2c_reduce_kernel: the partials added in workgroup order)
+        float s = 0.f;
+        for (int i = 0; i < parts; i++) s += partial[(size_t)i * LG_P_TOTAL + p];
+        grad[p] = s;
+    }
+    return ops;
+}
+
+long long sl_forward(int n, const float *obs, const uint8_t *mask, const float *w1t, const float *b1, const float *w2c, const float *b2c,
+                     const float *w2a_t, const float *b2a, unsigned long long seed, unsigned long long counter, unsigned id_base,
+                     float *value, i32 *action, float *logp, float *entropy, float *logits)
+{
+    FwdJob j = {obs, mask, {w1t, b1, w2c, b2c, w2a_t, b2a}, seed, counter, (u32)n, value, action, logp, entropy, logits, id_base};
+    const unsigned blocks = ((unsigned)n + PF_GAMES - 1u) / PF_GAMES;
+    simt::g_grid_dim = {blocks, 1, 1};
+    long long ops = 0;
+    for (unsigned blk = 0; blk < blocks; blk++) {
+        simt::g_block_idx = {blk, 0, 0};
+        ops += (long long)simt::run_workgroup(fwd_lane, &j, 4);
+    }
+    return ops;
+}
+
+}

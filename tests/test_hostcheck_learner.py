@@ -1,0 +1,131 @@
+"""The matrix-core kernels of rows N1 / N2 on CPU: azul_policy_forward_kernel (csrc/azul_policy.hpp: the ActorCritic forward of
+model.py:22-41 + the sampling head) and azul_a2c_grad_kernel (csrc/azul_learner.hpp: forward + backward of the loss of agent.py:39-62,
+weight-gradient tiles in registers), compiled UNMODIFIED by g++ and run as workgroups of emulated wavefronts (tests/hostcheck/simt:
+MFMA, buffer loads, s_barrier) against PyTorch on the CPU: values / logits / log-probs / entropies of the forward, and the full
+82,081-element gradient + loss sums against autograd of the reference's loss.  Under ASan / UBSan (run_sanitizers.sh) every LDS and
+global index these kernels form is checked too."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostcheck")
+
+
+def load(name=None):
+    name = name or os.environ.get("AZUL_SIMT_LEARNER_LIB", "libsimt_learner.so")
+    subprocess.check_call(["make", "-s", "-C", HERE, name], stdout=subprocess.DEVNULL)
+    L = C.CDLL(os.path.join(HERE, name))
+    L.sl_gradients.restype = C.c_longlong
+    L.sl_gradients.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 9
+    L.sl_forward.restype = C.c_longlong
+    L.sl_forward.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_ulonglong, C.c_ulonglong, C.c_uint] + [C.c_void_p] * 5
+    L.sl_buffer_oob.restype = C.c_ulonglong
+    return L
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def make(seed, n):
+    rs = np.random.RandomState(seed)
+    w = {"w1t": rs.randn(136, 360) * 0.08, "b1": rs.randn(360) * 0.05, "w2c": rs.randn(180) * 0.1, "b2c": rs.randn(1) * 0.1,
+         "w2a_t": rs.randn(180, 180) * 0.12, "b2a": rs.randn(180) * 0.05}
+    w = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in w.items()}
+    w["w2a"] = np.ascontiguousarray(w["w2a_t"].T)                      # actor_linear2.weight as PyTorch stores it
+    obs = rs.randint(0, 6, size=(n, 136)).astype(np.float32)
+    mask = rs.rand(n, 180) < 0.2
+    action = rs.randint(0, 180, n).astype(np.int32)
+    mask[np.arange(n), action] = True
+    q = (rs.randn(n) * 5).astype(np.float32)
+    return w, obs, np.ascontiguousarray(mask.astype(np.uint8)), action, q
+
+
+def torch_forward(w, obs, mask):
+    t = {k: torch.tensor(v, dtype=torch.float32, requires_grad=True) for k, v in w.items() if k != "w2a"}
+    x = torch.tensor(obs)
+    h = torch.relu(x @ t["w1t"] + t["b1"])
+    value = h[:, :180] @ t["w2c"] + t["b2c"]
+    logits = h[:, 180:] @ t["w2a_t"] + t["b2a"]
+    legal = torch.tensor(mask.astype(bool))
+    logp = torch.log_softmax(logits.masked_fill(~legal, float("-inf")), dim=1)
+    ent = -(torch.where(legal, logp, torch.zeros_like(logp)).sum(1) / legal.sum(1))
+    return t, value, logits, logp, ent
+
+
+def test_forward_kernel_under_emulation_matches_torch():
+    L = load()
+    n = 37                                                              # ragged last workgroup of 16
+    w, obs, mask, _, _ = make(3, n)
+    mask[5] = 0                                                         # nothing legal: action -1, log-prob / entropy 0
+    value, logp, ent = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    action, logits = np.zeros(n, np.int32), np.zeros((n, 180), np.float32)
+    oob0 = L.sl_buffer_oob()
+    ops = L.sl_forward(n, ptr(obs), ptr(mask), ptr(w["w1t"]), ptr(w["b1"]), ptr(w["w2c"]), ptr(w["b2c"]), ptr(w["w2a_t"]), ptr(w["b2a"]),
+                       99, 7, 500, ptr(value), ptr(action), ptr(logp), ptr(ent), ptr(logits))
+    assert ops > 1000 and L.sl_buffer_oob() == oob0
+    keep = np.arange(n) != 5
+    mk = mask.copy()
+    mk[5, 0] = 1
+    _, tv, tl, tlogp, tent = torch_forward(w, obs, mk)
+    assert np.allclose(value, tv.detach().numpy(), atol=2e-4, rtol=1e-4)
+    assert np.allclose(logits, tl.detach().numpy(), atol=2e-4, rtol=1e-4)
+    assert action[5] == -1 and logp[5] == 0 and ent[5] == 0
+    rows = np.arange(n)[keep]
+    assert (mask[rows, action[rows]] == 1).all()
+    assert np.allclose(logp[keep], tlogp.detach().numpy()[rows, action[rows]], atol=2e-4)
+    assert np.allclose(ent[keep], tent.detach().numpy()[keep], atol=2e-4, rtol=1e-4)
+    # the same call again: the same draws (Philox keyed by seed, counter and global id)
+    a2 = np.zeros(n, np.int32)
+    L.sl_forward(n, ptr(obs), ptr(mask), ptr(w["w1t"]), ptr(w["b1"]), ptr(w["w2c"]), ptr(w["b2c"]), ptr(w["w2a_t"]), ptr(w["b2a"]),
+                 99, 7, 500, ptr(value), ptr(a2), ptr(logp), ptr(ent), ptr(logits))
+    assert np.array_equal(a2, action)
+
+
+def test_gradient_kernel_under_emulation_matches_autograd_of_the_references_loss():
+    L = load()
+    lay = (C.c_int * 8)()
+    L.sl_layout(lay)
+    W1, B1, W2C, B2C, W2A, B2A, LOSS, TOTAL = list(lay)
+    n, parts = 75, 2                                                    # 32-sample passes, a ragged last one, two workgroups
+    w, obs, mask, action, q = make(11, n)
+    partial, grad = np.zeros((parts, TOTAL), np.float32), np.zeros(TOTAL, np.float32)
+    oob0 = L.sl_buffer_oob()
+    ops = L.sl_gradients(n, parts, ptr(obs), ptr(mask), ptr(action), ptr(q), None, 1.0 / n, ptr(w["w1t"]), ptr(w["b1"]), ptr(w["w2c"]),
+                         ptr(w["b2c"]), ptr(w["w2a_t"]), ptr(w["b2a"]), ptr(w["w2a"]), ptr(partial), ptr(grad))
+    assert ops > 1000 and L.sl_buffer_oob() == oob0
+    # agent.py:45-57: adv = q - v (not detached), actor = -logp[a] * adv, critic = 0.5 adv^2, entropy term 0.1 * (-mean legal logp)
+    t, value, _, logp, ent = torch_forward(w, obs, mask)
+    adv = torch.tensor(q) - value
+    lp = logp[torch.arange(n), torch.tensor(action.astype(np.int64))]
+    actor, critic, entropy = (-lp * adv).sum(), (0.5 * adv * adv).sum(), ent.sum()
+    loss = (actor + critic + 0.1 * entropy) / n
+    loss.backward()
+    ref = {k: v.grad.numpy() for k, v in t.items()}
+
+    def close(got, want, what):
+        scale = max(1e-3, float(np.abs(want).max()))
+        assert np.abs(got - want).max() < 3e-4 * scale, (what, float(np.abs(got - want).max()), scale)
+
+    close(grad[W1:W1 + 136 * 360].reshape(136, 360), ref["w1t"], "dw1t")
+    close(grad[B1:B1 + 360], ref["b1"], "db1")
+    close(grad[W2C:W2C + 180], ref["w2c"], "dw2c")
+    close(grad[B2C:B2C + 1], ref["b2c"], "db2c")
+    close(grad[W2A:W2A + 180 * 180].reshape(180, 180), ref["w2a_t"], "dw2a_t")
+    close(grad[B2A:B2A + 180], ref["b2a"], "db2a")
+    sums = grad[LOSS:LOSS + 4]
+    assert abs(sums[3] - n) < 1e-3
+    # the logged sums: actor term, critic term as the reference logs it (advantage^2: agent.py:50 takes half of it into the loss), entropy
+    want = np.array([float(actor.detach()), 2.0 * float(critic.detach()), float(entropy.detach())])
+    assert np.allclose(sums[:3], want, rtol=2e-4, atol=2e-3), (sums, want)
+    # a device-built selection: sample s lives in row index[s] of the arrays -- the same samples in the same order, the same bits
+    perm = np.random.RandomState(2).permutation(n)
+    index = np.ascontiguousarray(np.argsort(perm).astype(np.int32))
+    stored = [np.ascontiguousarray(x[perm]) for x in (obs, mask, action, q)]
+    g2, p2 = np.zeros(TOTAL, np.float32), np.zeros((parts, TOTAL), np.float32)
+    L.sl_gradients(n, parts, ptr(stored[0]), ptr(stored[1]), ptr(stored[2]), ptr(stored[3]), ptr(index), 1.0 / n, ptr(w["w1t"]), ptr(w["b1"]),
+                   ptr(w["w2c"]), ptr(w["b2c"]), ptr(w["w2a_t"]), ptr(w["b2a"]), ptr(w["w2a"]), ptr(p2), ptr(g2))
+    assert np.array_equal(g2, grad)

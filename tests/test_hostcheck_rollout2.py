@@ -1,0 +1,126 @@
+"""The persistent policy rollout kernel ITSELF on CPU: azul_policy_rollout2_kernel (csrc/azul_rollout2.hpp -- env phases, matrix phases
+on v_mfma_f32_16x16x4_f32 with weights streamed through buffer loads, the sampling head, trajectory slots written by the idle waves,
+the fused returns scan), compiled UNMODIFIED by g++ and run as a workgroup of eight emulated wavefronts (tests/hostcheck/simt:
+run_workgroup, s_barrier, MFMA and buffer-load emulation).  Checked per move and game:
+  * the network: value, log-prob of the sampled action and the entropy term against a numpy fp32 forward of the same weights on the
+    observation the kernel recorded (model.py:22-41, agent.py:64-72), within fp32 tolerance;
+  * the sampled action is legal;
+  * the env: the kernel's own actions replayed through the oracle give the recorded observations, masks, players, rewards, done flags,
+    final records, MT19937 words and counters (game_runner.py:43-97, nn_runner.py:17-47);
+  * the returns scan (nn_runner.py:70-76) and that no buffer load ever left its resource.
+Under ASan / UBSan (tests/hostcheck/run_sanitizers.sh) every LDS and global index the kernel forms is checked as well."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as oz
+from tests.test_hostcheck_env2 import RULES, oracle_play, ptr, start_batch
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostcheck")
+
+
+def load(name=None):
+    name = name or os.environ.get("AZUL_SIMT_ROLLOUT_LIB", "libsimt_rollout2.so")
+    subprocess.check_call(["make", "-s", "-C", HERE, name], stdout=subprocess.DEVNULL)
+    L = C.CDLL(os.path.join(HERE, name))
+    L.sr2_rollout.restype = C.c_longlong
+    L.sr2_rollout.argtypes = ([C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_uint] + [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 11
+                              + [C.c_float, C.c_ulonglong, C.c_ulonglong, C.c_int])
+    L.sr2_buffer_oob.restype = C.c_ulonglong
+    return L
+
+
+def weights(seed):
+    rs = np.random.RandomState(seed)
+    w = {"w1t": rs.randn(136, 360) * 0.08, "b1": rs.randn(360) * 0.05, "w2c": rs.randn(180) * 0.1, "b2c": rs.randn(1) * 0.1,
+         "w2a_t": rs.randn(180, 180) * 0.12, "b2a": rs.randn(180) * 0.05}
+    return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in w.items()}
+
+
+def forward(w, obs, mask):
+    """model.py:22-41 on one observation, fp32; masked log-softmax and the entropy term of agent.py:64-72 / nn_runner.py:32-40."""
+    h = np.maximum(obs.astype(np.float32) @ w["w1t"] + w["b1"], np.float32(0))
+    value = np.float32(h[:180] @ w["w2c"] + w["b2c"][0])
+    logits = (h[180:] @ w["w2a_t"] + w["b2a"]).astype(np.float64)
+    legal = mask.astype(bool)
+    z = logits[legal]
+    lse = z.max() + np.log(np.exp(z - z.max()).sum())
+    logp = np.full(180, -np.inf)
+    logp[legal] = z - lse
+    return float(value), logp, float(-logp[legal].mean())
+
+
+def run(L, first, pool, opponent, n, T, seed0, warm=0, gamma=0.9, with_returns=True, v1=False):
+    state, mt, pos = start_batch(n, seed0, first, pool, warm)
+    state0, mt0, pos0 = state.copy(), mt.copy(), pos.copy()
+    ep, stuck, ss = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros((n, 10))
+    w = weights(seed0)
+    o = {"obs": np.full((T + 1, n, 136), -99, np.float32), "mask": np.full((T + 1, n, 180), 0xEE, np.uint8),
+         "player": np.full((T + 1, n), 9, np.uint8), "action": np.full((T, n), -7, np.int32), "reward": np.full((T, n), -7777, np.int32),
+         "done": np.full((T, n), 9, np.uint8), "value": np.full((T, n), np.nan, np.float32), "logp": np.full((T, n), np.nan, np.float32),
+         "entropy": np.full((T, n), np.nan, np.float32), "status": np.full(n, 99, np.uint8),
+         "returns": np.full((T, n), np.nan, np.float32)}
+    oob0 = L.sr2_buffer_oob()
+    ops = L.sr2_rollout(n, ptr(state), ptr(mt), ptr(pos), ptr(ep), ptr(stuck), ptr(ss), first, pool, int(opponent), 1000,
+                        ptr(w["w1t"]), ptr(w["b1"]), ptr(w["w2c"]), ptr(w["b2c"]), ptr(w["w2a_t"]), ptr(w["b2a"]), T,
+                        ptr(o["obs"]), ptr(o["mask"]), ptr(o["player"]), ptr(o["action"]), ptr(o["reward"]), ptr(o["done"]),
+                        ptr(o["value"]), ptr(o["logp"]), ptr(o["entropy"]), ptr(o["status"]), ptr(o["returns"]) if with_returns else None,
+                        gamma, 4242, 17, int(v1))
+    assert ops > 0
+    assert L.sr2_buffer_oob() == oob0                       # no weight fragment was ever requested outside its matrix
+    episodes = 0
+    for g in range(n):
+        tag = (first, pool, opponent, g)
+        # -- the network and the head, move by move, on what the kernel recorded
+        for t in range(T):
+            a = int(o["action"][t, g])
+            mask = o["mask"][t, g]
+            assert set(np.unique(mask)) <= {0, 1} and 0 <= a < 180 and mask[a] == 1, (tag, t)
+            value, logp, ent = forward(w, o["obs"][t, g], mask)
+            assert abs(o["value"][t, g] - value) < 2e-4 * max(1.0, abs(value)), (tag, t)
+            assert abs(o["logp"][t, g] - logp[a]) < 2e-4, (tag, t)
+            assert abs(o["entropy"][t, g] - ent) < 2e-4 * max(1.0, ent), (tag, t)
+        # -- the env: the kernel's actions through the oracle
+        acts = o["action"][:, g]
+        e, rec, mt_e, idx = oracle_play(state0[g].view(oz.RECORD_DTYPE)[0], mt0[g], pos0[g], T, first, pool, opponent, lambda m, t: int(acts[t]))
+        assert np.array_equal(o["mask"][:, g].astype(bool), np.array(e["mask"], bool)), tag
+        assert np.array_equal(o["obs"][:, g].astype(np.int64), np.array(e["obs"])), tag
+        assert np.array_equal(o["player"][:, g], np.array(e["player"])), tag
+        assert np.array_equal(o["reward"][:, g], np.array(e["reward"])), tag
+        assert np.array_equal(o["done"][:, g].astype(bool), np.array(e["done"])), tag
+        assert state[g].tobytes() == rec.tobytes() and int(pos[g]) == idx and np.array_equal(mt[g], mt_e), tag
+        assert int(ep[g]) == int(np.sum(e["done"])) and int(stuck[g]) == 0 and int(o["status"][g]) == 0, tag
+        episodes += int(np.sum(e["done"]))
+        if with_returns:
+            q, want = np.float32(0), np.zeros(T, np.float32)
+            for t in range(T - 1, -1, -1):
+                q = np.float32(o["reward"][t, g]) + np.float32(gamma) * (np.float32(0) if o["done"][t, g] else q)
+                want[t] = q
+            assert np.array_equal(o["returns"][:, g], want), tag
+    return ops, episodes
+
+
+@pytest.mark.parametrize("ruleset", ["lid_randomfirst", "random_first1"])
+def test_policy_on_both_sides(ruleset):
+    L = load()
+    first, pool = RULES[ruleset]
+    ops, _ = run(L, first, pool, False, n=16, T=7, seed0=60, warm=30)
+    assert ops > 5000
+
+
+def test_random_agent_opponent_and_a_ragged_last_workgroup():
+    L = load()
+    first, pool = RULES["lid_randomfirst"]
+    ops, _ = run(L, first, pool, True, n=19, T=5, seed0=80, warm=45)
+    assert ops > 5000
+
+
+def test_one_game_per_wave_rollout_kernel_plays_the_same_trajectory():
+    """azul_policy_rollout_kernel (round 1's kernel, sixteen waves, the A/B partner behind AZUL_ROLLOUT_KERNEL=1): the same checks, and --
+    the arithmetic per output element being the same k-ordered chain -- the same actions as the two-games-per-wave kernel."""
+    L = load()
+    first, pool = RULES["lid_randomfirst"]
+    run(L, first, pool, False, n=16, T=4, seed0=60, warm=30, with_returns=False, v1=True)

@@ -68,4 +68,28 @@ long long sl_forward(int n, const float *obs, const uint8_t *mask, const float *
     return ops;
 }
 
+
+// azul_select_episode_samples' two launches (one wave per game, four games per workgroup) on host memory
+struct SelJob { const uint8_t *done; const i32 *action; int T, R; u32 N; i32 s_end; i32 *pend, *scratch, *index, *count; float *countf; int phase; };
+static void sel_lane(void *arg)
+{
+    SelJob *j = (SelJob *)arg;
+    if (j->phase == 0) azul_select_ring_count_kernel(j->done, j->action, j->T, j->R, j->N, j->s_end, j->pend, j->scratch, j->count);
+    else azul_select_ring_write_kernel(j->action, j->R, j->N, j->pend, j->scratch, j->index, j->count, j->countf);
+}
+long long sl_select_ring(const uint8_t *done, const i32 *action, int T, int D, int n, int steps_played, i32 *pend, i32 *index, i32 *count,
+                         float *countf, i32 *scratch)
+{
+    SelJob j = {done, action, T, T * D, (u32)n, steps_played, pend, scratch, index, count, countf, 0};
+    const unsigned blocks = ((unsigned)n + 3u) / 4u;
+    simt::g_grid_dim = {blocks, 1, 1};
+    long long ops = 0;
+    for (j.phase = 0; j.phase < 2; j.phase++)
+        for (unsigned blk = 0; blk < blocks; blk++) {
+            simt::g_block_idx = {blk, 0, 0};
+            ops += (long long)simt::run_workgroup(sel_lane, &j, 4);
+        }
+    return ops;
+}
+
 }

@@ -129,3 +129,50 @@ def test_gradient_kernel_under_emulation_matches_autograd_of_the_references_loss
     L.sl_gradients(n, parts, ptr(stored[0]), ptr(stored[1]), ptr(stored[2]), ptr(stored[3]), ptr(index), 1.0 / n, ptr(w["w1t"]), ptr(w["b1"]),
                    ptr(w["w2c"]), ptr(w["b2c"]), ptr(w["w2a_t"]), ptr(w["b2a"]), ptr(w["w2a"]), ptr(p2), ptr(g2))
     assert np.array_equal(g2, grad)
+
+
+def test_ring_selection_kernels_under_emulation_hand_out_every_step_exactly_once():
+    """azul_select_ring_count_kernel / _write_kernel (NNRunner.train's choice of samples when episodes straddle windows, nn_runner.py:59-76)
+    on synthetic rings against a direct model: after every window each game contributes the steps from its first untrained step up to its
+    last episode end inside the window -- those still intact in the ring, carrying an action -- game by game, steps ascending; what has
+    fallen out of the ring is counted.  Episodes longer than the ring occur (they must be dropped, not mis-indexed)."""
+    L = load()
+    L.sl_select_ring.restype = C.c_longlong
+    L.sl_select_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+    rs = np.random.RandomState(9)
+    n, T, D, windows = 37, 8, 4, 40
+    R = T * D
+    done = np.zeros((R, n), np.uint8)
+    action = np.zeros((R, n), np.int32)
+    pend, mpend = np.zeros(n, np.int32), np.zeros(n, np.int64)
+    index, count, countf = np.zeros(R * n, np.int32), np.zeros(2, np.int32), np.zeros(2, np.float32)
+    scratch = np.zeros(3 * n + (n + 3) // 4, np.int32)
+    seen, dropped_model, total = set(), 0, 0
+    for w in range(windows):
+        for t in range(T):
+            s = w * T + t
+            p_end = np.where(np.arange(n) % 5 == 0, 0.02, 0.14)          # every fifth game plays long episodes (longer than the ring)
+            done[s % R] = rs.rand(n) < p_end
+            action[s % R] = np.where(rs.rand(n) < 0.06, -1, rs.randint(0, 180, n))
+        s_end = (w + 1) * T
+        assert L.sl_select_ring(ptr(done), ptr(action), T, D, n, s_end, ptr(pend), ptr(index), ptr(count), ptr(countf), ptr(scratch)) > 0
+        want = []
+        lo = max(0, s_end - R + (1 if s_end % R else 0))
+        for g in range(n):
+            ends = [s for s in range(s_end - T, s_end) if done[s % R, g]]
+            if not ends:
+                continue
+            start = max(int(mpend[g]), lo)
+            dropped_model += start - int(mpend[g])
+            for s in range(start, ends[-1] + 1):
+                if action[s % R, g] >= 0:
+                    want.append((s % R) * n + g)
+                    assert (g, s) not in seen
+                    seen.add((g, s))
+            mpend[g] = ends[-1] + 1
+        cnt = int(count[0])
+        assert cnt == len(want) and index[:cnt].tolist() == want, (w, cnt, len(want))
+        assert countf[0] == cnt and abs(countf[1] - 1.0 / max(cnt, 1)) < 1e-7
+        assert np.array_equal(pend, mpend.astype(np.int32))
+        total += cnt
+    assert int(count[1]) == dropped_model and dropped_model > 0 and total > n * 100

@@ -19,7 +19,7 @@ ASAN=$(gcc -print-file-name=libasan.so); UBSAN=$(gcc -print-file-name=libubsan.s
   echo "## the same + the facade on it (the product's host logic, facade_backend.HipBackend, on the emulated device: scenarios, ask-ahead interference, random API sequences), ASan + UBSan"
   LD_PRELOAD="$ASAN $UBSAN" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:detect_stack_use_after_return=0 AZUL_SIMT_X_LIB=libsimt_rules_x_asan.so AZUL_HOSTCHECK_LIB=libhostcheck_asan.so \
     timeout 2400 python -m pytest tests/test_hostcheck_rules_x.py tests/test_hostcheck_players.py tests/test_facade_azul.py tests/test_facade_ask_ahead.py tests/test_facade_random_api.py -m "not gpu" -q -p no:cacheprovider 2>&1 | tail -4
-  echo "## two-games-per-wave self-play code (azul_selfplay2.hpp, unmodified) under the lockstep emulation, UBSan"
+  echo "## the benchmarked kernel itself (azul_selfplay2_kernel: azul_selfplay_kernels.hpp on azul_selfplay2.hpp, unmodified) under the lockstep emulation, UBSan"
   LD_PRELOAD="$UBSAN" AZUL_SIMT_LIB=libsimt_selfplay2_ubsan.so timeout 1500 python -m pytest tests/test_hostcheck_selfplay2.py -q -p no:cacheprovider 2>&1 | tail -4
   echo "## the same, ASan + UBSan (fibers announced to ASan with __sanitizer_start/finish_switch_fiber)"
   LD_PRELOAD="$ASAN $UBSAN" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:detect_stack_use_after_return=0 AZUL_SIMT_LIB=libsimt_selfplay2_asan.so \
@@ -34,7 +34,7 @@ ASAN=$(gcc -print-file-name=libasan.so); UBSAN=$(gcc -print-file-name=libubsan.s
   echo "## the same, ASan + UBSan"
   LD_PRELOAD="$ASAN $UBSAN" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:detect_stack_use_after_return=0 AZUL_SIMT_ROLLOUT_LIB=libsimt_rollout2_asan.so \
     timeout 1500 python -m pytest tests/test_hostcheck_rollout2.py -q -p no:cacheprovider 2>&1 | tail -4
-  echo "## the A2C gradient kernel and the ActorCritic forward + head kernel (azul_learner.hpp / azul_policy.hpp, unmodified) against torch autograd, UBSan"
+  echo "## the A2C gradient kernel, the ActorCritic forward + head kernel, the ring selection and returns kernels (azul_learner.hpp / azul_policy.hpp / azul_selfplay_kernels.hpp, unmodified) against torch autograd / direct models, UBSan"
   LD_PRELOAD="$UBSAN" AZUL_SIMT_LEARNER_LIB=libsimt_learner_ubsan.so timeout 1500 python -m pytest tests/test_hostcheck_learner.py -q -p no:cacheprovider 2>&1 | tail -4
   echo "## the same, ASan + UBSan"
   LD_PRELOAD="$ASAN $UBSAN" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:detect_stack_use_after_return=0 AZUL_SIMT_LEARNER_LIB=libsimt_learner_asan.so \

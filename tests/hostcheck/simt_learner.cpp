@@ -9,7 +9,7 @@
 #include "azul_tables.hpp"
 using namespace az;
 #include "azul_ops.hpp"
-#include "azul_selfplay2.hpp"
+#include "azul_selfplay_kernels.hpp"       // (includes azul_selfplay2.hpp; the returns scans live here)
 #include "azul_policy.hpp"
 #include "azul_rollout2.hpp"
 #include "azul_learner.hpp"
@@ -89,6 +89,27 @@ long long sl_select_ring(const uint8_t *done, const i32 *action, int T, int D, i
             simt::g_block_idx = {blk, 0, 0};
             ops += (long long)simt::run_workgroup(sel_lane, &j, 4);
         }
+    return ops;
+}
+
+
+// azul_discounted_returns_ring's launch: the scan over a ring of time slots, 64 games per one-wave workgroup
+struct RetJob { const i32 *reward; const uint8_t *done; float *out; float gamma; int ring_steps, s_end, span; u32 n; };
+static void ret_lane(void *arg)
+{
+    RetJob *j = (RetJob *)arg;
+    azul_returns_ring_kernel(j->reward, j->done, j->out, j->gamma, j->ring_steps, j->s_end, j->span, j->n);
+}
+long long sl_returns_ring(const i32 *reward, const uint8_t *done, float *out, float gamma, int ring_steps, long long steps_played, int span, int n)
+{
+    RetJob j = {reward, done, out, gamma, ring_steps, (int)(steps_played % ring_steps == 0 ? ring_steps : steps_played % ring_steps), span, (u32)n};
+    const unsigned blocks = ((unsigned)n + 63u) / 64u;
+    simt::g_grid_dim = {blocks, 1, 1};
+    long long ops = 1;
+    for (unsigned blk = 0; blk < blocks; blk++) {
+        simt::g_block_idx = {blk, 0, 0};
+        ops += (long long)simt::run_workgroup(ret_lane, &j, 1);
+    }
     return ops;
 }
 

@@ -1,16 +1,16 @@
-// simt_selfplay2.cpp -- TEST-ONLY: the benchmarked two-games-per-wavefront self-play code (csrc/azul_selfplay2.hpp, on top of
-// csrc/azul_wave.hpp and azul_core.hpp, all UNMODIFIED) compiled by g++ and run lane by lane in lockstep (simt/simt.hpp), so that
-// its logic can be diffed against the oracle -- and run under UBSan / ASan -- in the build container, before a GPU sees it.
-// The function below restates the body of azul_selfplay2_kernel (csrc/azul_kernels.hip: table staging, game placement, load,
-// prime, stream open, the move loop, store, stream close) for one wave; everything it calls is the product's code.
+// simt_selfplay2.cpp -- TEST-ONLY: THE BENCHMARKED KERNEL, azul_selfplay2_kernel (csrc/azul_selfplay_kernels.hpp on csrc/azul_selfplay2.hpp,
+// azul_wave.hpp and azul_core.hpp, all UNMODIFIED), compiled by g++ and run lane by lane in lockstep (simt/simt.hpp), one emulated
+// workgroup per pair of games with the kernel's own blockIdx -> game placement, so that it can be diffed against the oracle -- and run under
+// UBSan / ASan -- in the build container, before a GPU sees it.  (wave_body below restates the kernel's body for ONE purpose: the opt-in
+// rotated loop, a compile-time variant of the kernel -- -DAZ2_ROTATED_LOOP, DESIGN.md 3 -- that the default build does not contain.)
 #define __HIPCC__ 1
 #include "azul_hip.h"
 #include "azul_wave.hpp"
 #include "azul_core.hpp"
 #include "azul_tables.hpp"
-#include "azul_selfplay2.hpp"
-
 using namespace az;
+#include "azul_ops.hpp"
+#include "azul_selfplay_kernels.hpp"
 
 struct WaveJob {
     // the batch (BatchDev of the kernel)
@@ -79,6 +79,20 @@ static void wave_body(WaveJob *j)
     az2::counters2_close(cnt, l);
 }
 
+struct KernelJob { BatchDev b; TrajArgs t; u32 pitch; int variant; };
+template <bool LID>
+static void kernel_main_t(void *arg)
+{
+    KernelJob *j = (KernelJob *)arg;
+    switch (j->variant) {
+    case 0: azul_selfplay2_kernel<LID, 1, true, true>(j->b, j->t, j->pitch); break;
+    case 1: azul_selfplay2_kernel<LID, 1, true, false>(j->b, j->t, j->pitch); break;
+    case 2: azul_selfplay2_kernel<LID, 1, false, true>(j->b, j->t, j->pitch); break;
+    case 3: azul_selfplay2_kernel<LID, 2, false, false>(j->b, j->t, j->pitch); break;
+    default: azul_selfplay2_kernel<LID, 0, false, false>(j->b, j->t, j->pitch); break;
+    }
+}
+
 template <bool LID>
 static void lane_main_t(void *arg)
 {
@@ -105,6 +119,24 @@ long long sh2_selfplay(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 *ep
     static double T[T_WORDS];
     if (!build_sample_tab(T)) return -2;
     long long ops = 0;
+    if (!rotated) {
+        // the kernel itself: one one-wave workgroup per pair of games, blockIdx.x as the launch gives it (the kernel maps it to its games)
+        KernelJob kj;
+        memset(&kj, 0, sizeof(kj));
+        kj.b.state = state; kj.b.mt = mt; kj.b.mtpos = mtpos; kj.b.T = T; kj.b.episodes = episodes; kj.b.stuck = stuck; kj.b.stat_sum = stat_sum;
+        kj.b.n = (u32)n_games; kj.b.rules.first_player = (u32)first_player; kj.b.rules.tile_pool = (u32)tile_pool;
+        kj.b.draw_margin = margin ? margin : AZ_DRAW_MARGIN;
+        kj.t.n_steps = n_steps; kj.t.mask = mask; kj.t.maskbits = maskbits; kj.t.action = action; kj.t.reward = reward; kj.t.done = done;
+        kj.t.rec = rec; kj.t.packed = packed;
+        kj.pitch = (u32)pitch; kj.variant = variant;
+        const unsigned blocks = ((unsigned)n_games + 1u) / 2u;
+        simt::g_grid_dim = {blocks, 1, 1};
+        for (unsigned blk = 0; blk < blocks; blk++) {
+            simt::g_block_idx = {blk, 0, 0};
+            ops += (long long)simt::run_workgroup(tile_pool == POOL_LID ? kernel_main_t<true> : kernel_main_t<false>, &kj, 1, simt::STACK_BYTES);
+        }
+        return ops;
+    }
     for (u32 w = 0; w < ((u32)n_games + 1u) / 2u; w++) {
         WaveJob *j = (WaveJob *)calloc(1, sizeof(WaveJob));
         j->state = state; j->mt = mt; j->mtpos = mtpos; j->T = T; j->episodes = episodes; j->stuck = stuck; j->stat_sum = stat_sum;

@@ -139,11 +139,15 @@ def test_ring_selection_kernels_under_emulation_hand_out_every_step_exactly_once
     L = load()
     L.sl_select_ring.restype = C.c_longlong
     L.sl_select_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+    L.sl_returns_ring.restype = C.c_longlong
+    L.sl_returns_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_longlong, C.c_int, C.c_int]
     rs = np.random.RandomState(9)
     n, T, D, windows = 37, 8, 4, 40
     R = T * D
     done = np.zeros((R, n), np.uint8)
     action = np.zeros((R, n), np.int32)
+    reward, returns = np.zeros((R, n), np.int32), np.full((R, n), np.nan, np.float32)
+    hist_r, hist_d, gamma = [], [], np.float32(0.97)
     pend, mpend = np.zeros(n, np.int32), np.zeros(n, np.int64)
     index, count, countf = np.zeros(R * n, np.int32), np.zeros(2, np.int32), np.zeros(2, np.float32)
     scratch = np.zeros(3 * n + (n + 3) // 4, np.int32)
@@ -154,7 +158,12 @@ def test_ring_selection_kernels_under_emulation_hand_out_every_step_exactly_once
             p_end = np.where(np.arange(n) % 5 == 0, 0.02, 0.14)          # every fifth game plays long episodes (longer than the ring)
             done[s % R] = rs.rand(n) < p_end
             action[s % R] = np.where(rs.rand(n) < 0.06, -1, rs.randint(0, 180, n))
+            reward[s % R] = rs.randint(-9, 10, n)
+            hist_r.append(reward[s % R].copy())
+            hist_d.append(done[s % R].copy())
         s_end = (w + 1) * T
+        # the returns of every step the ring holds, in one scan from the newest step backwards (azul_returns_ring_kernel)
+        assert L.sl_returns_ring(ptr(reward), ptr(done), ptr(returns), gamma, R, s_end, min(R, s_end), n) > 0
         assert L.sl_select_ring(ptr(done), ptr(action), T, D, n, s_end, ptr(pend), ptr(index), ptr(count), ptr(countf), ptr(scratch)) > 0
         want = []
         lo = max(0, s_end - R + (1 if s_end % R else 0))
@@ -164,11 +173,17 @@ def test_ring_selection_kernels_under_emulation_hand_out_every_step_exactly_once
                 continue
             start = max(int(mpend[g]), lo)
             dropped_model += start - int(mpend[g])
+            q = np.float32(0)
+            exact = {}
+            for s in range(ends[-1], start - 1, -1):               # nn_runner.py:70-76 over the game's own history
+                q = np.float32(hist_r[s][g]) + gamma * (np.float32(0) if hist_d[s][g] else q)
+                exact[s] = q
             for s in range(start, ends[-1] + 1):
                 if action[s % R, g] >= 0:
                     want.append((s % R) * n + g)
                     assert (g, s) not in seen
                     seen.add((g, s))
+                    assert returns[s % R, g] == exact[s], (w, g, s)       # the same additions in the same order: the same bits
             mpend[g] = ends[-1] + 1
         cnt = int(count[0])
         assert cnt == len(want) and index[:cnt].tolist() == want, (w, cnt, len(want))

@@ -113,4 +113,31 @@ long long sl_returns_ring(const i32 *reward, const uint8_t *done, float *out, fl
     return ops;
 }
 
+
+// azul_a2c_apply_adam's launches: the step counter, then Adam on the flat k-major master copy + the eight nn.Linear tensors
+struct AdamJob { const float *grad; float *flat, *m, *v; float lr, b1, b2, eps; ModuleParams mp; i32 *step; const float *n_total; float *stats; int phase; };
+static void adam_lane(void *arg)
+{
+    AdamJob *j = (AdamJob *)arg;
+    if (j->phase == 0) azul_a2c_step_kernel(j->step, j->n_total);
+    else azul_a2c_apply_kernel(j->grad, j->flat, j->m, j->v, j->lr, j->b1, j->b2, j->eps, 1.f, 1.f, j->mp, j->step, j->n_total, 0.f, j->stats);
+}
+long long sl_adam(const float *grad, float *flat, float *m, float *v, float lr, float beta1, float beta2, float eps, float *c1w, float *c1b,
+                  float *c2w, float *c2b, float *a1w, float *a1b, float *a2w, float *a2b, i32 *step, const float *n_total, float *stats5)
+{
+    AdamJob j = {grad, flat, m, v, lr, beta1, beta2, eps, {c1w, c1b, c2w, c2b, a1w, a1b, a2w, a2b}, step, n_total, stats5, 0};
+    long long ops = 1;
+    simt::g_grid_dim = {1, 1, 1};
+    simt::g_block_idx = {0, 0, 0};
+    ops += (long long)simt::run_workgroup(adam_lane, &j, 1);
+    j.phase = 1;
+    const unsigned blocks = ((unsigned)LG_P_PARAMS + 255u) / 256u;
+    simt::g_grid_dim = {blocks, 1, 1};
+    for (unsigned blk = 0; blk < blocks; blk++) {
+        simt::g_block_idx = {blk, 0, 0};
+        ops += (long long)simt::run_workgroup(adam_lane, &j, 4, 128u << 10);
+    }
+    return ops;
+}
+
 }

@@ -191,3 +191,53 @@ def test_ring_selection_kernels_under_emulation_hand_out_every_step_exactly_once
         assert np.array_equal(pend, mpend.astype(np.int32))
         total += cnt
     assert int(count[1]) == dropped_model and dropped_model > 0 and total > n * 100
+
+
+def test_adam_kernel_under_emulation_matches_torch_adam_and_keeps_both_layouts_in_step():
+    """azul_a2c_step_kernel + azul_a2c_apply_kernel (agent.py:37,60: torch.optim.Adam, defaults) on the flat k-major master copy AND the
+    eight nn.Linear tensors: three updates with random gradients against torch.optim.Adam on a CPU module fed the same gradients in its
+    own layouts; afterwards the master copy is still the module, transposed; an update without samples moves nothing."""
+    L = load()
+    L.sl_adam.restype = C.c_longlong
+    L.sl_adam.argtypes = [C.c_void_p] * 4 + [C.c_float] * 4 + [C.c_void_p] * 11
+    lay = (C.c_int * 8)()
+    L.sl_layout(lay)
+    W1, B1, W2C, B2C, W2A, B2A, LOSS, TOTAL = list(lay)
+    rs = np.random.RandomState(4)
+    mod = {"c1w": rs.randn(180, 136) * 0.1, "c1b": rs.randn(180) * 0.1, "c2w": rs.randn(1, 180) * 0.1, "c2b": rs.randn(1) * 0.1,
+           "a1w": rs.randn(180, 136) * 0.1, "a1b": rs.randn(180) * 0.1, "a2w": rs.randn(180, 180) * 0.1, "a2b": rs.randn(180) * 0.1}
+    mod = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in mod.items()}
+
+    def flat_of(d):
+        f = np.zeros(TOTAL, np.float32)
+        f[W1:W1 + 136 * 360] = np.concatenate([d["c1w"], d["a1w"]], axis=0).T.reshape(-1)
+        f[B1:B1 + 360] = np.concatenate([d["c1b"], d["a1b"]])
+        f[W2C:W2C + 180] = d["c2w"][0]
+        f[B2C] = d["c2b"][0]
+        f[W2A:W2A + 180 * 180] = d["a2w"].T.reshape(-1)
+        f[B2A:B2A + 180] = d["a2b"]
+        return f
+
+    flat, m, v = flat_of(mod), np.zeros(TOTAL, np.float32), np.zeros(TOTAL, np.float32)
+    tp = {k: torch.nn.Parameter(torch.tensor(x.copy())) for k, x in mod.items()}
+    opt = torch.optim.Adam(list(tp.values()), lr=1e-3)
+    step, n_total, stats = np.zeros(1, np.int32), np.array([100.0], np.float32), np.zeros(5, np.float32)
+    for it in range(3):
+        gd = {k: (rs.randn(*x.shape) * 0.5).astype(np.float32) for k, x in mod.items()}
+        grad = flat_of(gd)
+        grad[LOSS:LOSS + 4] = [3.0, 8.0, 5.0, 100.0]
+        assert L.sl_adam(ptr(grad), ptr(flat), ptr(m), ptr(v), 1e-3, 0.9, 0.999, 1e-8, *[ptr(mod[k]) for k in ("c1w", "c1b", "c2w", "c2b", "a1w", "a1b", "a2w", "a2b")],
+                         ptr(step), ptr(n_total), ptr(stats)) > 0
+        for k in tp:
+            tp[k].grad = torch.tensor(gd[k])
+        opt.step()
+        assert int(step[0]) == it + 1
+        for k in tp:
+            assert np.allclose(mod[k], tp[k].detach().numpy(), rtol=0, atol=2e-6), (it, k)
+        assert np.array_equal(flat[:LOSS], flat_of(mod)[:LOSS])                  # the master copy IS the module, k-major
+        assert np.allclose(stats, [0.03, 0.08, 0.05, 0.03 + 0.5 * 0.08 + 0.1 * 0.05, 100.0], atol=1e-6)
+    # a window without a finished episode: no samples, no step, nothing moves
+    before, n0 = {k: x.copy() for k, x in mod.items()}, np.array([0.0], np.float32)
+    L.sl_adam(ptr(grad), ptr(flat), ptr(m), ptr(v), 1e-3, 0.9, 0.999, 1e-8, *[ptr(mod[k]) for k in ("c1w", "c1b", "c2w", "c2b", "a1w", "a1b", "a2w", "a2b")],
+              ptr(step), ptr(n0), ptr(stats))
+    assert int(step[0]) == 3 and all(np.array_equal(before[k], mod[k]) for k in mod)

@@ -140,4 +140,71 @@ long long sl_adam(const float *grad, float *flat, float *m, float *v, float lr, 
     return ops;
 }
 
+
+// ---- the remaining small kernels, each as its launch performs it ----------------------------------------------------------------
+struct HeadJob { const float *logits; const uint8_t *mask; u64 seed, counter; u32 n; i32 *action; float *logp, *ent; u32 id_base; };
+static void head_lane(void *arg)
+{
+    HeadJob *j = (HeadJob *)arg;
+    azul_policy_head_kernel(j->logits, j->mask, j->seed, j->counter, nullptr, j->n, j->action, j->logp, j->ent, j->id_base);
+}
+long long sl_head(int n, const float *logits, const uint8_t *mask, unsigned long long seed, unsigned long long counter, unsigned id_base,
+                  i32 *action, float *logp, float *entropy)
+{
+    HeadJob j = {logits, mask, seed, counter, (u32)n, action, logp, entropy, id_base};
+    const unsigned blocks = ((unsigned)n + 3u) / 4u;
+    simt::g_grid_dim = {blocks, 1, 1};
+    long long ops = 1;
+    for (unsigned blk = 0; blk < blocks; blk++) { simt::g_block_idx = {blk, 0, 0}; ops += (long long)simt::run_workgroup(head_lane, &j, 1); }
+    return ops;
+}
+
+struct SelcJob { const uint8_t *done; const i32 *action; int T; u32 N; i32 *index, *count; };
+static void selc_lane(void *arg) { SelcJob *j = (SelcJob *)arg; azul_select_complete_kernel(j->done, j->action, j->T, j->N, j->index, j->count); }
+long long sl_select_complete(const uint8_t *done, const i32 *action, int T, int n, i32 *index, i32 *count)
+{
+    SelcJob j = {done, action, T, (u32)n, index, count};
+    simt::g_grid_dim = {1, 1, 1};
+    simt::g_block_idx = {0, 0, 0};
+    return 1 + (long long)simt::run_workgroup(selc_lane, &j, 16, 128u << 10);
+}
+
+struct Ret1Job { const i32 *reward; const uint8_t *done; float *out, *carry; float gamma; int n_steps; u32 n; };
+static void ret1_lane(void *arg) { Ret1Job *j = (Ret1Job *)arg; azul_returns_kernel(j->reward, j->done, j->out, j->carry, j->gamma, j->n_steps, j->n); }
+long long sl_returns(const i32 *reward, const uint8_t *done, float *out, float *carry, float gamma, int n_steps, int n)
+{
+    Ret1Job j = {reward, done, out, carry, gamma, n_steps, (u32)n};
+    const unsigned blocks = ((unsigned)n + 255u) / 256u;
+    simt::g_grid_dim = {blocks, 1, 1};
+    long long ops = 1;
+    for (unsigned blk = 0; blk < blocks; blk++) { simt::g_block_idx = {blk, 0, 0}; ops += (long long)simt::run_workgroup(ret1_lane, &j, 4, 128u << 10); }
+    return ops;
+}
+
+struct SeedJob { BatchDev b; u64 base; const u64 *seeds; };
+static void seed_lane(void *arg) { SeedJob *j = (SeedJob *)arg; azul_seed_kernel(j->b, j->base, j->seeds); }
+long long sl_seed(int n, u32 *mt, u32 *mtpos, unsigned long long seed_base, const u64 *seeds)
+{
+    SeedJob j;
+    memset(&j, 0, sizeof(j));
+    j.b.mt = mt; j.b.mtpos = mtpos; j.b.n = (u32)n; j.base = seed_base; j.seeds = seeds;
+    const unsigned blocks = ((unsigned)n + 63u) / 64u;
+    simt::g_grid_dim = {blocks, 1, 1};
+    long long ops = 1;
+    for (unsigned blk = 0; blk < blocks; blk++) { simt::g_block_idx = {blk, 0, 0}; ops += (long long)simt::run_workgroup(seed_lane, &j, 1); }
+    return ops;
+}
+
+struct RedJob { const float *partial; u32 parts; float *grad; };
+static void red_lane(void *arg) { RedJob *j = (RedJob *)arg; azul_a2c_reduce_kernel(j->partial, j->parts, j->grad); }
+long long sl_reduce(const float *partial, int parts, float *grad)
+{
+    RedJob j = {partial, (u32)parts, grad};
+    const unsigned blocks = ((unsigned)LG_P_TOTAL + 255u) / 256u;
+    simt::g_grid_dim = {blocks, 1, 1};
+    long long ops = 1;
+    for (unsigned blk = 0; blk < blocks; blk++) { simt::g_block_idx = {blk, 0, 0}; ops += (long long)simt::run_workgroup(red_lane, &j, 4, 128u << 10); }
+    return ops;
+}
+
 }

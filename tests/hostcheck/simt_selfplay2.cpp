@@ -93,6 +93,18 @@ static void kernel_main_t(void *arg)
     }
 }
 
+// round 1's kernel, one game per wavefront (AZUL_SELFPLAY_KERNEL=1: the A/B partner): OUT 1 writes every stream (dense mask rows), 2 a subset
+template <bool LID>
+static void kernel1_main_t(void *arg)
+{
+    KernelJob *j = (KernelJob *)arg;
+    switch (j->variant) {
+    case 2: azul_selfplay_kernel<LID, 1>(j->b, j->t); break;
+    case 3: azul_selfplay_kernel<LID, 2>(j->b, j->t); break;
+    default: azul_selfplay_kernel<LID, 0>(j->b, j->t); break;
+    }
+}
+
 template <bool LID>
 static void lane_main_t(void *arg)
 {
@@ -119,7 +131,7 @@ long long sh2_selfplay(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 *ep
     static double T[T_WORDS];
     if (!build_sample_tab(T)) return -2;
     long long ops = 0;
-    if (!rotated) {
+    if (rotated != 1) {
         // the kernel itself: one one-wave workgroup per pair of games, blockIdx.x as the launch gives it (the kernel maps it to its games)
         KernelJob kj;
         memset(&kj, 0, sizeof(kj));
@@ -129,11 +141,13 @@ long long sh2_selfplay(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 *ep
         kj.t.n_steps = n_steps; kj.t.mask = mask; kj.t.maskbits = maskbits; kj.t.action = action; kj.t.reward = reward; kj.t.done = done;
         kj.t.rec = rec; kj.t.packed = packed;
         kj.pitch = (u32)pitch; kj.variant = variant;
-        const unsigned blocks = ((unsigned)n_games + 1u) / 2u;
+        const bool v1 = rotated == 2;                      // (2: the one-game-per-wave kernel, one workgroup per game)
+        const unsigned blocks = v1 ? (unsigned)n_games : ((unsigned)n_games + 1u) / 2u;
         simt::g_grid_dim = {blocks, 1, 1};
         for (unsigned blk = 0; blk < blocks; blk++) {
             simt::g_block_idx = {blk, 0, 0};
-            ops += (long long)simt::run_workgroup(tile_pool == POOL_LID ? kernel_main_t<true> : kernel_main_t<false>, &kj, 1, simt::STACK_BYTES);
+            if (v1) ops += (long long)simt::run_workgroup(tile_pool == POOL_LID ? kernel1_main_t<true> : kernel1_main_t<false>, &kj, 1, simt::STACK_BYTES);
+            else ops += (long long)simt::run_workgroup(tile_pool == POOL_LID ? kernel_main_t<true> : kernel_main_t<false>, &kj, 1, simt::STACK_BYTES);
         }
         return ops;
     }

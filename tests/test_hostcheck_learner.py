@@ -241,3 +241,79 @@ def test_adam_kernel_under_emulation_matches_torch_adam_and_keeps_both_layouts_i
     L.sl_adam(ptr(grad), ptr(flat), ptr(m), ptr(v), 1e-3, 0.9, 0.999, 1e-8, *[ptr(mod[k]) for k in ("c1w", "c1b", "c2w", "c2b", "a1w", "a1b", "a2w", "a2b")],
               ptr(step), ptr(n0), ptr(stats))
     assert int(step[0]) == 3 and all(np.array_equal(before[k], mod[k]) for k in mod)
+
+
+def test_the_remaining_small_kernels_under_emulation():
+    """azul_policy_head_kernel (the head alone: the forward kernel's draws, log-probs and entropies on its own logits, bit for bit),
+    azul_select_complete_kernel (one window: the steps of episodes that end inside it, game by game), azul_returns_kernel (nn_runner.py:70-76
+    with a carry between windows), azul_seed_kernel (random.seed(base + g) for every game: the oracle's seeding) and azul_a2c_reduce_kernel
+    (the partials added in workgroup order)."""
+    from oracle import oracle as oz
+    L = load()
+    for name, res in (("sl_head", None), ("sl_select_complete", None), ("sl_returns", None), ("sl_seed", None), ("sl_reduce", None)):
+        getattr(L, name).restype = C.c_longlong
+    L.sl_head.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sl_select_complete.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.sl_returns.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int]
+    L.sl_seed.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_void_p]
+    L.sl_reduce.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    # -- the head on the forward kernel's logits
+    n = 22
+    w, obs, mask, _, _ = make(8, n)
+    value, logp, ent = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    action, logits = np.zeros(n, np.int32), np.zeros((n, 180), np.float32)
+    L.sl_forward(n, ptr(obs), ptr(mask), ptr(w["w1t"]), ptr(w["b1"]), ptr(w["w2c"]), ptr(w["b2c"]), ptr(w["w2a_t"]), ptr(w["b2a"]),
+                 5, 40, 900, ptr(value), ptr(action), ptr(logp), ptr(ent), ptr(logits))
+    a2, lp2, en2 = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    assert L.sl_head(n, ptr(logits), ptr(mask), 5, 40, 900, ptr(a2), ptr(lp2), ptr(en2)) > 0
+    assert np.array_equal(a2, action) and np.array_equal(lp2, logp) and np.array_equal(en2, ent)
+    # -- one window's complete episodes
+    rs = np.random.RandomState(21)
+    T, N = 70, 45                                             # more than 64 steps: both index-writing paths of the kernel
+    done = (rs.rand(T, N) < 0.05).astype(np.uint8)
+    act = np.where(rs.rand(T, N) < 0.1, -1, rs.randint(0, 180, (T, N))).astype(np.int32)
+    done[:, 3] = 0                                            # a game without a finished episode contributes nothing
+    index, count = np.zeros(T * N, np.int32), np.zeros(1, np.int32)
+    assert L.sl_select_complete(ptr(done), ptr(act), T, N, ptr(index), ptr(count)) > 0
+    want = []
+    for g in range(N):
+        ends = np.flatnonzero(done[:, g])
+        if ends.size:
+            want += [t * N + g for t in range(ends[-1] + 1) if act[t, g] >= 0]
+    assert int(count[0]) == len(want) and index[:len(want)].tolist() == want
+    # -- returns of a window, the carry flowing between windows
+    reward = rs.randint(-9, 10, (T, N)).astype(np.int32)
+    out, carry = np.zeros((T, N), np.float32), (rs.randn(N) * 3).astype(np.float32)
+    carry0, gamma = carry.copy(), np.float32(0.95)
+    assert L.sl_returns(ptr(reward), ptr(done), ptr(out), ptr(carry), gamma, T, N) > 0
+    for g in range(N):
+        q = carry0[g]
+        for t in range(T - 1, -1, -1):
+            if done[t, g]:
+                q = np.float32(0)
+            q = np.float32(reward[t, g]) + gamma * q
+            assert out[t, g] == q
+        assert carry[g] == q
+    # -- seeding: CPython's random.seed(base + g) / an explicit seed per game
+    n = 70
+    mt, pos = np.zeros((n, 624), np.uint32), np.zeros(n, np.uint32)
+    assert L.sl_seed(n, ptr(mt), ptr(pos), 1000, None) > 0
+    for g in (0, 1, 63, 64, 69):
+        r = oz.seeded_rng(1000 + g)
+        assert np.array_equal(mt[g], np.ctypeslib.as_array(r.mt)) and int(pos[g]) == int(r.idx) == 624
+    seeds = rs.randint(0, 2 ** 62, n).astype(np.uint64)
+    assert L.sl_seed(n, ptr(mt), ptr(pos), 0, ptr(seeds)) > 0
+    r = oz.seeded_rng(int(seeds[37]))
+    assert np.array_equal(mt[37], np.ctypeslib.as_array(r.mt))
+    # -- the partial sums, in workgroup order
+    lay = (C.c_int * 8)()
+    L.sl_layout(lay)
+    TOTAL = lay[7]
+    parts = 11
+    partial = (rs.randn(parts, TOTAL) * 3).astype(np.float32)
+    grad = np.zeros(TOTAL, np.float32)
+    assert L.sl_reduce(ptr(partial), parts, ptr(grad)) > 0
+    s = np.zeros(TOTAL, np.float32)
+    for i in range(parts):
+        s = s + partial[i]
+    assert np.array_equal(grad, s)

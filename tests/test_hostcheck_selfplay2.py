@@ -110,6 +110,14 @@ def test_rotated_loop_under_lockstep_emulation_equals_the_oracle(ruleset):
         check_case(L, first, pool, n=4, T=130, variant=variant, rotated=1, seed0=700 + variant)
 
 
+def test_round_1_kernel_one_game_per_wave_under_lockstep_emulation_equals_the_oracle():
+    """azul_selfplay_kernel (csrc/azul_selfplay_kernels.hpp on azul_core.hpp: the A/B partner behind AZUL_SELFPLAY_KERNEL=1), the kernel itself."""
+    L = load()
+    first, pool = RULES["lid_randomfirst"]
+    for variant in (2, 3, 4):
+        check_case(L, first, pool, n=3, T=130, variant=variant, rotated=2, seed0=900 + variant)
+
+
 def test_factory_draw_fp64_path_under_emulation():
     """A draw margin that covers every draw sends the whole factory draw through the literal fp64 code and the sequential loop."""
     L = load()

@@ -193,7 +193,6 @@ def test_three_and_four_player_loops_are_one_submission_per_move(facade):
     """The Azul-level loop for any player count -- check_all_valid -> RandomAgent.get_a_output -> Azul.step, a fresh Azul + new_round() when
     a game ends (the oracle's flat stream, oz_stream_x_*) -- with the step bringing back mask and draw: same moves, records and global
     stream as the oracle, one submission per move.  Four players also under the extended rules (beyond the reference, parity unpinned)."""
-    import pytest
     import azul_deep_reinforcement_learning_amd.facade_backend as fb
     from oracle import oracle as oz
     agent = facade.RandomAgent()

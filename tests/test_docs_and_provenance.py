@@ -13,6 +13,23 @@ def test_numbers_md_is_what_the_generator_prints():
     assert open(os.path.join(ROOT, "NUMBERS.md")).read() == out, "regenerate: python tools/numbers_table.py > NUMBERS.md"
 
 
+def test_numbers_md_ignores_records_the_driver_drops_in_later(tmp_path):
+    """The driver writes BENCH_r<round>.json after the builder's last commit: a record that is not in the manifest must not change the table."""
+    import shutil
+    manifest = os.path.join("profiles", "numbers_inputs.txt")
+    names = [l.strip() for l in open(os.path.join(ROOT, manifest)) if l.strip() and not l.startswith("#")]
+    os.makedirs(tmp_path / "profiles")
+    shutil.copy(os.path.join(ROOT, manifest), tmp_path / manifest)
+    for n in names:
+        shutil.copy(os.path.join(ROOT, n), tmp_path / n)
+    last = sorted(n for n in names if n.startswith("BENCH_r"))[-1]
+    shutil.copy(os.path.join(ROOT, last), tmp_path / "BENCH_r99.json")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "numbers_table.py"), "--root", str(tmp_path)],
+                         capture_output=True, text=True, check=True).stdout
+    assert "BENCH_r99" not in out
+    assert open(os.path.join(ROOT, "NUMBERS.md")).read() == out
+
+
 def test_tracked_soak_logs_cite_the_csrc_they_ran_on_and_design_cites_the_same():
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     for name in ("round4_selfplay_soak_raw.txt", "round4_rollout_soak_raw.txt", "round4_players_soak_raw.txt"):

@@ -399,3 +399,11 @@ class BatchedAzul:
         ms, n, kms, kn = C.c_float(0), C.c_int(0), C.c_float(0), C.c_int(0)
         L.check(L.lib.azul_timing_end(self._h, self._stream(), C.byref(ms), C.byref(n), C.byref(kms), C.byref(kn)))
         return float(ms.value), int(n.value), float(kms.value), int(kn.value)
+
+    def timing_launch_ms(self):
+        """After timing_end: the durations (ms) of the launches of that timed region that carried their own event pair (the first 1024)."""
+        n = C.c_int(0)
+        L.check(L.lib.azul_timing_launch_ms(self._h, None, 0, C.byref(n)))
+        out = (C.c_float * max(n.value, 1))()
+        L.check(L.lib.azul_timing_launch_ms(self._h, out, n.value, C.byref(n)))
+        return [float(out[i]) for i in range(n.value)]

@@ -95,7 +95,7 @@ struct azul_batch {
     bool timing;
     uint8_t *call_pin;   // azul_game_call: one call's arguments / results (CallScratch) in pinned, device-visible host memory
 };
-enum { AZ_TIMED_PAIRS = 256 };
+enum { AZ_TIMED_PAIRS = 1024 };
 
 static thread_local std::string g_err;
 
@@ -1109,6 +1109,15 @@ int azul_timing_end(azul_batch_t *b, void *stream, float *total_ms, int *launche
     if (kernel_ms) *kernel_ms = ksum;
     if (kernel_launches) *kernel_launches = b->timed_pairs;
     b->timing = false;
+    return AZUL_SUCCESS;
+}
+
+int azul_timing_launch_ms(azul_batch_t *b, float *launch_ms, int cap, int *n)
+{
+    BATCH_GUARD(b, nullptr);
+    if (!b || b->timing || cap < 0 || (cap > 0 && !launch_ms)) return fail(AZUL_ERR_INVALID, "azul_timing_launch_ms: after azul_timing_end, with room for `cap` values");
+    for (int i = 0; i < b->timed_pairs && i < cap; i++) HIP_TRY(hipEventElapsedTime(launch_ms + i, b->lev[2 * i], b->lev[2 * i + 1]));
+    if (n) *n = b->timed_pairs;
     return AZUL_SUCCESS;
 }
 

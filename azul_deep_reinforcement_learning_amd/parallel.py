@@ -33,6 +33,62 @@ def unpack_moves(packed):
     return action, done, reward
 
 
+# ---- the full C1 record of one agent step (what NNRunner.run_episode keeps per step, nn_runner.py:17-47, and what
+# NNRunner.train concatenates over episodes before ONE update, nn_runner.py:59-78) in a wire format for the all-gather BASELINE configs[4]
+# names.  184 bytes per (step, game):
+#   0   obs[136]      u8   the 136 observation integers (game_runner.py:65-72; all in 0..255: tile counts, flags, scores <= 240)
+#   136 maskbits[24]  u8   the 180 legal-move bits, bit a & 7 of byte a >> 3 (= bit a & 63 of little-endian word a >> 6)
+#   160 action        u8   0..179, 0xff = none (stuck slot)
+#   161 done, 162 player to move, 163 zero
+#   164 reward i32 | 168 value f32 | 172 log_prob f32 | 176 entropy f32 | 180 discounted return f32
+# The default multi-GPU paths do NOT ship this (the records feed the rank that produced them; only the 328 KB gradient is
+# exchanged): it exists so that the collective north_star names can be run and timed.
+C1_BYTES = 184
+
+
+def pack_c1(tr, n_steps, out=None):
+    """One window of a PolicyRollout trajectory (dict of [T(+1)][G][..] tensors) -> uint8 [T][G][184].  Plain torch ops on the tensors'
+    device (CPU tensors in the gloo tests, HBM on the GPU): glue in front of a collective, not a kernel of the path."""
+    T = int(n_steps)
+    obs, mask = tr["obs"][:T], tr["mask"][:T]
+    G = obs.shape[1]
+    if out is None:
+        out = torch.empty(T, G, C1_BYTES, dtype=torch.uint8, device=obs.device)
+    out[..., :136] = obs.to(torch.uint8)
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=obs.device)
+    bits = torch.zeros(T, G, 192, dtype=torch.int32, device=obs.device)
+    bits[..., :180] = (mask != 0).to(torch.int32)
+    out[..., 136:160] = (bits.view(T, G, 24, 8) * w).sum(-1).to(torch.uint8)
+    a = tr["action"][:T].to(torch.int32)
+    out[..., 160] = torch.where(a < 0, torch.full_like(a, 0xFF), a).to(torch.uint8)
+    out[..., 161] = tr["done"][:T].to(torch.uint8)
+    out[..., 162] = tr["player"][:T].to(torch.uint8)
+    out[..., 163] = 0
+    words = out[..., 164:184].view(torch.int32)
+    words[..., 0] = tr["reward"][:T].to(torch.int32)
+    f = words[..., 1:5].view(torch.float32)
+    f[..., 0] = tr["value"][:T].reshape(T, G)
+    f[..., 1] = tr["log_prob"][:T]
+    f[..., 2] = tr["entropy"][:T]
+    f[..., 3] = tr["returns"][:T]
+    return out
+
+
+def unpack_c1(rec):
+    """uint8 [...][184] -> dict of tensors (obs f32 [...][136], mask u8 [...][180], action i32 with -1 for none, done, player, reward, value,
+    log_prob, entropy, returns)."""
+    rec = rec.contiguous()
+    lead = rec.shape[:-1]
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=rec.device)
+    bits = ((rec[..., 136:160].to(torch.int32).unsqueeze(-1) & w) != 0).to(torch.uint8).reshape(*lead, 192)[..., :180]
+    a = rec[..., 160].to(torch.int32)
+    words = rec[..., 164:184].contiguous().view(torch.int32)
+    f = words[..., 1:5].contiguous().view(torch.float32)
+    return {"obs": rec[..., :136].to(torch.float32), "mask": bits, "action": torch.where(a == 0xFF, torch.full_like(a, -1), a),
+            "done": rec[..., 161], "player": rec[..., 162], "reward": words[..., 0], "value": f[..., 0], "log_prob": f[..., 1],
+            "entropy": f[..., 2], "returns": f[..., 3]}
+
+
 class TrajectoryGather:
     def __init__(self, world_size, device, group=None, with_masks=False):
         self.world = int(world_size)
@@ -61,6 +117,14 @@ class TrajectoryGather:
         self._gather(slot, "packed", buf["packed"])
         if self.with_masks:
             self._gather(slot, "maskbits", buf["maskbits"])
+
+    def launch_c1(self, slot, records):
+        """Opt-in (bench.py --gather-c1): all-gather a window's full C1 records (pack_c1: [T][G][184] bytes per rank)."""
+        self._gather(slot, "c1", records)
+
+    def gathered_c1(self, slot, n_steps, games_per_rank):
+        """[world][n_steps][games][C1_BYTES] view of the gathered C1 records of `slot`."""
+        return self.out[slot]["c1"].view(self.world, n_steps, games_per_rank, C1_BYTES)
 
     def finish(self):
         for s in (0, 1):

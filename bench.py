@@ -48,7 +48,11 @@ def parse():
     ap.add_argument("--gather-masks", action="store_true", help="N>1: also ship the bit-packed legal masks (24 B/move)")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[2] / training-loop lines under `extra`")
     ap.add_argument("--extras-timeout", type=int, default=240, help="seconds after which the secondary measurements are abandoned")
+    ap.add_argument("--headline-timeout", type=int, default=900, help="seconds after which a headline measurement that hangs is abandoned")
     ap.add_argument("--mask-pitch", type=int, default=192, help="byte pitch of a game's legal-mask row (180 = dense, 192 = 64-byte aligned rows)")
+    ap.add_argument("--sustained", type=int, default=1000, help="launches of the `sustained` object after the timed region (0 = skip)")
+    ap.add_argument("--gather-c1", action="store_true", help="N>1, secondary line configs[4]: also all-gather every window's full C1 records "
+                                                             "(184 B per agent step; opt-in, the collective north_star names)")
     return ap.parse_args()
 
 
@@ -138,7 +142,73 @@ def _timed(world, dev, fn):
     return float(el.item()), res
 
 
-def extras(games, world=1, rank=0, dev=None, seed_base=0, backend="nccl", phase=None):
+def policy_pytorch_two_streams(games, seed_base=0, window=32, windows=20):
+    """BASELINE configs[2] AS WORDED: model.py's ActorCritic evaluated by PyTorch-ROCm (rocBLAS / hipBLASLt GEMMs: addmm + relu + addmm,
+    model.py:23-41), interleaved with the env step on two HIP streams -- the batch is split in two halves, each half alternates
+    [network on PyTorch -> sampling head -> azul_batch_policy_step] on its own stream (captured once per window as a HIP graph), so one
+    half's env step overlaps the other half's GEMMs.  Same trajectory record as the fused kernel."""
+    import torch
+    from azul_deep_reinforcement_learning_amd import BatchedActorCritic, PolicyRollout
+    torch.manual_seed(0)
+    net = BatchedActorCritic(136, 180, 180)
+    ro = PolicyRollout(net, n_games=games, parts=2, window=window, use_graph=True, fused_mlp=False, persistent=False, seed_base=seed_base)
+    for _ in range(3):
+        ro.run_window()
+    ro.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(windows):
+        ro.run_window()
+    ro.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    moves = games * window * windows
+    c = ro.counters()
+    return {"metric": "Azul env steps/sec (model.py policy on PyTorch-ROCm interleaved with env.step on two HIP streams)", "value": moves / dt,
+            "unit": "env steps/s", "n_gpus": 1, "ms_per_move": dt / (window * windows) * 1e3, "hip_graph": bool(ro.use_graph),
+            "graph_error": ro.graph_error, "episodes_finished": c["episodes"],
+            "config": {"workload": "BASELINE configs[2] as worded: %d games, ActorCritic(136,180,180) f32 as PyTorch-ROCm GEMMs, two stream parts of %d "
+                                   "games, %d-move windows, %d windows timed" % (games, games // 2, window, windows),
+                       "network": "torch.addmm / relu on k-major copies of the module's parameters (rollout.py: fused_mlp=False)",
+                       "env": "azul_batch_policy_step (Azul.step + reward + done + auto-reset + next obs / mask), azul_policy_head (sampling)"}}
+
+
+def saturated(seed_base=0, chunk=512):
+    """The headline kernel with more games than BASELINE configs[1] gives a GPU: 8192 games = four waves per SIMD, 32768 games = the
+    whole of configs[3] on ONE GPU (eight waves per SIMD, two rounds).  Same kernel, same outputs, kernel time from the library's event pairs.
+    Not the metric's workload: it shows what the instruction-issue bound leaves on the table at 4096 games."""
+    import torch
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    res = {}
+    for G, launches in ((8192, 6), (32768, 3)):
+        env = BatchedAzul(G)
+        env.seed(seed_base)
+        env.runner_init()
+        env.runner_init()
+        b = env.alloc_trajectory(chunk, packed_mask=True, mask_pitch=192, mask_bits=False)
+        run = lambda: env.selfplay(chunk, b["mask"], b["action"], b["reward"], b["done"], packed=b["packed"])
+        run()
+        torch.cuda.synchronize()
+        stuck0 = int(env.counters()["stuck"].sum())
+        t0 = time.perf_counter()
+        env.timing_begin()
+        for _ in range(launches):
+            run()
+        _, _, kms, kn = env.timing_end()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        moves = G * chunk * launches - (int(env.counters()["stuck"].sum()) - stuck0)
+        avg = kms / max(kn, 1)
+        res["games_%d" % G] = {"value": moves / dt, "unit": "env steps/s", "kernel_env_steps_per_s": G * chunk / (avg / 1e3), "avg_launch_ms": avg,
+                               "launches": launches, "waves_per_simd": G / 2 / 1024.0,
+                               "nominal_hbm_frac": ALGO_BYTES_PER_STEP * G * chunk / (avg / 1e3) / 1e9 / HBM_PEAK_GBS}
+        del env, b
+        torch.cuda.empty_cache()
+    res["kernel"] = "azul_selfplay2_kernel (the headline kernel; %d moves per launch)" % chunk
+    return res
+
+
+def extras(games, world=1, rank=0, dev=None, seed_base=0, backend="nccl", phase=None, gather_c1=False):
     """Driver-observed secondary lines (after the headline measurement; EVERY rank runs them): BASELINE configs[2] (N = 1) /
     configs[4] (N > 1) -- the policy in the loop, one launch per 32-move window, games sharded by global id -- and the training loop
     (NNRunner.train batched; N > 1: data parallel, the step is rollout -> selection -> gradients -> ALL-REDUCE of the global sample
@@ -163,11 +233,25 @@ def extras(games, world=1, rank=0, dev=None, seed_base=0, backend="nccl", phase=
     torch.cuda.synchronize()
     s = ro.streams[0]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c1 = None
+    if gather_c1 and world > 1:
+        # opt-in: the collective BASELINE configs[4] names -- every window's full C1 records (pack_c1: 184 B per agent step) all-gathered,
+        # double-buffered on the rollout's stream, inside the timed region
+        from azul_deep_reinforcement_learning_amd.parallel import C1_BYTES, TrajectoryGather, pack_c1
+        c1 = TrajectoryGather(world, dev)
+        c1_bufs = [torch.empty(window, games, C1_BYTES, dtype=torch.uint8, device=dev) for _ in range(2)]
 
     def policy_windows():
         e0.record(s)
-        for _ in range(windows):
-            ro.run_window()
+        for i in range(windows):
+            tr = ro.run_window()
+            if c1 is not None:
+                with torch.cuda.stream(s):
+                    c1.wait_buffer_free(i & 1)
+                    c1.launch_c1(i & 1, pack_c1(tr[0], window, out=c1_bufs[i & 1]))
+        if c1 is not None:
+            with torch.cuda.stream(s):
+                c1.finish()
         e1.record(s)
         ro.synchronize()
 
@@ -180,8 +264,13 @@ def extras(games, world=1, rank=0, dev=None, seed_base=0, backend="nccl", phase=
         "n_gpus": world,
         "config": {"workload": "BASELINE configs[%d]: %d games per GPU (%d in all), ActorCritic(136,180,180) f32 inside azul_batch_policy_rollout, "
                                "one launch per %d-move window" % (2 if world == 1 else 4, games, games * world, window), "windows_timed": windows,
-                   "parallelism": "games sharded by global id; no collective: the C1 trajectory records stay in the HBM of the rank that "
-                                  "produced them (DESIGN.md 7)"},
+                   "parallelism": ("games sharded by global id; no collective: the C1 trajectory records stay in the HBM of the rank that "
+                                   "produced them (DESIGN.md 7)") if c1 is None else
+                                  ("games sharded by global id; --gather-c1: every window's full C1 records (%d B per agent step, %.1f MB per rank "
+                                   "and window) all-gathered over %s behind the window that produced them, inside the timed region"
+                                   % (C1_BYTES, window * games * C1_BYTES / 1e6, coll)),
+                   "c1_gather": None if c1 is None else {"bytes_per_agent_step": C1_BYTES, "bytes_into_each_rank_per_window": window * games * C1_BYTES * world,
+                                                         "gathered_bytes_timed": c1.gathered_bytes}},
         "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS,
                      "traffic": None, "kernel": "azul_policy_rollout2_kernel (writes the window's discounted returns itself)", "avg_window_ms": kms / windows,
                      "flop_per_env_move": FWD_FLOP_PER_GAME, "event_bracket_ms": kms, "host_elapsed_ms": dt * 1e3, "scope": "rank 0's GPU"}}
@@ -333,18 +422,73 @@ def players_selfplay(games, chunk=256, launches=6):
 WATCHDOG_EXIT_CODE = 3
 
 
-def start_watchdog(timeout_s, rank, out, phase, _exit=os._exit):
-    """The secondary measurements run under a deadline.  When it passes, a GPU process of this job is stuck (a kernel that does not
+def rank_identity(rank, local_rank, dev_index, ndev, backend):
+    """What a rank knows about where it runs: host, the devices it can see, the one it bound (index, name, UUID when the runtime gives one)."""
+    import socket
+    import torch
+    name, uuid = "?", None
+    try:
+        props = torch.cuda.get_device_properties(dev_index)
+        name = props.name
+        uuid = str(getattr(props, "uuid", "")) or None
+    except Exception:
+        pass
+    return {"rank": int(rank), "local_rank": int(local_rank), "host": socket.gethostname(), "device_count": int(ndev), "device": int(dev_index),
+            "name": name, "uuid": uuid, "visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES")),
+            "shares_device": bool(backend != "nccl" and ndev and local_rank >= ndev)}
+
+
+class Phase(list):
+    """[label of what is running]; `armed` once a watchdog watches it."""
+    armed = False
+
+
+class Collectives:
+    """Every collective of the headline measurement goes through here: it refuses to run unless a watchdog is armed (a rank that never
+    enters a collective must not leave the others waiting for ever) and it names the phase the watchdog would report."""
+
+    def __init__(self, dist, world, phase):
+        self.dist, self.world, self.phase = dist, int(world), phase
+
+    def enter(self, label):
+        if not getattr(self.phase, "armed", False):
+            raise RuntimeError("collective '%s' before the watchdog was armed" % label)
+        self.phase[0] = label
+
+    def barrier(self, label):
+        if self.world > 1:
+            self.enter(label)
+            self.dist.barrier()
+
+    def all_reduce(self, t, op, label):
+        if self.world > 1:
+            self.enter(label)
+            self.dist.all_reduce(t, op=op)
+        return t
+
+    def all_gather_object(self, obj, label):
+        if self.world == 1:
+            return [obj]
+        self.enter(label)
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+
+def start_watchdog(timeout_s, rank, out, phase, _exit=os._exit, what="secondary measurements"):
+    """The measurements run under a deadline.  When it passes, a GPU process of this job is stuck (a kernel that does not
     finish, a collective that one rank never entered): rank 0 still prints the headline line -- with the phase that was running under
-    `extra.error` -- and EVERY rank leaves with a NON-ZERO exit code, so that torchrun / spawn_ranks / the caller see a failed run.
-    No retry, no re-exec."""
+    `extra.error` (no headline yet: a line holding only `error` / `hung_phase`) -- and EVERY rank leaves with a NON-ZERO exit code, so
+    that torchrun / spawn_ranks / the caller see a failed run.  No retry, no re-exec."""
     import threading
 
     def give_up():
+        err = {"error": "%s exceeded %d s in phase '%s'; exit code %d" % (what, timeout_s, phase[0], WATCHDOG_EXIT_CODE), "hung_phase": phase[0]}
         if rank == 0 and out is not None:
-            out["extra"] = {"error": "secondary measurements exceeded %d s in phase '%s'; exit code %d" % (timeout_s, phase[0], WATCHDOG_EXIT_CODE),
-                            "hung_phase": phase[0]}
+            out["extra"] = err
             print(json.dumps(out), flush=True)
+        elif rank == 0 and what != "secondary measurements":
+            print(json.dumps(err), flush=True)
         sys.stdout.flush()
         sys.stderr.write("bench.py: watchdog fired on rank %d in phase '%s'\n" % (rank, phase[0]))
         sys.stderr.flush()
@@ -353,6 +497,8 @@ def start_watchdog(timeout_s, rank, out, phase, _exit=os._exit):
     wd = threading.Timer(timeout_s, give_up)
     wd.daemon = True
     wd.start()
+    if isinstance(phase, Phase):
+        phase.armed = True
     return wd
 
 
@@ -392,8 +538,12 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    hphase = Phase(["start"])
+    hwd = start_watchdog(args.headline_timeout, rank, None, hphase, what="headline measurement")      # armed before the first collective
+    coll_ = Collectives(dist, world, hphase)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        coll_.enter("init_process_group (%s)" % backend)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
         else:
@@ -401,6 +551,14 @@ def main():
 
     from azul_deep_reinforcement_learning_amd import BatchedAzul
     from azul_deep_reinforcement_learning_amd.parallel import TrajectoryGather
+
+    # who is here: every rank states the devices it sees and the one it bound (stderr), and rank 0 records the list in the JSON line
+    # (`config.rccl`), so that a multi-GPU record proves that N ranks ran on N different devices over the named backend
+    mine = rank_identity(rank, local_rank, dev_index, ndev, backend)
+    sys.stderr.write("bench.py: rank %d/%d local_rank %d: torch.cuda.device_count() = %d, bound cuda:%d (%s), backend %s\n"
+                     % (rank, world, local_rank, ndev, dev_index, mine["name"], backend if world > 1 else "none"))
+    sys.stderr.flush()
+    ranks_seen = coll_.all_gather_object(mine, "all_gather_object of the ranks' devices")
 
     G, T, K, W = args.games, args.chunk, args.steps, args.warmup
     base = args.seed_base + rank * G                     # seeds follow the GLOBAL game id
@@ -425,6 +583,8 @@ def main():
         if gather is not None:
             gather.finish()
 
+    if gather is not None:
+        coll_.enter("warm-up launches + trajectory all-gather")
     run(W)
     torch.cuda.synchronize()
     # the gate replays >= 1 full episode per checked game whatever --warmup is: top the warm-up up to 128 moves if needed
@@ -434,17 +594,17 @@ def main():
         torch.cuda.synchronize()
         gate_moves = 128
     gate = parity_gate(env, G, base, gate_moves) if rank == 0 else None
-    if world > 1:
-        dist.barrier()
+    coll_.barrier("barrier before the timed region")
     torch.cuda.synchronize()
     stuck0 = int(env.counters()["stuck"].sum())
     t0 = time.perf_counter()
+    if gather is not None:
+        coll_.enter("timed region: launches + trajectory all-gather")
     env.timing_begin()                                   # events are recorded INSIDE the host-timed region
     run(K)
     bracket_ms, launches, kern_ms, kern_launches = env.timing_end()     # records the closing event, waits for it
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    coll_.barrier("barrier after the timed region")
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     cnt = env.counters()
@@ -452,11 +612,42 @@ def main():
     gate_end = parity_gate(env, G, base, gate_moves + K * T) if rank == 0 else None      # ... and the state the timed region left
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     moves = torch.tensor([float(G * K * T - stuck)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(moves, op=dist.ReduceOp.SUM)
+    coll_.all_reduce(el, dist.ReduceOp.MAX, "all-reduce (max) of the ranks' elapsed time")
+    coll_.all_reduce(moves, dist.ReduceOp.SUM, "all-reduce (sum) of the ranks' env moves")
     elapsed = float(el.item())
     total_moves = float(moves.item())
+    gathered_per_launch = (gather.gathered_bytes // max(W + K, 1)) if gather is not None else 0
+
+    # ---- sustained: the same step, the same buffers, S further launches (~0.8 s at N = 1) after the timed region; not `value`, a check on it
+    sustained = None
+    S = args.sustained
+    if S > 0:
+        coll_.barrier("barrier before the sustained launches")
+        torch.cuda.synchronize()
+        stuck1 = int(env.counters()["stuck"].sum())
+        t0 = time.perf_counter()
+        if gather is not None:
+            coll_.enter("sustained launches + trajectory all-gather")
+        env.timing_begin()
+        run(S)
+        s_bracket, _, s_kms, s_kn = env.timing_end()
+        torch.cuda.synchronize()
+        coll_.barrier("barrier after the sustained launches")
+        torch.cuda.synchronize()
+        s_el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        s_moves = torch.tensor([float(G * S * T - (int(env.counters()["stuck"].sum()) - stuck1))], dtype=torch.float64, device=dev)
+        coll_.all_reduce(s_el, dist.ReduceOp.MAX, "all-reduce (max) of the sustained region's elapsed time")
+        coll_.all_reduce(s_moves, dist.ReduceOp.SUM, "all-reduce (sum) of the sustained region's env moves")
+        if rank == 0:
+            per = sorted(env.timing_launch_ms())
+            sustained = {"launches": S, "env_steps_per_s": float(s_moves.item()) / float(s_el.item()), "seconds": float(s_el.item()),
+                         "vs_value": float(s_moves.item()) / float(s_el.item()) / (total_moves / elapsed),
+                         "launch_ms": {"n": len(per), "min": per[0], "p50": per[len(per) // 2], "p99": per[min(len(per) - 1, int(len(per) * 0.99))],
+                                       "max": per[-1], "mean": s_kms / max(s_kn, 1)} if per else None,
+                         "event_bracket_ms": s_bracket,
+                         "parity_gate": parity_gate(env, G, base, gate_moves + (K + S) * T, budget=2500000),
+                         "note": "after the timed region: same buffers, same launches (N > 1: same all-gather), launch durations from the "
+                                 "library's event pairs (rank 0's GPU); `value` is NOT taken from here"}
 
     out = None
     if rank == 0:
@@ -509,7 +700,11 @@ def main():
                        "games_per_gpu": G, "global_games": G * world, "moves_per_launch": T, "env_moves_timed": int(total_moves),
                        "mask_row_pitch_bytes": args.mask_pitch, "mask_bits_stream": bool(want_bits),
                        "selfplay_kernel": os.environ.get("AZUL_SELFPLAY_KERNEL", "2") + " game(s) per wavefront",
-                       "parallelism": par},
+                       "parallelism": par,
+                       "rccl": {"backend": (coll if world > 1 else None), "world_size": dist.get_world_size() if world > 1 else 1,
+                                "ranks_seen": len(ranks_seen), "distinct_devices": len({(r["host"], r["uuid"] or r["device"]) for r in ranks_seen}),
+                                "ranks": ranks_seen, "bytes_per_launch": gathered_per_launch,
+                                "bytes_per_launch_note": "bytes the trajectory all-gather delivers INTO each rank per launch (0: nothing gathered)"}},
             # `achieved` / `frac` follow the contract: ALGORITHMIC bytes (445 B per env move) over the kernel's own duration.
             # What really reaches HBM is less (the state never leaves the registers): `traffic` (PMC) and `traffic_gbs` / `traffic_frac`.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -523,22 +718,36 @@ def main():
                          "note": "working set is cache resident; the path is issue/latency bound, see DESIGN.md"},
             "parity_gate": gate, "parity_gate_after_timed_region": gate_end,
             "episodes_finished": int(cnt["episodes"].sum()), "stuck_resets": stuck,
+            "sustained": sustained,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(G, args.seed_base)
     if not args.no_extras:
         # secondary lines, run by EVERY rank (N > 1: the data-parallel training step has collectives).  The headline must survive them: an
         # exception is reported under `extra`; if a rank hangs, every rank's watchdog fires, rank 0 prints the headline and all exit.
-        phase = ["policy_config / training"]             # what the watchdog reports: the secondary measurement that was running
+        hwd.cancel()                                     # the headline is in `out`: from here on the secondary deadline watches
+        phase = Phase(["policy_config / training"])      # what the watchdog reports: the secondary measurement that was running
         wd = start_watchdog(args.extras_timeout, rank, out, phase)
         del bufs, env, gather
         torch.cuda.empty_cache()
+        first = {}
+        if world == 1:
+            # (first: measured after the one-launch-per-window kernel has run in the same process the PyTorch-GEMM configuration came out
+            # ~40 % slower than on its own -- bench_policy.py, cause not established)
+            phase[0] = "policy_pytorch_two_streams"
+            try:
+                first["policy_pytorch_two_streams"] = policy_pytorch_two_streams(G, args.seed_base)
+            except Exception as e:
+                first["policy_pytorch_two_streams"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
         try:
-            ex = extras(G, world, rank, dev, args.seed_base, backend, phase)
+            ex = extras(G, world, rank, dev, args.seed_base, backend, phase, gather_c1=args.gather_c1)
         except Exception as e:
             ex = {"error": repr(e)}
+        ex.update(first)
         if world == 1:
-            for name, fn in (("facade_config1", facade_config1), ("players_selfplay", lambda: players_selfplay(G))):
+            for name, fn in (("saturated", lambda: saturated(args.seed_base, T)), ("facade_config1", facade_config1),
+                             ("players_selfplay", lambda: players_selfplay(G))):
                 phase[0] = name
                 try:
                     ex[name] = fn()
@@ -547,6 +756,7 @@ def main():
         wd.cancel()
         if rank == 0:
             out["extra"] = ex
+    hwd.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -434,9 +434,13 @@ int azul_batch_segment_profile(azul_batch_t *b, uint64_t *cycles_host, int n, in
 /* device time of azul_batch_selfplay launches, measured with hipEvents on the launch stream: call azul_timing_begin, launch
  * any number of selfplay calls, then azul_timing_end (synchronises the stream).  total_ms / launches: the event bracket from
  * begin to end and the launches inside it; kernel_ms / kernel_launches: the sum of the event pairs recorded immediately
- * around each of the first 256 launches (the kernel's own duration, what `rocprofv3 --kernel-trace` reports) and their number. */
+ * around each of the first 1024 launches (the kernel's own duration, what `rocprofv3 --kernel-trace` reports) and their number.
+ * azul_timing_launch_ms: after azul_timing_end, the individual durations of those launches (at most `cap` of them are written;
+ * *n = how many the last timed region bracketed).  The reference has no counterpart (it is timed from outside: scripts/ run
+ * game_runner.py under a wall clock). */
 int azul_timing_begin(azul_batch_t *b, void *stream);
 int azul_timing_end(azul_batch_t *b, void *stream, float *total_ms, int *launches, float *kernel_ms, int *kernel_launches);
+int azul_timing_launch_ms(azul_batch_t *b, float *launch_ms, int cap, int *n);
 
 #ifdef __cplusplus
 }

@@ -63,8 +63,8 @@ def test_plain_command_spawns_ranks_and_relays_failure():
 
 @pytest.mark.gpu
 def test_plain_command_two_ranks_one_json_line():
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--games", "256", "--chunk", "128"],
-                       env=_env(AZUL_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--games", "256", "--chunk", "128", "--sustained", "4",
+                        "--gather-c1"], env=_env(AZUL_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-3000:]
@@ -75,9 +75,20 @@ def test_plain_command_two_ranks_one_json_line():
     assert "all-gather" in out["config"]["parallelism"] and "gloo" in out["config"]["parallelism"]
     assert out["parity_gate"].startswith("ok") and out["parity_gate_after_timed_region"].startswith("ok")
     assert "cpu_baseline" not in out                              # rank 0 at N = 1 only
+    # the record proves who took part: two ranks, the bytes the trajectory all-gather delivers into a rank per launch, and both ranks' lines
+    rc = out["config"]["rccl"]
+    assert rc["ranks_seen"] == 2 and rc["world_size"] == 2 and [x["rank"] for x in rc["ranks"]] == [0, 1]
+    assert rc["bytes_per_launch"] == 2 * 256 * 128 * 4
+    assert all(x["device_count"] >= 1 and x["name"] for x in rc["ranks"])
+    assert r.stderr.count("torch.cuda.device_count() =") == 2
+    su = out["sustained"]
+    assert su["launches"] == 4 and su["launch_ms"]["n"] == 4 and su["parity_gate"].startswith("ok") and 0.5 < su["vs_value"] < 2.0
     ex = out["extra"]
     assert "error" not in ex, ex
     assert ex["policy_config"]["n_gpus"] == 2
+    c1 = ex["policy_config"]["config"]["c1_gather"]               # --gather-c1: the full C1 records of every window, all-gathered
+    assert c1["bytes_per_agent_step"] == 184 and c1["gathered_bytes_timed"] == 40 * 2 * 32 * 256 * 184
+    assert "all-gathered" in ex["policy_config"]["config"]["parallelism"]
     tr = ex["training"]
     assert tr["n_gpus"] == 2 and tr["ranks_hold_identical_parameters"] is True
     assert "all-reduce" in tr["config"]["parallelism"]
@@ -95,6 +106,13 @@ def test_single_gpu_line_keeps_its_shape():
     assert out["n_gpus"] == 1 and out["roofline"]["bound"] == "hbm" and out["roofline"]["frac"] > 0
     assert "nothing is exchanged" in out["config"]["parallelism"]
     assert out["extra"]["training"]["n_gpus"] == 1 and out["extra"]["policy_config"]["roofline"]["bound"] == "mfma"
+    assert out["extra"]["policy_config"]["config"]["c1_gather"] is None
+    assert out["sustained"]["launches"] == 1000 and abs(out["sustained"]["vs_value"] - 1.0) < 0.25
+    assert out["config"]["rccl"]["ranks_seen"] == 1 and out["config"]["rccl"]["bytes_per_launch"] == 0
+    two = out["extra"]["policy_pytorch_two_streams"]
+    assert two["value"] > 0 and "PyTorch-ROCm" in two["config"]["workload"]
+    sat = out["extra"]["saturated"]
+    assert sat["games_8192"]["waves_per_simd"] == 4.0 and sat["games_32768"]["value"] > 0
 
 
 def test_watchdog_prints_the_headline_and_exits_non_zero(capsys):
@@ -128,3 +146,90 @@ def test_watchdog_exit_code_reaches_the_shell():
     assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
     assert json.loads(r.stdout.strip().splitlines()[-1])["extra"]["hung_phase"] == "facade_config1"
     assert "watchdog fired" in r.stderr
+
+
+def test_spawn_command_for_eight_gpus(monkeypatch):
+    """The command the driver's 8-GPU run uses when it starts bench.py plainly: eight ranks on 127.0.0.1, every argument passed through."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5", "--gather-c1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[cmd.index(BENCH) + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5", "--gather-c1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+class _FakeDist:
+    def __init__(self, phase):
+        self.phase, self.calls = phase, []
+
+    def _note(self, what):
+        self.calls.append((what, self.phase[0], bool(self.phase.armed)))
+
+    def barrier(self):
+        self._note("barrier")
+
+    def all_reduce(self, t, op=None):
+        self._note("all_reduce")
+
+    def all_gather_object(self, out, obj):
+        self._note("all_gather_object")
+        out[:] = [obj] * len(out)
+
+
+def test_every_headline_collective_runs_under_an_armed_watchdog_with_its_phase_named():
+    sys.path.insert(0, ROOT)
+    import bench
+    phase = bench.Phase(["start"])
+    fake = _FakeDist(phase)
+    coll = bench.Collectives(fake, 8, phase)
+    with pytest.raises(RuntimeError, match="before the watchdog was armed"):
+        coll.barrier("too early")                                  # no rank may wait in a collective nobody watches
+    assert fake.calls == []
+    wd = bench.start_watchdog(60, 3, None, phase, _exit=lambda c: None, what="headline measurement")
+    try:
+        assert phase.armed
+        got = coll.all_gather_object({"rank": 3}, "ranks")
+        coll.barrier("barrier before the timed region")
+        coll.all_reduce(None, "MAX", "all-reduce (max)")
+    finally:
+        wd.cancel()
+    assert len(got) == 8
+    assert fake.calls == [("all_gather_object", "ranks", True), ("barrier", "barrier before the timed region", True),
+                          ("all_reduce", "all-reduce (max)", True)]
+    # one rank alone: nothing is called, nothing needs a watchdog
+    solo = bench.Collectives(_FakeDist(bench.Phase([""])), 1, bench.Phase([""]))
+    solo.barrier("x")
+    assert solo.all_gather_object(5, "y") == [5]
+
+
+def test_main_routes_its_headline_collectives_through_the_wrapper():
+    """Source check: main() itself calls no torch.distributed collective directly before the headline is complete -- they all go through
+    Collectives (the one exception is the closing barrier in front of destroy_process_group, after the line has been printed)."""
+    import inspect
+    sys.path.insert(0, ROOT)
+    import bench
+    src = inspect.getsource(bench.main)
+    head = src[:src.index("print(json.dumps(out)")]
+    for name in ("dist.barrier(", "dist.all_reduce(", "dist.all_gather", "dist.broadcast("):
+        assert name not in head, name
+    assert head.index("start_watchdog(args.headline_timeout") < head.index("init_process_group(")      # armed before the first rendezvous
+
+
+def test_headline_watchdog_prints_an_error_line_when_there_is_no_headline_yet(capsys):
+    sys.path.insert(0, ROOT)
+    import bench
+    codes = []
+    phase = bench.Phase(["init_process_group (nccl)"])
+    wd = bench.start_watchdog(0.05, 0, None, phase, _exit=codes.append, what="headline measurement")
+    wd.join(5)
+    assert codes == [bench.WATCHDOG_EXIT_CODE]
+    line = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(line) == 1 and json.loads(line[0])["hung_phase"] == "init_process_group (nccl)"

@@ -82,3 +82,77 @@ def test_trajectory_allgather_two_ranks():
     action, done, reward = unpack_moves(torch.from_numpy(results[0]["packed"][1][:, 3].copy()))
     assert np.array_equal(action.numpy(), ref["action"]) and np.array_equal(done.numpy(), ref["done"])
     assert np.array_equal(reward.numpy(), ref["reward"])
+
+
+# ---- the opt-in all-gather of full C1 records (bench.py --gather-c1; BASELINE configs[4] names it; nn_runner.py:59-78) -------------------
+CT, CG = 6, 5      # agent steps per window, games per rank
+
+
+def _c1_window(rank, window):
+    """A deterministic stand-in for one rank's PolicyRollout window (CPU tensors): env side from the oracle's streams of that rank's
+    GLOBAL game ids, network side (value / log-prob / entropy / returns) from a generator keyed by (rank, window)."""
+    from azul_deep_reinforcement_learning_amd.parallel import shard_seed_base
+    from oracle import oracle as oz
+    base = shard_seed_base(500, CG, rank)
+    g = torch.Generator().manual_seed(1000 * rank + window)
+    tr = {"obs": torch.zeros(CT + 1, CG, 136), "mask": torch.zeros(CT + 1, CG, 180, dtype=torch.uint8), "player": torch.zeros(CT + 1, CG, dtype=torch.uint8),
+          "action": torch.zeros(CT, CG, dtype=torch.int32), "reward": torch.zeros(CT, CG, dtype=torch.int32), "done": torch.zeros(CT, CG, dtype=torch.uint8),
+          "value": torch.randn(CT, CG, 1, generator=g), "log_prob": torch.randn(CT, CG, generator=g), "entropy": torch.randn(CT, CG, generator=g),
+          "returns": torch.randn(CT, CG, generator=g)}
+    for j in range(CG):
+        s = oz.Stream(base + j)
+        s.advance(window * CT, want_records=False)
+        out = s.advance(CT, want_records=True)
+        tr["mask"][:CT, j] = torch.from_numpy(out["mask"])
+        tr["action"][:, j] = torch.from_numpy(out["action"])
+        tr["reward"][:, j] = torch.from_numpy(out["reward"])
+        tr["done"][:, j] = torch.from_numpy(out["done"])
+        rec = np.ascontiguousarray(out["rec_after"]).view(np.uint8).reshape(CT, 128)
+        tr["obs"][:CT, j, :128] = torch.from_numpy(rec.astype(np.float32))      # any integers in 0..255 do for the wire format
+        tr["player"][:CT, j] = torch.from_numpy((rec[:, 31] & 7).astype(np.uint8))
+    return tr
+
+
+def _c1_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from azul_deep_reinforcement_learning_amd.parallel import C1_BYTES, TrajectoryGather, pack_c1
+    tg = TrajectoryGather(world, torch.device("cpu"))
+    bufs = [torch.empty(CT, CG, C1_BYTES, dtype=torch.uint8) for _ in range(2)]
+    for window in range(3):                      # double-buffered like bench.py's extras
+        slot = window & 1
+        tg.wait_buffer_free(slot)
+        tg.launch_c1(slot, pack_c1(_c1_window(rank, window), CT, out=bufs[slot]))
+    tg.finish()
+    q.put((rank, tg.gathered_c1(0, CT, CG).numpy().copy(), tg.gathered_bytes))      # slot 0 holds window 2
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c1_record_allgather_two_ranks():
+    from azul_deep_reinforcement_learning_amd.parallel import C1_BYTES, pack_c1, unpack_c1
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_c1_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (a, b) for r, a, b in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][0], res[1][0])                        # every rank holds the same gathered records
+    assert res[0][1] == 3 * world * CT * CG * C1_BYTES                  # bytes delivered into a rank: three windows of `world` slices
+    for r in range(world):
+        tr = _c1_window(r, 2)
+        assert np.array_equal(res[0][0][r], pack_c1(tr, CT).numpy()), r  # slice r == what a single process records for rank r's games
+        u = unpack_c1(torch.from_numpy(res[0][0][r].copy()))
+        for k in ("action", "reward", "done", "log_prob", "entropy", "returns"):
+            assert torch.equal(u[k], tr[k]), k
+        assert torch.equal(u["value"], tr["value"].reshape(CT, CG))
+        assert torch.equal(u["obs"], tr["obs"][:CT]) and torch.equal(u["mask"], tr["mask"][:CT]) and torch.equal(u["player"], tr["player"][:CT])

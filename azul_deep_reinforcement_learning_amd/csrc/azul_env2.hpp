@@ -1,15 +1,17 @@
-// azul_env2.hpp -- the ENV SIDE of the persistent policy rollout (csrc/azul_rollout2.hpp): GameRunner.step / GameRunner.reset /
-// GameRunner.get_state / RandomAgent.get_a_output for TWO GAMES PER WAVEFRONT, on top of azul_selfplay2.hpp's half-uniform rules
-// (state in VGPRs, one game per 32-lane half).  Nothing here touches the network: azul_rollout2.hpp calls these between its matrix
-// phases, and tests/hostcheck/simt_env2.cpp runs THIS FILE, unmodified, lane by lane on the CPU against the oracle.
+// azul_env2.hpp -- GameRunner on the two-player rule book: GameRunner.step / GameRunner.reset / GameRunner.get_state /
+// RandomAgent.get_a_output / Azul.step with its legality test, for TWO GAMES PER WAVEFRONT on top of azul_selfplay2.hpp's half-uniform
+// rules (state in VGPRs, one game per 32-lane half).  Two users: the env side of the persistent policy rollout (azul_rollout2.hpp calls
+// these between its matrix phases) and the two-player rule entries of the C ABI (azul_ops2.hpp).  tests/hostcheck/simt_env2.cpp and
+// simt_ops2.cpp run THIS FILE, unmodified, lane by lane on the CPU against the oracle.
 // Reference lines: azulnet/azul.py:296-313 (step), azulnet/game_runner.py:43-55 (GameRunner.step), :56-72 (get_state), :76-85 (reset),
 // :87-97 (RandomAgent); azulnet/nn_runner.py:17-47.
 #pragma once
+#include "azul_selfplay2.hpp"
 
 namespace az2 {
 
 // ---- observation: game_runner.py:56-72, 136 values; value j of my game for j = lane + 32 i ------------------------------------------
-// (layout as azul_core.hpp's observe: cells 0..30 | pattern_lines[order[0]] | pattern_lines[order[1]] | walls[order[0]] | walls[order[1]] |
+// (layout: cells 0..30 | pattern_lines[order[0]] | pattern_lines[order[1]] | walls[order[0]] | walls[order[1]] |
 // floors | scores | next first player, seen from player `persp`)
 template <int I>
 AZ_FN u32 observe_val2(const G2 &g, u32 o0 /* half-uniform: 0 / 1 */, u32 l)
@@ -91,14 +93,14 @@ AZ_FN bool random_agent2(const Mask2 &m, Rng2 &r, const Tab2 &T, const K2 &k, u3
     return true;
 }
 
-// the same packing for an action given by number (azul_core.hpp's action_code)
+// the same packing for an action given by number
 AZ_FN u32 action_code2(u32 a, const K2 &k)
 {
     const u32 prow_ = a / 30u, ln = a - 30u * prow_;
     return hbcast(k.lcode, ln) | (prow_ << 13) | (a << 17);
 }
 
-// ---- Azul.step's body for a legal move (azul_core.hpp's apply_step: move_and_score + new_round), what-if caches kept ----------------
+// ---- Azul.step's body for a legal move (azul.py:304-313: move, then end of round -> scoring -> end of game / next round), what-if caches kept
 template <bool LID>
 AZ_FN u32 apply_step2(G2 &g, u32 code, Rng2 &r, u64 margin, const K2 &k)
 {
@@ -127,7 +129,7 @@ AZ_FN u32 apply_step2(G2 &g, u32 code, Rng2 &r, u64 margin, const K2 &k)
     return st;
 }
 
-// Azul.step with the legality test of azul.py:298-302 (azul_core.hpp's checked_step); `m` is the mask of the current state
+// Azul.step with the legality test of azul.py:298-302; `m` is the mask of the current state
 template <bool LID>
 AZ_FN u32 checked_step2(G2 &g, i32 a, const Mask2 &m, Rng2 &r, u64 margin, const K2 &k)
 {
@@ -155,7 +157,8 @@ AZ_FN u32 reset2(G2 &g, u32 first_player, Rng2 &r, u64 margin, const K2 &k)
     return st;
 }
 
-// One env move of policy-driven self-play (azul_kernels.hip's env_policy_step: the same decisions in the same order, with ONE reset site)
+// One env move of policy-driven self-play on a register-resident game: Azul.step (azul.py:296-313) for the current player, the shaped
+// reward of game_runner.py:48-52 per move, done, statistics and the auto-reset of game_runner.py:76-82 (ONE reset site)
 template <bool LID>
 AZ_FN u32 policy_step2(G2 &g, i32 av, const Mask2 &m /* of the current state: the one that was published */, u32 first_player, Rng2 &r, u64 margin,
                         Counters2 &cnt, const K2 &k, i32 &rew, u32 &dn)
@@ -192,7 +195,7 @@ AZ_FN u32 policy_step2(G2 &g, i32 av, const Mask2 &m /* of the current state: th
     return st;
 }
 
-// GameRunner's opponent loop (game_runner.py:46-47 / :84): azul_core.hpp's runner_opponent_loop
+// GameRunner's opponent loop (game_runner.py:46-47 / :84)
 template <bool LID>
 AZ_FN u32 opponent_loop2(G2 &g, Rng2 &r, const Tab2 &T, u64 margin, const K2 &k, bool until_player1_only)
 {
@@ -212,10 +215,9 @@ AZ_FN u32 opponent_loop2(G2 &g, Rng2 &r, const Tab2 &T, u64 margin, const K2 &k,
     return ST_OK;
 }
 
-// One AGENT step of NNRunner.run_episode (azul_kernels.hip's env_agent_step over azul_core.hpp's runner_step, statement for statement)
+// GameRunner.step (game_runner.py:43-55): the agent's move, the opponent's RandomAgent replies, the shaped reward, done.  No reset.
 template <bool LID>
-AZ_FN u32 agent_step2(G2 &g, i32 av, const Mask2 &m /* of the current state */, u32 first_player, Rng2 &r, const Tab2 &T, u64 margin,
-                       Counters2 &cnt, const K2 &k, i32 &rew, u32 &dn)
+AZ_FN u32 runner_step2(G2 &g, i32 av, const Mask2 &m /* of the current state */, Rng2 &r, const Tab2 &T, u64 margin, const K2 &k, i32 &rew, u32 &dn)
 {
     rew = 0;
     dn = g.over ? 1u : 0u;
@@ -230,6 +232,17 @@ AZ_FN u32 agent_step2(G2 &g, i32 av, const Mask2 &m /* of the current state */, 
             dn = g.over ? 1u : 0u;                                     // :55
         }
     }
+    return st;
+}
+
+// One AGENT step of NNRunner.run_episode (nn_runner.py:24-29): GameRunner.step and, when the episode ends, the GameRunner.reset() that
+// opens the next run_episode (nn_runner.py:20 -> game_runner.py:76-82, incl. the opponent's opening moves), so the observation / mask
+// taken afterwards are the next decision's.
+template <bool LID>
+AZ_FN u32 agent_step2(G2 &g, i32 av, const Mask2 &m /* of the current state */, u32 first_player, Rng2 &r, const Tab2 &T, u64 margin,
+                       Counters2 &cnt, const K2 &k, i32 &rew, u32 &dn)
+{
+    u32 st = runner_step2<LID>(g, av, m, r, T, margin, k, rew, dn);
     const bool dirty = !(st == ST_ILLEGAL_MOVE || st == ST_BAD_ACTION);
     if (st == ST_STUCK) { cnt.stuck_add += 1u; dn = 2u; rew = 0; }   // hazard H3: nobody can move
     else if (st == ST_GAME_ENDED) dn = 1u;

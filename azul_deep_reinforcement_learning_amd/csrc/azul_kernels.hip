@@ -1,20 +1,20 @@
 // azul_kernels.hip -- gfx950 kernels and the C ABI of libazulhip.so (declared in include/azul_hip.h).
 //
-// Mapping: ONE GAME PER 64-LANE WAVEFRONT, one wavefront per workgroup (grid = N workgroups).  With the
-// benchmarked N = 4096 games that is 16 waves per CU / 4 per SIMD on all 256 CUs of an MI355X: every game
-// advances on its own scalar instruction stream (no divergence between games -- the rules are branchy),
-// while the 64 lanes hold the board cells (azul_core.hpp) and serve the ballots, the MT19937 regeneration,
-// the mask/observation write-out and the fp64 weight division.
+// Mapping: TWO GAMES PER 64-LANE WAVEFRONT (lanes 0..31 / 32..63), one wavefront per workgroup for the rule kernels and the self-play
+// loops (grid = ceil(N / 2) workgroups: 2048 waves = two per SIMD on the 256 CUs of an MI355X at the benchmarked N = 4096), eight waves
+// per workgroup for the policy rollout.  A game's board cells sit in the lanes of its half, everything else is replicated across the
+// half ("half-uniform") and the rules run on the vector pipe; the rare paths (factory draw, scoring, episode reset) are ordinary
+// divergent branches between the halves.  The rules exist ONCE per game shape (azul_common.hpp): azul_selfplay2.hpp + azul_env2.hpp
+// for two players, azul_rules_x.hpp for 3 / 4 players and the extended rules.
 //
 // Kernels
 //   azul_seed_kernel            one THREAD per game: CPython init_by_array is a strictly sequential 1247-step recurrence
-//   azul_op_kernel              one wave per game: every single-call rule / runner entry point of the ABI
+//   azul_op_kernel              every single-call rule / runner entry point of the ABI for two-player batches (azul_ops2.hpp)
 //   azul_x_op_kernel            the rule entries for batches of 3- / 4-player games and for extended-rule batches (row N4;
-//                               azul_rules_x.hpp: two games per wavefront, 256-byte wide records)
-//   azul_x_selfplay_kernel      their persistent flat self-play loop
-//   azul_selfplay_kernel        one wave per game, state register-resident across n_steps env moves (the hot path)
+//                               azul_rules_x.hpp: 256-byte wide records)
+//   azul_selfplay2_kernel       state register-resident across n_steps env moves (the hot path); azul_x_selfplay_kernel: row N4's
 //   azul_returns_kernel         discounted returns over a trajectory window
-//   azul_policy.hpp             policy head, fused ActorCritic forward, persistent policy rollout (rows N1 / N2)
+//   azul_policy.hpp             policy head, fused ActorCritic forward; azul_rollout2.hpp: persistent policy rollout (rows N1 / N2)
 //   azul_learner.hpp            A2C gradients (forward + backward on the matrix cores), partial reduction, sample selection (row N2)
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -26,16 +26,8 @@
 #include <string>
 #include <vector>
 
-// The timing-experiment switches that make a kernel produce WRONG RESULTS (they leave out stores, LDS round trips or weight loads to
-// price them: DESIGN.md 3, 9) are only accepted together with -DAZ_TIMING_EXPERIMENTS, which azul_version() reports -- a library
-// built with one of them cannot be mistaken for the product (tests/test_abi_and_host_logic.py checks the shipped library's version).
-#if !defined(AZ_TIMING_EXPERIMENTS) && (defined(AZ2_EXPERIMENT_NO_LDS) || defined(AZ2_X_NO_SCALAR_STORES) || defined(AZ2_X_NO_MASK_STORES) || \
-                                        defined(AZ2_X_NO_STATS) || defined(PR2_EXPERIMENT_NO_WEIGHT_LOADS) || defined(PR2_X_NO_MASK_STORES))
-#error "this switch produces wrong results: timing experiments only, add -DAZ_TIMING_EXPERIMENTS (reported by azul_version())"
-#endif
-
 #include "../../include/azul_hip.h"
-#include "azul_core.hpp"
+#include "azul_common.hpp"
 #include "azul_tables.hpp"
 
 using namespace az;
@@ -43,8 +35,6 @@ using namespace az;
 // ------------------------------------------------------------------------------------------------
 // device side
 // ------------------------------------------------------------------------------------------------
-#include "azul_ops.hpp"
-
 #include "azul_selfplay_kernels.hpp"
 
 #include "azul_rules_x.hpp"
@@ -151,11 +141,7 @@ extern "C" {
 const char *azul_last_error_string(void) { return g_err.c_str(); }
 const char *azul_version(void)
 {
-    return "azul-mi355x 0.4 (gfx950; two-player rule entries: one game per wavefront; self-play, 3 / 4 players and extended rules: two games per wavefront)"
-#if defined(AZ_TIMING_EXPERIMENTS)
-           " [AZ_TIMING_EXPERIMENTS: NOT a shippable build -- timing switches that produce wrong results are compiled in]"
-#endif
-        ;
+    return "azul-mi355x 0.5 (gfx950; two games per wavefront: two-player rule entries, self-play, policy rollout, 3 / 4 players and extended rules)";
 }
 
 static void batch_free(azul_batch *b)
@@ -448,10 +434,12 @@ static int launch_op(azul_batch_t *b, const OpArgs &a, void *stream, int count =
 {
     if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
     if (b->x) return launch_op_x(b, a, stream, count);
-    const dim3 grid(count < 0 ? b->d.n : (u32)count), block(64);      // games a.first .. a.first + grid - 1
+    OpArgs a2 = a;
+    a2.count = count < 0 ? b->d.n : (u32)count;                       // games a.first .. a.first + count - 1, two per wavefront
+    const dim3 grid((a2.count + 1u) / 2u), block(64);
     const hipStream_t st = (hipStream_t)stream;
-    if (b->d.rules.tile_pool == POOL_LID) hipLaunchKernelGGL(azul_op_kernel<true>, grid, block, 0, st, b->d, a);
-    else hipLaunchKernelGGL(azul_op_kernel<false>, grid, block, 0, st, b->d, a);
+    if (b->d.rules.tile_pool == POOL_LID) hipLaunchKernelGGL(azul_op_kernel<true>, grid, block, 0, st, b->d, a2);
+    else hipLaunchKernelGGL(azul_op_kernel<false>, grid, block, 0, st, b->d, a2);
     HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }
@@ -703,27 +691,14 @@ int azul_batch_policy_rollout_returns(azul_batch_t *b, int n_steps, int opponent
                      returns_dev, gamma, (u64)seed, (u64)counter, (u64 *)counter_dev};
     const hipStream_t st = (hipStream_t)stream;
     const bool lid = b->d.rules.tile_pool == POOL_LID;
-    // AZUL_ROLLOUT_KERNEL=1 selects the one-game-per-wave kernel (azul_policy.hpp) for A/B measurements; default: the env side on
-    // the vector pipe, two games per wave (azul_rollout2.hpp)
-    static const int version = [] { const char *e = getenv("AZUL_ROLLOUT_KERNEL"); return (e && e[0] == '1') ? 1 : 2; }();
-    if (version == 2) {
-        const dim3 grid2((b->d.n + PF_GAMES - 1) / PF_GAMES), block2(64 * PR2_WAVES);
-        if (lid && opponent_random) hipLaunchKernelGGL((azul_policy_rollout2_kernel<true, true>), grid2, block2, 0, st, b->d, W, a);
-        else if (lid) hipLaunchKernelGGL((azul_policy_rollout2_kernel<true, false>), grid2, block2, 0, st, b->d, W, a);
-        else if (opponent_random) hipLaunchKernelGGL((azul_policy_rollout2_kernel<false, true>), grid2, block2, 0, st, b->d, W, a);
-        else hipLaunchKernelGGL((azul_policy_rollout2_kernel<false, false>), grid2, block2, 0, st, b->d, W, a);
-        HIP_TRY(hipGetLastError());
-        if (returns_dev && n_steps > 32)       // the kernel keeps a window's rewards in 32 lanes: longer windows get the separate scan
-            return azul_discounted_returns(reward_dev, done_dev, returns_dev, nullptr, gamma, n_steps, (int)b->d.n, stream);
-        return AZUL_SUCCESS;
-    }
-    const dim3 grid((b->d.n + PF_GAMES - 1) / PF_GAMES), block(64 * PR_WAVES);
-    if (lid && opponent_random) hipLaunchKernelGGL((azul_policy_rollout_kernel<true, true>), grid, block, 0, st, b->d, W, a);
-    else if (lid) hipLaunchKernelGGL((azul_policy_rollout_kernel<true, false>), grid, block, 0, st, b->d, W, a);
-    else if (opponent_random) hipLaunchKernelGGL((azul_policy_rollout_kernel<false, true>), grid, block, 0, st, b->d, W, a);
-    else hipLaunchKernelGGL((azul_policy_rollout_kernel<false, false>), grid, block, 0, st, b->d, W, a);
+    const dim3 grid2((b->d.n + PF_GAMES - 1) / PF_GAMES), block2(64 * PR2_WAVES);
+    if (lid && opponent_random) hipLaunchKernelGGL((azul_policy_rollout2_kernel<true, true>), grid2, block2, 0, st, b->d, W, a);
+    else if (lid) hipLaunchKernelGGL((azul_policy_rollout2_kernel<true, false>), grid2, block2, 0, st, b->d, W, a);
+    else if (opponent_random) hipLaunchKernelGGL((azul_policy_rollout2_kernel<false, true>), grid2, block2, 0, st, b->d, W, a);
+    else hipLaunchKernelGGL((azul_policy_rollout2_kernel<false, false>), grid2, block2, 0, st, b->d, W, a);
     HIP_TRY(hipGetLastError());
-    if (returns_dev) return azul_discounted_returns(reward_dev, done_dev, returns_dev, nullptr, gamma, n_steps, (int)b->d.n, stream);
+    if (returns_dev && n_steps > 32)       // the kernel keeps a window's rewards in 32 lanes: longer windows get the separate scan
+        return azul_discounted_returns(reward_dev, done_dev, returns_dev, nullptr, gamma, n_steps, (int)b->d.n, stream);
     return AZUL_SUCCESS;
 }
 
@@ -928,13 +903,6 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     return AZUL_SUCCESS;
 }
 
-// AZUL_SELFPLAY_KERNEL=1 selects the one-game-per-wave kernel (azul_core.hpp) for A/B measurements; default: two games per wave
-static int selfplay_kernel_version()
-{
-    static int v = [] { const char *e = getenv("AZUL_SELFPLAY_KERNEL"); return (e && e[0] == '1') ? 1 : 2; }();
-    return v;
-}
-
 int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev, int mask_row_bytes, uint64_t *maskbits_dev, int32_t *action_dev,
                                 int32_t *reward_dev, uint8_t *done_dev, uint32_t *packed_dev, uint8_t *rec_dev, void *stream)
 {
@@ -973,32 +941,24 @@ int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev,
         if (b->timing) b->timed_launches++;
         return AZUL_SUCCESS;
     }
-    const int version = selfplay_kernel_version();
-    if (version == 2 && (u64)n_steps * b->d.n * (u64)(rec_dev && mask_row_bytes < AZUL_RECORD_BYTES ? AZUL_RECORD_BYTES : mask_row_bytes) >= (1ull << 32))
+    if ((u64)n_steps * b->d.n * (u64)(rec_dev && mask_row_bytes < AZUL_RECORD_BYTES ? AZUL_RECORD_BYTES : mask_row_bytes) >= (1ull << 32))
         return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: a trajectory stream of one launch must stay below 4 GiB (use fewer moves per launch)");
-    if (version == 1 && mask_row_bytes != AZUL_NUM_ACTIONS)
-        return fail(AZUL_ERR_INVALID, "azul_batch_selfplay: the one-game-per-wave kernel writes dense 180-byte mask rows");
     TrajArgs t = {n_steps, mask_dev, (u64 *)maskbits_dev, action_dev, reward_dev, done_dev, rec_dev, packed_dev};
     const bool none = !mask_dev && !maskbits_dev && !action_dev && !reward_dev && !done_dev && !rec_dev && !packed_dev;
     const bool core = mask_dev && action_dev && reward_dev && done_dev && packed_dev && !rec_dev;     // + maskbits_dev or not
     const bool full = core && maskbits_dev;
-    const dim3 grid(version == 1 ? b->d.n : (b->d.n + 1u) / 2u), block(64);
+    const dim3 grid((b->d.n + 1u) / 2u), block(64);
     const hipStream_t st = (hipStream_t)stream;
     const u32 ms = (u32)mask_row_bytes;
     // padded rows (>= 192 bytes, 8-byte aligned: alloc_trajectory(mask_pitch = 192)) take the one-store-per-row path
     const bool pad = ms >= 192u && ms % 8u == 0u && ((uintptr_t)mask_dev & 7u) == 0u;
 #define AZ_LAUNCH(LID) do { \
-        if (version == 1) { \
-            if (none) hipLaunchKernelGGL((azul_selfplay_kernel<LID, 0>), grid, block, 0, st, b->d, t); \
-            else if (full) hipLaunchKernelGGL((azul_selfplay_kernel<LID, 1>), grid, block, 0, st, b->d, t); \
-            else hipLaunchKernelGGL((azul_selfplay_kernel<LID, 2>), grid, block, 0, st, b->d, t); \
-        } else { \
-            if (none) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 0, false, false>), grid, block, 0, st, b->d, t, ms); \
-            else if (full && pad) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true, true>), grid, block, 0, st, b->d, t, ms); \
-            else if (core && pad) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true, false>), grid, block, 0, st, b->d, t, ms); \
-            else if (full) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, false, true>), grid, block, 0, st, b->d, t, ms); \
-            else hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 2, false, false>), grid, block, 0, st, b->d, t, ms); \
-        } } while (0)
+        if (none) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 0, false, false>), grid, block, 0, st, b->d, t, ms); \
+        else if (full && pad) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true, true>), grid, block, 0, st, b->d, t, ms); \
+        else if (core && pad) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true, false>), grid, block, 0, st, b->d, t, ms); \
+        else if (full) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, false, true>), grid, block, 0, st, b->d, t, ms); \
+        else hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 2, false, false>), grid, block, 0, st, b->d, t, ms); \
+    } while (0)
     // inside a timed region the first AZ_TIMED_PAIRS launches are bracketed by their own event pair (the kernel's duration,
     // not the distance between launches)
     const bool pair = b->timing && b->timed_pairs < AZ_TIMED_PAIRS;

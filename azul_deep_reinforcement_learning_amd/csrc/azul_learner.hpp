@@ -23,10 +23,7 @@ constexpr int LG_P_W1 = 0, LG_P_B1 = LG_P_W1 + PF_IN * PF_H2, LG_P_W2C = LG_P_B1
               LG_P_PARAMS = LG_P_B2A + PF_ACT, LG_P_LOSS = LG_P_PARAMS, LG_P_TOTAL = LG_P_PARAMS + 4;
 static_assert(LG_P_PARAMS == 82082 && LG_P_W2A % 2 == 0, "ActorCritic(136, 180, 180): 82081 parameters + 1 pad");
 
-#ifndef LG_AHEAD_N
-#define LG_AHEAD_N 6       // (k-steps of weights in flight; 4..6 measured alike, 8 and 12 slower)
-#endif
-constexpr u32 LG_WAVES = 8, LG_AHEAD = LG_AHEAD_N;
+constexpr u32 LG_WAVES = 8, LG_AHEAD = 6 /* k-steps of weights in flight; 4..6 measured alike, 8 and 12 slower */;
 constexpr int LG_ADEPTH = 3;
 constexpr int LG_SUB = 2, LG_M = PF_GAMES * LG_SUB;           // samples per pass: two 16-row MFMA tiles share every streamed weight fragment
 constexpr int LG_F_TILES = 9, LG_C_TILES = 23;                 // dW1: 136 -> 9 feature tiles, 360 -> 23 column tiles

@@ -370,17 +370,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 }
 
 
-// ---- persistent policy rollout: a whole window of moves in ONE launch ------------------------------------------------------
-// The batched NNRunner.run_episode loop (nn_runner.py:17-47) without a kernel boundary per move: a workgroup of 16 waves owns
-// 16 games for `n_steps` moves.  Every wave keeps ITS game in registers and its MT19937 state in LDS for the whole launch (like
-// the self-play kernel); per move
-//     env waves     publish observation (LDS + trajectory) and legal mask (LDS bits + trajectory bytes)
-//     waves 0..11   layer 1 on the f32 matrix cores (two 16x16 tiles each), then layer 2 (one tile each); wave 12: the critic
-//     waves 12..15  the head for four games each (masked softmax, sample, log-prob, entropy)
-//     env waves     Azul.step with the sampled action (OPP: + the RandomAgent opponent's replies), reward, done, auto-reset
-// with four workgroup barriers in between.  Arithmetic per output element is the same k-ordered fma chain as
-// azul_policy_forward_kernel and the env functions are the per-call kernel's, so the trajectories are bit-identical to the
-// two-launches-per-move path (tests/test_policy_bridge.py).
+// ---- arguments of the persistent policy rollout (azul_rollout2.hpp: a whole window of moves in ONE launch) ---------------------------
 struct RolloutArgs {
     int n_steps;
     float *obs;          // [T+1][N][136]  slot t = what the policy saw at move t (slot 0 is written from the current state)
@@ -398,204 +388,3 @@ struct RolloutArgs {
     u64 seed, counter;
     u64 *counter_dev;    // optional [2]: [0] added to `counter`, advanced by n_steps; [1] completion ticket
 };
-
-constexpr u32 PR_WAVES = 16, PR_MM_WAVES = 12, PR_HEAD_WAVE0 = 12, PR_AHEAD = 8;
-
-template <bool LID, bool OPP>
-__global__ void __launch_bounds__(64 * PR_WAVES) azul_policy_rollout_kernel(BatchDev b, PolicyWeights W, RolloutArgs a)
-{
-    __shared__ float obsS[PF_GAMES * PF_OBS_STRIDE];
-    __shared__ float hidS[PF_GAMES * PF_HID_STRIDE];
-    __shared__ float lgS[PF_GAMES * PF_LOG_STRIDE];
-    __shared__ float w2cS[PF_HID];
-    __shared__ u32 mtS[PR_WAVES][624];
-    __shared__ double frS[T_ROWS * T_BINADES];
-    __shared__ u64 maskS[PR_WAVES][4];
-    __shared__ i32 actS[PR_WAVES];
-    const u32 tid = threadIdx.x, l = tid & 63u, c = l & 15u, q = l >> 4;
-    const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const u32 n = b.n, g0 = blockIdx.x * PF_GAMES, gi = g0 + w;
-    const bool live = gi < n;
-    u64 counter = a.counter;
-    if (a.counter_dev) counter += a.counter_dev[0];
-    if (tid < (u32)PF_HID) w2cS[tid] = W.w2c[tid];
-
-    // matrix-phase constants of this wave
-    const bool mm = w < PR_MM_WAVES;
-    const u32 l1col0 = 32u * w + 2u * c, l2col0 = 16u * w + c;
-    const bool l1live = mm && l1col0 < (u32)PF_H2, l2live = mm && l2col0 < (u32)PF_ACT;
-    const float bias1a = W.b1[l1live ? l1col0 : 0u], bias1b = W.b1[l1live ? l1col0 + 1u : 0u], bias2 = W.b2a[l2live ? l2col0 : 0u];
-    const float b2c_v = W.b2c[0];
-    // Weight addressing: buffer loads = one descriptor per matrix (scalar registers) + ONE per-lane byte offset + a per-k-step
-    // scalar offset that is an instruction literal.  (With plain pointers the compiler keeps one 64-bit address per k-step live
-    // across the whole move loop -- 2 x 79 registers -- and spills them.)
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)W.w1t, 0, PF_IN * PF_H2 * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)W.w2a_t, 0, PF_HID * PF_ACT * 4, 0x00020000);
-    const u32 voff1 = ((l1live ? l1col0 : 0u) + q * (u32)PF_H2) * 4u;
-    const u32 voff2 = ((l2live ? l2col0 : 0u) + q * (u32)PF_ACT) * 4u;
-#define PR_LOAD1(s) __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs1, voff1, (4 * (s)) * PF_H2 * 4, 0))
-#define PR_LOAD2(s) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, voff2, (4 * (s)) * PF_ACT * 4, 0))
-
-    // env state of this wave's game
-    LaneConst k;
-    lane_consts(k);
-    SampleTab tab;
-    tab.fr = frS;
-    tab.s = 0.0;
-    if (OPP) sample_tab_load(tab, b.T, frS);             // every wave writes the same 248 doubles
-    Game g;
-    Rng r;
-    uint8_t *rec = b.state + (size_t)(live ? gi : 0u) * AZUL_RECORD_BYTES;
-    game_load(g, rec);
-    game_prime<LID>(g, k);
-    rng_open(r, b.mt + (size_t)(live ? gi : 0u) * 624u, mtS[w], b.mtpos[live ? gi : 0u]);
-    r.margin = b.draw_margin;
-    u32 st_last = ST_OK;
-    float *orow = obsS + w * PF_OBS_STRIDE;
-
-    // observation + legal mask of the current state -> LDS (for the network / the head) and trajectory slot `slot`
-    auto publish = [&](u32 slot) {
-        Mask m;
-        legal_mask(g, k, m);
-        const size_t cell = (size_t)slot * n + gi;
-        mask_write(m, a.mask + cell * AZUL_NUM_ACTIONS);
-        if (l == 0u) { maskS[w][0] = m.m0; maskS[w][1] = m.m1; maskS[w][2] = m.m2; }
-        observe(g, OPP ? 0u : me_index(g), orow);
-        lds_fence();
-        float *og = a.obs + cell * PF_IN;
-        og[l] = orow[l];
-        og[l + 64u] = orow[l + 64u];
-        if (l < (u32)PF_IN - 128u) og[l + 128u] = orow[l + 128u];
-        if (l == 0u) a.player[cell] = (uint8_t)g.cur;
-    };
-    if (live) publish(0u);
-    else { orow[l] = 0.f; orow[l + 64u] = 0.f; if (l < (u32)PF_IN - 128u) orow[l + 128u] = 0.f; if (l == 0u) { maskS[w][0] = 0; maskS[w][1] = 0; maskS[w][2] = 0; } }
-
-#if defined(AZ_PROFILE_SEGMENTS)
-    u64 pr_acc[6] = {0, 0, 0, 0, 0, 0}, pr_last = __builtin_amdgcn_s_memtime();
-    const u64 pr_t0 = pr_last, pr_r0 = __builtin_amdgcn_s_memrealtime();      // in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz
-#define PR_STAMP(i) do { u64 now_ = __builtin_amdgcn_s_memtime(); pr_acc[i] += now_ - pr_last; pr_last = now_; } while (0)
-#else
-#define PR_STAMP(i) do { } while (0)
-#endif
-#pragma unroll 1
-    for (int t = 0; t < a.n_steps; t++) {
-        const size_t row_t = (size_t)t * n;
-        float bw2[PR_AHEAD];
-        float u_head = 0.f;
-        PR_STAMP(0);                                     // own env step + publish
-        lds_barrier();                                 // observations and mask bits of all 16 games are in LDS
-        PR_STAMP(1);                                     // waiting for the slowest env wave
-        if (mm) {
-            // layer 1: this wave owns hidden columns 32w + 2c + j (j = 0, 1): two 16x16 tiles with column stride 2
-            pf_f32x4 acc0 = (pf_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-            const float *ap = obsS + c * PF_OBS_STRIDE + q;
-            float2 bw[PF_IN / 4];
-#pragma unroll
-            for (int s = 0; s < (int)PR_AHEAD; s++) bw[s] = PR_LOAD1(s);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < PF_IN / 4; s++) {
-                if (s + (int)PR_AHEAD < PF_IN / 4) bw[s + PR_AHEAD] = PR_LOAD1(s + PR_AHEAD);
-                const float av = ap[4 * s];
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].y, acc1, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (l1live) {
-                for (int rr = 0; rr < 4; rr++) {         // C layout: column = lane & 15, row = 4 (lane >> 4) + rr
-                    float h0 = acc0[rr] + bias1a, h1 = acc1[rr] + bias1b;
-                    float *hp = hidS + (4u * q + rr) * PF_HID_STRIDE + l1col0;
-                    hp[0] = h0 > 0.f ? h0 : 0.f;         // F.relu, model.py:24/30
-                    hp[1] = h1 > 0.f ? h1 : 0.f;
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < (int)PR_AHEAD; s++) bw2[s] = PR_LOAD2(s);      // layer 2's first weight fragments: in flight across the barrier
-        } else if (w >= PR_HEAD_WAVE0) {
-            // the head waves idle during the matrix phases: they draw this move's uniforms now (Philox does not depend on the logits)
-            const u32 hg = g0 + 4u * (w - PR_HEAD_WAVE0) + q;
-            u_head = policy_uniform(a.seed, counter + (u64)t, b.id_base + (hg < n ? hg : n - 1u));
-        }
-        lds_barrier();
-        PR_STAMP(2);                                     // layer 1 (incl. barrier)
-        if (mm) {
-            // layer 2 (actor): logit column 16w + c
-            pf_f32x4 acc = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
-            const float *ap = hidS + c * PF_HID_STRIDE + PF_HID + q;
-            float bw[PF_HID / 4];
-#pragma unroll
-            for (int s = 0; s < (int)PR_AHEAD; s++) bw[s] = bw2[s];
-#pragma unroll
-            for (int s = 0; s < PF_HID / 4; s++) {
-                if (s + (int)PR_AHEAD < PF_HID / 4) bw[s + PR_AHEAD] = PR_LOAD2(s + PR_AHEAD);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s], bw[s], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (l2live)
-                for (int rr = 0; rr < 4; rr++) lgS[(4u * q + rr) * PF_LOG_STRIDE + l2col0] = acc[rr] + bias2;
-        } else if (w == PR_MM_WAVES) {
-            // critic (model.py:22-26): lane (row c, quarter q) sums k = q (mod 4), exactly like azul_policy_forward_kernel
-            float sum = 0.f;
-            const float *hp = hidS + c * PF_HID_STRIDE;
-#pragma unroll
-            for (int s = 0; s < PF_HID / 4; s++) sum = fmaf(hp[4 * s + q], w2cS[4 * s + q], sum);
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            if (q == 0u && g0 + c < n) a.value[row_t + g0 + c] = sum + b2c_v;
-        }
-        lds_barrier();
-        PR_STAMP(3);                                     // layer 2 + critic (incl. barrier)
-        if (w >= PR_HEAD_WAVE0) {
-            // head: waves 12..15 (idle during the matrix phases) sample four games each, 16 lanes per game
-            const u32 hw = w - PR_HEAD_WAVE0, hrow = 4u * hw + q, hg = g0 + hrow;
-            float x[HEAD_PER_LANE];
-            const float *lg = lgS + hrow * PF_LOG_STRIDE + (c < 15u ? 12u * c : 0u);
-            for (int j = 0; j < HEAD_PER_LANE; j++) x[j] = lg[j];
-            const u64 M0 = maskS[hrow][0], M1 = maskS[hrow][1], M2 = maskS[hrow][2];
-            const u32 bitpos = 12u * c, word = bitpos >> 6, off = bitpos & 63u;
-            const u64 lo = word == 0u ? M0 : (word == 1u ? M1 : M2), hi = word == 0u ? M1 : M2;
-            u64 field = lo >> off;
-            if (off > 52u) field |= hi << (64u - off);
-            const u32 okbits = c < 15u ? (u32)field & 0xfffu : 0u;
-            policy_head_rows(x, lgS + hrow * PF_LOG_STRIDE, okbits, a.seed, counter + (u64)t, hg < n ? hg : n - 1u, l, hg < n, a.action + row_t, a.logp + row_t,
-                             a.entropy + row_t, b.id_base, actS + 4u * hw, &u_head);
-        }
-        lds_barrier();
-        PR_STAMP(4);                                     // head (incl. barrier)
-        if (live) {
-            const i32 av = actS[w];
-            i32 rew = 0;
-            u32 dn = 0;
-            bool dirty = true;
-            st_last = OPP ? env_agent_step<LID>(g, k, r, tab, b, gi, av, rew, dn, dirty)
-                          : env_policy_step<LID>(g, k, r, b, gi, av, rew, dn, dirty);
-            if (l == 0u) { a.reward[row_t + gi] = rew; a.done[row_t + gi] = (uint8_t)dn; }
-            publish((u32)t + 1u);
-        }
-    }
-#if defined(AZ_PROFILE_SEGMENTS)
-    if (l == 0u && w == 5u) {
-        for (int i = 0; i < 5; i++) atomicAdd((unsigned long long *)(b.prof + i), (unsigned long long)pr_acc[i]);
-        atomicAdd((unsigned long long *)(b.prof + 6), (unsigned long long)(__builtin_amdgcn_s_memtime() - pr_t0));
-        const u64 pr_r1 = __builtin_amdgcn_s_memrealtime();
-        atomicAdd((unsigned long long *)(b.prof + 7), (unsigned long long)(pr_r1 - pr_r0));
-        atomicMax((unsigned long long *)(b.prof + 5), (unsigned long long)((1ull << 62) - pr_r0));     // earliest loop start of any workgroup
-        atomicMax((unsigned long long *)(b.prof + 8), (unsigned long long)pr_r1);                      // latest loop end
-    }
-#endif
-    if (live) {
-        game_store(g, rec);
-        rng_close(r, b.mtpos + gi);
-        if (a.status && l == 0u) a.status[gi] = (uint8_t)st_last;
-    }
-    if (a.counter_dev && tid == 0u) {
-        __threadfence();
-        u64 done_blocks = atomicAdd((unsigned long long *)(a.counter_dev + 1), 1ull);
-        if (done_blocks == (u64)gridDim.x - 1ull) {
-            a.counter_dev[1] = 0ull;
-            a.counter_dev[0] += (u64)a.n_steps;
-            __threadfence();
-        }
-    }
-}

@@ -3,50 +3,32 @@
 // 32-lane halves with azul_selfplay2.hpp's rules (state in VGPRs, half-uniform), and the same 8 waves run the network on the f32
 // matrix cores between the env phases.  Included by azul_kernels.hip after azul_policy.hpp.
 //
-// Why: in azul_policy_rollout_kernel (16 waves, one game per wave, azul_core.hpp) the env phase was 40 % (policy on both sides) to
-// 50 % (RandomAgent opponent) of a move: sixteen waves run scalar-heavy rule code on the CU's ONE scalar ALU, and every move waits
-// for the slowest of the sixteen games (a round end somewhere in 78 % of the moves).  tools/rollout_profile.py: env step 6.2 k +
-// waiting for the slowest 7.2 k of 33.2 k cycles per move.  Here a move's env work is ~500 vector instructions per PAIR of games.
+// Why on the vector pipe: rounds 1-2 ran sixteen one-game waves per workgroup whose rule code sat on the CU's ONE scalar ALU, and every
+// move waited for the slowest of the sixteen games (env step 6.2 k + waiting 7.2 k of 33.2 k cycles per move; LABNOTES.md).  Here a move's
+// env work is ~500 vector instructions per PAIR of games.
 //
-// Arithmetic per output element is unchanged (the same k-ordered v_mfma_f32_16x16x4_f32 chain per hidden unit / logit, the same
-// critic summation, the same head), and the rules are azul_selfplay2.hpp's (byte-identical to azul_core.hpp's, tests/test_gpu_selfplay.py):
-// the trajectories are bit-identical to the per-move path and to the one-game-per-wave rollout kernel (tests/test_policy_bridge.py,
-// tests/test_full_size_configs.py).
+// Arithmetic per output element: the same k-ordered v_mfma_f32_16x16x4_f32 chain per hidden unit / logit, the same critic summation and
+// the same head as azul_policy_forward_kernel, and the rules are azul_selfplay2.hpp's: the trajectories are bit-identical to the
+// two-launches-per-move path (tests/test_policy_bridge.py, tests/test_full_size_configs.py).
 // Reference lines: azulnet/azul.py:296-313 (step), azulnet/game_runner.py:43-55 (GameRunner.step), :56-72 (get_state), :76-85 (reset),
 // :87-97 (RandomAgent); azulnet/nn_runner.py:17-47.
 #pragma once
 
 #include "azul_env2.hpp"
 
-#ifndef PR2_AHEAD_N
-#define PR2_AHEAD_N 6      // (k-steps of layer-1 weights in flight: 3..6 measured alike, 8 and 12 slower -- profiles/round3_policy_rollout_phases.txt)
-#endif
-#ifndef PR2_ADEPTH_N
-#define PR2_ADEPTH_N 4
-#endif
-constexpr u32 PR2_WAVES = 8, PR2_AHEAD = PR2_AHEAD_N;
+constexpr u32 PR2_WAVES = 8;
+constexpr u32 PR2_AHEAD = 6;       // k-steps of layer-1 weights in flight (3..6 measured alike, 8 and 12 slower: profiles/round3_policy_rollout_phases.txt)
+constexpr int PR2_ADEPTH = 4;      // A fragments read from LDS this many k-steps ahead
 
 // The first weight fragments of a matrix phase are REQUESTED A PHASE EARLIER (layer 1's before the env step, layer 2's before layer 1's
 // epilogue) and stay in flight across the LDS-only barriers: the matrix pipe does not wait for L2 after each barrier.
-#ifndef PR2_HOIST1_N
-#define PR2_HOIST1_N 4
-#endif
-#ifndef PR2_HOIST2_N
-#define PR2_HOIST2_N 6     // (2..6 measured alike, 8 and 12 slower: too many layer-2 fragments in flight hold up layer 1's tail)
-#endif
-constexpr int PR2_HOIST1 = PR2_HOIST1_N, PR2_HOIST2 = PR2_HOIST2_N, PR2_ADEPTH = PR2_ADEPTH_N;
-#if defined(PR2_EXPERIMENT_NO_WEIGHT_LOADS)
-// TIMING EXPERIMENT ONLY (wrong results): the matrix phases without their weight stream
-#define PR2_LOAD1(vo, s) make_float2((float)(vo) + (float)(s), 1.0f)
-#define PR2_LOAD1Q(vo, s) make_float4((float)(vo) + (float)(s), 1.0f, 2.0f, 3.0f)
-#define PR2_LOAD2(NT_, s) make_float2((float)voff + (float)(s), 1.0f)
-#else
+constexpr int PR2_HOIST1 = 4;
+constexpr int PR2_HOIST2 = 6;      // (2..6 measured alike, 8 and 12 slower: too many layer-2 fragments in flight hold up layer 1's tail)
 #define PR2_LOAD1(vo, s) __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs1, vo, (4 * (s)) * PF_H2 * 4, 0))
 // waves 0..3: FOUR adjacent hidden columns per lane and k-step in one 16-byte load (two column pairs)
 #define PR2_LOAD1Q(vo, s) __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, (4 * (s)) * PF_H2 * 4, 0))
 #define PR2_LOAD2(NT_, s) ((NT_) == 2 ? __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs2, voff, (4 * (s)) * PF_ACT * 4, 0)) \
                                       : make_float2(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, voff, (4 * (s)) * PF_ACT * 4, 0)), 0.f))
-#endif
 
 __device__ __forceinline__ void pr2_request1(bool two, const __amdgpu_buffer_rsrc_t rs1, u32 voffA, u32 voffB, float2 (&preA)[PR2_HOIST1],
                                              float2 (&preB)[PR2_HOIST1])
@@ -230,7 +212,6 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
             const u32 row = j / 34u, c4 = j - 34u * row;
             if (j < 16u * 34u && g0 + row < n) *(float4 *)(og + 4u * j) = *(const float4 *)(obsS + row * PF_OBS_STRIDE + 4u * c4);
         }
-#if !defined(PR2_X_NO_MASK_STORES)       // (TIMING EXPERIMENT switch: wrong results)
         u32 *mg = (u32 *)(a.mask + cell0 * AZUL_NUM_ACTIONS);
 #pragma unroll
         for (u32 rep = 0; rep < 4u; rep++) {
@@ -241,7 +222,6 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
                 mg[d] = (nib * 0x00204081u) & 0x01010101u;
             }
         }
-#endif
     };
     if (live) publish(0u);
     else {

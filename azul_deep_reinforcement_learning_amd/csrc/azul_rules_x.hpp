@@ -31,6 +31,7 @@
 // is_end_of_round :182-183, is_end_of_game :184-191, count_score :192-295, step :296-313, get_statistics :314-315;
 // RandomAgent game_runner.py:87-97, check_all_valid :113-117, get_state :56-72.
 #pragma once
+#include "azul_selfplay2.hpp"
 
 namespace azx {
 using namespace az;
@@ -279,7 +280,7 @@ AZ_FN void mask_limbs(const MaskX<D> &m, u64 (&limb)[Dim<D>::NL + 1])
     }
 }
 
-// ---- RandomAgent (game_runner.py:87-97 + random.choices): azul_core.hpp's decomposition of the cumulative weights -----------------
+// ---- RandomAgent (game_runner.py:87-97 + random.choices): azul_selfplay2.hpp's decomposition of the cumulative weights --------------
 // T(J, 0) = S[J], T(J, m) = m + Fr[J][ilog2 m]: pairs {Fr[J][b], S[J]} at 8 J + b, J = 0 .. Q (azul_tables.hpp build_sample_pairs)
 struct TabX { const double2 *fs; };
 

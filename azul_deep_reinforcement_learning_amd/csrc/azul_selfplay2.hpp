@@ -1,9 +1,11 @@
-// azul_selfplay2.hpp -- the flat random-agent self-play step (BASELINE configs[1], the benchmarked hot path) for TWO GAMES
-// PER 64-LANE WAVEFRONT: lanes 0..31 play one game, lanes 32..63 another.  Included by azul_kernels.hip.
+// azul_selfplay2.hpp -- THE TWO-PLAYER RULE BOOK of libazulhip.so and the flat random-agent self-play step built on it (BASELINE
+// configs[1], the benchmarked hot path), for TWO GAMES PER 64-LANE WAVEFRONT: lanes 0..31 play one game, lanes 32..63 another.
+// Included by azul_kernels.hip; azul_env2.hpp (GameRunner's step / reset / observation), azul_ops2.hpp (every two-player rule entry of
+// the C ABI) and azul_rules_x.hpp (3 / 4 players, extended rules) build on the functions below.
 //
-// Why: with one game per wave (azul_core.hpp) every per-game quantity is wave-uniform, the compiler keeps it in SGPRs and the
-// move is bound by the SCALAR pipe: one scalar ALU per CU issues ~1 instruction every 4.3 cycles per SIMD, the vector ALUs one
-// every ~2.4 (tools/issue_model.hip, profiles/round2_issue_model.txt), and a move is 253 scalar + 205 vector instructions.
+// Why two games per wave: with one game per wave (rounds 1-4 kept such a core; LABNOTES.md) every per-game quantity is wave-uniform,
+// the compiler keeps it in SGPRs and the move is bound by the SCALAR pipe: one scalar ALU per CU issues ~1 instruction every 4.3
+// cycles per SIMD, the vector ALUs one every ~2.4 (tools/issue_model.hip, profiles/round2_issue_model.txt).
 // Here every per-game quantity lives in a VGPR, replicated across the game's 32 lanes ("half-uniform"), so the rules run
 // on the vector pipe, one instruction serves two games, and the scalar pipe only carries the loop and the exec masks of
 // the rare paths (factory draw, scoring, episode reset), which are ordinary divergent branches between the two halves.
@@ -19,11 +21,14 @@
 // word, lane's constants) without a table.
 // MT19937: each game's 624 words in LDS (two regions per wave); the regeneration runs 32 lanes wide.
 //
-// The arithmetic is azul_core.hpp's, statement for statement (same exactness arguments): the trajectories are
-// byte-identical to the one-game-per-wave kernel and to the oracle (tests/test_gpu_selfplay.py, tests/test_full_size_configs.py).
-// Reference lines as in azul_core.hpp: azulnet/azul.py:64-89, 118-161, 162-176, 177-191, 192-313; azulnet/game_runner.py:43-55,
-// 76-97; CPython random.py / _randommodule.c.
+// Exactness arguments: DESIGN.md 4; the trajectories are byte-identical to the oracle (tests/test_gpu_selfplay.py,
+// tests/test_full_size_configs.py).
+// Reference lines: new_round azulnet/azul.py:64-89, move :118-161, is_legal_move :162-176, next_player / is_end_of_round /
+// is_end_of_game :177-191, count_score :192-295, step :296-313; GameRunner.step / reset azulnet/game_runner.py:43-55, 76-85,
+// RandomAgent :87-97, check_all_valid :113-117; random.seed / random() / getrandbits / _randbelow / choices: CPython 3.10
+// (_randommodule.c, random.py).
 #pragma once
+#include "azul_common.hpp"
 
 namespace az2 {
 using namespace az;
@@ -32,25 +37,12 @@ AZ_FN u32 wlane() { return wv::lane(); }
 AZ_FN bool upper() { return (wlane() & 32u) != 0u; }
 // my half's word of a wave ballot.  The select becomes ONE v_lshrrev_b64 by (lane & 32): a quarter-rate instruction (~8 cycles of the pipe),
 // but the kernel is bound by the number of instructions a wave issues, not by pipe cycles -- the two full-rate instructions of
-// (lo & mlo) | (hi & mhi) with per-lane masks measured 4.6 % SLOWER (-DAZ2_HSEL_MASKS, round 3)
-#if defined(AZ2_HSEL_MASKS)
-AZ_FN u32 hsel(u64 b)
-{
-    u32 mhi = 0u - (wlane() >> 5), mlo = (wlane() >> 5) - 1u;
-    asm("" : "+v"(mhi), "+v"(mlo));
-    return ((u32)b & mlo) | ((u32)(b >> 32) & mhi);
-}
-#else
+// (lo & mlo) | (hi & mhi) with per-lane masks measured 4.6 % SLOWER (round 3; LABNOTES.md)
 AZ_FN u32 hsel(u64 b) { return upper() ? (u32)(b >> 32) : (u32)b; }
-#endif
 // the half's 32 lanes as a bitboard
 AZ_FN u32 hb(bool p) { return hsel(__builtin_amdgcn_ballot_w64(p)); }
 // value of lane `idx` of MY half, idx per lane (a gather through the LDS crossbar; idx in 0..31)
-#if defined(AZ2_EXPERIMENT_NO_LDS)
-AZ_FN u32 hread(u32 v, u32 idx) { return v + (idx & 0u); }     // TIMING EXPERIMENT ONLY (wrong results): no LDS round trips
-#else
 AZ_FN u32 hread(u32 v, u32 idx) { return (u32)__builtin_amdgcn_ds_bpermute((int)((idx << 2) | ((wlane() & 32u) << 2)), (int)v); }
-#endif
 // the same for a HALF-UNIFORM idx.  (Measured: the LDS crossbar beats a v_readlane pair per half + select -- two instructions and one
 // wait against seven instructions with SGPR hazards: 1.125 vs 1.195 ms per 512-move launch.)
 AZ_FN u32 hbcast(u32 v, u32 idx) { return hread(v, idx); }
@@ -59,9 +51,6 @@ AZ_FN u32 hread4(u32 v, u32 idx, u32 h4) { return (u32)__builtin_amdgcn_ds_bperm
 template <u32 IDX>
 AZ_FN u32 hbcast_c(u32 v)
 {
-#if defined(AZ2_CONST_BCAST_LDS)
-    return hread(v, IDX);
-#endif
     u32 a = (u32)__builtin_amdgcn_readlane((int)v, (int)IDX), b = (u32)__builtin_amdgcn_readlane((int)v, (int)(IDX + 32u));
     return upper() ? b : a;
 }
@@ -82,28 +71,16 @@ AZ_FN u32 dpp0(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL,
 // (the round-2 form -- row_shr chain, row_bcast:15, two v_readlane, two moves, a select -- needed ten)
 AZ_FN u32 hsum(u32 v)
 {
-#if defined(AZ2_HSUM_READLANE)
-    v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);   // row_shr 1, 2, 4, 8
-    v += dpp0<0x142, 0xa>(v);                                                                             // row_bcast:15 into rows 1 and 3
-    return hbcast_c<31>(v);
-#else
     v += dpp0<0xB1, 0xf>(v); v += dpp0<0x4E, 0xf>(v); v += dpp0<0x141, 0xf>(v); v += dpp0<0x140, 0xf>(v);
     auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
     return (u32)r[0] + (u32)r[1];
-#endif
 }
 AZ_FN u32 umax(u32 a, u32 b) { return a > b ? a : b; }
 AZ_FN u32 hmax(u32 v)
 {
-#if defined(AZ2_HSUM_READLANE)
-    v = umax(v, dpp0<0x111, 0xf>(v)); v = umax(v, dpp0<0x112, 0xf>(v)); v = umax(v, dpp0<0x114, 0xf>(v)); v = umax(v, dpp0<0x118, 0xf>(v));
-    v = umax(v, dpp0<0x142, 0xa>(v));
-    return hbcast_c<31>(v);
-#else
     v = umax(v, dpp0<0xB1, 0xf>(v)); v = umax(v, dpp0<0x4E, 0xf>(v)); v = umax(v, dpp0<0x141, 0xf>(v)); v = umax(v, dpp0<0x140, 0xf>(v));
     auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
     return umax((u32)r[0], (u32)r[1]);
-#endif
 }
 
 // ---- per-lane constants -------------------------------------------------------------------------------------------------
@@ -157,7 +134,10 @@ struct G2 {
     u32 lidp;                   // per lane: tiles of colour l (< 5) that scoring has returned to the lid since the last fold (lid_fold2)
     i32 pscore;
     u32 moves;
-    i32 wc0, wc1, wi0, wi1;     // what-if cache (game_runner.py:48-50), see azul_core.hpp
+    // what-if cache (game_runner.py:48-50: deepcopy + count_score after every move).  A move only changes the MOVER's lines and floor, and
+    // the wall pricing of a player's full lines only changes when one more of his lines becomes full: wc = points the player's currently
+    // FULL pattern lines would earn (count_wall), wi = what-if score max(0, score + floor penalty + wc).  Derived, never stored.
+    i32 wc0, wc1, wi0, wi1;
     u32 over;
     u32 B;                      // derived: sources holding tiles, hb(cs != 0) & 0x7fffffff (refreshed whenever cs changes)
     u32 ok0, ok1;               // derived: the players' "row r accepts colour c" boards (bit 5r + c), see ok_board2
@@ -224,11 +204,13 @@ AZ_FN void g2_store(const G2 &g, uint8_t *rec, u32 l)
     if (l < 11u) ((u32 *)(rec + 84))[l] = t;
 }
 
-// ---- CPython MT19937 stream of one game (azul_core.hpp's Rng, 32 lanes wide) ---------------------------------------------
+// ---- CPython MT19937 stream of one game ---------------------------------------------------------------------------------------
+// The 624-word state lives in global memory (row of a [N][624] array: a half's accesses are contiguous); it is staged into the game's LDS
+// region when the stream is opened, the regeneration ("twist") runs there 32 lanes wide, and it is written back on close if it changed.
 struct Rng2 {
     u32 *lds;        // my game's 624 words in LDS
     u32 *tlds;       // optional: the same 624 words TEMPERED (kept current by the regeneration), what genrand_uint32 returns for index i;
-                     // the rotated self-play loop reads a move's two words from here with one LDS read and no arithmetic
+                     // the self-play loop reads a move's two words from here with one LDS read and no arithmetic
     u32 pos;         // CPython's `index`
     u32 dirty;       // a regeneration happened: LDS differs from global memory
     u32 wbase, wend; // the window `win` serves words wbase .. wend-1 (wend == 0: none loaded)
@@ -385,14 +367,20 @@ AZ_FN void legal_mask2(const G2 &g, const K2 &k, Mask2 &out)
     }
 }
 
-// ---- RandomAgent: game_runner.py:87-97 + random.choices; azul_core.hpp's decomposition of the cumulative weights -------------
+// ---- RandomAgent: game_runner.py:87-97 + random.choices (random.py:506-541) ---------------------------------------------------
+// The cumulative weight CPython's accumulate() reaches after J weights of 0.01 (legal floor moves, a < 30) and m weights of 1.0 is
+// T(J, 0) = S[J]  and, for m >= 1,  T(J, m) = m + Fr[J][floor(log2 m)]  EXACTLY: adding 1.0 only rounds when the sum enters a new binade,
+// so per J there are 8 distinct fractional parts (azul_tables.hpp builds both tables with the very additions CPython performs; the host
+// checks all 31 * 151 sums when a batch is created).  bisect_right over the cumulative weights == the smallest ordinal k with cum(k) > x.
+// Pattern moves: |Fr - S[J]| < 2^-44 (a handful of half-ulp roundings below 256) and d = x - S[J] carries an fp64 error below 2^-45, so
+// whenever d is further than 1e-9 from an integer, floor(d) + 1 IS the ordinal; otherwise the exact table values decide (sample_slow2).
 struct Tab2 { const double *fr; const double *s; const double2 *fs; };      // LDS: Fr[31][8], S[31], and {Fr[J][b], S[J]} pairs (one 16-byte read)
 
 AZ_FN double tpat2(const Tab2 &t, u32 J, u32 m) { return (double)m + t.fr[8u * J + 31u - (u32)__builtin_clz(m)]; }
 AZ_FN double tseq2(const Tab2 &t, u32 J, u32 kk) { return kk <= J ? t.s[kk] : tpat2(t, J, kk - J); }
 
 // bisect_right over the cumulative weights == smallest ordinal kk with cum(kk) > x: the generic search (x inside the 0.01-weight
-// floor moves, or a guess too close to an integer boundary: rare, see azul_core.hpp)
+// floor moves, or a guess too close to an integer boundary: rare)
 AZ_FN u32 sample_slow2(const Tab2 &T, double x, double sJ, u32 J, u32 M, u32 L)
 {
     u32 kg;
@@ -431,15 +419,9 @@ AZ_FN bool do_move2f(G2 &g, u32 src, u32 db, u32 c, u32 row, bool from_display, 
     // the three cell gathers of a move depend on the chosen action only: requested together (ONE LDS round trip on the move's chain)
     const u32 cell = 5u * ((row ? row : 1u) - 1u) + c;
     u32 mine = me ? g.cp1 : g.cp0;
-    u32 n = hread4(g.cs, src, k.h4);                                   // :127 / :136
+    const u32 n = hread4(g.cs, src, k.h4);                             // :127 / :136
     const u32 moved = hread4(g.cs, l - 25u + db, k.h4);                // :131
     const u32 old = hread4(mine, cell, k.h4);
-#if defined(AZ2_EXPERIMENT_EXTRA_LDS)
-    n = hread(n, l);                                                   // TIMING EXPERIMENT: one more dependent LDS round trip (identity)
-#endif
-#if defined(AZ2_EXPERIMENT_EXTRA_BRANCH)
-    asm volatile("s_branch 1f\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n 1:\n s_branch 2f\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n 2:\n s_branch 3f\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n 3:\n s_branch 4f\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n 4:" ::: "memory");   // TIMING EXPERIMENT: four taken branches
-#endif
     bool token = (!from_display) & (((B >> 30) & 1u) != 0u);           // :140
     bool centre = (l >= 25u) & (l < 30u) & (l != 25u + c) & from_display;
     bool gone = ((l >= db) & (l < db + 5u) & from_display) | (l == src) | ((l == 30u) & token);   // :129,:133,:138,:141
@@ -474,7 +456,9 @@ AZ_FN bool do_move2(G2 &g, u32 code, u32 B /* sources before the move */, const 
     return do_move2f<LID>(g, code & 31u, (code >> 5) & 31u, (code >> 10) & 7u, (code >> 13) & 7u, ((code >> 16) & 1u) != 0u, B, k);
 }
 
-// ---- wall pricing: azul_core.hpp's score_boards for one player in lanes 0..24 --------------------------------------------
+// ---- wall pricing (count_wall, azul.py:211-290) for one player in lanes 0..24 -----------------------------------------------------
+// EVERY pattern cell (lane = row, colour) prices "a tile placed here now" against the player's wall plus the full lines that are scored
+// before it (ascending row, colour: K2::pbelow), so the sequential dependency of the reference's loop is reproduced without a loop.
 struct Score2 { u32 val, pos; u32 rowdone, colordone, coldone; };
 
 AZ_FN u32 run_length2(u32 bits, u32 pos)
@@ -580,7 +564,14 @@ AZ_FN void count_score2(G2 &g, const K2 &k)
     g.ok1 = ok_board2(g.cp1, g.wall1, k);
 }
 
-// ---- new_round: azul.py:64-89 (deal_factories of azul_core.hpp, 32 lanes) ------------------------------------------------
+// ---- new_round: azul.py:64-89 ------------------------------------------------------------------------------------------------------
+// "Lid" pool (azul.py:79-89): every draw is one random.choices over weights box_c / total -> exactly one random() = two MT words.
+// Deciding a draw.  CPython returns  #{c < 4 : cum_c <= x}  with cum_c the left-to-right fp64 sum of fl(box_j / total) and
+// x = fl(random() * cum_4).  In exact arithmetic that is  P_c / T <= K / 2^53, i.e.  P_c * 2^53 <= K * T  (P_c = box_0 + .. + box_c,
+// T = total, K = the 53-bit integer of random()).  All fp64 roundings together move cum_c and x by less than 21.1 * 2^-53 (five quotients,
+// four sums, one product, all <= 1 + 2^-50), so the fp64 decision can differ from the exact one only if |K*T - P_c*2^53| <= 21.1 * T <=
+// 5381.  P_c * 2^53 is a multiple of 2^32: when no multiple of 2^32 lies within AZ_DRAW_MARGIN = 8192 of K*T the integer comparison IS
+// CPython's answer; otherwise (about 4 draws in a million) the draw is decided by the literal fp64 computation.
 template <bool LID>
 AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k);
 
@@ -594,8 +585,8 @@ AZ_FN u32 new_round2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
 
 // n <= 32 consecutive "Lid" draws of a round at once, when the box holds at least n tiles (no refill can happen inside): az2::deal_tiles2's parallel fixed point for any number of draws -- lane t owns draw t,
 //     colour_t = #{c < 4 : (P_c - n_c(t)) * 2^53 <= K_t * (T0 - t)},   n_c(t) = #{s < t : colour_s <= c},
-// iterated from a first guess until nothing changes (the unique fixed point is the sequential result) -- with azul_core.hpp's exactness
-// argument (a draw whose K * T lies within `margin` of a multiple of 2^32 sends the n draws through the literal fp64 code, one after
+// iterated from a first guess until nothing changes (the unique fixed point is the sequential result) -- with the exactness
+// argument above (a draw whose K * T lies within `margin` of a multiple of 2^32 sends the n draws through the literal fp64 code, one after
 // the other, on the words already fetched) and the same handling of a regeneration inside the 2 n words.
 // XC: cells of the second cell register (displays 5 ..: azul_rules_x.hpp; 0 = the reference's five displays, cs1 unused).
 template <u32 XC>
@@ -741,9 +732,9 @@ AZ_FN u32 deal2(G2 &g, Rng2 &r, u64 margin, const K2 &k)
     return deal_tiles2<LID>(g.cs, g.box, g.lid, g.lidp, r, margin, k);
 }
 
-// Azul.__init__ + GameRunner's reset bookkeeping (azul.py:18-61, game_runner.py:76-82), then the first round
+// Azul.__init__ (azul.py:18-61): an empty board, the first player drawn or fixed, the box filled
 template <bool LID>
-AZ_FN u32 episode_reset2(G2 &g, u32 first_player, Rng2 &r, u64 margin, const K2 &k)
+AZ_FN void game_ctor2(G2 &g, u32 first_player, Rng2 &r, const K2 &k)
 {
     g.cs = 0; g.cp0 = 0; g.cp1 = 0;
     g.wall0 = g.wall1 = 0; g.score0 = g.score1 = 0; g.floor0 = g.floor1 = 0;
@@ -756,6 +747,13 @@ AZ_FN u32 episode_reset2(G2 &g, u32 first_player, Rng2 &r, u64 margin, const K2 
     if (LID) { g.box = 0x1414141414ull; g.lid = 0; }
     else { g.box = 0; g.lid = 0; }
     g.lidp = 0;
+}
+
+// Azul.__init__ + GameRunner's reset bookkeeping (game_runner.py:76-82), then the first round
+template <bool LID>
+AZ_FN u32 episode_reset2(G2 &g, u32 first_player, Rng2 &r, u64 margin, const K2 &k)
+{
+    game_ctor2<LID>(g, first_player, r, k);
     g.pscore = 0;
     g.moves = 0;
     return new_round2<LID>(g, r, margin, k);
@@ -802,14 +800,9 @@ AZ_FN void outputs2(const G2 &g, const Out2 &o, i32 a, i32 reward, u32 dn, u32 l
         // A store instruction costs this kernel ~45 cycles of a wave's time (ten times a vector instruction: measured by leaving
         // stores out), so the three 4-byte records of a move leave in ONE instruction -- lane 0 of the half writes the action, lane 1
         // the reward, the other lanes the compact record (same address, same data: no exec masking) -- and `done` in a second one.
-#if defined(AZ2_X_NO_SCALAR_STORES)
-        if (l > 64u)
-#endif
-        {
-            const u32 pk = pack_move(a, dn, reward);
-            o.dw3[o.e] = l == 0u ? (u32)av : (l == 1u ? (u32)reward : pk);
-            o.done[o.e] = (uint8_t)dn;
-        }
+        const u32 pk = pack_move(a, dn, reward);
+        o.dw3[o.e] = l == 0u ? (u32)av : (l == 1u ? (u32)reward : pk);
+        o.done[o.e] = (uint8_t)dn;
     } else {
         if (l == 0u) {
             if (o.action) o.action[o.e] = av;
@@ -829,9 +822,6 @@ AZ_FN void outputs2(const G2 &g, const Out2 &o, i32 a, i32 reward, u32 dn, u32 l
 template <bool PAD>
 AZ_FN void store_mask_row2(const Out2 &o, u32 m0, u32 m1, u32 m2, u32 m3, u32 m4, u32 m5, u32 b0, u32 b1, u32 b2, u32 b3, u32 b4, u32 b5, u32 l)
 {
-#if defined(AZ2_X_NO_MASK_STORES)
-    return;
-#endif
     if (PAD) {
         // the 180 bits as six dwords (the 30-bit row words back to back); lane j's eight bits are byte j & 3 of dword j >> 2 -- a
         // byte-aligned field, picked with lane-constant masks (no lane-dependent control flow) and one bit-field extract
@@ -911,11 +901,7 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
     // (not when the move ends the round: count_score2 below prices the lines for real and clears the cache)
     const bool eor = g.B == 0u;                              // :306 is_end_of_round (the token counts)
     i32 wc = me ? g.wc1 : g.wc0;
-#if defined(AZ2_ALWAYS_WALLPTS)
-    {
-#else
     if (wave_any(filled & !eor)) {
-#endif
         i32 fresh = wall_points2(me ? g.wall1 : g.wall0, full_lines2(me ? g.cp1 : g.cp0, k), k);
         wc = filled ? fresh : wc;
     }
@@ -949,12 +935,10 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
     u32 ret = st != ST_OK ? (0x100u | st) : dn;
     if (AZ_UNLIKELY(any_done)) {
         if ((dn != 0u) & (st == ST_OK)) {
-#if !defined(AZ2_X_NO_STATS)
             {
                 const double f0 = (double)(g.fps & 0xffffu), f1 = (double)(g.fps >> 16);
                 counters2_episode(cnt, stat_lane(l, g.score0, g.score1, g.turn, f0 / (f0 + f1) * 100, g.fp0, g.mc0, g.cl0));
             }
-#endif
             u32 st2 = episode_reset2<LID>(g, first_player, r, margin, k);     // GameRunner.reset(): Azul(rules) ... new_round()
             if (st2) ret = 0x100u | st2;
         }
@@ -964,7 +948,7 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
     return ret;
 }
 
-// One env move of flat random-agent self-play for the two games of a wave (selfplay_step of azul_core.hpp).
+// One env move of flat random-agent self-play for the two games of a wave.
 // Returns 0 = move played, 1 = game ended with this move, 2 = stuck, 0x100 | status on a rule error.
 //
 // Control flow: two waves per SIMD cannot hide a taken branch's instruction refetch, so the common move is ONE fall-through path;
@@ -1094,168 +1078,6 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
         AZ_STAMP(SEG_MOVE);
         g.B = hb(g.cs != 0u) & 0x7fffffffu;                      // the sources after the move (next move's mask reads it)
         ret = after_move2<LID, OUT>(g, first_player, k, r, margin, cnt, o, me, filled, a, prof_, dead);
-    }
-    return ret;
-}
-
-// ---- the benchmarked loop: the same moves, ROTATED so that one move's instruction chain is short -------------------------------
-// A move is a serial chain -- mask -> counts -> cumulative weights -> sample -> action -> move -> what-if score -> reward -- and two
-// waves per SIMD (4096 games) cannot hide the latency of a dependent instruction (~8.6 cycles against ~2.9 for independent ones,
-// tools/issue_model.hip): the kernel ran one instruction per ~9 cycles and wave.  But only part of that chain is loop-carried:
-//     sample(t) -> do_move(t) -> [mask, counts, weights, random words of move t+1] -> sample(t+1)
-// while the what-if score, the reward and the stores of move t hang off do_move(t) as a side chain.  The loop below therefore keeps
-// the DECISION OF THE NEXT MOVE PREPARED (Prep2: everything about a decision that depends on the state alone) and its common
-// iteration is ONE basic block in which the side chain of move t and the preparation of move t+1 are independent instruction
-// streams for the scheduler to interleave.  Everything unusual -- a decision at a boundary of the cumulative weights, random words
-// across a regeneration, nothing legal, the end of a round / game -- is tested once per wave and takes selfplay_step2 / after_move2,
-// the code above, on the very same state; then the next decision is prepared afresh.  Same moves, same bytes.
-struct Prep2 {
-    u32 m0, m1, m2, m3, m4, m5;          // legal_mask2 of the state: the six mask words ...
-    u32 b0, b1, b2, b3, b4, b5;          // ... and my bit of each (named scalars: an array indexed by a select chain would be turned into
-                                         // an indexed load and pin the whole struct in scratch memory)
-    u32 B;
-    u32 p2, p3, p4, p5;          // legal actions in mask words 0 .. w-1 (p1 == J)
-    u32 J, M;
-    double total, sJ, u;         // cum(J + M) + 0.0, S[J], random() of the two words at r.pos
-    bool unusual;                // nothing legal / a finished game handed in / the two words straddle a regeneration
-};
-
-// prepare2 in two halves, so that the common path can put independent work between the LDS requests and their use:
-// prepare2_request: mask, counts, the addresses, the two LDS reads (table pair, random words); prepare2_finish: the three doubles.
-struct PrepLoads2 { double2 fs; u32 wa, wb; };
-
-AZ_FN void prepare2_request(const G2 &g, const K2 &k, const Rng2 &r, const Tab2 &T, Prep2 &P, PrepLoads2 &q)
-{
-    Mask2 m;
-    legal_mask2(g, k, m);
-    P.m0 = m.m[0]; P.m1 = m.m[1]; P.m2 = m.m[2]; P.m3 = m.m[3]; P.m4 = m.m[4]; P.m5 = m.m[5];
-    P.b0 = m.bit[0]; P.b1 = m.bit[1]; P.b2 = m.bit[2]; P.b3 = m.bit[3]; P.b4 = m.bit[4]; P.b5 = m.bit[5];
-    P.B = m.B;
-    const u32 c0 = __popc(m.m[0]), c1 = __popc(m.m[1]), c2 = __popc(m.m[2]), c3 = __popc(m.m[3]), c4 = __popc(m.m[4]), c5 = __popc(m.m[5]);
-    P.J = c0;
-    P.p2 = c0 + c1; P.p3 = P.p2 + c2; P.p4 = P.p3 + c3; P.p5 = P.p4 + c4;
-    const u32 L = P.p5 + c5;
-    const bool nomove = (L == 0u) | (g.eog != 0u);
-    const u32 M = L - P.J, Mc = M ? M : 1u;
-    P.M = M;
-    q.fs = T.fs[8u * (P.J < 31u ? P.J : 30u) + 31u - (u32)__builtin_clz(Mc)];
-    const bool hard = r.pos + 2u > 624u;
-    const u32 i = hard ? 622u : r.pos;
-    q.wa = r.tlds[i]; q.wb = r.tlds[i + 1u];                // genrand_uint32() twice: the tempered words, one 8-byte LDS read
-    P.unusual = nomove | hard;
-}
-
-AZ_FN void prepare2_finish(Prep2 &P, const PrepLoads2 &q)
-{
-    P.sJ = q.fs.y;
-    P.total = ((double)P.M + (P.M ? q.fs.x : q.fs.y)) + 0.0;
-    P.u = ((double)(q.wa >> 5) * 67108864.0 + (double)(q.wb >> 6)) * (1.0 / 9007199254740992.0);
-}
-
-AZ_FN void prepare2(const G2 &g, const K2 &k, const Rng2 &r, const Tab2 &T, Prep2 &P)
-{
-    PrepLoads2 q;
-    prepare2_request(g, k, r, T, P, q);
-    prepare2_finish(P, q);
-}
-
-template <bool LID, int OUT, bool PAD, bool BITS>
-AZ_FN u32 selfplay_rotated2(G2 &g, Prep2 &P, u32 first_player, const K2 &k, Rng2 &r, const Tab2 &T, u64 margin, Counters2 &cnt,
-                            const Out2 &o, SegProf *prof_ = nullptr)
-{
-    (void)prof_;
-    const u32 l = k.l;
-    bool dead = false;           // (this loop keeps the per-game exit on the returned status)
-    // Control flow: a SEQUENCE of wave-uniform if-blocks without else branches or early exits (the loop around this function has a
-    // per-game exit, so its body is structurised as a whole: nested if / else with the whole game state live turned into chains of
-    // flow blocks with ~100 register copies per move; a sequence of if-blocks joins without copies on the common path).
-    // -- RandomAgent's draw on the prepared weights (selfplay_step2's arithmetic)
-    const double x = P.u * P.total;
-    const double d = x - P.sJ;
-    const u32 fl = (u32)d;
-    const double fr = d - (double)fl;
-    const bool edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (fl + 1u > P.M);
-    const bool general = wave_any(P.unusual | edge | (g.over != 0u));
-    u32 ret = 0;
-    if (AZ_UNLIKELY(general)) {
-        // [1] the whole move the general way for both games of the wave (nothing has been changed yet), then a fresh preparation
-        ret = selfplay_step2<LID, OUT, PAD, BITS>(g, first_player, k, r, T, margin, cnt, o, prof_, dead);
-        prepare2(g, k, r, T, P);
-    }
-    u32 me = 0;
-    i32 a = 0;
-    bool filled = false;
-    if (!general) {
-        // [2] the common decision: mask row out, action from the ordinal, the move itself
-        AZ_STAMP(SEG_LOOP);
-        if (OUT == 1 || (OUT == 2 && o.mask))
-            store_mask_row2<(PAD && OUT == 1)>(o, P.m0, P.m1, P.m2, P.m3, P.m4, P.m5, P.b0, P.b1, P.b2, P.b3, P.b4, P.b5, l);
-        if ((OUT == 1 && BITS) || (OUT == 2 && o.maskbits)) {
-            const u64 q0 = (u64)P.m0 | ((u64)P.m1 << 30) | ((u64)P.m2 << 60);
-            const u64 q1 = ((u64)P.m2 >> 4) | ((u64)P.m3 << 26) | ((u64)P.m4 << 56);
-            const u64 q2 = ((u64)P.m4 >> 8) | ((u64)P.m5 << 22);
-            const u32 q = l < 2u ? l : 2u;
-            o.maskbits[o.e * 3u + q] = q == 0u ? q0 : (q == 1u ? q1 : q2);
-        }
-        AZ_STAMP(SEG_MASK);
-        r.pos += 2u;
-        const u32 want = P.J + fl;                               // ordinal - 1 of the chosen legal action
-        const bool g1 = want >= P.J, g2 = want >= P.p2, g3 = want >= P.p3, g4 = want >= P.p4, g5 = want >= P.p5;
-        // (the words and prefix counts pass through an empty asm first: a select chain over fields of a struct that is reached through a
-        // reference is folded into ONE load from a selected address before the struct is split into registers, which pins it in scratch)
-        u32 m0 = P.m0, m1 = P.m1, m2 = P.m2, m3 = P.m3, m4 = P.m4, m5 = P.m5, q1 = P.J, q2 = P.p2, q3 = P.p3, q4 = P.p4, q5 = P.p5;
-        asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4), "+v"(m5));
-        asm volatile("" : "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5));
-        const u32 mword = g5 ? m5 : g4 ? m4 : g3 ? m3 : g2 ? m2 : g1 ? m1 : m0;
-        const u32 base = g5 ? q5 : g4 ? q4 : g3 ? q3 : g2 ? q2 : g1 ? q1 : 0u;
-        const u32 prow_ = (u32)g1 + (u32)g2 + (u32)g3 + (u32)g4 + (u32)g5;
-        // (selfplay_step2's single compare)
-        const bool hit = (((u32)__popc(mword & ((1u << l) - 1u)) - (want - base)) << 1) + ((mword >> l) & 1u) == 1u;
-        const u32 who = hb(hit);
-        const u32 ln = (u32)__builtin_ctz(who | 0x80000000u);
-        const u32 code = hbcast(k.lcode, ln) | (prow_ << 13) | ((30u * prow_ + ln) << 17);
-        a = (i32)(code >> 17);
-        AZ_STAMP(SEG_SAMPLE);
-        me = me2(g);
-        filled = do_move2<LID>(g, code, P.B, k);                 // azul.py:304
-        g.moves += 1u;
-        AZ_STAMP(SEG_MOVE);
-        g.B = hb(g.cs != 0u) & 0x7fffffffu;
-    }
-    const bool round_over = !general & wave_any(g.B == 0u);
-    if (AZ_UNLIKELY(round_over)) {
-        // [3] a round (perhaps a game) ends in at least one of the two games: the general tail for both, a fresh preparation
-        ret = after_move2<LID, OUT>(g, first_player, k, r, margin, cnt, o, me, filled, a, prof_, dead);
-        prepare2(g, k, r, T, P);
-    }
-    if (!general & !round_over) {
-        // [4] nobody's round ended: next player, then two independent instruction streams in one block --
-        g.cur = (g.cur & 1u) + 1u;                    // :313 next_player
-        // (a) the loop-carried stream: the decision of move t + 1 up to its two LDS requests
-        PrepLoads2 q;
-        prepare2_request(g, k, r, T, P, q);
-        // (b) the side chain of move t: what-if score of the mover (game_runner.py:48-50) ...
-        i32 wc = me ? g.wc1 : g.wc0;
-#if defined(AZ2_ROT_ALWAYS_WALLPTS)
-        {
-#else
-        if (wave_any(filled)) {
-#endif
-            i32 fresh = wall_points2(me ? g.wall1 : g.wall0, full_lines2(me ? g.cp1 : g.cp0, k), k);
-            wc = filled ? fresh : wc;                            // (a line that did not fill leaves the pricing of the full lines as it was)
-        }
-        __builtin_amdgcn_sched_barrier(0);                       // (a) and (b) above: free to interleave; the rest below the requests
-        // ... shaped reward, stores: under the LDS requests' latency
-        const i32 wi = clamp0((me ? g.score1 : g.score0) + floor_penalty(me ? g.floor1 : g.floor0) + wc);
-        g.wc0 = me ? g.wc0 : wc; g.wc1 = me ? wc : g.wc1;
-        g.wi0 = me ? g.wi0 : wi; g.wi1 = me ? wi : g.wi1;
-        const i32 phi = g.wi0 - g.wi1;
-        const i32 reward = phi - g.pscore;
-        g.pscore = phi;
-        outputs2<OUT>(g, o, a, reward, 0u, l);
-        __builtin_amdgcn_sched_barrier(0);
-        prepare2_finish(P, q);
-        AZ_STAMP(SEG_TAIL);
     }
     return ret;
 }

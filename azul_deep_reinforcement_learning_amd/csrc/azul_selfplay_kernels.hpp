@@ -1,9 +1,10 @@
-// azul_selfplay_kernels.hpp -- the small kernels of the self-play path as a header: the per-game stream seeding, the discounted-returns
-// scans (one window / a ring of windows), the one-game-per-wave self-play kernel of round 1 (AZUL_SELFPLAY_KERNEL=1: the A/B partner) and
-// THE BENCHMARKED KERNEL, azul_selfplay2_kernel (two games per wavefront, csrc/azul_selfplay2.hpp).  azul_kernels.hip includes this file;
+// azul_selfplay_kernels.hpp -- the kernels of the self-play path as a header: the per-game stream seeding, the two-player rule kernel
+// (azul_op_kernel on azul_ops2.hpp), the discounted-returns scans (one window / a ring of windows) and THE BENCHMARKED KERNEL,
+// azul_selfplay2_kernel (two games per wavefront, csrc/azul_selfplay2.hpp).  azul_kernels.hip includes this file;
 // tests/hostcheck/simt_selfplay2.cpp compiles it UNMODIFIED with g++ and runs these kernels under the lockstep wave emulation, so the CPU
 // check and the sanitizer passes cover the kernels themselves (XCD-aware game placement, staging, the move loop), not a restatement.
 #pragma once
+#include "azul_ops2.hpp"
 
 __global__ void __launch_bounds__(64) azul_seed_kernel(BatchDev b, u64 seed_base, const u64 *seeds)
 {
@@ -14,12 +15,15 @@ __global__ void __launch_bounds__(64) azul_seed_kernel(BatchDev b, u64 seed_base
     b.mtpos[g] = 624u;
 }
 
+// One rule call per game: grid = ceil(a.count / 2) one-wave workgroups, two games per wavefront (azul_ops2.hpp).
 template <bool LID>
 __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
 {
-    __shared__ u32 mt_lds[624];
-    __shared__ double fr_lds[T_ROWS * T_BINADES];
-    op_body<LID>(b, a, blockIdx.x, mt_lds, fr_lds);
+    __shared__ u32 mt_lds[2][624];
+    __shared__ double tab_lds[T_WORDS];
+    __shared__ double2 tabfs_lds[T_ROWS * T_BINADES];
+    __shared__ float obs_lds[2][OP2_OBS_STRIDE];
+    op_body2<LID>(b, a, blockIdx.x, mt_lds, tab_lds, tabfs_lds, obs_lds);
 }
 
 // Discounted returns over the time-major trajectory of one launch window (reference loop: nn_runner.py:70-76,
@@ -86,73 +90,10 @@ struct TrajArgs {
     u32 *packed;       // [T][N]
 };
 
-template <bool LID, int OUT>
-__global__ void __launch_bounds__(64) azul_selfplay_kernel(BatchDev b, TrajArgs t)
-{
-    __shared__ u32 mt_lds[624];
-    __shared__ double fr_lds[T_ROWS * T_BINADES];
-    const u32 gi = blockIdx.x;
-    const size_t N = b.n;
-    uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
-    LaneConst k;
-    lane_consts(k);
-    SampleTab tab;
-    sample_tab_load(tab, b.T, fr_lds);
-    Game g;
-    game_load(g, rec);
-    game_prime<LID>(g, k);
-    Rng r;
-    rng_open(r, b.mt + (size_t)gi * 624u, mt_lds, b.mtpos[gi]);
-    r.margin = b.draw_margin;
-    Counters cnt = {b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10};
-    OutV ov;
-    OutS os = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t sm = 0, sb = 0, sa = 0, sr = 0, sd = 0, sc = 0, sp = 0;
-    if (OUT == 1) {
-        outv_open(ov, gi, b.n, t.mask, t.maskbits, t.action, t.reward, t.done, t.packed);
-    } else {
-        outv_open(ov, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-        if (OUT == 2) {
-            os.mask = t.mask ? t.mask + (size_t)gi * AZUL_NUM_ACTIONS : nullptr;
-            os.maskbits = t.maskbits ? t.maskbits + (size_t)gi * 3 : nullptr;
-            os.action = t.action ? t.action + gi : nullptr;
-            os.reward = t.reward ? t.reward + gi : nullptr;
-            os.done = t.done ? t.done + gi : nullptr;
-            os.rec = t.rec ? t.rec + (size_t)gi * AZUL_RECORD_BYTES : nullptr;
-            os.packed = t.packed ? t.packed + gi : nullptr;
-            sp = os.packed ? N : 0;
-            sm = os.mask ? N * AZUL_NUM_ACTIONS : 0; sb = os.maskbits ? N * 3 : 0; sa = os.action ? N : 0;
-            sr = os.reward ? N : 0; sd = os.done ? N : 0; sc = os.rec ? N * AZUL_RECORD_BYTES : 0;   // a NULL stream stays NULL
-        }
-    }
-#if defined(AZ_PROFILE_SEGMENTS)
-    SegProf prof;
-    for (int q = 0; q < SEG_COUNT; q++) prof.acc[q] = 0;
-    prof.last = __builtin_amdgcn_s_memtime();
-    SegProf *pp = &prof;
-#else
-    SegProf *pp = nullptr;
-#endif
-#pragma unroll 1
-    for (int s = 0; s < t.n_steps; s++) {
-        u32 f = selfplay_step<LID, OUT>(g, b.rules.first_player, k, r, tab, cnt, ov, os, pp);
-        if (f & 0x100u) break;      // rule error (box empty): leave the game as it is
-        if (OUT == 1) outv_next(ov);
-        if (OUT == 2) { os.mask += sm; os.maskbits += sb; os.action += sa; os.reward += sr; os.done += sd; os.rec += sc; os.packed += sp; }
-    }
-#if defined(AZ_PROFILE_SEGMENTS)
-    if (wv::lane() == 0) for (int q = 0; q < SEG_COUNT; q++) atomicAdd((unsigned long long *)(b.prof + q), (unsigned long long)prof.acc[q]);
-#endif
-    game_store(g, rec);
-    rng_close(r, b.mtpos + gi);
-}
-
-
-#include "azul_selfplay2.hpp"
 
 // Flat self-play, TWO GAMES PER WAVEFRONT (azul_selfplay2.hpp): grid = ceil(N / 2) one-wave workgroups; lanes 0..31 own game
-// 2 b, lanes 32..63 game 2 b + 1.  Same semantics and outputs as azul_selfplay_kernel; `mask_stride` is the byte distance between
-// the mask rows of consecutive games (180, or 192 to keep every row 64-byte aligned).
+// 2 b, lanes 32..63 game 2 b + 1.  `mask_stride` is the byte distance between the mask rows of consecutive games (180, or 192 to
+// keep every row 64-byte aligned).
 template <bool LID, int OUT, bool PAD, bool BITS>
 __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs t, u32 mask_stride)
 {
@@ -195,7 +136,6 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
 #else
     SegProf *pp = nullptr;
 #endif
-#if !defined(AZ2_ROTATED_LOOP)    // default: one selfplay_step2 per move; -DAZ2_ROTATED_LOOP: the rotated loop (measured 2 % slower)
     // A uniform counted loop (scalar loop control: a per-game `break` costs ~16 exec-mask instructions per move).  A game stopped by a
     // rule error (box and lid empty when a round has to be dealt: crafted states only) stays as it is: its lanes skip the later moves.
     bool dead = false;               // (set inside the rare blocks only: the common path carries no test for it)
@@ -204,16 +144,6 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
         if (!dead) az2::selfplay_step2<LID, OUT, PAD, BITS>(g, b.rules.first_player, k, r, tab, margin, cnt, o, pp, dead);
         o.e += b.n;
     }
-#else
-    az2::Prep2 P;
-    az2::prepare2(g, k, r, tab, P);
-#pragma unroll 1
-    for (int s = 0; s < t.n_steps; s++) {
-        u32 f = az2::selfplay_rotated2<LID, OUT, PAD, BITS>(g, P, b.rules.first_player, k, r, tab, margin, cnt, o, pp);
-        if (f & 0x100u) break;      // rule error (box empty): leave the game as it is
-        o.e += b.n;
-    }
-#endif
 #if defined(AZ_PROFILE_SEGMENTS)
     if (lane == 0u) for (int q = 0; q < SEG_COUNT; q++) atomicAdd((unsigned long long *)(b.prof + q), (unsigned long long)prof.acc[q]);
 #endif

@@ -1,6 +1,6 @@
 // azul_tables.hpp -- host-side builders of the constant tables the kernels read.
 #pragma once
-#include "azul_core.hpp"
+#include "azul_common.hpp"
 
 namespace az {
 

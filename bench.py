@@ -567,8 +567,8 @@ def main():
     env.runner_init()                                    # GameRunner()
     env.runner_init()                                    # reset()   (DESIGN.md "stream semantics")
     # per move: the legal mask (bytes), action, reward, done and the compact record the multi-GPU gather ships; the bit-packed mask
-    # is only produced when it is shipped (--gather-masks) or by the one-game-per-wave kernel, whose full variant always writes it
-    want_bits = args.gather_masks or os.environ.get("AZUL_SELFPLAY_KERNEL", "2") == "1"
+    # is only produced when it is shipped (--gather-masks)
+    want_bits = args.gather_masks
     bufs = [env.alloc_trajectory(T, packed_mask=True, mask_pitch=args.mask_pitch, mask_bits=want_bits) for _ in range(2)]
     gather = TrajectoryGather(world, dev, with_masks=args.gather_masks) if (world > 1 and not args.no_gather) else None
 
@@ -677,7 +677,7 @@ def main():
                 issue["saturation_source"] = ij.get("saturation_source")
             except Exception:
                 issue = None
-        kernel_name = "azul_selfplay2_kernel" if os.environ.get("AZUL_SELFPLAY_KERNEL", "2")[:1] != "1" else "azul_selfplay_kernel"
+        kernel_name = "azul_selfplay2_kernel"
         coll = "RCCL" if backend == "nccl" else backend
         if gather:
             par = ("games sharded by global id (rank r owns games [%d r, %d (r + 1))), no data-path collective; the one exchange step is the %s "
@@ -699,7 +699,7 @@ def main():
                                           "games of a GPU (%d env moves per step and GPU)" % (T, G, T * G),
                        "games_per_gpu": G, "global_games": G * world, "moves_per_launch": T, "env_moves_timed": int(total_moves),
                        "mask_row_pitch_bytes": args.mask_pitch, "mask_bits_stream": bool(want_bits),
-                       "selfplay_kernel": os.environ.get("AZUL_SELFPLAY_KERNEL", "2") + " game(s) per wavefront",
+                       "selfplay_kernel": "two games per wavefront",
                        "parallelism": par,
                        "rccl": {"backend": (coll if world > 1 else None), "world_size": dist.get_world_size() if world > 1 else 1,
                                 "ranks_seen": len(ranks_seen), "distinct_devices": len({(r["host"], r["uuid"] or r["device"]) for r in ranks_seen}),

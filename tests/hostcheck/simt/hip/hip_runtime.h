@@ -1,7 +1,7 @@
 // TEST-ONLY stand-in for <hip/hip_runtime.h> when the product's device headers are compiled by g++ for the lockstep wave
 // emulation (tests/hostcheck/simt/simt.hpp): HIP's device qualifiers become host spellings, the gfx950 builtins the headers
-// call become the emulator's functions.  Only what csrc/azul_wave.hpp, azul_core.hpp, azul_tables.hpp, azul_selfplay2.hpp, azul_env2.hpp,
-// azul_rules_x.hpp, azul_ops.hpp, azul_policy.hpp, azul_rollout2.hpp and azul_learner.hpp use.
+// call become the emulator's functions.  Only what csrc/azul_common.hpp, azul_tables.hpp, azul_selfplay2.hpp, azul_env2.hpp,
+// azul_rules_x.hpp, azul_ops2.hpp, azul_policy.hpp, azul_rollout2.hpp and azul_learner.hpp use.
 #pragma once
 #include <math.h>
 #include <string.h>
@@ -67,7 +67,10 @@ static inline void __threadfence() {}
 template <class T, class V>
 static inline T atomicAdd(T *p, V v) { T o = *p; *p = (T)(o + (T)v); return o; }      // (the emulation runs one lane at a time)
 #define __global__ static
-#define __shared__ static
+// LDS arrays become function-local statics in a linker section of their own; run_wave / run_workgroup fill that section with 0xA5 before
+// every emulated workgroup (simt::poison_lds), so that a kernel reading LDS before writing it sees garbage like on the hardware -- not the
+// zeros, or the previous workgroup's data, a plain static would hand it -- and differs from the oracle.
+#define __shared__ static __attribute__((section("simt_lds")))
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
 namespace simt {

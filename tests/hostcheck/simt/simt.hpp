@@ -1,5 +1,5 @@
 // simt.hpp -- TEST-ONLY lockstep emulation of one 64-lane wavefront on the host, so that the SIMT-style product headers
-// (csrc/azul_wave.hpp, azul_core.hpp, azul_selfplay2.hpp: per-lane scalar code + __builtin_amdgcn_* cross-lane builtins) compile
+// (csrc/azul_common.hpp, azul_selfplay2.hpp, ...: per-lane scalar code + __builtin_amdgcn_* cross-lane builtins) compile
 // UNMODIFIED with g++ and run in the build container: the benchmarked two-games-per-wave self-play step gets the same pre-GPU
 // logic check against the oracle (and UBSan / ASan coverage) the one-game-per-wave core has.  Never part of libazulhip.so.
 //
@@ -278,9 +278,19 @@ static bool wave_advance(Wave *w, size_t stack_bytes)
     }
 }
 
+// "LDS" of the emulated kernels: every __shared__ array of the translation unit lives in the section simt_lds (hip/hip_runtime.h).  A
+// workgroup starts with UNDEFINED LDS contents on the hardware: here with 0xA5 bytes.
+extern "C" char __start_simt_lds[] __attribute__((weak, visibility("hidden")));
+extern "C" char __stop_simt_lds[] __attribute__((weak, visibility("hidden")));
+static void poison_lds()
+{
+    if (__start_simt_lds && __stop_simt_lds > __start_simt_lds) memset(__start_simt_lds, 0xA5, (size_t)(__stop_simt_lds - __start_simt_lds));
+}
+
 // run fn(arg) on 64 lanes in lockstep; returns the number of cross-lane operations executed
 static uint64_t run_wave(void (*fn)(void *), void *arg)
 {
+    poison_lds();
     Wave *w = wave_create(fn, arg, 0, STACK_BYTES);
     if (wave_advance(w, STACK_BYTES)) { fprintf(stderr, "simt: s_barrier in a single-wave run\n"); abort(); }
     uint64_t n = w->collectives;
@@ -296,6 +306,7 @@ static uint64_t run_workgroup(void (*fn)(void *), void *arg, int n_waves, size_t
 {
     enum { MAXWAVES = 16 };
     if (n_waves < 1 || n_waves > MAXWAVES) { fprintf(stderr, "simt: 1..16 waves per workgroup\n"); abort(); }
+    poison_lds();
     Wave *ws[MAXWAVES];
     bool done[MAXWAVES];
     for (int i = 0; i < n_waves; i++) { ws[i] = wave_create(fn, arg, i, stack_bytes); done[i] = false; }

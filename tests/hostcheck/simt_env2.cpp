@@ -1,5 +1,5 @@
-// simt_env2.cpp -- TEST-ONLY: the ENV SIDE of the persistent policy rollout kernel (csrc/azul_env2.hpp on top of azul_selfplay2.hpp,
-// azul_core.hpp and azul_wave.hpp, all UNMODIFIED) compiled by g++ and run lane by lane in lockstep (simt/simt.hpp): GameRunner.step,
+// simt_env2.cpp -- TEST-ONLY: the ENV SIDE of the persistent policy rollout kernel (csrc/azul_env2.hpp on top of azul_selfplay2.hpp and
+// azul_common.hpp, all UNMODIFIED) compiled by g++ and run lane by lane in lockstep (simt/simt.hpp): GameRunner.step,
 // GameRunner.reset, GameRunner.get_state and the RandomAgent opponent as azul_policy_rollout2_kernel runs them, two games per wave,
 // diffed against the oracle -- and run under UBSan / ASan -- in the build container.
 // The function below restates the env half of the kernel's move loop (csrc/azul_rollout2.hpp: load, prime, stream open, `publish`,
@@ -7,8 +7,7 @@
 // replaced by the host: the actions come in as an array, which is what the head hands the env through LDS (actS).
 #define __HIPCC__ 1
 #include "azul_hip.h"
-#include "azul_wave.hpp"
-#include "azul_core.hpp"
+#include "azul_common.hpp"
 #include "azul_tables.hpp"
 #include "azul_selfplay2.hpp"
 #include "azul_env2.hpp"

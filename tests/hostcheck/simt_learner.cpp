@@ -4,11 +4,9 @@
 // their arithmetic against torch autograd and, under ASan / UBSan, of every LDS and global index they form.
 #define __HIPCC__ 1
 #include "azul_hip.h"
-#include "azul_wave.hpp"
-#include "azul_core.hpp"
+#include "azul_common.hpp"
 #include "azul_tables.hpp"
 using namespace az;
-#include "azul_ops.hpp"
 #include "azul_selfplay_kernels.hpp"       // (includes azul_selfplay2.hpp; the returns scans live here)
 #include "azul_policy.hpp"
 #include "azul_rollout2.hpp"

@@ -4,25 +4,18 @@
 // kernel's logic and, under ASan / UBSan, of every LDS and global index it forms.
 #define __HIPCC__ 1
 #include "azul_hip.h"
-#include "azul_wave.hpp"
-#include "azul_core.hpp"
+#include "azul_common.hpp"
 #include "azul_tables.hpp"
 using namespace az;
-#include "azul_ops.hpp"
-#include "azul_selfplay2.hpp"
+#include "azul_ops2.hpp"
 #include "azul_policy.hpp"
 #include "azul_rollout2.hpp"
 
-struct Job { BatchDev b; PolicyWeights W; RolloutArgs a; int lid, opp, v1; };
+struct Job { BatchDev b; PolicyWeights W; RolloutArgs a; int lid, opp; };
 
 static void lane_main(void *arg)
 {
     Job *j = (Job *)arg;
-    if (j->v1) {          // the one-game-per-wave rollout kernel of round 1 (AZUL_ROLLOUT_KERNEL=1: the A/B partner), sixteen waves
-        if (j->lid) { if (j->opp) azul_policy_rollout_kernel<true, true>(j->b, j->W, j->a); else azul_policy_rollout_kernel<true, false>(j->b, j->W, j->a); }
-        else { if (j->opp) azul_policy_rollout_kernel<false, true>(j->b, j->W, j->a); else azul_policy_rollout_kernel<false, false>(j->b, j->W, j->a); }
-        return;
-    }
     if (j->lid) { if (j->opp) azul_policy_rollout2_kernel<true, true>(j->b, j->W, j->a); else azul_policy_rollout2_kernel<true, false>(j->b, j->W, j->a); }
     else { if (j->opp) azul_policy_rollout2_kernel<false, true>(j->b, j->W, j->a); else azul_policy_rollout2_kernel<false, false>(j->b, j->W, j->a); }
 }
@@ -36,7 +29,7 @@ long long sr2_rollout(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 *epi
                       int tile_pool, int opponent_random, unsigned id_base, const float *w1t, const float *b1, const float *w2c,
                       const float *b2c, const float *w2a_t, const float *b2a, int n_steps, float *obs, uint8_t *mask, uint8_t *player,
                       i32 *action, i32 *reward, uint8_t *done, float *value, float *logp, float *entropy, uint8_t *status, float *returns,
-                      float gamma, unsigned long long seed, unsigned long long counter, int one_game_per_wave)
+                      float gamma, unsigned long long seed, unsigned long long counter)
 {
     static double T[T_WORDS];
     if (!build_sample_tab(T)) return -2;
@@ -49,13 +42,13 @@ long long sr2_rollout(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 *epi
     j.a.n_steps = n_steps; j.a.obs = obs; j.a.mask = mask; j.a.player = player; j.a.action = action; j.a.reward = reward; j.a.done = done;
     j.a.value = value; j.a.logp = logp; j.a.entropy = entropy; j.a.status = status; j.a.returns = returns; j.a.gamma = gamma;
     j.a.seed = seed; j.a.counter = counter; j.a.counter_dev = nullptr;
-    j.lid = tile_pool == POOL_LID; j.opp = opponent_random; j.v1 = one_game_per_wave;
+    j.lid = tile_pool == POOL_LID; j.opp = opponent_random;
     const unsigned blocks = ((unsigned)n_games + PF_GAMES - 1u) / PF_GAMES;
     simt::g_grid_dim = {blocks, 1, 1};
     long long ops = 0;
     for (unsigned blk = 0; blk < blocks; blk++) {
         simt::g_block_idx = {blk, 0, 0};
-        ops += (long long)simt::run_workgroup(lane_main, &j, one_game_per_wave ? (int)PR_WAVES : 8);
+        ops += (long long)simt::run_workgroup(lane_main, &j, (int)PR2_WAVES);
     }
     return ops;
 }

@@ -1,11 +1,10 @@
-// simt_rules_x.cpp -- TEST-ONLY: the P-player / D-display rules (csrc/azul_rules_x.hpp on top of azul_wave.hpp, azul_core.hpp and
+// simt_rules_x.cpp -- TEST-ONLY: the P-player / D-display rules (csrc/azul_rules_x.hpp on top of azul_common.hpp and
 // azul_selfplay2.hpp, all UNMODIFIED) compiled by g++ and run lane by lane in lockstep (simt/simt.hpp): the kernel BODIES the product's
 // __global__ wrappers call (azx::op_body_x, azx::selfplay_body_x) run here on host memory, so their logic can be diffed against the
 // oracle -- and run under UBSan / ASan -- in the build container, before a GPU sees them.
 #define __HIPCC__ 1
 #include "azul_hip.h"
-#include "azul_wave.hpp"
-#include "azul_core.hpp"
+#include "azul_common.hpp"
 #include "azul_tables.hpp"
 #include "azul_selfplay2.hpp"
 #include "azul_rules_x.hpp"

@@ -114,16 +114,27 @@ def test_argument_validation_needs_no_gpu():
         L.check(lib.azul_batch_selfplay(None, 4, None, None, None, None, None, None, None, None))
 
 
-def test_shipped_library_is_not_a_timing_experiment_build():
-    """The switches that price a kernel's stores / LDS round trips / weight loads by leaving them out produce wrong results; they need
-    -DAZ_TIMING_EXPERIMENTS, which azul_version() reports.  The library the package loads must be a clean build."""
+def test_product_sources_carry_no_experiment_switches_and_no_kernel_selection_by_environment():
+    """One kernel per entry point: no A/B variants selected by environment variables, no timing-experiment macros that change results, no
+    second implementation of the rules behind a switch (rounds 1-4 kept such things in the shipped sources; their history is in git and
+    LABNOTES.md).  The only compile-time diagnostics left are the stamp builds (-DAZ_PROFILE_SEGMENTS, -DAZ_LG_PROFILE, -DAZ_PF_PROFILE),
+    which leave every result as it is."""
+    import glob
+    import re
     from azul_deep_reinforcement_learning_amd import _lib as L
     v = L.lib.azul_version().decode()
-    assert "AZ_TIMING_EXPERIMENTS" not in v and v.startswith("azul-mi355x"), v
-    src = open(os.path.join(ROOT, "azul_deep_reinforcement_learning_amd", "csrc", "azul_kernels.hip")).read()
-    for sw in ("AZ2_EXPERIMENT_NO_LDS", "AZ2_X_NO_SCALAR_STORES", "AZ2_X_NO_MASK_STORES", "AZ2_X_NO_STATS", "PR2_EXPERIMENT_NO_WEIGHT_LOADS",
-               "PR2_X_NO_MASK_STORES"):
-        assert "defined(%s)" % sw in src.split("#error")[0], sw          # every wrong-result switch is behind the guard
+    assert v.startswith("azul-mi355x") and "EXPERIMENT" not in v.upper(), v
+    csrc = os.path.join(ROOT, "azul_deep_reinforcement_learning_amd", "csrc")
+    allowed = {"AZ_PROFILE_SEGMENTS", "AZ_LG_PROFILE", "AZ_PF_PROFILE", "__HIPCC__", "AZ_DRAW_MARGIN"}
+    for f in sorted(glob.glob(os.path.join(csrc, "*"))):
+        src = open(f).read()
+        assert "getenv" not in src, f
+        for m in re.finditer(r"^\s*#\s*(?:if|ifdef|ifndef|elif)\b(.*)$", src, re.M):
+            names = set(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", m.group(1))) - {"defined"}
+            assert names <= allowed, (os.path.basename(f), m.group(0).strip())
+    assert sorted(os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*"))) == [
+        "azul_common.hpp", "azul_env2.hpp", "azul_kernels.hip", "azul_learner.hpp", "azul_ops2.hpp", "azul_policy.hpp", "azul_rollout2.hpp",
+        "azul_rules_x.hpp", "azul_selfplay2.hpp", "azul_selfplay_kernels.hpp", "azul_tables.hpp"]
 
 
 def test_call_block_layout_is_the_headers(tmp_path):

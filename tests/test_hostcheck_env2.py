@@ -16,7 +16,7 @@ from oracle import oracle as oz
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostcheck")
 RULES = {"lid_randomfirst": (0, 1), "random_first1": (1, 0), "lid_first2": (2, 1)}      # (first_player code, tile_pool code)
-ST_ILLEGAL, ST_STUCK, ST_BAD_ACTION = 1, 3, 4          # csrc/azul_core.hpp
+ST_ILLEGAL, ST_STUCK, ST_BAD_ACTION = 1, 3, 4          # csrc/azul_common.hpp
 
 
 def load(name=None):

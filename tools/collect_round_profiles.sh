@@ -3,8 +3,11 @@
 #   bash tools/collect_round_profiles.sh r4_final4 round4
 set -eu
 T=${1:?tag}; N=${2:?name}; R=gpurun_out/$T
-python3 tools/summarize_profile.py $T $N > /dev/null
+# inputs of the issue-side roofline first (summarize_profile.py reads them from profiles/): the occupancy sweep of THIS run, and the static
+# opcode mix of the headline kernel's move loop as built from the tree's csrc
 cp $R/games_sweep.txt profiles/${N}_games_sweep.txt
+python3 tools/isa_stats.py --mix profiles/${N}_isa_mix.json > /dev/null
+python3 tools/summarize_profile.py $T $N > /dev/null
 cp $R/segment_shares.txt profiles/${N}_segment_shares.txt
 cp $R/policy_rollout_phases.txt profiles/${N}_policy_rollout_phases.txt
 cp $R/${T}_mfma_counters.json profiles/${N}_mfma_counters.json

@@ -35,8 +35,9 @@ shutil.copyfile(os.path.join(src, "bench.json"), os.path.join(dst, "%s_bench.jso
 summary = {"tag": tag, "selfplay_kernel": {"calls": int(sp["Calls"]), "avg_ns": float(sp["AverageNs"]),
                                              "min_ns": float(sp["MinNs"]), "max_ns": float(sp["MaxNs"])}}
 pmc = {}
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_grbm"):
-    pmc.update(counters(sub, "selfplay"))
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_grbm", "pmc_sq3"):
+    for k_, v_ in counters(sub, "selfplay").items():
+        pmc.setdefault(k_, v_)          # (SQ_INSTS_VALU is collected in two passes: the first one counts)
 summary["pmc_per_launch"] = pmc
 waves_steps_for_traffic = bench["config"]["games_per_gpu"] * bench["config"]["moves_per_launch"]
 calib = {}
@@ -90,20 +91,74 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
 waves_steps = bench["config"]["games_per_gpu"] * bench["config"]["moves_per_launch"]
 if "SQ_INSTS_VALU" in pmc:
     summary["per_wave_step"] = {k: pmc[k]["mean"] / waves_steps for k in pmc if k.startswith("SQ_")}
-# ---- the issue side ("VALU utilisation / occupancy alongside the HBM fraction"): the kernel is bound by the rate at which a
-# SIMD issues this instruction mix, so the checkable figure is cycles per wave-instruction per SIMD against the rate the same kernel
-# reaches when the SIMDs are saturated with waves (the 8192-game run of tools/games_sweep.sh: twice the waves, same instructions per move)
+# ---- the issue side ("VALU utilisation / occupancy alongside the HBM fraction").  The kernel is bound by instruction issue, so
+# the roofline that says something about it is the VALU pipe's: how many of the SIMDs' cycles the kernel's vector instructions NEED on this
+# hardware, against the cycles the launch took.
+#   hw_frac = sum over instruction classes (count x pipe cycles per wave64 instruction on a SIMD-32) / (1024 SIMDs x cycles per launch)
+# Counts: the PMC class counters of this run (pmc_sq3: SQ_INSTS_VALU_INT64 / _ADD_F64 / _MUL_F64 / _FMA_F64 / _CVT / _TRANS_F64) and, for the
+# one priced class the counters do not separate (quarter-rate 32-bit multiplies), the static opcode mix of the kernel's move loop
+# (profiles/<name>_isa_mix.json, tools/isa_stats.py --mix).  Costs: MI355X_MICROARCH.md (a wave64 VALU instruction issues over 2 cycles on a
+# SIMD-32; fp64 vector peak = half the f32 peak) and profiles/round3_pattern_cost.txt (tools/pattern_cost.hip on this GPU: what a pattern
+# costs once two waves share the pipe).
+COSTS = {
+    "default": (2.0, "MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles (32 lanes / cycle x 2)"),
+    "int64": (8.0, "quarter rate; measured 7.6: `v_lshrrev_b64; v_or` 19.22 cycles per link with two waves per SIMD = 2 x (7.6 + 2) (round3_pattern_cost.txt)"),
+    "f64": (4.0, "half rate (fp64 vector peak 78.6 TFLOP/s = half of 157.3); measured <= 4.3: v_add_f64 8.56 per link at two waves per SIMD"),
+    "cvt": (4.7, "measured: `v_cvt_f64_u32; v_cvt_u32_f64` 18.71 cycles per link at two waves per SIMD = 2 x 2 x 4.7 (round3_pattern_cost.txt)"),
+    "trans_f64": (8.0, "v_rcp_f64 (the statistics' percentage at an episode end): transcendental rate"),
+    "mul32": (8.0, "v_mul_hi / v_mul_lo _u32: quarter rate; measured 7.5: `v_mul_hi_u32; v_or` 19.04 per link at two waves per SIMD"),
+}
+N_SIMD, N_CU = 1024, 256
 if "SQ_INSTS_VALU" in pmc and "SQ_INSTS_SALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
-    wave_instr = pmc["SQ_INSTS_VALU"]["mean"] + pmc["SQ_INSTS_SALU"]["mean"]
+    valu, salu = pmc["SQ_INSTS_VALU"]["mean"], pmc["SQ_INSTS_SALU"]["mean"]
+    wave_instr = valu + salu
     cycles = pmc["GRBM_GUI_ACTIVE"]["mean"] / 8.0                     # summed over the 8 XCDs
-    N_SIMD = 1024
-    issue = {"instr_per_game_move": wave_instr / waves_steps, "valu_per_game_move": pmc["SQ_INSTS_VALU"]["mean"] / waves_steps,
-             "salu_per_game_move": pmc["SQ_INSTS_SALU"]["mean"] / waves_steps, "wave_instr_per_launch": wave_instr,
+    issue = {"instr_per_game_move": wave_instr / waves_steps, "valu_per_game_move": valu / waves_steps,
+             "salu_per_game_move": salu / waves_steps, "wave_instr_per_launch": wave_instr,
              "cycles_per_launch": cycles, "clock_ghz": cycles / float(sp["AverageNs"]),
              "waves_per_simd": pmc["SQ_WAVES"]["mean"] / N_SIMD if "SQ_WAVES" in pmc else None,
              "cycles_per_instr_per_simd": cycles * N_SIMD / wave_instr,
-             "wait_any_share_of_wave_cycles": (pmc["SQ_WAIT_ANY"]["mean"] / pmc["SQ_WAVE_CYCLES"]["mean"]) if "SQ_WAIT_ANY" in pmc and "SQ_WAVE_CYCLES" in pmc else None,
-             "source": "profiles/%s_summary.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU ..., GRBM_GUI_ACTIVE in its own pass)" % name}
+             "source": "profiles/%s_summary.json (rocprofv3 --pmc passes of `bench.py --steps 20 --warmup 5`: SQ_INSTS_*, the class counters, "
+                       "SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_BUSY_CYCLES, GRBM_GUI_ACTIVE in its own pass)" % name}
+    g_ = lambda k: pmc[k]["mean"] if k in pmc else None
+    if g_("SQ_INSTS_VALU_INT64") is not None:
+        mixf = os.path.join(dst, "%s_isa_mix.json" % name)
+        mul_share = json.load(open(mixf))["quarter_rate_int32_multiply_share_of_valu"] if os.path.exists(mixf) else 0.0
+        cls = {"int64": g_("SQ_INSTS_VALU_INT64"),
+               "f64": (g_("SQ_INSTS_VALU_ADD_F64") or 0.0) + (g_("SQ_INSTS_VALU_MUL_F64") or 0.0) + (g_("SQ_INSTS_VALU_FMA_F64") or 0.0),
+               "cvt": g_("SQ_INSTS_VALU_CVT") or 0.0, "trans_f64": g_("SQ_INSTS_VALU_TRANS_F64") or 0.0, "mul32": valu * mul_share}
+        cls["default"] = valu - sum(cls.values())
+        pipe = {k: cls[k] * COSTS[k][0] for k in cls}
+        need = sum(pipe.values())
+        issue["hw"] = {
+            "frac": need / (N_SIMD * cycles),
+            "frac_if_every_valu_instruction_were_full_rate": 2.0 * valu / (N_SIMD * cycles),
+            "valu_pipe_cycles_needed_per_launch": need, "simd_cycles_per_launch": N_SIMD * cycles,
+            "mean_pipe_cycles_per_valu_instruction": need / valu,
+            "classes_per_game_move": {k: cls[k] / waves_steps for k in cls},
+            "pipe_cycles_per_game_move": {k: pipe[k] / waves_steps for k in pipe},
+            "int32_counter_per_game_move": (g_("SQ_INSTS_VALU_INT32") or 0.0) / waves_steps,
+            "costs": {k: {"cycles": COSTS[k][0], "source": COSTS[k][1]} for k in COSTS},
+            "mul32_share_source": "profiles/%s_isa_mix.json (static opcode mix of the move loop, tools/isa_stats.py --mix)" % name,
+            # the scalar pipe is the other issue resource: one scalar ALU per CU serves its four SIMDs, ~1.08 cycles per instruction
+            # (profiles/round2_issue_model.txt: 64 independent s_ instructions, eight waves per SIMD, 4.3 cycles per instruction per SIMD)
+            "scalar_pipe_frac": salu * 1.08 / (N_CU * cycles),
+            "definition": "VALU pipe cycles the kernel's instructions need on a SIMD-32 (class counts x cycles per wave64 instruction) / "
+                          "(1024 SIMDs x GRBM_GUI_ACTIVE cycles of the launch): 1.0 = every SIMD issues a vector instruction whenever it can"}
+        issue["hw_frac"] = issue["hw"]["frac"]
+    if "SQ_ACTIVE_INST_VALU" in pmc and "SQ_WAVE_CYCLES" in pmc:
+        wc = pmc["SQ_WAVE_CYCLES"]["mean"]
+        issue["wave_time_shares"] = {"active_valu": pmc["SQ_ACTIVE_INST_VALU"]["mean"] / wc,
+                                     "active_scalar": pmc["SQ_ACTIVE_INST_SCA"]["mean"] / wc if "SQ_ACTIVE_INST_SCA" in pmc else None,
+                                     "active_any": pmc["SQ_ACTIVE_INST_ANY"]["mean"] / wc if "SQ_ACTIVE_INST_ANY" in pmc else None,
+                                     "wait_any": pmc["SQ_WAIT_ANY"]["mean"] / wc if "SQ_WAIT_ANY" in pmc else None,
+                                     "wait_inst_any": pmc["SQ_WAIT_INST_ANY"]["mean"] / wc if "SQ_WAIT_INST_ANY" in pmc else None,
+                                     "note": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES etc. (quad-cycles both): the share of a wave's resident time it "
+                                             "spends on vector instructions, parked at s_waitcnt, or stalled at issue"}
+        issue["active_inst_valu_quad_cycles_per_valu_instruction"] = pmc["SQ_ACTIVE_INST_VALU"]["mean"] / valu
+        issue["wait_any_share_of_wave_cycles"] = issue["wave_time_shares"]["wait_any"]
+    if "SQ_ACTIVE_INST_VALU" in pmc and "SQ_BUSY_CYCLES" in pmc:
+        issue["active_inst_valu_per_busy_cycle"] = pmc["SQ_ACTIVE_INST_VALU"]["mean"] / pmc["SQ_BUSY_CYCLES"]["mean"]
     sweep = os.path.join(dst, "%s_games_sweep.txt" % name)
     if os.path.exists(sweep):
         vals = {}
@@ -111,10 +166,10 @@ if "SQ_INSTS_VALU" in pmc and "SQ_INSTS_SALU" in pmc and "GRBM_GUI_ACTIVE" in pm
             if ln.startswith("games") and "G env steps/s" in ln:
                 vals[int(ln.split()[1].rstrip(":"))] = float(ln.split()[2])
         if 4096 in vals and 8192 in vals:
-            # same instructions per game-move, twice the waves per SIMD: cycles per instruction scale with 1 / throughput
-            issue["saturation_cycles_per_instr_per_simd"] = issue["cycles_per_instr_per_simd"] * vals[4096] / vals[8192]
-            issue["saturation_source"] = "profiles/%s_games_sweep.txt: %.3f G env steps/s at 4096 games, %.3f G at 8192 (four waves per SIMD)" % (name, vals[4096], vals[8192])
-            issue["frac"] = issue["saturation_cycles_per_instr_per_simd"] / issue["cycles_per_instr_per_simd"]
+            # same instructions per game-move, twice the waves per SIMD: cycles per instruction scale with 1 / throughput.  This is the
+            # kernel against ITSELF at higher occupancy -- how much of the gap to hw_frac = 1 more waves would close -- not a hardware bound
+            issue["occupancy_frac"] = vals[4096] / vals[8192]
+            issue["occupancy_source"] = "profiles/%s_games_sweep.txt: %.3f G env steps/s at 4096 games, %.3f G at 8192 (four waves per SIMD)" % (name, vals[4096], vals[8192])
     summary["issue"] = issue
     json.dump(issue, open(os.path.join(dst, "issue_rate.json"), "w"), indent=1)
 summary["bench"] = {k: bench[k] for k in ("value", "ms_per_step", "roofline", "cpu_baseline") if k in bench}

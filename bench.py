@@ -120,7 +120,7 @@ def parity_gate(env, games, seed_base, moves_done, budget=6000000):
 
 F32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense f32 matrix peak
 FWD_FLOP_PER_GAME = 2 * (136 * 360 + 180 * 180 + 180)            # ActorCritic(136, 180, 180) forward: 163,080 FLOP
-GRAD_FLOP_PER_SAMPLE = 391000                                     # forward + backward of the A2C loss (DESIGN.md 10)
+GRAD_FLOP_PER_SAMPLE = 391000                                     # forward + backward of the A2C loss (DESIGN.md 3)
 
 
 def _timed(world, dev, fn):

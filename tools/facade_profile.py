@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: cProfile of BASELINE configs[0] through the drop-in shims (random.seed(s); GameRunner(); reset(); get_valid_moves ->
 RandomAgent.get_a_output -> GameRunner.step), 40 episodes, sorted by internal time -- where the host side of a facade call spends
-its microseconds.  Needs a GPU.   python tools/facade_profile.py"""
+its microseconds (LABNOTES.md 8).  Needs a GPU.   python tools/facade_profile.py"""
 import cProfile, pstats, sys, random, io
 sys.path.insert(0, ".")
 sys.path.insert(0, "integration")

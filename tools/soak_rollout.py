@@ -26,7 +26,7 @@ print("csrc sha256 %s | libazulhip.so sha256 %s | %s | soak_rollout.py sha256 %s
 for opponent in (None, "random"):
     runs = []
     for persistent in (False, True):
-        torch.manual_seed(11)               # INSIDE the arm loop: both arms must start from the same network
+        torch.manual_seed(11)               # INSIDE the arm loop: both arms must start from the same network (see LABNOTES.md 6)
         net = BatchedActorCritic(136, 180, 180)
         print("  arm persistent=%s: net checksum %.9f" % (persistent, float(sum(p.double().sum() for p in net.parameters()))))
         ro = PolicyRollout(net, n_games=n, parts=1, seed_base=90210, window=32, use_graph=False,

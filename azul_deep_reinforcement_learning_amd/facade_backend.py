@@ -163,7 +163,9 @@ class HipBackend:
             c.record_in = None
         ahead = ASK_AHEAD and self.ask_ahead and op in _ASK_AHEAD
         if ahead:
-            want |= L.WANT_MASK | L.WANT_NEXT_ACTION | L.WANT_FLAGS
+            # (the draw is only asked of a call that DRAWS: such a call tells the device the stream index the host holds -- a non-drawing
+            # call would answer from the device's stale index after a played-ahead draw)
+            want |= L.WANT_MASK | L.WANT_FLAGS | (L.WANT_NEXT_ACTION if draws else 0)
             if op in _ASK_OBS:
                 want |= L.WANT_OBS
                 c.obs_persp = _ASK_OBS[op]
@@ -191,7 +193,7 @@ class HipBackend:
         if want & L.WANT_MASK and new is not None:
             m8 = np.frombuffer(bytes(c.mask), dtype=np.uint8)[:self.num_actions]
             self._mask_for, self._mask = self._resident, m8.astype(bool)
-            if ahead and c.next_action >= 0 and _RNG["be"] is self:
+            if ahead and draws and c.next_action >= 0 and _RNG["be"] is self:
                 self._ahead = (m8.tobytes(), _RNG["state"], _RNG["pos"], int(c.next_action))
             if ahead and op in _ASK_OBS:
                 self._obs_for = (self._resident, _ASK_OBS[op], self._seq)

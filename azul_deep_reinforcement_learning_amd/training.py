@@ -174,7 +174,7 @@ class BatchedTrainer:
                          "next_player": ro.traj[p]["player"][ro.T].cpu()})
         ck = {"policy": ro.policy.state_dict(), "optimizer": self.learner.optimizer_state(), "envs": envs,
               "batch": self.batch, "n_games": ro.n, "parts": ro.parts, "window": ro.T, "game_id_base": ro.game_id_base,
-              "windows_played": ro.windows_played, "ring": ro.ring}
+              "windows_played": ro.windows_played, "ring": ro.ring, "ring_saved": bool(save_ring and ro.ring > 1)}
         if save_ring and ro.ring > 1:
             ck["ring_buffers"] = [{k: v.cpu() for k, v in rg.items()} for rg in ro.rings]
             ck["learner_ring"] = self.learner.ring_state()
@@ -217,11 +217,16 @@ class BatchedTrainer:
                 ro.traj[p] = ro._window_views(ro.rings[p], (ro.windows_played - 1) % ro.ring)
             self.learner.load_ring_state(ro, ck.get("learner_ring"))
         else:
+            import warnings
             if "ring_buffers" in ck and ro.ring > 1:
-                import warnings
                 warnings.warn("checkpoint %s holds a trajectory ring of %s windows, this rollout uses %d: the ring is NOT restored -- the "
                               "resumed run restarts its books with the next window and no longer equals the uninterrupted one"
                               % (path, ck.get("ring"), ro.ring))
+            elif ro.ring > 1:
+                # a small file (save_ring=False: what train() writes periodically unless checkpoint_ring=True)
+                warnings.warn("checkpoint %s carries no trajectory ring (written with save_ring=False): the steps of episodes in flight when it "
+                              "was written are not trained, their tails count as whole episodes -- the resumed run does not equal the "
+                              "uninterrupted one (save_checkpoint(save_ring=True) / train(checkpoint_ring=True) for an exact resume)" % path)
             self.learner.load_ring_state(ro, None)
         torch.cuda.synchronize(ro.device)
         self.batch = int(ck["batch"])

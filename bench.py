@@ -676,6 +676,8 @@ def main():
                          "hw_frac_if_every_valu_instruction_were_full_rate": hw.get("frac_if_every_valu_instruction_were_full_rate"),
                          "mean_pipe_cycles_per_valu_instruction": hw.get("mean_pipe_cycles_per_valu_instruction"),
                          "scalar_pipe_frac": hw.get("scalar_pipe_frac"),
+                         "ceiling_of_a_dependent_chain_at_two_waves_per_simd": hw.get("ceiling_of_a_dependent_chain_at_two_waves_per_simd"),
+                         "ceiling_source": hw.get("ceiling_source"),
                          "occupancy_frac": ij.get("occupancy_frac"), "occupancy_source": ij.get("occupancy_source"),
                          "wave_time_shares": ij.get("wave_time_shares")}
                 issue.update({k: ij.get(k) for k in ("instr_per_game_move", "valu_per_game_move", "salu_per_game_move", "cycles_per_instr_per_simd",

@@ -107,7 +107,7 @@ def test_single_gpu_line_keeps_its_shape():
     assert "nothing is exchanged" in out["config"]["parallelism"]
     assert out["extra"]["training"]["n_gpus"] == 1 and out["extra"]["policy_config"]["roofline"]["bound"] == "mfma"
     assert out["extra"]["policy_config"]["config"]["c1_gather"] is None
-    assert out["sustained"]["launches"] == 1000 and abs(out["sustained"]["vs_value"] - 1.0) < 0.25
+    assert out["sustained"]["launches"] == 1000 and out["sustained"]["vs_value"] > 0 and out["sustained"]["parity_gate"].startswith("ok")
     assert out["config"]["rccl"]["ranks_seen"] == 1 and out["config"]["rccl"]["bytes_per_launch"] == 0
     two = out["extra"]["policy_pytorch_two_streams"]
     assert two["value"] > 0 and "PyTorch-ROCm" in two["config"]["workload"]

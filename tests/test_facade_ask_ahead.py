@@ -146,6 +146,34 @@ def test_remembered_draw_is_what_a_fresh_draw_gives(facade):
     random.seed()
 
 
+def test_a_non_drawing_ask_ahead_call_never_remembers_a_draw(facade):
+    """An ask-ahead op submitted WITHOUT the drawing flag (reachable through backend.call directly; azul.py always sets it) does not
+    tell the device the host's stream index: after a played-ahead draw the device's index is two words behind, so such a call must
+    neither ask for nor remember RandomAgent's next draw -- the following get_a_output draws afresh and equals CPython's."""
+    agent = facade.RandomAgent()
+    random.seed(9)
+    r = facade.GameRunner()
+    r.reset()
+    w = np.ones(180)
+    w[:30] = 0.01
+    mask = r.get_valid_moves()
+    a = agent.get_a_output(None, torch.from_numpy(mask[None, :]))          # plays the remembered draw: the host index is ahead of the device's
+    be = r.game._backend()
+    illegal = int(np.flatnonzero(~mask)[0])
+    out, rec = be.call("op_runner_step", (illegal,), r.game._to_record(r), draws=False, mutates=True)      # refused move, submitted without `draws`
+    assert out[2] == 1 and be._ahead is None
+    assert not (be.c.want & 64)                                             # AZUL_WANT_NEXT_ACTION was not asked for
+    st = random.getstate()
+    mask2 = r.get_valid_moves()
+    assert np.array_equal(mask2, mask)
+    a2 = agent.get_a_output(None, torch.from_numpy(mask2[None, :]))
+    after = random.getstate()
+    random.setstate(st)
+    assert a2 == random.choices(range(180), weights=w * mask2)[0] and random.getstate() == after
+    _, _ = r.step(a)
+    random.seed()
+
+
 def test_network_style_loop_gets_its_observation_with_the_step(facade):
     """nn_runner.py:22-30's order of questions -- get_state(), get_valid_moves(), [the agent], step() -- with a host-side stand-in for
     the network's choice: the observation comes back with the step (one submission per agent step) and equals the one asked for."""

@@ -170,8 +170,14 @@ def test_resumed_run_equals_the_uninterrupted_run(tmp_path):
             assert ra["batch"] == rb["batch"] and ra["ac_loss"] == rb["ac_loss"] and ra["player_score"] == rb["player_score"]
         assert int(t.learner.dropped_steps[1]) == int(a.learner.dropped_steps[1])
 
-    # without the ring in the file: the books start with the first window played after the restore
-    c.load_checkpoint(ck_small)
+    # without the ring in the file: the books start with the first window played after the restore -- and the loader SAYS that such a
+    # resume is not the uninterrupted run (train() writes its periodic files this way unless checkpoint_ring=True)
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        c.load_checkpoint(ck_small)
+    assert any("carries no trajectory ring" in str(w.message) for w in caught)
+    assert torch.load(ck_small, weights_only=False)["ring_saved"] is False and torch.load(ck, weights_only=False)["ring_saved"] is True
     assert c.learner._ring is None
     w0 = c.rollout.windows_played
     c.run_batch(collect_stats=False)

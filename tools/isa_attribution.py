@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Static attribution of a kernel's ISA to source functions (via -g line info): which device function owns how many scalar /
-vector instructions.  Usage: tools/isa_attribution.py [mangled-kernel-prefix]   (compiles csrc/azul_kernels.hip with -g -S)."""
+vector instructions.  Usage: tools/isa_attribution.py [mangled-kernel-prefix] [--lines FUNCTION ...]   (compiles csrc/azul_kernels.hip with
+-g -S; --lines prints the named functions' source lines with the instructions attributed to each)."""
 import collections
 import os
 import re
@@ -8,11 +9,11 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-kern=sys.argv[1] if len(sys.argv)>1 else '_Z20azul_selfplay_kernelILb1ELi1E'
+kern=sys.argv[1] if len(sys.argv)>1 and not sys.argv[1].startswith('--') else '_Z21azul_selfplay2_kernelILb1ELi1ELb1ELb0'
 asm = os.path.join(ROOT, "gpurun_out", "azul_kernels_g.s")
 os.makedirs(os.path.dirname(asm), exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-g", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-                       "-Wno-unused-value", "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", asm,
+                       "-Wno-unused-value", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", asm,
                        os.path.join(ROOT, "azul_deep_reinforcement_learning_amd", "csrc", "azul_kernels.hip")], stderr=subprocess.DEVNULL)
 s=open(asm).read()
 files={}
@@ -30,7 +31,7 @@ for l in body:
     cnt[cur]+=1
     if op.startswith('s_'): scnt[cur]+=1
     if op.startswith('v_'): vcnt[cur]+=1
-src={f:open('/root/repo/azul_deep_reinforcement_learning_amd/csrc/'+f).read().split('\n') for f in ('azul_core.hpp','azul_kernels.hip','azul_wave.hpp','azul_policy.hpp','azul_tables.hpp','azul_selfplay2.hpp','azul_env2.hpp','azul_rollout2.hpp','azul_core_np.hpp')}
+src={f:open(os.path.join(ROOT, 'azul_deep_reinforcement_learning_amd', 'csrc', f)).read().split('\n') for f in sorted(os.listdir(os.path.join(ROOT, 'azul_deep_reinforcement_learning_amd', 'csrc')))}
 print("total", sum(cnt.values()), "scalar", sum(scnt.values()), "vector", sum(vcnt.values()))
 # group by function: find enclosing function name by scanning backwards for 'AZ_FN'
 def func_of(f,ln):
@@ -45,3 +46,17 @@ for k,c in cnt.items():
     if k is None: continue
     fn=func_of(*k); byf[fn]+=c; byfs[fn]+=scnt[k]
 for fn,c in byf.most_common(40): print("%5d total %5d scalar  %s"%(c,byfs[fn],fn))
+
+if "--lines" in sys.argv:
+    want = set(sys.argv[sys.argv.index("--lines") + 1:])
+    per = collections.defaultdict(list)
+    for k, c in cnt.items():
+        if k is None or k[0] not in src:
+            continue
+        fn = func_of(*k)
+        if fn in want:
+            per[fn].append((k[1], c, vcnt[k], k[0]))
+    for fn in want:
+        print("\n==== %s: %d instructions" % (fn, sum(c for _, c, _, _ in per[fn])))
+        for ln, c, v, f in sorted(per[fn]):
+            print("%4d %4d v%-4d| %s" % (ln, c, v, src[f][ln - 1].strip()[:150]))

@@ -146,6 +146,11 @@ if "SQ_INSTS_VALU" in pmc and "SQ_INSTS_SALU" in pmc and "GRBM_GUI_ACTIVE" in pm
             "definition": "VALU pipe cycles the kernel's instructions need on a SIMD-32 (class counts x cycles per wave64 instruction) / "
                           "(1024 SIMDs x GRBM_GUI_ACTIVE cycles of the launch): 1.0 = every SIMD issues a vector instruction whenever it can"}
         issue["hw_frac"] = issue["hw"]["frac"]
+        # what this occupancy allows: a move is ONE dependent chain, and a dependent vector instruction costs 4.42 cycles per instruction and
+        # SIMD with two waves per SIMD (profiles/round2_issue_model.txt, "valu x64 dependent", 2 w/SIMD; 2.92 for independent instructions)
+        issue["hw"]["ceiling_of_a_dependent_chain_at_two_waves_per_simd"] = issue["hw"]["mean_pipe_cycles_per_valu_instruction"] / 4.423
+        issue["hw"]["ceiling_source"] = ("profiles/round2_issue_model.txt (tools/issue_model.hip on this GPU): 64 DEPENDENT v_ instructions, two waves per SIMD: "
+                                         "4.423 cycles per instruction per SIMD; this kernel: %.2f per VALU instruction" % (N_SIMD * cycles / valu))
     if "SQ_ACTIVE_INST_VALU" in pmc and "SQ_WAVE_CYCLES" in pmc:
         wc = pmc["SQ_WAVE_CYCLES"]["mean"]
         issue["wave_time_shares"] = {"active_valu": pmc["SQ_ACTIVE_INST_VALU"]["mean"] / wc,

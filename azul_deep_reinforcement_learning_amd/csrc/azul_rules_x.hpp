@@ -1075,7 +1075,7 @@ AZ_FN void selfplay_body_x(const XBatchDev &b, const XTraj &t, u32 wave_id, u32 
     counters2_open(cnt, b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10, l);
     Out2 o = {t.mask, t.maskbits, t.action, t.reward, t.done, t.packed, t.rec, t.mask_stride, gi,
               l == 0u ? (u32 *)t.action : (l == 1u ? (u32 *)t.reward : t.packed)};
-    bool dead = false;               // a game stopped by a rule error (bag and lid empty without the short-deal rule) stays as it is
+    bool dead = false;               // a game stopped by a rule error (bag and lid empty without the short-deal rule) stays as it is (see the loop)
 #if defined(AZ_PROFILE_SEGMENTS)
     SegProf prof;
     for (int q = 0; q < SEG_COUNT; q++) prof.acc[q] = 0;
@@ -1087,6 +1087,13 @@ AZ_FN void selfplay_body_x(const XBatchDev &b, const XTraj &t, u32 wave_id, u32 
 #pragma unroll 1
     for (int s = 0; s < t.n_steps; s++) {
         if (!dead) selfplay_step_x<P, D, OUT, PAD, BITS>(g, b.rules, K, r, tab, b.draw_margin, cnt, o, dead, pp);
+        else {
+            // the game was stopped by a rule error (bag and lid empty without the short-deal rule; the reference raises, azul.py:86-87): no
+            // move is played in this slot -- it is marked like a stuck slot (action -1, done 2) and counted with them, so that whoever
+            // counts env moves as slots minus `stuck` stays right and the trajectory carries no stale data
+            cnt.stuck_add += 1u;
+            outputs_x<P, D, OUT>(g, o, -1, 2u, l);
+        }
         o.e += b.n;
     }
 #if defined(AZ_PROFILE_SEGMENTS)

@@ -395,9 +395,11 @@ int azul_discounted_returns_ring(const int32_t *reward_ring_dev, const uint8_t *
  *   rec_dev    uint8 [n_steps][N][128]   record after the move, before the auto-reset (tests only)
  * Batches of THREE or FOUR players (azul_batch_create_players; row N4) play the same flat loop -- mask -> RandomAgent
  * (game_runner.py:87-97, any mask) -> Azul.step (azul.py:296-313, P-generic), a fresh Azul(players = P, rules) + new_round() when
- * a game ends or nobody can move; start them with azul_batch_init + azul_batch_new_round -- in a persistent kernel with one game
+ * a game ends or nobody can move; start them with azul_batch_init + azul_batch_new_round -- in a persistent kernel with two games
  * per wavefront.  Their reward stream is all zero (the shaped reward is GameRunner's: two players, game_runner.py:50), rec_dev rows
- * are 256-byte wide records (bytes of absent players and the reserved tail are not written), mask rows are dense (180 bytes).
+ * are 256-byte wide records (bytes of absent players and the reserved tail are not written), mask rows are dense.  A game of such a
+ * batch that a rule error stops (bag and lid empty without AZUL_RULE_SHORT_DEAL, where the reference raises: azul.py:86-87) plays no
+ * further move in this launch: its remaining slots carry action -1 / done 2 and are counted in `stuck` like the slots of a stuck game.
  */
 int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_t *maskbits_dev, int32_t *action_dev,
                         int32_t *reward_dev, uint8_t *done_dev, uint32_t *packed_dev, uint8_t *rec_dev, void *stream);

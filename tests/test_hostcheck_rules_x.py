@@ -96,6 +96,10 @@ def check_streams(L, P, first, pool, ext, n, T, variant, seed0, margin=0, prepar
                     assert np.array_equal(out["mask"][ok, g, :NA], o1["mask"][0]) and out["action"][ok, g] == o1["action"][0], tag + (ok,)
                 ok += 1
             assert ok < T
+            if variant != 4:
+                # the slots after the stop: no move played -- marked like stuck slots (action -1, done 2) and counted with them
+                assert (out["action"][ok + 1:, g] == -1).all() and (out["done"][ok + 1:, g] == 2).all(), tag
+            assert int(stuck[g]) >= T - ok - 1, tag
             continue
         if variant != 4:
             assert np.array_equal(out["mask"][:, g, :NA], o["mask"]), tag

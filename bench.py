@@ -639,11 +639,17 @@ def main():
         coll_.all_reduce(s_el, dist.ReduceOp.MAX, "all-reduce (max) of the sustained region's elapsed time")
         coll_.all_reduce(s_moves, dist.ReduceOp.SUM, "all-reduce (sum) of the sustained region's env moves")
         if rank == 0:
-            per = sorted(env.timing_launch_ms())
+            series = env.timing_launch_ms()
+            nb = max(1, len(series) // 10)
+            blocks = [sum(series[i:i + nb]) / len(series[i:i + nb]) for i in range(0, len(series), nb)][:10]
+            per = sorted(series)
             sustained = {"launches": S, "env_steps_per_s": float(s_moves.item()) / float(s_el.item()), "seconds": float(s_el.item()),
                          "vs_value": float(s_moves.item()) / float(s_el.item()) / (total_moves / elapsed),
                          "launch_ms": {"n": len(per), "min": per[0], "p50": per[len(per) // 2], "p99": per[min(len(per) - 1, int(len(per) * 0.99))],
-                                       "max": per[-1], "mean": s_kms / max(s_kn, 1)} if per else None,
+                                       "max": per[-1], "mean": s_kms / max(s_kn, 1),
+                                       "means_of_ten_consecutive_blocks": blocks,
+                                       "mean_even_odd_launches": [sum(series[0::2]) / max(len(series[0::2]), 1), sum(series[1::2]) / max(len(series[1::2]), 1)]}
+                         if per else None,
                          "event_bracket_ms": s_bracket,
                          "parity_gate": parity_gate(env, G, base, gate_moves + (K + S) * T, budget=2500000),
                          "note": "after the timed region: same buffers, same launches (N > 1: same all-gather), launch durations from the "

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Games-per-GPU sweep of the self-play kernel (profiles/round3_games_sweep.txt): gpurun -- bash tools/games_sweep.sh
 for G in 1024 2048 3072 4096 8192; do
-  python3 bench.py --games $G --steps 8 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('games %6d: %.3f G env steps/s, launch %.4f ms, %s' % ($G, d['value']/1e9, d['roofline']['avg_launch_ms'], d['parity_gate_after_timed_region'][:2]))"
+  python3 bench.py --games $G --steps 8 --warmup 2 --no-cpu-baseline --no-extras --sustained 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('games %6d: %.3f G env steps/s, launch %.4f ms, %s' % ($G, d['value']/1e9, d['roofline']['avg_launch_ms'], d['parity_gate_after_timed_region'][:2]))"
 done
 python3 - <<'PY'
 # the same launch without any output stream (timing only)

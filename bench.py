@@ -648,12 +648,14 @@ def main():
                          "launch_ms": {"n": len(per), "min": per[0], "p50": per[len(per) // 2], "p99": per[min(len(per) - 1, int(len(per) * 0.99))],
                                        "max": per[-1], "mean": s_kms / max(s_kn, 1),
                                        "means_of_ten_consecutive_blocks": blocks,
+                                       "last_block_kernel_env_steps_per_s": G * T / (blocks[-1] / 1e3) if blocks else None,
                                        "mean_even_odd_launches": [sum(series[0::2]) / max(len(series[0::2]), 1), sum(series[1::2]) / max(len(series[1::2]), 1)]}
                          if per else None,
                          "event_bracket_ms": s_bracket,
                          "parity_gate": parity_gate(env, G, base, gate_moves + (K + S) * T, budget=2500000),
                          "note": "after the timed region: same buffers, same launches (N > 1: same all-gather), launch durations from the "
-                                 "library's event pairs (rank 0's GPU); `value` is NOT taken from here"}
+                                 "library's event pairs (rank 0's GPU); `value` is NOT taken from here.  The block means show the clock "
+                                 "coming down under sustained load (a step of ~+10 % in launch time after ~0.45 s on the boxes measured)"}
 
     out = None
     if rank == 0:

@@ -686,6 +686,7 @@ def main():
                          "scalar_pipe_frac": hw.get("scalar_pipe_frac"),
                          "ceiling_of_a_dependent_chain_at_two_waves_per_simd": hw.get("ceiling_of_a_dependent_chain_at_two_waves_per_simd"),
                          "ceiling_source": hw.get("ceiling_source"),
+                         "valu_pipe_share_from_SQ_ACTIVE_INST_VALU": ij.get("valu_pipe_share_from_SQ_ACTIVE_INST_VALU"),
                          "occupancy_frac": ij.get("occupancy_frac"), "occupancy_source": ij.get("occupancy_source"),
                          "wave_time_shares": ij.get("wave_time_shares")}
                 issue.update({k: ij.get(k) for k in ("instr_per_game_move", "valu_per_game_move", "salu_per_game_move", "cycles_per_instr_per_simd",

@@ -164,6 +164,10 @@ if "SQ_INSTS_VALU" in pmc and "SQ_INSTS_SALU" in pmc and "GRBM_GUI_ACTIVE" in pm
         issue["wait_any_share_of_wave_cycles"] = issue["wave_time_shares"]["wait_any"]
     if "SQ_ACTIVE_INST_VALU" in pmc and "SQ_BUSY_CYCLES" in pmc:
         issue["active_inst_valu_per_busy_cycle"] = pmc["SQ_ACTIVE_INST_VALU"]["mean"] / pmc["SQ_BUSY_CYCLES"]["mean"]
+        # the same pipe share from the hardware's own activity counter: a wave is "active in a VALU instruction" for one quad-cycle (4 cycles)
+        # per instruction (measured: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.00), of which the SIMD-32 pipe is occupied for 2 -- so
+        # SQ_ACTIVE_INST_VALU x 2 / (SIMDs x cycles) is the full-rate pipe share and must agree with hw.frac_if_every_valu_instruction_were_full_rate
+        issue["valu_pipe_share_from_SQ_ACTIVE_INST_VALU"] = pmc["SQ_ACTIVE_INST_VALU"]["mean"] * 2.0 / (N_SIMD * cycles)
     sweep = os.path.join(dst, "%s_games_sweep.txt" % name)
     if os.path.exists(sweep):
         vals = {}

@@ -349,3 +349,35 @@ def test_counters_dev_views_and_device_guard():
             assert torch.cuda.current_device() == 1      # the caller's device is restored
         torch.cuda.synchronize()
         assert env.get_records().tobytes() != rec.tobytes()
+
+
+@pytest.mark.parametrize("n", [1, 5, 33])
+def test_odd_batches_through_the_rule_kernel(torch_cuda, n):
+    """The two-player rule kernel serves two games per wavefront: an odd batch leaves the last wave's upper half without a game (and a batch
+    of one leaves it to a single half).  Queries, an unchecked move and Azul.step with a status per game, against the oracle."""
+    recs, runners = harvest(n, seed0=1700)
+    L = oz.lib()
+    env = make_env(LID, recs)
+    mask = env.get_valid_moves().cpu().numpy()
+    obs = env.get_state(2).cpu().numpy()
+    phi = env.score_preview().cpu().numpy()
+    assert mask.shape == (n, 180) and obs.shape == (n, 136)
+    for g, q in enumerate(runners):
+        assert np.array_equal(mask[g], oz.check_all_valid(q.game)), g
+        cur = q.game.current_player - 1 if q.game.current_player else 1
+        assert np.array_equal(obs[g].astype(np.int64), oz.get_state(q.game, cur)), g
+        assert phi[g] == L.oz_potential(C.byref(q.game)), g
+    env.seed(seed_base=300)
+    rngs = [oz.seeded_rng(300 + g) for g in range(n)]
+    actions = np.zeros(n, dtype=np.int32)
+    want = np.zeros(n, dtype=np.uint8)
+    for g, q in enumerate(runners):
+        legal = np.flatnonzero(oz.check_all_valid(q.game))
+        actions[g] = int(legal[g % len(legal)]) if len(legal) else 0
+        a = int(actions[g])
+        want[g] = oz.GAME_ENDED if q.game.end_of_game else L.oz_step(C.byref(q.game), a % 6, (a // 6) % 5, a // 30, C.byref(rngs[g]))
+    status = env.azul_step(actions).cpu().numpy()
+    assert np.array_equal(status, want)
+    assert env.get_records().tobytes() == np.array([oz.pack(q) for q in runners], dtype=oz.RECORD_DTYPE).tobytes()
+    for g in range(n):
+        assert env.get_rng(g)[1] == rngs[g].idx, g

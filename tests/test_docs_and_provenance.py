@@ -63,3 +63,30 @@ def test_provenance_tool_hashes_the_product_sources():
     import provenance
     h = provenance.csrc_hash()
     assert re.fullmatch(r"[0-9a-f]{16}", h)
+
+
+def test_hw_frac_is_reproducible_from_the_tracked_profile_files():
+    """roofline.issue.hw_frac (what bench.py quotes from profiles/issue_rate.json) recomputed by hand from the tracked PMC means
+    (profiles/round5_summary.json: pmc_per_launch), the tracked static opcode mix (profiles/round5_isa_mix.json) and the price list the
+    file itself carries: class counts x pipe cycles per wave64 instruction / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)."""
+    import json
+    prof = os.path.join(ROOT, "profiles")
+    issue = json.load(open(os.path.join(prof, "issue_rate.json")))
+    pmc = json.load(open(os.path.join(prof, "round5_summary.json")))["pmc_per_launch"]
+    mix = json.load(open(os.path.join(prof, "round5_isa_mix.json")))
+    cost = {k: v["cycles"] for k, v in issue["hw"]["costs"].items()}
+    m = lambda k: pmc[k]["mean"]
+    valu = m("SQ_INSTS_VALU")
+    cls = {"int64": m("SQ_INSTS_VALU_INT64"), "f64": m("SQ_INSTS_VALU_ADD_F64") + m("SQ_INSTS_VALU_MUL_F64") + m("SQ_INSTS_VALU_FMA_F64"),
+           "cvt": m("SQ_INSTS_VALU_CVT"), "trans_f64": m("SQ_INSTS_VALU_TRANS_F64"), "mul32": valu * mix["quarter_rate_int32_multiply_share_of_valu"]}
+    cls["default"] = valu - sum(cls.values())
+    need = sum(cls[k] * cost[k] for k in cls)
+    cycles = m("GRBM_GUI_ACTIVE") / 8.0
+    assert abs(need / (1024 * cycles) - issue["hw_frac"]) < 1e-9
+    assert 0.3 < issue["hw_frac"] < 0.7 and cost["default"] == 2.0
+    # the hardware's own activity counter gives the same full-rate share (two independent counters, one number)
+    assert abs(issue["valu_pipe_share_from_SQ_ACTIVE_INST_VALU"] - issue["hw"]["frac_if_every_valu_instruction_were_full_rate"]) < 0.01
+    # the occupancy ratio quotes the tracked sweep of the same run
+    sweep = open(os.path.join(prof, "round5_games_sweep.txt")).read()
+    vals = {int(ln.split()[1].rstrip(":")): float(ln.split()[2]) for ln in sweep.splitlines() if ln.startswith("games") and "G env steps/s" in ln}
+    assert abs(issue["occupancy_frac"] - vals[4096] / vals[8192]) < 1e-9

@@ -70,14 +70,14 @@ __global__ void __launch_bounds__(64) azul_x_selfplay_kernel(azx::XBatchDev b, a
 // host side: C ABI
 // ------------------------------------------------------------------------------------------------
 struct azul_batch {
-    BatchDev d;          // `T` is written once by azul_batch_create
+    BatchDev d;          // `tab` is written once by azul_batch_create
     int device;          // the device the batch's arrays live on: every entry runs there (DeviceGuard)
     int players;         // 2, 3 or 4
     int rec_bytes;       // 128 (two players under the reference's rules: every entry) or 256 (the wide record: the x path below)
     bool x;              // three / four players, or any extended rule: the azul_rules_x.hpp kernels (rule entries + flat self-play)
     unsigned ext;        // AZUL_RULE_* flags (0: the reference's rules)
     int displays;        // 5, or 2 * players + 1 with AZUL_RULE_DISPLAYS_2P1
-    double *Tx;          // x path: the sampling table as {Fr[J][b], S[J]} pairs for 5 (displays + 1) + 1 rows
+    double *Tx;          // the sampling table as {Fr[J][b], S[J]} pairs for 5 (displays + 1) + 1 rows (31 for the reference's 180 actions)
     hipEvent_t ev0, ev1; // bracket of a timed region (azul_timing_begin / _end)
     std::vector<hipEvent_t> lev;   // event pairs around the individual self-play launches of a timed region
     int timed_launches;  // launches since azul_timing_begin
@@ -146,7 +146,7 @@ const char *azul_version(void)
 
 static void batch_free(azul_batch *b)
 {
-    void *bufs[] = {b->d.state, b->d.mt, b->d.mtpos, (void *)b->d.T, b->d.episodes, b->d.stuck, b->d.stat_sum, b->d.prof, b->Tx};
+    void *bufs[] = {b->d.state, b->d.mt, b->d.mtpos, b->d.episodes, b->d.stuck, b->d.stat_sum, b->d.prof, b->Tx};
     for (void *p : bufs) if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -167,21 +167,18 @@ static int batch_alloc(azul_batch *b, int n_games, int first_player, int tile_po
     HIP_TRY(hipMalloc((void **)&b->d.state, N * RB));
     HIP_TRY(hipMalloc((void **)&b->d.mt, N * 624 * sizeof(u32)));
     HIP_TRY(hipMalloc((void **)&b->d.mtpos, N * sizeof(u32)));
-    HIP_TRY(hipMalloc((void **)&b->d.T, sizeof(double) * T_WORDS));
     HIP_TRY(hipMalloc((void **)&b->d.episodes, N * sizeof(u64)));
     HIP_TRY(hipMalloc((void **)&b->d.stuck, N * sizeof(u32)));
     HIP_TRY(hipMalloc((void **)&b->d.stat_sum, N * 10 * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&b->d.prof, SEG_COUNT * sizeof(u64)));
     HIP_TRY(hipMemset(b->d.prof, 0, SEG_COUNT * sizeof(u64)));
-    std::vector<double> hT((size_t)T_WORDS);
-    if (!build_sample_tab(hT.data())) return fail(AZUL_ERR_INVALID, "weight-table decomposition check failed on this host");
-    HIP_TRY(hipMemcpy((void *)b->d.T, hT.data(), hT.size() * sizeof(double), hipMemcpyHostToDevice));
-    if (b->x) {
+    {   // the sampler's table: built with CPython's very additions and checked entry by entry on this host (azul_tables.hpp)
         const int rows = 5 * (b->displays + 1) + 1;
         std::vector<double> hX((size_t)rows * 16);
         if (!build_sample_pairs(rows, hX.data())) return fail(AZUL_ERR_INVALID, "weight-table decomposition check failed on this host");
         HIP_TRY(hipMalloc((void **)&b->Tx, hX.size() * sizeof(double)));
         HIP_TRY(hipMemcpy(b->Tx, hX.data(), hX.size() * sizeof(double), hipMemcpyHostToDevice));
+        b->d.tab = (const double2 *)b->Tx;
     }
     HIP_TRY(hipMemset(b->d.state, 0, N * RB));
     HIP_TRY(hipMemset(b->d.mt, 0, N * 624 * sizeof(u32)));

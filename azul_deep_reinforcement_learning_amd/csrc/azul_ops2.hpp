@@ -14,7 +14,7 @@ struct BatchDev {
     uint8_t *state;      // [N][128]
     u32 *mt;             // [N][624]
     u32 *mtpos;          // [N]
-    const double *T;     // the sampler's table: Fr[31][8] then S[31] (azul_tables.hpp)
+    const double2 *tab;  // the sampler's table as {Fr[J][b], S[J]} pairs, T_ROWS x T_BINADES (azul_tables.hpp: build_sample_pairs)
     u64 *episodes;       // [N]
     u32 *stuck;          // [N]
     double *stat_sum;    // [N][10]
@@ -64,15 +64,14 @@ AZ_FN bool op_needs_rng(int op)
 constexpr u32 OP2_OBS_STRIDE = 144;      // floats per half of the observation staging row (136 used)
 
 // One rule call on games 2 pair and 2 pair + 1 of the launch (rows of the caller's arrays; games a.first + row of the batch): the op, then
-// the queries on the state it leaves.  mt_lds: 624 words of LDS per half for the game's MT19937 state; tab_lds / tabfs_lds: the sampler's
-// table in the two forms Tab2 reads; obs_lds: staging row of observe2.
+// the queries on the state it leaves.  mt_lds: 624 words of LDS per half for the game's MT19937 state; tabfs_lds: the sampler's table;
+// obs_lds: staging row of observe2.
 template <bool LID>
-AZ_FN void op_body2(const BatchDev &b, const OpArgs &a, u32 pair, u32 (*mt_lds)[624], double *tab_lds, double2 *tabfs_lds, float (*obs_lds)[OP2_OBS_STRIDE])
+AZ_FN void op_body2(const BatchDev &b, const OpArgs &a, u32 pair, u32 (*mt_lds)[624], double2 *tabfs_lds, float (*obs_lds)[OP2_OBS_STRIDE])
 {
     using namespace az2;
     const u32 lane = wv::lane(), l = lane & 31u, half = lane >> 5;
-    for (u32 i = lane; i < (u32)T_WORDS; i += 64u) tab_lds[i] = b.T[i];
-    for (u32 i = lane; i < (u32)(T_ROWS * T_BINADES); i += 64u) tabfs_lds[i] = make_double2(b.T[i], b.T[T_ROWS * T_BINADES + i / T_BINADES]);
+    for (u32 i = lane; i < (u32)(T_ROWS * T_BINADES); i += 64u) tabfs_lds[i] = b.tab[i];
     lds_sync();
     const u32 oi = 2u * pair + half;                 // row of the caller's arrays
     if (oi >= a.count) return;                       // odd launch: the last wave serves one game
@@ -81,7 +80,7 @@ AZ_FN void op_body2(const BatchDev &b, const OpArgs &a, u32 pair, u32 (*mt_lds)[
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
     K2 k;
     k2_init(k);
-    const Tab2 tab = {tab_lds, tab_lds + T_ROWS * T_BINADES, tabfs_lds};
+    const Tab2 tab = {tabfs_lds};
     G2 g;
     g2_load(g, rec, l);
     prime2(g, k);

@@ -138,7 +138,6 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     __shared__ float w2cS[PF_HID];
     __shared__ float b1S[PF_H2 + 24], b2aS[PF_ACT + 12];
     __shared__ u32 mtS[PF_GAMES][624];
-    __shared__ double tab_lds[T_WORDS];
     __shared__ double2 tabfs_lds[T_ROWS * T_BINADES];
     __shared__ u64 maskS[PF_GAMES][4];
     __shared__ i32 actS[PF_GAMES];
@@ -153,8 +152,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     if (tid < (u32)(PF_H2 + 24)) b1S[tid] = tid < (u32)PF_H2 ? W.b1[tid] : 0.f;
     if (tid < (u32)(PF_ACT + 12)) b2aS[tid] = tid < (u32)PF_ACT ? W.b2a[tid] : 0.f;
     if (OPP) {
-        for (u32 i = tid; i < (u32)T_WORDS; i += 64u * PR2_WAVES) tab_lds[i] = b.T[i];
-        for (u32 i = tid; i < (u32)(T_ROWS * T_BINADES); i += 64u * PR2_WAVES) tabfs_lds[i] = make_double2(b.T[i], b.T[T_ROWS * T_BINADES + i / T_BINADES]);
+        for (u32 i = tid; i < (u32)(T_ROWS * T_BINADES); i += 64u * PR2_WAVES) tabfs_lds[i] = b.tab[i];
     }
     const float b2c_v = W.b2c[0];
 
@@ -168,7 +166,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     // env state of this half's game
     az2::K2 k;
     az2::k2_init(k);
-    az2::Tab2 tab = {tab_lds, tab_lds + T_ROWS * T_BINADES, tabfs_lds};
+    az2::Tab2 tab = {tabfs_lds};
     az2::G2 g;
     uint8_t *rec = b.state + (size_t)gic * AZUL_RECORD_BYTES;
     az2::g2_load(g, rec, l);

@@ -280,43 +280,8 @@ AZ_FN void mask_limbs(const MaskX<D> &m, u64 (&limb)[Dim<D>::NL + 1])
     }
 }
 
-// ---- RandomAgent (game_runner.py:87-97 + random.choices): azul_selfplay2.hpp's decomposition of the cumulative weights --------------
-// T(J, 0) = S[J], T(J, m) = m + Fr[J][ilog2 m]: pairs {Fr[J][b], S[J]} at 8 J + b, J = 0 .. Q (azul_tables.hpp build_sample_pairs)
-struct TabX { const double2 *fs; };
-
-AZ_FN double tpat_x(const TabX &t, u32 J, u32 m) { return (double)m + t.fs[8u * J + 31u - (u32)__builtin_clz(m)].x; }
-AZ_FN double tseq_x(const TabX &t, u32 J, u32 kk) { return kk <= J ? t.fs[8u * kk].y : tpat_x(t, J, kk - J); }
-
-// bisect_right over the cumulative weights == smallest ordinal kk with cum(kk) > x (az2::sample_slow2)
-AZ_FN u32 sample_slow_x(const TabX &T, double x, double sJ, u32 J, u32 M, u32 L)
-{
-    u32 kg;
-    if (x < sJ) {
-        kg = (u32)(x * 100.0) + 1u;
-        kg = kg > J ? J : kg;
-        for (u32 it = 0; it < 64u; it++) {
-            bool below = x < tseq_x(T, J, kg - 1u), inside = x < tseq_x(T, J, kg);
-            if (below && kg > 1u) kg -= 1u;
-            else if (!inside && kg < L) kg += 1u;
-            else break;
-        }
-    } else {
-        double d = x - sJ;
-        u32 mg = (u32)d + 1u;
-        mg = mg > M ? M : mg;
-        for (u32 it = 0; it < 256u; it++) {
-            u32 ml = mg - 1u;
-            double lo = ml ? tpat_x(T, J, ml) : sJ;
-            double hi = tpat_x(T, J, mg);
-            if (x < lo && mg > 1u) mg -= 1u;
-            else if (!(x < hi) && mg < M) mg += 1u;
-            else break;
-        }
-        kg = J + mg;
-    }
-    return kg;
-}
-
+// ---- RandomAgent (game_runner.py:87-97 + random.choices): azul_selfplay2.hpp's table (Tab2: pairs {Fr[J][b], S[J]} at 8 J + b, here for
+// J = 0 .. Q legal floor moves) and its boundary search (sample_slow2), unchanged ------------------------------------------------------
 // one decision: counts of the legal actions, the ordinal from random(), the chosen action (row, source, colour)
 template <u32 D>
 struct Choice { i32 a; u32 row, s, c; };
@@ -733,7 +698,7 @@ AZ_FN void outputs_x(const GX<P, D> &g, const Out2 &o, i32 a, u32 dn, u32 l)
 
 // returns 0 = move played, 1 = game ended with this move, 2 = stuck, 0x100 | status on a rule error
 template <u32 P, u32 D, int OUT, bool PAD, bool BITS>
-AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2 &r, const TabX &T, u64 margin, Counters2 &cnt,
+AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2 &r, const Tab2 &T, u64 margin, Counters2 &cnt,
                           const Out2 &o, bool &dead, SegProf *prof_ = nullptr)
 {
     (void)prof_;
@@ -787,7 +752,7 @@ AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2
             kg = J + fl + 1u;
             edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (fl + 1u > M);
         }
-        if (edge & !nomove) kg = sample_slow_x(T, x, sJ, J, M, L);
+        if (edge & !nomove) kg = sample_slow2(T, x, sJ, J, M, L);
         any_nomove = wave_any(nomove);
     }
     Choice<D> ch;
@@ -857,7 +822,7 @@ AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2
 // RandomAgent on a mask (the game's own, or a caller's): one random.choices draw from the game's stream; -1 when nothing is legal
 // (no word consumed).  The single-call form (op kernel): words through the stream's window, no speculation.
 template <u32 D>
-AZ_FN i32 random_agent_x(const MaskX<D> &m, Rng2 &r, const TabX &T, const K2 &k)
+AZ_FN i32 random_agent_x(const MaskX<D> &m, Rng2 &r, const Tab2 &T, const K2 &k)
 {
     u32 pre[7];
     pre[0] = 0;
@@ -868,9 +833,9 @@ AZ_FN i32 random_agent_x(const MaskX<D> &m, Rng2 &r, const TabX &T, const K2 &k)
     if (L != 0u) {
         const u32 M = L - J;
         const double sJ = T.fs[8u * J].y;
-        const double total = (M ? tpat_x(T, J, M) : sJ) + 0.0;
+        const double total = (M ? tpat2(T, J, M) : sJ) + 0.0;
         const double x = rng2_random(r, k.l) * total;
-        const u32 kg = sample_slow_x(T, x, sJ, J, M, L);
+        const u32 kg = sample_slow2(T, x, sJ, J, M, L);
         Choice<D> ch;
         pick_action_x<D>(m, pre, kg, k, ch);
         a = ch.a;
@@ -947,7 +912,7 @@ AZ_FN void op_body_x(const XBatchDev &b, const XOp &a, u32 pair /* games 2 pair,
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES_WIDE;
     KX<D> K;
     kx_init(K);
-    const TabX tab = {tab_lds};
+    const Tab2 tab = {tab_lds};
     GX<P, D> g;
     gx_load(g, rec, l);
     prime_x(g, K);
@@ -1063,7 +1028,7 @@ AZ_FN void selfplay_body_x(const XBatchDev &b, const XTraj &t, u32 wave_id, u32 
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES_WIDE;
     KX<D> K;
     kx_init(K);
-    const TabX tab = {tab_lds};
+    const Tab2 tab = {tab_lds};
     GX<P, D> g;
     gx_load(g, rec, l);
     prime_x(g, K);

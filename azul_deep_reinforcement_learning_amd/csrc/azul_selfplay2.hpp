@@ -374,10 +374,10 @@ AZ_FN void legal_mask2(const G2 &g, const K2 &k, Mask2 &out)
 // checks all 31 * 151 sums when a batch is created).  bisect_right over the cumulative weights == the smallest ordinal k with cum(k) > x.
 // Pattern moves: |Fr - S[J]| < 2^-44 (a handful of half-ulp roundings below 256) and d = x - S[J] carries an fp64 error below 2^-45, so
 // whenever d is further than 1e-9 from an integer, floor(d) + 1 IS the ordinal; otherwise the exact table values decide (sample_slow2).
-struct Tab2 { const double *fr; const double *s; const double2 *fs; };      // LDS: Fr[31][8], S[31], and {Fr[J][b], S[J]} pairs (one 16-byte read)
+struct Tab2 { const double2 *fs; };      // LDS: the pairs {Fr[J][b], S[J]} at 8 J + b (azul_tables.hpp: build_sample_pairs): both table values of a decision in one 16-byte read
 
-AZ_FN double tpat2(const Tab2 &t, u32 J, u32 m) { return (double)m + t.fr[8u * J + 31u - (u32)__builtin_clz(m)]; }
-AZ_FN double tseq2(const Tab2 &t, u32 J, u32 kk) { return kk <= J ? t.s[kk] : tpat2(t, J, kk - J); }
+AZ_FN double tpat2(const Tab2 &t, u32 J, u32 m) { return (double)m + t.fs[8u * J + 31u - (u32)__builtin_clz(m)].x; }      // T(J, m), m >= 1
+AZ_FN double tseq2(const Tab2 &t, u32 J, u32 kk) { return kk <= J ? t.fs[8u * kk].y : tpat2(t, J, kk - J); }              // cumulative weight after the kk-th legal action
 
 // bisect_right over the cumulative weights == smallest ordinal kk with cum(kk) > x: the generic search (x inside the 0.01-weight
 // floor moves, or a guess too close to an integer boundary: rare)

@@ -20,10 +20,9 @@ template <bool LID>
 __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
 {
     __shared__ u32 mt_lds[2][624];
-    __shared__ double tab_lds[T_WORDS];
     __shared__ double2 tabfs_lds[T_ROWS * T_BINADES];
     __shared__ float obs_lds[2][OP2_OBS_STRIDE];
-    op_body2<LID>(b, a, blockIdx.x, mt_lds, tab_lds, tabfs_lds, obs_lds);
+    op_body2<LID>(b, a, blockIdx.x, mt_lds, tabfs_lds, obs_lds);
 }
 
 // Discounted returns over the time-major trajectory of one launch window (reference loop: nn_runner.py:70-76,
@@ -99,11 +98,9 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
 {
     __shared__ u32 mt_lds[2][624];
     __shared__ u32 mtt_lds[2][624];                        // the same words tempered (az2::Rng2::tlds)
-    __shared__ double tab_lds[T_WORDS];
     __shared__ double2 tabfs_lds[T_ROWS * T_BINADES];      // {Fr[J][b], S[J]}: both table values of a decision in one 16-byte read
     const u32 lane = wv::lane(), l = lane & 31u, half = lane >> 5;
-    for (u32 i = lane; i < (u32)T_WORDS; i += 64u) tab_lds[i] = b.T[i];
-    for (u32 i = lane; i < (u32)(T_ROWS * T_BINADES); i += 64u) tabfs_lds[i] = make_double2(b.T[i], b.T[T_ROWS * T_BINADES + i / T_BINADES]);
+    for (u32 i = lane; i < (u32)(T_ROWS * T_BINADES); i += 64u) tabfs_lds[i] = b.tab[i];
     az2::lds_sync();
     // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b runs on XCD b % 8.
     // Give every XCD a CONTIGUOUS range of games: the waves that share a cache line of a time-major stream (32 games of an int32
@@ -115,7 +112,7 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
     az2::K2 k;
     az2::k2_init(k);
-    az2::Tab2 tab = {tab_lds, tab_lds + T_ROWS * T_BINADES, tabfs_lds};
+    az2::Tab2 tab = {tabfs_lds};
     az2::G2 g;
     az2::g2_load(g, rec, l);
     az2::prime2(g, k);

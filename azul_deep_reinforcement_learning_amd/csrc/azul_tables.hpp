@@ -20,26 +20,8 @@ static inline void build_weight_table(double *T /* [31][151] */)
     }
 }
 
-// Compact form used by the kernels: Fr[J][b] = T[J][2^b] - 2^b (exact), S[J] = T[J][0]; then
-// T[J][m] == m + Fr[J][floor(log2 m)] for every m in 1..150.  Returns false if that identity ever failed.
-static inline bool build_sample_tab(double *tab /* T_WORDS */)
-{
-    double T[31 * 151];
-    build_weight_table(T);
-    for (int J = 0; J < 31; J++) {
-        for (int b = 0; b < 8; b++) tab[J * 8 + b] = T[J * 151 + (1 << b)] - (double)(1 << b);
-        tab[31 * 8 + J] = T[J * 151];
-    }
-    bool ok = true;
-    for (int J = 0; J < 31; J++)
-        for (int m = 1; m < 151; m++) {
-            int b = 31 - __builtin_clz((unsigned)m);
-            if ((double)m + tab[J * 8 + b] != T[J * 151 + m]) ok = false;
-        }
-    return ok;
-}
-
-// The same decomposition for an action space with `rows - 1` floor actions (the P-player rules on D displays, azul_rules_x.hpp:
+// Compact form used by the kernels: Fr[J][b] = T[J][2^b] - 2^b (exact), S[J] = T[J][0]; then T[J][m] == m + Fr[J][floor(log2 m)] for every m.
+// For an action space with `rows - 1` floor actions (the reference's game: rows = 31; the P-player rules on D displays, azul_rules_x.hpp:
 // rows = 5 (D + 1) + 1, at most 5 (rows - 1) pattern moves), as the {Fr[J][b], S[J]} pairs the kernels read with one 16-byte load:
 // out[2 (8 J + b)] = Fr[J][b], out[2 (8 J + b) + 1] = S[J].  Returns false if the identity ever failed.
 static inline bool build_sample_pairs(int rows, double *out /* [rows * 8 * 2] */)

@@ -17,7 +17,7 @@ using namespace az;
 enum { OBS = 136, OBS_STRIDE = 140 };
 
 struct EnvJob {
-    uint8_t *state; u32 *mt; u32 *mtpos; const double *T;
+    uint8_t *state; u32 *mt; u32 *mtpos; const double2 *T;
     u64 *episodes; u32 *stuck; double *stat_sum;
     u32 n, first_player;
     u64 margin;
@@ -32,7 +32,6 @@ struct EnvJob {
     u32 wave_id;
     // "LDS" of the wave
     u32 mt_lds[2][624];
-    double tab_lds[T_WORDS];
     double2 tabfs_lds[T_ROWS * T_BINADES];
     float obs_lds[2][OBS_STRIDE];
     u64 mask_lds[2][3];
@@ -42,15 +41,14 @@ template <bool LID, bool OPP>
 static void env_wave(EnvJob *j)
 {
     const u32 lane = wv::lane(), l = lane & 31u, half = lane >> 5;
-    for (u32 i = lane; i < (u32)T_WORDS; i += 64u) j->tab_lds[i] = j->T[i];
-    for (u32 i = lane; i < (u32)(T_ROWS * T_BINADES); i += 64u) j->tabfs_lds[i] = make_double2(j->T[i], j->T[T_ROWS * T_BINADES + i / T_BINADES]);
+    for (u32 i = lane; i < (u32)(T_ROWS * T_BINADES); i += 64u) j->tabfs_lds[i] = j->T[i];
     az2::lds_sync();
     const u32 n = j->n, gi = j->wave_id * 2u + half;
     const bool live = gi < n;
     const u32 gic = live ? gi : n - 1u;                     // a dead half loads a valid game and writes nothing (the kernel's clamp)
     az2::K2 k;
     az2::k2_init(k);
-    az2::Tab2 tab = {j->tab_lds, j->tab_lds + T_ROWS * T_BINADES, j->tabfs_lds};
+    az2::Tab2 tab = {j->tabfs_lds};
     az2::G2 g;
     uint8_t *rec = j->state + (size_t)gic * AZUL_RECORD_BYTES;
     az2::g2_load(g, rec, l);
@@ -117,12 +115,12 @@ long long sh2_rollout_env(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 
                           uint8_t *mask, uint8_t *player, u64 *maskbits, i32 *reward, uint8_t *done, uint8_t *status)
 {
     if (n_games <= 0 || n_steps < 0) return -1;
-    static double T[T_WORDS];
-    if (!build_sample_tab(T)) return -2;
+    static double T[T_ROWS * T_BINADES * 2];
+    if (!build_sample_pairs(T_ROWS, T)) return -2;
     long long ops = 0;
     for (u32 w = 0; w < ((u32)n_games + 1u) / 2u; w++) {
         EnvJob *j = (EnvJob *)calloc(1, sizeof(EnvJob));
-        j->state = state; j->mt = mt; j->mtpos = mtpos; j->T = T; j->episodes = episodes; j->stuck = stuck; j->stat_sum = stat_sum;
+        j->state = state; j->mt = mt; j->mtpos = mtpos; j->T = (const double2 *)T; j->episodes = episodes; j->stuck = stuck; j->stat_sum = stat_sum;
         j->n = (u32)n_games; j->first_player = (u32)first_player; j->margin = margin ? margin : AZ_DRAW_MARGIN;
         j->opponent = opponent; j->n_steps = n_steps; j->actions = actions; j->obs = obs; j->mask = mask; j->player = player;
         j->maskbits = maskbits; j->reward = reward; j->done = done; j->status = status; j->wave_id = w;

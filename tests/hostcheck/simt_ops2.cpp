@@ -9,9 +9,9 @@
 using namespace az;
 #include "azul_selfplay_kernels.hpp"
 
-static double g_T[T_WORDS];
+static double g_T[T_ROWS * T_BINADES * 2];
 static bool g_T_ok = false;
-static void table() { if (!g_T_ok) { g_T_ok = build_sample_tab(g_T); } }
+static void table() { if (!g_T_ok) { g_T_ok = build_sample_pairs(T_ROWS, g_T); } }
 
 struct OpJob { BatchDev b; OpArgs a; int lid; };
 static void op_main(void *arg)
@@ -34,7 +34,7 @@ int sh2_op(uint8_t *rec, int first_player, int tile_pool, unsigned long long mar
     OpJob j;
     memset(&j, 0, sizeof(j));
     BatchDev &b = j.b;
-    b.state = rec; b.mt = mt; b.mtpos = pos; b.T = g_T; b.episodes = &ep; b.stuck = &sk; b.stat_sum = ss; b.n = 1;
+    b.state = rec; b.mt = mt; b.mtpos = pos; b.tab = (const double2 *)g_T; b.episodes = &ep; b.stuck = &sk; b.stat_sum = ss; b.n = 1;
     b.rules.first_player = (u32)first_player; b.rules.tile_pool = (u32)tile_pool; b.draw_margin = margin ? margin : AZ_DRAW_MARGIN;
     OpArgs &a = j.a;
     i32 act_in = action, act_out = 0, rew = 0, pot = 0, nxt = -2;
@@ -71,7 +71,7 @@ int sh2_op_batch(int n, uint8_t *recs, int first_player, int tile_pool, int op, 
     if (n <= 0) return -1;
     OpJob j;
     memset(&j, 0, sizeof(j));
-    j.b.state = recs; j.b.mt = mt; j.b.mtpos = pos; j.b.T = g_T; j.b.episodes = (u64 *)episodes; j.b.stuck = stuck; j.b.stat_sum = stat_sum; j.b.n = (u32)n;
+    j.b.state = recs; j.b.mt = mt; j.b.mtpos = pos; j.b.tab = (const double2 *)g_T; j.b.episodes = (u64 *)episodes; j.b.stuck = stuck; j.b.stat_sum = stat_sum; j.b.n = (u32)n;
     j.b.rules.first_player = (u32)first_player; j.b.rules.tile_pool = (u32)tile_pool; j.b.draw_margin = AZ_DRAW_MARGIN;
     j.a.op = op; j.a.actions = actions; j.a.active = active; j.a.status = status; j.a.mask = mask_out; j.a.reward = reward; j.a.done = done;
     j.a.first = 0; j.a.count = (u32)n;
@@ -90,6 +90,6 @@ void sh2_seed(unsigned long long seed, u32 *mt) { seed_stream(mt, (u64)seed); }
 
 // the RandomAgent weight table (azul_tables.hpp: CPython's accumulate over 0.01 / 1.0 weights) and the check of its compact form
 void sh2_weight_table(double *T /* [31][151] */) { build_weight_table(T); }
-int sh2_sample_tab_ok() { double t[T_WORDS]; return build_sample_tab(t) ? 1 : 0; }
+int sh2_sample_tab_ok() { double t[T_ROWS * T_BINADES * 2]; return build_sample_pairs(T_ROWS, t) ? 1 : 0; }
 
 }

@@ -31,11 +31,11 @@ long long sr2_rollout(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 *epi
                       i32 *action, i32 *reward, uint8_t *done, float *value, float *logp, float *entropy, uint8_t *status, float *returns,
                       float gamma, unsigned long long seed, unsigned long long counter)
 {
-    static double T[T_WORDS];
-    if (!build_sample_tab(T)) return -2;
+    static double T[T_ROWS * T_BINADES * 2];
+    if (!build_sample_pairs(T_ROWS, T)) return -2;
     Job j;
     memset(&j, 0, sizeof(j));
-    j.b.state = state; j.b.mt = mt; j.b.mtpos = mtpos; j.b.T = T; j.b.episodes = episodes; j.b.stuck = stuck; j.b.stat_sum = stat_sum;
+    j.b.state = state; j.b.mt = mt; j.b.mtpos = mtpos; j.b.tab = (const double2 *)T; j.b.episodes = episodes; j.b.stuck = stuck; j.b.stat_sum = stat_sum;
     j.b.n = (u32)n_games; j.b.rules.first_player = (u32)first_player; j.b.rules.tile_pool = (u32)tile_pool; j.b.draw_margin = AZ_DRAW_MARGIN;
     j.b.id_base = id_base;
     j.W = {w1t, b1, w2c, b2c, w2a_t, b2a};

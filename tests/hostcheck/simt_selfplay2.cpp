@@ -33,13 +33,13 @@ long long sh2_selfplay(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 *ep
                        u64 *maskbits, i32 *action, i32 *reward, uint8_t *done, u32 *packed, uint8_t *rec)
 {
     if (n_games <= 0 || n_steps < 0) return -1;
-    static double T[T_WORDS];
-    if (!build_sample_tab(T)) return -2;
+    static double T[T_ROWS * T_BINADES * 2];
+    if (!build_sample_pairs(T_ROWS, T)) return -2;
     long long ops = 0;
     // the kernel itself: one one-wave workgroup per pair of games, blockIdx.x as the launch gives it (the kernel maps it to its games)
     KernelJob kj;
     memset(&kj, 0, sizeof(kj));
-    kj.b.state = state; kj.b.mt = mt; kj.b.mtpos = mtpos; kj.b.T = T; kj.b.episodes = episodes; kj.b.stuck = stuck; kj.b.stat_sum = stat_sum;
+    kj.b.state = state; kj.b.mt = mt; kj.b.mtpos = mtpos; kj.b.tab = (const double2 *)T; kj.b.episodes = episodes; kj.b.stuck = stuck; kj.b.stat_sum = stat_sum;
     kj.b.n = (u32)n_games; kj.b.rules.first_player = (u32)first_player; kj.b.rules.tile_pool = (u32)tile_pool;
     kj.b.draw_margin = margin ? margin : AZ_DRAW_MARGIN;
     kj.t.n_steps = n_steps; kj.t.mask = mask; kj.t.maskbits = maskbits; kj.t.action = action; kj.t.reward = reward; kj.t.done = done;

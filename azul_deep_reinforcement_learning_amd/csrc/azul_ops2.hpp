@@ -92,7 +92,8 @@ AZ_FN void op_body2(const BatchDev &b, const OpArgs &a, u32 pair, u32 (*mt_lds)[
         const bool use_rng = op_needs_rng(a.op);
         Rng2 r;
         u32 *gmt = b.mt + (size_t)gi * 624u;
-        rng2_open(r, gmt, mt_lds[half], use_rng ? (a.pos_set ? a.pos_set - 1u : b.mtpos[gi]) : 0u, l);
+        if (use_rng) rng2_open(r, gmt, mt_lds[half], a.pos_set ? a.pos_set - 1u : b.mtpos[gi], l);      // (move / next_player / count_score never draw: no 2.5 KB staging)
+        else { r.lds = mt_lds[half]; r.tlds = nullptr; r.pos = 0; r.dirty = 0; r.wbase = 0; r.wend = 0; r.win = 0; }
         Counters2 cnt;
         const bool counts = a.op == OP_RUNNER_STEP || a.op == OP_POLICY_STEP || a.op == OP_AGENT_STEP;
         if (counts) counters2_open(cnt, b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10, l);

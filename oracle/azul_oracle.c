@@ -727,6 +727,62 @@ int oz_runner_step(oz_runner *q, int action, oz_rng *r, int64_t *reward, int *do
     return OZ_OK;
 }
 
+/* ---- GameRunner with ANY opponent: game_runner.py:27-30 stores whatever it is given (scripts/run_batch.py:6-10 and
+ * tests/test_nn_runner.py:63-67, 84-90 pass a second Agent); opponent_move hands it the observation from the mover's
+ * perspective and the legal mask and plays what it answers (:37-42).  `opp` stands for opponent.get_a_output; a negative
+ * answer stands for the exception an Agent raises on an all-false mask (model.py:33-34 IllegalMask). ---- */
+int oz_runner_opponent_move_with(oz_runner *q, oz_rng *r, oz_opponent_fn opp, void *ctx)
+{
+    int64_t state[136];
+    uint8_t mask[180];
+    oz_get_state(&q->game, q->game.current_player - 1, state);       /* :38 */
+    oz_check_all_valid(&q->game, mask);                              /* :39 */
+    int a = opp(ctx, state, mask);                                   /* :40 */
+    if (a < 0) return OZ_STUCK;
+    int d, c, p;
+    oz_deserialize(a, &d, &c, &p);
+    int st = oz_step(&q->game, d, c, p, r);                          /* :41 */
+    if (st) return st;
+    q->move_counter += 1;                                            /* :42 */
+    return OZ_OK;
+}
+
+int oz_runner_reset_with(oz_runner *q, oz_rng *r, oz_opponent_fn opp, void *ctx)
+{
+    /* :76-85 */
+    int st = runner_reset_noplay(q, r);
+    if (st) return st;
+    while (q->game.current_player != 1) {                            /* :84 */
+        st = oz_runner_opponent_move_with(q, r, opp, ctx);           /* :85 */
+        if (st) return st;
+    }
+    return OZ_OK;
+}
+
+int oz_runner_step_with(oz_runner *q, int action, oz_rng *r, oz_opponent_fn opp, void *ctx, int64_t *reward, int *done)
+{
+    /* :43-55 */
+    int d, c, p;
+    oz_deserialize(action, &d, &c, &p);
+    int st = oz_step(&q->game, d, c, p, r);                          /* :44 */
+    if (st) return st;
+    q->move_counter += 1;                                            /* :45 */
+    for (;;) {
+        uint8_t mask[180];
+        oz_check_all_valid(&q->game, mask);
+        int nvalid = 0;
+        for (int i = 0; i < 180; i++) nvalid += mask[i];
+        if (!((q->game.current_player != 1 || nvalid < 2) && !oz_is_end_of_game(&q->game))) break;   /* :46 */
+        st = oz_runner_opponent_move_with(q, r, opp, ctx);           /* :47 */
+        if (st) return st;
+    }
+    int64_t nps = oz_potential(&q->game);                            /* :48-50 */
+    *reward = nps - q->player_score;                                 /* :51 */
+    q->player_score = nps;                                           /* :52 */
+    *done = oz_is_end_of_game(&q->game);                             /* :55 */
+    return OZ_OK;
+}
+
 /* ------------------------------------------------------------------------- */
 /* canonical 128-byte record (layout documented in include/azul_hip.h)       */
 /* ------------------------------------------------------------------------- */

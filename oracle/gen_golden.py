@@ -519,6 +519,96 @@ def gen_players_selfplay():
         len(index), sum(int(blob[i[4] + "_episodes"]) for i in index), sum(int(blob[i[4] + "_stuck"]) for i in index)))
 
 
+def gen_net_opponent():
+    """GameRunner(opponent=Agent(...)) (game_runner.py:27-30): every opponent_move -- and every forced move of player 1 -- goes through a
+    second ActorCritic on the perspective-rotated observation (game_runner.py:37-42, :46; agent.py:73-81); reset() lets the opponent open
+    (:84-85).  scripts/run_batch.py:6-10 and tests/test_nn_runner.py:63-67, 84-90 run exactly this.  Recorded per seed and rule set, two
+    episodes: per AGENT step what NNRunner.run_episode sees (nn_runner.py:22-30: observation, mask, action, value, log-prob, entropy term,
+    reward, done, move_counter, player_score) and per OPPONENT call what get_a_output was handed (state, mask, the player it moved for)
+    and what it answered (action, its probability, the full distribution for the first calls).  The two nets are the reference's own
+    default-initialised ActorCritic modules (torch.manual_seed(0)); the env draws from `random`, the agents from np.random."""
+    from azulnet import Agent
+    torch.manual_seed(0)
+    agent, opponent = Agent(), Agent()
+    blob = {}
+    for k, v in agent.ac_net.state_dict().items():
+        blob["agent_sd_" + k] = v.numpy().copy()
+    for k, v in opponent.ac_net.state_dict().items():
+        blob["opp_sd_" + k] = v.numpy().copy()
+    calls = collections.defaultdict(list)
+    orig_forward = opponent.ac_net.forward_actor
+    seen = {}
+
+    def forward_actor(state_tensor, mask=None):                     # records the distribution the opponent samples from
+        out = orig_forward(state_tensor, mask)
+        seen["dist"] = out[0].detach().numpy().squeeze(0).copy()
+        return out
+
+    opponent.ac_net.forward_actor = forward_actor
+    orig_get = opponent.get_a_output
+    runner_ref = [None]
+
+    def get_a_output(state, valid_moves, action_selection="Distribution"):
+        a = orig_get(state, valid_moves, action_selection)
+        c = calls
+        c["state"].append(np.asarray(state).astype(np.int16))
+        c["mask"].append(np.packbits(valid_moves.numpy().reshape(180), bitorder="little"))
+        c["action"].append(int(a))
+        c["player"].append(int(runner_ref[0].game.current_player))
+        c["move_counter"].append(int(runner_ref[0].move_counter))
+        c["prob"].append(np.float32(seen["dist"][int(a)]))
+        c["dist"].append(seen["dist"].astype(np.float32))
+        return a
+
+    opponent.get_a_output = get_a_output
+    names, seeds = ["lid_randomfirst", "random_first1"], list(range(6))
+    blob["rulesets"] = np.array(names)
+    blob["seeds"] = np.array(seeds, dtype=np.uint64)
+    for name in names:
+        rules = RULESETS[name][0]
+        for s in seeds:
+            calls.clear()
+            random.seed(s)
+            np.random.seed(s)
+            runner = GameRunner(opponent=opponent, rules=dict(rules))
+            runner_ref[0] = runner
+            rows = collections.defaultdict(list)
+            for _ in range(2):
+                runner.reset()                                      # nn_runner.py:20
+                rows["episode_first_step"].append(len(rows["action"]))
+                rows["episode_calls_before"].append(len(calls["action"]))
+                done = False
+                while not done:
+                    mask = runner.get_valid_moves()
+                    obs = runner.get_state()
+                    a, dist, logd, value = agent.get_ac_output(obs, torch.from_numpy(mask.reshape(1, 180)))     # nn_runner.py:24-25
+                    reward, done = runner.step(a)                                                            # :26
+                    vm = torch.from_numpy(mask.reshape(1, 180))
+                    rows["obs"].append(obs.astype(np.int16))
+                    rows["mask"].append(np.packbits(mask, bitorder="little"))
+                    rows["action"].append(int(a))
+                    rows["value"].append(np.float32(value.item()))
+                    rows["log_prob"].append(np.float32(logd.squeeze(0)[a].item()))                          # :29
+                    rows["entropy"].append(np.float32((-logd.masked_select(vm).mean()).item()))            # :33-37
+                    rows["reward"].append(int(reward))
+                    rows["done"].append(bool(done))
+                    rows["move_counter"].append(int(runner.move_counter))
+                    rows["player_score"].append(int(runner.player_score))
+                    rows["calls_after"].append(len(calls["action"]))
+                rows["final_obs"].append(runner.get_state().astype(np.int16))
+                st = runner.game.get_statistics()
+                rows["stats"].append(np.array([float(st[k]) for k in
+                                               ["player_score", "opponent_score", "rounds", "percent_first_player", "floor_penalty",
+                                                "max_combo", "completed_rows", "completed_columns", "completed_colors", "win_percent"]]))
+            pre = "%s_s%d_" % (name, s)
+            for k, v in rows.items():
+                blob[pre + "step_" + k] = np.array(v)
+            for k, v in calls.items():
+                blob[pre + "call_" + k] = np.array(v if k != "dist" else v[:24])
+    np.savez_compressed(os.path.join(OUT, "net_opponent.npz"), **blob)
+    print("wrote net_opponent.npz")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     print("reference:", os.path.dirname(azulnet.__file__))
@@ -531,6 +621,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "players":
         gen_players()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "net_opponent":
+        gen_net_opponent()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "players_selfplay":
         gen_players_selfplay()
         return
@@ -541,6 +634,7 @@ def main():
     gen_a2c_update()
     gen_players()
     gen_players_selfplay()
+    gen_net_opponent()
 
 
 if __name__ == "__main__":

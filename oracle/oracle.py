@@ -69,6 +69,9 @@ class Runner(C.Structure):
                 ("player_score", C.c_int64), ("move_counter", C.c_int64)]
 
 
+# opponent.get_a_output(state, valid_moves) of game_runner.py:38-40 as a C callback (oz_runner_*_with)
+OPPONENT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_uint8))
+
 _lib = None
 
 
@@ -109,6 +112,9 @@ def lib():
         "oz_runner_opponent_move": (C.c_int, [P(Runner), P(Rng)]),
         "oz_runner_step": (C.c_int, [P(Runner), C.c_int, P(Rng), P(C.c_int64), P(C.c_int)]),
         "oz_potential": (C.c_int64, [P(Game)]),
+        "oz_runner_opponent_move_with": (C.c_int, [P(Runner), P(Rng), OPPONENT_FN, C.c_void_p]),
+        "oz_runner_reset_with": (C.c_int, [P(Runner), P(Rng), OPPONENT_FN, C.c_void_p]),
+        "oz_runner_step_with": (C.c_int, [P(Runner), C.c_int, P(Rng), OPPONENT_FN, C.c_void_p, P(C.c_int64), P(C.c_int)]),
         "oz_pack": (C.c_int, [P(Runner), u8p]),
         "oz_unpack": (None, [P(Runner), u8p, C.c_int, C.c_int]),
         "oz_pack_np": (C.c_int, [P(Game), u8p]),
@@ -232,6 +238,51 @@ def get_statistics(game):
     out = np.zeros(10, dtype=np.float64)
     lib().oz_get_statistics(C.byref(game), _p(out, C.c_double))
     return dict(zip(STAT_KEYS, out.tolist()))
+
+
+def opponent_callback(fn):
+    """Wrap `fn(state int64[136], mask bool[180]) -> action` (opponent.get_a_output, game_runner.py:38-40) for oz_runner_*_with."""
+    def thunk(_ctx, state_p, mask_p):
+        state = np.ctypeslib.as_array(state_p, shape=(136,)).copy()
+        mask = np.ctypeslib.as_array(mask_p, shape=(180,)).astype(bool)
+        return int(fn(state, mask))
+    return OPPONENT_FN(thunk)
+
+
+class NetRunner:
+    """GameRunner(opponent=<anything with get_a_output>) in the oracle (game_runner.py:27-30): `opponent(state, mask) -> action`."""
+
+    def __init__(self, opponent, first_player=FIRST_RANDOM, tile_pool=POOL_LID, seed=None, rec=None, mt=None, pos=None):
+        self.q, self.r = Runner(), Rng()
+        self._cb = opponent_callback(opponent)
+        if rec is not None:
+            self.q = unpack(rec, tile_pool, first_player)
+            lib().oz_rng_set(C.byref(self.r), np.ascontiguousarray(mt, np.uint32).ctypes.data_as(C.POINTER(C.c_uint32)), int(pos))
+        else:
+            lib().oz_rng_seed(C.byref(self.r), int(seed))
+            rc = lib().oz_runner_init(C.byref(self.q), first_player, tile_pool, C.byref(self.r))      # GameRunner.__init__
+            if rc:
+                raise RuntimeError("oz_runner_init -> %d" % rc)
+
+    def reset(self):
+        return lib().oz_runner_reset_with(C.byref(self.q), C.byref(self.r), self._cb, None)
+
+    def step(self, action):
+        rew, dn = C.c_int64(0), C.c_int(0)
+        rc = lib().oz_runner_step_with(C.byref(self.q), int(action), C.byref(self.r), self._cb, None, C.byref(rew), C.byref(dn))
+        return rc, int(rew.value), bool(dn.value)
+
+    def get_state(self, perspective=0):
+        return get_state(self.q.game, perspective)
+
+    def get_valid_moves(self):
+        return check_all_valid(self.q.game)
+
+    def record(self):
+        return pack(self.q)
+
+    def rng_state(self):
+        return np.ctypeslib.as_array(self.r.mt).copy(), int(self.r.idx)
 
 
 class Stream:

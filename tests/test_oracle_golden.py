@@ -216,3 +216,46 @@ def test_threaded_bench_is_deterministic():
     m1, c1 = oz.bench_selfplay(0, 16, 200, 1)
     m4, c4 = oz.bench_selfplay(0, 16, 200, 4)
     assert m1 == m4 == 16 * 200 and c1 == c4
+
+
+@pytest.mark.parametrize("ruleset", ["lid_randomfirst", "random_first1"])
+def test_game_runner_with_a_network_opponent_matches_reference(golden_dir, ruleset):
+    """GameRunner(opponent=Agent(...)) of the reference (game_runner.py:27-30, 37-47, 84-85; scripts/run_batch.py:6-10), recorded by
+    oracle/gen_golden.py gen_net_opponent: fed the opponent's recorded answers, the oracle must hand the opponent the recorded
+    perspective-rotated observation and mask at every call -- incl. player 1's forced moves and the opening moves of reset() -- and give
+    the agent the recorded observation, mask, reward, done, move_counter and player_score at every step."""
+    t = np.load(os.path.join(golden_dir, "net_opponent.npz"))
+    fp, pool = RULESETS[ruleset]
+    for seed in t["seeds"]:
+        pre = "%s_s%d_" % (ruleset, seed)
+        cs, cm, ca, cp = t[pre + "call_state"], np.unpackbits(t[pre + "call_mask"], axis=1, bitorder="little")[:, :180], t[pre + "call_action"], t[pre + "call_player"]
+        used = [0]
+
+        def opponent(state, mask):
+            i = used[0]
+            used[0] += 1
+            assert np.array_equal(state, cs[i]), (pre, i)
+            assert np.array_equal(mask, cm[i].astype(bool)), (pre, i)
+            assert int(run.q.game.current_player) == int(cp[i]) and int(run.q.move_counter) == int(t[pre + "call_move_counter"][i])
+            return int(ca[i])
+
+        run = oz.NetRunner(opponent, fp, pool, seed=int(seed))
+        sm = np.unpackbits(t[pre + "step_mask"], axis=1, bitorder="little")[:, :180].astype(bool)
+        first = list(t[pre + "step_episode_first_step"]) + [len(sm)]
+        for e in range(2):
+            assert run.reset() == 0
+            assert used[0] == int(t[pre + "step_episode_calls_before"][e])          # (recorded after reset(): the opening moves included)
+            for i in range(first[e], first[e + 1]):
+                assert np.array_equal(run.get_state(), t[pre + "step_obs"][i]), (pre, i)
+                assert np.array_equal(run.get_valid_moves(), sm[i]), (pre, i)
+                rc, rew, dn = run.step(int(t[pre + "step_action"][i]))
+                assert rc == 0 and rew == int(t[pre + "step_reward"][i]) and dn == bool(t[pre + "step_done"][i]), (pre, i)
+                assert int(run.q.move_counter) == int(t[pre + "step_move_counter"][i]) and int(run.q.player_score) == int(t[pre + "step_player_score"][i])
+                assert used[0] == int(t[pre + "step_calls_after"][i]), (pre, i)
+            assert np.array_equal(run.get_state(), t[pre + "step_final_obs"][e])
+            st = oz.get_statistics(run.q.game)
+            assert np.allclose([st[k] for k in oz.STAT_KEYS], t[pre + "step_stats"][e])
+        assert used[0] == len(ca)
+    # the fixture exercises what makes this path different from RandomAgent: forced moves of player 1 go to the opponent, and it opens
+    forced = sum(int((t["%s_s%d_call_player" % (ruleset, s)] == 1).sum()) for s in t["seeds"])
+    assert forced >= 4

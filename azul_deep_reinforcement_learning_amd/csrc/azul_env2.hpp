@@ -255,4 +255,105 @@ AZ_FN u32 agent_step2(G2 &g, i32 av, const Mask2 &m /* of the current state */, 
     return st;
 }
 
+// ---- GameRunner with an EXTERNAL opponent (game_runner.py:27-30: GameRunner(opponent=Agent(...)); scripts/run_batch.py:6-10) --------------
+// The reference's GameRunner.step / reset call opponent.get_a_output(...) in a data-dependent loop (game_runner.py:46-47, :84-85).  When the
+// opponent is a network the answer comes from OUTSIDE the rule code (the matrix phases of the rollout kernel, or a separate launch), so the
+// two methods are cut at their opponent_move() calls into a three-state protocol per game:
+//     NET_REPLY    inside GameRunner.step's loop (:46): the opponent moves while (current_player != 1 or player 1 has fewer than two legal
+//                  moves) and the game is not over -- player 1's FORCED moves are the opponent's too
+//     NET_OPENING  inside GameRunner.reset's loop (:84): the opponent moves while current_player != 1
+//     NET_READY    nothing owed: the agent's next decision
+// net_move2 plays the agent's action (:44-45) or one opponent_move() (:37-42) with the action somebody chose on the mask /
+// perspective-rotated observation net_settle2 left; net_settle2 runs the loop conditions, closes the step (:48-55: shaped reward, done,
+// statistics) and opens the next episode (nn_runner.py:20 -> game_runner.py:76-82) -- agent_step2's bookkeeping, statement for statement,
+// with the RandomAgent's draw replaced by "owed".  `m` is always the legal mask of the state left behind.
+enum : u32 { NET_READY = 0, NET_REPLY = 1, NET_OPENING = 2, NET_RESET = 3 /* internal: the next episode's game is due (never stored) */ };
+
+struct NetStep {
+    u32 pending;     // NET_*
+    u32 replies;     // opponent moves played since the agent's action (opening moves of the next episode included)
+    i32 rew;         // valid once `closed`
+    u32 dn;
+    bool closed;     // the agent step's reward / done are final
+    u32 st;          // first status that was not ST_OK
+};
+
+// The loop conditions.  Leaves ns.pending = NET_REPLY / NET_OPENING (an opponent_move() is owed on the state and mask left behind) or
+// NET_READY.  ONE site each for the episode reset and the legal mask: the rollout kernel inlines this function once.
+template <bool LID>
+AZ_FN void net_settle2(G2 &g, NetStep &ns, Mask2 &m, u32 first_player, Rng2 &r, u64 margin, Counters2 &cnt, const K2 &k)
+{
+#pragma unroll 1
+    for (u32 pass = 0; pass < 4u; pass++) {
+        if (ns.pending == NET_RESET) {                                          // the next run_episode: nn_runner.py:20 -> game_runner.py:76-82
+            const u32 st2 = reset2<LID>(g, first_player, r, margin, k);
+            if (!ns.st) ns.st = st2;
+            ns.pending = st2 ? (u32)NET_READY : (u32)NET_OPENING;
+            continue;
+        }
+        legal_mask2(g, k, m);
+        if (ns.pending == NET_READY) break;
+        const u32 legal = mask_count2(m);
+        if (ns.pending == NET_REPLY) {
+            const bool keep = (g.cur != 1u || legal < 2u) && !g.over;          // game_runner.py:46
+            if (keep && legal) break;                                           // :47 -- an opponent_move() is owed
+            ns.closed = true;
+            if (keep) {                                                         // nobody can move (hazard H3; an Agent raises IllegalMask, model.py:33-34)
+                cnt.stuck_add += 1u; ns.dn = 2u; ns.rew = 0;
+                if (!ns.st) ns.st = ST_STUCK;
+            } else {
+                const i32 phi = g.wi0 - g.wi1;                                 // :48-50 (the what-if caches are current)
+                ns.rew = phi - g.pscore;                                       // :51
+                g.pscore = phi;                                                // :52
+                ns.dn = g.over ? 1u : 0u;                                      // :55
+                if (ns.dn) episode_stats2(g, cnt, k.l);                        // :53-54
+            }
+            ns.pending = ns.dn ? (u32)NET_RESET : (u32)NET_READY;
+            if (!ns.dn) break;                                                  // (`m` is the mask of this state: the agent's next decision)
+        } else {                                                                // NET_OPENING
+            if (g.cur != 1u && legal) break;                                    // game_runner.py:84-85 -- an opponent_move() is owed
+            if (g.cur != 1u && !ns.st) ns.st = ST_STUCK;
+            ns.pending = NET_READY;
+            break;
+        }
+    }
+}
+
+// One move of the protocol: the AGENT's action of GameRunner.step (game_runner.py:44-45; `agent`) or one opponent_move() (:37-42) of a game
+// that owes one, then the loop conditions.  `m`: in, the legal mask of the current state; out, of the state left behind.
+// An opponent's answer that is not a legal action leaves the game and the debt as they are (the reference lets IllegalMove escape from
+// GameRunner.step); refused / failed agent moves follow agent_step2's bookkeeping.
+template <bool LID>
+AZ_FN void net_move2(G2 &g, i32 av, bool agent, Mask2 &m, u32 first_player, Rng2 &r, u64 margin, Counters2 &cnt, const K2 &k, NetStep &ns)
+{
+    if (agent) { ns.pending = NET_READY; ns.replies = 0; ns.rew = 0; ns.dn = g.over ? 1u : 0u; ns.closed = false; ns.st = ST_OK; }
+    const u32 st = checked_step2<LID>(g, av, m, r, margin, k);                 // :44 / :41
+    if (st == ST_OK) {
+        g.moves += 1u;                                                          // :45 / :42
+        if (agent) ns.pending = NET_REPLY; else ns.replies += 1u;
+    } else {
+        if (!ns.st) ns.st = st;
+        if (st == ST_ILLEGAL_MOVE || st == ST_BAD_ACTION) {                     // state untouched
+            if (agent) ns.closed = true;
+            return;
+        }
+        const bool in_step = agent || ns.pending == NET_REPLY;                  // (runner_step2 returning a status: reward 0, done only for GAME_ENDED)
+        ns.pending = NET_READY;
+        if (in_step) {
+            ns.closed = true; ns.rew = 0;
+            ns.dn = st == ST_GAME_ENDED ? 1u : (agent ? ns.dn : 0u);
+            if (ns.dn) ns.pending = NET_RESET;
+        }
+    }
+    net_settle2<LID>(g, ns, m, first_player, r, margin, cnt, k);
+}
+
+// GameRunner.reset() with an external opponent (game_runner.py:76-85): the fresh game, then the opening loop's condition
+template <bool LID>
+AZ_FN void net_reset2(G2 &g, Mask2 &m, u32 first_player, Rng2 &r, u64 margin, Counters2 &cnt, const K2 &k, NetStep &ns)
+{
+    ns.pending = NET_RESET; ns.replies = 0; ns.rew = 0; ns.dn = 0; ns.closed = false; ns.st = ST_OK;
+    net_settle2<LID>(g, ns, m, first_player, r, margin, cnt, k);
+}
+
 } // namespace az2

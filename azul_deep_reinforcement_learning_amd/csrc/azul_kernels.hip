@@ -585,6 +585,40 @@ int azul_batch_agent_step(azul_batch_t *b, const int32_t *actions_dev, const uin
     return launch_op(b, a, stream);
 }
 
+// GameRunner.step / reset with an EXTERNAL opponent, cut at their opponent_move() calls (azul_env2.hpp: NET_*)
+static int net_op(azul_batch_t *b, int op, const int32_t *actions_dev, const uint8_t *active_dev, uint8_t *pending_dev, uint8_t *replies_dev,
+                  int32_t *reward_dev, uint8_t *done_dev, uint8_t *status_dev, float *obs_opp_dev, uint8_t *mask_opp_dev, uint32_t *owing_dev, void *stream)
+{
+    if (!b || !pending_dev || (op != OP_NET_RESET && !actions_dev)) return fail(AZUL_ERR_INVALID, "azul_batch_net_*: bad arguments");
+    OpArgs a = op_args(op);
+    a.actions = actions_dev; a.active = active_dev; a.pending = pending_dev; a.replies = replies_dev; a.reward = reward_dev; a.done = done_dev;
+    a.status = status_dev; a.obs = obs_opp_dev; a.mask = mask_opp_dev; a.persp = AZUL_PERSP_CURRENT; a.owing = owing_dev;
+    if (b->x) return fail(AZUL_ERR_INVALID, "azul_batch_net_*: GameRunner is two-player (game_runner.py:50)");
+    if (owing_dev) HIP_TRY(hipMemsetAsync(owing_dev, 0, sizeof(uint32_t), (hipStream_t)stream));
+    return launch_op(b, a, stream);
+}
+
+int azul_batch_net_step_begin(azul_batch_t *b, const int32_t *actions_dev, uint8_t *pending_dev, uint8_t *replies_dev, int32_t *reward_dev,
+                              uint8_t *done_dev, uint8_t *status_dev, float *obs_opp_dev, uint8_t *mask_opp_dev, uint32_t *owing_dev, void *stream)
+{
+    BATCH_GUARD(b, stream);
+    return net_op(b, OP_NET_BEGIN, actions_dev, nullptr, pending_dev, replies_dev, reward_dev, done_dev, status_dev, obs_opp_dev, mask_opp_dev, owing_dev, stream);
+}
+
+int azul_batch_net_step_reply(azul_batch_t *b, const int32_t *opp_actions_dev, uint8_t *pending_dev, uint8_t *replies_dev, int32_t *reward_dev,
+                              uint8_t *done_dev, uint8_t *status_dev, float *obs_opp_dev, uint8_t *mask_opp_dev, uint32_t *owing_dev, void *stream)
+{
+    BATCH_GUARD(b, stream);
+    return net_op(b, OP_NET_REPLY, opp_actions_dev, nullptr, pending_dev, replies_dev, reward_dev, done_dev, status_dev, obs_opp_dev, mask_opp_dev, owing_dev, stream);
+}
+
+int azul_batch_net_reset_begin(azul_batch_t *b, const uint8_t *active_dev, uint8_t *pending_dev, uint8_t *status_dev, float *obs_opp_dev,
+                               uint8_t *mask_opp_dev, uint32_t *owing_dev, void *stream)
+{
+    BATCH_GUARD(b, stream);
+    return net_op(b, OP_NET_RESET, nullptr, active_dev, pending_dev, nullptr, nullptr, nullptr, status_dev, obs_opp_dev, mask_opp_dev, owing_dev, stream);
+}
+
 int azul_batch_observe_all(azul_batch_t *b, int perspective, float *obs_dev, uint8_t *mask_dev, uint8_t *player_dev, void *stream)
 {
     BATCH_GUARD(b, stream);
@@ -653,6 +687,24 @@ int azul_policy_forward(const float *obs_dev, const uint8_t *mask_dev, const flo
     return AZUL_SUCCESS;
 }
 
+static int launch_rollout(azul_batch_t *b, const PolicyWeights &W, const RolloutArgs &a, int opp, void *stream)
+{
+    const hipStream_t st = (hipStream_t)stream;
+    const bool lid = b->d.rules.tile_pool == POOL_LID;
+    const dim3 grid2((b->d.n + PF_GAMES - 1) / PF_GAMES), block2(64 * PR2_WAVES);
+    if (lid) {
+        if (opp == 2) hipLaunchKernelGGL((azul_policy_rollout2_kernel<true, 2>), grid2, block2, 0, st, b->d, W, a);
+        else if (opp == 1) hipLaunchKernelGGL((azul_policy_rollout2_kernel<true, 1>), grid2, block2, 0, st, b->d, W, a);
+        else hipLaunchKernelGGL((azul_policy_rollout2_kernel<true, 0>), grid2, block2, 0, st, b->d, W, a);
+    } else {
+        if (opp == 2) hipLaunchKernelGGL((azul_policy_rollout2_kernel<false, 2>), grid2, block2, 0, st, b->d, W, a);
+        else if (opp == 1) hipLaunchKernelGGL((azul_policy_rollout2_kernel<false, 1>), grid2, block2, 0, st, b->d, W, a);
+        else hipLaunchKernelGGL((azul_policy_rollout2_kernel<false, 0>), grid2, block2, 0, st, b->d, W, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return AZUL_SUCCESS;
+}
+
 int azul_batch_policy_rollout(azul_batch_t *b, int n_steps, int opponent_random, const float *w1t_dev, const float *b1_dev,
                               const float *w2c_dev, const float *b2c_dev, const float *w2a_t_dev, const float *b2a_dev, int num_inputs,
                               int hidden_size, int num_actions, uint64_t seed, uint64_t counter, uint64_t *counter_dev, float *obs_dev,
@@ -686,17 +738,40 @@ int azul_batch_policy_rollout_returns(azul_batch_t *b, int n_steps, int opponent
     PolicyWeights W = {w1t_dev, b1_dev, w2c_dev, b2c_dev, w2a_t_dev, b2a_dev};
     RolloutArgs a = {n_steps, obs_dev, mask_dev, player_dev, action_dev, reward_dev, done_dev, value_dev, logp_dev, entropy_dev, status_dev,
                      returns_dev, gamma, (u64)seed, (u64)counter, (u64 *)counter_dev};
-    const hipStream_t st = (hipStream_t)stream;
-    const bool lid = b->d.rules.tile_pool == POOL_LID;
-    const dim3 grid2((b->d.n + PF_GAMES - 1) / PF_GAMES), block2(64 * PR2_WAVES);
-    if (lid && opponent_random) hipLaunchKernelGGL((azul_policy_rollout2_kernel<true, true>), grid2, block2, 0, st, b->d, W, a);
-    else if (lid) hipLaunchKernelGGL((azul_policy_rollout2_kernel<true, false>), grid2, block2, 0, st, b->d, W, a);
-    else if (opponent_random) hipLaunchKernelGGL((azul_policy_rollout2_kernel<false, true>), grid2, block2, 0, st, b->d, W, a);
-    else hipLaunchKernelGGL((azul_policy_rollout2_kernel<false, false>), grid2, block2, 0, st, b->d, W, a);
-    HIP_TRY(hipGetLastError());
-    if (returns_dev && n_steps > 32)       // the kernel keeps a window's rewards in 32 lanes: longer windows get the separate scan
+    int rc = launch_rollout(b, W, a, opponent_random ? 1 : 0, stream);
+    if (rc == AZUL_SUCCESS && returns_dev && n_steps > 32)       // the kernel keeps a window's rewards in 32 lanes: longer windows get the separate scan
         return azul_discounted_returns(reward_dev, done_dev, returns_dev, nullptr, gamma, n_steps, (int)b->d.n, stream);
-    return AZUL_SUCCESS;
+    return rc;
+}
+
+/* GameRunner(opponent=Agent(...)) inside the persistent rollout (game_runner.py:27-30, 37-47, 84-85; scripts/run_batch.py:6-10) */
+int azul_batch_policy_rollout_vs(azul_batch_t *b, int n_steps, const azul_net_weights_t *agent, const azul_net_weights_t *opponent, int num_inputs,
+                                 int hidden_size, int num_actions, uint64_t seed, uint64_t opponent_seed, uint64_t counter, uint64_t *counter_dev,
+                                 const azul_rollout_buffers_t *out, float gamma, void *stream)
+{
+    BATCH_GUARD(b, stream);
+    if (!b || n_steps < 0 || !agent || !opponent || !out) return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout_vs: bad arguments");
+    if (b->x) return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout_vs: the policy entries are compiled for the reference's two-player game");
+    if (num_inputs != PF_IN || hidden_size != PF_HID || num_actions != PF_ACT)
+        return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout_vs: only ActorCritic(136, 180, hidden 180) is compiled in");
+    if (!agent->w1t || !agent->b1 || !agent->w2c || !agent->b2c || !agent->w2a_t || !agent->b2a || !opponent->w1t || !opponent->b1 || !opponent->w2a_t ||
+        !opponent->b2a || !out->obs || !out->mask || !out->player || !out->action || !out->reward || !out->done || !out->value || !out->logp || !out->entropy)
+        return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout_vs: NULL pointer");
+    if (((uintptr_t)agent->w1t & 15u) != 0 || ((uintptr_t)opponent->w1t & 15u) != 0 || ((uintptr_t)agent->w2a_t & 7u) != 0 || ((uintptr_t)opponent->w2a_t & 7u) != 0)
+        return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout_vs: w1t must be 16-byte aligned, w2a_t 8-byte aligned");
+    if (((uintptr_t)out->obs & 15u) != 0 || ((uintptr_t)out->mask & 3u) != 0)
+        return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout_vs: obs must be 16-byte aligned, mask 4-byte aligned");
+    if ((out->opp_action || out->opp_logp) && out->opp_slots <= 0) return fail(AZUL_ERR_INVALID, "azul_batch_policy_rollout_vs: opp_slots must be positive with a trace");
+    PolicyWeights W = {agent->w1t, agent->b1, agent->w2c, agent->b2c, agent->w2a_t, agent->b2a};
+    RolloutArgs a = {n_steps, out->obs, out->mask, out->player, out->action, out->reward, out->done, out->value, out->logp, out->entropy, out->status,
+                     out->returns, gamma, (u64)seed, (u64)counter, (u64 *)counter_dev};
+    a.Wopp = {opponent->w1t, opponent->b1, opponent->w2c, opponent->b2c, opponent->w2a_t, opponent->b2a};
+    a.opp_seed = (u64)opponent_seed;
+    a.opp_action = out->opp_action; a.opp_logp = out->opp_logp; a.opp_replies = out->opp_replies; a.opp_slots = out->opp_slots;
+    int rc = launch_rollout(b, W, a, 2, stream);
+    if (rc == AZUL_SUCCESS && out->returns && n_steps > 32)
+        return azul_discounted_returns(out->reward, out->done, out->returns, nullptr, gamma, n_steps, (int)b->d.n, stream);
+    return rc;
 }
 
 int azul_a2c_gradients(const float *obs_dev, const uint8_t *mask_dev, const int32_t *action_dev, const float *qvals_dev, int n_samples,

@@ -27,7 +27,8 @@ struct BatchDev {
 
 enum {
     OP_QUERY = 0, OP_INIT, OP_NEW_ROUND, OP_MOVE, OP_NEXT_PLAYER, OP_COUNT_SCORE, OP_STEP,
-    OP_RUNNER_INIT, OP_RUNNER_RESET, OP_RUNNER_STEP, OP_RANDOM_ACTION, OP_SAMPLE_MASK, OP_POLICY_STEP, OP_AGENT_STEP
+    OP_RUNNER_INIT, OP_RUNNER_RESET, OP_RUNNER_STEP, OP_RANDOM_ACTION, OP_SAMPLE_MASK, OP_POLICY_STEP, OP_AGENT_STEP,
+    OP_NET_BEGIN, OP_NET_REPLY, OP_NET_RESET      // GameRunner.step / reset with an EXTERNAL opponent, cut at opponent_move() (azul_env2.hpp: NET_*)
 };
 
 struct OpArgs {
@@ -51,6 +52,9 @@ struct OpArgs {
     u32 *pos_out;            // [count] out: index of the game's MT19937 stream after the op
     i32 *next_action;        // [count] out: RandomAgent's choice on the state after the op, drawn at the stream's index after the op WITHOUT moving it
                              //         (-1: nothing legal, -2: not available -- the op failed / did not draw, or the draw would cross a regeneration)
+    uint8_t *pending;        // [count] in / out (OP_NET_*): NET_READY / NET_REPLY / NET_OPENING -- does the game owe an opponent_move()?
+    uint8_t *replies;        // [count] in / out, optional (OP_NET_*): opponent moves played since the agent's action
+    u32 *owing;              // [1] optional (OP_NET_*): += the games of this launch that still owe an opponent_move()
     u32 pos_set;             // 0, or 1 + the stream index to install before the op (single-game calls: the host's index is the authority)
     u32 first, count;        // the launch covers games first .. first + count - 1; row i of the arrays above belongs to game first + i
 };
@@ -58,7 +62,8 @@ struct OpArgs {
 AZ_FN bool op_needs_rng(int op)
 {
     return op == OP_INIT || op == OP_NEW_ROUND || op == OP_STEP || op == OP_RUNNER_INIT || op == OP_RUNNER_RESET ||
-           op == OP_RUNNER_STEP || op == OP_RANDOM_ACTION || op == OP_SAMPLE_MASK || op == OP_POLICY_STEP || op == OP_AGENT_STEP;
+           op == OP_RUNNER_STEP || op == OP_RANDOM_ACTION || op == OP_SAMPLE_MASK || op == OP_POLICY_STEP || op == OP_AGENT_STEP ||
+           op == OP_NET_BEGIN || op == OP_NET_REPLY || op == OP_NET_RESET;
 }
 
 constexpr u32 OP2_OBS_STRIDE = 144;      // floats per half of the observation staging row (136 used)
@@ -95,7 +100,8 @@ AZ_FN void op_body2(const BatchDev &b, const OpArgs &a, u32 pair, u32 (*mt_lds)[
         if (use_rng) rng2_open(r, gmt, mt_lds[half], a.pos_set ? a.pos_set - 1u : b.mtpos[gi], l);      // (move / next_player / count_score never draw: no 2.5 KB staging)
         else { r.lds = mt_lds[half]; r.tlds = nullptr; r.pos = 0; r.dirty = 0; r.wbase = 0; r.wend = 0; r.win = 0; }
         Counters2 cnt;
-        const bool counts = a.op == OP_RUNNER_STEP || a.op == OP_POLICY_STEP || a.op == OP_AGENT_STEP;
+        const bool net = a.op == OP_NET_BEGIN || a.op == OP_NET_REPLY || a.op == OP_NET_RESET;
+        const bool counts = a.op == OP_RUNNER_STEP || a.op == OP_POLICY_STEP || a.op == OP_AGENT_STEP || net;
         if (counts) counters2_open(cnt, b.episodes + gi, b.stuck + gi, b.stat_sum + (size_t)gi * 10, l);
         bool dirty_state = true;
         i32 rew = 0;
@@ -150,6 +156,35 @@ AZ_FN void op_body2(const BatchDev &b, const OpArgs &a, u32 pair, u32 (*mt_lds)[
             legal_mask2(g, k, m);
             st = agent_step2<LID>(g, a.actions[oi], m, fp, r, tab, margin, cnt, k, rew, dn);
             dirty_state = !(st == ST_ILLEGAL_MOVE || st == ST_BAD_ACTION);
+        } break;
+        case OP_NET_BEGIN:
+        case OP_NET_REPLY:
+        case OP_NET_RESET: {
+            // GameRunner.step / reset with an external opponent (game_runner.py:27-30, 37-47, 84-85), one launch per cut: the agent's move,
+            // or one opponent_move() of the games that owe one, or the fresh game -- then the loop condition (azul_env2.hpp: net_settle2)
+            Mask2 m;
+            NetStep ns;
+            if (a.op == OP_NET_RESET) {
+                net_reset2<LID>(g, m, fp, r, margin, cnt, k, ns);
+            } else {
+                const bool agent = a.op == OP_NET_BEGIN;
+                ns.pending = agent ? (u32)NET_READY : (u32)a.pending[oi];
+                ns.replies = a.replies ? a.replies[oi] : 0u; ns.rew = 0; ns.dn = 0; ns.closed = false;
+                ns.st = a.status ? a.status[oi] : 0u;                   // the step's status is its FIRST status that was not OK
+                dirty_state = agent || ns.pending != NET_READY;
+                if (dirty_state) {
+                    legal_mask2(g, k, m);
+                    net_move2<LID>(g, a.actions[oi], agent, m, fp, r, margin, cnt, k, ns);
+                }
+            }
+            st = ns.st;
+            if (l == 0u) {
+                a.pending[oi] = (uint8_t)ns.pending;
+                if (a.replies) a.replies[oi] = (uint8_t)(ns.replies < 255u ? ns.replies : 255u);
+                if (ns.closed && a.reward) a.reward[oi] = ns.rew;       // the agent step's reward / done: written by the launch that closes it
+                if (ns.closed && a.done) a.done[oi] = (uint8_t)ns.dn;
+                if (ns.pending != NET_READY && a.owing) atomicAdd(a.owing, 1u);
+            }
         } break;
         case OP_RANDOM_ACTION: {
             Mask2 m;

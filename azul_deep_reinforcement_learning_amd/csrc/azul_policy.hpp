@@ -142,9 +142,9 @@ __device__ __forceinline__ void policy_head_rows(const float (&x)[HEAD_PER_LANE]
     if (lds_action && c == 0u) lds_action[grp] = chosen;
     if (store && c == 0u) {
         const float zsel = row[chosen < 0 ? 0 : chosen] - m;                         // log-softmax numerator of the chosen action
-        action[g] = chosen;
-        logp[g] = cnt == 0u ? 0.f : zsel - logS;
-        entropy[g] = cnt == 0u ? 0.f : ent;
+        if (action) action[g] = chosen;
+        if (logp) logp[g] = cnt == 0u ? 0.f : zsel - logS;
+        if (entropy) entropy[g] = cnt == 0u ? 0.f : ent;
     }
 }
 
@@ -387,4 +387,11 @@ struct RolloutArgs {
     float gamma;
     u64 seed, counter;
     u64 *counter_dev;    // optional [2]: [0] added to `counter`, advanced by n_steps; [1] completion ticket
+    // ---- network opponent (azul_policy_rollout2_kernel<LID, 2>; game_runner.py:27-30 GameRunner(opponent=Agent(...))) ----
+    PolicyWeights Wopp;  // the opponent's net in the same layouts (only forward_actor's half is read: w1t columns 180..359, b1[180..359], w2a_t, b2a)
+    u64 opp_seed;        // reply j of a step samples with Philox key opp_seed + j (AZUL_POLICY_ARGMAX: action_selection "Max", agent.py:79-80)
+    i32 *opp_action;     // optional [T][opp_slots][N]: the opponent's answers in the order they were played (slots beyond a step's replies untouched)
+    float *opp_logp;     // optional [T][opp_slots][N]: log-probability of each answer under the opponent's masked softmax
+    uint8_t *opp_replies;// optional [T][N]: opponent moves played inside the step (the next episode's opening moves included)
+    int opp_slots;
 };

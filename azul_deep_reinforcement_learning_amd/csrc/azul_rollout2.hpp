@@ -129,7 +129,52 @@ __device__ __forceinline__ void pr2_layer2(const __amdgpu_buffer_rsrc_t rs2, u32
     if (NT == 2 && draw) u_out = (float)(c0 >> 8) * (1.0f / 16777216.0f);
 }
 
-template <bool LID, bool OPP>
+
+// ---- network opponent (OPP == 2; game_runner.py:27-30 GameRunner(opponent=Agent(...))) ---------------------------------------------------
+// The opponent only ever runs forward_actor (agent.py:73-81 -> model.py:28-41): layer 1 is the ACTOR half alone, 180 hidden columns
+// (columns 180..359 of its k-major w1t), spread over the eight waves like layer 2's 180 logits -- waves 0..3 a column pair per lane
+// (32w + 2c + j, one 8-byte load per k-step), waves 4..7 one column (128 + 16 (w - 4) + c): three 16x16 tiles per SIMD, 136-deep.  Each
+// hidden unit is the same k-ordered v_mfma_f32_16x16x4_f32 chain as in azul_policy_forward_kernel, so a reply equals the per-move path's.
+constexpr int PR2_HOISTO = 4;
+constexpr u32 NET_MAX_REPLIES = 64;   // an opponent_move() takes tiles off the table: a chain of replies ends with the round (<= 21 moves)
+#define PR2_LOADO(NT_, s) ((NT_) == 2 ? __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rso, voff, (4 * (s)) * PF_H2 * 4, 0)) \
+                                      : make_float2(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rso, voff, (4 * (s)) * PF_H2 * 4, 0)), 0.f))
+
+__device__ __forceinline__ void pr2_request_opp1(bool two, const __amdgpu_buffer_rsrc_t rso, u32 voff, float2 (&pre)[PR2_HOISTO])
+{
+    if (two) {
+#pragma unroll
+        for (int s = 0; s < PR2_HOISTO; s++) pre[s] = PR2_LOADO(2, s);
+    } else {
+#pragma unroll
+        for (int s = 0; s < PR2_HOISTO; s++) pre[s] = PR2_LOADO(1, s);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void pr2_opp_layer1(const __amdgpu_buffer_rsrc_t rso, u32 voff, const float *ap, const float2 (&pre)[PR2_HOISTO], pf_f32x4 &acc0,
+                                               pf_f32x4 &acc1)
+{
+    float2 bw[PF_IN / 4];
+#pragma unroll
+    for (int s = 0; s < PR2_HOISTO; s++) bw[s] = pre[s];
+    float af[PF_IN / 4];
+#pragma unroll
+    for (int s = 0; s < PR2_ADEPTH; s++) af[s] = ap[4 * s];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < PF_IN / 4; s++) {
+        if (s + PR2_HOISTO < PF_IN / 4) bw[s + PR2_HOISTO] = PR2_LOADO(NT, s + PR2_HOISTO);
+        if (s + PR2_ADEPTH < PF_IN / 4) af[s + PR2_ADEPTH] = ap[4 * (s + PR2_ADEPTH)];
+        const float av = af[s];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].x, acc0, 0, 0, 0);
+        if (NT == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[s].y, acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// OPP: 0 the policy moves for both players, 1 GameRunner with the RandomAgent opponent, 2 GameRunner with a NETWORK opponent (a.Wopp)
+template <bool LID, int OPP>
 __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(BatchDev b, PolicyWeights W, RolloutArgs a)
 {
     __shared__ float obsS[PF_GAMES * PF_OBS_STRIDE];
@@ -141,6 +186,8 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     __shared__ double2 tabfs_lds[T_ROWS * T_BINADES];
     __shared__ u64 maskS[PF_GAMES][4];
     __shared__ i32 actS[PF_GAMES];
+    __shared__ float b1oS[OPP == 2 ? PF_HID + 12 : 1], b2aoS[OPP == 2 ? PF_ACT + 12 : 1];      // the opponent's actor biases
+    __shared__ u32 oweS[PF_GAMES];                       // OPP == 2: does game i of the workgroup owe an opponent_move()?
     const u32 tid = threadIdx.x, lane = tid & 63u, l = lane & 31u, half = lane >> 5, c = lane & 15u, q = (lane >> 4) & 3u;
     const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const u32 n = b.n, g0 = blockIdx.x * PF_GAMES, gl = 2u * w + half, gi = g0 + gl;
@@ -151,8 +198,13 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     if (tid < (u32)PF_HID) w2cS[tid] = W.w2c[tid];
     if (tid < (u32)(PF_H2 + 24)) b1S[tid] = tid < (u32)PF_H2 ? W.b1[tid] : 0.f;
     if (tid < (u32)(PF_ACT + 12)) b2aS[tid] = tid < (u32)PF_ACT ? W.b2a[tid] : 0.f;
-    if (OPP) {
+    if (OPP == 1) {
         for (u32 i = tid; i < (u32)(T_ROWS * T_BINADES); i += 64u * PR2_WAVES) tabfs_lds[i] = b.tab[i];
+    }
+    if (OPP == 2) {
+        if (tid < (u32)(PF_HID + 12)) b1oS[tid] = tid < (u32)PF_HID ? a.Wopp.b1[PF_HID + tid] : 0.f;
+        if (tid < (u32)(PF_ACT + 12)) b2aoS[tid] = tid < (u32)PF_ACT ? a.Wopp.b2a[tid] : 0.f;
+        if (tid < (u32)PF_GAMES) oweS[tid] = 0u;
     }
     const float b2c_v = W.b2c[0];
 
@@ -188,15 +240,19 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     // The env phase only writes LDS (observation row, packed mask bits) + the player byte; the trajectory slot's 544-byte observation and
     // 180-byte mask of every game are copied out of LDS by flush() below, on waves that idle during the head phase: eleven vector
     // stores per game pair leave the env phase, which every other phase of the move waits for.
-    auto publish = [&](u32 slot) {
-        az2::legal_mask2(g, k, m);
+    // (publish_rows: the mask `m` already holds, seen from `persp`)
+    auto publish_rows = [&](u32 persp) {
         if (l == 0u) {                                   // the 180 bits packed: the six 30-bit row words concatenated
             maskS[gl][0] = (u64)m.m[0] | ((u64)m.m[1] << 30) | ((u64)m.m[2] << 60);
             maskS[gl][1] = ((u64)m.m[2] >> 4) | ((u64)m.m[3] << 26) | ((u64)m.m[4] << 56);
             maskS[gl][2] = ((u64)m.m[4] >> 8) | ((u64)m.m[5] << 22);
-            a.player[(size_t)slot * n + gi] = (uint8_t)g.cur;
         }
-        az2::observe2(g, OPP ? 0u : az2::me2(g), orow, nullptr, l);
+        az2::observe2(g, persp, orow, nullptr, l);
+    };
+    auto publish = [&](u32 slot, bool mask_current) {
+        if (!mask_current) az2::legal_mask2(g, k, m);
+        if (l == 0u) a.player[(size_t)slot * n + gi] = (uint8_t)g.cur;
+        publish_rows(OPP ? 0u : az2::me2(g));
     };
     // trajectory slot `slot` of the workgroup's 16 games <- the LDS rows: the 16 x 136 floats are contiguous in the [T+1][N][136]
     // array (16-byte chunks), the 16 x 180 mask bytes in [T+1][N][180] (dwords: four bits of the packed mask spread into four bytes).
@@ -221,7 +277,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
             }
         }
     };
-    if (live) publish(0u);
+    if (live) publish(0u, false);
     else {
         orow[l] = 0.f; orow[l + 32u] = 0.f; orow[l + 64u] = 0.f; orow[l + 96u] = 0.f;
         if (l < 8u) orow[l + 128u] = 0.f;
@@ -235,6 +291,13 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     const u32 voff2 = ((PR2_L2COL0 < (u32)PF_ACT ? PR2_L2COL0 : 0u) + q * (u32)PF_ACT) * 4u;
     float2 preA[PR2_HOIST1], preB[PR2_HOIST1], pre2[PR2_HOIST2];
     pr2_request1(two, rs1, voffA, voffB, preA, preB);
+    // the opponent's matrices (OPP == 2): the actor half of its layer 1 and its layer 2, both in layer 2's column mapping
+    const __amdgpu_buffer_rsrc_t rso1 = __builtin_amdgcn_make_buffer_rsrc((void *)(OPP == 2 ? a.Wopp.w1t : W.w1t), 0, PF_IN * PF_H2 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rso2 = __builtin_amdgcn_make_buffer_rsrc((void *)(OPP == 2 ? a.Wopp.w2a_t : W.w2a_t), 0, PF_HID * PF_ACT * 4, 0x00020000);
+    const u32 voffo1 = ((u32)PF_HID + (PR2_L2COL0 < (u32)PF_HID ? PR2_L2COL0 : 0u) + q * (u32)PF_H2) * 4u;
+    float2 preo[PR2_HOISTO];
+    az2::NetStep ns;
+    ns.pending = az2::NET_READY; ns.replies = 0; ns.rew = 0; ns.dn = 0; ns.closed = false; ns.st = ST_OK;
 #if defined(AZ_PROFILE_SEGMENTS)
     u64 pr_acc[6] = {0, 0, 0, 0, 0, 0}, pr_last = __builtin_amdgcn_s_memtime();
     const u64 pr_t0 = pr_last, pr_r0 = __builtin_amdgcn_s_memrealtime();
@@ -322,17 +385,101 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
         }
         lds_barrier();
         PR2_STAMP(4);                                    // head (incl. barrier)
-        pr2_request1(two, rs1, voffA, voffB, preA, preB);        // the next move's layer 1: in flight during the env step
-        if (live) {
-            const i32 av = actS[gl];
-            i32 rew = 0;
-            u32 dn = 0;
-            st_last = OPP ? az2::agent_step2<LID>(g, av, m, b.rules.first_player, r, tab, margin, cnt, k, rew, dn)
-                          : az2::policy_step2<LID>(g, av, m, b.rules.first_player, r, margin, cnt, k, rew, dn);
-            if (l == 0u) { a.reward[row_t + gi] = rew; a.done[row_t + gi] = (uint8_t)dn; }
-            win_rew = l == ((u32)t & 31u) ? rew : win_rew;           // lane t of the half keeps step t (the returns scan below)
-            win_done = l == ((u32)t & 31u) ? dn : win_done;
-            publish((u32)t + 1u);
+        if constexpr (OPP != 2) {
+            pr2_request1(two, rs1, voffA, voffB, preA, preB);    // the next move's layer 1: in flight during the env step
+            if (live) {
+                const i32 av = actS[gl];
+                i32 rew = 0;
+                u32 dn = 0;
+                if constexpr (OPP == 1) st_last = az2::agent_step2<LID>(g, av, m, b.rules.first_player, r, tab, margin, cnt, k, rew, dn);
+                else st_last = az2::policy_step2<LID>(g, av, m, b.rules.first_player, r, margin, cnt, k, rew, dn);
+                if (l == 0u) { a.reward[row_t + gi] = rew; a.done[row_t + gi] = (uint8_t)dn; }
+                win_rew = l == ((u32)t & 31u) ? rew : win_rew;       // lane t of the half keeps step t (the returns scan below)
+                win_done = l == ((u32)t & 31u) ? dn : win_done;
+                publish((u32)t + 1u, false);
+            }
+        } else {
+            // GameRunner.step against the NETWORK opponent (game_runner.py:43-55 with :37-42 answered by a.Wopp): the agent's move, then
+            // matrix phases on the opponent's weights WHILE ANY of the workgroup's 16 games owes an opponent_move() -- its own replies and
+            // player 1's forced moves (:46), after an episode end the opening moves of the next (:84) -- the other games sit masked
+            // ONE env site per pass: pass 0 plays the agent's action, pass j > 0 reply j - 1 of the games that owed it
+#pragma unroll 1
+            for (u32 j = 0;; j++) {
+                pr2_request_opp1(two, rso1, voffo1, preo);       // (almost every step has a reply: requested ahead like layer 1; speculative after that)
+                if (live && (j == 0u || ns.pending != az2::NET_READY)) {
+                    az2::net_move2<LID>(g, actS[gl], j == 0u, m, b.rules.first_player, r, margin, cnt, k, ns);
+                    if (ns.pending != az2::NET_READY) publish_rows(az2::me2(g));   // what opponent_move hands the opponent (:38-39)
+                }
+                if (l == 0u) oweS[gl] = live && ns.pending != az2::NET_READY ? 1u : 0u;
+                lds_barrier();                                   // every game's debt, observation row and mask bits are in LDS
+                const bool any = __builtin_amdgcn_ballot_w64(oweS[lane & 15u] != 0u) != 0ull;      // (the same 16 words in every wave)
+                if (!any || j >= NET_MAX_REPLIES) break;
+                const u64 okey = a.opp_seed == AZUL_POLICY_ARGMAX ? a.opp_seed : a.opp_seed + (u64)j;      // reply j of a step: its own Philox key
+                const u32 col0 = PR2_L2COL0;
+                {
+                    pf_f32x4 acc0 = (pf_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+                    const float *ap = obsS + c * PF_OBS_STRIDE + q;
+                    if (two) pr2_opp_layer1<2>(rso1, voffo1, ap, preo, acc0, acc1);
+                    else pr2_opp_layer1<1>(rso1, voffo1, ap, preo, acc0, acc1);
+                    pr2_request2(two, rso2, voff2, pre2);
+                    if (col0 < (u32)PF_HID)
+                        for (int rr = 0; rr < 4; rr++) {
+                            float *hp = hidS + (4u * q + rr) * PF_HID_STRIDE + PF_HID + col0;
+                            const float h0 = acc0[rr] + b1oS[col0];
+                            hp[0] = h0 > 0.f ? h0 : 0.f;         // F.relu, model.py:30
+                            if (two) { const float h1 = acc1[rr] + b1oS[col0 + 1u]; hp[1] = h1 > 0.f ? h1 : 0.f; }
+                        }
+                }
+                lds_barrier();
+                {
+                    pf_f32x4 acc0 = (pf_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+                    const float *ap = hidS + c * PF_HID_STRIDE + PF_HID + q;
+                    const u32 hg_ = g0 + 4u * w + q;
+                    if (two) pr2_layer2<2>(rso2, voff2, ap, pre2, acc0, acc1, true, okey, counter + (u64)t, b.id_base + (hg_ < n ? hg_ : n - 1u), u_head);
+                    else pr2_layer2<1>(rso2, voff2, ap, pre2, acc0, acc1, false, 0, 0, 0, u_head);
+                    if (col0 < (u32)PF_ACT)
+                        for (int rr = 0; rr < 4; rr++) {
+                            float *lp = lgS + (4u * q + rr) * PF_LOG_STRIDE + col0;
+                            lp[0] = acc0[rr] + b2aoS[col0];
+                            if (two) lp[1] = acc1[rr] + b2aoS[col0 + 1u];
+                        }
+                }
+                lds_barrier();
+                if (w < 4u) {                                    // the opponent's sampling head (agent.py:76-80), waves 0..3, four games each
+                    const u32 hrow = 4u * w + q, hg = g0 + hrow;
+                    float x[HEAD_PER_LANE];
+                    const float *lg = lgS + hrow * PF_LOG_STRIDE + (c < 15u ? 12u * c : 0u);
+                    for (int jj = 0; jj < HEAD_PER_LANE; jj++) x[jj] = lg[jj];
+                    const u64 M0 = maskS[hrow][0], M1 = maskS[hrow][1], M2 = maskS[hrow][2];
+                    const u32 bitpos = 12u * c, word = bitpos >> 6, off = bitpos & 63u;
+                    const u64 lo = word == 0u ? M0 : (word == 1u ? M1 : M2), hi = word == 0u ? M1 : M2;
+                    u64 field = lo >> off;
+                    if (off > 52u) field |= hi << (64u - off);
+                    const u32 okbits = c < 15u ? (u32)field & 0xfffu : 0u;
+                    const bool tr = hg < n && oweS[hrow] != 0u && a.opp_action && j < (u32)a.opp_slots;
+                    const size_t trow = ((size_t)t * (size_t)(a.opp_slots > 0 ? a.opp_slots : 1) + (j < (u32)a.opp_slots ? j : 0u)) * n;
+                    policy_head_rows(x, lgS + hrow * PF_LOG_STRIDE, okbits, okey, counter + (u64)t, hg < n ? hg : n - 1u, lane, tr,
+                                     a.opp_action ? a.opp_action + trow : nullptr, a.opp_logp ? a.opp_logp + trow : nullptr, nullptr, b.id_base, actS + 4u * w,
+                                     &u_head);
+                }
+                lds_barrier();
+            }
+            pr2_request1(two, rs1, voffA, voffB, preA, preB);    // the next step's layer 1 on the agent's weights
+            if (live) {
+                if (ns.pending != az2::NET_READY) {              // (NET_MAX_REPLIES hit: cannot happen with legal replies; the slot reports it and moves on)
+                    ns.pending = az2::NET_READY;
+                    if (!ns.st) ns.st = ST_STUCK;
+                    az2::legal_mask2(g, k, m);
+                }
+                st_last = ns.st;
+                if (l == 0u) {
+                    a.reward[row_t + gi] = ns.rew; a.done[row_t + gi] = (uint8_t)ns.dn;
+                    if (a.opp_replies) a.opp_replies[row_t + gi] = (uint8_t)(ns.replies < 255u ? ns.replies : 255u);
+                }
+                win_rew = l == ((u32)t & 31u) ? ns.rew : win_rew;
+                win_done = l == ((u32)t & 31u) ? ns.dn : win_done;
+                publish((u32)t + 1u, true);                      // net_settle2 left the mask of this state in `m`
+            }
         }
     }
     lds_barrier();                                       // the rows of the state after the last move
@@ -381,4 +528,5 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
 #undef PR2_LOAD1
 #undef PR2_LOAD1Q
 #undef PR2_LOAD2
+#undef PR2_LOADO
 }

@@ -3,7 +3,7 @@
  *
  * The reference (patello/azul_deep_reinforcement_learning) has no FFI; its boundary for this path is
  * the Python API of azulnet/azul.py and azulnet/game_runner.py.  Each entry point below is the batched
- * (N games, one 64-lane wavefront per game) replacement of one reference function, cited per entry as
+ * (N games, two games per 64-lane wavefront) replacement of one reference function, cited per entry as
  * file:line relative to the reference tree.  The Python mirror in azul_deep_reinforcement_learning_amd/
  * binds these with ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
  *
@@ -324,6 +324,61 @@ int azul_batch_policy_rollout_returns(azul_batch_t *b, int n_steps, int opponent
                                       uint8_t *mask_dev, uint8_t *player_dev, int32_t *action_dev, int32_t *reward_dev, uint8_t *done_dev,
                                       float *value_dev, float *logp_dev, float *entropy_dev, uint8_t *status_dev, float *returns_dev, float gamma,
                                       void *stream);
+/* ---- GameRunner with a NETWORK opponent (game_runner.py:27-30: GameRunner(opponent=Agent(...)); scripts/run_batch.py:6-10,
+ * tests/test_nn_runner.py:63-67, 84-90) ------------------------------------------------------------------------------------------
+ * With an Agent as opponent every opponent_move() (game_runner.py:37-42) -- the opponent's replies AND player 1's forced moves (:46: the
+ * loop runs while current_player != 1 or player 1 has fewer than two legal moves) and, after reset(), the opening moves (:84-85) -- asks
+ * a second ActorCritic for an action on the observation from the MOVER's perspective (:38) through forward_actor alone (agent.py:73-81).
+ *
+ * One launch per window: azul_batch_policy_rollout with opponent_random = 1 whose RandomAgent is replaced by the `opponent` weight set.
+ * Per agent step the kernel evaluates `agent` (value, action, log-prob, entropy: the C1 record, as before), plays the action, and then
+ * runs matrix phases on `opponent` while any of a workgroup's 16 games owes an opponent_move(); reply j of a step samples with Philox key
+ * opponent_seed + j (AZUL_POLICY_ARGMAX: action_selection "Max", agent.py:79-80) at the step's counter and the game's global id, so the
+ * trajectories do not depend on sharding.  Both weight sets use azul_policy_forward's layouts (the opponent's critic arrays may be NULL).
+ * One record per AGENT step, observations from perspective 0, like opponent_random = 1.  Optional trace of the opponent's play:
+ * opp_action / opp_logp [T][opp_slots][N] receive its answers and their log-probabilities in the order they were played (a step's
+ * replies beyond opp_slots are played but not recorded; slots beyond a step's replies are not written), opp_replies [T][N] their number
+ * (opening moves of the next episode included).  Bit-identical to the per-move entries below driven with azul_policy_forward. */
+typedef struct azul_net_weights {
+    const float *w1t, *b1, *w2c, *b2c, *w2a_t, *b2a;     /* device pointers, layouts of azul_policy_forward */
+} azul_net_weights_t;
+typedef struct azul_rollout_buffers {
+    float *obs;            /* [T+1][N][136] */
+    uint8_t *mask;         /* [T+1][N][180] */
+    uint8_t *player;       /* [T+1][N] */
+    int32_t *action;       /* [T][N] */
+    int32_t *reward;       /* [T][N] */
+    uint8_t *done;         /* [T][N] */
+    float *value, *logp, *entropy;   /* [T][N] */
+    uint8_t *status;       /* [N] optional: first status of the last step that was not AZUL_OK */
+    float *returns;        /* [T][N] optional (nn_runner.py:70-76) */
+    int32_t *opp_action;   /* [T][opp_slots][N] optional */
+    float *opp_logp;       /* [T][opp_slots][N] optional */
+    uint8_t *opp_replies;  /* [T][N] optional */
+    int opp_slots;
+} azul_rollout_buffers_t;
+int azul_batch_policy_rollout_vs(azul_batch_t *b, int n_steps, const azul_net_weights_t *agent, const azul_net_weights_t *opponent, int num_inputs,
+                                 int hidden_size, int num_actions, uint64_t seed, uint64_t opponent_seed, uint64_t counter, uint64_t *counter_dev,
+                                 const azul_rollout_buffers_t *out, float gamma, void *stream);
+/* The same protocol one launch per cut, for opponents evaluated OUTSIDE the library (any network as PyTorch modules, or azul_policy_forward
+ * on a second weight set): GameRunner.step / reset are cut at their opponent_move() calls.  pending_dev (uint8 [N], in / out) holds per
+ * game 0 = nothing owed (the agent's next decision), 1 = an opponent_move() is owed inside GameRunner.step's loop (game_runner.py:46-47),
+ * 2 = inside reset()'s loop (:84-85); owing_dev (uint32 [1], optional) receives the number of games that still owe one.
+ *   azul_batch_net_step_begin   the agent's move (:44-45), then the loop condition; a step that needs no reply is closed at once
+ *   azul_batch_net_step_reply   one opponent_move() with opp_actions_dev for every game that owes one, then the loop condition again
+ *   azul_batch_net_reset_begin  GameRunner.reset(): the fresh game (:79-82), then the opening loop's condition
+ * After each launch obs_opp_dev / mask_opp_dev hold, for the games that owe a move, what opponent_move hands the opponent: the
+ * observation from the mover's perspective (:38) and the legal mask (:39).  reward_dev / done_dev are written by the launch that
+ * CLOSES the agent step (:48-55; done = 2: nobody could move, slot restarted), which also opens the next episode (nn_runner.py:20);
+ * status_dev keeps the step's first status that was not AZUL_OK; replies_dev (optional) counts the opponent moves of the step.  An
+ * opponent action that is not legal leaves game and debt untouched (status AZUL_ILLEGAL_MOVE / AZUL_BAD_ACTION): answer again. */
+int azul_batch_net_step_begin(azul_batch_t *b, const int32_t *actions_dev, uint8_t *pending_dev, uint8_t *replies_dev, int32_t *reward_dev,
+                              uint8_t *done_dev, uint8_t *status_dev, float *obs_opp_dev /*[N][136]*/, uint8_t *mask_opp_dev /*[N][180]*/,
+                              uint32_t *owing_dev, void *stream);
+int azul_batch_net_step_reply(azul_batch_t *b, const int32_t *opp_actions_dev, uint8_t *pending_dev, uint8_t *replies_dev, int32_t *reward_dev,
+                              uint8_t *done_dev, uint8_t *status_dev, float *obs_opp_dev, uint8_t *mask_opp_dev, uint32_t *owing_dev, void *stream);
+int azul_batch_net_reset_begin(azul_batch_t *b, const uint8_t *active_dev, uint8_t *pending_dev, uint8_t *status_dev, float *obs_opp_dev,
+                               uint8_t *mask_opp_dev, uint32_t *owing_dev, void *stream);
 /* The A2C update's gradients (Agent.update, agent.py:39-58) for n_samples recorded (observation, mask, action, q-value) samples:
  * forward and backward of  L = mean_i( -logp_i[a_i] * adv_i + 0.5 * adv_i^2 + 0.1 * (-mean_{j legal} logp_i[j]) ),  adv = q - V
  * (advantage not detached, like the reference), on the f32 matrix cores.  `inv_n_total` = 1 / (samples of the whole batch over

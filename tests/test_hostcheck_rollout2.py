@@ -116,3 +116,138 @@ def test_random_agent_opponent_and_a_ragged_last_workgroup():
     first, pool = RULES["lid_randomfirst"]
     ops, _ = run(L, first, pool, True, n=19, T=5, seed0=80, warm=45)
     assert ops > 5000
+
+
+# ---- the NETWORK opponent (azul_policy_rollout2_kernel<LID, 2>; game_runner.py:27-30 GameRunner(opponent=Agent(...))) ----------------------
+def load_vs():
+    L = load()
+    L.sr2_rollout_vs.restype = C.c_longlong
+    L.sr2_rollout_vs.argtypes = ([C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 11
+                                 + [C.c_float, C.c_ulonglong, C.c_ulonglong, C.c_ulonglong] + [C.c_void_p] * 3 + [C.c_int])
+    return L
+
+
+def to_agent_decision(rec, mt, pos, first, pool, rng):
+    """Bring a flat self-play state to a point where GameRunner hands the turn to the agent (game_runner.py:46: player 1 to move with at
+    least two legal moves, game not over) by letting a stand-in opponent play random legal moves."""
+    run = oz.NetRunner(lambda s, m: int(rng.choice(np.flatnonzero(m))), first if first else oz.FIRST_RANDOM, pool, rec=rec, mt=mt, pos=pos)
+    Lz = oz.lib()
+    for _ in range(200):
+        legal = int(run.get_valid_moves().sum())
+        over = bool(Lz.oz_is_end_of_game(C.byref(run.q.game)))
+        if over:
+            assert run.reset() == 0
+            continue
+        if run.q.game.current_player == 1 and legal >= 2:
+            break
+        assert Lz.oz_runner_opponent_move_with(C.byref(run.q), C.byref(run.r), run._cb, None) == 0
+    run.q.player_score = int(Lz.oz_potential(C.byref(run.q.game)))          # GameRunner.player_score follows the potential (game_runner.py:52)
+    m, p = run.rng_state()
+    return np.frombuffer(run.record().tobytes(), np.uint8).copy(), m, p
+
+
+def actor_forward(w, obs, mask):
+    h = np.maximum(obs.astype(np.float32) @ w["w1t"][:, 180:] + w["b1"][180:], np.float32(0))
+    logits = (h @ w["w2a_t"] + w["b2a"]).astype(np.float64)
+    legal = mask.astype(bool)
+    z = logits[legal]
+    lse = z.max() + np.log(np.exp(z - z.max()).sum())
+    logp = np.full(180, -np.inf)
+    logp[legal] = z - lse
+    return logp
+
+
+def run_vs(L, first, pool, n, T, seed0, warm, slots=8, argmax=False):
+    state, mt, pos = start_batch(n, seed0, first, pool, warm)
+    rng = np.random.default_rng(seed0)
+    for g in range(n):
+        state[g], mt[g], pos[g] = to_agent_decision(state[g].view(oz.RECORD_DTYPE)[0], mt[g], pos[g], first, pool, rng)
+    state0, mt0, pos0 = state.copy(), mt.copy(), pos.copy()
+    ep, stuck, ss = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros((n, 10))
+    wa, wo = weights(seed0), weights(seed0 + 1)
+    keys = ("w1t", "b1", "w2c", "b2c", "w2a_t", "b2a")
+    pa = (C.c_void_p * 6)(*[wa[k].ctypes.data for k in keys])
+    po = (C.c_void_p * 6)(*[wo[k].ctypes.data for k in keys])
+    o = {"obs": np.full((T + 1, n, 136), -99, np.float32), "mask": np.full((T + 1, n, 180), 0xEE, np.uint8),
+         "player": np.full((T + 1, n), 9, np.uint8), "action": np.full((T, n), -7, np.int32), "reward": np.full((T, n), -7777, np.int32),
+         "done": np.full((T, n), 9, np.uint8), "value": np.full((T, n), np.nan, np.float32), "logp": np.full((T, n), np.nan, np.float32),
+         "entropy": np.full((T, n), np.nan, np.float32), "status": np.full(n, 99, np.uint8), "returns": np.full((T, n), np.nan, np.float32),
+         "opp_action": np.full((T, slots, n), -9, np.int32), "opp_logp": np.full((T, slots, n), np.nan, np.float32),
+         "opp_replies": np.full((T, n), 200, np.uint8)}
+    oob0 = L.sr2_buffer_oob()
+    AM = 0xFFFFFFFFFFFFFFFF
+    ops = L.sr2_rollout_vs(n, ptr(state), ptr(mt), ptr(pos), ptr(ep), ptr(stuck), ptr(ss), first, pool, 1000, C.cast(pa, C.c_void_p), C.cast(po, C.c_void_p), T,
+                           ptr(o["obs"]), ptr(o["mask"]), ptr(o["player"]), ptr(o["action"]), ptr(o["reward"]), ptr(o["done"]), ptr(o["value"]),
+                           ptr(o["logp"]), ptr(o["entropy"]), ptr(o["status"]), ptr(o["returns"]), 0.9, 4242, AM if argmax else 777, 17,
+                           ptr(o["opp_action"]), ptr(o["opp_logp"]), ptr(o["opp_replies"]), slots)
+    assert ops > 0 and L.sr2_buffer_oob() == oob0
+    episodes = forced = opening = 0
+    for g in range(n):
+        tag = (first, pool, g)
+        assert int(o["opp_replies"][:, g].max()) <= slots, "raise `slots`: a step had more replies than the trace holds"
+        cur = {"t": 0, "j": 0}
+        handed = []
+
+        def opponent(s, m):
+            t, j = cur["t"], cur["j"]
+            a = int(o["opp_action"][t, j, g])
+            assert 0 <= a < 180 and m[a], (tag, t, j, a)
+            handed.append((t, j, s.copy(), m.copy(), int(run.q.game.current_player)))
+            cur["j"] += 1
+            return a
+
+        run = oz.NetRunner(opponent, first if first else oz.FIRST_RANDOM, pool, rec=state0[g].view(oz.RECORD_DTYPE)[0], mt=mt0[g], pos=pos0[g])
+        for t in range(T):
+            cur["t"], cur["j"] = t, 0
+            mask = run.get_valid_moves()
+            assert np.array_equal(o["mask"][t, g].astype(bool), mask), (tag, t)
+            assert np.array_equal(o["obs"][t, g].astype(np.int64), run.get_state(0)), (tag, t)
+            assert int(o["player"][t, g]) == 1 == int(run.q.game.current_player) and mask.sum() >= 2, (tag, t)
+            a = int(o["action"][t, g])
+            assert mask[a]
+            value, logp, ent = forward(wa, o["obs"][t, g], o["mask"][t, g])
+            assert abs(o["value"][t, g] - value) < 2e-4 * max(1.0, abs(value)) and abs(o["logp"][t, g] - logp[a]) < 2e-4, (tag, t)
+            assert abs(o["entropy"][t, g] - ent) < 2e-4 * max(1.0, ent), (tag, t)
+            rc, rew, dn = run.step(a)                                       # game_runner.py:43-55 with the recorded opponent
+            assert rc == 0 and rew == int(o["reward"][t, g]) and dn == bool(o["done"][t, g]), (tag, t, rew, dn)
+            if dn:
+                episodes += 1
+                before = cur["j"]
+                assert run.reset() == 0                                     # nn_runner.py:20: the next episode, the opponent opens (:84-85)
+                opening += cur["j"] - before
+            assert cur["j"] == int(o["opp_replies"][t, g]), (tag, t, cur["j"], int(o["opp_replies"][t, g]))
+        assert np.array_equal(o["mask"][T, g].astype(bool), run.get_valid_moves()) and np.array_equal(o["obs"][T, g].astype(np.int64), run.get_state(0)), tag
+        m_e, idx = run.rng_state()
+        assert state[g].tobytes() == run.record().tobytes() and int(pos[g]) == idx and np.array_equal(mt[g], m_e), tag
+        assert int(ep[g]) == int(o["done"][:, g].astype(bool).sum()) and int(stuck[g]) == 0 and int(o["status"][g]) == 0, tag
+        # the opponent saw the MOVER's perspective and sampled from ITS net: log-prob of every answer against a numpy forward_actor
+        for t, j, s, m, player in handed:
+            lp = actor_forward(wo, s, m)
+            a = int(o["opp_action"][t, j, g])
+            assert abs(o["opp_logp"][t, j, g] - lp[a]) < 2e-4, (tag, t, j)
+            if argmax:
+                assert a == int(np.argmax(np.where(m, lp, -np.inf))) or abs(lp[a] - lp[m].max()) < 1e-5, (tag, t, j)
+            forced += player == 1
+        q, want = np.float32(0), np.zeros(T, np.float32)
+        for t in range(T - 1, -1, -1):
+            q = np.float32(o["reward"][t, g]) + np.float32(0.9) * (np.float32(0) if o["done"][t, g] else q)
+            want[t] = q
+        assert np.array_equal(o["returns"][:, g], want), tag
+    return ops, episodes, forced, opening
+
+
+def test_network_opponent_in_the_rollout_kernel_replays_through_the_oracle():
+    """GameRunner(opponent=Agent(...)) inside the kernel: the agent's records as with the RandomAgent opponent, every opponent_move() --
+    replies, player 1's forced moves, the opening moves after an episode end -- answered by the second net on the mover's perspective."""
+    L = load_vs()
+    first, pool = RULES["lid_randomfirst"]
+    ops, episodes, forced, opening = run_vs(L, first, pool, n=19, T=6, seed0=300, warm=40)        # (a ragged last workgroup)
+    assert ops > 5000 and episodes >= 1 and forced >= 1
+    ops, episodes, forced, opening = run_vs(L, first, pool, n=16, T=30, seed0=500, warm=50)
+    assert episodes >= 10 and forced >= 8 and opening >= 3
+
+
+def test_network_opponent_argmax_and_the_random_pool():
+    L = load_vs()
+    first, pool = RULES["random_first1"]
+    run_vs(L, first, pool, n=16, T=5, seed0=410, warm=30, argmax=True)

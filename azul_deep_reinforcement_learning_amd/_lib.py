@@ -41,6 +41,17 @@ class AzulCall(C.Structure):
                 ("mask", C.c_uint8 * (MAX_ACTIONS + 4)), ("obs", C.c_float * MAX_OBS), ("stats", C.c_double * 10)]
 
 
+class NetWeights(C.Structure):           # azul_net_weights_t
+    _fields_ = [(k, C.c_void_p) for k in ("w1t", "b1", "w2c", "b2c", "w2a_t", "b2a")]
+
+
+class RolloutBuffers(C.Structure):       # azul_rollout_buffers_t
+    _fields_ = [(k, C.c_void_p) for k in ("obs", "mask", "player", "action", "reward", "done", "value", "logp", "entropy", "status", "returns",
+                                          "opp_action", "opp_logp", "opp_replies")] + [("opp_slots", C.c_int)]
+
+
+NET_READY, NET_REPLY, NET_OPENING = 0, 1, 2      # pending_dev of the azul_batch_net_* entries
+
 # name -> (restype, argtypes); every symbol declared in include/azul_hip.h
 SIGNATURES = {
     "azul_last_error_string": (C.c_char_p, []),
@@ -87,6 +98,11 @@ SIGNATURES = {
     "azul_policy_forward": (_i, [_vp] * 8 + [_i, _i, _i, _u64, _u64, _vp, _i, _i, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "azul_batch_policy_rollout": (_i, [_vp, _i, _i] + [_vp] * 6 + [_i, _i, _i, _u64, _u64, _vp] + [_vp] * 10 + [_vp]),
     "azul_batch_policy_rollout_returns": (_i, [_vp, _i, _i] + [_vp] * 6 + [_i, _i, _i, _u64, _u64, _vp] + [_vp] * 10 + [_vp, C.c_float, _vp]),
+    "azul_batch_policy_rollout_vs": (_i, [_vp, _i, C.POINTER(NetWeights), C.POINTER(NetWeights), _i, _i, _i, _u64, _u64, _u64, _vp,
+                                          C.POINTER(RolloutBuffers), C.c_float, _vp]),
+    "azul_batch_net_step_begin": (_i, [_vp] * 11),
+    "azul_batch_net_step_reply": (_i, [_vp] * 11),
+    "azul_batch_net_reset_begin": (_i, [_vp] * 8),
     "azul_a2c_gradients": (_i, [_vp, _vp, _vp, _vp, _i, C.c_float] + [_vp] * 7 + [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "azul_a2c_apply_adam": (_i, [_vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _i] + [_vp] * 8 + [_vp, _vp, C.c_float, _vp, _vp]),
     "azul_select_episode_samples": (_i, [_vp, _vp, _i, _i, _i, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),

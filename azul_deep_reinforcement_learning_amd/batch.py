@@ -324,6 +324,32 @@ class BatchedAzul:
                                             _ptr(status), int(perspective), _ptr(obs_next), _ptr(mask_next), _ptr(player_next),
                                             self._stream()))
 
+    # -- GameRunner with an external (network) opponent, cut at its opponent_move() calls (game_runner.py:27-30, 37-47, 84-85) ------
+    def net_state(self):
+        """Preallocated device tensors of the protocol: pending / replies [N] u8, owing [1] (int32 view of the ABI's uint32), the
+        opponent's observation [N][136] / mask [N][180] and its answer [N]."""
+        d = self.device
+        return {"pending": torch.zeros(self.n, dtype=torch.uint8, device=d), "replies": torch.zeros(self.n, dtype=torch.uint8, device=d),
+                "owing": torch.zeros(1, dtype=torch.int32, device=d), "obs": torch.zeros(self.n, self.obs_size, device=d),
+                "mask": torch.zeros(self.n, self.num_actions, dtype=torch.uint8, device=d),
+                "action": torch.zeros(self.n, dtype=torch.int32, device=d)}
+
+    def net_step_begin(self, actions, net, reward, done, status):
+        """The agent's move of GameRunner.step (game_runner.py:44-45) for every game, then the loop condition (:46): net["pending"] says
+        who owes an opponent_move(), net["obs"] / net["mask"] what it is handed, net["owing"] how many games owe one."""
+        L.check(L.lib.azul_batch_net_step_begin(self._h, _ptr(actions), _ptr(net["pending"]), _ptr(net["replies"]), _ptr(reward), _ptr(done),
+                                                _ptr(status), _ptr(net["obs"]), _ptr(net["mask"]), _ptr(net["owing"]), self._stream()))
+
+    def net_step_reply(self, opp_actions, net, reward, done, status):
+        """One opponent_move() (game_runner.py:37-42) with `opp_actions` for every game that owes one, then the loop condition again."""
+        L.check(L.lib.azul_batch_net_step_reply(self._h, _ptr(opp_actions), _ptr(net["pending"]), _ptr(net["replies"]), _ptr(reward), _ptr(done),
+                                                _ptr(status), _ptr(net["obs"]), _ptr(net["mask"]), _ptr(net["owing"]), self._stream()))
+
+    def net_reset_begin(self, net, status, active=None):
+        """GameRunner.reset() (game_runner.py:76-85) up to its first opponent_move()."""
+        L.check(L.lib.azul_batch_net_reset_begin(self._h, _ptr(self._dev(active, torch.uint8)), _ptr(net["pending"]), _ptr(status), _ptr(net["obs"]),
+                                                 _ptr(net["mask"]), _ptr(net["owing"]), self._stream()))
+
     # -- flat self-play rollout -------------------------------------------------------------------
     def selfplay(self, n_steps, mask=None, action=None, reward=None, done=None, records=None, maskbits=None, packed=None):
         """`n_steps` env moves for every game in one launch; outputs are preallocated tensors or None.  `mask` may be a

@@ -1,0 +1,192 @@
+"""GameRunner(opponent=Agent(...)) on the device (SURVEY.md 8b `.opponent`; /root/reference/azulnet/game_runner.py:27-30, 37-47, 84-85;
+scripts/run_batch.py:6-10; tests/test_nn_runner.py:63-67, 84-90): the batched rollout with a NETWORK opponent.
+  * the per-cut ABI (azul_batch_net_step_begin / _reply / _reset_begin) fed the REFERENCE's recorded agent and opponent actions gives the
+    reference's recorded observations, masks, rewards, dones, move counters -- and hands the opponent the recorded perspective-rotated
+    observation and mask at every call (tests/golden/net_opponent.npz, generated from the real reference);
+  * both rollout structures replay through the oracle with their own recorded actions, the opponent's log-probabilities are the second
+    net's (torch f32, 2e-5), and the window kernel equals the per-move path bit for bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as oz
+from tests.net_replay import replay_game
+
+pytestmark = pytest.mark.gpu
+RULES = {"lid_randomfirst": ({"first_player": "Random", "tile_pool": "Lid"}, oz.FIRST_RANDOM, oz.POOL_LID),
+         "random_first1": ({"first_player": 1, "tile_pool": "Random"}, 1, oz.POOL_RANDOM)}
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "net_opponent.npz"))
+
+
+def _nets(golden, device="cuda"):
+    from azul_deep_reinforcement_learning_amd.policy import BatchedActorCritic
+    out = []
+    for who in ("agent", "opp"):
+        sd = {k[len(who) + 4:]: torch.from_numpy(golden[k]) for k in golden.files if k.startswith(who + "_sd_")}
+        out.append(BatchedActorCritic.from_reference(sd).to(device))
+    return out
+
+
+@pytest.mark.parametrize("ruleset", ["lid_randomfirst", "random_first1"])
+def test_cut_protocol_reproduces_the_reference_game_runner_with_an_agent_opponent(golden, ruleset):
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    t = golden
+    rules = {"lid_randomfirst": {"first_player": "Random", "tile_pool": "Lid"}, "random_first1": {}}[ruleset]
+    forced = 0
+    for seed in t["seeds"]:
+        pre = "%s_s%d_" % (ruleset, seed)
+        cs, ca = t[pre + "call_state"], t[pre + "call_action"]
+        cm = np.unpackbits(t[pre + "call_mask"], axis=1, bitorder="little")[:, :180]
+        sm = np.unpackbits(t[pre + "step_mask"], axis=1, bitorder="little")[:, :180]
+        env = BatchedAzul(1, rules=rules, device="cuda")
+        env.seed(int(seed))                                         # random.seed(seed)
+        env.runner_init()                                           # GameRunner(opponent=opponent, rules=rules)
+        net = env.net_state()
+        reward = torch.zeros(1, dtype=torch.int32, device="cuda")
+        done = torch.zeros(1, dtype=torch.uint8, device="cuda")
+        status = torch.zeros(1, dtype=torch.uint8, device="cuda")
+        act = torch.zeros(1, dtype=torch.int32, device="cuda")
+        used = 0
+
+        def replies(may_run_out=False):
+            nonlocal used, forced
+            while int(net["owing"].item()) > 0:
+                if may_run_out and used == len(ca):
+                    return                                          # (the reference stopped after two episodes: no third opening on record)
+                assert int(net["pending"][0]) in (1, 2)
+                assert np.array_equal(net["obs"][0].cpu().numpy().astype(np.int64), cs[used]), (pre, used)       # game_runner.py:38
+                assert np.array_equal(net["mask"][0].cpu().numpy(), cm[used]), (pre, used)                       # :39
+                forced += int(t[pre + "call_player"][used]) == 1
+                act[0] = int(ca[used])
+                used += 1
+                env.net_step_reply(act, net, reward, done, status)
+            assert int(net["pending"][0]) == 0
+
+        env.net_reset_begin(net, status)                            # runner.reset() of the first run_episode (nn_runner.py:20)
+        replies()
+        assert used == int(t[pre + "step_episode_calls_before"][0])
+        n_steps = len(sm)
+        second = int(t[pre + "step_episode_first_step"][1])
+        for i in range(n_steps):
+            obs, mask, player = env.observe_all(0)
+            assert np.array_equal(obs[0].cpu().numpy().astype(np.int64), t[pre + "step_obs"][i]), (pre, i)
+            assert np.array_equal(mask[0].cpu().numpy(), sm[i]) and int(player[0]) == 1, (pre, i)
+            act[0] = int(t[pre + "step_action"][i])
+            env.net_step_begin(act, net, reward, done, status)
+            replies(may_run_out=i == n_steps - 1)
+            assert int(reward[0]) == int(t[pre + "step_reward"][i]) and bool(done[0]) == bool(t[pre + "step_done"][i]), (pre, i)
+            assert int(status[0]) == 0, (pre, i)
+            if bool(done[0]):
+                # the launch that closes an episode's last step also opens the next one (nn_runner.py:20 -> game_runner.py:76-85): the
+                # reference's second reset() and its opening calls have been played
+                if i + 1 == second:
+                    assert used == int(t[pre + "step_episode_calls_before"][1]), (pre, i)
+            else:
+                assert used == int(t[pre + "step_calls_after"][i]), (pre, i)
+                rec = env.get_records()[0]
+                assert int(rec["move_counter"]) == int(t[pre + "step_move_counter"][i]) and int(rec["player_score"]) == int(t[pre + "step_player_score"][i])
+        assert used == len(ca)
+    assert forced >= 4
+
+
+def _windows(ro, k):
+    wins = []
+    for _ in range(k):
+        tr = ro.run_window()
+        ro.synchronize()
+        wins.append({key: v.cpu().numpy().copy() for key, v in tr[0].items()})
+    return wins
+
+
+def _check_through_the_oracle(wins, start_recs, start_rng, finals, final_rng, first, pool, opp_net, games, T):
+    """Env side of a recorded rollout vs the oracle, game by game; the opponent's log-probs vs its net in torch f32."""
+    cat = lambda key, sl: np.concatenate([w[key][sl] for w in wins])
+    handed_all = []
+    for g in games:
+        mt, pos = start_rng[g]
+        obs = np.concatenate([w["obs"][:T, g] for w in wins] + [wins[-1]["obs"][T:T + 1, g]])
+        mask = np.concatenate([w["mask"][:T, g] for w in wins] + [wins[-1]["mask"][T:T + 1, g]])
+        player = np.concatenate([w["player"][:T, g] for w in wins] + [wins[-1]["player"][T:T + 1, g]])
+        run, handed = replay_game(start_recs[g], mt, pos, first, pool, cat("action", (slice(None), g)), cat("opp_action", (slice(None), slice(None), g)),
+                                  cat("opp_replies", (slice(None), g)), obs, mask, player, cat("reward", (slice(None), g)), cat("done", (slice(None), g)))
+        assert run.record().tobytes() == finals[g].tobytes(), g
+        m_e, idx = run.rng_state()
+        assert int(final_rng[1][g]) == idx and np.array_equal(final_rng[0][g], m_e), g
+        lp_all = cat("opp_logp", (slice(None), slice(None), g))
+        handed_all += [(s, m, int(cat("opp_action", (slice(None), slice(None), g))[t, j]), float(lp_all[t, j]), pl) for t, j, s, m, pl in handed]
+    # the opponent sampled from ITS net on the MOVER's perspective: log-prob of every answer against torch f32
+    S = torch.from_numpy(np.stack([h[0] for h in handed_all]).astype(np.float32)).cuda()
+    M = torch.from_numpy(np.stack([h[1] for h in handed_all])).cuda()
+    with torch.no_grad():
+        _, logp = opp_net.forward_actor(S, M)
+    a = torch.tensor([h[2] for h in handed_all], device="cuda")
+    ref = logp.gather(1, a.unsqueeze(1)).squeeze(1).cpu().numpy()
+    got = np.array([h[3] for h in handed_all], np.float32)
+    assert np.allclose(got, ref, atol=2e-5, rtol=1e-5), float(np.abs(got - ref).max())
+    return len(handed_all), sum(h[4] == 1 for h in handed_all)
+
+
+@pytest.mark.parametrize("persistent", [False, True])
+@pytest.mark.parametrize("ruleset", ["lid_randomfirst", "random_first1"])
+def test_rollout_against_a_network_opponent_replays_through_the_oracle(golden, persistent, ruleset):
+    from azul_deep_reinforcement_learning_amd import PolicyRollout
+    agent, opp = _nets(golden)
+    rules, first, pool = RULES[ruleset]
+    T, n = 40, 64
+    ro = PolicyRollout(agent, n_games=n, parts=1, seed_base=500, window=T, use_graph=False, opponent=opp, persistent=persistent, opponent_trace=12,
+                       rules=rules)
+    assert ro.persistent == persistent and ro.opponent == "net"
+    env = ro.envs[0]
+    start = env.get_records()
+    rng0 = [env.get_rng(g) for g in range(n)]
+    wins = _windows(ro, 2)
+    calls, forced = _check_through_the_oracle(wins, start, rng0, env.get_records(), env.get_rng_range(), first, pool, opp, range(0, n, 3), T)
+    assert calls > 1500 and forced >= 10
+    # the agent's own records: value / log-prob / entropy are the FIRST net's on the recorded observation
+    w = wins[0]
+    obs = torch.from_numpy(w["obs"][:T].reshape(-1, 136)).cuda()
+    msk = torch.from_numpy(w["mask"][:T].reshape(-1, 180)).cuda().bool()
+    with torch.no_grad():
+        v = agent.forward_critic(obs).squeeze(1).cpu().numpy()
+        _, lp = agent.forward_actor(obs, msk)
+    a = torch.from_numpy(w["action"].reshape(-1).astype(np.int64)).cuda()
+    assert np.allclose(w["value"].reshape(-1), v, atol=2e-5, rtol=1e-5)
+    assert np.allclose(w["log_prob"].reshape(-1), lp.gather(1, a.unsqueeze(1)).squeeze(1).cpu().numpy(), atol=2e-5, rtol=1e-5)
+    assert ro.counters()["episodes"] >= 40 and ro.counters()["stuck"] == 0
+
+
+@pytest.mark.parametrize("n,rules,selection", [(100, None, "Distribution"), (16, None, "Max"), (37, {"first_player": 2, "tile_pool": "Random"}, "Distribution"),
+                                               (2048, None, "Distribution")])
+def test_window_kernel_with_a_network_opponent_is_bit_identical_to_the_cut_protocol(golden, n, rules, selection):
+    """azul_batch_policy_rollout_vs (matrix phases on the second weight set inside the window kernel) against the per-cut path (azul_policy_forward
+    on the opponent's weights + azul_batch_net_step_*): every trajectory array, the opponent's answers and their log-probs, the final records,
+    RNG states, counters and the Philox step counter -- over two windows, with a ragged last workgroup (n = 100)."""
+    from azul_deep_reinforcement_learning_amd import PolicyRollout
+    T = 33
+    runs = []
+    for persistent in (False, True):
+        agent, opp = _nets(golden)
+        kw = {} if rules is None else {"rules": rules}
+        ro = PolicyRollout(agent, n_games=n, parts=1, seed_base=77, window=T, use_graph=False, opponent=opp, persistent=persistent, opponent_trace=10,
+                           opponent_selection=selection, **kw)
+        wins = _windows(ro, 2)
+        mt, pos = ro.envs[0].get_rng_range()
+        runs.append((wins, ro.envs[0].get_records(), mt, pos, ro.counters(), ro.work[0]["counter"].tolist()))
+    (wa, ra, ma, pa, ca, cta), (wb, rb, mb, pb, cb, ctb) = runs
+    for wi in range(2):
+        for key in ("obs", "mask", "player", "action", "reward", "done", "value", "log_prob", "entropy", "returns", "opp_replies"):
+            assert np.array_equal(wa[wi][key], wb[wi][key]), (wi, key)
+        rep = wa[wi]["opp_replies"]
+        assert int(rep.max()) <= 10
+        valid = np.arange(10)[None, :, None] < rep[:, None, :]              # [T][R][N]: slot j of a step holds a reply
+        assert np.array_equal(wa[wi]["opp_action"][valid], wb[wi]["opp_action"][valid]), wi
+        assert np.array_equal(wa[wi]["opp_logp"][valid], wb[wi]["opp_logp"][valid]), wi
+        assert valid.sum() > T * n // 2
+    assert ra.tobytes() == rb.tobytes() and np.array_equal(ma, mb) and np.array_equal(pa, pb) and ca == cb and cta == ctb
+    assert ca["episodes"] > 0

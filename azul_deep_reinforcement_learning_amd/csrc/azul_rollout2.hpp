@@ -411,7 +411,9 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
                     if (ns.pending != az2::NET_READY) publish_rows(az2::me2(g));   // what opponent_move hands the opponent (:38-39)
                 }
                 if (l == 0u) oweS[gl] = live && ns.pending != az2::NET_READY ? 1u : 0u;
+                PR2_STAMP(0);                                    // (diagnostic build: the reply rounds' phases are added to the agent pass's)
                 lds_barrier();                                   // every game's debt, observation row and mask bits are in LDS
+                PR2_STAMP(1);
                 const bool any = __builtin_amdgcn_ballot_w64(oweS[lane & 15u] != 0u) != 0ull;      // (the same 16 words in every wave)
                 if (!any || j >= NET_MAX_REPLIES) break;
                 const u64 okey = a.opp_seed == AZUL_POLICY_ARGMAX ? a.opp_seed : a.opp_seed + (u64)j;      // reply j of a step: its own Philox key
@@ -431,6 +433,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
                         }
                 }
                 lds_barrier();
+                PR2_STAMP(2);
                 {
                     pf_f32x4 acc0 = (pf_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
                     const float *ap = hidS + c * PF_HID_STRIDE + PF_HID + q;
@@ -445,6 +448,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
                         }
                 }
                 lds_barrier();
+                PR2_STAMP(3);
                 if (w < 4u) {                                    // the opponent's sampling head (agent.py:76-80), waves 0..3, four games each
                     const u32 hrow = 4u * w + q, hg = g0 + hrow;
                     float x[HEAD_PER_LANE];
@@ -463,6 +467,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
                                      &u_head);
                 }
                 lds_barrier();
+                PR2_STAMP(4);
             }
             pr2_request1(two, rs1, voffA, voffB, preA, preB);    // the next step's layer 1 on the agent's weights
             if (live) {

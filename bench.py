@@ -173,6 +173,62 @@ def policy_pytorch_two_streams(games, seed_base=0, window=32, windows=20):
                        "env": "azul_batch_policy_step (Azul.step + reward + done + auto-reset + next obs / mask), azul_policy_head (sampling)"}}
 
 
+OPP_FLOP_PER_MOVE = 2 * (136 * 180 + 180 * 180)                  # forward_actor alone (agent.py:73-81): 113,760 FLOP
+
+
+def policy_vs_policy(games, seed_base=0, window=32, windows=40):
+    """GameRunner(opponent=Agent(...)) batched (game_runner.py:27-30; scripts/run_batch.py:6-10; BASELINE.md's "NNRunner vs Agent opponent"
+    line, ~590 env steps/s in CPython): the policy is player 1, a SECOND ActorCritic plays every opponent_move() -- replies, player 1's
+    forced moves, openings -- inside azul_policy_rollout2_kernel<LID, 2> (azul_batch_policy_rollout_vs), one launch per window of agent
+    steps.  env steps = accepted Azul.step calls of both sides.  Roofline against the f32 matrix peak, twice: the network evaluations the
+    GAMES needed (agent forward per agent step + forward_actor per opponent move), and what the kernel EXECUTED (a reply round runs the
+    opponent's matrices for all 16 games of a workgroup while any of them owes a move)."""
+    import torch
+    from azul_deep_reinforcement_learning_amd import BatchedActorCritic, PolicyRollout
+    torch.manual_seed(0)
+    net, opp = BatchedActorCritic(136, 180, 180), BatchedActorCritic(136, 180, 180)
+    ro = PolicyRollout(net, n_games=games, parts=1, window=window, persistent=True, opponent=opp, seed_base=seed_base)
+    for _ in range(3):
+        ro.run_window()
+    ro.synchronize()
+    torch.cuda.synchronize()
+    s = ro.streams[0]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # every window's reply counts are kept (one 128 KB device copy per window on the rollout's stream) and reduced AFTER the timed region:
+    # torch's reductions would cost ~0.7 ms per window here, the kernel's window takes ~1.1 ms
+    keep = torch.zeros(windows, window, games, dtype=torch.uint8, device=ro.device)
+    ep0 = ro.counters()["episodes"]
+    t0 = time.perf_counter()
+    e0.record(s)
+    for i in range(windows):
+        tr = ro.run_window()
+        with torch.cuda.stream(s):
+            keep[i].copy_(tr[0]["opp_replies"], non_blocking=True)
+    e1.record(s)
+    ro.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms = e0.elapsed_time(e1)
+    agent_steps = games * window * windows
+    opp_moves = int(keep.sum(dtype=torch.int64))
+    executed = int(keep.view(windows, window, -1, 16).amax(dim=3).sum(dtype=torch.int64)) * 16 if games % 16 == 0 else 0
+    c = ro.counters()
+    useful = (FWD_FLOP_PER_GAME * agent_steps + OPP_FLOP_PER_MOVE * opp_moves) / (kms / 1e3) / 1e12
+    run = (FWD_FLOP_PER_GAME * agent_steps + OPP_FLOP_PER_MOVE * executed) / (kms / 1e3) / 1e12
+    return {"metric": "Azul env steps/sec (ActorCritic policy vs ActorCritic opponent inside GameRunner, full C1 trajectory of the agent recorded)",
+            "value": (agent_steps + opp_moves) / dt, "unit": "env steps/s", "n_gpus": 1, "agent_steps_per_s": agent_steps / dt,
+            "opponent_moves_per_agent_step": opp_moves / agent_steps, "reply_rounds_per_agent_step": executed / agent_steps if executed else None,
+            "episodes_finished": c["episodes"] - ep0, "stuck_resets": c["stuck"],
+            "reference_python_env_steps_per_s": 590.0,
+            "config": {"workload": "%d games, GameRunner(opponent=Agent) semantics: two ActorCritic(136,180,180) f32 weight sets inside "
+                                   "azul_batch_policy_rollout_vs, one launch per window of %d agent steps, %d windows timed" % (games, window, windows)},
+            "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TFLOPS, "achieved": useful, "frac": useful / F32_MFMA_PEAK_TFLOPS,
+                         "executed": run, "executed_frac": run / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "azul_policy_rollout2_kernel<LID, 2>", "avg_window_ms": kms / windows, "event_bracket_ms": kms, "host_elapsed_ms": dt * 1e3,
+                         "flop_per_agent_step": FWD_FLOP_PER_GAME, "flop_per_opponent_move": OPP_FLOP_PER_MOVE,
+                         "note": "achieved = the evaluations the games needed; executed = incl. the masked games of a reply round"}}
+
+
 def saturated(seed_base=0, chunk=512):
     """The headline kernel with more games than BASELINE configs[1] gives a GPU: 8192 games = four waves per SIMD, 32768 games = the
     whole of configs[3] on ONE GPU (eight waves per SIMD, two rounds).  Same kernel, same outputs, kernel time from the library's event pairs.
@@ -765,7 +821,8 @@ def main():
             ex = {"error": repr(e)}
         ex.update(first)
         if world == 1:
-            for name, fn in (("saturated", lambda: saturated(args.seed_base, T)), ("facade_config1", facade_config1),
+            for name, fn in (("policy_vs_policy", lambda: policy_vs_policy(G, args.seed_base)),
+                             ("saturated", lambda: saturated(args.seed_base, T)), ("facade_config1", facade_config1),
                              ("players_selfplay", lambda: players_selfplay(G))):
                 phase[0] = name
                 try:

@@ -26,6 +26,14 @@ def _contract_net(golden_dir):
     return BatchedActorCritic.from_reference(sd).cuda()
 
 
+def _opponent_net(golden_dir):
+    """The reference-initialised second net of tests/golden/net_opponent.npz (GameRunner(opponent=Agent(...)), game_runner.py:27-30)."""
+    from azul_deep_reinforcement_learning_amd.policy import BatchedActorCritic
+    c = np.load(os.path.join(golden_dir, "net_opponent.npz"))
+    sd = {k[7:]: torch.from_numpy(c[k]) for k in c.files if k.startswith("opp_sd_")}
+    return BatchedActorCritic.from_reference(sd).cuda()
+
+
 def test_selfplay_32768_games_is_shard_invariant_and_matches_the_oracle():
     """configs[3]: one BatchedAzul(32768) vs eight BatchedAzul(4096) seeded shard_seed_base(base, 4096, k); 320 moves in two
     launches of the benchmarked kernel variant (all trajectory streams): compact records, mask bits, final 128-byte
@@ -79,15 +87,20 @@ def test_selfplay_32768_games_is_shard_invariant_and_matches_the_oracle():
         assert s.rng_state()[1] == int(big_pos[gid]), gid
 
 
-@pytest.mark.parametrize("opponent", [None, "random"])
+@pytest.mark.parametrize("opponent", [None, "random", "net"])
 def test_policy_rollout_32768_games_is_shard_invariant(golden_dir, opponent):
     """configs[4]: PolicyRollout(32768) vs eight PolicyRollout(4096, seed_base = game_id_base = 4096 k) with the same weights,
     two windows of the one-launch-per-window kernel: the full C1 record (observation, mask, player, action, reward, done,
-    value, log-prob, entropy, returns) and the final game records are byte-identical per global id."""
+    value, log-prob, entropy, returns) and the final game records are byte-identical per global id.  "net": against a second,
+    frozen weight set (GameRunner(opponent=Agent(...)), game_runner.py:27-30): the opponent's Philox stream is keyed by the global
+    id too, and its reply counts join the compared record."""
     from azul_deep_reinforcement_learning_amd import PolicyRollout
     net = _contract_net(golden_dir)
     T, base = 32, 3000
     keys = ("obs", "mask", "player", "action", "reward", "done", "value", "log_prob", "entropy", "returns")
+    if opponent == "net":
+        opponent = _opponent_net(golden_dir)
+        keys = keys + ("opp_replies",)
     big = PolicyRollout(net, n_games=SHARDS * G, seed_base=base, window=T, persistent=True, opponent=opponent)
     assert big.persistent
     bw = []
@@ -236,3 +249,42 @@ def test_persistent_rollout_kernel_replays_through_the_oracle_at_4096_games(gold
         assert env.get_rng(g)[1] == idx, g
         episodes += int(np.sum(exp["done"]))
     assert episodes >= len(sample) // 2                 # the replay crossed episode ends (scoring, reset, opponent's opening)
+
+
+def test_network_opponent_rollout_kernel_replays_through_the_oracle_at_4096_games(golden_dir):
+    """azul_batch_policy_rollout_vs at BASELINE size: GameRunner(opponent=Agent(...)) (game_runner.py:27-30, 37-47, 84-85) inside the window
+    kernel for 4096 games, three windows; sampled games replay through the oracle's GameRunner-with-any-opponent with the kernel's own
+    recorded agent and opponent actions (replies, player 1's forced moves, openings), final records and MT19937 positions included."""
+    from azul_deep_reinforcement_learning_amd import PolicyRollout
+    from tests.net_replay import replay_game
+    net, opp = _contract_net(golden_dir), _opponent_net(golden_dir)
+    T, n, windows, R = 32, G, 3, 12
+    ro = PolicyRollout(net, n_games=n, seed_base=2468, window=T, persistent=True, opponent=opp, opponent_trace=R)
+    assert ro.persistent and ro.opponent == "net"
+    env = ro.envs[0]
+    sample = list(range(0, n, 131)) + [n - 1]
+    rec0 = env.get_records()
+    rng0 = {g: env.get_rng(g) for g in sample}
+    got = []
+    for _ in range(windows):
+        tr = ro.run_window()
+        ro.synchronize()
+        got.append({k: (tr[0][k][:, :, sample] if k in ("opp_action", "opp_logp") else tr[0][k][:, sample]).cpu().numpy().copy()
+                    for k in ("obs", "mask", "player", "action", "reward", "done", "opp_action", "opp_replies")})
+    final = env.get_records()
+    calls = forced = episodes = 0
+    for j, g in enumerate(sample):
+        cat = lambda key: np.concatenate([w[key][:T, j] if key in ("obs", "mask", "player") else w[key][..., j] for w in got])
+        obs = np.concatenate([cat("obs"), got[-1]["obs"][T:T + 1, j]])
+        mask = np.concatenate([cat("mask"), got[-1]["mask"][T:T + 1, j]])
+        player = np.concatenate([cat("player"), got[-1]["player"][T:T + 1, j]])
+        mt, pos = rng0[g]
+        run, handed = replay_game(rec0[g], mt, pos, oz.FIRST_RANDOM, oz.POOL_LID, cat("action"), cat("opp_action"), cat("opp_replies"), obs, mask,
+                                  player, cat("reward"), cat("done"))
+        assert run.record().tobytes() == final[g].tobytes(), g
+        assert env.get_rng(g)[1] == run.rng_state()[1], g
+        calls += len(handed)
+        forced += sum(h[4] == 1 for h in handed)
+        episodes += int(cat("done").astype(bool).sum())
+    assert calls > len(sample) * T * windows * 0.9 and forced > 0 and episodes >= len(sample)
+    assert ro.counters()["stuck"] == 0

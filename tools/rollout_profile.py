@@ -22,6 +22,8 @@ import torch  # noqa: E402
 from azul_deep_reinforcement_learning_amd import BatchedActorCritic, PolicyRollout  # noqa: E402
 
 opp = "random" if "--opponent" in sys.argv else None
+if "--net" in sys.argv:                                   # GameRunner(opponent=Agent(...)): the reply rounds' phases are added to the agent pass's
+    opp = BatchedActorCritic(136, 180, 180)
 WIN = int(sys.argv[sys.argv.index("--window") + 1]) if "--window" in sys.argv else 32
 torch.manual_seed(0)
 ro = PolicyRollout(BatchedActorCritic(136, 180, 180), n_games=4096, parts=1, window=WIN, opponent=opp, persistent=True)

@@ -29,6 +29,25 @@ def main():
     os.symlink(os.path.join(REF, "tests"), os.path.join(tmp, "reftests"))
     with open(os.path.join(tmp, "conftest.py"), "w") as fh:
         fh.write("import sys\nsys.path.insert(0, %r)\nsys.path.insert(0, %r)\n" % (ROOT, tmp))
+        # pytest-benchmark is not installed (no network): the three tests that take its `benchmark` fixture (tests/test_nn_runner.py:45-51,
+        # 84-90, 92-98) get a minimal stand-in -- the callable form and .pedantic(fn, args, kwargs, rounds, iterations) -- that RUNS the
+        # benchmarked function and reports its wall time; it measures nothing else
+        fh.write("import time, pytest\n"
+                 "class _Bench:\n"
+                 "    def __init__(self): self.seconds = []\n"
+                 "    def __call__(self, fn, *a, **k):\n"
+                 "        t0 = time.perf_counter(); out = fn(*a, **k); self.seconds.append(time.perf_counter() - t0); return out\n"
+                 "    def pedantic(self, fn, args=(), kwargs=None, rounds=1, iterations=1, warmup_rounds=0, setup=None):\n"
+                 "        out = None\n"
+                 "        for _ in range(max(1, rounds) * max(1, iterations)):\n"
+                 "            a, k = (setup() if setup else (args, kwargs or {}))\n"
+                 "            out = self(fn, *a, **(k or {}))\n"
+                 "        return out\n"
+                 "@pytest.fixture\n"
+                 "def benchmark(request):\n"
+                 "    b = _Bench()\n"
+                 "    yield b\n"
+                 "    if b.seconds: print('\\n[benchmark stand-in] %s: %d calls, mean %.3f s' % (request.node.name, len(b.seconds), sum(b.seconds) / len(b.seconds)))\n")
         if not hip:
             fh.write("from tests.hostcheck import hostcheck as hc\n"
                      "import azul_deep_reinforcement_learning_amd.facade_backend as fb\n"
@@ -38,8 +57,7 @@ def main():
            "--confcutdir", tmp,
            os.path.join(tmp, "reftests", "test_azul.py"), os.path.join(tmp, "reftests", "test_game_runner.py"),
            os.path.join(tmp, "reftests", "test_random_agent.py"), os.path.join(tmp, "reftests", "test_model.py"),
-           os.path.join(tmp, "reftests", "test_nn_runner.py"),
-           "-k", "not train_1_1 and not run_batch_agent and not run_batch_random"]   # the three pytest-benchmark tests (plugin not installed)
+           os.path.join(tmp, "reftests", "test_nn_runner.py")] + [a for a in sys.argv[1:] if a != "--hip"]
     print(" ".join(cmd))
     return subprocess.call(cmd, cwd=tmp, env=env)
 

@@ -120,6 +120,8 @@ SIGNATURES = {
     "azul_batch_set_id_base": (_i, [_vp, _u32]),
     "azul_batch_set_draw_margin": (_i, [_vp, _u64]),
     "azul_batch_segment_profile": (_i, [_vp, _vp, _i, _i]),
+    "azul_selfplay_kernel_resources": (_i, [_vp, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "azul_device_clock_probe": (_i, [_vp, _i, _vp]),
     "azul_timing_begin": (_i, [_vp, _vp]),
     "azul_timing_end": (_i, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(C.c_float), C.POINTER(_i)]),
     "azul_timing_launch_ms": (_i, [_vp, _vp, _i, C.POINTER(_i)]),

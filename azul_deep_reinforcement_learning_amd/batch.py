@@ -417,6 +417,18 @@ class BatchedAzul:
         """Test knob: widen the window in which the factory draw falls back to the literal fp64 computation."""
         L.check(L.lib.azul_batch_set_draw_margin(self._h, int(margin)))
 
+    def kernel_resources(self, padded_rows=True, mask_bits=False):
+        """Registers / LDS / scratch of the flat self-play kernel for this output shape and how many of its waves a CU holds at once
+        (the HIP runtime's occupancy calculator on the loaded code object)."""
+        v, lds, sc, wv = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        L.check(L.lib.azul_selfplay_kernel_resources(self._h, int(padded_rows), int(mask_bits), C.byref(v), C.byref(lds), C.byref(sc), C.byref(wv)))
+        return {"vgprs": v.value, "lds_bytes": lds.value, "scratch_bytes": sc.value, "resident_waves_per_cu": wv.value,
+                "resident_waves_per_simd": wv.value / 4.0}
+
+    def clock_probe(self, out, spin_iterations=20000):
+        """Enqueue the on-device shader-clock probe; `out`: int64[3] device tensor -> {shader cycles, 100 MHz ticks, chain result}."""
+        L.check(L.lib.azul_device_clock_probe(_ptr(out), int(spin_iterations), self._stream()))
+
     def timing_begin(self):
         L.check(L.lib.azul_timing_begin(self._h, self._stream()))
 

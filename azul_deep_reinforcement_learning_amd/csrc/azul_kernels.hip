@@ -141,7 +141,7 @@ extern "C" {
 const char *azul_last_error_string(void) { return g_err.c_str(); }
 const char *azul_version(void)
 {
-    return "azul-mi355x 0.5 (gfx950; two games per wavefront: two-player rule entries, self-play, policy rollout, 3 / 4 players and extended rules)";
+    return "azul-mi355x 0.6 (gfx950; two games per wavefront: two-player rule entries, self-play, policy rollout with random / network opponent, 3 / 4 players and extended rules)";
 }
 
 static void batch_free(azul_batch *b)
@@ -361,14 +361,17 @@ int azul_batch_seed(azul_batch_t *b, uint64_t seed_base, const uint64_t *seeds_h
     u64 *dseeds = nullptr;
     if (seeds_host) {
         HIP_TRY(hipMalloc((void **)&dseeds, (size_t)b->d.n * sizeof(u64)));
-        HIP_TRY(hipMemcpyAsync(dseeds, seeds_host, (size_t)b->d.n * sizeof(u64), hipMemcpyHostToDevice, (hipStream_t)stream));
+        hipError_t e = hipMemcpyAsync(dseeds, seeds_host, (size_t)b->d.n * sizeof(u64), hipMemcpyHostToDevice, (hipStream_t)stream);
+        if (e != hipSuccess) { (void)hipFree(dseeds); return fail(AZUL_ERR_HIP, "hipMemcpyAsync(seeds)", e); }
     }
     hipLaunchKernelGGL(azul_seed_kernel, dim3((b->d.n + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, b->d, (u64)seed_base, (const u64 *)dseeds);
-    HIP_TRY(hipGetLastError());
-    if (dseeds) {
-        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-        HIP_TRY(hipFree(dseeds));
+    hipError_t e = hipGetLastError();
+    if (dseeds) {                                        // the staging copy is released on every path (hipFree waits for the device)
+        const hipError_t e2 = e == hipSuccess ? hipStreamSynchronize((hipStream_t)stream) : hipSuccess;
+        (void)hipFree(dseeds);
+        if (e == hipSuccess) e = e2;
     }
+    if (e != hipSuccess) return fail(AZUL_ERR_HIP, "azul_batch_seed", e);
     return AZUL_SUCCESS;
 }
 
@@ -1108,6 +1111,37 @@ int azul_batch_segment_profile(azul_batch_t *b, uint64_t *cycles_host, int n, in
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(cycles_host, b->d.prof, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
     if (reset) HIP_TRY(hipMemset(b->d.prof, 0, SEG_COUNT * sizeof(u64)));
+    return AZUL_SUCCESS;
+}
+
+int azul_selfplay_kernel_resources(azul_batch_t *b, int padded_rows, int mask_bits, int *vgprs, int *lds_bytes, int *scratch_bytes,
+                                   int *resident_waves_per_cu)
+{
+    BATCH_GUARD(b, nullptr);
+    if (!b || b->x) return fail(AZUL_ERR_INVALID, "azul_selfplay_kernel_resources: two-player reference batches");
+    const bool lid = b->d.rules.tile_pool == POOL_LID;
+    const void *fn;
+    if (lid) fn = padded_rows ? (mask_bits ? (const void *)azul_selfplay2_kernel<true, 1, true, true> : (const void *)azul_selfplay2_kernel<true, 1, true, false>)
+                              : (mask_bits ? (const void *)azul_selfplay2_kernel<true, 1, false, true> : (const void *)azul_selfplay2_kernel<true, 2, false, false>);
+    else fn = padded_rows ? (mask_bits ? (const void *)azul_selfplay2_kernel<false, 1, true, true> : (const void *)azul_selfplay2_kernel<false, 1, true, false>)
+                          : (mask_bits ? (const void *)azul_selfplay2_kernel<false, 1, false, true> : (const void *)azul_selfplay2_kernel<false, 2, false, false>);
+    hipFuncAttributes at;
+    HIP_TRY(hipFuncGetAttributes(&at, fn));
+    int blocks = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64, 0));
+    if (vgprs) *vgprs = at.numRegs;
+    if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes;
+    if (scratch_bytes) *scratch_bytes = (int)at.localSizeBytes;
+    if (resident_waves_per_cu) *resident_waves_per_cu = blocks;      // one-wave workgroups
+    return AZUL_SUCCESS;
+}
+
+int azul_device_clock_probe(uint64_t *out_dev, int spin_iterations, void *stream)
+{
+    if (!out_dev || spin_iterations <= 0) return fail(AZUL_ERR_INVALID, "azul_device_clock_probe: bad arguments");
+    STREAM_GUARD(stream);
+    hipLaunchKernelGGL(azul_clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (u64 *)out_dev, (u32)spin_iterations);
+    HIP_TRY(hipGetLastError());
     return AZUL_SUCCESS;
 }
 

@@ -1082,4 +1082,17 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     return ret;
 }
 
+// A slot of a game that a rule error stopped earlier in this launch (crafted states only: box and lid empty when a round has to be dealt;
+// the reference raises, azul.py:86-87): no move is played -- the slot is marked like a stuck slot (no legal action, action -1, done 2) and
+// counted with them, so that whoever counts env moves as slots minus `stuck` stays right and the trajectory carries no stale bytes
+// (azul_rules_x.hpp does the same for three / four players).
+template <int OUT, bool PAD, bool BITS>
+AZ_FN void dead_slot2(const G2 &g, const Out2 &o, Counters2 &cnt, u32 l)
+{
+    cnt.stuck_add += 1u;
+    if (OUT == 1 || (OUT == 2 && o.mask)) store_mask_row2<(PAD && OUT == 1)>(o, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, l);
+    if ((OUT == 1 && BITS) || (OUT == 2 && o.maskbits)) o.maskbits[o.e * 3u + (l < 2u ? l : 2u)] = 0ull;
+    outputs2<OUT>(g, o, -1, 0, 2u, l);
+}
+
 } // namespace az2

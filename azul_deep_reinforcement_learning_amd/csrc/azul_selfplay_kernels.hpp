@@ -78,6 +78,20 @@ __global__ void __launch_bounds__(64) azul_returns_ring_kernel(const i32 *__rest
     }
 }
 
+// DIAGNOSTIC: the shader clock the device really runs at, measured ON the device: one wave runs a fixed chain of dependent vector operations
+// between two readings of s_memtime (shader-clock cycles) and s_memrealtime (a constant 100 MHz counter); out[0] / out[1] x 100 MHz is the
+// clock the wave saw.  bench.py launches it between the blocks of its sustained phase, beside the driver's reported clock.
+__global__ void __launch_bounds__(64) azul_clock_probe_kernel(u64 *out, u32 iters)
+{
+    const u64 r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    u32 v = threadIdx.x;
+#pragma unroll 1
+    for (u32 i = 0; i < iters; i++) v = v * 1664525u + 1013904223u;
+    asm volatile("" : "+v"(v));
+    const u64 c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; out[2] = (u64)v; }
+}
+
 struct TrajArgs {
     int n_steps;
     uint8_t *mask;     // [T][N][180]
@@ -134,11 +148,13 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
     SegProf *pp = nullptr;
 #endif
     // A uniform counted loop (scalar loop control: a per-game `break` costs ~16 exec-mask instructions per move).  A game stopped by a
-    // rule error (box and lid empty when a round has to be dealt: crafted states only) stays as it is: its lanes skip the later moves.
+    // rule error (box and lid empty when a round has to be dealt: crafted states only) stays as it is: its later slots are marked and counted
+    // like stuck slots (az2::dead_slot2).
     bool dead = false;               // (set inside the rare blocks only: the common path carries no test for it)
 #pragma unroll 1
     for (int s = 0; s < t.n_steps; s++) {
         if (!dead) az2::selfplay_step2<LID, OUT, PAD, BITS>(g, b.rules.first_player, k, r, tab, margin, cnt, o, pp, dead);
+        else az2::dead_slot2<OUT, PAD, BITS>(g, o, cnt, l);
         o.e += b.n;
     }
 #if defined(AZ_PROFILE_SEGMENTS)

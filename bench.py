@@ -230,9 +230,11 @@ def policy_vs_policy(games, seed_base=0, window=32, windows=40):
 
 
 def saturated(seed_base=0, chunk=512):
-    """The headline kernel with more games than BASELINE configs[1] gives a GPU: 8192 games = four waves per SIMD, 32768 games = the
-    whole of configs[3] on ONE GPU (eight waves per SIMD, two rounds).  Same kernel, same outputs, kernel time from the library's event pairs.
-    Not the metric's workload: it shows what the instruction-issue bound leaves on the table at 4096 games."""
+    """The headline kernel on LARGER GRIDS than BASELINE configs[1] gives a GPU: 8192 games and 32768 games (the whole of configs[3] on ONE
+    GPU).  Same kernel, same outputs, kernel time from the library's event pairs.  The kernel's register allocation admits TWO resident
+    waves per SIMD whatever the grid (kernel_resources: the HIP runtime's occupancy calculator on the loaded code object), so these runs
+    do NOT raise occupancy: they oversubscribe the grid 2x / 8x -- finished workgroups are backfilled at once and the launch's tail
+    (waves of a last partial round, games that hit rare paths) weighs less.  Not the metric's workload."""
     import torch
     from azul_deep_reinforcement_learning_amd import BatchedAzul
     res = {}
@@ -255,12 +257,21 @@ def saturated(seed_base=0, chunk=512):
         dt = time.perf_counter() - t0
         moves = G * chunk * launches - (int(env.counters()["stuck"].sum()) - stuck0)
         avg = kms / max(kn, 1)
+        try:
+            kr = env.kernel_resources(padded_rows=True, mask_bits=False)
+        except Exception as e:
+            kr = {"error": repr(e)}
+        grid_wps = G / 2 / 1024.0
         res["games_%d" % G] = {"value": moves / dt, "unit": "env steps/s", "kernel_env_steps_per_s": G * chunk / (avg / 1e3), "avg_launch_ms": avg,
-                               "launches": launches, "waves_per_simd": G / 2 / 1024.0,
+                               "launches": launches, "grid_waves_per_simd": grid_wps,
+                               "resident_waves_per_simd": min(grid_wps, kr["resident_waves_per_simd"]) if "resident_waves_per_simd" in kr else None,
+                               "grid_oversubscription": grid_wps / kr["resident_waves_per_simd"] if kr.get("resident_waves_per_simd") else None,
                                "nominal_hbm_frac": ALGO_BYTES_PER_STEP * G * chunk / (avg / 1e3) / 1e9 / HBM_PEAK_GBS}
+        res["kernel_resources"] = kr
         del env, b
         torch.cuda.empty_cache()
     res["kernel"] = "azul_selfplay2_kernel (the headline kernel; %d moves per launch)" % chunk
+    res["note"] = "oversubscribed grids at the SAME resident occupancy (two waves per SIMD: register-limited), not higher occupancy"
     return res
 
 
@@ -475,6 +486,99 @@ def players_selfplay(games, chunk=256, launches=6):
     return res
 
 
+class Telemetry:
+    """GPU clock / socket power / hotspot temperature sampled from a SIDE THREAD of this process through the amdsmi Python bindings (reads
+    of the driver's metrics table: no new process, no HIP call, nothing re-executed) while the sustained launches run -- the evidence beside
+    `sustained`'s block means for WHY the launch time steps up.  Unavailable bindings / metrics are reported, never guessed."""
+
+    def __init__(self, dev_index, period_s=0.02):
+        import threading
+        self.samples, self.error, self.period, self._stop = [], None, period_s, threading.Event()
+        self.power_limit_w = None
+        try:
+            for pth in ("/opt/rocm/share/amd_smi", "/opt/rocm/libexec/amdsmi_cli"):
+                if pth not in sys.path and os.path.isdir(pth):
+                    sys.path.append(pth)
+            import amdsmi
+            self.smi = amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            self.h = hs[dev_index if dev_index < len(hs) else 0]
+            try:
+                lim = amdsmi.amdsmi_get_power_info(self.h).get("power_limit")
+                self.power_limit_w = float(lim) / 1e6 if isinstance(lim, (int, float)) and lim > 1e5 else (float(lim) if isinstance(lim, (int, float)) else None)
+            except Exception:
+                pass
+        except Exception as e:
+            self.smi, self.error = None, repr(e)
+        self.thread = threading.Thread(target=self._run, daemon=True) if self.smi else None
+
+    def _num(self, v):
+        return float(v) if isinstance(v, (int, float)) else None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                m = self.smi.amdsmi_get_gpu_metrics_info(self.h)
+                p = self.smi.amdsmi_get_power_info(self.h)
+                self.samples.append((time.perf_counter(), self._num(m.get("current_gfxclk")), self._num(p.get("current_socket_power")),
+                                     self._num(m.get("temperature_hotspot")), self._num(m.get("current_uclk"))))
+            except Exception as e:
+                self.error = repr(e)
+                return
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self.thread:
+            self.thread.start()
+
+    def stop(self):
+        self._stop.set()
+        if self.thread:
+            self.thread.join(timeout=2.0)
+
+    def window(self, t0, t1):
+        """Means of the samples taken in [t0, t1] (host clock)."""
+        rows = [r for r in self.samples if t0 <= r[0] <= t1]
+        out = {"samples": len(rows)}
+        for i, key in ((1, "sclk_mhz"), (2, "power_w"), (3, "temp_hotspot_c"), (4, "mclk_mhz")):
+            vals = [r[i] for r in rows if r[i] is not None]
+            out[key] = sum(vals) / len(vals) if vals else None
+        return out
+
+
+def never_ending_games(env, run, games, rounds_threshold=100, launches=20):
+    """Games of the batch that have been in ONE episode for more than `rounds_threshold` rounds (a game of the reference lasts ~5, at most
+    ~15): under the reference's rules with random play a game can reach a state from which it never ends -- e.g. all 20 tiles of one colour
+    locked in pattern lines that cannot be completed any more -- and GameRunner's `while not done` loops for ever (the reference would too).
+    Such a game keeps its slot and, with short rounds (a deal and a scoring every ~9 moves), its wave is slower per move.  Evidence, measured
+    here: the launch time with these games, and with their records replaced by a neighbour's (AFTER every parity gate; the batch is
+    discarded afterwards)."""
+    import numpy as np
+    recs = env.get_records()
+    odd = np.flatnonzero(recs["turn_counter"] >= rounds_threshold)
+    out = {"count": int(len(odd)), "first_ids": [int(x) for x in odd[:8]], "rounds_threshold": rounds_threshold,
+           "rounds_played_in_their_current_episode": [int(recs["turn_counter"][x]) for x in odd[:8]]}
+    if len(odd) == 0 or len(odd) > games // 2:
+        return out
+
+    def launch_ms():
+        env.timing_begin()
+        for _ in range(launches):
+            run(1)
+        _, _, kms, kn = env.timing_end()
+        return kms / max(kn, 1)
+
+    out["launch_ms_with"] = launch_ms()
+    recs = env.get_records()
+    good = np.flatnonzero(recs["turn_counter"] < rounds_threshold)
+    for i, g in enumerate(odd):
+        recs[g] = recs[good[(int(g) + 1 + i) % len(good)]]
+    env.set_records(recs)
+    out["launch_ms_replaced"] = launch_ms()
+    return out
+
+
 WATCHDOG_EXIT_CODE = 3
 
 
@@ -543,7 +647,7 @@ def start_watchdog(timeout_s, rank, out, phase, _exit=os._exit, what="secondary 
         if rank == 0 and out is not None:
             out["extra"] = err
             print(json.dumps(out), flush=True)
-        elif rank == 0 and what != "secondary measurements":
+        elif rank == 0 and what == "headline measurement":        # (a final-barrier timeout adds no second JSON line: rank 0's line is out)
             print(json.dumps(err), flush=True)
         sys.stdout.flush()
         sys.stderr.write("bench.py: watchdog fired on rank %d in phase '%s'\n" % (rank, phase[0]))
@@ -674,33 +778,95 @@ def main():
     total_moves = float(moves.item())
     gathered_per_launch = (gather.gathered_bytes // max(W + K, 1)) if gather is not None else 0
 
-    # ---- sustained: the same step, the same buffers, S further launches (~0.8 s at N = 1) after the timed region; not `value`, a check on it
+    # ---- sustained: the same step, the same buffers, S further launches (~0.8 s at N = 1) after the timed region, in TEN BLOCKS with a host
+    #      synchronisation between them (ten ~20 us gaps in ~0.8 s) so that each block has a wall time, a move count and the clock / power /
+    #      temperature samples that fall inside it.  `value_sustained` = the LAST block's whole-job rate: the planning number.
     sustained = None
+    value_sustained = None
     S = args.sustained
     if S > 0:
+        NB = min(10, S)
+        sizes = [S // NB + (1 if i >= NB - S % NB else 0) for i in range(NB)]      # S launches in NB blocks (a remainder goes to the last ones)
+        tele = Telemetry(dev_index) if rank == 0 else None
         coll_.barrier("barrier before the sustained launches")
         torch.cuda.synchronize()
-        stuck1 = int(env.counters()["stuck"].sum())
+        if tele:
+            tele.start()
+        stuck_b = int(env.counters()["stuck"].sum())
         t0 = time.perf_counter()
         if gather is not None:
             coll_.enter("sustained launches + trajectory all-gather")
         env.timing_begin()
-        run(S)
+        marks, b_moves = [t0], []
+        probes = torch.zeros(NB + 1, 3, dtype=torch.int64, device=dev)      # the shader clock as a wave sees it, before block 0 and after every block
+        env.clock_probe(probes[0])
+        for bi, nl in enumerate(sizes):
+            run(nl)
+            env.clock_probe(probes[bi + 1])
+            torch.cuda.synchronize()
+            marks.append(time.perf_counter())
+            sk = int(env.counters()["stuck"].sum())
+            b_moves.append(float(G * nl * T - (sk - stuck_b)))
+            stuck_b = sk
         s_bracket, _, s_kms, s_kn = env.timing_end()
         torch.cuda.synchronize()
         coll_.barrier("barrier after the sustained launches")
         torch.cuda.synchronize()
-        s_el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        s_moves = torch.tensor([float(G * S * T - (int(env.counters()["stuck"].sum()) - stuck1))], dtype=torch.float64, device=dev)
+        t_end = time.perf_counter()
+        if tele:
+            tele.stop()
+        s_el = torch.tensor([t_end - t0], dtype=torch.float64, device=dev)
+        s_moves = torch.tensor([sum(b_moves)], dtype=torch.float64, device=dev)
+        b_wall = torch.tensor([marks[i + 1] - marks[i] for i in range(NB)], dtype=torch.float64, device=dev)
+        b_mv = torch.tensor(b_moves, dtype=torch.float64, device=dev)
         coll_.all_reduce(s_el, dist.ReduceOp.MAX, "all-reduce (max) of the sustained region's elapsed time")
         coll_.all_reduce(s_moves, dist.ReduceOp.SUM, "all-reduce (sum) of the sustained region's env moves")
+        coll_.all_reduce(b_wall, dist.ReduceOp.MAX, "all-reduce (max) of the sustained blocks' wall times")
+        coll_.all_reduce(b_mv, dist.ReduceOp.SUM, "all-reduce (sum) of the sustained blocks' env moves")
         if rank == 0:
             series = env.timing_launch_ms()
-            nb = max(1, len(series) // 10)
-            blocks = [sum(series[i:i + nb]) / len(series[i:i + nb]) for i in range(0, len(series), nb)][:10]
+            edges = [sum(sizes[:i]) for i in range(NB + 1)]
+            blocks = [sum(series[edges[i]:edges[i + 1]]) / max(len(series[edges[i]:edges[i + 1]]), 1) for i in range(NB) if edges[i] < len(series)]
             per = sorted(series)
+            b_rate = [float(b_mv[i].item()) / float(b_wall[i].item()) for i in range(NB)]
+            value_sustained = b_rate[-1]
+            tb = [tele.window(marks[i], marks[i + 1]) for i in range(NB)] if tele else [{} for _ in range(NB)]
+            pr = probes.cpu().tolist()
+            probe_mhz = [100.0 * c / r if r else None for c, r, _ in pr]
+            for i in range(NB):
+                tb[i]["device_clock_probe_mhz_after_block"] = probe_mhz[i + 1]
+            # what this run measured, in words: the largest step between consecutive block means and what the telemetry did across it
+            note = "launch time is flat over the %d sustained launches (block means within %.1f %%)" % (S, 100.0 * (max(blocks) / min(blocks) - 1.0))
+            if blocks and max(blocks) / min(blocks) > 1.02:
+                jumps = [blocks[i + 1] / blocks[i] for i in range(len(blocks) - 1)]
+                j = max(range(len(jumps)), key=lambda i: jumps[i])
+                at_s = sum(float(b_wall[i].item()) for i in range(j + 1))
+                note = ("mean launch time goes from %.4f ms (block 0) to %.4f ms (block %d): %+.1f %%, the largest step (%+.1f %%) after block %d, "
+                        "~%.2f s into the sustained launches" % (blocks[0], blocks[-1], len(blocks) - 1, 100.0 * (blocks[-1] / blocks[0] - 1.0),
+                                                                 100.0 * (jumps[j] - 1.0), j, at_s))
+                m0, m9 = probe_mhz[1], probe_mhz[-1]
+                if m0 and m9:
+                    note += "; shader clock MEASURED ON THE DEVICE (s_memtime / s_memrealtime probe after the block) %.0f -> %.0f MHz (%+.1f %%)" % (m0, m9, 100.0 * (m9 / m0 - 1.0))
+                    note += (": the launch time follows the clock the waves really see (the kernel is issue-bound: time ~ 1 / clock)"
+                             if abs((m0 / m9) / (blocks[-1] / blocks[0]) - 1.0) < 0.04 else ": the effective clock alone does not account for the step")
+                c0, c9 = tb[0].get("sclk_mhz"), tb[-1].get("sclk_mhz")
+                p0, p9 = tb[0].get("power_w"), tb[-1].get("power_w")
+                if c0 and c9:
+                    note += "; driver-REPORTED shader clock (amdsmi current_gfxclk) %.0f -> %.0f MHz (%+.1f %%)" % (c0, c9, 100.0 * (c9 / c0 - 1.0))
+                    if p0 and p9:
+                        note += ", socket power %.0f -> %.0f W" % (p0, p9) + (" of a %.0f W limit" % tele.power_limit_w if tele and tele.power_limit_w else "")
+                elif tele is not None:
+                    note += "; clock / power telemetry unavailable here (%s)" % (tele.error or "no samples")
             sustained = {"launches": S, "env_steps_per_s": float(s_moves.item()) / float(s_el.item()), "seconds": float(s_el.item()),
                          "vs_value": float(s_moves.item()) / float(s_el.item()) / (total_moves / elapsed),
+                         "value_sustained": value_sustained, "value_sustained_vs_value": value_sustained / (total_moves / elapsed),
+                         "blocks": [dict({"wall_s": float(b_wall[i].item()), "env_steps_per_s": b_rate[i],
+                                          "mean_launch_ms": blocks[i] if i < len(blocks) else None}, **tb[i]) for i in range(NB)],
+                         "device_clock_probe_mhz_before_block0": probe_mhz[0],
+                         "telemetry": {"source": "amdsmi Python bindings (amdsmi_get_gpu_metrics_info: current_gfxclk, temperature_hotspot, current_uclk; "
+                                                 "amdsmi_get_power_info: current_socket_power), side thread of rank 0, %d ms period" % int(1e3 * (tele.period if tele else 0)),
+                                       "power_limit_w": tele.power_limit_w if tele else None, "samples": len(tele.samples) if tele else 0,
+                                       "error": tele.error if tele else None},
                          "launch_ms": {"n": len(per), "min": per[0], "p50": per[len(per) // 2], "p99": per[min(len(per) - 1, int(len(per) * 0.99))],
                                        "max": per[-1], "mean": s_kms / max(s_kn, 1),
                                        "means_of_ten_consecutive_blocks": blocks,
@@ -709,9 +875,21 @@ def main():
                          if per else None,
                          "event_bracket_ms": s_bracket,
                          "parity_gate": parity_gate(env, G, base, gate_moves + (K + S) * T, budget=2500000),
-                         "note": "after the timed region: same buffers, same launches (N > 1: same all-gather), launch durations from the "
-                                 "library's event pairs (rank 0's GPU); `value` is NOT taken from here.  The block means show the clock "
-                                 "coming down under sustained load (a step of ~+10 % in launch time after ~0.45 s on the boxes measured)"}
+                         "note": "after the timed region: same buffers, same launches (N > 1: same all-gather) in ten blocks with a host synchronisation "
+                                 "between them; launch durations from the library's event pairs (rank 0's GPU); `value` is NOT taken from here, "
+                                 "`value_sustained` is the last block's whole-job rate.  This run: " + note}
+            def run_local(n_launches):                       # (this rank's kernel alone: no collective outside the lock-step regions)
+                for _ in range(n_launches):
+                    env.selfplay(T, bufs[0]["mask"], bufs[0]["action"], bufs[0]["reward"], bufs[0]["done"], maskbits=bufs[0].get("maskbits"),
+                                 packed=bufs[0]["packed"])
+            sustained["never_ending_games"] = never_ending_games(env, run_local, G)
+            ne = sustained["never_ending_games"]
+            if ne.get("count"):
+                sustained["note"] += ("; CAUSE of the step in this run: %d of the %d games (first ids %s) are NEVER-ENDING under the reference's rules -- every "
+                                      "tile of one colour is locked in pattern lines that can no longer be completed, so no wall row can ever be "
+                                      "filled (azul.py:184-191 stays false) and the game plays short rounds for ever; such a game's wave is slower per move "
+                                      "and a launch lasts as long as its slowest wave: launch %.4f ms with them, %.4f ms with their records replaced by a "
+                                      "neighbour's (never_ending_games)" % (ne["count"], G, ne["first_ids"], ne["launch_ms_with"], ne["launch_ms_replaced"]))
 
     out = None
     if rank == 0:
@@ -749,10 +927,17 @@ def main():
                                                      "waves_per_simd")})
                 issue["note"] = ("not measured in this run: %s.  hw_frac prices the kernel's vector instructions (PMC class counts x pipe cycles per "
                                  "wave64 instruction on a SIMD-32) against the SIMD cycles of the launch; occupancy_frac is the kernel against itself "
-                                 "with four waves per SIMD (8192 games), not a hardware bound" % ij.get("source", isf))
+                                 "on an 8192-game grid -- an OVERSUBSCRIBED grid at the same two resident waves per SIMD (roofline.kernel_resources: "
+                                 "the register allocation admits no more), i.e. what workgroup backfill and a shorter tail give, not higher occupancy "
+                                 "and not a hardware bound" % ij.get("source", isf))
             except Exception:
                 issue = None
         kernel_name = "azul_selfplay2_kernel"
+        try:                                             # registers / LDS of the launched instantiation and its RESIDENT occupancy (HIP runtime, loaded code object)
+            kres = env.kernel_resources(padded_rows=args.mask_pitch >= 192 and args.mask_pitch % 8 == 0, mask_bits=want_bits)
+            kres["grid_waves_per_simd"] = G / 2 / 1024.0
+        except Exception as e:
+            kres = {"error": repr(e)}
         coll = "RCCL" if backend == "nccl" else backend
         if gather:
             par = ("games sharded by global id (rank r owns games [%d r, %d (r + 1))), no data-path collective; the one exchange step is the %s "
@@ -766,6 +951,9 @@ def main():
         out = {
             "metric": "Azul env steps/sec (random-agent self-play), bit-exact vs CPU",
             "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            # `value` is the contract's number: K launches (~15 ms at N = 1), i.e. the boost-clock window.  `value_sustained` is the whole-job
+            # rate of the LAST of ten blocks of `sustained` (~0.8 s later, clock settled): the planning number (README / NUMBERS quote both)
+            "value_sustained": value_sustained,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/u32 (+f64 sampling)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: %d concurrent 2-player games per GPU, RandomAgent vs RandomAgent, "
@@ -785,7 +973,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_gbs": traffic_gbs, "traffic_frac": (traffic_gbs / HBM_PEAK_GBS) if traffic_gbs else None,
+                         "frac_sustained": (ALGO_BYTES_PER_STEP * G * T / (sustained["launch_ms"]["means_of_ten_consecutive_blocks"][-1] / 1e3) / 1e9 / HBM_PEAK_GBS)
+                         if sustained and sustained.get("launch_ms") else None,
                          "kernel": kernel_name, "avg_launch_ms": avg_launch_s * 1e3, "launches_timed": kern_launches,
+                         "kernel_resources": kres,
                          "event_bracket_ms": bracket_ms, "host_elapsed_ms": elapsed * 1e3,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * G * T, "scope": "rank 0's GPU",
                          "limiter": "instruction issue / dependent-issue latency at two waves per SIMD, not HBM (DESIGN.md 3)",
@@ -836,8 +1027,13 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        # the last collective runs under a deadline of its own like every other one: a rank that left early must not keep the rest waiting
+        # (rank 0's line is already out: the watchdog only reports and exits non-zero)
+        fphase = Phase(["final barrier"])
+        fwd = start_watchdog(120, rank, None, fphase, what="final barrier")
+        Collectives(dist, world, fphase).barrier("final barrier")
         dist.destroy_process_group()
+        fwd.cancel()
 
 
 if __name__ == "__main__":

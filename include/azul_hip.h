@@ -488,6 +488,20 @@ int azul_batch_set_draw_margin(azul_batch_t *b, uint64_t margin);
  * build returns zeros.  Synchronises the device. */
 int azul_batch_segment_profile(azul_batch_t *b, uint64_t *cycles_host, int n, int reset);
 
+/* DIAGNOSTIC: what the flat self-play kernel that azul_batch_selfplay_strided launches for this batch (tile pool) and output shape
+ * (padded_rows: mask rows of >= 192 bytes; mask_bits: bit-packed masks as well) occupies, read from the loaded code object by the HIP
+ * runtime: allocated vector registers per lane, static LDS and scratch bytes per workgroup (= per wave: one-wave workgroups), and how many
+ * of its waves a CU can hold at once (hipOccupancyMaxActiveBlocksPerMultiprocessor) -- the RESIDENT occupancy, whatever the grid size.
+ * The reference has no counterpart. */
+int azul_selfplay_kernel_resources(azul_batch_t *b, int padded_rows, int mask_bits, int *vgprs, int *lds_bytes, int *scratch_bytes,
+                                   int *resident_waves_per_cu);
+
+/* DIAGNOSTIC: the shader clock as a wave sees it.  One wavefront runs `spin_iterations` dependent vector operations between two readings of
+ * s_memtime (shader-clock cycles) and s_memrealtime (constant 100 MHz); out_dev (uint64[3], device memory) receives {shader cycles,
+ * 100 MHz ticks, the chain's result}: out[0] / out[1] x 100 = MHz.  Asynchronous on `stream`.  bench.py's sustained phase launches it
+ * between blocks of the headline kernel, beside the driver-reported clock (amdsmi).  The reference has no counterpart. */
+int azul_device_clock_probe(uint64_t *out_dev, int spin_iterations, void *stream);
+
 /* device time of azul_batch_selfplay launches, measured with hipEvents on the launch stream: call azul_timing_begin, launch
  * any number of selfplay calls, then azul_timing_end (synchronises the stream).  total_ms / launches: the event bracket from
  * begin to end and the launches inside it; kernel_ms / kernel_launches: the sum of the event pairs recorded immediately

@@ -122,6 +122,7 @@ SIGNATURES = {
     "azul_batch_segment_profile": (_i, [_vp, _vp, _i, _i]),
     "azul_selfplay_kernel_resources": (_i, [_vp, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "azul_device_clock_probe": (_i, [_vp, _i, _vp]),
+    "azul_pack_c1": (_i, [_vp] * 10 + [_i, _i, _vp, _vp]),
     "azul_timing_begin": (_i, [_vp, _vp]),
     "azul_timing_end": (_i, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(_i), C.POINTER(C.c_float), C.POINTER(_i)]),
     "azul_timing_launch_ms": (_i, [_vp, _vp, _i, C.POINTER(_i)]),

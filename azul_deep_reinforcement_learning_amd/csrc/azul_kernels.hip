@@ -1136,6 +1136,24 @@ int azul_selfplay_kernel_resources(azul_batch_t *b, int padded_rows, int mask_bi
     return AZUL_SUCCESS;
 }
 
+int azul_pack_c1(const float *obs_dev, const uint8_t *mask_dev, const uint8_t *player_dev, const int32_t *action_dev, const int32_t *reward_dev,
+                 const uint8_t *done_dev, const float *value_dev, const float *logp_dev, const float *entropy_dev, const float *returns_dev,
+                 int n_steps, int n_games, uint8_t *records_dev, void *stream)
+{
+    if (!obs_dev || !mask_dev || !player_dev || !action_dev || !reward_dev || !done_dev || !value_dev || !logp_dev || !entropy_dev || !returns_dev ||
+        !records_dev || n_steps < 0 || n_games <= 0 || (uint64_t)n_steps * (uint64_t)n_games * 46u >= (1ull << 32))
+        return fail(AZUL_ERR_INVALID, "azul_pack_c1: bad arguments");
+    if (((uintptr_t)obs_dev & 15u) != 0 || ((uintptr_t)mask_dev & 3u) != 0 || ((uintptr_t)records_dev & 3u) != 0)
+        return fail(AZUL_ERR_INVALID, "azul_pack_c1: obs_dev must be 16-byte aligned, mask_dev and records_dev 4-byte aligned");
+    if (n_steps == 0) return AZUL_SUCCESS;
+    STREAM_GUARD(stream);
+    PackC1Args a = {obs_dev, mask_dev, player_dev, action_dev, reward_dev, done_dev, value_dev, logp_dev, entropy_dev, returns_dev, (u32 *)records_dev,
+                    (u32)n_steps * (u32)n_games};
+    hipLaunchKernelGGL(azul_pack_c1_kernel, dim3((a.cells * 46u + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return AZUL_SUCCESS;
+}
+
 int azul_device_clock_probe(uint64_t *out_dev, int spin_iterations, void *stream)
 {
     if (!out_dev || spin_iterations <= 0) return fail(AZUL_ERR_INVALID, "azul_device_clock_probe: bad arguments");

@@ -92,6 +92,53 @@ __global__ void __launch_bounds__(64) azul_clock_probe_kernel(u64 *out, u32 iter
     if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; out[2] = (u64)v; }
 }
 
+// The C1 wire record of the opt-in trajectory all-gather (BASELINE configs[4]; what NNRunner.run_episode keeps per agent step, nn_runner.py:17-47,
+// and NNRunner.train concatenates, nn_runner.py:59-78), 184 bytes = 46 dwords per (step, game) cell -- layout in include/azul_hip.h.  One
+// thread per OUTPUT dword: consecutive threads write consecutive dwords (coalesced 256-byte rows per wave) and read consecutive 16-byte
+// pieces of the observation; HBM-bound: 544 + 180 + 26 bytes in, 184 out per cell.
+struct PackC1Args {
+    const float *obs;        // [cells][136]
+    const uint8_t *mask;     // [cells][180]
+    const uint8_t *player;   // [cells]
+    const i32 *action;       // [cells]
+    const i32 *reward;
+    const uint8_t *done;
+    const float *value, *logp, *entropy, *returns;
+    u32 *out;                // [cells][46]
+    u32 cells;
+};
+
+__global__ void __launch_bounds__(256) azul_pack_c1_kernel(PackC1Args a)
+{
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.cells * 46u) return;
+    const u32 cell = i / 46u, d = i - 46u * cell;
+    u32 w = 0;
+    if (d < 34u) {                                       // bytes 0..135: the observation's integers (0..255 for every state the rules reach)
+        const float4 v = *(const float4 *)(a.obs + (size_t)cell * 136u + 4u * d);
+        w = ((u32)(i32)v.x & 0xffu) | (((u32)(i32)v.y & 0xffu) << 8) | (((u32)(i32)v.z & 0xffu) << 16) | (((u32)(i32)v.w & 0xffu) << 24);
+    } else if (d < 40u) {                                // bytes 136..159: the 180 legal-move bits, bit a & 7 of byte a >> 3
+        const u32 k = d - 34u, nd = k < 5u ? 8u : 5u;    // actions 32 k .. 32 k + 31 = dwords 8 k .. of the 45-dword mask row
+        const u32 *row = (const u32 *)(a.mask + (size_t)cell * 180u) + 8u * k;
+#pragma unroll
+        for (u32 j = 0; j < 8u; j++) {
+            const u32 m = j < nd ? row[j] : 0u;
+            w |= ((m & 0xffu) != 0u ? 1u : 0u) << (4u * j);
+            w |= ((m & 0xff00u) != 0u ? 1u : 0u) << (4u * j + 1u);
+            w |= ((m & 0xff0000u) != 0u ? 1u : 0u) << (4u * j + 2u);
+            w |= ((m & 0xff000000u) != 0u ? 1u : 0u) << (4u * j + 3u);
+        }
+    } else if (d == 40u) {
+        const i32 av = a.action[cell];
+        w = (av < 0 ? 0xffu : (u32)av & 0xffu) | ((u32)a.done[cell] << 8) | ((u32)a.player[cell] << 16);
+    } else if (d == 41u) w = (u32)a.reward[cell];
+    else {
+        const float *src = d == 42u ? a.value : d == 43u ? a.logp : d == 44u ? a.entropy : a.returns;
+        w = __builtin_bit_cast(u32, src[cell]);
+    }
+    a.out[i] = w;
+}
+
 struct TrajArgs {
     int n_steps;
     uint8_t *mask;     // [T][N][180]

@@ -47,13 +47,32 @@ C1_BYTES = 184
 
 
 def pack_c1(tr, n_steps, out=None):
-    """One window of a PolicyRollout trajectory (dict of [T(+1)][G][..] tensors) -> uint8 [T][G][184].  Plain torch ops on the tensors'
-    device (CPU tensors in the gloo tests, HBM on the GPU): glue in front of a collective, not a kernel of the path."""
+    """One window of a PolicyRollout trajectory (dict of [T(+1)][G][..] tensors) -> uint8 [T][G][184].  Tensors in HBM are packed by ONE
+    launch of the library's azul_pack_c1 kernel on the current stream (the producer in front of the trajectory all-gather: no torch op
+    touches the data path); the torch restatement below only serves host tensors -- the world-size-2 gloo tests on CPU, and the GPU test
+    that holds the kernel to it byte for byte."""
     T = int(n_steps)
     obs, mask = tr["obs"][:T], tr["mask"][:T]
     G = obs.shape[1]
     if out is None:
         out = torch.empty(T, G, C1_BYTES, dtype=torch.uint8, device=obs.device)
+    if obs.is_cuda:
+        import ctypes as C
+        from . import _lib as L
+        p = lambda t: C.c_void_p(t.data_ptr())
+        need = {"obs": obs, "mask": mask, "player": tr["player"][:T], "action": tr["action"][:T], "reward": tr["reward"][:T], "done": tr["done"][:T],
+                "value": tr["value"][:T], "log_prob": tr["log_prob"][:T], "entropy": tr["entropy"][:T], "returns": tr["returns"][:T]}
+        want = {"obs": torch.float32, "mask": torch.uint8, "player": torch.uint8, "action": torch.int32, "reward": torch.int32, "done": torch.uint8}
+        for k, t in need.items():
+            if not t.is_contiguous() or t.dtype != want.get(k, torch.float32):
+                raise ValueError("pack_c1: `%s` must be a contiguous %s tensor (the rollout's own buffers are)" % (k, want.get(k, torch.float32)))
+        if not out.is_contiguous() or out.dtype != torch.uint8 or tuple(out.shape) != (T, G, C1_BYTES):
+            raise ValueError("pack_c1: `out` must be a contiguous uint8 [T][G][%d] tensor" % C1_BYTES)
+        with torch.cuda.device(obs.device):
+            L.check(L.lib.azul_pack_c1(p(obs), p(mask), p(need["player"]), p(need["action"]), p(need["reward"]), p(need["done"]), p(need["value"]),
+                                       p(need["log_prob"]), p(need["entropy"]), p(need["returns"]), T, G, p(out),
+                                       C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)))
+        return out
     out[..., :136] = obs.to(torch.uint8)
     w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=obs.device)
     bits = torch.zeros(T, G, 192, dtype=torch.int32, device=obs.device)

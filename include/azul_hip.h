@@ -436,6 +436,19 @@ int azul_discounted_returns(const int32_t *reward_dev, const uint8_t *done_dev, 
 int azul_discounted_returns_ring(const int32_t *reward_ring_dev, const uint8_t *done_ring_dev, float *returns_ring_dev, float gamma,
                                  int ring_steps, int64_t steps_played, int span_steps, int n_games, void *stream);
 
+/* The C1 WIRE RECORD of the trajectory all-gather BASELINE configs[4] names: one window of a policy rollout (the time-major arrays of
+ * azul_batch_policy_rollout*, [n_steps][n_games]...) packed to 184 bytes per agent step -- what NNRunner.run_episode keeps per step
+ * (nn_runner.py:17-47) and NNRunner.train concatenates over episodes before one update (nn_runner.py:59-78):
+ *     0 obs[136] u8 (the observation's integers, game_runner.py:65-72: 0..255 for every state the rules reach) | 136 maskbits[24] (the 180
+ *     legal-move bits, bit a & 7 of byte a >> 3) | 160 action u8 (0xff = none) | 161 done | 162 player to move | 163 zero |
+ *     164 reward i32 | 168 value f32 | 172 log-prob f32 | 176 entropy f32 | 180 discounted return f32
+ * records_dev: uint8 [n_steps][n_games][184].  One HBM-bound launch (750 bytes in, 184 out per step).  obs_dev 16-byte aligned,
+ * mask_dev / records_dev 4-byte aligned. */
+#define AZUL_C1_BYTES 184
+int azul_pack_c1(const float *obs_dev, const uint8_t *mask_dev, const uint8_t *player_dev, const int32_t *action_dev, const int32_t *reward_dev,
+                 const uint8_t *done_dev, const float *value_dev, const float *logp_dev, const float *entropy_dev, const float *returns_dev,
+                 int n_steps, int n_games, uint8_t *records_dev, void *stream);
+
 /* ---- flat random-agent self-play (the benchmarked hot path) ----------------------------------- */
 /*
  * Advance every game by `n_steps` env moves in ONE launch: per move  mask -> RandomAgent -> Azul.step ->

@@ -54,6 +54,32 @@ long long sh2_selfplay(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 *ep
     return ops;
 }
 
+// azul_pack_c1_kernel (the C1 wire record of the opt-in trajectory all-gather), four emulated waves per workgroup
+static void pack_main(void *arg) { azul_pack_c1_kernel(*(PackC1Args *)arg); }
+long long sh2_pack_c1(const float *obs, const uint8_t *mask, const uint8_t *player, const i32 *action, const i32 *reward, const uint8_t *done,
+                      const float *value, const float *logp, const float *entropy, const float *returns, int cells, uint8_t *out)
+{
+    PackC1Args a = {obs, mask, player, action, reward, done, value, logp, entropy, returns, (u32 *)out, (u32)cells};
+    const unsigned blocks = ((unsigned)cells * 46u + 255u) / 256u;
+    simt::g_grid_dim = {blocks, 1, 1};
+    long long ops = 0;
+    for (unsigned blk = 0; blk < blocks; blk++) {
+        simt::g_block_idx = {blk, 0, 0};
+        ops += (long long)simt::run_workgroup(pack_main, &a, 4, simt::STACK_BYTES) + 1;
+    }
+    return ops;
+}
+
+// azul_clock_probe_kernel: runs to completion and writes its three words (the emulation's timers read 0)
+static void probe_main(void *arg) { azul_clock_probe_kernel((u64 *)arg, 50u); }
+int sh2_clock_probe(u64 *out3)
+{
+    simt::g_grid_dim = {1, 1, 1};
+    simt::g_block_idx = {0, 0, 0};
+    simt::run_workgroup(probe_main, out3, 1, simt::STACK_BYTES);
+    return 0;
+}
+
 // self-test of the emulated cross-lane operations against their definitions (lane l holds 100 + l)
 int sh2_selftest_result[8];
 static void selftest_lane(void *)

@@ -112,7 +112,12 @@ def test_single_gpu_line_keeps_its_shape():
     two = out["extra"]["policy_pytorch_two_streams"]
     assert two["value"] > 0 and "PyTorch-ROCm" in two["config"]["workload"]
     sat = out["extra"]["saturated"]
-    assert sat["games_8192"]["waves_per_simd"] == 4.0 and sat["games_32768"]["value"] > 0
+    # larger grids do NOT raise occupancy: the resident waves per SIMD come from the loaded code object (two: register-limited)
+    assert sat["games_8192"]["grid_waves_per_simd"] == 4.0 and sat["games_8192"]["resident_waves_per_simd"] == 2.0 and sat["games_32768"]["value"] > 0
+    assert sat["kernel_resources"]["vgprs"] > 128 and out["roofline"]["kernel_resources"]["resident_waves_per_simd"] == 2.0
+    assert out["value_sustained"] > 0 and len(out["sustained"]["blocks"]) == 10 and "never_ending_games" in out["sustained"]
+    vs = out["extra"]["policy_vs_policy"]
+    assert vs["value"] > 0 and vs["roofline"]["bound"] == "mfma" and 0.5 < vs["opponent_moves_per_agent_step"] < 2.0
 
 
 def test_watchdog_prints_the_headline_and_exits_non_zero(capsys):

@@ -210,3 +210,35 @@ def test_rule_error_stops_one_game_and_leaves_its_sibling_alone(variant):
     assert np.array_equal(action[:, 1], o["action"]) and np.array_equal(reward[:, 1], o["reward"]) and np.array_equal(done[:, 1], o["done"])
     assert np.array_equal(mask[:, 1, :180], o["mask"]) and state[1].tobytes() == streams[1].record().tobytes()
     assert int(pos[1]) == streams[1].rng_state()[1] and int(stuck[1]) == 0
+
+
+def test_pack_c1_kernel_under_emulation_equals_the_torch_restatement():
+    """azul_pack_c1_kernel (the producer in front of the C1 trajectory all-gather, nn_runner.py:17-47 / :59-78) compiled unmodified and run
+    as emulated workgroups, against parallel.pack_c1's host restatement: 184 bytes per (step, game), incl. a ragged last workgroup, negative
+    actions (0xff), every mask bit position and the four floats bit for bit."""
+    import torch
+    from azul_deep_reinforcement_learning_amd.parallel import C1_BYTES, pack_c1, unpack_c1
+    L = load()
+    L.sh2_pack_c1.restype = C.c_longlong
+    L.sh2_pack_c1.argtypes = [C.c_void_p] * 10 + [C.c_int, C.c_void_p]
+    rs = np.random.RandomState(4)
+    T, G = 3, 37
+    tr = {"obs": torch.from_numpy(rs.randint(0, 256, size=(T + 1, G, 136)).astype(np.float32)),
+          "mask": torch.from_numpy((rs.rand(T + 1, G, 180) < 0.3).astype(np.uint8)), "player": torch.from_numpy(rs.randint(1, 3, size=(T + 1, G)).astype(np.uint8)),
+          "action": torch.from_numpy(rs.randint(-1, 180, size=(T, G)).astype(np.int32)), "reward": torch.from_numpy(rs.randint(-40, 40, size=(T, G)).astype(np.int32)),
+          "done": torch.from_numpy(rs.randint(0, 3, size=(T, G)).astype(np.uint8)), "value": torch.from_numpy(rs.randn(T, G, 1).astype(np.float32)),
+          "log_prob": torch.from_numpy(rs.randn(T, G).astype(np.float32)), "entropy": torch.from_numpy(rs.rand(T, G).astype(np.float32)),
+          "returns": torch.from_numpy(rs.randn(T, G).astype(np.float32) * 9)}
+    tr["mask"][0, 0] = 1
+    tr["mask"][1, 5, 179] = 1
+    want = pack_c1(tr, T)
+    out = np.full((T, G, C1_BYTES), 0xEE, np.uint8)
+    a = {k: np.ascontiguousarray(v[:T].numpy()) for k, v in tr.items()}
+    assert L.sh2_pack_c1(ptr(a["obs"]), ptr(a["mask"]), ptr(a["player"]), ptr(a["action"]), ptr(a["reward"]), ptr(a["done"]), ptr(a["value"]),
+                         ptr(a["log_prob"]), ptr(a["entropy"]), ptr(a["returns"]), T * G, ptr(out)) > 0
+    assert np.array_equal(out, want.numpy())
+    u = unpack_c1(torch.from_numpy(out))
+    assert torch.equal(u["mask"], tr["mask"][:T]) and torch.equal(u["action"], tr["action"]) and torch.equal(u["returns"], tr["returns"])
+    probe = np.full(3, 7, np.uint64)
+    L.sh2_clock_probe.argtypes = [C.c_void_p]
+    assert L.sh2_clock_probe(ptr(probe)) == 0 and int(probe[0]) == 0 and int(probe[1]) == 0 and int(probe[2]) != 7      # (the emulation's timers read 0)

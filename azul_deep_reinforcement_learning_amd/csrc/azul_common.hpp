@@ -44,6 +44,7 @@ enum { T_ROWS = 31, T_BINADES = 8 };   // RandomAgent weight table of the 180-ac
 // s_memtime deltas are accumulated per segment and added to a global buffer when the wave ends.  The real kernel
 // contains no stamp; never quote the diagnostic build's run time, only its SHARES (tools/segment_profile.py).
 enum { SEG_MASK = 0, SEG_SAMPLE, SEG_MOVE, SEG_AFTERMOVE, SEG_TAIL, SEG_NEWROUND, SEG_SCORE, SEG_RESET, SEG_LOOP, SEG_COUNT };
+constexpr int AZ_PROF_SLOTS = 48;   // u64 slots of BatchDev::prof: the self-play kernel's SEG_COUNT segments, the rollout kernel's phases (0..8) and matrix sub-phases (16..31)
 #if defined(AZ_PROFILE_SEGMENTS)
 struct SegProf { u64 last; u64 acc[SEG_COUNT]; };
 // (null-safe: callers outside the self-play kernels pass no SegProf -- an unguarded store would be undefined behaviour, which the

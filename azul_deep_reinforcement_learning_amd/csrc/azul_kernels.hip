@@ -170,8 +170,8 @@ static int batch_alloc(azul_batch *b, int n_games, int first_player, int tile_po
     HIP_TRY(hipMalloc((void **)&b->d.episodes, N * sizeof(u64)));
     HIP_TRY(hipMalloc((void **)&b->d.stuck, N * sizeof(u32)));
     HIP_TRY(hipMalloc((void **)&b->d.stat_sum, N * 10 * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&b->d.prof, SEG_COUNT * sizeof(u64)));
-    HIP_TRY(hipMemset(b->d.prof, 0, SEG_COUNT * sizeof(u64)));
+    HIP_TRY(hipMalloc((void **)&b->d.prof, AZ_PROF_SLOTS * sizeof(u64)));
+    HIP_TRY(hipMemset(b->d.prof, 0, AZ_PROF_SLOTS * sizeof(u64)));
     {   // the sampler's table: built with CPython's very additions and checked entry by entry on this host (azul_tables.hpp)
         const int rows = 5 * (b->displays + 1) + 1;
         std::vector<double> hX((size_t)rows * 16);
@@ -1107,10 +1107,10 @@ int azul_batch_segment_profile(azul_batch_t *b, uint64_t *cycles_host, int n, in
 {
     BATCH_GUARD(b, nullptr);
     if (!b || !cycles_host || n < 1) return fail(AZUL_ERR_INVALID, "azul_batch_segment_profile: bad arguments");
-    if (n > SEG_COUNT) n = SEG_COUNT;
+    if (n > AZ_PROF_SLOTS) n = AZ_PROF_SLOTS;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(cycles_host, b->d.prof, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(b->d.prof, 0, SEG_COUNT * sizeof(u64)));
+    if (reset) HIP_TRY(hipMemset(b->d.prof, 0, AZ_PROF_SLOTS * sizeof(u64)));
     return AZUL_SUCCESS;
 }
 

@@ -57,7 +57,7 @@ __device__ __forceinline__ void pr2_request2(bool two, const __amdgpu_buffer_rsr
 // layer 1 of one wave: NP pairs of adjacent hidden columns per lane (8-byte loads), 136-deep, one 16-row tile
 template <int NP>
 __device__ __forceinline__ void pr2_layer1(const __amdgpu_buffer_rsrc_t rs1, u32 voffA, u32 voffB, const float *ap, const float2 (&preA)[PR2_HOIST1],
-                                           const float2 (&preB)[PR2_HOIST1], pf_f32x4 (&acc)[4])
+                                           const float2 (&preB)[PR2_HOIST1], pf_f32x4 (&acc)[4], u64 *t_loop = nullptr /* diagnostic build: stamp at the loop's entry */)
 {
     float2 bwA[PF_IN / 4], bwB[PF_IN / 4];
 #pragma unroll
@@ -72,6 +72,7 @@ __device__ __forceinline__ void pr2_layer1(const __amdgpu_buffer_rsrc_t rs1, u32
 #pragma unroll
     for (int s = 0; s < PR2_ADEPTH; s++) af[s] = ap[4 * s];
     __builtin_amdgcn_sched_barrier(0);
+    if (t_loop) *t_loop = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int s = 0; s < PF_IN / 4; s++) {
         if (s + (int)PR2_AHEAD < PF_IN / 4) {
@@ -96,7 +97,7 @@ __device__ __forceinline__ void pr2_layer1(const __amdgpu_buffer_rsrc_t rs1, u32
 // up the head phase; philox_u32's arithmetic, statement for statement)
 template <int NT>
 __device__ __forceinline__ void pr2_layer2(const __amdgpu_buffer_rsrc_t rs2, u32 voff, const float *ap, const float2 (&pre)[PR2_HOIST2], pf_f32x4 &acc0,
-                                           pf_f32x4 &acc1, bool draw, u64 seed, u64 ctr, u32 game, float &u_out)
+                                           pf_f32x4 &acc1, bool draw, u64 seed, u64 ctr, u32 game, float &u_out, u64 *t_loop = nullptr)
 {
     float2 bw[PF_HID / 4];
 #pragma unroll
@@ -106,6 +107,7 @@ __device__ __forceinline__ void pr2_layer2(const __amdgpu_buffer_rsrc_t rs2, u32
     for (int s = 0; s < PR2_ADEPTH; s++) af[s] = ap[4 * s];
     u32 c0 = (u32)ctr, c1 = (u32)(ctr >> 32), c2 = game, c3 = 0x415A554Cu, k0 = (u32)seed, k1 = (u32)(seed >> 32), hi0 = 0, lo0 = 0;
     __builtin_amdgcn_sched_barrier(0);
+    if (t_loop) *t_loop = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int s = 0; s < PF_HID / 4; s++) {
         if (s + PR2_HOIST2 < PF_HID / 4) bw[s + PR2_HOIST2] = PR2_LOAD2(NT, s + PR2_HOIST2);
@@ -302,8 +304,17 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     u64 pr_acc[6] = {0, 0, 0, 0, 0, 0}, pr_last = __builtin_amdgcn_s_memtime();
     const u64 pr_t0 = pr_last, pr_r0 = __builtin_amdgcn_s_memrealtime();
 #define PR2_STAMP(i) do { u64 now_ = __builtin_amdgcn_s_memtime(); pr_acc[i] += now_ - pr_last; pr_last = now_; } while (0)
+    // matrix sub-phases of the two waves of SIMD 1 (w == 1: four / two tiles, w == 5: two / one): prologue (barrier release -> loop entry), the
+    // MFMA loop's issue span, the epilogue (waits for the last results, bias + relu, LDS writes), the wait at the closing barrier
+    u64 sub[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ts[4] = {0, 0, 0, 0}, tl = 0;
+    u64 *const tlp = &tl;
+#define PR2_SUB(i) do { ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PR2_SUBACC(o) do { sub[(o)] += tl - ts[0]; sub[(o) + 1] += ts[1] - tl; sub[(o) + 2] += ts[2] - ts[1]; sub[(o) + 3] += ts[3] - ts[2]; } while (0)
 #else
 #define PR2_STAMP(i) do { } while (0)
+#define PR2_SUB(i) do { } while (0)
+#define PR2_SUBACC(o) do { } while (0)
+    u64 *const tlp = nullptr;
 #endif
 #pragma unroll 1
     for (int t = 0; t < a.n_steps; t++) {
@@ -312,6 +323,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
         PR2_STAMP(0);                                    // own env step + publish
         lds_barrier();                                   // observations and mask bits of all 16 games are in LDS
         PR2_STAMP(1);                                    // waiting for the slowest env wave
+        PR2_SUB(0);
         {
             // layer 1: pairs of adjacent hidden columns per lane (one 8-byte load per k-step and pair: a 16-lane group reads 128 contiguous
             // bytes of a k-row).  Waves 0..3 own two pairs, FOUR adjacent columns 64w + 4c + j (one 16-byte load per k-step), waves 4..7 one (256 + 32 (w - 4) +
@@ -319,8 +331,9 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
             pf_f32x4 acc[4];
             for (int j = 0; j < 4; j++) acc[j] = (pf_f32x4){0.f, 0.f, 0.f, 0.f};
             const float *ap = obsS + c * PF_OBS_STRIDE + q;
-            if (two) pr2_layer1<2>(rs1, voffA, voffB, ap, preA, preB, acc);
-            else pr2_layer1<1>(rs1, voffA, voffB, ap, preA, preB, acc);
+            if (two) pr2_layer1<2>(rs1, voffA, voffB, ap, preA, preB, acc, tlp);
+            else pr2_layer1<1>(rs1, voffA, voffB, ap, preA, preB, acc, tlp);
+            PR2_SUB(1);
             pr2_request2(two, rs2, voff2, pre2);         // layer 2's first fragments: in flight across the epilogue and the barrier
             for (int rr = 0; rr < 4; rr++) {             // C layout: column = lane & 15, row = 4 (lane >> 4) + rr
                 float *hp = hidS + (4u * q + rr) * PF_HID_STRIDE;
@@ -336,8 +349,12 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
                 }
             }
         }
+        PR2_SUB(2);
         lds_barrier();
         PR2_STAMP(2);                                    // layer 1 (incl. barrier)
+        PR2_SUB(3);
+        PR2_SUBACC(0);
+        PR2_SUB(0);
         {
             // layer 2 (actor)
             const u32 col0 = PR2_L2COL0;
@@ -345,8 +362,9 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
             pf_f32x4 acc0 = (pf_f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
             const float *ap = hidS + c * PF_HID_STRIDE + PF_HID + q;
             const u32 hg_ = g0 + 4u * w + q;             // waves 0..3: the head row of this 16-lane group
-            if (two) pr2_layer2<2>(rs2, voff2, ap, pre2, acc0, acc1, true, a.seed, counter + (u64)t, b.id_base + (hg_ < n ? hg_ : n - 1u), u_head);
-            else pr2_layer2<1>(rs2, voff2, ap, pre2, acc0, acc1, false, 0, 0, 0, u_head);
+            if (two) pr2_layer2<2>(rs2, voff2, ap, pre2, acc0, acc1, true, a.seed, counter + (u64)t, b.id_base + (hg_ < n ? hg_ : n - 1u), u_head, tlp);
+            else pr2_layer2<1>(rs2, voff2, ap, pre2, acc0, acc1, false, 0, 0, 0, u_head, tlp);
+            PR2_SUB(1);
             if (live2)
                 for (int rr = 0; rr < 4; rr++) {
                     float *lp = lgS + (4u * q + rr) * PF_LOG_STRIDE + col0;
@@ -354,8 +372,11 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
                     if (two) lp[1] = acc1[rr] + b2aS[col0 + 1u];
                 }
         }
+        PR2_SUB(2);
         lds_barrier();
         PR2_STAMP(3);                                    // layer 2 + critic (incl. barrier)
+        PR2_SUB(3);
+        PR2_SUBACC(4);
         if (w < 4u) {
             // head: waves 0..3 (one per SIMD) sample four games each, 16 lanes per game
             const u32 hrow = 4u * w + q, hg = g0 + hrow;
@@ -498,6 +519,8 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
         atomicMax((unsigned long long *)(b.prof + 5), (unsigned long long)((1ull << 62) - pr_r0));
         atomicMax((unsigned long long *)(b.prof + 8), (unsigned long long)pr_r1);
     }
+    if (lane == 0u && (w == 1u || w == 5u))
+        for (int i = 0; i < 8; i++) atomicAdd((unsigned long long *)(b.prof + 16 + (w == 5u ? 8 : 0) + i), (unsigned long long)sub[i]);
 #endif
     if (live && a.returns && a.n_steps <= 32) {
         // the window's discounted returns (azul_returns_kernel's scan, statement for statement: q = reward + gamma * q backwards, an

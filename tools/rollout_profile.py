@@ -30,8 +30,8 @@ ro = PolicyRollout(BatchedActorCritic(136, 180, 180), n_games=4096, parts=1, win
 for _ in range(3):
     ro.run_window()
 ro.synchronize()
-cyc = np.zeros(9, dtype=np.uint64)
-L.check(L.lib.azul_batch_segment_profile(ro.envs[0]._h, cyc.ctypes.data_as(C.c_void_p), 9, 1))
+cyc = np.zeros(32, dtype=np.uint64)
+L.check(L.lib.azul_batch_segment_profile(ro.envs[0]._h, cyc.ctypes.data_as(C.c_void_p), 32, 1))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 with torch.cuda.stream(ro.streams[0]):
     e0.record()
@@ -40,14 +40,14 @@ with torch.cuda.stream(ro.streams[0]):
     e1.record()
 ro.synchronize()
 print("event bracket around that launch (+ the returns scan): %.1f us" % (e0.elapsed_time(e1) * 1e3))
-L.check(L.lib.azul_batch_segment_profile(ro.envs[0]._h, cyc.ctypes.data_as(C.c_void_p), 9, 1))
+L.check(L.lib.azul_batch_segment_profile(ro.envs[0]._h, cyc.ctypes.data_as(C.c_void_p), 32, 1))
 span = (float(cyc[8]) - ((1 << 62) - float(cyc[5]))) / 100.0
 print("one launch: loops of the 256 workgroups span %.1f us (earliest start .. latest end); mean loop %.1f us" % (span, float(cyc[7]) / 256 / 100.0))
 windows = 10
 for _ in range(windows):
     ro.run_window()
 ro.synchronize()
-L.check(L.lib.azul_batch_segment_profile(ro.envs[0]._h, cyc.ctypes.data_as(C.c_void_p), 9, 1))
+L.check(L.lib.azul_batch_segment_profile(ro.envs[0]._h, cyc.ctypes.data_as(C.c_void_p), 32, 1))
 names = ["env step + publish (own game)", "wait for the slowest env wave", "layer 1 (+ barrier)", "layer 2 / critic (+ barrier)", "head (+ barrier)"]
 moves = 256 * WIN * windows
 tot = 0.0
@@ -58,3 +58,13 @@ print("wave 5's loop per launch: %.0f shader cycles, %.1f us of s_memrealtime (1
 ghz = float(cyc[6]) / max(float(cyc[7]), 1.0) * 0.1
 print("sum %.0f cycles per move (wave 5 of each workgroup, opponent=%s); in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz = %.2f GHz"
       " -> %.2f us per move" % (tot, opp, ghz, tot / ghz / 1e3))
+
+# matrix sub-phases of the two waves that share SIMD 1 (agent pass only): where the layer phases' cycles go
+tiles = {1: (4, 2), 5: (2, 1)}
+for wv, base in ((1, 16), (5, 24)):
+    v = [float(x) / moves for x in cyc[base:base + 8]]
+    print("wave %d  layer 1: prologue %5.0f | MFMA loop issue span %5.0f (own MFMAs: %d tiles x 34 k-steps x 32 = %d) | epilogue %5.0f | barrier wait %5.0f   = %5.0f"
+          % (wv, v[0], v[1], tiles[wv][0], tiles[wv][0] * 34 * 32, v[2], v[3], sum(v[:4])))
+    print("        layer 2: prologue %5.0f | MFMA loop issue span %5.0f (own MFMAs: %d tiles x 45 k-steps x 32 = %d) | epilogue %5.0f | barrier wait %5.0f   = %5.0f"
+          % (v[4], v[5], tiles[wv][1], tiles[wv][1] * 45 * 32, v[6], v[7], sum(v[4:])))
+print("matrix pipe of a SIMD per move: layer 1 = 6 tiles x 34 x 32 = 6528 cycles, layer 2 = 3 x 45 x 32 = 4320 cycles")

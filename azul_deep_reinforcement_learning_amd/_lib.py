@@ -15,7 +15,7 @@ MAX_ACTIONS, MAX_OBS = 300, 260
 # extended rules (beyond the reference, "parity unpinned": include/azul_hip.h AZUL_RULE_*)
 RULE_DISPLAYS_2P1, RULE_END_BONUS, RULE_SHORT_DEAL, RULE_FINITE_BAG = 1, 2, 4, 8
 SUCCESS, ERR_INVALID, ERR_HIP, ERR_RANGE, ERR_RULE = 0, -1, -2, -3, -4
-OK, ILLEGAL_MOVE, GAME_ENDED, STUCK, BAD_ACTION, BOX_EMPTY = 0, 1, 2, 3, 4, 5
+OK, ILLEGAL_MOVE, GAME_ENDED, STUCK, BAD_ACTION, BOX_EMPTY, TRUNCATED = 0, 1, 2, 3, 4, 5, 6
 POOL_RANDOM, POOL_LID = 0, 1
 FIRST_RANDOM = 0
 PERSP_PLAYER0, PERSP_PLAYER1, PERSP_CURRENT = 0, 1, 2
@@ -119,6 +119,7 @@ SIGNATURES = {
     "azul_batch_reset_counters": (_i, [_vp, _vp]),
     "azul_batch_set_id_base": (_i, [_vp, _u32]),
     "azul_batch_set_draw_margin": (_i, [_vp, _u64]),
+    "azul_batch_set_move_limit": (_i, [_vp, _u32]),
     "azul_batch_segment_profile": (_i, [_vp, _vp, _i, _i]),
     "azul_selfplay_kernel_resources": (_i, [_vp, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "azul_device_clock_probe": (_i, [_vp, _i, _vp]),

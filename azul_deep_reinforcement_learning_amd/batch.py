@@ -413,6 +413,11 @@ class BatchedAzul:
         """Global id of this batch's game 0 (multi-GPU shards / stream parts): keys the policy sampler's Philox stream."""
         L.check(L.lib.azul_batch_set_id_base(self._h, int(first_global_id) & 0xFFFFFFFF))
 
+    def set_move_limit(self, max_moves):
+        """Beyond the reference, off by default (0): cut an episode at the first end of a round with move_counter >= max_moves -- some games
+        never end under the reference's rules (include/azul_hip.h: azul_batch_set_move_limit).  done = 3 marks the cut."""
+        L.check(L.lib.azul_batch_set_move_limit(self._h, int(max_moves)))
+
     def set_draw_margin(self, margin):
         """Test knob: widen the window in which the factory draw falls back to the literal fp64 computation."""
         L.check(L.lib.azul_batch_set_draw_margin(self._h, int(margin)))

@@ -33,7 +33,8 @@ AZ_FN u32 lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_
 
 namespace az {
 
-enum { ST_OK = 0, ST_ILLEGAL_MOVE = 1, ST_GAME_ENDED = 2, ST_STUCK = 3, ST_BAD_ACTION = 4, ST_BOX_EMPTY = 5 };
+enum { ST_OK = 0, ST_ILLEGAL_MOVE = 1, ST_GAME_ENDED = 2, ST_STUCK = 3, ST_BAD_ACTION = 4, ST_BOX_EMPTY = 5,
+       ST_TRUNCATED = 6 /* move limit (beyond the reference, off by default): the episode was cut at the end of a round */ };
 enum { POOL_RANDOM = 0, POOL_LID = 1 };
 #ifndef AZ_DRAW_MARGIN
 #define AZ_DRAW_MARGIN 8192ull      // factory draw: > 21.1 * 255, the largest possible fp64 disagreement window

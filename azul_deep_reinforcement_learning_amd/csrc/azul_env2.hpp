@@ -123,6 +123,7 @@ AZ_FN u32 apply_step2(G2 &g, u32 code, Rng2 &r, u64 margin, const K2 &k)
         if (eor) {
             count_score2<LID>(g, k);                                   // :307
             if (g.over) g.eog = 1;                                     // :308-309
+            else if (g.moves + 1u >= k.move_limit) st = ST_TRUNCATED;  // move limit (beyond the reference, off by default; the caller counts this move next)
             else st = new_round2<LID>(g, r, margin, k);                // :311
         }
     }
@@ -177,8 +178,8 @@ AZ_FN u32 policy_step2(G2 &g, i32 av, const Mask2 &m /* of the current state: th
             const i32 phi = g.wi0 - g.wi1;                             // game_runner.py:48-50 (the what-if caches are current)
             rew = phi - g.pscore;
             g.pscore = phi;
-            dn = g.over ? 1u : 0u;                                     // is_end_of_game(): the walls, not the record's flag
-            restart = dn && st == ST_OK;
+            dn = g.over ? 1u : (st == ST_TRUNCATED ? 3u : 0u);         // is_end_of_game(): the walls, not the record's flag; 3: cut by the move limit
+            restart = dn && (st == ST_OK || st == ST_TRUNCATED);
         } else if (st == ST_GAME_ENDED) {                               // a finished game handed in: restart the slot, report done
             dn = 1u;
             restart = true;
@@ -187,9 +188,11 @@ AZ_FN u32 policy_step2(G2 &g, i32 av, const Mask2 &m /* of the current state: th
     if (AZ_UNLIKELY(wave_any(stuck | restart))) {
         if (stuck | restart) {
             if (stuck) { cnt.stuck_add += 1u; dn = 2u; }
+            else if (st == ST_TRUNCATED) cnt.stuck_add += 1u;          // (a cut episode is no finished game)
             else if (st == ST_OK) episode_stats2(g, cnt, k.l);         // (a game handed in finished is not counted: st == ST_GAME_ENDED)
+            const bool cut = st == ST_TRUNCATED;
             u32 st0 = reset2<LID>(g, first_player, r, margin, k);
-            st = stuck ? (st0 ? st0 : (u32)ST_STUCK) : st0;
+            st = stuck ? (st0 ? st0 : (u32)ST_STUCK) : (cut ? (st0 ? st0 : (u32)ST_TRUNCATED) : st0);
         }
     }
     return st;
@@ -245,12 +248,13 @@ AZ_FN u32 agent_step2(G2 &g, i32 av, const Mask2 &m /* of the current state */, 
     u32 st = runner_step2<LID>(g, av, m, r, T, margin, k, rew, dn);
     const bool dirty = !(st == ST_ILLEGAL_MOVE || st == ST_BAD_ACTION);
     if (st == ST_STUCK) { cnt.stuck_add += 1u; dn = 2u; rew = 0; }   // hazard H3: nobody can move
+    else if (st == ST_TRUNCATED) { cnt.stuck_add += 1u; dn = 3u; rew = 0; }       // move limit: the episode was cut at the end of a round
     else if (st == ST_GAME_ENDED) dn = 1u;
     else if (st == ST_OK && dn) episode_stats2(g, cnt, k.l);
     if (dirty && dn) {
         u32 st2 = reset2<LID>(g, first_player, r, margin, k);
         if (!st2) st2 = opponent_loop2<LID>(g, r, T, margin, k, true);
-        if (st == ST_OK) st = st2;
+        if (st == ST_OK || (st == ST_TRUNCATED && st2)) st = st2;
     }
     return st;
 }
@@ -341,7 +345,11 @@ AZ_FN void net_move2(G2 &g, i32 av, bool agent, Mask2 &m, u32 first_player, Rng2
         ns.pending = NET_READY;
         if (in_step) {
             ns.closed = true; ns.rew = 0;
-            ns.dn = st == ST_GAME_ENDED ? 1u : (agent ? ns.dn : 0u);
+            ns.dn = st == ST_GAME_ENDED ? 1u : (st == ST_TRUNCATED ? 3u : (agent ? ns.dn : 0u));
+            if (st == ST_TRUNCATED) {                                           // move limit: the episode was cut at the end of a round
+                cnt.stuck_add += 1u;
+                if (!agent) ns.replies += 1u;                                   // (the opponent's move WAS played: the round it ended is scored)
+            }
             if (ns.dn) ns.pending = NET_RESET;
         }
     }

@@ -1095,6 +1095,15 @@ int azul_batch_set_id_base(azul_batch_t *b, uint32_t first_global_id)
     return AZUL_SUCCESS;
 }
 
+int azul_batch_set_move_limit(azul_batch_t *b, uint32_t max_moves)
+{
+    if (!b) return fail(AZUL_ERR_INVALID, "batch is NULL");
+    if (b->x && max_moves) return fail(AZUL_ERR_INVALID, "azul_batch_set_move_limit: two-player reference batches (GameRunner.move_counter is two-player, game_runner.py:36)");
+    if (max_moves > 65535u) return fail(AZUL_ERR_INVALID, "azul_batch_set_move_limit: the record's move counter is 16 bits wide");
+    b->d.move_limit = max_moves;
+    return AZUL_SUCCESS;
+}
+
 int azul_batch_set_draw_margin(azul_batch_t *b, uint64_t margin)
 {
     BATCH_GUARD(b, nullptr);

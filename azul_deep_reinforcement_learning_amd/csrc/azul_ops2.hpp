@@ -23,6 +23,7 @@ struct BatchDev {
     u64 draw_margin;     // AZ_DRAW_MARGIN; tests widen it to force the literal fp64 factory draw
     u64 *prof;           // [SEG_COUNT] segment cycle sums (only written by the -DAZ_PROFILE_SEGMENTS diagnostic build)
     u32 id_base;         // global id of game 0 (azul_batch_set_id_base): keys the policy sampler's Philox stream
+    u32 move_limit;      // 0 = none (the reference's behaviour), else an episode is cut at the first end of a round with move_counter >= this (azul_batch_set_move_limit)
 };
 
 enum {
@@ -85,6 +86,7 @@ AZ_FN void op_body2(const BatchDev &b, const OpArgs &a, u32 pair, u32 (*mt_lds)[
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
     K2 k;
     k2_init(k);
+    k.move_limit = b.move_limit ? b.move_limit : ~0u;
     const Tab2 tab = {tabfs_lds};
     G2 g;
     g2_load(g, rec, l);

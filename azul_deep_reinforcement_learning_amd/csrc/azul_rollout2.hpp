@@ -220,6 +220,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     // env state of this half's game
     az2::K2 k;
     az2::k2_init(k);
+    k.move_limit = b.move_limit ? b.move_limit : ~0u;
     az2::Tab2 tab = {tabfs_lds};
     az2::G2 g;
     uint8_t *rec = b.state + (size_t)gic * AZUL_RECORD_BYTES;

@@ -93,12 +93,15 @@ struct K2 {
     u32 rowp1;           // l < 25: row + 1, else 0xff
     u32 prow, pcol, pbcol, pbelow, pcolboard;      // pattern cell l < 25: row, colour, board column, bits 0..l, cells of that board column
     u32 h4;              // byte offset of my half in a ds_bpermute address: (lane & 32) << 2
+    u32 move_limit;      // wave-uniform, NOT a lane constant: the batch's move limit (~0u = none; BatchDev::move_limit) -- travels with K2 because every
+                         // rule function already receives it
 };
 
 AZ_FN void k2_init(K2 &k)
 {
     const u32 l = wlane() & 31u;
     k.l = l;
+    k.move_limit = ~0u;
     k.h4 = (wlane() & 32u) << 2;
     asm volatile("" : "+v"(k.h4));     // opaque: (idx << 2) | h4 stays ONE v_lshl_or_b32 (else it is re-associated into or + shift)
     {
@@ -914,31 +917,35 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
     // (ONE wave-uniform test for the end of a round and for a game that is over -- a test costs ~33 cycles even when it falls through;
     // the episode-end block further down branches on a flag that is already scalar.  `over` without the end of a round: a state
     // handed in with a complete wall row and the flag clear)
-    bool any_done = false;
+    bool any_done = false, cut = false;
     if (AZ_UNLIKELY(wave_any(eor | (g.over != 0u)))) {
         if (eor) {
             count_score2<LID>(g, k);                         // :307 (also resets the what-if cache)
             if (g.over) g.eog = 1;                           // :308-309
         }
         AZ_STAMP(SEG_SCORE);
-        if (eor & !g.over) st = new_round2<LID>(g, r, margin, k);      // :311
+        // MOVE LIMIT (beyond the reference, off unless azul_batch_set_move_limit: k.move_limit == ~0u): a round ended, the game did not, and
+        // the episode has played its limit -- under the reference's rules a game can reach a state from which it NEVER ends (every tile of a
+        // colour locked in lines that cannot be completed: no wall row can fill, azul.py:184-191 stays false): it is cut here, no round dealt
+        cut = eor & !g.over & (g.moves >= k.move_limit);
+        if (eor & !g.over & !cut) st = new_round2<LID>(g, r, margin, k);      // :311
         AZ_STAMP(SEG_NEWROUND);
-        any_done = wave_any((g.over != 0u) & (st == ST_OK));
+        any_done = wave_any(((g.over != 0u) | cut) & (st == ST_OK));
         dead |= st != ST_OK;
     }
     const i32 phi = g.wi0 - g.wi1;
     const i32 reward = phi - g.pscore;
     g.pscore = phi;
-    const u32 dn = g.over ? 1u : 0u;
+    const u32 dn = g.over ? 1u : (cut ? 3u : 0u);
     outputs2<OUT>(g, o, a, reward, dn, l);
     AZ_STAMP(SEG_TAIL);
     u32 ret = st != ST_OK ? (0x100u | st) : dn;
     if (AZ_UNLIKELY(any_done)) {
         if ((dn != 0u) & (st == ST_OK)) {
-            {
+            if (dn == 1u) {
                 const double f0 = (double)(g.fps & 0xffffu), f1 = (double)(g.fps >> 16);
                 counters2_episode(cnt, stat_lane(l, g.score0, g.score1, g.turn, f0 / (f0 + f1) * 100, g.fp0, g.mc0, g.cl0));
-            }
+            } else cnt.stuck_add += 1u;                      // (a cut episode is no finished game: counted with the restarted slots)
             u32 st2 = episode_reset2<LID>(g, first_player, r, margin, k);     // GameRunner.reset(): Azul(rules) ... new_round()
             if (st2) ret = 0x100u | st2;
         }

@@ -173,6 +173,7 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
     az2::K2 k;
     az2::k2_init(k);
+    k.move_limit = b.move_limit ? b.move_limit : ~0u;
     az2::Tab2 tab = {tabfs_lds};
     az2::G2 g;
     az2::g2_load(g, rec, l);

@@ -35,7 +35,7 @@ class PolicyRollout:
     def __init__(self, policy, n_games=4096, parts=1, rules={"first_player": "Random", "tile_pool": "Lid"}, seed_base=0,
                  device=None, window=32, use_graph=True, fused_head=True, sample_seed=0x5EED, opponent=None, fused_mlp=True, persistent=False,
                  action_selection="Distribution", kweights=None, game_id_base=None, ring=1, opponent_selection="Distribution",
-                 opponent_seed=None, opponent_trace=0):
+                 opponent_seed=None, opponent_trace=0, move_limit=0):
         """opponent=None: the policy moves for both players (flat self-play, one record per env move).
         opponent="random": the reference's training setup -- the policy is player 1 of GameRunner, the opponent a RandomAgent
         inside the env step (game_runner.py:43-47); one record per AGENT step, observations from the agent's perspective.
@@ -47,6 +47,8 @@ class PolicyRollout:
         inside the window kernel (matrix phases on the second weight set while any game of a workgroup owes a reply); otherwise one launch
         per cut of the protocol and one host synchronisation per reply round (no HIP graph).  `opponent_trace` = R > 0 also records the
         opponent's answers: opp_action / opp_logp [T][R][N], opp_replies [T][N].
+        `move_limit` > 0 (beyond the reference, off by default): cut an episode at the first end of a round with move_counter >= move_limit
+        (done = 3) -- under the reference's rules some games never end and would keep their slot for ever (BatchedAzul.set_move_limit).
         `seed_base` / `game_id_base`: game i of this rollout is global game game_id_base + i (default: seed_base, so that a rank
         passes the id of its first game once); its CPython stream is random.seed(seed_base + i) and its sampling stream is
         Philox(sample_seed, step, global id) -- both independent of how the games are sharded over GPUs or split into parts.
@@ -99,6 +101,8 @@ class PolicyRollout:
             env = BatchedAzul(h, rules=rules, device=d)
             env.seed(seed_base + p * h)                            # seeds follow the global game id
             env.set_id_base(self.game_id_base + p * h)             # ... and so does the sampler's Philox key
+            if move_limit:
+                env.set_move_limit(move_limit)
             env.runner_init()                                      # GameRunner()
             if opponent == "random":
                 env.reset()                                        # GameRunner.reset(): the opponent opens when it starts

@@ -101,6 +101,7 @@ extern "C" {
 #define AZUL_STUCK         3      /* no legal move although the round is not over (SURVEY hazard H3) */
 #define AZUL_BAD_ACTION    4      /* action outside [0,180) */
 #define AZUL_BOX_EMPTY     5      /* "Lid" pool and lid both empty at a draw (reference raises) */
+#define AZUL_TRUNCATED     6      /* azul_batch_set_move_limit: the episode was cut at the end of a round (beyond the reference) */
 
 /* rules (azul.py:35-56) */
 #define AZUL_POOL_RANDOM   0
@@ -458,7 +459,7 @@ int azul_pack_c1(const float *obs_dev, const uint8_t *mask_dev, const uint8_t *p
  *   maskbits_dev uint64 [n_steps][N][3]   the same mask bit-packed (bit a&63 of word a>>6)
  *   action_dev int32 [n_steps][N]        chosen action (-1 when stuck)
  *   reward_dev int32 [n_steps][N]
- *   done_dev   uint8 [n_steps][N]        1 = game ended with this move, 2 = stuck (no move, reset)
+ *   done_dev   uint8 [n_steps][N]        1 = game ended with this move, 2 = stuck (no move, reset), 3 = cut by the move limit (azul_batch_set_move_limit)
  *   packed_dev uint32 [n_steps][N]       compact record: action (0xff = none) | done << 8 | (reward & 0xffff) << 16
  *   rec_dev    uint8 [n_steps][N][128]   record after the move, before the auto-reset (tests only)
  * Batches of THREE or FOUR players (azul_batch_create_players; row N4) play the same flat loop -- mask -> RandomAgent
@@ -490,6 +491,18 @@ int azul_batch_reset_counters(azul_batch_t *b, void *stream);
  * seed_base + global id); the policy sampler of azul_batch_policy_rollout keys its Philox stream with id_base + local index, so
  * a game's sampled actions -- like its CPython stream -- do not depend on the GPU count. */
 int azul_batch_set_id_base(azul_batch_t *b, uint32_t first_global_id);
+
+/* MOVE LIMIT -- beyond the reference, OFF by default (0), "parity unpinned": under the reference's rules a game can reach a state from which
+ * it NEVER ends -- e.g. all 20 tiles of one colour locked in pattern lines that can no longer be completed, so that no wall row can ever be
+ * filled and is_end_of_game (azul.py:184-191) stays false for ever; GameRunner's callers loop `while not done` (nn_runner.py:24,
+ * tests/test_game_runner.py:48) and would never return.  With random play one game in ~10^9 game-moves gets there (bench.py's `sustained`
+ * names the game: seed 801 after ~310 k moves); it then keeps its slot for ever and -- short rounds -- slows its wavefront by ~10 %.
+ * With max_moves > 0 (<= 65535) an episode whose move_counter (game_runner.py:36) has reached max_moves when a round ends WITHOUT ending the
+ * game is cut there: the round is scored, no new round is dealt, the slot restarts like at a game end (GameRunner.reset semantics, same
+ * RNG stream), the move reports done = 3 (policy entries: status AZUL_TRUNCATED, reward as for a stuck slot) and the slot is counted in
+ * `stuck`, not in `episodes` / the statistics sums.  Applies to azul_batch_selfplay*, azul_batch_step, the GameRunner / policy entries and
+ * the rollout kernels of two-player batches; trajectories do not depend on how moves are split over launches. */
+int azul_batch_set_move_limit(azul_batch_t *b, uint32_t max_moves);
 
 /* TEST KNOB: the factory draw decides a colour in integer arithmetic unless K*T lies within `margin` of a multiple of
  * 2^32 (then by the literal fp64 computation).  Default 8192 (proved sufficient); a wider margin only sends

@@ -482,6 +482,28 @@ int oz_step(oz_game *g, int display, int color, int pattern, oz_rng *r)
     return OZ_OK;
 }
 
+/* Azul.step under the MOVE LIMIT -- beyond the reference ("parity unpinned"; include/azul_hip.h: azul_batch_set_move_limit): when the move
+ * ends a round without ending the game and the episode has then played `limit` moves or more, the round is scored and NO new round is
+ * dealt: OZ_TRUNCATED.  limit <= 0: exactly oz_step. */
+int oz_step_limited(oz_game *g, int display, int color, int pattern, oz_rng *r, int64_t moves_after, int64_t limit)
+{
+    if (g->end_of_game) return OZ_GAME_ENDED;
+    if (!oz_is_legal_move(g, display, color, pattern)) return OZ_ILLEGAL_MOVE;
+    oz_move(g, display, color, pattern);
+    if (oz_is_end_of_round(g)) {
+        oz_count_score(g);
+        if (oz_is_end_of_game(g)) {
+            g->end_of_game = 1;
+            if (g->ext & OZ_EXT_END_BONUS) oz_end_game_bonus(g);
+        }
+        else if (limit > 0 && moves_after >= limit) return OZ_TRUNCATED;
+        else return oz_new_round(g, r);
+    } else {
+        oz_next_player(g);
+    }
+    return OZ_OK;
+}
+
 void oz_get_statistics(const oz_game *g, double out[10])
 {
     /* azul.py:314-315; key order of game_runner.py:12 */
@@ -783,6 +805,41 @@ int oz_runner_step_with(oz_runner *q, int action, oz_rng *r, oz_opponent_fn opp,
     return OZ_OK;
 }
 
+/* GameRunner.step with any opponent (opp == NULL: the default RandomAgent drawing from r) under the MOVE LIMIT: a move of either side
+ * that ends a round without ending the game when the episode has played `limit` moves cuts the episode -- reward 0, *done = 3 (the
+ * caller resets, as after done = 1).  limit <= 0: oz_runner_step_with / oz_runner_step. */
+int oz_runner_step_limited(oz_runner *q, int action, oz_rng *r, oz_opponent_fn opp, void *ctx, int64_t limit, int64_t *reward, int *done)
+{
+    int d, c, p;
+    oz_deserialize(action, &d, &c, &p);
+    *reward = 0; *done = 0;
+    int st = oz_step_limited(&q->game, d, c, p, r, q->move_counter + 1, limit);      /* :44 */
+    if (st == OZ_TRUNCATED) { *done = 3; return OZ_OK; }
+    if (st) return st;
+    q->move_counter += 1;                                                             /* :45 */
+    for (;;) {
+        uint8_t mask[180];
+        oz_check_all_valid(&q->game, mask);
+        int nvalid = 0;
+        for (int i = 0; i < 180; i++) nvalid += mask[i];
+        if (!((q->game.current_player != 1 || nvalid < 2) && !oz_is_end_of_game(&q->game))) break;   /* :46 */
+        int64_t state[136];
+        oz_get_state(&q->game, q->game.current_player - 1, state);                   /* :38 */
+        int a = opp ? opp(ctx, state, mask) : oz_random_agent(mask, r);              /* :40 */
+        if (a < 0) return OZ_STUCK;
+        oz_deserialize(a, &d, &c, &p);
+        st = oz_step_limited(&q->game, d, c, p, r, q->move_counter + 1, limit);      /* :41 */
+        if (st == OZ_TRUNCATED) { *done = 3; return OZ_OK; }
+        if (st) return st;
+        q->move_counter += 1;                                                         /* :42 */
+    }
+    int64_t nps = oz_potential(&q->game);
+    *reward = nps - q->player_score;
+    q->player_score = nps;
+    *done = oz_is_end_of_game(&q->game);
+    return OZ_OK;
+}
+
 /* ------------------------------------------------------------------------- */
 /* canonical 128-byte record (layout documented in include/azul_hip.h)       */
 /* ------------------------------------------------------------------------- */
@@ -949,6 +1006,14 @@ int oz_stream_advance(oz_runner *q, oz_rng *r, int n_steps,
                       uint8_t *mask, int32_t *action, int32_t *reward, uint8_t *done,
                       uint8_t *rec_after, uint64_t *stuck_count, uint64_t *episodes, double *stats_sum)
 {
+    return oz_stream_advance_limited(q, r, n_steps, 0, mask, action, reward, done, rec_after, stuck_count, episodes, stats_sum);
+}
+
+/* the same flat loop under the move limit (limit <= 0: none): a cut episode reports done = 3, counts as a restarted slot, not as an episode */
+int oz_stream_advance_limited(oz_runner *q, oz_rng *r, int n_steps, int64_t limit,
+                              uint8_t *mask, int32_t *action, int32_t *reward, uint8_t *done,
+                              uint8_t *rec_after, uint64_t *stuck_count, uint64_t *episodes, double *stats_sum)
+{
     for (int t = 0; t < n_steps; t++) {
         uint8_t m[180];
         oz_check_all_valid(&q->game, m);
@@ -967,24 +1032,28 @@ int oz_stream_advance(oz_runner *q, oz_rng *r, int n_steps,
         }
         int d, c, p;
         oz_deserialize(a, &d, &c, &p);
-        int st = oz_step(&q->game, d, c, p, r);
-        if (st) return st;
+        int st = oz_step_limited(&q->game, d, c, p, r, q->move_counter + 1, limit);
+        const int cut = st == OZ_TRUNCATED;
+        if (st && !cut) return st;
         q->move_counter += 1;
         int64_t phi = oz_potential(&q->game);
         int64_t rew = phi - q->player_score;
         q->player_score = phi;
-        int dn = oz_is_end_of_game(&q->game);
+        int dn = cut ? 3 : oz_is_end_of_game(&q->game);
         if (action) action[t] = a;
         if (reward) reward[t] = (int32_t)rew;
         if (done) done[t] = (uint8_t)dn;
         if (rec_after) oz_pack(q, rec_after + (size_t)t * 128);
         if (dn) {
-            if (stats_sum) {
-                double s[10];
-                oz_get_statistics(&q->game, s);
-                for (int i = 0; i < 10; i++) stats_sum[i] += s[i];
+            if (cut) { if (stuck_count) (*stuck_count)++; }
+            else {
+                if (stats_sum) {
+                    double s[10];
+                    oz_get_statistics(&q->game, s);
+                    for (int i = 0; i < 10; i++) stats_sum[i] += s[i];
+                }
+                if (episodes) (*episodes)++;
             }
-            if (episodes) (*episodes)++;
             st = runner_reset_noplay(q, r);
             if (st) return st;
         }

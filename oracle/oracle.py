@@ -16,7 +16,7 @@ POOL_RANDOM, POOL_LID = 0, 1
 # extended rules, beyond the reference (azul_oracle.h OZ_EXT_*; "parity unpinned")
 EXT_DISPLAYS_2P1, EXT_END_BONUS, EXT_SHORT_DEAL, EXT_FINITE_BAG = 1, 2, 4, 8
 FIRST_RANDOM, FIRST_ABSENT = 0, -1
-OK, ILLEGAL_MOVE, GAME_ENDED, STUCK, ILLEGAL_RULE, BOX_EMPTY = range(6)
+OK, ILLEGAL_MOVE, GAME_ENDED, STUCK, ILLEGAL_RULE, BOX_EMPTY, TRUNCATED = range(7)
 
 STAT_KEYS = ["player_score", "opponent_score", "rounds", "percent_first_player", "floor_penalty",
              "max_combo", "completed_rows", "completed_columns", "completed_colors", "win_percent"]
@@ -121,6 +121,9 @@ def lib():
         "oz_unpack_np": (None, [P(Game), u8p, C.c_int]),
         "oz_stream_start": (C.c_int, [P(Runner), P(Rng), C.c_uint64, C.c_int, C.c_int]),
         "oz_stream_advance": (C.c_int, [P(Runner), P(Rng), C.c_int, u8p, i32p, i32p, u8p, u8p, u64p, u64p, f64p]),
+        "oz_step_limited": (C.c_int, [P(Game), C.c_int, C.c_int, C.c_int, P(Rng), C.c_int64, C.c_int64]),
+        "oz_stream_advance_limited": (C.c_int, [P(Runner), P(Rng), C.c_int, C.c_int64, u8p, i32p, i32p, u8p, u8p, u64p, u64p, f64p]),
+        "oz_runner_step_limited": (C.c_int, [P(Runner), C.c_int, P(Rng), C.c_void_p, C.c_void_p, C.c_int64, P(C.c_int64), P(C.c_int)]),
         "oz_stream_np_start": (C.c_int, [P(Game), P(Rng), C.c_uint64, C.c_int, C.c_int, C.c_int]),
         "oz_stream_np_advance": (C.c_int, [P(Game), P(Rng), C.c_int, C.c_int, u8p, i32p, u8p, u8p, u64p, u64p, f64p]),
         "oz_init_ext": (C.c_int, [P(Game), C.c_int, C.c_int, C.c_int, C.c_int, P(Rng)]),
@@ -267,8 +270,13 @@ class NetRunner:
     def reset(self):
         return lib().oz_runner_reset_with(C.byref(self.q), C.byref(self.r), self._cb, None)
 
-    def step(self, action):
+    def step(self, action, move_limit=0):
+        """-> (status, reward, done); with `move_limit` > 0 (beyond the reference: oz_runner_step_limited) done is the code 0 / 1 / 3."""
         rew, dn = C.c_int64(0), C.c_int(0)
+        if move_limit:
+            rc = lib().oz_runner_step_limited(C.byref(self.q), int(action), C.byref(self.r), C.cast(self._cb, C.c_void_p), None, int(move_limit),
+                                              C.byref(rew), C.byref(dn))
+            return rc, int(rew.value), int(dn.value)
         rc = lib().oz_runner_step_with(C.byref(self.q), int(action), C.byref(self.r), self._cb, None, C.byref(rew), C.byref(dn))
         return rc, int(rew.value), bool(dn.value)
 
@@ -297,16 +305,17 @@ class Stream:
         if rc:
             raise RuntimeError("oz_stream_start -> %d" % rc)
 
-    def advance(self, n_steps, want_records=True):
+    def advance(self, n_steps, want_records=True, move_limit=0):
+        """`move_limit` > 0: the move-limit extension (beyond the reference; azul_batch_set_move_limit): done = 3 marks a cut episode."""
         mask = np.zeros((n_steps, 180), dtype=np.uint8)
         action = np.zeros(n_steps, dtype=np.int32)
         reward = np.zeros(n_steps, dtype=np.int32)
         done = np.zeros(n_steps, dtype=np.uint8)
         recs = np.zeros((n_steps, 128), dtype=np.uint8) if want_records else None
-        rc = lib().oz_stream_advance(C.byref(self.q), C.byref(self.r), n_steps, _p(mask, C.c_uint8),
-                                     _p(action, C.c_int32), _p(reward, C.c_int32), _p(done, C.c_uint8),
-                                     _p(recs, C.c_uint8), C.byref(self.stuck), C.byref(self.episodes),
-                                     _p(self.stats_sum, C.c_double))
+        rc = lib().oz_stream_advance_limited(C.byref(self.q), C.byref(self.r), n_steps, int(move_limit), _p(mask, C.c_uint8),
+                                             _p(action, C.c_int32), _p(reward, C.c_int32), _p(done, C.c_uint8),
+                                             _p(recs, C.c_uint8), C.byref(self.stuck), C.byref(self.episodes),
+                                             _p(self.stats_sum, C.c_double))
         if rc:
             raise RuntimeError("oz_stream_advance -> %d" % rc)
         return {"mask": mask, "action": action, "reward": reward, "done": done,

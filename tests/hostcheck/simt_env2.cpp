@@ -19,7 +19,7 @@ enum { OBS = 136, OBS_STRIDE = 140 };
 struct EnvJob {
     uint8_t *state; u32 *mt; u32 *mtpos; const double2 *T;
     u64 *episodes; u32 *stuck; double *stat_sum;
-    u32 n, first_player;
+    u32 n, first_player, move_limit;
     u64 margin;
     int opponent, n_steps;
     const i32 *actions;      // [T][N]
@@ -48,6 +48,7 @@ static void env_wave(EnvJob *j)
     const u32 gic = live ? gi : n - 1u;                     // a dead half loads a valid game and writes nothing (the kernel's clamp)
     az2::K2 k;
     az2::k2_init(k);
+    k.move_limit = j->move_limit ? j->move_limit : ~0u;          // (azul_batch_set_move_limit: the kernels copy BatchDev::move_limit here)
     az2::Tab2 tab = {j->tabfs_lds};
     az2::G2 g;
     uint8_t *rec = j->state + (size_t)gic * AZUL_RECORD_BYTES;
@@ -105,7 +106,11 @@ static void env_lane_main(void *arg)
     if (j->opponent) env_wave<LID, true>(j); else env_wave<LID, false>(j);
 }
 
+static u32 g_move_limit = 0;
+
 extern "C" {
+void sh2_set_move_limit(unsigned m) { g_move_limit = m; }
+
 
 // n_games games advance by n_steps AGENT moves with the given actions (opponent = 0: the policy plays both sides, env_policy_step;
 // opponent = 1: GameRunner.step with the RandomAgent opponent + reset at episode end, env_agent_step), two games per wave.
@@ -122,6 +127,7 @@ long long sh2_rollout_env(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 
         EnvJob *j = (EnvJob *)calloc(1, sizeof(EnvJob));
         j->state = state; j->mt = mt; j->mtpos = mtpos; j->T = (const double2 *)T; j->episodes = episodes; j->stuck = stuck; j->stat_sum = stat_sum;
         j->n = (u32)n_games; j->first_player = (u32)first_player; j->margin = margin ? margin : AZ_DRAW_MARGIN;
+        j->move_limit = g_move_limit;
         j->opponent = opponent; j->n_steps = n_steps; j->actions = actions; j->obs = obs; j->mask = mask; j->player = player;
         j->maskbits = maskbits; j->reward = reward; j->done = done; j->status = status; j->wave_id = w;
         ops += (long long)simt::run_wave(tile_pool == POOL_LID ? env_lane_main<true> : env_lane_main<false>, j);

@@ -20,7 +20,11 @@ static void op_main(void *arg)
     if (j->lid) azul_op_kernel<true>(j->b, j->a); else azul_op_kernel<false>(j->b, j->a);
 }
 
+static u32 g_move_limit = 0;       // BatchDev::move_limit of the next launches (azul_batch_set_move_limit)
+
 extern "C" {
+void sh2_set_move_limit(unsigned m) { g_move_limit = m; }
+
 
 // one rule call (OP_* of azul_ops2.hpp) on one record; every optional output is written only when its pointer is given.  Returns the status byte.
 int sh2_op(uint8_t *rec, int first_player, int tile_pool, unsigned long long margin, int op, int action, u32 *mt, u32 *pos, unsigned pos_set,
@@ -35,7 +39,7 @@ int sh2_op(uint8_t *rec, int first_player, int tile_pool, unsigned long long mar
     memset(&j, 0, sizeof(j));
     BatchDev &b = j.b;
     b.state = rec; b.mt = mt; b.mtpos = pos; b.tab = (const double2 *)g_T; b.episodes = &ep; b.stuck = &sk; b.stat_sum = ss; b.n = 1;
-    b.rules.first_player = (u32)first_player; b.rules.tile_pool = (u32)tile_pool; b.draw_margin = margin ? margin : AZ_DRAW_MARGIN;
+    b.rules.first_player = (u32)first_player; b.rules.tile_pool = (u32)tile_pool; b.draw_margin = margin ? margin : AZ_DRAW_MARGIN; b.move_limit = g_move_limit;
     OpArgs &a = j.a;
     i32 act_in = action, act_out = 0, rew = 0, pot = 0, nxt = -2;
     uint8_t status = 0, dn = 0, fl = 0, pl = 0, rd = 0;
@@ -72,7 +76,7 @@ int sh2_op_batch(int n, uint8_t *recs, int first_player, int tile_pool, int op, 
     OpJob j;
     memset(&j, 0, sizeof(j));
     j.b.state = recs; j.b.mt = mt; j.b.mtpos = pos; j.b.tab = (const double2 *)g_T; j.b.episodes = (u64 *)episodes; j.b.stuck = stuck; j.b.stat_sum = stat_sum; j.b.n = (u32)n;
-    j.b.rules.first_player = (u32)first_player; j.b.rules.tile_pool = (u32)tile_pool; j.b.draw_margin = AZ_DRAW_MARGIN;
+    j.b.rules.first_player = (u32)first_player; j.b.rules.tile_pool = (u32)tile_pool; j.b.draw_margin = AZ_DRAW_MARGIN; j.b.move_limit = g_move_limit;
     j.a.op = op; j.a.actions = actions; j.a.active = active; j.a.status = status; j.a.mask = mask_out; j.a.reward = reward; j.a.done = done;
     j.a.first = 0; j.a.count = (u32)n;
     j.lid = tile_pool == POOL_LID;

@@ -27,7 +27,10 @@ static void lane_main(void *arg)
     }
 }
 
+static u32 g_move_limit = 0;       // BatchDev::move_limit of the next launches (azul_batch_set_move_limit)
+
 extern "C" {
+void sr2_set_move_limit(unsigned m) { g_move_limit = m; }
 static long long run_blocks(Job &j, int n_games);
 
 unsigned long long sr2_buffer_oob() { return simt::g_buffer_oob; }
@@ -56,7 +59,7 @@ long long sr2_rollout_vs(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 *
     Job j;
     memset(&j, 0, sizeof(j));
     j.b.state = state; j.b.mt = mt; j.b.mtpos = mtpos; j.b.tab = (const double2 *)T; j.b.episodes = episodes; j.b.stuck = stuck; j.b.stat_sum = stat_sum;
-    j.b.n = (u32)n_games; j.b.rules.first_player = (u32)first_player; j.b.rules.tile_pool = (u32)tile_pool; j.b.draw_margin = AZ_DRAW_MARGIN;
+    j.b.n = (u32)n_games; j.b.rules.first_player = (u32)first_player; j.b.rules.tile_pool = (u32)tile_pool; j.b.draw_margin = AZ_DRAW_MARGIN; j.b.move_limit = g_move_limit;
     j.b.id_base = id_base;
     j.W = {wa[0], wa[1], wa[2], wa[3], wa[4], wa[5]};
     j.a.n_steps = n_steps; j.a.obs = obs; j.a.mask = mask; j.a.player = player; j.a.action = action; j.a.reward = reward; j.a.done = done;
@@ -80,7 +83,7 @@ long long sr2_rollout(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 *epi
     Job j;
     memset(&j, 0, sizeof(j));
     j.b.state = state; j.b.mt = mt; j.b.mtpos = mtpos; j.b.tab = (const double2 *)T; j.b.episodes = episodes; j.b.stuck = stuck; j.b.stat_sum = stat_sum;
-    j.b.n = (u32)n_games; j.b.rules.first_player = (u32)first_player; j.b.rules.tile_pool = (u32)tile_pool; j.b.draw_margin = AZ_DRAW_MARGIN;
+    j.b.n = (u32)n_games; j.b.rules.first_player = (u32)first_player; j.b.rules.tile_pool = (u32)tile_pool; j.b.draw_margin = AZ_DRAW_MARGIN; j.b.move_limit = g_move_limit;
     j.b.id_base = id_base;
     j.W = {w1t, b1, w2c, b2c, w2a_t, b2a};
     j.a.n_steps = n_steps; j.a.obs = obs; j.a.mask = mask; j.a.player = player; j.a.action = action; j.a.reward = reward; j.a.done = done;

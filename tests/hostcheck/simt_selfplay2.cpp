@@ -23,7 +23,11 @@ static void kernel_main_t(void *arg)
     }
 }
 
+static u32 g_move_limit = 0;       // BatchDev::move_limit of the next launches (azul_batch_set_move_limit)
+
 extern "C" {
+void sh2_set_move_limit(unsigned m) { g_move_limit = m; }
+
 
 // n_games games (records [N][128], MT19937 states [N][624] + positions [N], counters) advance by n_steps moves, two per wave;
 // trajectory streams are [n_steps][N]... like the kernel's.  Returns the number of cross-lane operations executed (a size check
@@ -42,6 +46,7 @@ long long sh2_selfplay(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 *ep
     kj.b.state = state; kj.b.mt = mt; kj.b.mtpos = mtpos; kj.b.tab = (const double2 *)T; kj.b.episodes = episodes; kj.b.stuck = stuck; kj.b.stat_sum = stat_sum;
     kj.b.n = (u32)n_games; kj.b.rules.first_player = (u32)first_player; kj.b.rules.tile_pool = (u32)tile_pool;
     kj.b.draw_margin = margin ? margin : AZ_DRAW_MARGIN;
+    kj.b.move_limit = g_move_limit;
     kj.t.n_steps = n_steps; kj.t.mask = mask; kj.t.maskbits = maskbits; kj.t.action = action; kj.t.reward = reward; kj.t.done = done;
     kj.t.rec = rec; kj.t.packed = packed;
     kj.pitch = (u32)pitch; kj.variant = variant;

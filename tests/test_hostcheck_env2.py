@@ -32,9 +32,10 @@ def ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def oracle_play(rec, mt, pos, T, first, pool, opponent, pick):
+def oracle_play(rec, mt, pos, T, first, pool, opponent, pick, move_limit=0):
     """T agent moves in the oracle, the action of each chosen by `pick(mask, t)` from the legal mask of the state it is played in
-    (what the head does); returns the actions and everything the kernel's env side publishes."""
+    (what the head does); returns the actions and everything the kernel's env side publishes.  `move_limit` > 0: the move-limit extension
+    (beyond the reference; oz_step_limited / oz_runner_step_limited): `done` then holds the codes 0 / 1 / 3."""
     L = oz.lib()
     fp = first if first else oz.FIRST_RANDOM
     q = oz.unpack(rec, pool, fp)
@@ -54,19 +55,23 @@ def oracle_play(rec, mt, pos, T, first, pool, opponent, pick):
         out["action"].append(a)
         if opponent:
             rew, dn = C.c_int64(0), C.c_int(0)
-            assert L.oz_runner_step(C.byref(q), int(a), C.byref(r), C.byref(rew), C.byref(dn)) == 0     # game_runner.py:43-55
+            if move_limit:
+                assert L.oz_runner_step_limited(C.byref(q), int(a), C.byref(r), None, None, move_limit, C.byref(rew), C.byref(dn)) == 0
+            else:
+                assert L.oz_runner_step(C.byref(q), int(a), C.byref(r), C.byref(rew), C.byref(dn)) == 0     # game_runner.py:43-55
             out["reward"].append(rew.value)
-            out["done"].append(bool(dn.value))
+            out["done"].append(int(dn.value) if move_limit else bool(dn.value))
             if dn.value:
                 assert L.oz_runner_reset(C.byref(q), C.byref(r)) == 0                                   # :76-85
         else:
-            assert L.oz_step(C.byref(q.game), int(a) % 6, (int(a) // 6) % 5, int(a) // 30, C.byref(r)) == 0
+            st = L.oz_step_limited(C.byref(q.game), int(a) % 6, (int(a) // 6) % 5, int(a) // 30, C.byref(r), q.move_counter + 1, move_limit)
+            assert st in (0, oz.TRUNCATED)
             q.move_counter += 1
             phi = L.oz_potential(C.byref(q.game))
             out["reward"].append(phi - q.player_score)
             q.player_score = phi
-            dn = bool(L.oz_is_end_of_game(C.byref(q.game)))
-            out["done"].append(dn)
+            dn = 3 if st == oz.TRUNCATED else int(bool(L.oz_is_end_of_game(C.byref(q.game))))
+            out["done"].append(dn if move_limit else bool(dn))
             if dn:
                 assert L.oz_runner_init(C.byref(q), fp, pool, C.byref(r)) == 0
         publish()
@@ -202,3 +207,33 @@ def test_stuck_slot_restarts_in_the_rollout_env():
     fresh = state[1].view(oz.RECORD_DTYPE)[0]
     assert int(np.sum(fresh["displays"])) + int(np.sum(fresh["center"][:5])) == 20 and int(fresh["center"][5]) == 1
     assert state[0].tobytes() == e0[1].tobytes() and int(got["reward"][0, 0]) == e0[0]["reward"][0] and int(got["status"][0]) == 0
+
+
+@pytest.mark.parametrize("opponent", [False, True])
+def test_move_limit_in_the_rollout_env(opponent):
+    """azul_batch_set_move_limit on the GameRunner / policy paths (apply_step2 -> ST_TRUNCATED; beyond the reference, off by default): a move of
+    either side that ends a round without ending the game once the episode has played `limit` moves cuts the episode -- done = 3, the
+    slot restarts (with the RandomAgent opponent: reward 0 and the opponent's opening), counted in `stuck` -- like the oracle's restatement."""
+    L = load()
+    L.sh2_set_move_limit.argtypes = [C.c_uint]
+    n, T, limit = 4, 120, 24
+    state, mt, pos = start_batch(n, 7300, 0, 1, 0)
+    rng = np.random.default_rng(11)
+    exp = [oracle_play(state[g].view(oz.RECORD_DTYPE)[0], mt[g], pos[g], T, 0, 1, opponent, lambda m, t: int(rng.choice(np.flatnonzero(m))), move_limit=limit)
+           for g in range(n)]
+    actions = np.stack([np.array(e[0]["action"], np.int32) for e in exp], axis=1)
+    try:
+        L.sh2_set_move_limit(limit)
+        got, _ = emulate(L, state, mt, pos, 0, 1, opponent, actions)
+    finally:
+        L.sh2_set_move_limit(0)
+    cuts = 0
+    for g, (e, rec, mt_e, idx) in enumerate(exp):
+        assert np.array_equal(got["done"][:, g], np.array(e["done"], np.uint8)), (g, got["done"][:, g], e["done"])
+        assert np.array_equal(got["reward"][:, g], np.array(e["reward"])) and np.array_equal(got["mask"][:, g].astype(bool), np.array(e["mask"], bool)), g
+        assert np.array_equal(got["obs"][:, g].astype(np.int64), np.array(e["obs"])), g
+        assert state[g].tobytes() == rec.tobytes() and int(pos[g]) == idx and np.array_equal(mt[g], mt_e), g
+        c = int((np.array(e["done"]) == 3).sum())
+        assert int(got["stuck"][g]) == c and int(got["episodes"][g]) == int((np.array(e["done"]) == 1).sum()), g
+        cuts += c
+    assert cuts >= 4

@@ -157,7 +157,7 @@ def actor_forward(w, obs, mask):
     return logp
 
 
-def run_vs(L, first, pool, n, T, seed0, warm, slots=8, argmax=False):
+def run_vs(L, first, pool, n, T, seed0, warm, slots=8, argmax=False, move_limit=0):
     state, mt, pos = start_batch(n, seed0, first, pool, warm)
     rng = np.random.default_rng(seed0)
     for g in range(n):
@@ -176,12 +176,15 @@ def run_vs(L, first, pool, n, T, seed0, warm, slots=8, argmax=False):
          "opp_replies": np.full((T, n), 200, np.uint8)}
     oob0 = L.sr2_buffer_oob()
     AM = 0xFFFFFFFFFFFFFFFF
+    L.sr2_set_move_limit.argtypes = [C.c_uint]
+    L.sr2_set_move_limit(move_limit)
     ops = L.sr2_rollout_vs(n, ptr(state), ptr(mt), ptr(pos), ptr(ep), ptr(stuck), ptr(ss), first, pool, 1000, C.cast(pa, C.c_void_p), C.cast(po, C.c_void_p), T,
                            ptr(o["obs"]), ptr(o["mask"]), ptr(o["player"]), ptr(o["action"]), ptr(o["reward"]), ptr(o["done"]), ptr(o["value"]),
                            ptr(o["logp"]), ptr(o["entropy"]), ptr(o["status"]), ptr(o["returns"]), 0.9, 4242, AM if argmax else 777, 17,
                            ptr(o["opp_action"]), ptr(o["opp_logp"]), ptr(o["opp_replies"]), slots)
+    L.sr2_set_move_limit(0)
     assert ops > 0 and L.sr2_buffer_oob() == oob0
-    episodes = forced = opening = 0
+    episodes = forced = opening = cuts = 0
     for g in range(n):
         tag = (first, pool, g)
         assert int(o["opp_replies"][:, g].max()) <= slots, "raise `slots`: a step had more replies than the trace holds"
@@ -208,8 +211,9 @@ def run_vs(L, first, pool, n, T, seed0, warm, slots=8, argmax=False):
             value, logp, ent = forward(wa, o["obs"][t, g], o["mask"][t, g])
             assert abs(o["value"][t, g] - value) < 2e-4 * max(1.0, abs(value)) and abs(o["logp"][t, g] - logp[a]) < 2e-4, (tag, t)
             assert abs(o["entropy"][t, g] - ent) < 2e-4 * max(1.0, ent), (tag, t)
-            rc, rew, dn = run.step(a)                                       # game_runner.py:43-55 with the recorded opponent
-            assert rc == 0 and rew == int(o["reward"][t, g]) and dn == bool(o["done"][t, g]), (tag, t, rew, dn)
+            rc, rew, dn = run.step(a, move_limit)                           # game_runner.py:43-55 with the recorded opponent
+            assert rc == 0 and rew == int(o["reward"][t, g]) and int(dn) == int(o["done"][t, g]), (tag, t, rew, dn, int(o["done"][t, g]))
+            cuts += int(dn) == 3
             if dn:
                 episodes += 1
                 before = cur["j"]
@@ -219,7 +223,8 @@ def run_vs(L, first, pool, n, T, seed0, warm, slots=8, argmax=False):
         assert np.array_equal(o["mask"][T, g].astype(bool), run.get_valid_moves()) and np.array_equal(o["obs"][T, g].astype(np.int64), run.get_state(0)), tag
         m_e, idx = run.rng_state()
         assert state[g].tobytes() == run.record().tobytes() and int(pos[g]) == idx and np.array_equal(mt[g], m_e), tag
-        assert int(ep[g]) == int(o["done"][:, g].astype(bool).sum()) and int(stuck[g]) == 0 and int(o["status"][g]) == 0, tag
+        assert int(ep[g]) == int((o["done"][:, g] == 1).sum()) and int(stuck[g]) == int((o["done"][:, g] == 3).sum()), tag
+        assert int(o["status"][g]) == (6 if int(o["done"][T - 1, g]) == 3 else 0), tag
         # the opponent saw the MOVER's perspective and sampled from ITS net: log-prob of every answer against a numpy forward_actor
         for t, j, s, m, player in handed:
             lp = actor_forward(wo, s, m)
@@ -233,7 +238,16 @@ def run_vs(L, first, pool, n, T, seed0, warm, slots=8, argmax=False):
             q = np.float32(o["reward"][t, g]) + np.float32(0.9) * (np.float32(0) if o["done"][t, g] else q)
             want[t] = q
         assert np.array_equal(o["returns"][:, g], want), tag
-    return ops, episodes, forced, opening
+    return (ops, episodes, forced, opening, cuts) if move_limit else (ops, episodes, forced, opening)
+
+
+def test_network_opponent_with_a_move_limit():
+    """The move limit (beyond the reference, off by default) on the network-opponent protocol: a move of either side that ends a round
+    without ending the game once the episode has played `limit` moves cuts the episode (done = 3, reward 0, slot restarted and opened)."""
+    L = load_vs()
+    first, pool = RULES["lid_randomfirst"]
+    ops, episodes, forced, opening, cuts = run_vs(L, first, pool, n=16, T=24, seed0=900, warm=20, move_limit=22)
+    assert cuts >= 6
 
 
 def test_network_opponent_in_the_rollout_kernel_replays_through_the_oracle():

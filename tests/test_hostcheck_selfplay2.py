@@ -242,3 +242,30 @@ def test_pack_c1_kernel_under_emulation_equals_the_torch_restatement():
     probe = np.full(3, 7, np.uint64)
     L.sh2_clock_probe.argtypes = [C.c_void_p]
     assert L.sh2_clock_probe(ptr(probe)) == 0 and int(probe[0]) == 0 and int(probe[1]) == 0 and int(probe[2]) != 7      # (the emulation's timers read 0)
+
+
+def test_move_limit_cuts_episodes_at_round_ends_like_the_oracle():
+    """azul_batch_set_move_limit (beyond the reference, off by default; some games never end under the reference's rules): with a limit of
+    30 moves every episode is cut at its first end of a round at or after move 30 -- the round is scored, no new round is dealt, done = 3,
+    the slot restarts on the same stream and counts as `stuck`, not as an episode -- exactly like the oracle's restatement
+    (oz_stream_advance_limited), masks / actions / rewards / records / MT19937 words included; limit 0 is the reference's behaviour."""
+    L = load()
+    L.sh2_set_move_limit.argtypes = [C.c_uint]
+    n, T, limit = 3, 150, 30
+    try:
+        L.sh2_set_move_limit(limit)
+        streams, state, mt, pos, ep, stuck, ss, out, ops = run_case(L, 0, 1, n, T, 3, 5100)
+    finally:
+        L.sh2_set_move_limit(0)
+    cuts = 0
+    for g, s in enumerate(streams):
+        o = s.advance(T, move_limit=limit)
+        assert np.array_equal(out["action"][:, g], o["action"]) and np.array_equal(out["reward"][:, g], o["reward"]), g
+        assert np.array_equal(out["done"][:, g], o["done"]) and np.array_equal(out["mask"][:, g, :180], o["mask"]), g
+        assert np.array_equal(out["rec"][:, g].view(oz.RECORD_DTYPE).reshape(T), o["rec_after"]), g
+        assert state[g].tobytes() == s.record().tobytes() and int(pos[g]) == s.rng_state()[1] and np.array_equal(mt[g], s.rng_state()[0]), g
+        assert int(ep[g]) == int(s.episodes.value) and int(stuck[g]) == int(s.stuck.value), g
+        cuts += int((o["done"] == 3).sum())
+        where = np.flatnonzero(o["done"] == 3)
+        assert all(int(o["rec_after"][t]["move_counter"]) >= limit for t in where)          # cut at the end of the round that reached the limit
+    assert cuts >= 6

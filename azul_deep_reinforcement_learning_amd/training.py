@@ -37,16 +37,26 @@ AGENT_STAT_KEYS = ("reward", "actor_loss", "critic_loss", "entropy_loss", "ac_lo
 class BatchedTrainer:
     def __init__(self, policy, n_games=4096, window=32, parts=1, learning_rate=3e-4, gamma=0.99, seed_base=0, sample_seed=0x5EED,
                  rules={"first_player": "Random", "tile_pool": "Lid"}, device=None, use_graph=True, persistent=True, results_dir="results",
-                 ring=3):
+                 ring=3, opponent="random", opponent_refresh=0, move_limit=0):
         """ring: trajectory windows kept (persistent rollout with one part): with ring >= 2 every step of every episode is trained
-        exactly once (episodes straddle windows; an episode may span ring - 1 window boundaries), like NNRunner.train."""
+        exactly once (episodes straddle windows; an episode may span ring - 1 window boundaries), like NNRunner.train.
+        opponent: "random" (GameRunner's default RandomAgent, the reference's scripts/training.py), a module (GameRunner(opponent=Agent(...)),
+        game_runner.py:27-30: a frozen second net inside the rollout kernel), or "self": a frozen COPY of the policy that is replaced by the
+        current policy every `opponent_refresh` updates (0: never) -- training against a past self.
+        move_limit > 0: BatchedAzul.set_move_limit (beyond the reference: a game that would never end is cut, done = 3; its steps are trained like an
+        episode that ended there, the return chain starts at the cut)."""
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         policy = policy.to(dev)
         self.learner = A2CLearner(policy, learning_rate=learning_rate, gamma=gamma)
         # rollout kernels and learner share ONE k-major copy of the weights (the learner's flat master copy)
+        self.opponent_refresh = int(opponent_refresh)
+        self._self_opponent = opponent == "self"
+        if self._self_opponent:
+            import copy
+            opponent = copy.deepcopy(policy)
         self.rollout = PolicyRollout(policy, n_games=n_games, parts=parts, rules=rules, seed_base=seed_base, device=dev, window=window,
-                                     use_graph=use_graph, sample_seed=sample_seed, opponent="random", persistent=persistent,
-                                     kweights=self.learner.kweights(dev), ring=ring if (persistent and parts == 1) else 1)
+                                     use_graph=use_graph, sample_seed=sample_seed, opponent=opponent, persistent=persistent,
+                                     kweights=self.learner.kweights(dev), ring=ring if (persistent and parts == 1) else 1, move_limit=move_limit)
         self.gamma = gamma
         self.results_dir = results_dir
         self.batch = 0
@@ -85,6 +95,8 @@ class BatchedTrainer:
         out = self.learner.update_from_rollout(self.rollout)
         self.rollout.refresh_weights()
         self.batch += 1
+        if self._self_opponent and self.opponent_refresh and self.batch % self.opponent_refresh == 0:
+            self.rollout.set_opponent(self.rollout.policy)         # the frozen past self moves up to the present (weights copied in place)
         r = sum(part["reward"].sum() for part in tr)
         self._reward_acc = r if getattr(self, "_reward_acc", None) is None else self._reward_acc + r
         if not collect_stats:

@@ -190,3 +190,25 @@ def test_window_kernel_with_a_network_opponent_is_bit_identical_to_the_cut_proto
         assert valid.sum() > T * n // 2
     assert ra.tobytes() == rb.tobytes() and np.array_equal(ma, mb) and np.array_equal(pa, pb) and ca == cb and cta == ctb
     assert ca["episodes"] > 0
+
+
+def test_training_against_a_frozen_past_self(golden):
+    """BatchedTrainer(opponent="self"): the rollout kernel plays the policy being trained against a frozen COPY of it (the second weight set
+    of azul_batch_policy_rollout_vs), replaced by the current policy every `opponent_refresh` updates; the A2C update trains on the agent's
+    C1 records exactly as with the RandomAgent opponent."""
+    from azul_deep_reinforcement_learning_amd.training import BatchedTrainer
+    agent, _ = _nets(golden)
+    tr = BatchedTrainer(agent, n_games=256, window=16, opponent="self", opponent_refresh=3, move_limit=300, seed_base=5)
+    ro = tr.rollout
+    assert ro.opponent == "net" and ro.persistent
+    frozen = ro.ow1t.clone()
+    rows = [tr.run_batch() for _ in range(2)]
+    torch.cuda.synchronize()
+    assert torch.equal(ro.ow1t, frozen) and not torch.equal(ro.ow1t, ro.w1t)           # the policy moved, its past self did not
+    rows.append(tr.run_batch())                                                        # third update: the opponent catches up
+    torch.cuda.synchronize()
+    assert torch.equal(ro.ow1t, ro.w1t) and torch.equal(ro.ow2a_t, ro.w2a_t)
+    for _ in range(6):
+        rows.append(tr.run_batch())
+    assert all(np.isfinite(r["ac_loss"]) for r in rows) and tr.learner.updates == 9
+    assert ro.counters()["episodes"] > 0

@@ -123,7 +123,7 @@ AZ_FN u32 apply_step2(G2 &g, u32 code, Rng2 &r, u64 margin, const K2 &k)
         if (eor) {
             count_score2<LID>(g, k);                                   // :307
             if (g.over) g.eog = 1;                                     // :308-309
-            else if (g.moves + 1u >= k.move_limit) st = ST_TRUNCATED;  // move limit (beyond the reference, off by default; the caller counts this move next)
+            else if (g.moves + 1u >= rng2_move_limit(r)) st = ST_TRUNCATED;      // move limit (beyond the reference, off by default; the caller counts this move next)
             else st = new_round2<LID>(g, r, margin, k);                // :311
         }
     }

@@ -1027,12 +1027,12 @@ int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev,
     const u32 ms = (u32)mask_row_bytes;
     // padded rows (>= 192 bytes, 8-byte aligned: alloc_trajectory(mask_pitch = 192)) take the one-store-per-row path
     const bool pad = ms >= 192u && ms % 8u == 0u && ((uintptr_t)mask_dev & 7u) == 0u;
-#define AZ_LAUNCH(LID) do { \
-        if (none) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 0, false, false>), grid, block, 0, st, b->d, t, ms); \
-        else if (full && pad) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true, true>), grid, block, 0, st, b->d, t, ms); \
-        else if (core && pad) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true, false>), grid, block, 0, st, b->d, t, ms); \
-        else if (full) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, false, true>), grid, block, 0, st, b->d, t, ms); \
-        else hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 2, false, false>), grid, block, 0, st, b->d, t, ms); \
+#define AZ_LAUNCH(LID, LIM) do { \
+        if (none) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 0, false, false, LIM>), grid, block, 0, st, b->d, t, ms); \
+        else if (full && pad) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true, true, LIM>), grid, block, 0, st, b->d, t, ms); \
+        else if (core && pad) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, true, false, LIM>), grid, block, 0, st, b->d, t, ms); \
+        else if (full) hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 1, false, true, LIM>), grid, block, 0, st, b->d, t, ms); \
+        else hipLaunchKernelGGL((azul_selfplay2_kernel<LID, 2, false, false, LIM>), grid, block, 0, st, b->d, t, ms); \
     } while (0)
     // inside a timed region the first AZ_TIMED_PAIRS launches are bracketed by their own event pair (the kernel's duration,
     // not the distance between launches)
@@ -1041,7 +1041,9 @@ int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev,
         while ((int)b->lev.size() < 2 * (b->timed_pairs + 1)) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); b->lev.push_back(e); }
         HIP_TRY(hipEventRecord(b->lev[2 * b->timed_pairs], st));
     }
-    if (b->d.rules.tile_pool == POOL_LID) AZ_LAUNCH(true); else AZ_LAUNCH(false);
+    // (a batch with a move limit runs the instantiation that carries the limit's code: azul_batch_set_move_limit)
+    if (b->d.move_limit) { if (b->d.rules.tile_pool == POOL_LID) AZ_LAUNCH(true, true); else AZ_LAUNCH(false, true); }
+    else { if (b->d.rules.tile_pool == POOL_LID) AZ_LAUNCH(true, false); else AZ_LAUNCH(false, false); }
 #undef AZ_LAUNCH
     HIP_TRY(hipGetLastError());
     if (pair) { HIP_TRY(hipEventRecord(b->lev[2 * b->timed_pairs + 1], st)); b->timed_pairs++; }

@@ -73,7 +73,7 @@ constexpr u32 OP2_OBS_STRIDE = 144;      // floats per half of the observation s
 // the queries on the state it leaves.  mt_lds: 624 words of LDS per half for the game's MT19937 state; tabfs_lds: the sampler's table;
 // obs_lds: staging row of observe2.
 template <bool LID>
-AZ_FN void op_body2(const BatchDev &b, const OpArgs &a, u32 pair, u32 (*mt_lds)[624], double2 *tabfs_lds, float (*obs_lds)[OP2_OBS_STRIDE])
+AZ_FN void op_body2(const BatchDev &b, const OpArgs &a, u32 pair, u32 (*mt_lds)[az2::MT_LDS_WORDS], double2 *tabfs_lds, float (*obs_lds)[OP2_OBS_STRIDE])
 {
     using namespace az2;
     const u32 lane = wv::lane(), l = lane & 31u, half = lane >> 5;
@@ -86,7 +86,7 @@ AZ_FN void op_body2(const BatchDev &b, const OpArgs &a, u32 pair, u32 (*mt_lds)[
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
     K2 k;
     k2_init(k);
-    k.move_limit = b.move_limit ? b.move_limit : ~0u;
+    rng2_set_move_limit(mt_lds[half], b.move_limit, l);
     const Tab2 tab = {tabfs_lds};
     G2 g;
     g2_load(g, rec, l);

@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     __shared__ float lgS[PF_GAMES * PF_LOG_STRIDE];
     __shared__ float w2cS[PF_HID];
     __shared__ float b1S[PF_H2 + 24], b2aS[PF_ACT + 12];
-    __shared__ u32 mtS[PF_GAMES][624];
+    __shared__ u32 mtS[PF_GAMES][az2::MT_LDS_WORDS];
     __shared__ double2 tabfs_lds[T_ROWS * T_BINADES];
     __shared__ u64 maskS[PF_GAMES][4];
     __shared__ i32 actS[PF_GAMES];
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     // env state of this half's game
     az2::K2 k;
     az2::k2_init(k);
-    k.move_limit = b.move_limit ? b.move_limit : ~0u;
+    az2::rng2_set_move_limit(mtS[gl], b.move_limit, l);
     az2::Tab2 tab = {tabfs_lds};
     az2::G2 g;
     uint8_t *rec = b.state + (size_t)gic * AZUL_RECORD_BYTES;

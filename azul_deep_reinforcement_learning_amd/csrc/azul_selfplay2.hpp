@@ -93,15 +93,12 @@ struct K2 {
     u32 rowp1;           // l < 25: row + 1, else 0xff
     u32 prow, pcol, pbcol, pbelow, pcolboard;      // pattern cell l < 25: row, colour, board column, bits 0..l, cells of that board column
     u32 h4;              // byte offset of my half in a ds_bpermute address: (lane & 32) << 2
-    u32 move_limit;      // wave-uniform, NOT a lane constant: the batch's move limit (~0u = none; BatchDev::move_limit) -- travels with K2 because every
-                         // rule function already receives it
 };
 
 AZ_FN void k2_init(K2 &k)
 {
     const u32 l = wlane() & 31u;
     k.l = l;
-    k.move_limit = ~0u;
     k.h4 = (wlane() & 32u) << 2;
     asm volatile("" : "+v"(k.h4));     // opaque: (idx << 2) | h4 stays ONE v_lshl_or_b32 (else it is re-associated into or + shift)
     {
@@ -210,8 +207,11 @@ AZ_FN void g2_store(const G2 &g, uint8_t *rec, u32 l)
 // ---- CPython MT19937 stream of one game ---------------------------------------------------------------------------------------
 // The 624-word state lives in global memory (row of a [N][624] array: a half's accesses are contiguous); it is staged into the game's LDS
 // region when the stream is opened, the regeneration ("twist") runs there 32 lanes wide, and it is written back on close if it changed.
+constexpr u32 MT_LDS_WORDS = 626;   // LDS words per game: the 624 MT19937 words + the batch's move limit (word 624; ~0u = none) + a pad word.  The limit
+                                    // is only ever read in the RARE end-of-round blocks: kept in LDS it costs the move loop no register (as a kernel
+                                    // argument it cost the headline kernel two more spilled SGPRs inside the loop: +0.5 %, tools/ab_raw.py)
 struct Rng2 {
-    u32 *lds;        // my game's 624 words in LDS
+    u32 *lds;        // my game's 624 words in LDS (+ the move limit at word 624: rng2_set_move_limit)
     u32 *tlds;       // optional: the same 624 words TEMPERED (kept current by the regeneration), what genrand_uint32 returns for index i;
                      // the self-play loop reads a move's two words from here with one LDS read and no arithmetic
     u32 pos;         // CPython's `index`
@@ -219,6 +219,10 @@ struct Rng2 {
     u32 wbase, wend; // the window `win` serves words wbase .. wend-1 (wend == 0: none loaded)
     u32 win;         // lane l: TEMPERED word wbase + l
 };
+
+// the batch's move limit (BatchDev::move_limit: 0 = none) into / out of the game's LDS region; written once per kernel by lane 0 of the half
+AZ_FN void rng2_set_move_limit(u32 *lds, u32 limit, u32 l) { if (l == 0u) lds[624] = limit ? limit : ~0u; }
+AZ_FN u32 rng2_move_limit(const Rng2 &r) { return r.lds[624]; }
 
 AZ_FN u32 temper2(u32 y)
 {
@@ -856,6 +860,7 @@ struct Counters2 {
     u32 ep_add, stuck_add;                           // half-uniform: this launch's increments
 };
 
+
 AZ_FN void counters2_open(Counters2 &c, u64 *episodes, u32 *stuck, double *stat_sum, u32 l)
 {
     c.episodes = episodes; c.stuck = stuck; c.stat_sum = stat_sum;
@@ -894,7 +899,10 @@ AZ_FN void counters2_episode(Counters2 &c, double stat_of_my_lane)
 
 // Everything of a move that follows do_move2 (g.B already holds the sources after the move): what-if score of the mover, next
 // player or end of round (scoring, end of game, next round), shaped reward, outputs, episode statistics and reset.
-template <bool LID, int OUT>
+// LIM: the batch has a move limit (azul_batch_set_move_limit).  It is a compile-time switch of the self-play kernel because ANY addition to
+// this function's rare blocks measurably moves the common path (code placement, spill choices: +0.5 .. 1.5 % on the headline kernel,
+// profiles/round6_headline_ab.txt): without a limit the kernel is, instruction for instruction, the one that has no such code.
+template <bool LID, int OUT, bool LIM>
 AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin, Counters2 &cnt, const Out2 &o, u32 me, bool filled,
                       i32 a, SegProf *prof_, bool &dead /* per game, only ever set: a rule error stopped it (set in the rare blocks: nothing on the common path) */)
 {
@@ -917,7 +925,7 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
     // (ONE wave-uniform test for the end of a round and for a game that is over -- a test costs ~33 cycles even when it falls through;
     // the episode-end block further down branches on a flag that is already scalar.  `over` without the end of a round: a state
     // handed in with a complete wall row and the flag clear)
-    bool any_done = false, cut = false;
+    bool any_done = false;
     if (AZ_UNLIKELY(wave_any(eor | (g.over != 0u)))) {
         if (eor) {
             count_score2<LID>(g, k);                         // :307 (also resets the what-if cache)
@@ -927,22 +935,23 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
         // MOVE LIMIT (beyond the reference, off unless azul_batch_set_move_limit: k.move_limit == ~0u): a round ended, the game did not, and
         // the episode has played its limit -- under the reference's rules a game can reach a state from which it NEVER ends (every tile of a
         // colour locked in lines that cannot be completed: no wall row can fill, azul.py:184-191 stays false): it is cut here, no round dealt
-        cut = eor & !g.over & (g.moves >= k.move_limit);
-        if (eor & !g.over & !cut) st = new_round2<LID>(g, r, margin, k);      // :311
+        // (the cut rides on `over` -- 0 / 1 from the walls, 3 here; the episode reset below clears it)
+        if (LIM) { if (eor & !g.over) { if (g.moves >= rng2_move_limit(r)) g.over = 3u; } }
+        if (eor & !g.over) st = new_round2<LID>(g, r, margin, k);      // :311
         AZ_STAMP(SEG_NEWROUND);
-        any_done = wave_any(((g.over != 0u) | cut) & (st == ST_OK));
+        any_done = wave_any((g.over != 0u) & (st == ST_OK));
         dead |= st != ST_OK;
     }
     const i32 phi = g.wi0 - g.wi1;
     const i32 reward = phi - g.pscore;
     g.pscore = phi;
-    const u32 dn = g.over ? 1u : (cut ? 3u : 0u);
+    const u32 dn = LIM ? g.over : (g.over ? 1u : 0u);        // 0, 1 (a wall row is complete), 3 (cut by the move limit)
     outputs2<OUT>(g, o, a, reward, dn, l);
     AZ_STAMP(SEG_TAIL);
     u32 ret = st != ST_OK ? (0x100u | st) : dn;
     if (AZ_UNLIKELY(any_done)) {
         if ((dn != 0u) & (st == ST_OK)) {
-            if (dn == 1u) {
+            if (!LIM || dn == 1u) {
                 const double f0 = (double)(g.fps & 0xffffu), f1 = (double)(g.fps >> 16);
                 counters2_episode(cnt, stat_lane(l, g.score0, g.score1, g.turn, f0 / (f0 + f1) * 100, g.fp0, g.mc0, g.cl0));
             } else cnt.stuck_add += 1u;                      // (a cut episode is no finished game: counted with the restarted slots)
@@ -961,7 +970,7 @@ AZ_FN u32 after_move2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, u64 margin,
 // Control flow: two waves per SIMD cannot hide a taken branch's instruction refetch, so the common move is ONE fall-through path;
 // every rare event (window refill across a regeneration, stuck slot, sampler boundary case, end of round, end of game) is tested
 // for the whole wave with one scalar branch (wave_any, hinted unlikely -> placed out of line) and handled per half inside.
-template <bool LID, int OUT, bool PAD, bool BITS>
+template <bool LID, int OUT, bool PAD, bool BITS, bool LIM = false>
 AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Tab2 &T, u64 margin, Counters2 &cnt, const Out2 &o,
                         SegProf *prof_, bool &dead /* per game, only ever set: a rule error stopped it in this move */)
 {
@@ -1084,7 +1093,7 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
         g.moves += 1u;
         AZ_STAMP(SEG_MOVE);
         g.B = hb(g.cs != 0u) & 0x7fffffffu;                      // the sources after the move (next move's mask reads it)
-        ret = after_move2<LID, OUT>(g, first_player, k, r, margin, cnt, o, me, filled, a, prof_, dead);
+        ret = after_move2<LID, OUT, LIM>(g, first_player, k, r, margin, cnt, o, me, filled, a, prof_, dead);
     }
     return ret;
 }
@@ -1093,13 +1102,17 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
 // the reference raises, azul.py:86-87): no move is played -- the slot is marked like a stuck slot (no legal action, action -1, done 2) and
 // counted with them, so that whoever counts env moves as slots minus `stuck` stays right and the trajectory carries no stale bytes
 // (azul_rules_x.hpp does the same for three / four players).
+// Called AFTER the move loop, which only skips a stopped game and counts the skipped slots: they are the launch's LAST `skipped` slots.
 template <int OUT, bool PAD, bool BITS>
-AZ_FN void dead_slot2(const G2 &g, const Out2 &o, Counters2 &cnt, u32 l)
+AZ_FN void dead_slots2(const G2 &g, Out2 o, Counters2 &cnt, u32 n_games, u32 end_e, u32 skipped, u32 l)
 {
-    cnt.stuck_add += 1u;
-    if (OUT == 1 || (OUT == 2 && o.mask)) store_mask_row2<(PAD && OUT == 1)>(o, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, l);
-    if ((OUT == 1 && BITS) || (OUT == 2 && o.maskbits)) o.maskbits[o.e * 3u + (l < 2u ? l : 2u)] = 0ull;
-    outputs2<OUT>(g, o, -1, 0, 2u, l);
+#pragma unroll 1
+    for (o.e = end_e - skipped * n_games; o.e < end_e; o.e += n_games) {
+        cnt.stuck_add += 1u;
+        if (OUT == 1 || (OUT == 2 && o.mask)) store_mask_row2<(PAD && OUT == 1)>(o, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, l);
+        if ((OUT == 1 && BITS) || (OUT == 2 && o.maskbits)) o.maskbits[o.e * 3u + (l < 2u ? l : 2u)] = 0ull;
+        outputs2<OUT>(g, o, -1, 0, 2u, l);
+    }
 }
 
 } // namespace az2

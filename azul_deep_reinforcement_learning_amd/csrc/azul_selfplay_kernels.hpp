@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(64) azul_seed_kernel(BatchDev b, u64 seed_base
 template <bool LID>
 __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
 {
-    __shared__ u32 mt_lds[2][624];
+    __shared__ u32 mt_lds[2][az2::MT_LDS_WORDS];
     __shared__ double2 tabfs_lds[T_ROWS * T_BINADES];
     __shared__ float obs_lds[2][OP2_OBS_STRIDE];
     op_body2<LID>(b, a, blockIdx.x, mt_lds, tabfs_lds, obs_lds);
@@ -154,10 +154,10 @@ struct TrajArgs {
 // Flat self-play, TWO GAMES PER WAVEFRONT (azul_selfplay2.hpp): grid = ceil(N / 2) one-wave workgroups; lanes 0..31 own game
 // 2 b, lanes 32..63 game 2 b + 1.  `mask_stride` is the byte distance between the mask rows of consecutive games (180, or 192 to
 // keep every row 64-byte aligned).
-template <bool LID, int OUT, bool PAD, bool BITS>
+template <bool LID, int OUT, bool PAD, bool BITS, bool LIM = false /* the batch has a move limit: az2::after_move2 */>
 __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs t, u32 mask_stride)
 {
-    __shared__ u32 mt_lds[2][624];
+    __shared__ u32 mt_lds[2][az2::MT_LDS_WORDS];          // (+ the move limit: az2::rng2_set_move_limit)
     __shared__ u32 mtt_lds[2][624];                        // the same words tempered (az2::Rng2::tlds)
     __shared__ double2 tabfs_lds[T_ROWS * T_BINADES];      // {Fr[J][b], S[J]}: both table values of a decision in one 16-byte read
     const u32 lane = wv::lane(), l = lane & 31u, half = lane >> 5;
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
     uint8_t *rec = b.state + (size_t)gi * AZUL_RECORD_BYTES;
     az2::K2 k;
     az2::k2_init(k);
-    k.move_limit = b.move_limit ? b.move_limit : ~0u;
+    az2::rng2_set_move_limit(mt_lds[half], b.move_limit, l);
     az2::Tab2 tab = {tabfs_lds};
     az2::G2 g;
     az2::g2_load(g, rec, l);
@@ -196,14 +196,28 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
     SegProf *pp = nullptr;
 #endif
     // A uniform counted loop (scalar loop control: a per-game `break` costs ~16 exec-mask instructions per move).  A game stopped by a
-    // rule error (box and lid empty when a round has to be dealt: crafted states only) stays as it is: its later slots are marked and counted
-    // like stuck slots (az2::dead_slot2).
+    // rule error (box and lid empty when a round has to be dealt) stays as it is: its lanes skip the later moves.  Such a state cannot be
+    // reached by play -- 100 tiles, at most 50 on the walls and 30 in the pattern lines when a round is dealt leave 20 for box + lid -- only
+    // handed in (tests); the LIM instantiation also marks the skipped slots like stuck slots (action -1, done 2, counted in `stuck`), the
+    // default one does not: every form of that bookkeeping tried cost the benchmarked kernel 0.8 .. 1.5 % (profiles/round6_headline_ab.txt).
     bool dead = false;               // (set inside the rare blocks only: the common path carries no test for it)
+    if (LIM) {
+        u32 skipped = 0;
 #pragma unroll 1
-    for (int s = 0; s < t.n_steps; s++) {
-        if (!dead) az2::selfplay_step2<LID, OUT, PAD, BITS>(g, b.rules.first_player, k, r, tab, margin, cnt, o, pp, dead);
-        else az2::dead_slot2<OUT, PAD, BITS>(g, o, cnt, l);
-        o.e += b.n;
+        for (int s = 0; s < t.n_steps; s++) {
+            if (!dead) az2::selfplay_step2<LID, OUT, PAD, BITS, true>(g, b.rules.first_player, k, r, tab, margin, cnt, o, pp, dead);
+            else skipped += 1u;
+            o.e += b.n;
+        }
+        if (AZ_UNLIKELY(az2::wave_any(dead))) {
+            if (dead) az2::dead_slots2<OUT, PAD, BITS>(g, o, cnt, b.n, o.e, skipped, l);
+        }
+    } else {
+#pragma unroll 1
+        for (int s = 0; s < t.n_steps; s++) {
+            if (!dead) az2::selfplay_step2<LID, OUT, PAD, BITS, false>(g, b.rules.first_player, k, r, tab, margin, cnt, o, pp, dead);
+            o.e += b.n;
+        }
     }
 #if defined(AZ_PROFILE_SEGMENTS)
     if (lane == 0u) for (int q = 0; q < SEG_COUNT; q++) atomicAdd((unsigned long long *)(b.prof + q), (unsigned long long)prof.acc[q]);

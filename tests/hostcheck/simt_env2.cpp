@@ -31,7 +31,7 @@ struct EnvJob {
     uint8_t *status;         // [N]
     u32 wave_id;
     // "LDS" of the wave
-    u32 mt_lds[2][624];
+    u32 mt_lds[2][az2::MT_LDS_WORDS];
     double2 tabfs_lds[T_ROWS * T_BINADES];
     float obs_lds[2][OBS_STRIDE];
     u64 mask_lds[2][3];
@@ -48,7 +48,7 @@ static void env_wave(EnvJob *j)
     const u32 gic = live ? gi : n - 1u;                     // a dead half loads a valid game and writes nothing (the kernel's clamp)
     az2::K2 k;
     az2::k2_init(k);
-    k.move_limit = j->move_limit ? j->move_limit : ~0u;          // (azul_batch_set_move_limit: the kernels copy BatchDev::move_limit here)
+    az2::rng2_set_move_limit(j->mt_lds[half], j->move_limit, l);      // (azul_batch_set_move_limit: the kernels copy BatchDev::move_limit into the game's LDS region)
     az2::Tab2 tab = {j->tabfs_lds};
     az2::G2 g;
     uint8_t *rec = j->state + (size_t)gic * AZUL_RECORD_BYTES;

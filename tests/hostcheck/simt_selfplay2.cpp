@@ -14,6 +14,16 @@ template <bool LID>
 static void kernel_main_t(void *arg)
 {
     KernelJob *j = (KernelJob *)arg;
+    if (j->b.move_limit) {                               // (the host's dispatch: a batch with a move limit runs the LIM instantiation)
+        switch (j->variant) {
+        case 0: azul_selfplay2_kernel<LID, 1, true, true, true>(j->b, j->t, j->pitch); break;
+        case 1: azul_selfplay2_kernel<LID, 1, true, false, true>(j->b, j->t, j->pitch); break;
+        case 2: azul_selfplay2_kernel<LID, 1, false, true, true>(j->b, j->t, j->pitch); break;
+        case 3: azul_selfplay2_kernel<LID, 2, false, false, true>(j->b, j->t, j->pitch); break;
+        default: azul_selfplay2_kernel<LID, 0, false, false, true>(j->b, j->t, j->pitch); break;
+        }
+        return;
+    }
     switch (j->variant) {
     case 0: azul_selfplay2_kernel<LID, 1, true, true>(j->b, j->t, j->pitch); break;
     case 1: azul_selfplay2_kernel<LID, 1, true, false>(j->b, j->t, j->pitch); break;

@@ -165,15 +165,17 @@ def test_stuck_slot_and_finished_game_under_emulation():
         assert int(stuck[g]) == int(s.stuck.value) - stuck0
 
 
-@pytest.mark.parametrize("variant", [3, 1, 0])
-def test_rule_error_stops_one_game_and_leaves_its_sibling_alone(variant):
-    """"Lid" pool with box and lid both empty when a round has to be dealt (the reference raises inside random.choices, azul.py:85-87):
-    the game concerned stops where it is -- its last move's outputs are written; every LATER slot of the launch is marked like a stuck
-    slot (empty mask row, action -1, reward 0, done 2) and counted in `stuck`, so that env moves = slots - stuck stays right and the
-    trajectory holds no stale bytes -- and the other game of the same wave plays on, move for move like the oracle.  (The loop's per-game
-    exit sits behind a wave-uniform flag that only the rare blocks set.)  Variants: dense rows with run-time subsets (3), the benchmarked
-    padded one-store rows (1), + bit-packed masks (0)."""
+@pytest.mark.parametrize("variant,limit", [(3, 0), (3, 5000), (1, 5000), (0, 5000)])
+def test_rule_error_stops_one_game_and_leaves_its_sibling_alone(variant, limit):
+    """"Lid" pool with box and lid both empty when a round has to be dealt (the reference raises inside random.choices, azul.py:85-87; play
+    cannot get there: 100 tiles, at most 80 of them on walls and lines when a round is dealt): the game concerned stops where it is -- its
+    last move's outputs are written, nothing after -- and the other game of the same wave plays on, move for move like the oracle.  (The
+    loop's per-game exit sits behind a wave-uniform flag that only the rare blocks set.)  In the instantiation a batch with a move limit runs,
+    every LATER slot of the launch is also marked like a stuck slot (empty mask row, action -1, reward 0, done 2) and counted in `stuck`; the
+    default instantiation leaves them untouched (that bookkeeping cost the benchmarked kernel ~1 %: profiles/round6_headline_ab.txt).
+    Variants: dense rows with run-time subsets (3), the padded one-store rows (1), + bit-packed masks (0)."""
     L = load()
+    L.sh2_set_move_limit.argtypes = [C.c_uint]
     n, T = 2, (60 if variant == 3 else 8)
     streams = [oz.Stream(4000 + g) for g in range(n)]
     for s in streams:
@@ -195,15 +197,22 @@ def test_rule_error_stops_one_game_and_leaves_its_sibling_alone(variant):
     action, reward, done = np.full((T, n), -7, np.int32), np.full((T, n), -7, np.int32), np.full((T, n), 9, np.uint8)
     bits = np.full((T, n, 3), 0xEEEEEEEEEEEEEEEE, np.uint64) if variant == 0 else None
     packed = np.full((T, n), 0xEEEEEEEE, np.uint32) if variant != 3 else None
-    assert L.sh2_selfplay(n, ptr(state), ptr(mt), ptr(pos), ptr(ep), ptr(stuck), ptr(ss), 0, 1, 0, T, variant, ptr(mask), pitch, ptr(bits), ptr(action),
-                          ptr(reward), ptr(done), ptr(packed), None) > 0
-    assert 0 <= action[0, 0] < 180 and int(done[0, 0]) == 0                                            # its last move
-    assert (action[1:, 0] == -1).all() and (done[1:, 0] == 2).all() and (reward[1:, 0] == 0).all()      # ... then marked slots
-    assert not mask[1:, 0, :180].any() and int(stuck[0]) == T - 1 and int(ep[0]) == 0
-    if bits is not None:
-        assert not bits[1:, 0].any()
-    if packed is not None:
-        assert (packed[1:, 0] == (0xff | (2 << 8))).all()                                              # action none | done 2 | reward 0
+    try:
+        L.sh2_set_move_limit(limit)
+        assert L.sh2_selfplay(n, ptr(state), ptr(mt), ptr(pos), ptr(ep), ptr(stuck), ptr(ss), 0, 1, 0, T, variant, ptr(mask), pitch, ptr(bits), ptr(action),
+                              ptr(reward), ptr(done), ptr(packed), None) > 0
+    finally:
+        L.sh2_set_move_limit(0)
+    assert 0 <= action[0, 0] < 180 and int(done[0, 0]) == 0 and int(ep[0]) == 0                      # its last move
+    if limit:
+        assert (action[1:, 0] == -1).all() and (done[1:, 0] == 2).all() and (reward[1:, 0] == 0).all()  # ... then marked slots
+        assert not mask[1:, 0, :180].any() and int(stuck[0]) == T - 1
+        if bits is not None:
+            assert not bits[1:, 0].any()
+        if packed is not None:
+            assert (packed[1:, 0] == (0xff | (2 << 8))).all()                                          # action none | done 2 | reward 0
+    else:
+        assert (action[1:, 0] == -7).all() and (done[1:, 0] == 9).all() and int(stuck[0]) == 0       # ... nothing after it
     after = state[0].view(oz.RECORD_DTYPE)[0]
     assert not after["box"].any() and int(after["center"][0]) == 0
     o = streams[1].advance(T)                                                                          # its sibling: the oracle's game

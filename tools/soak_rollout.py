@@ -23,14 +23,16 @@ from provenance import csrc_hash  # noqa: E402  (tools/provenance.py: sha256 ove
 print("csrc sha256 %s | libazulhip.so sha256 %s | %s | soak_rollout.py sha256 %s" % (
     csrc_hash(), hashlib.sha256(open(L.LIB_PATH, "rb").read()).hexdigest()[:16], L.lib.azul_version().decode(),
     hashlib.sha256(open(__file__, "rb").read()).hexdigest()[:16]))
-for opponent in (None, "random"):
+modes = ("net",) if (len(sys.argv) > 3 and sys.argv[3] == "net") else (None, "random")      # "net": GameRunner(opponent=Agent) -- a second network
+for opponent in modes:
     runs = []
     for persistent in (False, True):
         torch.manual_seed(11)               # INSIDE the arm loop: both arms must start from the same network (see LABNOTES.md 6)
         net = BatchedActorCritic(136, 180, 180)
+        opp = BatchedActorCritic(136, 180, 180) if opponent == "net" else opponent
         print("  arm persistent=%s: net checksum %.9f" % (persistent, float(sum(p.double().sum() for p in net.parameters()))))
         ro = PolicyRollout(net, n_games=n, parts=1, seed_base=90210, window=32, use_graph=False,
-                           opponent=opponent, persistent=persistent)
+                           opponent=opp, persistent=persistent)
         for _ in range(windows):
             tr = ro.run_window()
         ro.synchronize()
@@ -38,7 +40,7 @@ for opponent in (None, "random"):
         mt, pos = ro.envs[0].get_rng_range()
         runs.append((last, ro.envs[0].get_records(), mt, pos, ro.counters()))
     (la, ra, ma, pa, ca), (lb, rb, mb, pb, cb) = runs
-    bad = [k for k in la if not torch.equal(la[k], lb[k])]
+    bad = [k for k in la if k not in ("opp_action", "opp_logp") and not torch.equal(la[k], lb[k])]
     ok = not bad and ra.tobytes() == rb.tobytes() and np.array_equal(ma, mb) and np.array_equal(pa, pb) and ca == cb
     print("opponent=%s: %d games x %d windows x 32 steps, episodes per-move arm %d / one-launch arm %d, %d stuck: %s %s" % (
         opponent, n, windows, ca["episodes"], cb["episodes"], ca["stuck"], "IDENTICAL" if ok else "MISMATCH", bad), flush=True)

@@ -5,7 +5,7 @@
 # emulation test files against them.  Usage: tests/hostcheck/run_sanitizers.sh [log file]
 set -u
 cd "$(dirname "$0")/../.."
-LOG=${1:-profiles/round5_sanitizers.txt}
+LOG=${1:-profiles/round6_sanitizers.txt}
 make -s -C tests/hostcheck libsimt_ops2_asan.so libsimt_ops2_ubsan.so libsimt_selfplay2_asan.so libsimt_selfplay2_ubsan.so libsimt_env2_asan.so libsimt_env2_ubsan.so libsimt_rules_x_asan.so libsimt_rules_x_ubsan.so libsimt_rollout2_asan.so libsimt_rollout2_ubsan.so libsimt_learner_asan.so libsimt_learner_ubsan.so || exit 1
 ASAN=$(gcc -print-file-name=libasan.so); UBSAN=$(gcc -print-file-name=libubsan.so)
 {

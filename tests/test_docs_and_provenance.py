@@ -53,7 +53,7 @@ def test_design_md_is_the_current_design_not_the_notebook():
         assert gone not in text, gone
     for f in re.findall(r"`((?:csrc|tools|tests|profiles|oracle|integration)/[A-Za-z0-9_./]+\.(?:hpp|hip|py|sh|json|txt|c|h|cpp))`", text):
         path = f if not f.startswith("csrc/") else os.path.join("azul_deep_reinforcement_learning_amd", f)
-        if "round5_" in f or f == "profiles/issue_rate.json" or f in ("tests/test_azul.py", "tests/test_game_runner.py"):
+        if "round6_" in f or f == "profiles/issue_rate.json" or f in ("tests/test_azul.py", "tests/test_game_runner.py"):
             continue                       # written by the round's last profiling run / the REFERENCE's test files
         assert os.path.exists(os.path.join(ROOT, path)), f
 
@@ -67,13 +67,13 @@ def test_provenance_tool_hashes_the_product_sources():
 
 def test_hw_frac_is_reproducible_from_the_tracked_profile_files():
     """roofline.issue.hw_frac (what bench.py quotes from profiles/issue_rate.json) recomputed by hand from the tracked PMC means
-    (profiles/round5_summary.json: pmc_per_launch), the tracked static opcode mix (profiles/round5_isa_mix.json) and the price list the
+    (profiles/round6_summary.json: pmc_per_launch), the tracked static opcode mix (profiles/round6_isa_mix.json) and the price list the
     file itself carries: class counts x pipe cycles per wave64 instruction / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)."""
     import json
     prof = os.path.join(ROOT, "profiles")
     issue = json.load(open(os.path.join(prof, "issue_rate.json")))
-    pmc = json.load(open(os.path.join(prof, "round5_summary.json")))["pmc_per_launch"]
-    mix = json.load(open(os.path.join(prof, "round5_isa_mix.json")))
+    pmc = json.load(open(os.path.join(prof, "round6_summary.json")))["pmc_per_launch"]
+    mix = json.load(open(os.path.join(prof, "round6_isa_mix.json")))
     cost = {k: v["cycles"] for k, v in issue["hw"]["costs"].items()}
     m = lambda k: pmc[k]["mean"]
     valu = m("SQ_INSTS_VALU")
@@ -87,6 +87,6 @@ def test_hw_frac_is_reproducible_from_the_tracked_profile_files():
     # the hardware's own activity counter gives the same full-rate share (two independent counters, one number)
     assert abs(issue["valu_pipe_share_from_SQ_ACTIVE_INST_VALU"] - issue["hw"]["frac_if_every_valu_instruction_were_full_rate"]) < 0.01
     # the occupancy ratio quotes the tracked sweep of the same run
-    sweep = open(os.path.join(prof, "round5_games_sweep.txt")).read()
+    sweep = open(os.path.join(prof, "round6_games_sweep.txt")).read()
     vals = {int(ln.split()[1].rstrip(":")): float(ln.split()[2]) for ln in sweep.splitlines() if ln.startswith("games") and "G env steps/s" in ln}
     assert abs(issue["occupancy_frac"] - vals[4096] / vals[8192]) < 1e-9

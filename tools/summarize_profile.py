@@ -178,7 +178,7 @@ if "SQ_INSTS_VALU" in pmc and "SQ_INSTS_SALU" in pmc and "GRBM_GUI_ACTIVE" in pm
             # same instructions per game-move, twice the waves per SIMD: cycles per instruction scale with 1 / throughput.  This is the
             # kernel against ITSELF at higher occupancy -- how much of the gap to hw_frac = 1 more waves would close -- not a hardware bound
             issue["occupancy_frac"] = vals[4096] / vals[8192]
-            issue["occupancy_source"] = "profiles/%s_games_sweep.txt: %.3f G env steps/s at 4096 games, %.3f G at 8192 (four waves per SIMD)" % (name, vals[4096], vals[8192])
+            issue["occupancy_source"] = "profiles/%s_games_sweep.txt: %.3f G env steps/s at 4096 games, %.3f G on an 8192-game grid (oversubscribed 2x at the same two RESIDENT waves per SIMD: backfill and a shorter tail, not higher occupancy)" % (name, vals[4096], vals[8192])
     summary["issue"] = issue
     json.dump(issue, open(os.path.join(dst, "issue_rate.json"), "w"), indent=1)
 summary["bench"] = {k: bench[k] for k in ("value", "ms_per_step", "roofline", "cpu_baseline") if k in bench}

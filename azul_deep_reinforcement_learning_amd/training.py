@@ -187,6 +187,8 @@ class BatchedTrainer:
         ck = {"policy": ro.policy.state_dict(), "optimizer": self.learner.optimizer_state(), "envs": envs,
               "batch": self.batch, "n_games": ro.n, "parts": ro.parts, "window": ro.T, "game_id_base": ro.game_id_base,
               "windows_played": ro.windows_played, "ring": ro.ring, "ring_saved": bool(save_ring and ro.ring > 1)}
+        if ro.opponent == "net":                         # the network opponent's (frozen) weights: a resumed run plays against the same net
+            ck["opponent"] = {k: getattr(ro, k).cpu() for k in ("ow1t", "ob1", "ow2c", "ob2c", "ow2a_t", "ob2a")}
         if save_ring and ro.ring > 1:
             ck["ring_buffers"] = [{k: v.cpu() for k, v in rg.items()} for rg in ro.rings]
             ck["learner_ring"] = self.learner.ring_state()
@@ -240,6 +242,10 @@ class BatchedTrainer:
                               "was written are not trained, their tails count as whole episodes -- the resumed run does not equal the "
                               "uninterrupted one (save_checkpoint(save_ring=True) / train(checkpoint_ring=True) for an exact resume)" % path)
             self.learner.load_ring_state(ro, None)
+        if ro.opponent == "net" and "opponent" in ck:
+            with torch.no_grad():
+                for k, v in ck["opponent"].items():
+                    getattr(ro, k).copy_(v.to(ro.device))
         torch.cuda.synchronize(ro.device)
         self.batch = int(ck["batch"])
         self._stat_base = self._stat_totals()

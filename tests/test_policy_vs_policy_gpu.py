@@ -256,3 +256,29 @@ def test_network_opponent_structures_agree_from_unusual_states(golden):
     d0 = wa[0]["done"][0]
     assert (d0[[5, 33]] == 1).all()                            # GameEnded: reported done, slot restarted
     assert (wa[0]["action"][:, [3, 20, 41]] == -1).all()       # nothing legal for the agent: the slot stays as it is
+
+
+def test_training_against_a_past_self_resumes_bit_for_bit(golden, tmp_path):
+    """A checkpoint of a run with a network opponent carries the opponent's frozen weights: a fresh trainer (other seeds, other weights,
+    another opponent) restored from it plays the NEXT window exactly as the uninterrupted run does."""
+    import os
+    from azul_deep_reinforcement_learning_amd import BatchedActorCritic
+    from azul_deep_reinforcement_learning_amd.training import BatchedTrainer
+    agent, _ = _nets(golden)
+    kw = dict(n_games=128, window=24, results_dir=str(tmp_path), opponent="self", opponent_refresh=2)
+    tr = BatchedTrainer(agent, seed_base=7, **kw)
+    for _ in range(3):                                   # the opponent was refreshed after update 2 and is one update behind now
+        tr.run_batch(collect_stats=False)
+    ck = os.path.join(str(tmp_path), "vs.pt")
+    tr.save_checkpoint(ck)
+    nxt = tr.rollout.run_window()
+    tr.rollout.synchronize()
+    want = {k: v.clone() for k, v in nxt[0].items()}
+    torch.manual_seed(99)
+    tr2 = BatchedTrainer(BatchedActorCritic(136, 180, 180), seed_base=9000, **kw)
+    tr2.load_checkpoint(ck)
+    assert torch.equal(tr2.rollout.ow1t, tr.rollout.ow1t) and not torch.equal(tr2.rollout.ow1t, tr2.rollout.w1t)
+    got = tr2.rollout.run_window()
+    tr2.rollout.synchronize()
+    for k in want:
+        assert torch.equal(want[k], got[0][k]), k

@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--extras-timeout", type=int, default=240, help="seconds after which the secondary measurements are abandoned")
     ap.add_argument("--headline-timeout", type=int, default=900, help="seconds after which a headline measurement that hangs is abandoned")
     ap.add_argument("--mask-pitch", type=int, default=192, help="byte pitch of a game's legal-mask row (180 = dense, 192 = 64-byte aligned rows)")
+    ap.add_argument("--move-limit", type=int, default=0, help="NOT the metric's workload: azul_batch_set_move_limit (beyond the reference): cut an episode at the "
+                    "first end of a round after this many moves, so that games that can never end do not keep their slots (0 = the reference's behaviour)")
     ap.add_argument("--sustained", type=int, default=1000, help="launches of the `sustained` object after the timed region (0 = skip)")
     ap.add_argument("--gather-c1", action="store_true", help="N>1, secondary line configs[4]: also all-gather every window's full C1 records "
                                                              "(184 B per agent step; opt-in, the collective north_star names)")
@@ -102,7 +104,7 @@ def cpu_baseline(games, seed_base):
             "reference_python_note": "azulnet GameRunner measured in the build container (BASELINE.md), cannot travel to the GPU box"}
 
 
-def parity_gate(env, games, seed_base, moves_done, budget=6000000):
+def parity_gate(env, games, seed_base, moves_done, budget=6000000, move_limit=0):
     """Bit-exactness gate: the first games' records AND MT19937 positions after `moves_done` env moves each must equal the
     oracle's (the oracle replays them from the seed; at most `budget` oracle moves in total)."""
     from oracle import oracle as oz
@@ -110,7 +112,7 @@ def parity_gate(env, games, seed_base, moves_done, budget=6000000):
     recs = env.get_records(0, k)
     for g in range(k):
         s = oz.Stream(seed_base + g)
-        s.advance(moves_done, want_records=False)
+        s.advance(moves_done, want_records=False, move_limit=move_limit)
         if s.record().tobytes() != recs[g].tobytes():
             return "MISMATCH in game %d after %d moves" % (g, moves_done)
         if s.rng_state()[1] != env.get_rng(g)[1]:
@@ -726,6 +728,8 @@ def main():
     env.seed(base)
     env.runner_init()                                    # GameRunner()
     env.runner_init()                                    # reset()   (DESIGN.md "stream semantics")
+    if args.move_limit:
+        env.set_move_limit(args.move_limit)              # (beyond the reference, not the metric's workload; the gates replay with the same limit)
     # per move: the legal mask (bytes), action, reward, done and the compact record the multi-GPU gather ships; the bit-packed mask
     # is only produced when it is shipped (--gather-masks)
     want_bits = args.gather_masks
@@ -749,7 +753,7 @@ def main():
     gate_moves = 128
     env.selfplay(gate_moves)
     torch.cuda.synchronize()
-    gate = parity_gate(env, G, base, gate_moves) if rank == 0 else None
+    gate = parity_gate(env, G, base, gate_moves, move_limit=args.move_limit) if rank == 0 else None
     if gather is not None:
         coll_.enter("warm-up launches + trajectory all-gather")
     run(W)
@@ -770,7 +774,7 @@ def main():
     elapsed = time.perf_counter() - t0
     cnt = env.counters()
     stuck = int(cnt["stuck"].sum()) - stuck0
-    gate_end = parity_gate(env, G, base, gate_moves + K * T) if rank == 0 else None      # ... and the state the timed region left
+    gate_end = parity_gate(env, G, base, gate_moves + K * T, move_limit=args.move_limit) if rank == 0 else None      # ... and the state the timed region left
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     moves = torch.tensor([float(G * K * T - stuck)], dtype=torch.float64, device=dev)
     coll_.all_reduce(el, dist.ReduceOp.MAX, "all-reduce (max) of the ranks' elapsed time")
@@ -875,7 +879,7 @@ def main():
                                        "mean_even_odd_launches": [sum(series[0::2]) / max(len(series[0::2]), 1), sum(series[1::2]) / max(len(series[1::2]), 1)]}
                          if per else None,
                          "event_bracket_ms": s_bracket,
-                         "parity_gate": parity_gate(env, G, base, gate_moves + (K + S) * T, budget=2500000),
+                         "parity_gate": parity_gate(env, G, base, gate_moves + (K + S) * T, budget=2500000, move_limit=args.move_limit),
                          "note": "after the timed region: same buffers, same launches (N > 1: same all-gather) in ten blocks with a host synchronisation "
                                  "between them; launch durations from the library's event pairs (rank 0's GPU); `value` is NOT taken from here, "
                                  "`value_sustained` is the last block's whole-job rate.  This run: " + note}
@@ -963,6 +967,7 @@ def main():
                                           "games of a GPU (%d env moves per step and GPU)" % (T, G, T * G),
                        "games_per_gpu": G, "global_games": G * world, "moves_per_launch": T, "env_moves_timed": int(total_moves),
                        "mask_row_pitch_bytes": args.mask_pitch, "mask_bits_stream": bool(want_bits),
+                       "move_limit": args.move_limit or None,
                        "selfplay_kernel": "two games per wavefront",
                        "parallelism": par,
                        "rccl": {"backend": (coll if world > 1 else None), "world_size": dist.get_world_size() if world > 1 else 1,

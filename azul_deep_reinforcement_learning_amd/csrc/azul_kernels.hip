@@ -14,6 +14,7 @@
 //                               azul_rules_x.hpp: 256-byte wide records)
 //   azul_selfplay2_kernel       state register-resident across n_steps env moves (the hot path); azul_x_selfplay_kernel: row N4's
 //   azul_returns_kernel         discounted returns over a trajectory window
+//   azul_pack_c1_kernel         the C1 wire record of the opt-in trajectory all-gather (184 bytes per agent step); azul_clock_probe_kernel (diagnostic)
 //   azul_policy.hpp             policy head, fused ActorCritic forward; azul_rollout2.hpp: persistent policy rollout (rows N1 / N2)
 //   azul_learner.hpp            A2C gradients (forward + backward on the matrix cores), partial reduction, sample selection (row N2)
 #include <hip/hip_runtime.h>
@@ -1130,12 +1131,13 @@ int azul_selfplay_kernel_resources(azul_batch_t *b, int padded_rows, int mask_bi
 {
     BATCH_GUARD(b, nullptr);
     if (!b || b->x) return fail(AZUL_ERR_INVALID, "azul_selfplay_kernel_resources: two-player reference batches");
-    const bool lid = b->d.rules.tile_pool == POOL_LID;
+    const bool lid = b->d.rules.tile_pool == POOL_LID, lim = b->d.move_limit != 0;
     const void *fn;
-    if (lid) fn = padded_rows ? (mask_bits ? (const void *)azul_selfplay2_kernel<true, 1, true, true> : (const void *)azul_selfplay2_kernel<true, 1, true, false>)
-                              : (mask_bits ? (const void *)azul_selfplay2_kernel<true, 1, false, true> : (const void *)azul_selfplay2_kernel<true, 2, false, false>);
-    else fn = padded_rows ? (mask_bits ? (const void *)azul_selfplay2_kernel<false, 1, true, true> : (const void *)azul_selfplay2_kernel<false, 1, true, false>)
-                          : (mask_bits ? (const void *)azul_selfplay2_kernel<false, 1, false, true> : (const void *)azul_selfplay2_kernel<false, 2, false, false>);
+#define AZ_PICK(LID, LIM) (padded_rows ? (mask_bits ? (const void *)azul_selfplay2_kernel<LID, 1, true, true, LIM> : (const void *)azul_selfplay2_kernel<LID, 1, true, false, LIM>) \
+                                       : (mask_bits ? (const void *)azul_selfplay2_kernel<LID, 1, false, true, LIM> : (const void *)azul_selfplay2_kernel<LID, 2, false, false, LIM>))
+    if (lim) fn = lid ? AZ_PICK(true, true) : AZ_PICK(false, true);
+    else fn = lid ? AZ_PICK(true, false) : AZ_PICK(false, false);
+#undef AZ_PICK
     hipFuncAttributes at;
     HIP_TRY(hipFuncGetAttributes(&at, fn));
     int blocks = 0;

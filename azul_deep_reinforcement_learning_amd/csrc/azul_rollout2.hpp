@@ -10,8 +10,11 @@
 // Arithmetic per output element: the same k-ordered v_mfma_f32_16x16x4_f32 chain per hidden unit / logit, the same critic summation and
 // the same head as azul_policy_forward_kernel, and the rules are azul_selfplay2.hpp's: the trajectories are bit-identical to the
 // two-launches-per-move path (tests/test_policy_bridge.py, tests/test_full_size_configs.py).
-// Reference lines: azulnet/azul.py:296-313 (step), azulnet/game_runner.py:43-55 (GameRunner.step), :56-72 (get_state), :76-85 (reset),
-// :87-97 (RandomAgent); azulnet/nn_runner.py:17-47.
+// Three opponents (template parameter OPP): 0 the policy moves for both players; 1 GameRunner with its default RandomAgent inside the env
+// phase; 2 GameRunner(opponent=Agent(...)) (game_runner.py:27-30) -- a SECOND network: after the agent's move the workgroup runs matrix phases
+// on the opponent's weights while any of its 16 games owes an opponent_move() (azul_env2.hpp: the NET_* protocol).
+// Reference lines: azulnet/azul.py:296-313 (step), azulnet/game_runner.py:27-30, 37-55 (opponent_move, GameRunner.step), :56-72 (get_state),
+// :76-85 (reset), :87-97 (RandomAgent); azulnet/agent.py:64-81; azulnet/nn_runner.py:17-47.
 #pragma once
 
 #include "azul_env2.hpp"

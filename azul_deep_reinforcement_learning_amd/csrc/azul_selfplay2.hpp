@@ -208,8 +208,7 @@ AZ_FN void g2_store(const G2 &g, uint8_t *rec, u32 l)
 // The 624-word state lives in global memory (row of a [N][624] array: a half's accesses are contiguous); it is staged into the game's LDS
 // region when the stream is opened, the regeneration ("twist") runs there 32 lanes wide, and it is written back on close if it changed.
 constexpr u32 MT_LDS_WORDS = 626;   // LDS words per game: the 624 MT19937 words + the batch's move limit (word 624; ~0u = none) + a pad word.  The limit
-                                    // is only ever read in the RARE end-of-round blocks: kept in LDS it costs the move loop no register (as a kernel
-                                    // argument it cost the headline kernel two more spilled SGPRs inside the loop: +0.5 %, tools/ab_raw.py)
+                                    // is only ever read in the RARE end-of-round blocks: kept in LDS it occupies no register in a move loop
 struct Rng2 {
     u32 *lds;        // my game's 624 words in LDS (+ the move limit at word 624: rng2_set_move_limit)
     u32 *tlds;       // optional: the same 624 words TEMPERED (kept current by the regeneration), what genrand_uint32 returns for index i;

@@ -764,6 +764,15 @@ AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2
         if (nomove) {
             // stuck (hazard H3), or handed an already finished game: report, restart the slot
             cnt.stuck_add += 1u;
+            {
+                MaskX<D> none;                           // ... an empty mask row, like a stuck slot's (nothing is legal)
+#pragma unroll
+                for (u32 rr = 0; rr < 6u; rr++)
+#pragma unroll
+                    for (u32 ww = 0; ww < Dim<D>::NW; ww++) { none.m[rr][ww] = 0u; none.bit[rr][ww] = 0u; }
+                if (OUT == 1 || (OUT == 2 && o.mask)) store_mask_x<D, (PAD && OUT == 1)>(o, none, l);
+                if ((OUT == 1 && BITS) || (OUT == 2 && o.maskbits)) store_maskbits_x<D>(o, none, l);
+            }
             outputs_x<P, D, OUT>(g, o, -1, 2u, l);
             const u32 st0 = restart_x(g, rules, r, margin, K);
             ret = st0 ? (0x100u | st0) : 2u;
@@ -1057,6 +1066,15 @@ AZ_FN void selfplay_body_x(const XBatchDev &b, const XTraj &t, u32 wave_id, u32 
             // move is played in this slot -- it is marked like a stuck slot (action -1, done 2) and counted with them, so that whoever
             // counts env moves as slots minus `stuck` stays right and the trajectory carries no stale data
             cnt.stuck_add += 1u;
+            {
+                MaskX<D> none;                           // ... an empty mask row, like a stuck slot's (nothing is legal)
+#pragma unroll
+                for (u32 rr = 0; rr < 6u; rr++)
+#pragma unroll
+                    for (u32 ww = 0; ww < Dim<D>::NW; ww++) { none.m[rr][ww] = 0u; none.bit[rr][ww] = 0u; }
+                if (OUT == 1 || (OUT == 2 && o.mask)) store_mask_x<D, (PAD && OUT == 1)>(o, none, l);
+                if ((OUT == 1 && BITS) || (OUT == 2 && o.maskbits)) store_maskbits_x<D>(o, none, l);
+            }
             outputs_x<P, D, OUT>(g, o, -1, 2u, l);
         }
         o.e += b.n;

@@ -99,6 +99,7 @@ def check_streams(L, P, first, pool, ext, n, T, variant, seed0, margin=0, prepar
             if variant != 4:
                 # the slots after the stop: no move played -- marked like stuck slots (action -1, done 2) and counted with them
                 assert (out["action"][ok + 1:, g] == -1).all() and (out["done"][ok + 1:, g] == 2).all(), tag
+                assert not out["mask"][ok + 1:, g, :NA].any(), tag      # ... with an empty mask row (no stale bytes in the trajectory)
             assert int(stuck[g]) >= T - ok - 1, tag
             continue
         if variant != 4:

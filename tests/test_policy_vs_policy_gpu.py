@@ -162,7 +162,7 @@ def test_rollout_against_a_network_opponent_replays_through_the_oracle(golden, p
 
 
 @pytest.mark.parametrize("n,rules,selection", [(100, None, "Distribution"), (16, None, "Max"), (37, {"first_player": 2, "tile_pool": "Random"}, "Distribution"),
-                                               (2048, None, "Distribution")])
+                                               (2048, None, "Distribution"), (1, None, "Distribution")])
 def test_window_kernel_with_a_network_opponent_is_bit_identical_to_the_cut_protocol(golden, n, rules, selection):
     """azul_batch_policy_rollout_vs (matrix phases on the second weight set inside the window kernel) against the per-cut path (azul_policy_forward
     on the opponent's weights + azul_batch_net_step_*): every trajectory array, the opponent's answers and their log-probs, the final records,
@@ -187,7 +187,7 @@ def test_window_kernel_with_a_network_opponent_is_bit_identical_to_the_cut_proto
         valid = np.arange(10)[None, :, None] < rep[:, None, :]              # [T][R][N]: slot j of a step holds a reply
         assert np.array_equal(wa[wi]["opp_action"][valid], wb[wi]["opp_action"][valid]), wi
         assert np.array_equal(wa[wi]["opp_logp"][valid], wb[wi]["opp_logp"][valid]), wi
-        assert valid.sum() > T * n // 2
+        assert valid.sum() > T * n // 2 or n == 1
     assert ra.tobytes() == rb.tobytes() and np.array_equal(ma, mb) and np.array_equal(pa, pb) and ca == cb and cta == ctb
     assert ca["episodes"] > 0
 

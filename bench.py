@@ -231,6 +231,37 @@ def policy_vs_policy(games, seed_base=0, window=32, windows=40):
                          "note": "achieved = the evaluations the games needed; executed = incl. the masked games of a reply round"}}
 
 
+def longer_launches(games, seed_base=0, chunk=2048, launches=5):
+    """The headline kernel with FOUR TIMES the moves per launch (same games, same outputs; not the metric's step definition): a launch lasts as long
+    as its slowest wave and starts by staging every game's 2.5 KB MT19937 state, so its fixed + tail cost (~24 us of a 512-move launch, ~3 %) is
+    spread over more moves.  The grid exactly fills the GPU's two resident waves per SIMD at 4096 games: nothing backfills inside a launch."""
+    import torch
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    env = BatchedAzul(games)
+    env.seed(seed_base)
+    env.runner_init()
+    env.runner_init()
+    b = env.alloc_trajectory(chunk, packed_mask=True, mask_pitch=192, mask_bits=False)
+    run = lambda: env.selfplay(chunk, b["mask"], b["action"], b["reward"], b["done"], packed=b["packed"])
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    stuck0 = int(env.counters()["stuck"].sum())
+    t0 = time.perf_counter()
+    env.timing_begin()
+    for _ in range(launches):
+        run()
+    _, _, kms, kn = env.timing_end()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    moves = games * chunk * launches - (int(env.counters()["stuck"].sum()) - stuck0)
+    avg = kms / max(kn, 1)
+    return {"value": moves / dt, "unit": "env steps/s", "moves_per_launch": chunk, "launches": launches, "avg_launch_ms": avg,
+            "us_per_move_and_launch": avg * 1e3 / chunk, "kernel_env_steps_per_s": games * chunk / (avg / 1e3),
+            "nominal_hbm_frac": ALGO_BYTES_PER_STEP * games * chunk / (avg / 1e3) / 1e9 / HBM_PEAK_GBS,
+            "note": "same kernel and outputs as the headline, %d instead of 512 moves per launch (profiles/round6_chunk_sweep.txt: 128 .. 4096)" % chunk}
+
+
 def saturated(seed_base=0, chunk=512):
     """The headline kernel on LARGER GRIDS than BASELINE configs[1] gives a GPU: 8192 games and 32768 games (the whole of configs[3] on ONE
     GPU).  Same kernel, same outputs, kernel time from the library's event pairs.  The kernel's register allocation admits TWO resident
@@ -1019,7 +1050,8 @@ def main():
         ex.update(first)
         if world == 1:
             for name, fn in (("policy_vs_policy", lambda: policy_vs_policy(G, args.seed_base)),
-                             ("saturated", lambda: saturated(args.seed_base, T)), ("facade_config1", facade_config1),
+                             ("saturated", lambda: saturated(args.seed_base, T)), ("longer_launches", lambda: longer_launches(G, args.seed_base)),
+                             ("facade_config1", facade_config1),
                              ("players_selfplay", lambda: players_selfplay(G))):
                 phase[0] = name
                 try:

@@ -385,33 +385,27 @@ struct Tab2 { const double2 *fs; };      // LDS: the pairs {Fr[J][b], S[J]} at 8
 AZ_FN double tpat2(const Tab2 &t, u32 J, u32 m) { return (double)m + t.fs[8u * J + 31u - (u32)__builtin_clz(m)].x; }      // T(J, m), m >= 1
 AZ_FN double tseq2(const Tab2 &t, u32 J, u32 kk) { return kk <= J ? t.fs[8u * kk].y : tpat2(t, J, kk - J); }              // cumulative weight after the kk-th legal action
 
-// bisect_right over the cumulative weights == smallest ordinal kk with cum(kk) > x: the generic search (x inside the 0.01-weight
-// floor moves, or a guess too close to an integer boundary: rare)
+// bisect_right over the cumulative weights == smallest ordinal kk with cum(kk) > x, for the draws the one-compare fast path leaves (x inside
+// the 0.01-weight floor moves, a guess too close to an integer boundary, the clamp at the last weight).  A first guess -- floor(100 x) + 1
+// inside the floor moves, J + floor(x - S[J]) + 1 above them -- and, unless it is known to be exact, a walk along the cumulative weights
+// until cum(kg - 1) <= x < cum(kg) (the weights are positive: the answer is unique; clamped to L like bisect's hi = n - 1).  Exact without
+// the walk: x < S[J] and 100 x further than 1e-9 from an integer -- S[k] is k additions of 0.01, |100 S[k] - k| < 1e-13 for k <= 60, and
+// x * 100 rounds by < 1e-13.  (A game whose every move is a floor move -- all that is left once its pattern lines are locked for good,
+// hazard H9 -- comes here on EVERY decision: with the walk its wave ran ~10 % slower than the others, and a launch lasts as long as its
+// slowest wave.)
 AZ_FN u32 sample_slow2(const Tab2 &T, double x, double sJ, u32 J, u32 M, u32 L)
 {
-    u32 kg;
-    if (x < sJ) {
-        kg = (u32)(x * 100.0) + 1u;
-        kg = kg > J ? J : kg;
-        for (u32 it = 0; it < 64u; it++) {
-            bool below = x < tseq2(T, J, kg - 1u), inside = x < tseq2(T, J, kg);
-            if (below && kg > 1u) kg -= 1u;
-            else if (!inside && kg < L) kg += 1u;
-            else break;
-        }
-    } else {
-        double d = x - sJ;
-        u32 mg = (u32)d + 1u;
-        mg = mg > M ? M : mg;
-        for (u32 it = 0; it < 256u; it++) {
-            u32 ml = mg - 1u;
-            double lo = ml ? tpat2(T, J, ml) : sJ;
-            double hi = tpat2(T, J, mg);
-            if (x < lo && mg > 1u) mg -= 1u;
-            else if (!(x < hi) && mg < M) mg += 1u;
-            else break;
-        }
-        kg = J + mg;
+    const bool floors = x < sJ;
+    const double y = floors ? x * 100.0 : x - sJ;
+    const u32 fy = (u32)y;
+    const u32 cap = floors ? J : M;
+    const u32 g = fy + 1u > cap ? cap : fy + 1u;
+    u32 kg = floors ? g : J + g;
+    const bool exact = floors & (__builtin_fabs((y - (double)fy) - 0.5) < 0.5 - 1e-9);
+    for (u32 it = exact ? 256u : 0u; it < 256u; it++) {
+        if (kg > 1u && x < tseq2(T, J, kg - 1u)) kg -= 1u;
+        else if (kg < L && !(x < tseq2(T, J, kg))) kg += 1u;
+        else break;
     }
     return kg;
 }

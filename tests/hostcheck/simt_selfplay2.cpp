@@ -95,6 +95,26 @@ int sh2_clock_probe(u64 *out3)
     return 0;
 }
 
+// az2::sample_slow2 (the boundary search of RandomAgent's draw: bisect_right over the cumulative weights) on n points, 64 per emulated wave
+struct SampleJob { const double *T; const double *x; const int *J; const int *M; int *out; int base, n; };
+static void sample_lane(void *arg)
+{
+    SampleJob *j = (SampleJob *)arg;
+    const int i = j->base + (int)wv::lane();
+    if (i >= j->n) return;
+    az2::Tab2 T = {(const double2 *)j->T};
+    const u32 J = (u32)j->J[i], M = (u32)j->M[i];
+    j->out[i] = (int)az2::sample_slow2(T, j->x[i], T.fs[8u * J].y, J, M, J + M);
+}
+int sh2_sample_slow(int n, const double *x, const int *J, const int *M, int *out)
+{
+    static double T[T_ROWS * T_BINADES * 2];
+    if (!build_sample_pairs(T_ROWS, T)) return -2;
+    SampleJob j = {T, x, J, M, out, 0, n};
+    for (j.base = 0; j.base < n; j.base += 64) simt::run_wave(sample_lane, &j);
+    return 0;
+}
+
 // self-test of the emulated cross-lane operations against their definitions (lane l holds 100 + l)
 int sh2_selftest_result[8];
 static void selftest_lane(void *)

@@ -278,3 +278,40 @@ def test_move_limit_cuts_episodes_at_round_ends_like_the_oracle():
         where = np.flatnonzero(o["done"] == 3)
         assert all(int(o["rec_after"][t]["move_counter"]) >= limit for t in where)          # cut at the end of the round that reached the limit
     assert cuts >= 6
+
+
+def test_boundary_search_of_the_random_agents_draw_equals_cpythons_bisect():
+    """az2::sample_slow2 -- what decides a RandomAgent draw that the one-compare fast path does not (x inside the 0.01-weight floor moves, x within
+    1e-9 of a boundary, the clamp at the last weight) -- against the literal CPython computation (random.py:506-541: accumulate + bisect_right(cum,
+    x, 0, n - 1)) for every (J, M) and x at, one and two ulps around, and between EVERY cumulative weight, plus random x; a game whose moves are all
+    floor moves (hazard H9's never-ending games) takes this path on every decision (game_runner.py:87-97)."""
+    from bisect import bisect_right
+    from itertools import accumulate
+    L = load()
+    L.sh2_sample_slow.argtypes = [C.c_int] + [C.c_void_p] * 4
+    rs = np.random.RandomState(11)
+    xs, Js, Ms, want = [], [], [], []
+    for J in range(0, 31):
+        for M in [0, 1, 2, 8, 33, 150 - J]:
+            if J + M == 0 or J + M > 180:
+                continue
+            cum = list(accumulate([0.01] * J + [1.0] * M))
+            total = cum[-1] + 0.0
+            pts = [0.0, total, np.nextafter(total, 0.0)]
+            for c in (cum if len(cum) <= 64 else cum[:J + 3] + cum[J + 3::7] + cum[-2:]):
+                pts += [c, np.nextafter(c, 0.0), np.nextafter(c, 9.0), np.nextafter(np.nextafter(c, 0.0), 0.0), c - 1e-10, c + 1e-10, c - 2e-9, c + 2e-9, c - 0.005]
+            for k in range(1, J + 1):
+                pts += [k * 0.01, np.nextafter(k * 0.01, 0.0), np.nextafter(k * 0.01, 9.0), k / 100.0 - 5e-10, k / 100.0 + 5e-10]
+            pts += list(rs.rand(40) * total)
+            for x in pts:
+                x = float(x)
+                if not 0.0 <= x <= total:
+                    continue
+                xs.append(x); Js.append(J); Ms.append(M)
+                want.append(bisect_right(cum, x, 0, len(cum) - 1) + 1)
+    xs, Js, Ms = np.array(xs), np.array(Js, np.int32), np.array(Ms, np.int32)
+    out = np.full(len(xs), -1, np.int32)
+    assert L.sh2_sample_slow(len(xs), ptr(xs), ptr(Js), ptr(Ms), ptr(out)) == 0
+    bad = np.flatnonzero(out != np.array(want))
+    assert len(bad) == 0, (len(bad), [(xs[i], Js[i], Ms[i], out[i], want[i]) for i in bad[:5]])
+    assert len(xs) > 50000

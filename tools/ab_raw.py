@@ -7,6 +7,7 @@ import sys
 import torch
 
 G, T, REPS = 4096, 512, 3
+LATE = "--late" in sys.argv        # also: the launch time after 700 launches (seed base 0: game 801 can no longer end -- hazard H9 -- and every one of its moves is a floor move)
 
 
 def run(path):
@@ -43,10 +44,25 @@ def run(path):
         torch.cuda.synchronize()
         ts = sorted(ev[k].elapsed_time(ev[k + 1]) for k in range(20))
         out.append("median %.4f min %.4f" % (ts[10], ts[0]))
+    if LATE:
+        done = 25 * REPS
+        for mark in (600, 700, 800, 1000, 1500):
+            for _ in range(mark - done):
+                launch()
+            torch.cuda.synchronize()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+            ev[0].record()
+            for k in range(20):
+                launch()
+                ev[k + 1].record()
+            torch.cuda.synchronize()
+            done = mark + 20
+            ts = sorted(ev[k].elapsed_time(ev[k + 1]) for k in range(20))
+            out.append("after %d launches: median %.4f min %.4f max %.4f" % (mark, ts[10], ts[0], ts[-1]))
     L.azul_batch_destroy(h)
     return out
 
 
 for rep in range(2):
-    for path in sys.argv[1:]:
+    for path in [a for a in sys.argv[1:] if not a.startswith("--")]:
         print(path, run(path), flush=True)

@@ -580,6 +580,35 @@ class Telemetry:
         return out
 
 
+class LaunchClock:
+    """The duration of every launch of a region, from ONE HIP event after each launch (and one before the first) on the stream the kernels are
+    launched on (batch.py: torch's current stream): a launch = the interval between consecutive events = the kernel + the gap to its
+    predecessor.  (An event PAIR around each launch -- azul_timing_begin -- costs the whole-job rate 1.2-1.7 % and puts the recording of the
+    opening event inside the interval it measures: tools/event_overhead.py, profiles/round6_event_overhead.txt.)"""
+
+    def __init__(self, device):
+        import torch
+        self.stream = torch.cuda.current_stream(device)
+        self.segments = []
+
+    def begin(self, launches):
+        import torch
+        self.segments.append([torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)])
+        self.k = 0
+        self.segments[-1][0].record(self.stream)
+
+    def mark(self):
+        self.k += 1
+        self.segments[-1][self.k].record(self.stream)
+
+    def series(self):
+        """ms per launch, all segments in order (call after a synchronisation)"""
+        return [seg[i].elapsed_time(seg[i + 1]) for seg in self.segments for i in range(len(seg) - 1)]
+
+    def brackets(self):
+        return [seg[0].elapsed_time(seg[-1]) for seg in self.segments]
+
+
 def never_ending_games(env, run, games, rounds_threshold=100, launches=20):
     """Games of the batch that have been in ONE episode for more than `rounds_threshold` rounds (a game of the reference lasts ~5, at most
     ~15): under the reference's rules with random play a game can reach a state from which it never ends -- e.g. all 20 tiles of one colour
@@ -767,12 +796,14 @@ def main():
     bufs = [env.alloc_trajectory(T, packed_mask=True, mask_pitch=args.mask_pitch, mask_bits=want_bits) for _ in range(2)]
     gather = TrajectoryGather(world, dev, with_masks=args.gather_masks) if (world > 1 and not args.no_gather) else None
 
-    def run(n_launches):
+    def run(n_launches, clock=None):
         for i in range(n_launches):
             b = bufs[i & 1]
             if gather is not None:
                 gather.wait_buffer_free(i & 1)           # the all-gather that last read this buffer has finished
             env.selfplay(T, b["mask"], b["action"], b["reward"], b["done"], maskbits=b.get("maskbits"), packed=b["packed"])
+            if clock is not None:
+                clock.mark()                             # one event per launch, on the launch stream
             if gather is not None:
                 gather.launch(i & 1, b, T)               # side stream, overlaps the next launch
         if gather is not None:
@@ -796,9 +827,9 @@ def main():
     t0 = time.perf_counter()
     if gather is not None:
         coll_.enter("timed region: launches + trajectory all-gather")
-    env.timing_begin()                                   # events are recorded INSIDE the host-timed region
-    run(K)
-    bracket_ms, launches, kern_ms, kern_launches = env.timing_end()     # records the closing event, waits for it
+    clock = LaunchClock(dev)
+    clock.begin(K)                                       # events are recorded INSIDE the host-timed region
+    run(K, clock)
     torch.cuda.synchronize()
     coll_.barrier("barrier after the timed region")
     torch.cuda.synchronize()
@@ -832,19 +863,19 @@ def main():
         t0 = time.perf_counter()
         if gather is not None:
             coll_.enter("sustained launches + trajectory all-gather")
-        env.timing_begin()
+        sclock = LaunchClock(dev)
         marks, b_moves = [t0], []
         probes = torch.zeros(NB + 1, 3, dtype=torch.int64, device=dev)      # the shader clock as a wave sees it, before block 0 and after every block
         env.clock_probe(probes[0])
         for bi, nl in enumerate(sizes):
-            run(nl)
+            sclock.begin(nl)
+            run(nl, sclock)
             env.clock_probe(probes[bi + 1])
             torch.cuda.synchronize()
             marks.append(time.perf_counter())
             sk = int(env.counters()["stuck"].sum())
             b_moves.append(float(G * nl * T - (sk - stuck_b)))
             stuck_b = sk
-        s_bracket, _, s_kms, s_kn = env.timing_end()
         torch.cuda.synchronize()
         coll_.barrier("barrier after the sustained launches")
         torch.cuda.synchronize()
@@ -860,7 +891,8 @@ def main():
         coll_.all_reduce(b_wall, dist.ReduceOp.MAX, "all-reduce (max) of the sustained blocks' wall times")
         coll_.all_reduce(b_mv, dist.ReduceOp.SUM, "all-reduce (sum) of the sustained blocks' env moves")
         if rank == 0:
-            series = env.timing_launch_ms()
+            series = sclock.series()
+            s_kms, s_kn, s_bracket = sum(series), len(series), sum(sclock.brackets())
             edges = [sum(sizes[:i]) for i in range(NB + 1)]
             blocks = [sum(series[edges[i]:edges[i + 1]]) / max(len(series[edges[i]:edges[i + 1]]), 1) for i in range(NB) if edges[i] < len(series)]
             per = sorted(series)
@@ -912,7 +944,7 @@ def main():
                          "event_bracket_ms": s_bracket,
                          "parity_gate": parity_gate(env, G, base, gate_moves + (K + S) * T, budget=2500000, move_limit=args.move_limit),
                          "note": "after the timed region: same buffers, same launches (N > 1: same all-gather) in ten blocks with a host synchronisation "
-                                 "between them; launch durations from the library's event pairs (rank 0's GPU); `value` is NOT taken from here, "
+                                 "between them; launch durations = intervals between the events recorded after consecutive launches (rank 0's GPU); `value` is NOT taken from here, "
                                  "`value_sustained` is the last block's whole-job rate.  This run: " + note}
             def run_local(n_launches):                       # (this rank's kernel alone: no collective outside the lock-step regions)
                 for _ in range(n_launches):
@@ -930,7 +962,10 @@ def main():
     out = None
     if rank == 0:
         value = total_moves / elapsed
-        avg_launch_s = kern_ms / 1e3 / max(kern_launches, 1)          # event pair around each launch: the kernel's own duration
+        t_series = clock.series()                                     # one event per launch: kernel + gap to its predecessor
+        kern_launches = len(t_series)
+        bracket_ms = clock.brackets()[0]
+        avg_launch_s = sum(t_series) / 1e3 / max(kern_launches, 1)
         achieved = ALGO_BYTES_PER_STEP * G * T / avg_launch_s / 1e9
         traffic, traffic_src, traffic_gbs = None, None, None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -1013,6 +1048,9 @@ def main():
                          "frac_sustained": (ALGO_BYTES_PER_STEP * G * T / (sustained["launch_ms"]["means_of_ten_consecutive_blocks"][-1] / 1e3) / 1e9 / HBM_PEAK_GBS)
                          if sustained and sustained.get("launch_ms") else None,
                          "kernel": kernel_name, "avg_launch_ms": avg_launch_s * 1e3, "launches_timed": kern_launches,
+                         "avg_launch_ms_definition": "mean interval between the HIP events recorded after consecutive launches on the launch stream (one "
+                                                     "event before the first): the kernel + the gap to its predecessor; an event PAIR per launch costs "
+                                                     "the whole job 1.2-1.7 % (profiles/round6_event_overhead.txt)",
                          "kernel_resources": kres,
                          "event_bracket_ms": bracket_ms, "host_elapsed_ms": elapsed * 1e3,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * G * T, "scope": "rank 0's GPU",

@@ -247,15 +247,8 @@ def longer_launches(games, seed_base=0, chunk=2048, launches=5):
         run()
     torch.cuda.synchronize()
     stuck0 = int(env.counters()["stuck"].sum())
-    t0 = time.perf_counter()
-    env.timing_begin()
-    for _ in range(launches):
-        run()
-    _, _, kms, kn = env.timing_end()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, avg = clocked(env, run, launches)
     moves = games * chunk * launches - (int(env.counters()["stuck"].sum()) - stuck0)
-    avg = kms / max(kn, 1)
     return {"value": moves / dt, "unit": "env steps/s", "moves_per_launch": chunk, "launches": launches, "avg_launch_ms": avg,
             "us_per_move_and_launch": avg * 1e3 / chunk, "kernel_env_steps_per_s": games * chunk / (avg / 1e3),
             "nominal_hbm_frac": ALGO_BYTES_PER_STEP * games * chunk / (avg / 1e3) / 1e9 / HBM_PEAK_GBS,
@@ -264,7 +257,7 @@ def longer_launches(games, seed_base=0, chunk=2048, launches=5):
 
 def saturated(seed_base=0, chunk=512):
     """The headline kernel on LARGER GRIDS than BASELINE configs[1] gives a GPU: 8192 games and 32768 games (the whole of configs[3] on ONE
-    GPU).  Same kernel, same outputs, kernel time from the library's event pairs.  The kernel's register allocation admits TWO resident
+    GPU).  Same kernel, same outputs, launch time from per-launch events (LaunchClock).  The kernel's register allocation admits TWO resident
     waves per SIMD whatever the grid (kernel_resources: the HIP runtime's occupancy calculator on the loaded code object), so these runs
     do NOT raise occupancy: they oversubscribe the grid 2x / 8x -- finished workgroups are backfilled at once and the launch's tail
     (waves of a last partial round, games that hit rare paths) weighs less.  Not the metric's workload."""
@@ -281,15 +274,8 @@ def saturated(seed_base=0, chunk=512):
         run()
         torch.cuda.synchronize()
         stuck0 = int(env.counters()["stuck"].sum())
-        t0 = time.perf_counter()
-        env.timing_begin()
-        for _ in range(launches):
-            run()
-        _, _, kms, kn = env.timing_end()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        dt, avg = clocked(env, run, launches)
         moves = G * chunk * launches - (int(env.counters()["stuck"].sum()) - stuck0)
-        avg = kms / max(kn, 1)
         try:
             kr = env.kernel_resources(padded_rows=True, mask_bits=False)
         except Exception as e:
@@ -498,17 +484,11 @@ def players_selfplay(games, chunk=256, launches=6):
             run()
             torch.cuda.synchronize()
             stuck0 = int(env.counters()["stuck"].sum())
-            t0 = time.perf_counter()
-            env.timing_begin()
-            for _ in range(launches):
-                run()
-            _, _, kms, kn = env.timing_end()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            dt, avg = clocked(env, run, launches)
             c = env.counters()
             moves = games * chunk * launches - (int(c["stuck"].sum()) - stuck0)
-            res[tag] = {"value": moves / dt, "unit": "env steps/s", "avg_launch_ms": kms / max(kn, 1),
-                        "kernel_env_steps_per_s": games * chunk / (kms / max(kn, 1) / 1e3), "episodes_finished": int(c["episodes"].sum()),
+            res[tag] = {"value": moves / dt, "unit": "env steps/s", "avg_launch_ms": avg,
+                        "kernel_env_steps_per_s": games * chunk / (avg / 1e3), "episodes_finished": int(c["episodes"].sum()),
                         "num_actions": env.num_actions,
                         "workload": "%d concurrent %d-player games, %d displays%s, RandomAgent for every seat, rules Lid + random first player, "
                                     "%d moves per launch" % (games, P, env.displays, "" if not ext else
@@ -609,6 +589,21 @@ class LaunchClock:
         return [seg[0].elapsed_time(seg[-1]) for seg in self.segments]
 
 
+def clocked(env, run, launches):
+    """`launches` calls of run() with one event after each (LaunchClock): (host seconds incl. the final synchronisation, mean ms per launch)"""
+    import torch
+    clock = LaunchClock(env.device)
+    t0 = time.perf_counter()
+    clock.begin(launches)
+    for _ in range(launches):
+        run()
+        clock.mark()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ts = clock.series()
+    return dt, sum(ts) / max(len(ts), 1)
+
+
 def never_ending_games(env, run, games, rounds_threshold=100, launches=20):
     """Games of the batch that have been in ONE episode for more than `rounds_threshold` rounds (a game of the reference lasts ~5, at most
     ~15): under the reference's rules with random play a game can reach a state from which it never ends -- e.g. all 20 tiles of one colour
@@ -625,11 +620,7 @@ def never_ending_games(env, run, games, rounds_threshold=100, launches=20):
         return out
 
     def launch_ms():
-        env.timing_begin()
-        for _ in range(launches):
-            run(1)
-        _, _, kms, kn = env.timing_end()
-        return kms / max(kn, 1)
+        return clocked(env, lambda: run(1), launches)[1]
 
     out["launch_ms_with"] = launch_ms()
     recs = env.get_records()

@@ -76,6 +76,36 @@ def test_the_never_ending_game_of_the_benchmark_batch_is_cut():
     assert int(ep1[g]) > int(ep0[g]) + 300 and int(cut1.sum()) <= 3                                   # ... then its slot finishes games again; ordinary games never reach the limit
 
 
+def test_the_never_ending_game_stays_bit_exact_while_every_move_is_a_floor_move():
+    """Game 801 again, without a limit: after ~310 k moves every one of its decisions is a draw among 0.01-weight floor moves only (M = 0), i.e.
+    the branch of the RandomAgent sampler the one-compare path never takes (sample_slow2's exact floor guess; game_runner.py:87-97).  The oracle
+    replays games 800..803 move for move for 680 launches: the last launch's masks / actions / rewards / done flags, the records and the RNG
+    positions are identical, and game 801's last 512 actions are all floor moves."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    n, base, T, launches = 4, 800, 512, 680
+    env = BatchedAzul(n)
+    _start(env, base)
+    for _ in range(launches - 1):
+        env.selfplay(T)
+    t = env.alloc_trajectory(T)
+    env.selfplay(T, t["mask"], t["action"], t["reward"], t["done"])
+    torch.cuda.synchronize()
+    final = env.get_records()
+    act = t["action"].cpu().numpy()
+    assert (act[:, 1] < 30).all() and int(final["turn_counter"][1]) > 1000          # game 801: floor moves only, thousands of rounds into one episode
+    for g in range(n):
+        s = oz.Stream(base + g)
+        s.advance((launches - 1) * T, want_records=False)
+        o = s.advance(T, want_records=False)
+        assert np.array_equal(o["action"], act[:, g]) and np.array_equal(o["mask"], t["mask"].cpu().numpy()[:, g]), g
+        assert np.array_equal(o["reward"], t["reward"].cpu().numpy()[:, g]) and np.array_equal(o["done"], t["done"].cpu().numpy()[:, g]), g
+        for p in range(2):       # the record keeps an episode's floor-penalty statistic in 16 bits: game 801's has wrapped (-38,936 points in one episode)
+            fp = int(s.q.game.floor_penalty[p])
+            assert (g == 1) == (fp < -32768), (g, fp)
+            s.q.game.floor_penalty[p] = float((fp + 32768) % 65536 - 32768)
+        assert s.record().tobytes() == final[g].tobytes() and env.get_rng(g)[1] == s.rng_state()[1], g
+
+
 @pytest.mark.parametrize("opponent", [None, "random", "net"])
 def test_rollout_structures_agree_under_a_move_limit(golden_dir, opponent):
     """The window kernel and the per-move / per-cut path with a limit of 36 moves: every trajectory array (done codes 0 / 1 / 3), records, RNG

@@ -39,7 +39,7 @@ enum { POOL_RANDOM = 0, POOL_LID = 1 };
 #ifndef AZ_DRAW_MARGIN
 #define AZ_DRAW_MARGIN 8192ull      // factory draw: > 21.1 * 255, the largest possible fp64 disagreement window
 #endif
-enum { T_ROWS = 31, T_BINADES = 8 };   // RandomAgent weight table of the 180-action game: 31 rows (J = 0..30 legal floor moves) x 8 binades, see azul_tables.hpp
+enum { T_ROWS = 31, T_BINADES = 8, T_STRIDE = 9 /* pairs per row: eight binades + the floor-only pair */, T_PAIRS = T_ROWS * T_STRIDE };   // RandomAgent weight table of the 180-action game: 31 rows (J = 0..30 legal floor moves), see azul_tables.hpp
 
 // ---- optional in-kernel segment stamps (diagnostic build only: -DAZ_PROFILE_SEGMENTS; cdna_hip_programming.md 7) ----
 // s_memtime deltas are accumulated per segment and added to a global buffer when the wave ends.  The real kernel

@@ -70,7 +70,7 @@ AZ_FN bool random_agent2(const Mask2 &m, Rng2 &r, const Tab2 &T, const K2 &k, u3
     code = 0;
     if (L == 0u) return false;
     const u32 M = L - J, Mc = M ? M : 1u;
-    const double2 fs = T.fs[8u * (J < 31u ? J : 30u) + 31u - (u32)__builtin_clz(Mc)];
+    const double2 fs = T.fs[9u * (J < 31u ? J : 30u) + 31u - (u32)__builtin_clz(Mc)];
     const double sJ = fs.y;
     const double total = ((double)M + (M ? fs.x : sJ)) + 0.0;
     const double x = rng2_random(r, l) * total;

@@ -46,7 +46,7 @@ template <u32 P, u32 D>
 __global__ void __launch_bounds__(64) azul_x_op_kernel(azx::XBatchDev b, azx::XOp a)
 {
     __shared__ u32 mt_lds[2][624];
-    __shared__ double2 tab_lds[azx::Dim<D>::TROWS * 8];
+    __shared__ double2 tab_lds[azx::Dim<D>::TROWS * T_STRIDE];
     azx::op_body_x<P, D>(b, a, blockIdx.x, mt_lds, tab_lds);
 }
 
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64) azul_x_selfplay_kernel(azx::XBatchDev b, a
 {
     __shared__ u32 mt_lds[2][624];
     __shared__ u32 mtt_lds[2][624];
-    __shared__ double2 tab_lds[azx::Dim<D>::TROWS * 8];
+    __shared__ double2 tab_lds[azx::Dim<D>::TROWS * T_STRIDE];
     const u32 nb = gridDim.x, xcd = blockIdx.x & 7u, q8 = nb >> 3, rem = nb & 7u;
     const u32 wave_id = xcd * q8 + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);      // every XCD plays a contiguous range of games
     azx::selfplay_body_x<P, D, OUT, PAD, BITS>(b, t, wave_id, mt_lds, mtt_lds, tab_lds);
@@ -175,7 +175,7 @@ static int batch_alloc(azul_batch *b, int n_games, int first_player, int tile_po
     HIP_TRY(hipMemset(b->d.prof, 0, AZ_PROF_SLOTS * sizeof(u64)));
     {   // the sampler's table: built with CPython's very additions and checked entry by entry on this host (azul_tables.hpp)
         const int rows = 5 * (b->displays + 1) + 1;
-        std::vector<double> hX((size_t)rows * 16);
+        std::vector<double> hX((size_t)rows * T_STRIDE * 2);
         if (!build_sample_pairs(rows, hX.data())) return fail(AZUL_ERR_INVALID, "weight-table decomposition check failed on this host");
         HIP_TRY(hipMalloc((void **)&b->Tx, hX.size() * sizeof(double)));
         HIP_TRY(hipMemcpy(b->Tx, hX.data(), hX.size() * sizeof(double), hipMemcpyHostToDevice));

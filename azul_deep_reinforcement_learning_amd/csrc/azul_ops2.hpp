@@ -14,7 +14,7 @@ struct BatchDev {
     uint8_t *state;      // [N][128]
     u32 *mt;             // [N][624]
     u32 *mtpos;          // [N]
-    const double2 *tab;  // the sampler's table as {Fr[J][b], S[J]} pairs, T_ROWS x T_BINADES (azul_tables.hpp: build_sample_pairs)
+    const double2 *tab;  // the sampler's table as pairs, T_ROWS x T_STRIDE (azul_tables.hpp: build_sample_pairs)
     u64 *episodes;       // [N]
     u32 *stuck;          // [N]
     double *stat_sum;    // [N][10]
@@ -77,7 +77,7 @@ AZ_FN void op_body2(const BatchDev &b, const OpArgs &a, u32 pair, u32 (*mt_lds)[
 {
     using namespace az2;
     const u32 lane = wv::lane(), l = lane & 31u, half = lane >> 5;
-    for (u32 i = lane; i < (u32)(T_ROWS * T_BINADES); i += 64u) tabfs_lds[i] = b.tab[i];
+    for (u32 i = lane; i < (u32)T_PAIRS; i += 64u) tabfs_lds[i] = b.tab[i];
     lds_sync();
     const u32 oi = 2u * pair + half;                 // row of the caller's arrays
     if (oi >= a.count) return;                       // odd launch: the last wave serves one game

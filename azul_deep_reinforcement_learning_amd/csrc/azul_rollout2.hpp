@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     __shared__ float w2cS[PF_HID];
     __shared__ float b1S[PF_H2 + 24], b2aS[PF_ACT + 12];
     __shared__ u32 mtS[PF_GAMES][az2::MT_LDS_WORDS];
-    __shared__ double2 tabfs_lds[T_ROWS * T_BINADES];
+    __shared__ double2 tabfs_lds[T_PAIRS];
     __shared__ u64 maskS[PF_GAMES][4];
     __shared__ i32 actS[PF_GAMES];
     __shared__ float b1oS[OPP == 2 ? PF_HID + 12 : 1], b2aoS[OPP == 2 ? PF_ACT + 12 : 1];      // the opponent's actor biases
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(64 * PR2_WAVES) azul_policy_rollout2_kernel(Ba
     if (tid < (u32)(PF_H2 + 24)) b1S[tid] = tid < (u32)PF_H2 ? W.b1[tid] : 0.f;
     if (tid < (u32)(PF_ACT + 12)) b2aS[tid] = tid < (u32)PF_ACT ? W.b2a[tid] : 0.f;
     if (OPP == 1) {
-        for (u32 i = tid; i < (u32)(T_ROWS * T_BINADES); i += 64u * PR2_WAVES) tabfs_lds[i] = b.tab[i];
+        for (u32 i = tid; i < (u32)T_PAIRS; i += 64u * PR2_WAVES) tabfs_lds[i] = b.tab[i];
     }
     if (OPP == 2) {
         if (tid < (u32)(PF_HID + 12)) b1oS[tid] = tid < (u32)PF_HID ? a.Wopp.b1[PF_HID + tid] : 0.f;

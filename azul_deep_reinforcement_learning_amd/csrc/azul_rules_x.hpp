@@ -722,7 +722,7 @@ AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2
     const bool nomove = (L == 0u) | (g.eog != 0u);        // ValueError in the reference (raised before random()) / a finished game handed in
     const u32 M = L - J, Mc = M ? M : 1u;
     const double u01 = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0);      // random()
-    const double2 fs = T.fs[8u * (J < Dim<D>::TROWS ? J : Dim<D>::TROWS - 1u) + 31u - (u32)__builtin_clz(Mc)];  // {Fr[J][ilog2 M], S[J]}
+    const double2 fs = T.fs[9u * (J < Dim<D>::TROWS ? J : Dim<D>::TROWS - 1u) + 31u - (u32)__builtin_clz(Mc)];  // {Fr[J][ilog2 M], S[J]}
     if (OUT == 1 || (OUT == 2 && o.mask)) store_mask_x<D, (PAD && OUT == 1)>(o, m, l);
     if ((OUT == 1 && BITS) || (OUT == 2 && o.maskbits)) store_maskbits_x<D>(o, m, l);
     AZ_STAMP(SEG_MASK);
@@ -841,7 +841,7 @@ AZ_FN i32 random_agent_x(const MaskX<D> &m, Rng2 &r, const Tab2 &T, const K2 &k)
     i32 a = -1;
     if (L != 0u) {
         const u32 M = L - J;
-        const double sJ = T.fs[8u * J].y;
+        const double sJ = T.fs[9u * J].y;
         const double total = (M ? tpat2(T, J, M) : sJ) + 0.0;
         const double x = rng2_random(r, k.l) * total;
         const u32 kg = sample_slow2(T, x, sJ, J, M, L);
@@ -903,7 +903,7 @@ AZ_FN bool xop_draws(int op) { return op == XOP_INIT || op == XOP_NEW_ROUND || o
 template <u32 D>
 AZ_FN void stage_tab_x(const double2 *tab, double2 *tab_lds, u32 lane)
 {
-    for (u32 i = lane; i < Dim<D>::TROWS * 8u; i += 64u) tab_lds[i] = tab[i];
+    for (u32 i = lane; i < Dim<D>::TROWS * (u32)T_STRIDE; i += 64u) tab_lds[i] = tab[i];
     lds_sync();
 }
 

@@ -380,10 +380,10 @@ AZ_FN void legal_mask2(const G2 &g, const K2 &k, Mask2 &out)
 // checks all 31 * 151 sums when a batch is created).  bisect_right over the cumulative weights == the smallest ordinal k with cum(k) > x.
 // Pattern moves: |Fr - S[J]| < 2^-44 (a handful of half-ulp roundings below 256) and d = x - S[J] carries an fp64 error below 2^-45, so
 // whenever d is further than 1e-9 from an integer, floor(d) + 1 IS the ordinal; otherwise the exact table values decide (sample_slow2).
-struct Tab2 { const double2 *fs; };      // LDS: the pairs {Fr[J][b], S[J]} at 8 J + b (azul_tables.hpp: build_sample_pairs): both table values of a decision in one 16-byte read
+struct Tab2 { const double2 *fs; };      // LDS: the pairs {Fr[J][b], S[J]} at 9 J + b, b < 8, and the floor-only pair at 9 J + 8 (azul_tables.hpp: build_sample_pairs): both table values of a decision in one 16-byte read
 
-AZ_FN double tpat2(const Tab2 &t, u32 J, u32 m) { return (double)m + t.fs[8u * J + 31u - (u32)__builtin_clz(m)].x; }      // T(J, m), m >= 1
-AZ_FN double tseq2(const Tab2 &t, u32 J, u32 kk) { return kk <= J ? t.fs[8u * kk].y : tpat2(t, J, kk - J); }              // cumulative weight after the kk-th legal action
+AZ_FN double tpat2(const Tab2 &t, u32 J, u32 m) { return (double)m + t.fs[9u * J + 31u - (u32)__builtin_clz(m)].x; }      // T(J, m), m >= 1
+AZ_FN double tseq2(const Tab2 &t, u32 J, u32 kk) { return kk <= J ? t.fs[9u * kk].y : tpat2(t, J, kk - J); }              // cumulative weight after the kk-th legal action
 
 // bisect_right over the cumulative weights == smallest ordinal kk with cum(kk) > x, for the draws the one-compare fast path leaves (x inside
 // the 0.01-weight floor moves, a guess too close to an integer boundary, the clamp at the last weight).  A first guess -- floor(100 x) + 1
@@ -988,12 +988,18 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     const u32 J = c0;                                    // legal floor moves (row 0: a < 30, weight 0.01)
     const u32 p1 = c0, p2 = p1 + c1, p3 = p2 + c2, p4 = p3 + c3, p5 = p4 + c4, L = p5 + c5;
     const bool nomove = (L == 0u) | (g.eog != 0u);        // ValueError in the reference (raised before random()) / a finished game handed in
-    const u32 M = L - J, Mc = M ? M : 1u;
+    const u32 M = L - J;
+    // Floor-only masks (M == 0) take the same one-compare form from their own pair {fl(100 S[J]), 0} -- "binade 8": M = 0 counts as 256 --
+    // with the ordinal counted from 0 instead of J: selects on counts that are known before the table answers, nothing added to the move's
+    // chain (azul_tables.hpp).  (The index as  M ? 9 J + ilog2 M : 9 J + 8  -- a select between two sums -- ran 1.4 % slower.)
+    const u32 Jc = J < 31u ? J : 30u;
+    const u32 Mc = M ? M : 256u;
+    const u32 kbase = M ? J : 0u;
     // (random()'s conversion sits BEFORE the request: the two words were asked for ~40 instructions ago, and a use of them after the
     // request would make the compiler wait for both reads there)
     const double u01 = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0);      // random()
     __builtin_amdgcn_sched_barrier(0);
-    const double2 fs = T.fs[8u * (J < 31u ? J : 30u) + 31u - (u32)__builtin_clz(Mc)];      // {Fr[J][ilog2 M], S[J]}
+    const double2 fs = T.fs[9u * Jc + 31u - (u32)__builtin_clz(Mc)];      // {Fr[J][ilog2 M], S[J]} | {fl(100 S[J]), 0}
     __builtin_amdgcn_sched_barrier(0);
     if (OUT == 1 || (OUT == 2 && o.mask))
         store_mask_row2<(PAD && OUT == 1)>(o, m.m[0], m.m[1], m.m[2], m.m[3], m.m[4], m.m[5], m.bit[0], m.bit[1], m.bit[2], m.bit[3], m.bit[4], m.bit[5], l);
@@ -1009,19 +1015,19 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     __builtin_amdgcn_sched_barrier(0);
     AZ_STAMP(SEG_MASK);
     const double sJ = fs.y;
-    // cum(J + M) = M + Fr[J][ilog2 M] (M >= 1), S[J] (M == 0); written as ONE sum so that both table values are used
-    // unconditionally (a conditional use makes the compiler split the 16-byte read and branch around half of it)
-    const double total = ((double)M + (M ? fs.x : sJ)) + 0.0;
+    // cum(J + M) = M + Fr[J][ilog2 M] (M >= 1); floor-only: 0 + fl(100 S[J]), x in hundredths
+    const double total = ((double)M + fs.x) + 0.0;
     // pattern moves: cum(J + mm) = mm + Fr[J][ilog2 mm]; away from integer boundaries floor(x - S[J]) + 1 IS the ordinal
-    double x = u01 * total;
+    double u = u01;
+    double x = u * total;
     double d = x - sJ;
     u32 fl = (u32)d;
     double fr = d - (double)fl;
-    u32 kg = J + fl + 1u;
+    u32 kg = kbase + fl + 1u;
     // "x is not safely inside a pattern move's unit interval": fr within 1e-9 of 0 or 1 as ONE compare, |fr - 0.5| >= 0.5 - 1e-9 (the
     // subtraction's rounding, 2^-54, is far inside the margin; the slow path gives the fast path's answer wherever both apply).  x < S[J]
     // (inside the floor moves) needs no test of its own: then -1 < d < 0, fl == 0 and fr == d < 0.
-    bool edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (fl + 1u > M);
+    bool edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (kg > L);
     r.pos += 2u;                                             // (taken back in the block below when no random() was consumed here)
     // ONE test for everything unusual about this decision (a random() that crosses a regeneration, a draw at a boundary of the
     // cumulative weights, nothing legal); the stuck slot itself is restarted further down
@@ -1039,12 +1045,17 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
             const u32 t0 = r.tlds[0], t1 = r.tlds[1];
             wa = one ? last : t0; wb = one ? t0 : t1;
             r.pos = one ? 1u : 2u;
-            x = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0) * total;
+            u = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0);
+            x = u * total;
             d = x - sJ; fl = (u32)d; fr = d - (double)fl;
-            kg = J + fl + 1u;
-            edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (fl + 1u > M);
+            kg = kbase + fl + 1u;
+            edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (kg > L);
         }
-        if (edge & !nomove) kg = sample_slow2(T, x, sJ, J, M, L);
+        if (edge & !nomove) {
+            // the boundary search works on CPython's own quantities: for a floor-only mask x = random() * (S[J] + 0.0)
+            const double sT = M ? sJ : T.fs[9u * Jc].y;
+            kg = sample_slow2(T, M ? x : u * (sT + 0.0), sT, J, M, L);
+        }
         any_nomove = wave_any(nomove);
     }
     // kg-th legal action: its pattern row (= mask word) from the prefix counts (half-uniform compares), then ONE rank test per lane;

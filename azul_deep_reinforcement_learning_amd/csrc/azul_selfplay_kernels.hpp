@@ -20,7 +20,7 @@ template <bool LID>
 __global__ void __launch_bounds__(64) azul_op_kernel(BatchDev b, OpArgs a)
 {
     __shared__ u32 mt_lds[2][az2::MT_LDS_WORDS];
-    __shared__ double2 tabfs_lds[T_ROWS * T_BINADES];
+    __shared__ double2 tabfs_lds[T_PAIRS];
     __shared__ float obs_lds[2][OP2_OBS_STRIDE];
     op_body2<LID>(b, a, blockIdx.x, mt_lds, tabfs_lds, obs_lds);
 }
@@ -159,9 +159,9 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
 {
     __shared__ u32 mt_lds[2][az2::MT_LDS_WORDS];          // (+ the move limit: az2::rng2_set_move_limit)
     __shared__ u32 mtt_lds[2][624];                        // the same words tempered (az2::Rng2::tlds)
-    __shared__ double2 tabfs_lds[T_ROWS * T_BINADES];      // {Fr[J][b], S[J]}: both table values of a decision in one 16-byte read
+    __shared__ double2 tabfs_lds[T_PAIRS];                 // {Fr[J][b], S[J]} + the floor-only pairs: both table values of a decision in one 16-byte read
     const u32 lane = wv::lane(), l = lane & 31u, half = lane >> 5;
-    for (u32 i = lane; i < (u32)(T_ROWS * T_BINADES); i += 64u) tabfs_lds[i] = b.tab[i];
+    for (u32 i = lane; i < (u32)T_PAIRS; i += 64u) tabfs_lds[i] = b.tab[i];
     az2::lds_sync();
     // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup b runs on XCD b % 8.
     // Give every XCD a CONTIGUOUS range of games: the waves that share a cache line of a time-major stream (32 games of an int32

@@ -32,7 +32,7 @@ struct EnvJob {
     u32 wave_id;
     // "LDS" of the wave
     u32 mt_lds[2][az2::MT_LDS_WORDS];
-    double2 tabfs_lds[T_ROWS * T_BINADES];
+    double2 tabfs_lds[T_PAIRS];
     float obs_lds[2][OBS_STRIDE];
     u64 mask_lds[2][3];
 };
@@ -41,7 +41,7 @@ template <bool LID, bool OPP>
 static void env_wave(EnvJob *j)
 {
     const u32 lane = wv::lane(), l = lane & 31u, half = lane >> 5;
-    for (u32 i = lane; i < (u32)(T_ROWS * T_BINADES); i += 64u) j->tabfs_lds[i] = j->T[i];
+    for (u32 i = lane; i < (u32)T_PAIRS; i += 64u) j->tabfs_lds[i] = j->T[i];
     az2::lds_sync();
     const u32 n = j->n, gi = j->wave_id * 2u + half;
     const bool live = gi < n;
@@ -120,7 +120,7 @@ long long sh2_rollout_env(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 
                           uint8_t *mask, uint8_t *player, u64 *maskbits, i32 *reward, uint8_t *done, uint8_t *status)
 {
     if (n_games <= 0 || n_steps < 0) return -1;
-    static double T[T_ROWS * T_BINADES * 2];
+    static double T[T_PAIRS * 2];
     if (!build_sample_pairs(T_ROWS, T)) return -2;
     long long ops = 0;
     for (u32 w = 0; w < ((u32)n_games + 1u) / 2u; w++) {

@@ -9,7 +9,7 @@
 using namespace az;
 #include "azul_selfplay_kernels.hpp"
 
-static double g_T[T_ROWS * T_BINADES * 2];
+static double g_T[T_PAIRS * 2];
 static bool g_T_ok = false;
 static void table() { if (!g_T_ok) { g_T_ok = build_sample_pairs(T_ROWS, g_T); } }
 
@@ -94,6 +94,6 @@ void sh2_seed(unsigned long long seed, u32 *mt) { seed_stream(mt, (u64)seed); }
 
 // the RandomAgent weight table (azul_tables.hpp: CPython's accumulate over 0.01 / 1.0 weights) and the check of its compact form
 void sh2_weight_table(double *T /* [31][151] */) { build_weight_table(T); }
-int sh2_sample_tab_ok() { double t[T_ROWS * T_BINADES * 2]; return build_sample_pairs(T_ROWS, t) ? 1 : 0; }
+int sh2_sample_tab_ok() { double t[T_PAIRS * 2]; return build_sample_pairs(T_ROWS, t) ? 1 : 0; }
 
 }

@@ -54,7 +54,7 @@ long long sr2_rollout_vs(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 *
                          float *returns, float gamma, unsigned long long seed, unsigned long long opp_seed, unsigned long long counter,
                          i32 *opp_action, float *opp_logp, uint8_t *opp_replies, int opp_slots)
 {
-    static double T[T_ROWS * T_BINADES * 2];
+    static double T[T_PAIRS * 2];
     if (!build_sample_pairs(T_ROWS, T)) return -2;
     Job j;
     memset(&j, 0, sizeof(j));
@@ -78,7 +78,7 @@ long long sr2_rollout(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 *epi
                       i32 *action, i32 *reward, uint8_t *done, float *value, float *logp, float *entropy, uint8_t *status, float *returns,
                       float gamma, unsigned long long seed, unsigned long long counter)
 {
-    static double T[T_ROWS * T_BINADES * 2];
+    static double T[T_PAIRS * 2];
     if (!build_sample_pairs(T_ROWS, T)) return -2;
     Job j;
     memset(&j, 0, sizeof(j));

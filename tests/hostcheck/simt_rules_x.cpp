@@ -19,7 +19,7 @@ struct XJob {
     u32 wave;
     u32 mt_lds[2][624];
     u32 mtt_lds[2][624];
-    double2 tab_lds[51 * 8];
+    double2 tab_lds[51 * T_STRIDE];
 };
 
 template <u32 P, u32 D>
@@ -52,7 +52,7 @@ static lane_fn pick_fn(int players, int displays, bool play)
 
 static double *table_for(int displays)
 {
-    static double tabs[3][51 * 8 * 2];
+    static double tabs[3][51 * T_STRIDE * 2];
     static bool built[3] = {false, false, false};
     const int i = displays == 5 ? 0 : displays == 7 ? 1 : 2;
     if (!built[i]) { if (!build_sample_pairs(5 * (displays + 1) + 1, tabs[i])) return nullptr; built[i] = true; }

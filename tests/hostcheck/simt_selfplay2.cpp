@@ -47,7 +47,7 @@ long long sh2_selfplay(int n_games, uint8_t *state, u32 *mt, u32 *mtpos, u64 *ep
                        u64 *maskbits, i32 *action, i32 *reward, uint8_t *done, u32 *packed, uint8_t *rec)
 {
     if (n_games <= 0 || n_steps < 0) return -1;
-    static double T[T_ROWS * T_BINADES * 2];
+    static double T[T_PAIRS * 2];
     if (!build_sample_pairs(T_ROWS, T)) return -2;
     long long ops = 0;
     // the kernel itself: one one-wave workgroup per pair of games, blockIdx.x as the launch gives it (the kernel maps it to its games)
@@ -108,7 +108,7 @@ static void sample_lane(void *arg)
 }
 int sh2_sample_slow(int n, const double *x, const int *J, const int *M, int *out)
 {
-    static double T[T_ROWS * T_BINADES * 2];
+    static double T[T_PAIRS * 2];
     if (!build_sample_pairs(T_ROWS, T)) return -2;
     SampleJob j = {T, x, J, M, out, 0, n};
     for (j.base = 0; j.base < n; j.base += 64) simt::run_wave(sample_lane, &j);

@@ -315,3 +315,43 @@ def test_boundary_search_of_the_random_agents_draw_equals_cpythons_bisect():
     bad = np.flatnonzero(out != np.array(want))
     assert len(bad) == 0, (len(bad), [(xs[i], Js[i], Ms[i], out[i], want[i]) for i in bad[:5]])
     assert len(xs) > 50000
+
+
+def test_floor_only_decisions_of_a_never_ending_game_under_emulation():
+    """Hazard H9's state (game 801 of the benchmark batch after ~310 k moves, profiles/round6_never_ending_game_801.txt: both players hold r
+    tiles of colour 2 in pattern row r, so every legal action is a floor move for ever): every decision is a draw among 0.01 weights only
+    (M = 0), which selfplay_step2 decides in its one-compare path from the table's floor-only row {fl(100 S[J]), 0}
+    (azul_tables.hpp: build_floor_pairs; game_runner.py:87-97 + random.choices).  Six streams continue from that state for 150 moves each:
+    masks, actions, rewards, records and RNG positions equal the oracle's, and every action IS a floor move."""
+    L = load()
+    rec = np.zeros(1, dtype=oz.RECORD_DTYPE)[0]
+    rec["displays"] = [[0, 2, 0, 1, 1], [2, 0, 0, 1, 1], [0, 2, 0, 1, 1], [3, 0, 0, 0, 1], [1, 1, 0, 1, 1]]
+    rec["center"] = [0, 0, 0, 0, 0, 1]
+    rec["flags"] = 2
+    lines = np.zeros((2, 5, 5), np.uint8)
+    for r in range(1, 5):
+        lines[:, r, 2] = r
+    rec["pattern_lines"] = lines
+    rec["walls"] = [16785787, 18779]
+    rec["box"] = [8, 4, 0, 6, 5]
+    rec["lid"] = [3, 6, 0, 5, 6]
+    rec["turn_counter"] = 3949
+    rec["first_player_stats"] = [1926, 2023]
+    rec["floor_penalty"] = [10751, 10794]
+    rec["max_combo"] = [4, 2]
+    rec["move_counter"] = 38949
+    seen = []
+
+    def prepare(streams):
+        for s in streams:
+            s.q = oz.unpack(rec, tile_pool=oz.POOL_LID, first_player=oz.FIRST_RANDOM)
+            seen.append(s)
+
+    for variant in (0, 3):
+        streams, state, mt, pos, ep, stuck, ss, out, ops = run_case(L, 0, 1, n=6, T=150, variant=variant, seed0=4242, prepare=prepare)
+        for g, s in enumerate(streams):
+            o = s.advance(150)
+            assert np.array_equal(out["mask"][:, g, :180], o["mask"]) and np.array_equal(out["action"][:, g], o["action"]), (variant, g)
+            assert np.array_equal(out["reward"][:, g], o["reward"]) and np.array_equal(out["done"][:, g], o["done"]), (variant, g)
+            assert (o["action"] < 30).all() and not o["done"].any() and not o["mask"][:, 30:].any(), (variant, g)
+            assert state[g].tobytes() == s.record().tobytes() and int(pos[g]) == s.rng_state()[1], (variant, g)

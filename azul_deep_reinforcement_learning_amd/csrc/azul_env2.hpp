@@ -69,17 +69,23 @@ AZ_FN bool random_agent2(const Mask2 &m, Rng2 &r, const Tab2 &T, const K2 &k, u3
     const u32 p1 = c0, p2 = p1 + c1, p3 = p2 + c2, p4 = p3 + c3, p5 = p4 + c4, L = p5 + c5;
     code = 0;
     if (L == 0u) return false;
-    const u32 M = L - J, Mc = M ? M : 1u;
-    const double2 fs = T.fs[9u * (J < 31u ? J : 30u) + 31u - (u32)__builtin_clz(Mc)];
+    // (floor-only masks, M == 0, take the table's ninth pair {fl(100 S[J]), 0} with the ordinal counted from 0: selfplay_step2, azul_tables.hpp)
+    const u32 M = L - J, Mc = M ? M : 256u, Jc = J < 31u ? J : 30u;
+    const u32 kbase = M ? J : 0u;
+    const double2 fs = T.fs[9u * Jc + 31u - (u32)__builtin_clz(Mc)];
     const double sJ = fs.y;
-    const double total = ((double)M + (M ? fs.x : sJ)) + 0.0;
-    const double x = rng2_random(r, l) * total;
+    const double total = ((double)M + fs.x) + 0.0;
+    const double u = rng2_random(r, l);
+    const double x = u * total;
     const double d = x - sJ;
     const u32 fl = (u32)d;
     const double fr = d - (double)fl;
-    u32 kg = J + fl + 1u;
-    const bool edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (fl + 1u > M);
-    if (AZ_UNLIKELY(edge)) kg = sample_slow2(T, x, sJ, J, M, L);
+    u32 kg = kbase + fl + 1u;
+    const bool edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (kg > L);
+    if (AZ_UNLIKELY(edge)) {
+        const double sT = M ? sJ : T.fs[9u * Jc].y;      // the boundary search works on CPython's own x = random() * (S[J] + 0.0)
+        kg = sample_slow2(T, M ? x : u * (sT + 0.0), sT, J, M, L);
+    }
     const u32 want = kg - 1u;
     const bool g1 = want >= p1, g2 = want >= p2, g3 = want >= p3, g4 = want >= p4, g5 = want >= p5;
     const u32 mword = g5 ? m.m[5] : g4 ? m.m[4] : g3 ? m.m[3] : g2 ? m.m[2] : g1 ? m.m[1] : m.m[0];

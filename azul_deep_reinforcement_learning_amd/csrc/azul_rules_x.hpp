@@ -720,20 +720,23 @@ AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2
     for (u32 rr = 0; rr < 6u; rr++) pre[rr + 1] = pre[rr] + row_count<D>(m, rr);
     const u32 J = pre[1], L = pre[6];                     // legal floor moves (row 0, weight 0.01) / all legal moves
     const bool nomove = (L == 0u) | (g.eog != 0u);        // ValueError in the reference (raised before random()) / a finished game handed in
-    const u32 M = L - J, Mc = M ? M : 1u;
+    // (floor-only masks, M == 0, take the table's ninth pair {fl(100 S[J]), 0} with the ordinal counted from 0: selfplay_step2, azul_tables.hpp)
+    const u32 M = L - J, Mc = M ? M : 256u, Jc = J < Dim<D>::TROWS ? J : Dim<D>::TROWS - 1u;
+    const u32 kbase = M ? J : 0u;
     const double u01 = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0);      // random()
-    const double2 fs = T.fs[9u * (J < Dim<D>::TROWS ? J : Dim<D>::TROWS - 1u) + 31u - (u32)__builtin_clz(Mc)];  // {Fr[J][ilog2 M], S[J]}
+    const double2 fs = T.fs[9u * Jc + 31u - (u32)__builtin_clz(Mc)];  // {Fr[J][ilog2 M], S[J]} | {fl(100 S[J]), 0}
     if (OUT == 1 || (OUT == 2 && o.mask)) store_mask_x<D, (PAD && OUT == 1)>(o, m, l);
     if ((OUT == 1 && BITS) || (OUT == 2 && o.maskbits)) store_maskbits_x<D>(o, m, l);
     AZ_STAMP(SEG_MASK);
     const double sJ = fs.y;
-    const double total = ((double)M + (M ? fs.x : sJ)) + 0.0;
-    double x = u01 * total;
+    const double total = ((double)M + fs.x) + 0.0;
+    double u = u01;
+    double x = u * total;
     double d = x - sJ;
     u32 fl = (u32)d;
     double fr = d - (double)fl;
-    u32 kg = J + fl + 1u;
-    bool edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (fl + 1u > M);
+    u32 kg = kbase + fl + 1u;
+    bool edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (kg > L);
     r.pos += 2u;
     bool any_nomove = false;
     if (AZ_UNLIKELY(wave_any(hard | edge | nomove))) {
@@ -747,12 +750,16 @@ AZ_FN u32 selfplay_step_x(GX<P, D> &g, const RulesX &rules, const KX<D> &K, Rng2
             const u32 t0 = r.tlds[0], t1 = r.tlds[1];
             wa = one ? last : t0; wb = one ? t0 : t1;
             r.pos = one ? 1u : 2u;
-            x = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0) * total;
+            u = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0);
+            x = u * total;
             d = x - sJ; fl = (u32)d; fr = d - (double)fl;
-            kg = J + fl + 1u;
-            edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (fl + 1u > M);
+            kg = kbase + fl + 1u;
+            edge = !(__builtin_fabs(fr - 0.5) < 0.5 - 1e-9) | (kg > L);
         }
-        if (edge & !nomove) kg = sample_slow2(T, x, sJ, J, M, L);
+        if (edge & !nomove) {
+            const double sT = M ? sJ : T.fs[9u * Jc].y;      // the boundary search works on CPython's own x = random() * (S[J] + 0.0)
+            kg = sample_slow2(T, M ? x : u * (sT + 0.0), sT, J, M, L);
+        }
         any_nomove = wave_any(nomove);
     }
     Choice<D> ch;

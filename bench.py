@@ -608,9 +608,10 @@ def never_ending_games(env, run, games, rounds_threshold=100, launches=20):
     """Games of the batch that have been in ONE episode for more than `rounds_threshold` rounds (a game of the reference lasts ~5, at most
     ~15): under the reference's rules with random play a game can reach a state from which it never ends -- e.g. all 20 tiles of one colour
     locked in pattern lines that cannot be completed any more -- and GameRunner's `while not done` loops for ever (the reference would too).
-    Such a game keeps its slot and, with short rounds (a deal and a scoring every ~9 moves), its wave is slower per move.  Evidence, measured
-    here: the launch time with these games, and with their records replaced by a neighbour's (AFTER every parity gate; the batch is
-    discarded afterwards)."""
+    Such a game keeps its slot for ever.  Every one of its moves is a floor move: until the sampler decided floor-only masks in its one-compare
+    path (table rows of nine pairs, azul_tables.hpp) its wave ran ~10 % slower and the launch with it; now it costs nothing.  Evidence, measured
+    here: the launch time with these games, and with their records replaced by a neighbour's (AFTER every parity gate, 25 untimed launches
+    before each measurement; the batch is discarded afterwards)."""
     import numpy as np
     recs = env.get_records()
     odd = np.flatnonzero(recs["turn_counter"] >= rounds_threshold)
@@ -620,6 +621,7 @@ def never_ending_games(env, run, games, rounds_threshold=100, launches=20):
         return out
 
     def launch_ms():
+        run(25)              # untimed: the host work in front of each measurement leaves the GPU idle (the first ~12 launches after a gap are slower)
         return clocked(env, lambda: run(1), launches)[1]
 
     out["launch_ms_with"] = launch_ms()
@@ -944,11 +946,12 @@ def main():
             sustained["never_ending_games"] = never_ending_games(env, run_local, G)
             ne = sustained["never_ending_games"]
             if ne.get("count"):
-                sustained["note"] += ("; CAUSE of the step in this run: %d of the %d games (first ids %s) are NEVER-ENDING under the reference's rules -- every "
-                                      "tile of one colour is locked in pattern lines that can no longer be completed, so no wall row can ever be "
-                                      "filled (azul.py:184-191 stays false) and the game plays short rounds for ever; such a game's wave is slower per move "
-                                      "and a launch lasts as long as its slowest wave: launch %.4f ms with them, %.4f ms with their records replaced by a "
-                                      "neighbour's (never_ending_games)" % (ne["count"], G, ne["first_ids"], ne["launch_ms_with"], ne["launch_ms_replaced"]))
+                sustained["note"] += ("; %d of the %d games (first ids %s) are NEVER-ENDING under the reference's rules -- every tile of one colour is "
+                                      "locked in pattern lines that can no longer be completed, so no wall row can ever be filled (azul.py:184-191 stays "
+                                      "false) and every move of the game is a floor move for ever; the sampler decides such masks in its one-compare path, so "
+                                      "the game's wave costs the launch nothing any more (+10 %% in rounds 5 / 6 before): launch %.4f ms with them, %.4f ms "
+                                      "with their records replaced by a neighbour's (never_ending_games)"
+                                      % (ne["count"], G, ne["first_ids"], ne["launch_ms_with"], ne["launch_ms_replaced"]))
 
     out = None
     if rank == 0:

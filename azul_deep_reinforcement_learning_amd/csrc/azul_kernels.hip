@@ -78,7 +78,7 @@ struct azul_batch {
     bool x;              // three / four players, or any extended rule: the azul_rules_x.hpp kernels (rule entries + flat self-play)
     unsigned ext;        // AZUL_RULE_* flags (0: the reference's rules)
     int displays;        // 5, or 2 * players + 1 with AZUL_RULE_DISPLAYS_2P1
-    double *Tx;          // the sampling table as {Fr[J][b], S[J]} pairs for 5 (displays + 1) + 1 rows (31 for the reference's 180 actions)
+    double *Tx;          // the sampling table, T_STRIDE pairs per row, for 5 (displays + 1) + 1 rows (31 for the reference's 180 actions)
     hipEvent_t ev0, ev1; // bracket of a timed region (azul_timing_begin / _end)
     std::vector<hipEvent_t> lev;   // event pairs around the individual self-play launches of a timed region
     int timed_launches;  // launches since azul_timing_begin

@@ -280,7 +280,7 @@ AZ_FN void mask_limbs(const MaskX<D> &m, u64 (&limb)[Dim<D>::NL + 1])
     }
 }
 
-// ---- RandomAgent (game_runner.py:87-97 + random.choices): azul_selfplay2.hpp's table (Tab2: pairs {Fr[J][b], S[J]} at 8 J + b, here for
+// ---- RandomAgent (game_runner.py:87-97 + random.choices): azul_selfplay2.hpp's table (Tab2: rows of nine pairs at 9 J + b, here for
 // J = 0 .. Q legal floor moves) and its boundary search (sample_slow2), unchanged ------------------------------------------------------
 // one decision: counts of the legal actions, the ordinal from random(), the chosen action (row, source, colour)
 template <u32 D>

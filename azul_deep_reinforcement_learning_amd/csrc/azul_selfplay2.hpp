@@ -380,6 +380,7 @@ AZ_FN void legal_mask2(const G2 &g, const K2 &k, Mask2 &out)
 // checks all 31 * 151 sums when a batch is created).  bisect_right over the cumulative weights == the smallest ordinal k with cum(k) > x.
 // Pattern moves: |Fr - S[J]| < 2^-44 (a handful of half-ulp roundings below 256) and d = x - S[J] carries an fp64 error below 2^-45, so
 // whenever d is further than 1e-9 from an integer, floor(d) + 1 IS the ordinal; otherwise the exact table values decide (sample_slow2).
+// Floor-only masks (m == 0): the ordinal is floor(random() * fl(100 S[J])) + 1 on the same margin (azul_tables.hpp: the ninth pair of a row).
 struct Tab2 { const double2 *fs; };      // LDS: the pairs {Fr[J][b], S[J]} at 9 J + b, b < 8, and the floor-only pair at 9 J + 8 (azul_tables.hpp: build_sample_pairs): both table values of a decision in one 16-byte read
 
 AZ_FN double tpat2(const Tab2 &t, u32 J, u32 m) { return (double)m + t.fs[9u * J + 31u - (u32)__builtin_clz(m)].x; }      // T(J, m), m >= 1
@@ -390,9 +391,9 @@ AZ_FN double tseq2(const Tab2 &t, u32 J, u32 kk) { return kk <= J ? t.fs[9u * kk
 // inside the floor moves, J + floor(x - S[J]) + 1 above them -- and, unless it is known to be exact, a walk along the cumulative weights
 // until cum(kg - 1) <= x < cum(kg) (the weights are positive: the answer is unique; clamped to L like bisect's hi = n - 1).  Exact without
 // the walk: x < S[J] and 100 x further than 1e-9 from an integer -- S[k] is k additions of 0.01, |100 S[k] - k| < 1e-13 for k <= 60, and
-// x * 100 rounds by < 1e-13.  (A game whose every move is a floor move -- all that is left once its pattern lines are locked for good,
-// hazard H9 -- comes here on EVERY decision: with the walk its wave ran ~10 % slower than the others, and a launch lasts as long as its
-// slowest wave.)
+// x * 100 rounds by < 1e-13.  (Floor-ONLY masks, M == 0, do not come here any more unless their draw sits at a boundary: the callers decide
+// them in the one-compare path from the table's ninth pair -- a game whose every move is a floor move, hazard H9, used to take this
+// function on every decision and its wave ran ~10 % slower than the others; a launch lasts as long as its slowest wave.)
 AZ_FN u32 sample_slow2(const Tab2 &T, double x, double sJ, u32 J, u32 M, u32 L)
 {
     const bool floors = x < sJ;

@@ -1063,8 +1063,11 @@ AZ_FN u32 selfplay_step2(G2 &g, u32 first_player, const K2 &k, Rng2 &r, const Ta
     // the lane that answers holds (display, colour) as a constant, the row is the word index
     const u32 want = kg - 1u;
     const bool g1 = want >= p1, g2 = want >= p2, g3 = want >= p3, g4 = want >= p4, g5 = want >= p5;
-    const u32 mword = g5 ? m.m[5] : g4 ? m.m[4] : g3 ? m.m[3] : g2 ? m.m[2] : g1 ? m.m[1] : m.m[0];
-    const u32 base = g5 ? p5 : g4 ? p4 : g3 ? p3 : g2 ? p2 : g1 ? p1 : 0u;
+    // (the selects as a tree of depth three -- the g's are monotone, g5 => g4 => .. => g1 -- instead of a chain of five: -0.45 % on the headline kernel)
+    const u32 w01 = g1 ? m.m[1] : m.m[0], w23 = g3 ? m.m[3] : m.m[2], w45 = g5 ? m.m[5] : m.m[4];
+    const u32 b01 = g1 ? p1 : 0u, b23 = g3 ? p3 : p2, b45 = g5 ? p5 : p4;
+    const u32 mword = g4 ? w45 : (g2 ? w23 : w01);
+    const u32 base = g4 ? b45 : (g2 ? b23 : b01);
     const u32 prow_ = (u32)g1 + (u32)g2 + (u32)g3 + (u32)g4 + (u32)g5;
     // my bit is set AND its rank among the word's set bits is the wanted one, as ONE compare (a ballot of an and of two compares goes
     // through a 0 / 1 register): 2 (rank - wanted) + bit == 1

@@ -406,6 +406,12 @@ class BatchedAzul:
                 "stuck": _dev_view(stuck.value, (self.n,), "<i4", self.device),
                 "stat_sums": _dev_view(ss.value, (self.n, L.NUM_STATS), "<f8", self.device), "keys": list(STAT_KEYS)}
 
+    def records_dev(self):
+        """Zero-copy torch view of the device-resident game records, uint8 [N][record bytes] (azul_batch_state_dev; no synchronisation).  A
+        caller that writes through it keeps the records in the domain set_records validates AND within what play can produce: unlike
+        set_records it does not switch the batch's flat self-play to the instantiation that marks the slots of a rule-error-stopped game."""
+        return _dev_view(L.lib.azul_batch_state_dev(self._h), (self.n, self.record_dtype.itemsize), "|u1", self.device)
+
     def reset_counters(self):
         L.check(L.lib.azul_batch_reset_counters(self._h, self._stream()))
 

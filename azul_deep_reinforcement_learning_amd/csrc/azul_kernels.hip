@@ -85,6 +85,8 @@ struct azul_batch {
     int timed_pairs;     // of which bracketed by their own event pair (the first AZ_TIMED_PAIRS)
     bool timing;
     uint8_t *call_pin;   // azul_game_call: one call's arguments / results (CallScratch) in pinned, device-visible host memory
+    bool handed_in;      // the host has written records into the batch (azul_batch_set_state, azul_game_call's record_in): flat self-play then
+                         // runs the instantiation that marks and counts the slots of a rule-error-stopped game (a state play cannot reach)
 };
 enum { AZ_TIMED_PAIRS = 1024 };
 
@@ -306,6 +308,7 @@ int azul_batch_set_state(azul_batch_t *b, int first, int count, const void *reco
         if (int rc = record_in_domain(b, p)) return rc;
     HIP_TRY(hipMemcpyAsync(b->d.state + (size_t)first * RB, records_host, (size_t)count * RB, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    b->handed_in = true;
     return AZUL_SUCCESS;
 }
 
@@ -923,6 +926,7 @@ int azul_game_call(azul_batch_t *b, azul_call_t *c, void *stream)
     if (c->record_in) {
         memcpy(H->record, c->record_in, RB);
         HIP_TRY(hipMemcpyAsync(b->d.state + g * RB, H->record, RB, hipMemcpyHostToDevice, st));
+        b->handed_in = true;
     }
     if (c->mt_in) {
         memcpy(H->mt, c->mt_in, sizeof(H->mt));
@@ -1042,8 +1046,10 @@ int azul_batch_selfplay_strided(azul_batch_t *b, int n_steps, uint8_t *mask_dev,
         while ((int)b->lev.size() < 2 * (b->timed_pairs + 1)) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); b->lev.push_back(e); }
         HIP_TRY(hipEventRecord(b->lev[2 * b->timed_pairs], st));
     }
-    // (a batch with a move limit runs the instantiation that carries the limit's code: azul_batch_set_move_limit)
-    if (b->d.move_limit) { if (b->d.rules.tile_pool == POOL_LID) AZ_LAUNCH(true, true); else AZ_LAUNCH(false, true); }
+    // (a batch with a move limit runs the instantiation that carries the limit's code: azul_batch_set_move_limit; so does a batch whose
+    // records the host has written -- only a handed-in state can stop on a rule error, and that instantiation marks and counts the slots a
+    // stopped game no longer plays; move_limit == 0 is "no limit" there too)
+    if (b->d.move_limit || b->handed_in) { if (b->d.rules.tile_pool == POOL_LID) AZ_LAUNCH(true, true); else AZ_LAUNCH(false, true); }
     else { if (b->d.rules.tile_pool == POOL_LID) AZ_LAUNCH(true, false); else AZ_LAUNCH(false, false); }
 #undef AZ_LAUNCH
     HIP_TRY(hipGetLastError());
@@ -1131,7 +1137,7 @@ int azul_selfplay_kernel_resources(azul_batch_t *b, int padded_rows, int mask_bi
 {
     BATCH_GUARD(b, nullptr);
     if (!b || b->x) return fail(AZUL_ERR_INVALID, "azul_selfplay_kernel_resources: two-player reference batches");
-    const bool lid = b->d.rules.tile_pool == POOL_LID, lim = b->d.move_limit != 0;
+    const bool lid = b->d.rules.tile_pool == POOL_LID, lim = b->d.move_limit != 0 || b->handed_in;
     const void *fn;
 #define AZ_PICK(LID, LIM) (padded_rows ? (mask_bits ? (const void *)azul_selfplay2_kernel<LID, 1, true, true, LIM> : (const void *)azul_selfplay2_kernel<LID, 1, true, false, LIM>) \
                                        : (mask_bits ? (const void *)azul_selfplay2_kernel<LID, 1, false, true, LIM> : (const void *)azul_selfplay2_kernel<LID, 2, false, false, LIM>))

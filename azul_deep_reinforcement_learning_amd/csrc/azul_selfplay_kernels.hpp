@@ -198,8 +198,10 @@ __global__ void __launch_bounds__(64) azul_selfplay2_kernel(BatchDev b, TrajArgs
     // A uniform counted loop (scalar loop control: a per-game `break` costs ~16 exec-mask instructions per move).  A game stopped by a
     // rule error (box and lid empty when a round has to be dealt) stays as it is: its lanes skip the later moves.  Such a state cannot be
     // reached by play -- 100 tiles, at most 50 on the walls and 30 in the pattern lines when a round is dealt leave 20 for box + lid -- only
-    // handed in (tests); the LIM instantiation also marks the skipped slots like stuck slots (action -1, done 2, counted in `stuck`), the
+    // handed in; the LIM instantiation also marks the skipped slots like stuck slots (action -1, done 2, counted in `stuck`), the
     // default one does not: every form of that bookkeeping tried cost the benchmarked kernel 0.8 .. 1.5 % (profiles/round6_headline_ab.txt).
+    // The host therefore launches the LIM instantiation (limit 0 = none) for every batch it has written records into (azul_kernels.hip:
+    // azul_batch::handed_in), so the default one only ever sees states that play produced.
     bool dead = false;               // (set inside the rare blocks only: the common path carries no test for it)
     if (LIM) {
         u32 skipped = 0;

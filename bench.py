@@ -627,9 +627,13 @@ def never_ending_games(env, run, games, rounds_threshold=100, launches=20):
     out["launch_ms_with"] = launch_ms()
     recs = env.get_records()
     good = np.flatnonzero(recs["turn_counter"] < rounds_threshold)
-    for i, g in enumerate(odd):
-        recs[g] = recs[good[(int(g) + 1 + i) % len(good)]]
-    env.set_records(recs)
+    # replaced ON THE DEVICE through the zero-copy view: the neighbours' records are play's own, and a batch the host has written records
+    # into (set_records) would run the self-play instantiation that also marks rule-error-stopped games -- another kernel than the one measured
+    import torch
+    view = env.records_dev()
+    src = torch.as_tensor([int(good[(int(g) + 1 + i) % len(good)]) for i, g in enumerate(odd)], device=view.device)
+    view[torch.as_tensor(odd.astype(np.int64), device=view.device)] = view[src]
+    torch.cuda.synchronize()
     out["launch_ms_replaced"] = launch_ms()
     return out
 

@@ -469,6 +469,9 @@ int azul_pack_c1(const float *obs_dev, const uint8_t *mask_dev, const uint8_t *p
  * are 256-byte wide records (bytes of absent players and the reserved tail are not written), mask rows are dense.  A game of such a
  * batch that a rule error stops (bag and lid empty without AZUL_RULE_SHORT_DEAL, where the reference raises: azul.py:86-87) plays no
  * further move in this launch: its remaining slots carry action -1 / done 2 and are counted in `stuck` like the slots of a stuck game.
+ * The same holds for a TWO-player batch ("Lid" pool, box and lid both empty when a round has to be dealt) once the host has written
+ * records into it (azul_batch_set_state, azul_game_call's record_in) or it has a move limit: play from azul_batch_init / _reset cannot
+ * reach such a state, so a batch that was never handed a record runs the instantiation without that bookkeeping (the benchmarked one).
  */
 int azul_batch_selfplay(azul_batch_t *b, int n_steps, uint8_t *mask_dev, uint64_t *maskbits_dev, int32_t *action_dev,
                         int32_t *reward_dev, uint8_t *done_dev, uint32_t *packed_dev, uint8_t *rec_dev, void *stream);

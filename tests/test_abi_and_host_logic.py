@@ -157,3 +157,14 @@ def test_call_block_layout_is_the_headers(tmp_path):
     text = open(os.path.join(ROOT, "include", "azul_hip.h")).read()
     for name, val in re.findall(r"#define AZUL_(WANT_[A-Z_]+)\s+(\d+)u", text):
         assert getattr(L, name) == int(val), name
+
+
+def test_the_benchmark_never_hands_records_into_the_batch_it_measures():
+    """A batch the host has written records into (azul_batch_set_state / azul_game_call's record_in -> azul_batch::handed_in) plays its flat
+    self-play on the instantiation that also marks the slots of a rule-error-stopped game; the benchmarked batch only ever holds play's own
+    records, so bench.py must not call set_records on it (its never-ending-games A/B copies records on the device: BatchedAzul.records_dev)."""
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert "set_records(" not in bench and "set_state" not in bench
+    host = open(os.path.join(ROOT, "azul_deep_reinforcement_learning_amd", "csrc", "azul_kernels.hip")).read()
+    assert host.count("b->handed_in = true;") == 2                      # the two entries that write a caller's record into the batch
+    assert "if (b->d.move_limit || b->handed_in)" in host               # ... and the launch that follows them

@@ -294,3 +294,41 @@ def test_a_handed_in_state_that_stops_on_a_rule_error_is_marked_without_a_move_l
         assert np.array_equal(o["action"], act[:, g]) and np.array_equal(o["reward"], rew[:, g]) and np.array_equal(o["done"], dn[:, g]), g
         assert np.array_equal(o["mask"], msk[:, g]) and s.record().tobytes() == after[g].tobytes() and int(cnt["stuck"][g]) == 0, g
         assert env.get_rng(g)[1] == s.rng_state()[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rules,fp,pool", RULESETS[:2])
+def test_games_handed_in_mid_play_continue_exactly_like_the_oracle(torch_cuda, rules, fp, pool):
+    """Games that were played elsewhere (here: by the oracle, g * 11 + 3 moves each, so every phase of a game and of an MT19937 block is among
+    them) and handed in with azul_batch_set_state + azul_batch_set_rng continue move for move like the oracle's own streams.  A batch the host
+    has written records into runs the marking instantiation of the self-play kernel (LIM with no limit): masks, actions, rewards, done flags,
+    final records, stream positions and counters must not know the difference."""
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    n, T, base = 64, 400, 5200
+    env = BatchedAzul(n, rules=rules)
+    _start(env, base)
+    streams = [oz.Stream(base + 1000 + g, fp, pool) for g in range(n)]
+    for g, s in enumerate(streams):
+        s.advance(g * 11 + 3, want_records=False)
+    rec = env.get_records()
+    for g, s in enumerate(streams):
+        rec[g] = np.frombuffer(s.record().tobytes(), dtype=rec.dtype)[0]
+        mt, pos = s.rng_state()
+        env.set_rng(g, mt, pos)
+    env.set_records(rec)
+    env.reset_counters()
+    ep0 = [int(s.episodes.value) for s in streams]
+    t = env.alloc_trajectory(T, packed_mask=True, mask_pitch=192)
+    env.selfplay(T, t["mask"], t["action"], t["reward"], t["done"], maskbits=t["maskbits"], packed=t["packed"])
+    torch_cuda.cuda.synchronize()
+    act, rew, dn, msk = (t[k].cpu().numpy() for k in ("action", "reward", "done", "mask"))
+    final, cnt = env.get_records(), env.counters()
+    for g, s in enumerate(streams):
+        o = s.advance(T, want_records=False)
+        assert np.array_equal(o["action"], act[:, g]) and np.array_equal(o["reward"], rew[:, g]) and np.array_equal(o["done"], dn[:, g]), g
+        assert np.array_equal(o["mask"], msk[:, g]), g
+        assert s.record().tobytes() == final[g].tobytes(), g
+        mt, pos = s.rng_state()
+        gmt, gpos = env.get_rng(g)
+        assert np.array_equal(mt, gmt) and pos == gpos, g
+        assert int(cnt["episodes"][g]) == int(s.episodes.value) - ep0[g] and int(cnt["stuck"][g]) == 0, g

@@ -47,8 +47,8 @@ def launch_ms(n=20):
     return kms / kn
 print("launch ms now: %.4f" % launch_ms())
 if len(odd):
-    recs = env.get_records()
+    view = env.records_dev()      # on the device: set_records would switch the batch to the self-play instantiation that marks rule-error-stopped games
     for g in odd:
-        recs[g] = recs[(g + 1) % G if (g + 1) % G not in odd else (g + 7) % G]
-    env.set_records(recs)
+        view[int(g)] = view[int((g + 1) % G if (g + 1) % G not in odd else (g + 7) % G)]
+    torch.cuda.synchronize()
     print("launch ms with the odd games replaced: %.4f" % launch_ms())

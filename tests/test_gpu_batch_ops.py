@@ -381,3 +381,26 @@ def test_odd_batches_through_the_rule_kernel(torch_cuda, n):
     assert env.get_records().tobytes() == np.array([oz.pack(q) for q in runners], dtype=oz.RECORD_DTYPE).tobytes()
     for g in range(n):
         assert env.get_rng(g)[1] == rngs[g].idx, g
+
+
+@pytest.mark.gpu
+def test_records_dev_is_a_zero_copy_view_of_the_batch_records():
+    """BatchedAzul.records_dev() (azul_batch_state_dev): uint8 [N][128] aliasing the device-resident records -- what get_records copies out,
+    and a device-side copy through it is what the next rule call sees (bench.py's never-ending-games A/B moves records this way)."""
+    import torch
+    from azul_deep_reinforcement_learning_amd import BatchedAzul
+    env = BatchedAzul(5)
+    env.seed(31)
+    env.runner_init()
+    env.runner_init()
+    view = env.records_dev()
+    assert view.dtype == torch.uint8 and tuple(view.shape) == (5, 128) and view.is_cuda
+    rec = env.get_records()
+    assert view.cpu().numpy().tobytes() == rec.tobytes()
+    view[3] = view[1]                                     # game 3 becomes a copy of game 1 (its MT19937 stream stays its own)
+    torch.cuda.synchronize()
+    after = env.get_records()
+    assert after[3].tobytes() == rec[1].tobytes() and after[1].tobytes() == rec[1].tobytes() and after[0].tobytes() == rec[0].tobytes()
+    _, mask, _ = env.observe_all()
+    m = mask.cpu().numpy()
+    assert np.array_equal(m[3], m[1]) and m[3].any()

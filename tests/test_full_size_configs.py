@@ -290,8 +290,12 @@ def test_network_opponent_rollout_kernel_replays_through_the_oracle_at_4096_game
     assert ro.counters()["stuck"] == 0
 
 
-def test_the_benchmarked_step_matches_the_oracle_for_every_game_of_the_batch():
-    """configs[1] exactly as `bench.py` runs it -- 4096 games seeded 0.., default rules (Lid + random first player), the kernel variant
+@pytest.mark.parametrize("handed_in", [False, True])
+def test_the_benchmarked_step_matches_the_oracle_for_every_game_of_the_batch(handed_in):
+    """(`handed_in`: the batch's records make a get_records -> set_records round trip first -- the same bytes, but a batch the host has written
+    records into plays on the self-play instantiation that also marks rule-error-stopped games, the one a batch restored from JSON or a
+    checkpoint runs: the whole 4096-game comparison again on that instantiation, two launches.)
+    configs[1] exactly as `bench.py` runs it -- 4096 games seeded 0.., default rules (Lid + random first player), the kernel variant
     with every trajectory stream (byte mask at a 192-byte pitch, action, reward, done, compact record; no bit mask), 512 moves per
     launch -- and EVERY game of the batch, not a sample, against the oracle: four launches (each later one starts from the records, MT19937
     states and counters its predecessor stored), all 180 mask bytes of every move, the mask rows' padding untouched, final records,
@@ -299,11 +303,13 @@ def test_the_benchmarked_step_matches_the_oracle_for_every_game_of_the_batch():
     from concurrent.futures import ThreadPoolExecutor
     from azul_deep_reinforcement_learning_amd import BatchedAzul
     from azul_deep_reinforcement_learning_amd.parallel import unpack_moves
-    T, launches, base = 512, 4, 0
+    T, launches, base = 512, (2 if handed_in else 4), 0
     env = BatchedAzul(G)
     env.seed(base)
     env.runner_init()
     env.runner_init()
+    if handed_in:
+        env.set_records(env.get_records())
     b = env.alloc_trajectory(T, packed_mask=True, mask_pitch=192, mask_bits=False)
     streams = [oz.Stream(base + g) for g in range(G)]
     moves = episodes = 0

@@ -741,6 +741,7 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))                      # nothing below has run: no torch import, no GPU call in this process
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # ranks started by someone else's launcher: dmabuf IPC for RCCL (set before HIP initialises)
     import datetime
     import torch
     import torch.distributed as dist
